@@ -1,0 +1,157 @@
+"""ctypes binding of include/hnh_kernels.h (lib/libhnh_kernels.so).  Fails loudly if the HIP library
+is missing or no GPU is present — there is no fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libhnh_kernels.so")
+
+OK = 0
+STREAM_COMPUTE, STREAM_COMM = 0, 1
+H2D, D2H, D2D = 0, 1, 2
+FUSED_VALUES_OVERWRITE, FUSED_OUT_OVERWRITE = 1, 2
+UNIQUE_ID_BYTES = 128
+
+_vp, _i32, _i64, _dbl, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes): every symbol include/hnh_kernels.h declares
+SIGNATURES = {
+    "hnh_backend_name": (C.c_char_p, []),
+    "hnh_ctx_create": (_i32, [_i32, C.POINTER(_vp)]),
+    "hnh_ctx_destroy": (_i32, [_vp]),
+    "hnh_last_error": (C.c_char_p, [_vp]),
+    "hnh_ctx_stream": (_vp, [_vp, _i32]),
+    "hnh_malloc": (_i32, [_vp, _sz, C.POINTER(_vp)]),
+    "hnh_free": (_i32, [_vp, _vp]),
+    "hnh_memcpy": (_i32, [_vp, _vp, _vp, _sz, _i32, _i32]),
+    "hnh_memset": (_i32, [_vp, _vp, _i32, _sz, _i32]),
+    "hnh_stream_sync": (_i32, [_vp, _i32]),
+    "hnh_event_create": (_i32, [_vp, C.POINTER(_vp)]),
+    "hnh_event_destroy": (_i32, [_vp, _vp]),
+    "hnh_event_record": (_i32, [_vp, _vp, _i32]),
+    "hnh_event_wait": (_i32, [_vp, _vp, _i32]),
+    "hnh_event_sync": (_i32, [_vp, _vp]),
+    "hnh_event_elapsed_ms": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float)]),
+    "hnh_sddmm_coo": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32]),
+    "hnh_sddmm_csr": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32]),
+    "hnh_spmm_csr": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32]),
+    "hnh_fused_sddmm_spmm_csr": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _i32]),
+    "hnh_fill_f64": (_i32, [_vp, _vp, _i64, _dbl, _i32]),
+    "hnh_hadamard_f64": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32]),
+    "hnh_axpy_f64": (_i32, [_vp, _vp, _vp, _dbl, _i64, _i32]),
+    "hnh_expand_rowptr": (_i32, [_vp, _i64, _vp, _vp, _i32]),
+    "hnh_comm_unique_id": (_i32, [_vp]),
+    "hnh_comm_init": (_i32, [_vp, _i32, _i32, _vp, C.POINTER(_vp)]),
+    "hnh_comm_split": (_i32, [_vp, _vp, _i32, _i32, C.POINTER(_vp)]),
+    "hnh_comm_destroy": (_i32, [_vp, _vp]),
+    "hnh_comm_sendrecv": (_i32, [_vp, _vp, _vp, _sz, _i32, _vp, _sz, _i32, _i32]),
+    "hnh_comm_allgather": (_i32, [_vp, _vp, _vp, _vp, _sz, _i32]),
+    "hnh_comm_reduce_scatter_f64": (_i32, [_vp, _vp, _vp, _vp, _sz, _i32]),
+    "hnh_comm_allreduce_f64": (_i32, [_vp, _vp, _vp, _vp, _sz, _i32]),
+}
+
+_lib = None
+
+
+def load(path: str | None = None) -> C.CDLL:
+    """dlopen the HIP kernel library and bind every declared symbol (raises if any is missing)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError("HIP kernel library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % p)
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64/librccl (same SONAMEs as
+    # /opt/rocm's).  If torch is going to be used (bench.py, torch.distributed bootstrap) it must be
+    # imported BEFORE this library so that both bind to the same runtime; loading in the other order
+    # leaves two allocators fighting at process exit.
+    if os.environ.get("HNH_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+    lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class HnhError(RuntimeError):
+    pass
+
+
+class Ctx:
+    """One hnh_ctx (device + compute/comm streams).  Raises if there is no GPU."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = _vp()
+        rc = self.lib.hnh_ctx_create(device, C.byref(h))
+        if rc != OK:
+            raise HnhError("hnh_ctx_create(device=%d) failed with status %d: no usable MI355X (HIP) device" % (device, rc))
+        self.h = h
+
+    def check(self, rc: int, what: str = ""):
+        if rc != OK:
+            raise HnhError("%s failed (%d): %s" % (what, rc, self.lib.hnh_last_error(self.h).decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hnh_ctx_destroy(self.h)
+            self.h = None
+
+    # ---- memory helpers
+    def alloc(self, nbytes: int) -> int:
+        p = _vp()
+        self.check(self.lib.hnh_malloc(self.h, nbytes, C.byref(p)), "hnh_malloc")
+        return p.value
+
+    def free(self, ptr: int):
+        self.check(self.lib.hnh_free(self.h, ptr), "hnh_free")
+
+    def upload(self, arr: np.ndarray) -> "DevArray":
+        return DevArray.from_host(self, arr)
+
+    def sync(self, stream: int = STREAM_COMPUTE):
+        self.check(self.lib.hnh_stream_sync(self.h, stream), "hnh_stream_sync")
+
+
+class DevArray:
+    """A typed device allocation owned by Python (test / bench plumbing only)."""
+
+    def __init__(self, ctx: Ctx, shape, dtype):
+        self.ctx, self.shape, self.dtype = ctx, tuple(np.atleast_1d(shape)), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = ctx.alloc(self.nbytes)
+
+    @classmethod
+    def from_host(cls, ctx: Ctx, arr: np.ndarray) -> "DevArray":
+        arr = np.ascontiguousarray(arr)
+        d = cls(ctx, arr.shape, arr.dtype)
+        d.set(arr)
+        return d
+
+    def set(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert arr.nbytes == self.nbytes
+        self.ctx.check(self.ctx.lib.hnh_memcpy(self.ctx.h, self.ptr, arr.ctypes.data, self.nbytes, H2D, STREAM_COMPUTE), "h2d")
+        self.ctx.sync()
+
+    def get(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        self.ctx.sync()
+        self.ctx.check(self.ctx.lib.hnh_memcpy(self.ctx.h, out.ctypes.data, self.ptr, self.nbytes, D2H, STREAM_COMPUTE), "d2h")
+        self.ctx.sync()
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.free(self.ptr)
+            self.ptr = None

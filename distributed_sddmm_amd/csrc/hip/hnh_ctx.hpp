@@ -1,0 +1,38 @@
+// Internal: the per-rank context behind the opaque `hnh_ctx` of include/hnh_kernels.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include "hnh_kernels.h"
+
+struct hnh_ctx {
+    int device = 0;
+    hipStream_t streams[2] = {nullptr, nullptr};  // [HNH_STREAM_COMPUTE], [HNH_STREAM_COMM]
+    std::string last_error;
+};
+
+namespace hnh {
+
+inline int fail(hnh_ctx* ctx, int code, const std::string& what) {
+    if (ctx) ctx->last_error = what;
+    return code;
+}
+
+inline int check_hip(hnh_ctx* ctx, hipError_t e, const char* what) {
+    if (e == hipSuccess) return HNH_OK;
+    return fail(ctx, HNH_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+inline bool valid_stream(int s) { return s == HNH_STREAM_COMPUTE || s == HNH_STREAM_COMM; }
+
+}  // namespace hnh
+
+#define HNH_TRY_HIP(ctx, expr)                                   \
+    do {                                                         \
+        int _st = hnh::check_hip((ctx), (expr), #expr);          \
+        if (_st != HNH_OK) return _st;                           \
+    } while (0)
+
+#define HNH_ENTER(ctx, stream)                                                        \
+    if (!(ctx)) return HNH_ERR_INVALID;                                               \
+    if (!hnh::valid_stream(stream)) return hnh::fail((ctx), HNH_ERR_INVALID, "bad stream selector"); \
+    HNH_TRY_HIP((ctx), hipSetDevice((ctx)->device))

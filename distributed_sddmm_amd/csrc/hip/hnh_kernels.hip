@@ -1,0 +1,505 @@
+// Hand-written CDNA4 (gfx950) local kernels behind include/hnh_kernels.h.
+//
+// What they replace (reference = PASSIONLab/distributed_sddmm, CPU only):
+//   sddmm_*  : StandardKernel::sddmm_local, OpenMP loop over COO nonzeros  (sparse_kernels.cpp:13-57)
+//   spmm_csr : StandardKernel::spmm_local -> mkl_sparse_d_mm(alpha=1,beta=1) (sparse_kernels.cpp:59-127)
+//   fused    : the back-to-back sddmm/spmm pair of the "local kernel fusion" schedule
+//              (15D_dense_shift.hpp:203-217) as one pass with a single gather of each dense row.
+//
+// Design (MI355X first):
+//   * The path is HBM/gather bound (0.49 flop/B), so no MFMA: the work is laid out so that every
+//     vector-memory instruction of a wave reads whole, contiguous dense rows.
+//   * "Group per sparse row": a group of LPR lanes (power of two, <= 64) owns one CSR row; lane l of the
+//     group holds elements (v*LPR + l)*W .. +W of a dense row for v < VEC, W = 2 doubles (one 16-byte
+//     dwordx4 load).  For R = 128 that is LPR = 64, VEC = 1: one wave per row, one 1 KiB fully coalesced
+//     load instruction per nonzero.  For R = 16 it is LPR = 8: eight rows per wave.
+//   * The row operand X[i,:] and the output accumulator live in registers for the whole sparse row (the
+//     register file is the "LDS tile": nothing is shared between groups, so staging through LDS would
+//     only add a round trip).  The output row is written once, without atomics.
+//   * U nonzeros are in flight per group (U independent 16-byte loads per lane issued before the first
+//     use), and their U dot products are reduced together with a transposed butterfly: (U-1) + log2(LPR/U)
+//     cross-lane exchanges instead of U*log2(LPR).
+//   * With LPR = 64 the row index is wave-uniform (readfirstlane), so rowptr / col_idx / svalues go
+//     through the scalar cache and the vector memory pipe carries only dense rows and `values`.
+//   * Launch: rows/(256/LPR) workgroups of 256 threads (cfg2: 262 144 workgroups >> 256 CUs); consecutive
+//     workgroups own consecutive rows, so the CSR index stream is read in order.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "hnh_ctx.hpp"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------- small device helpers
+
+template <int W>
+__device__ __forceinline__ void load_w(double (&dst)[W], const double* __restrict__ p) {
+    if constexpr (W == 2) {
+        const double2 t = *reinterpret_cast<const double2*>(p);
+        dst[0] = t.x;
+        dst[1] = t.y;
+    } else {
+        dst[0] = *p;
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void store_w(double* __restrict__ p, const double (&src)[W]) {
+    if constexpr (W == 2) {
+        *reinterpret_cast<double2*>(p) = make_double2(src[0], src[1]);
+    } else {
+        *p = src[0];
+    }
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
+
+// Broadcast the value held by lane `src` of each LPR-lane group to the whole group.
+template <int LPR>
+__device__ __forceinline__ double group_bcast(double v, int src) {
+    if constexpr (LPR == 1) {
+        return v;
+    } else if constexpr (LPR == 64) {
+        // wave-wide: result is uniform, keep it in SGPRs so the following FMAs take a scalar operand
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+        return __hiloint2double(hi, lo);
+    } else {
+        return __shfl(v, src, LPR);
+    }
+}
+
+// Transposed butterfly: on entry d[0..U) are this lane's partial sums of U independent reductions over
+// the LPR lanes of its group; on exit the return value is the complete sum of reduction number
+// (lane_in_group / (LPR / U)).  S is the exchange stride of the current level (start at LPR / 2).
+template <int U, int S>
+__device__ __forceinline__ double multi_reduce(double (&d)[U], int lig) {
+    if constexpr (U == 1) {
+        double v = d[0];
+#pragma unroll
+        for (int s = S; s >= 1; s >>= 1) v += shfl_xor_f64(v, s);
+        return v;
+    } else {
+        static_assert(S >= 1, "needs U <= LPR");
+        const bool upper = (lig & S) != 0;
+        double n[U / 2];
+#pragma unroll
+        for (int j = 0; j < U / 2; j++) {
+            const double send = upper ? d[j] : d[j + U / 2];
+            const double keep = upper ? d[j + U / 2] : d[j];
+            n[j] = keep + shfl_xor_f64(send, S);
+        }
+        return multi_reduce<U / 2, S / 2>(n, lig);
+    }
+}
+
+template <int LPR, int U>
+__device__ __forceinline__ double group_multi_reduce(double (&d)[U], int lig) {
+    if constexpr (LPR == 1) {
+        static_assert(U == 1, "LPR == 1 needs U == 1");
+        return d[0];
+    } else {
+        return multi_reduce<U, LPR / 2>(d, lig);
+    }
+}
+
+// nonzeros in flight per group
+template <int LPR, int VEC>
+struct Unroll {
+    static constexpr int byvec = VEC == 1 ? 8 : (VEC == 2 ? 4 : (VEC <= 4 ? 2 : 1));
+    static constexpr int value = byvec < LPR ? byvec : LPR;
+};
+
+enum class Op { kSddmm, kSpmm, kFused };
+
+// ---------------------------------------------------------------- the row kernel (sddmm / spmm / fused)
+//
+// Columns handled: [col0, col0 + ncols) of rows of length `ld`; EXACT means ncols == W*LPR*VEC.
+template <Op OP, int LPR, int VEC, int W, bool EXACT>
+__global__ __launch_bounds__(kBlock) void row_kernel(int64_t rows, const int32_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ colidx, double* values,
+                                                     const double* __restrict__ svalues,
+                                                     const double* __restrict__ X, const double* __restrict__ Y,
+                                                     double* __restrict__ Out, int64_t ld, int col0, int ncols,
+                                                     unsigned flags) {
+    constexpr int U = Unroll<LPR, VEC>::value;
+    constexpr int SUB = LPR / U;  // lanes that end up holding the same reduced value
+    constexpr int GROUPS = kBlock / LPR;
+    const int tid = threadIdx.x;
+    const int lig = tid % LPR;
+    int64_t row = (int64_t)blockIdx.x * GROUPS + tid / LPR;
+    if constexpr (LPR == 64) row = ((int64_t)blockIdx.x * GROUPS) + __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (row >= rows) return;
+
+    int beg = rowptr[row];
+    int end = rowptr[row + 1];
+    if constexpr (LPR == 64) {
+        beg = __builtin_amdgcn_readfirstlane(beg);
+        end = __builtin_amdgcn_readfirstlane(end);
+    }
+    if (OP == Op::kSddmm && beg == end) return;
+
+    bool act[VEC];
+    int64_t coff[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) {
+        const int c = (v * LPR + lig) * W;
+        act[v] = EXACT ? true : (c < ncols);
+        coff[v] = (int64_t)col0 + c;
+    }
+
+    double x[VEC][W];    // SDDMM row operand X[row, :]
+    double acc[VEC][W];  // SpMM accumulator Out[row, :]
+#pragma unroll
+    for (int v = 0; v < VEC; v++) {
+#pragma unroll
+        for (int w = 0; w < W; w++) { x[v][w] = 0.0; acc[v][w] = 0.0; }
+        if (act[v]) {
+            if constexpr (OP != Op::kSpmm) load_w<W>(x[v], X + row * ld + coff[v]);
+            if constexpr (OP != Op::kSddmm) {
+                if (!(flags & HNH_FUSED_OUT_OVERWRITE)) load_w<W>(acc[v], Out + row * ld + coff[v]);
+            }
+        }
+    }
+
+    for (int e = beg; e < end; e += U) {
+        int c[U];
+        double y[U][VEC][W];
+        // issue all gathers of this batch before the first use
+#pragma unroll
+        for (int u = 0; u < U; u++) c[u] = (e + u < end) ? colidx[e + u] : -1;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int v = 0; v < VEC; v++) {
+#pragma unroll
+                for (int w = 0; w < W; w++) y[u][v][w] = 0.0;
+                if (c[u] >= 0 && act[v]) {
+                    const double* src = (OP == Op::kSpmm ? X : Y) + (int64_t)c[u] * ld + coff[v];
+                    load_w<W>(y[u][v], src);
+                }
+            }
+        }
+
+        double wgt;  // weight of nonzero (e + lig / SUB), valid in every lane of its SUB-lane subgroup
+        const int mine = e + lig / SUB;
+        if constexpr (OP == Op::kSpmm) {
+            wgt = (mine < end) ? values[mine] : 0.0;
+            if (svalues != nullptr && mine < end) wgt *= svalues[mine];
+        } else {
+            double d[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                double s = 0.0;
+#pragma unroll
+                for (int v = 0; v < VEC; v++)
+#pragma unroll
+                    for (int w = 0; w < W; w++) s = fma(x[v][w], y[u][v][w], s);
+                d[u] = s;
+            }
+            wgt = group_multi_reduce<LPR, U>(d, lig);
+            if (mine < end) {
+                const bool overwrite = (OP == Op::kFused) && (flags & HNH_FUSED_VALUES_OVERWRITE);
+                if (!overwrite) wgt += values[mine];
+                if (lig % SUB == 0) values[mine] = wgt;
+                if (OP == Op::kFused && svalues != nullptr) wgt *= svalues[mine];
+            } else {
+                wgt = 0.0;
+            }
+        }
+
+        if constexpr (OP != Op::kSddmm) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const double wu = group_bcast<LPR>(wgt, u * SUB);
+#pragma unroll
+                for (int v = 0; v < VEC; v++)
+#pragma unroll
+                    for (int w = 0; w < W; w++) acc[v][w] = fma(wu, y[u][v][w], acc[v][w]);
+            }
+        }
+    }
+
+    if constexpr (OP != Op::kSddmm) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++)
+            if (act[v]) store_w<W>(Out + row * ld + coff[v], acc[v]);
+    }
+}
+
+// ---------------------------------------------------------------- COO SDDMM (no rowptr available)
+// A group owns U consecutive nonzeros at a time; both dense rows are gathered per nonzero.
+template <int LPR, int VEC, int W, bool EXACT>
+__global__ __launch_bounds__(kBlock) void sddmm_coo_kernel(int64_t nnz, const int32_t* __restrict__ rowidx,
+                                                           const int32_t* __restrict__ colidx, double* values,
+                                                           const double* __restrict__ X,
+                                                           const double* __restrict__ Y, int64_t ld, int col0,
+                                                           int ncols) {
+    constexpr int U = Unroll<LPR, VEC>::value > 4 ? 4 : Unroll<LPR, VEC>::value;
+    constexpr int SUB = LPR / U;
+    constexpr int GROUPS = kBlock / LPR;
+    const int tid = threadIdx.x;
+    const int lig = tid % LPR;
+    const int64_t group = (int64_t)blockIdx.x * GROUPS + tid / LPR;
+    const int64_t ngroups = (int64_t)gridDim.x * GROUPS;
+    for (int64_t e = group * U; e < nnz; e += ngroups * U) {
+        double d[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            double s = 0.0;
+            if (e + u < nnz) {
+                const int64_t r = rowidx[e + u], c = colidx[e + u];
+#pragma unroll
+                for (int v = 0; v < VEC; v++) {
+                    const int cc = (v * LPR + lig) * W;
+                    if (EXACT || cc < ncols) {
+                        double a[W], b[W];
+                        load_w<W>(a, X + r * ld + col0 + cc);
+                        load_w<W>(b, Y + c * ld + col0 + cc);
+#pragma unroll
+                        for (int w = 0; w < W; w++) s = fma(a[w], b[w], s);
+                    }
+                }
+            }
+            d[u] = s;
+        }
+        const double tot = group_multi_reduce<LPR, U>(d, lig);
+        const int64_t mine = e + lig / SUB;
+        if (mine < nnz && lig % SUB == 0) values[mine] += tot;
+    }
+}
+
+// ---------------------------------------------------------------- element-wise
+__global__ __launch_bounds__(kBlock) void fill_kernel(double* __restrict__ dst, int64_t n, double v) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) dst[i] = v;
+}
+
+__global__ __launch_bounds__(kBlock) void hadamard_kernel(double* out, const double* a, const double* b, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = a[i] * b[i];
+}
+
+__global__ __launch_bounds__(kBlock) void axpy_kernel(double* y, const double* __restrict__ x, double alpha, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) y[i] = fma(alpha, x[i], y[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void expand_rowptr_kernel(int64_t rows, const int32_t* __restrict__ rowptr,
+                                                               int32_t* __restrict__ rowidx) {
+    // one wave per row (rows are short on the target matrices)
+    const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 64;
+    const int lane = threadIdx.x % 64;
+    if (row >= rows) return;
+    for (int e = rowptr[row] + lane; e < rowptr[row + 1]; e += 64) rowidx[e] = (int32_t)row;
+}
+
+int ew_grid(int64_t n) {
+    int64_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 resident blocks, grid-stride the rest
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+// ---------------------------------------------------------------- dispatch
+
+struct Shape {
+    int lpr = 0, vec = 0, w = 0;
+    bool exact = false;  // false: tiled fallback (LPR 64, VEC 1, tile = 64 * w columns)
+};
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+Shape pick_shape(int R, bool vec_ok) {
+    Shape s;
+    s.w = (R % 2 == 0 && vec_ok) ? 2 : 1;
+    if (s.w == 2) {
+        const int chunks = R / 2;
+        if (chunks <= 64 && (chunks & (chunks - 1)) == 0) { s.lpr = chunks; s.vec = 1; s.exact = true; return s; }
+        if (chunks % 64 == 0 && chunks / 64 <= 4) { s.lpr = 64; s.vec = chunks / 64; s.exact = true; return s; }
+        if (chunks % 32 == 0 && (chunks / 32 == 3 || chunks / 32 == 5 || chunks / 32 == 7)) {
+            s.lpr = 32; s.vec = chunks / 32; s.exact = true; return s;
+        }
+    }
+    s.lpr = 64; s.vec = 1; s.exact = false;
+    return s;
+}
+
+template <Op OP, int LPR, int VEC, int W, bool EXACT>
+int launch_row(hnh_ctx* ctx, hipStream_t st, int64_t rows, const int32_t* rowptr, const int32_t* colidx,
+               double* values, const double* svalues, const double* X, const double* Y, double* Out, int64_t ld,
+               int col0, int ncols, unsigned flags) {
+    constexpr int GROUPS = kBlock / LPR;
+    const int64_t blocks = (rows + GROUPS - 1) / GROUPS;
+    if (blocks <= 0) return HNH_OK;
+    if (blocks > 0x7fffffffLL) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "too many rows for one launch");
+    hipLaunchKernelGGL((row_kernel<OP, LPR, VEC, W, EXACT>), dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, rowptr,
+                       colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags);
+    return hnh::check_hip(ctx, hipGetLastError(), "row_kernel launch");
+}
+
+template <Op OP>
+int dispatch_row(hnh_ctx* ctx, hipStream_t st, const Shape& s, int64_t rows, const int32_t* rowptr,
+                 const int32_t* colidx, double* values, const double* svalues, const double* X, const double* Y,
+                 double* Out, int R, unsigned flags) {
+#define HNH_CASE(L, V)                                                                                         \
+    if (s.lpr == L && s.vec == V)                                                                              \
+        return launch_row<OP, L, V, 2, true>(ctx, st, rows, rowptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags);
+    if (s.exact) {
+        HNH_CASE(1, 1) HNH_CASE(2, 1) HNH_CASE(4, 1) HNH_CASE(8, 1) HNH_CASE(16, 1) HNH_CASE(32, 1) HNH_CASE(64, 1)
+        HNH_CASE(64, 2) HNH_CASE(64, 3) HNH_CASE(64, 4) HNH_CASE(32, 3) HNH_CASE(32, 5) HNH_CASE(32, 7)
+        return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "no kernel instance for this shape");
+    }
+#undef HNH_CASE
+    // tiled fallback: any R; SDDMM partial dot products accumulate into `values` tile by tile
+    if (OP == Op::kFused) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "fused fallback is composed by the caller");
+    const int tile = 64 * s.w;
+    for (int col0 = 0; col0 < R; col0 += tile) {
+        const int ncols = (R - col0 < tile) ? (R - col0) : tile;
+        int rc;
+        if (s.w == 2)
+            rc = launch_row<OP, 64, 1, 2, false>(ctx, st, rows, rowptr, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags);
+        else
+            rc = launch_row<OP, 64, 1, 1, false>(ctx, st, rows, rowptr, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags);
+        if (rc != HNH_OK) return rc;
+    }
+    return HNH_OK;
+}
+
+template <int LPR, int VEC, int W, bool EXACT>
+int launch_coo(hnh_ctx* ctx, hipStream_t st, int64_t nnz, const int32_t* rowidx, const int32_t* colidx,
+               double* values, const double* X, const double* Y, int64_t ld, int col0, int ncols) {
+    constexpr int GROUPS = kBlock / LPR;
+    constexpr int U = Unroll<LPR, VEC>::value > 4 ? 4 : Unroll<LPR, VEC>::value;
+    int64_t blocks = (nnz + (int64_t)GROUPS * U - 1) / ((int64_t)GROUPS * U);
+    if (blocks <= 0) return HNH_OK;
+    if (blocks > (1 << 20)) blocks = 1 << 20;  // grid-stride beyond that
+    hipLaunchKernelGGL((sddmm_coo_kernel<LPR, VEC, W, EXACT>), dim3((unsigned)blocks), dim3(kBlock), 0, st, nnz, rowidx,
+                       colidx, values, X, Y, ld, col0, ncols);
+    return hnh::check_hip(ctx, hipGetLastError(), "sddmm_coo_kernel launch");
+}
+
+int check_common(hnh_ctx* ctx, int64_t n, int R, const char* who) {
+    if (n < 0) return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": negative size");
+    if (R <= 0) return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": R must be positive");
+    return HNH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hnh_sddmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
+                  const double* X, const double* Y, int R, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (int rc = check_common(ctx, rows, R, "hnh_sddmm_csr")) return rc;
+    if (rows == 0) return HNH_OK;
+    if (!rowptr || !col_idx || !values || !X || !Y) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sddmm_csr: null pointer");
+    const Shape s = pick_shape(R, aligned16(X) && aligned16(Y));
+    return dispatch_row<Op::kSddmm>(ctx, ctx->streams[stream], s, rows, rowptr, col_idx, values, nullptr, X, Y, nullptr, R, 0u);
+}
+
+int hnh_spmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values,
+                 const double* X, double* Out, int R, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (int rc = check_common(ctx, rows, R, "hnh_spmm_csr")) return rc;
+    if (rows == 0) return HNH_OK;
+    if (!rowptr || !col_idx || !values || !X || !Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_spmm_csr: null pointer");
+    if (X == Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_spmm_csr: X and Out alias");
+    const Shape s = pick_shape(R, aligned16(X) && aligned16(Out));
+    return dispatch_row<Op::kSpmm>(ctx, ctx->streams[stream], s, rows, rowptr, col_idx, const_cast<double*>(values), nullptr,
+                                   X, nullptr, Out, R, 0u);
+}
+
+int hnh_fused_sddmm_spmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
+                             const double* svalues, const double* X, const double* Y, double* Out, int R,
+                             unsigned flags, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (int rc = check_common(ctx, rows, R, "hnh_fused_sddmm_spmm_csr")) return rc;
+    if (rows == 0) return HNH_OK;
+    if (!rowptr || !col_idx || !values || !X || !Y || !Out)
+        return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr: null pointer");
+    if (X == Out || Y == Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr: Out aliases an input");
+    if (flags & ~(HNH_FUSED_VALUES_OVERWRITE | HNH_FUSED_OUT_OVERWRITE))
+        return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr: unknown flag");
+    hipStream_t st = ctx->streams[stream];
+    const Shape s = pick_shape(R, aligned16(X) && aligned16(Y) && aligned16(Out));
+    if (s.exact)
+        return dispatch_row<Op::kFused>(ctx, st, s, rows, rowptr, col_idx, values, svalues, X, Y, Out, R, flags);
+    // Tiled fallback (R odd or not a supported multiple): the dot product needs the whole row before the
+    // axpy can start, so compose the two column-tiled passes; same arithmetic, one extra gather.
+    int nnz = 0;
+    HNH_TRY_HIP(ctx, hipMemcpyAsync(&nnz, rowptr + rows, sizeof(int), hipMemcpyDeviceToHost, st));
+    HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
+    if (flags & HNH_FUSED_VALUES_OVERWRITE) HNH_TRY_HIP(ctx, hipMemsetAsync(values, 0, sizeof(double) * (size_t)nnz, st));
+    if (flags & HNH_FUSED_OUT_OVERWRITE) HNH_TRY_HIP(ctx, hipMemsetAsync(Out, 0, sizeof(double) * (size_t)rows * R, st));
+    if (int rc = dispatch_row<Op::kSddmm>(ctx, st, s, rows, rowptr, col_idx, values, nullptr, X, Y, nullptr, R, 0u)) return rc;
+    return dispatch_row<Op::kSpmm>(ctx, st, s, rows, rowptr, col_idx, values, svalues, Y, nullptr, Out, R, 0u);
+}
+
+int hnh_sddmm_coo(hnh_ctx* ctx, int64_t nnz, const int32_t* row_idx, const int32_t* col_idx, double* values,
+                  const double* X, const double* Y, int R, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (int rc = check_common(ctx, nnz, R, "hnh_sddmm_coo")) return rc;
+    if (nnz == 0) return HNH_OK;
+    if (!row_idx || !col_idx || !values || !X || !Y) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sddmm_coo: null pointer");
+    hipStream_t st = ctx->streams[stream];
+    const Shape s = pick_shape(R, aligned16(X) && aligned16(Y));
+#define HNH_CASE(L, V) \
+    if (s.lpr == L && s.vec == V) return launch_coo<L, V, 2, true>(ctx, st, nnz, row_idx, col_idx, values, X, Y, R, 0, R);
+    if (s.exact) {
+        HNH_CASE(1, 1) HNH_CASE(2, 1) HNH_CASE(4, 1) HNH_CASE(8, 1) HNH_CASE(16, 1) HNH_CASE(32, 1) HNH_CASE(64, 1)
+        HNH_CASE(64, 2) HNH_CASE(64, 3) HNH_CASE(64, 4) HNH_CASE(32, 3) HNH_CASE(32, 5) HNH_CASE(32, 7)
+        return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "no kernel instance for this shape");
+    }
+#undef HNH_CASE
+    const int tile = 64 * s.w;
+    for (int col0 = 0; col0 < R; col0 += tile) {
+        const int ncols = (R - col0 < tile) ? (R - col0) : tile;
+        int rc = (s.w == 2) ? launch_coo<64, 1, 2, false>(ctx, st, nnz, row_idx, col_idx, values, X, Y, R, col0, ncols)
+                            : launch_coo<64, 1, 1, false>(ctx, st, nnz, row_idx, col_idx, values, X, Y, R, col0, ncols);
+        if (rc != HNH_OK) return rc;
+    }
+    return HNH_OK;
+}
+
+int hnh_fill_f64(hnh_ctx* ctx, double* dst, int64_t n, double value, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (n < 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fill_f64: negative size");
+    if (n == 0) return HNH_OK;
+    if (!dst) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fill_f64: null pointer");
+    if (value == 0.0) return hnh::check_hip(ctx, hipMemsetAsync(dst, 0, sizeof(double) * (size_t)n, ctx->streams[stream]), "hipMemsetAsync");
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, ctx->streams[stream], dst, n, value);
+    return hnh::check_hip(ctx, hipGetLastError(), "fill_kernel launch");
+}
+
+int hnh_hadamard_f64(hnh_ctx* ctx, double* out, const double* a, const double* b, int64_t n, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (n < 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_hadamard_f64: negative size");
+    if (n == 0) return HNH_OK;
+    if (!out || !a || !b) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_hadamard_f64: null pointer");
+    hipLaunchKernelGGL(hadamard_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, ctx->streams[stream], out, a, b, n);
+    return hnh::check_hip(ctx, hipGetLastError(), "hadamard_kernel launch");
+}
+
+int hnh_axpy_f64(hnh_ctx* ctx, double* y, const double* x, double alpha, int64_t n, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (n < 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_axpy_f64: negative size");
+    if (n == 0) return HNH_OK;
+    if (!y || !x) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_axpy_f64: null pointer");
+    hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, ctx->streams[stream], y, x, alpha, n);
+    return hnh::check_hip(ctx, hipGetLastError(), "axpy_kernel launch");
+}
+
+int hnh_expand_rowptr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, int32_t* row_idx, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (rows < 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_expand_rowptr: negative size");
+    if (rows == 0) return HNH_OK;
+    if (!rowptr || !row_idx) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_expand_rowptr: null pointer");
+    const int64_t blocks = (rows * 64 + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(expand_rowptr_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->streams[stream], rows, rowptr, row_idx);
+    return hnh::check_hip(ctx, hipGetLastError(), "expand_rowptr_kernel launch");
+}
+
+}  // extern "C"

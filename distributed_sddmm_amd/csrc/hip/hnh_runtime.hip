@@ -1,0 +1,129 @@
+// Context / memory / stream / event entry points of include/hnh_kernels.h (gfx950, HIP runtime only).
+#include <hip/hip_runtime.h>
+#include <new>
+#include "hnh_ctx.hpp"
+
+extern "C" {
+
+const char* hnh_backend_name(void) { return "hip-gfx950"; }
+
+int hnh_ctx_create(int device, hnh_ctx** out) {
+    if (!out) return HNH_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return HNH_ERR_DEVICE;  // no GPU: fail loudly
+    if (device < 0 || device >= count) return HNH_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return HNH_ERR_DEVICE;
+    hnh_ctx* ctx = new (std::nothrow) hnh_ctx();
+    if (!ctx) return HNH_ERR_NOMEM;
+    ctx->device = device;
+    for (int s = 0; s < 2; s++) {
+        if (hipStreamCreateWithFlags(&ctx->streams[s], hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return HNH_ERR_DEVICE;
+        }
+    }
+    *out = ctx;
+    return HNH_OK;
+}
+
+int hnh_ctx_destroy(hnh_ctx* ctx) {
+    if (!ctx) return HNH_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    for (int s = 0; s < 2; s++) {
+        if (ctx->streams[s]) { (void)hipStreamSynchronize(ctx->streams[s]); (void)hipStreamDestroy(ctx->streams[s]); }
+    }
+    delete ctx;
+    return HNH_OK;
+}
+
+const char* hnh_last_error(hnh_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+void* hnh_ctx_stream(hnh_ctx* ctx, int stream) {
+    if (!ctx || !hnh::valid_stream(stream)) return nullptr;
+    return (void*)ctx->streams[stream];
+}
+
+int hnh_malloc(hnh_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out) return HNH_ERR_INVALID;
+    HNH_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    *out = nullptr;
+    hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+    if (e == hipErrorOutOfMemory) return hnh::fail(ctx, HNH_ERR_NOMEM, "hipMalloc: out of memory");
+    return hnh::check_hip(ctx, e, "hipMalloc");
+}
+
+int hnh_free(hnh_ctx* ctx, void* ptr) {
+    if (!ctx) return HNH_ERR_INVALID;
+    if (!ptr) return HNH_OK;
+    HNH_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    return hnh::check_hip(ctx, hipFree(ptr), "hipFree");
+}
+
+int hnh_memcpy(hnh_ctx* ctx, void* dst, const void* src, size_t bytes, int kind, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (bytes == 0) return HNH_OK;
+    if (!dst || !src) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_memcpy: null pointer");
+    hipMemcpyKind k;
+    switch (kind) {
+        case HNH_COPY_H2D: k = hipMemcpyHostToDevice; break;
+        case HNH_COPY_D2H: k = hipMemcpyDeviceToHost; break;
+        case HNH_COPY_D2D: k = hipMemcpyDeviceToDevice; break;
+        default: return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_memcpy: bad kind");
+    }
+    return hnh::check_hip(ctx, hipMemcpyAsync(dst, src, bytes, k, ctx->streams[stream]), "hipMemcpyAsync");
+}
+
+int hnh_memset(hnh_ctx* ctx, void* dst, int byte, size_t bytes, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (bytes == 0) return HNH_OK;
+    if (!dst) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_memset: null pointer");
+    return hnh::check_hip(ctx, hipMemsetAsync(dst, byte, bytes, ctx->streams[stream]), "hipMemsetAsync");
+}
+
+int hnh_stream_sync(hnh_ctx* ctx, int stream) {
+    HNH_ENTER(ctx, stream);
+    return hnh::check_hip(ctx, hipStreamSynchronize(ctx->streams[stream]), "hipStreamSynchronize");
+}
+
+int hnh_event_create(hnh_ctx* ctx, void** event) {
+    if (!ctx || !event) return HNH_ERR_INVALID;
+    HNH_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    hipEvent_t ev;
+    HNH_TRY_HIP(ctx, hipEventCreate(&ev));  // timing enabled: bench.py measures kernels with these
+    *event = (void*)ev;
+    return HNH_OK;
+}
+
+int hnh_event_destroy(hnh_ctx* ctx, void* event) {
+    if (!ctx) return HNH_ERR_INVALID;
+    if (!event) return HNH_OK;
+    HNH_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    return hnh::check_hip(ctx, hipEventDestroy((hipEvent_t)event), "hipEventDestroy");
+}
+
+int hnh_event_record(hnh_ctx* ctx, void* event, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (!event) return hnh::fail(ctx, HNH_ERR_INVALID, "null event");
+    return hnh::check_hip(ctx, hipEventRecord((hipEvent_t)event, ctx->streams[stream]), "hipEventRecord");
+}
+
+int hnh_event_wait(hnh_ctx* ctx, void* event, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (!event) return hnh::fail(ctx, HNH_ERR_INVALID, "null event");
+    return hnh::check_hip(ctx, hipStreamWaitEvent(ctx->streams[stream], (hipEvent_t)event, 0), "hipStreamWaitEvent");
+}
+
+int hnh_event_sync(hnh_ctx* ctx, void* event) {
+    if (!ctx || !event) return HNH_ERR_INVALID;
+    HNH_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    return hnh::check_hip(ctx, hipEventSynchronize((hipEvent_t)event), "hipEventSynchronize");
+}
+
+int hnh_event_elapsed_ms(hnh_ctx* ctx, void* start, void* stop, float* ms) {
+    if (!ctx || !start || !stop || !ms) return HNH_ERR_INVALID;
+    HNH_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    return hnh::check_hip(ctx, hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop), "hipEventElapsedTime");
+}
+
+}  // extern "C"

@@ -1,0 +1,138 @@
+/*
+ * hnh_kernels.h — C ABI of the MI355X (gfx950) local-kernel library  (libhnh_kernels.so)
+ *
+ * This is the drop-in boundary for the hot path of PASSIONLab/distributed_sddmm ("HnH"): the bodies of
+ * the reference's plugin class `StandardKernel` (sparse_kernels.h:84-99) marshal to these entry points.
+ * Plain pointers and sizes only; every data pointer is a DEVICE pointer unless a comment says "host".
+ * Every function returns an int status (HNH_OK == 0); no exceptions cross this boundary; the text of
+ * the last error of a context is available through hnh_last_error().
+ *
+ * Conventions (all from the reference, file:line relative to /root/reference):
+ *   - dense matrices are row-major fp64 with leading dimension == number of columns == R
+ *     (common.h:13; asserted equal for A and B at sparse_kernels.cpp:21);
+ *   - a sparse block is CSR (rowptr / col_idx / values) of the *active* buffer of a CSRLocal
+ *     (SpmatLocal.hpp:55-62,171-179).  Device indices are 32-bit (per-rank nnz < 2^31 is already a
+ *     constraint of the reference, which counts nonzeros in `int`: SpmatLocal.hpp:68);
+ *   - SDDMM ACCUMULATES into `values` (sparse_kernels.cpp:54) and SpMM uses alpha = 1, beta = 1
+ *     (sparse_kernels.cpp:97,104): callers zero the destination first, exactly as in the reference.
+ *
+ * `stream` arguments select one of the context's HIP streams: HNH_STREAM_COMPUTE or HNH_STREAM_COMM.
+ * All kernels and copies are asynchronous with respect to the host.
+ */
+#ifndef HNH_KERNELS_H
+#define HNH_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HNH_OK 0
+#define HNH_ERR_INVALID 1     /* bad argument (null pointer, negative size, R <= 0 ...) */
+#define HNH_ERR_DEVICE 2      /* HIP / RCCL runtime error, see hnh_last_error()           */
+#define HNH_ERR_NOMEM 3
+#define HNH_ERR_UNSUPPORTED 4
+
+#define HNH_STREAM_COMPUTE 0
+#define HNH_STREAM_COMM 1
+
+#define HNH_COPY_H2D 0
+#define HNH_COPY_D2H 1
+#define HNH_COPY_D2D 2
+
+/* flags of hnh_fused_sddmm_spmm_csr */
+#define HNH_FUSED_VALUES_OVERWRITE 1u /* values[e]  = dot  instead of  values[e] += dot (caller knows they are zero) */
+#define HNH_FUSED_OUT_OVERWRITE 2u    /* Out[i,:]   = sum  instead of  Out[i,:] += sum  (caller knows it is zero)    */
+
+typedef struct hnh_ctx hnh_ctx; /* opaque, one per rank: device ordinal, two streams, scratch */
+
+/* Identifies the implementation behind this ABI; the product library returns "hip-gfx950". */
+const char* hnh_backend_name(void);
+
+/* ---- context, memory, streams, events ------------------------------------------------------------
+ * Replaces: host allocation of Eigen matrices / std::vector storage in the reference
+ * (common.h:13, SpmatLocal.hpp:55-62); the reference has no device. */
+int hnh_ctx_create(int device, hnh_ctx** out);
+int hnh_ctx_destroy(hnh_ctx* ctx);
+const char* hnh_last_error(hnh_ctx* ctx);
+void* hnh_ctx_stream(hnh_ctx* ctx, int stream); /* the raw hipStream_t, for interop (RCCL, torch) */
+int hnh_malloc(hnh_ctx* ctx, size_t bytes, void** out);
+int hnh_free(hnh_ctx* ctx, void* ptr);
+int hnh_memcpy(hnh_ctx* ctx, void* dst, const void* src, size_t bytes, int kind, int stream);
+int hnh_memset(hnh_ctx* ctx, void* dst, int byte, size_t bytes, int stream);
+int hnh_stream_sync(hnh_ctx* ctx, int stream);
+int hnh_event_create(hnh_ctx* ctx, void** event);
+int hnh_event_destroy(hnh_ctx* ctx, void* event);
+int hnh_event_record(hnh_ctx* ctx, void* event, int stream);
+int hnh_event_wait(hnh_ctx* ctx, void* event, int stream); /* `stream` waits for `event` (device side) */
+int hnh_event_sync(hnh_ctx* ctx, void* event);            /* host waits for `event`                    */
+int hnh_event_elapsed_ms(hnh_ctx* ctx, void* start, void* stop, float* ms);
+
+/* ---- local kernels --------------------------------------------------------------------------------
+ * hnh_sddmm_coo — replaces StandardKernel::sddmm_local (sparse_kernels.cpp:13-57), COO view:
+ *     for e in [0, nnz):  values[e] += < X[row_idx[e], :], Y[col_idx[e], :] >
+ *   X, Y are the (possibly role-swapped, sparse_kernels.cpp:29-37) dense operands, R columns each. */
+int hnh_sddmm_coo(hnh_ctx* ctx, int64_t nnz, const int32_t* row_idx, const int32_t* col_idx, double* values,
+                  const double* X, const double* Y, int R, int stream);
+
+/* hnh_sddmm_csr — same arithmetic as hnh_sddmm_coo on the CSR view of the same block (row_idx is the
+ *   expansion of rowptr, SpmatLocal.hpp:139-147); the X row is staged once per sparse row. */
+int hnh_sddmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
+                  const double* X, const double* Y, int R, int stream);
+
+/* hnh_spmm_csr — replaces StandardKernel::spmm_local's mkl_sparse_d_mm call (sparse_kernels.cpp:95-121):
+ *     Out[i, :] += sum_{e in row i} values[e] * X[col_idx[e], :]        (alpha = 1, beta = 1)
+ *   Amat mode: Out = A, X = B; Bmat mode (block stored transposed): Out = B, X = A. */
+int hnh_spmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values,
+                 const double* X, double* Out, int R, int stream);
+
+/* hnh_fused_sddmm_spmm_csr — the "local kernel fusion" pair of calls in
+ *   Sparse15D_Dense_Shift::fusedSpMM (15D_dense_shift.hpp:203-217) as ONE pass over the block:
+ *     for each row i, each nonzero e=(i,j):  d = < X[i,:], Y[j,:] >;  values[e] (+)= d;
+ *                                            Out[i,:] (+)= w_e * Y[j,:]
+ *   with w_e = values[e] after the update (the reference never applies Svalues on this path), or
+ *   w_e = svalues[e] * values[e] when `svalues` is non-null (extension; not used for parity).
+ *   One gather of Y[j,:] serves both the dot product and the axpy. X and Out must not alias. */
+int hnh_fused_sddmm_spmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx,
+                             double* values, const double* svalues, const double* X, const double* Y,
+                             double* Out, int R, unsigned flags, int stream);
+
+/* ---- element-wise helpers (K3-K5 of SURVEY §2.4) ----------------------------------------------------
+ * hnh_fill_f64      — SpmatLocal::setValuesConstant (SpmatLocal.hpp:595-605), DenseMatrix::setZero
+ * hnh_hadamard_f64  — `SValues.cwiseProduct(choice->getCSRValues())` (15D_dense_shift.hpp:366)
+ * hnh_axpy_f64      — y += alpha * x : local reduction step of MPI_Reduce_scatter / `tmp *= 0.0`
+ * hnh_expand_rowptr — rebuilds COO row_idx from rowptr (SpmatLocal.hpp:139-147) */
+int hnh_fill_f64(hnh_ctx* ctx, double* dst, int64_t n, double value, int stream);
+int hnh_hadamard_f64(hnh_ctx* ctx, double* out, const double* a, const double* b, int64_t n, int stream);
+int hnh_axpy_f64(hnh_ctx* ctx, double* y, const double* x, double alpha, int64_t n, int stream);
+int hnh_expand_rowptr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, int32_t* row_idx, int stream);
+
+/* ---- RCCL ring / collectives over xGMI ---------------------------------------------------------------
+ * Replace the MPI calls of the shift schedules:
+ *   hnh_comm_sendrecv        — MPI_Sendrecv in shiftDenseMatrix (distributed_sparse.h:351-361) and the
+ *                              Isend/Irecv set of CSRLocal::shiftCSR (SpmatLocal.hpp:200-259), issued as one
+ *                              ncclGroup of explicit-peer send+recv (no MPI_ANY_SOURCE);
+ *   hnh_comm_allgather       — MPI_Allgather (15D_dense_shift.hpp:194-195,310-311; 25D_cannon_dense.hpp:265);
+ *   hnh_comm_reduce_scatter  — MPI_Reduce_scatter, equal counts (15D_dense_shift.hpp:240-242,378-380).
+ * A communicator is created from a 128-byte unique id made on rank 0 (hnh_comm_unique_id) and handed to
+ * the other ranks by the launcher (torch.distributed store, MPI, a file ...). */
+#define HNH_UNIQUE_ID_BYTES 128
+int hnh_comm_unique_id(void* id_host /* HNH_UNIQUE_ID_BYTES, host */);
+int hnh_comm_init(hnh_ctx* ctx, int nranks, int rank, const void* id_host, void** comm);
+int hnh_comm_split(hnh_ctx* ctx, void* comm, int color, int key, void** newcomm);
+int hnh_comm_destroy(hnh_ctx* ctx, void* comm);
+int hnh_comm_sendrecv(hnh_ctx* ctx, void* comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf,
+                      size_t recvbytes, int src, int stream);
+int hnh_comm_allgather(hnh_ctx* ctx, void* comm, const void* sendbuf, void* recvbuf, size_t bytes_per_rank,
+                       int stream);
+int hnh_comm_reduce_scatter_f64(hnh_ctx* ctx, void* comm, const double* sendbuf, double* recvbuf,
+                                size_t count_per_rank, int stream);
+int hnh_comm_allreduce_f64(hnh_ctx* ctx, void* comm, const double* sendbuf, double* recvbuf, size_t count,
+                           int stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HNH_KERNELS_H */

@@ -1,0 +1,163 @@
+"""GPU parity of the hand-written HIP kernels (through the C ABI of include/hnh_kernels.h) against the
+CPU oracle (oracle/oracle.py: sddmm_local = sparse_kernels.cpp:44-55, spmm_local = :95-107).
+
+Tolerance (BASELINE.md / SURVEY §8d): fp64, only the summation order differs ->
+    max|x - x_ref| <= 1e-11 * max|x_ref|.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from distributed_sddmm_amd import _kernels as K
+    c = K.Ctx(0)
+    assert K.load().hnh_backend_name() == b"hip-gfx950"
+    yield c
+    c.close()
+
+
+def rel(x, y):
+    return float(np.max(np.abs(x - y)) / max(float(np.max(np.abs(y))), 1e-300)) if x.size else 0.0
+
+
+def random_block(rows, cols, nnz_target, seed, empty_rows=True):
+    rng = np.random.default_rng(seed)
+    r = rng.integers(0, rows, nnz_target)
+    if empty_rows and rows > 4:
+        r = r[(r % 5) != 3]  # leave some rows empty
+    c = rng.integers(0, cols, len(r))
+    keys = np.unique(r.astype(np.int64) * cols + c)
+    r, c = (keys // cols).astype(np.int32), (keys % cols).astype(np.int32)
+    rowptr = np.zeros(rows + 1, dtype=np.int32)
+    np.add.at(rowptr, r + 1, 1)
+    rowptr = np.cumsum(rowptr).astype(np.int32)
+    return rowptr, r, c
+
+
+RS = [1, 2, 3, 4, 8, 16, 17, 32, 64, 100, 128, 192, 256, 320, 384, 448, 512, 130]
+
+
+@pytest.mark.parametrize("R", RS)
+def test_sddmm_spmm_fused_vs_oracle(ctx, R):
+    from distributed_sddmm_amd import _kernels as K
+    lib = ctx.lib
+    rows, cols = 301, 257
+    rowptr, ridx, cidx = random_block(rows, cols, 4000, seed=R)
+    nnz = len(cidx)
+    rng = np.random.default_rng(R + 1000)
+    X = rng.uniform(-1, 1, (rows, R)); Y = rng.uniform(-1, 1, (cols, R))
+    v0 = rng.uniform(-1, 1, nnz); out0 = rng.uniform(-1, 1, (rows, R)); sv = rng.uniform(-1, 1, nnz)
+    d_rowptr, d_ridx, d_cidx = ctx.upload(rowptr), ctx.upload(ridx), ctx.upload(cidx)
+    dX, dY = ctx.upload(X), ctx.upload(Y)
+
+    # --- SDDMM (CSR and COO views): values += <X[r], Y[c]>
+    want = O.sddmm_local(ridx, cidx, v0, X, Y)
+    dv = ctx.upload(v0)
+    ctx.check(lib.hnh_sddmm_csr(ctx.h, rows, d_rowptr.ptr, d_cidx.ptr, dv.ptr, dX.ptr, dY.ptr, R, 0), "sddmm_csr")
+    assert rel(dv.get(), want) <= TOL
+    dv.set(v0)
+    ctx.check(lib.hnh_sddmm_coo(ctx.h, nnz, d_ridx.ptr, d_cidx.ptr, dv.ptr, dX.ptr, dY.ptr, R, 0), "sddmm_coo")
+    assert rel(dv.get(), want) <= TOL
+
+    # --- SpMM: Out += S * Y   (alpha = beta = 1)
+    want_out = O.spmm_local(rowptr, cidx, v0, Y, out0)
+    dv.set(v0)
+    dOut = ctx.upload(out0)
+    ctx.check(lib.hnh_spmm_csr(ctx.h, rows, d_rowptr.ptr, d_cidx.ptr, dv.ptr, dY.ptr, dOut.ptr, R, 0), "spmm_csr")
+    assert rel(dOut.get(), want_out) <= TOL
+
+    # --- fused, accumulate semantics (reference call pair, 15D_dense_shift.hpp:203-217)
+    vals_after = O.sddmm_local(ridx, cidx, v0, X, Y)
+    want_out = O.spmm_local(rowptr, cidx, vals_after, Y, out0)
+    dv.set(v0); dOut.set(out0)
+    ctx.check(lib.hnh_fused_sddmm_spmm_csr(ctx.h, rows, d_rowptr.ptr, d_cidx.ptr, dv.ptr, None, dX.ptr, dY.ptr,
+                                           dOut.ptr, R, 0, 0), "fused")
+    assert rel(dv.get(), vals_after) <= TOL
+    assert rel(dOut.get(), want_out) <= TOL
+
+    # --- fused, overwrite flags (values and Out known to be zero) + svalues extension
+    dots = O.sddmm_local(ridx, cidx, np.zeros(nnz), X, Y)
+    want_out = O.spmm_local(rowptr, cidx, dots * sv, Y, np.zeros((rows, R)))
+    dv.set(v0); dOut.set(out0)  # garbage on purpose: overwrite must ignore it
+    dsv = ctx.upload(sv)
+    ctx.check(lib.hnh_fused_sddmm_spmm_csr(ctx.h, rows, d_rowptr.ptr, d_cidx.ptr, dv.ptr, dsv.ptr, dX.ptr, dY.ptr,
+                                           dOut.ptr, R, K.FUSED_VALUES_OVERWRITE | K.FUSED_OUT_OVERWRITE, 0), "fused ow")
+    assert rel(dv.get(), dots) <= TOL
+    assert rel(dOut.get(), want_out) <= TOL
+    for d in (d_rowptr, d_ridx, d_cidx, dX, dY, dv, dOut, dsv):
+        d.free()
+
+
+def test_empty_and_degenerate(ctx):
+    lib = ctx.lib
+    R = 16
+    # rows = 0 and nnz = 0 are no-ops (sparse_kernels.cpp:25-27,85-87)
+    assert lib.hnh_sddmm_csr(ctx.h, 0, None, None, None, None, None, R, 0) == 0
+    assert lib.hnh_sddmm_coo(ctx.h, 0, None, None, None, None, None, R, 0) == 0
+    assert lib.hnh_spmm_csr(ctx.h, 0, None, None, None, None, None, R, 0) == 0
+    # a block whose rows are all empty: SpMM leaves Out unchanged, overwrite-fused zeroes it
+    rows = 70
+    rowptr = np.zeros(rows + 1, dtype=np.int32)
+    out0 = np.arange(rows * R, dtype=np.float64).reshape(rows, R)
+    d_rowptr, d_c, d_v = ctx.upload(rowptr), ctx.upload(np.zeros(1, np.int32)), ctx.upload(np.zeros(1))
+    dX, dOut = ctx.upload(np.ones((rows, R))), ctx.upload(out0)
+    ctx.check(lib.hnh_spmm_csr(ctx.h, rows, d_rowptr.ptr, d_c.ptr, d_v.ptr, dX.ptr, dOut.ptr, R, 0), "spmm empty")
+    assert np.array_equal(dOut.get(), out0)
+    dY = ctx.upload(np.ones((rows, R)))
+    ctx.check(lib.hnh_fused_sddmm_spmm_csr(ctx.h, rows, d_rowptr.ptr, d_c.ptr, d_v.ptr, None, dX.ptr, dY.ptr, dOut.ptr, R, 3, 0), "fused empty")
+    assert np.all(dOut.get() == 0.0)
+    # argument errors are reported, not crashed on
+    assert lib.hnh_sddmm_csr(ctx.h, 4, d_rowptr.ptr, d_c.ptr, d_v.ptr, dX.ptr, dY.ptr, 0, 0) != 0
+    assert lib.hnh_sddmm_csr(ctx.h, -1, d_rowptr.ptr, d_c.ptr, d_v.ptr, dX.ptr, dY.ptr, R, 0) != 0
+    assert lib.hnh_spmm_csr(ctx.h, 4, d_rowptr.ptr, d_c.ptr, d_v.ptr, dX.ptr, dX.ptr, R, 0) != 0  # aliasing
+
+
+def test_long_row_and_unaligned(ctx):
+    """One hub row with many nonzeros (skewed graphs) and an operand pointer that is only 8-byte aligned."""
+    lib = ctx.lib
+    rows, cols, R = 9, 5000, 128
+    rng = np.random.default_rng(5)
+    c_hub = np.sort(rng.choice(cols, 3001, replace=False)).astype(np.int32)
+    rowptr = np.array([0, 0, 3001, 3001, 3003, 3003, 3003, 3003, 3003, 3004], dtype=np.int32)
+    cidx = np.concatenate([c_hub, np.array([7, 4999, 0], dtype=np.int32)])
+    ridx = np.repeat(np.arange(rows, dtype=np.int32), np.diff(rowptr))
+    X = rng.uniform(-1, 1, (rows, R)); Y = rng.uniform(-1, 1, (cols, R)); v0 = rng.uniform(-1, 1, len(cidx))
+    d_rowptr, d_c, dv = ctx.upload(rowptr), ctx.upload(cidx), ctx.upload(v0)
+    dX, dY = ctx.upload(X), ctx.upload(Y)
+    ctx.check(lib.hnh_sddmm_csr(ctx.h, rows, d_rowptr.ptr, d_c.ptr, dv.ptr, dX.ptr, dY.ptr, R, 0), "sddmm hub")
+    assert rel(dv.get(), O.sddmm_local(ridx, cidx, v0, X, Y)) <= TOL
+    # R = 3 rows starting 8 bytes into an allocation -> scalar (W = 1) path
+    R3 = 3
+    Xp = np.zeros(rows * R3 + 1); Xp[1:] = rng.uniform(-1, 1, rows * R3)
+    Yp = np.zeros(cols * R3 + 1); Yp[1:] = rng.uniform(-1, 1, cols * R3)
+    dXp, dYp = ctx.upload(Xp), ctx.upload(Yp)
+    dv.set(v0)
+    ctx.check(lib.hnh_sddmm_csr(ctx.h, rows, d_rowptr.ptr, d_c.ptr, dv.ptr, dXp.ptr + 8, dYp.ptr + 8, R3, 0), "sddmm unaligned")
+    assert rel(dv.get(), O.sddmm_local(ridx, cidx, v0, Xp[1:].reshape(rows, R3), Yp[1:].reshape(cols, R3))) <= TOL
+
+
+def test_elementwise(ctx):
+    lib = ctx.lib
+    n = 100003
+    rng = np.random.default_rng(3)
+    a, b = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    da, db, do = ctx.upload(a), ctx.upload(b), ctx.upload(np.zeros(n))
+    ctx.check(lib.hnh_hadamard_f64(ctx.h, do.ptr, da.ptr, db.ptr, n, 0), "hadamard")
+    assert np.array_equal(do.get(), a * b)
+    ctx.check(lib.hnh_fill_f64(ctx.h, do.ptr, n, 2.5, 0), "fill")
+    assert np.all(do.get() == 2.5)
+    ctx.check(lib.hnh_axpy_f64(ctx.h, do.ptr, da.ptr, -3.0, n, 0), "axpy")
+    assert rel(do.get(), 2.5 - 3.0 * a) <= 1e-15
+    rows = 50
+    rowptr, ridx, _ = random_block(rows, 40, 300, seed=9)
+    dr, di = ctx.upload(rowptr), ctx.upload(np.full(len(ridx), -1, np.int32))
+    ctx.check(lib.hnh_expand_rowptr(ctx.h, rows, dr.ptr, di.ptr, 0), "expand")
+    assert np.array_equal(di.get(), ridx)
