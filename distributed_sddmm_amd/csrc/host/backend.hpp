@@ -1,0 +1,37 @@
+// Function table over the C ABI of include/hnh_kernels.h.  The host layer never links the HIP library:
+// it dlopen()s it (default: libhnh_kernels.so next to this library) and fails loudly if that is not
+// possible.  There is NO built-in CPU implementation; the only other implementation of this ABI in the
+// repository is the test double under oracle/, which tests load explicitly by path.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include "hnh_kernels.h"
+
+namespace hnh {
+
+struct Backend {
+    void* dl = nullptr;
+    std::string path, name;
+
+#define HNH_FN(sym) decltype(&::sym) sym = nullptr;
+    HNH_FN(hnh_backend_name)
+    HNH_FN(hnh_ctx_create) HNH_FN(hnh_ctx_destroy) HNH_FN(hnh_last_error) HNH_FN(hnh_ctx_stream)
+    HNH_FN(hnh_malloc) HNH_FN(hnh_free) HNH_FN(hnh_memcpy) HNH_FN(hnh_memset) HNH_FN(hnh_stream_sync)
+    HNH_FN(hnh_event_create) HNH_FN(hnh_event_destroy) HNH_FN(hnh_event_record) HNH_FN(hnh_event_wait)
+    HNH_FN(hnh_event_sync) HNH_FN(hnh_event_elapsed_ms)
+    HNH_FN(hnh_sddmm_coo) HNH_FN(hnh_sddmm_csr) HNH_FN(hnh_spmm_csr) HNH_FN(hnh_fused_sddmm_spmm_csr)
+    HNH_FN(hnh_fill_f64) HNH_FN(hnh_hadamard_f64) HNH_FN(hnh_axpy_f64) HNH_FN(hnh_expand_rowptr)
+    HNH_FN(hnh_comm_unique_id) HNH_FN(hnh_comm_init) HNH_FN(hnh_comm_split) HNH_FN(hnh_comm_destroy)
+    HNH_FN(hnh_comm_sendrecv) HNH_FN(hnh_comm_allgather) HNH_FN(hnh_comm_reduce_scatter_f64)
+    HNH_FN(hnh_comm_allreduce_f64)
+#undef HNH_FN
+};
+
+// Loads (once per path) and returns the backend; path == nullptr or "" selects the product HIP library.
+// Calls hnh::fatal() (print + exit(1) / exception) if the library or any symbol is missing.
+Backend* load_backend(const char* path);
+Backend* default_backend();           // the most recently loaded one; loads the HIP library on first use
+std::string default_backend_path();   // <dir of libhnh_host.so>/libhnh_kernels.so
+
+}  // namespace hnh

@@ -1,0 +1,384 @@
+// C ABI of the host layer (include/hnh_dist.h): thin handle wrappers over the C++ classes.
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "cannon_dense_25d.hpp"
+#include "cannon_sparse_25d.hpp"
+#include "dense_shift_15d.hpp"
+#include "er_generator.hpp"
+#include "hnh_dist.h"
+#include "sparse_shift_15d.hpp"
+
+struct hnh_thread_group {
+    std::shared_ptr<hnh::ThreadGroup> g;
+};
+struct hnh_world {
+    std::unique_ptr<hnh::World> w;
+};
+struct hnh_spmat {
+    hnh::World* w;
+    std::unique_ptr<SpmatLocal> s;
+};
+struct hnh_dense {
+    hnh::World* w;
+    DenseMatrix m;
+};
+struct hnh_vec {
+    hnh::World* w;
+    VectorXd v;
+};
+struct hnh_dist {
+    hnh::World* w;
+    std::unique_ptr<StandardKernel> kernel;
+    std::unique_ptr<Distributed_Sparse> d;
+};
+
+namespace {
+thread_local std::string t_error;
+
+template <typename F>
+int guarded(hnh::World* w, F&& f) {
+    try {
+        hnh::set_throw_on_error(true);
+        if (w) hnh::set_current_world(w);
+        f();
+        return HNH_OK;
+    } catch (const hnh::Error& e) {
+        t_error = e.what();
+        return HNH_ERR_INVALID;
+    } catch (const std::bad_alloc&) {
+        t_error = "out of host memory";
+        return HNH_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        t_error = e.what();
+        return HNH_ERR_DEVICE;
+    }
+}
+struct ErKeys {
+    uint64_t n;
+    std::vector<uint64_t> keys;
+};
+}  // namespace
+
+extern "C" {
+
+const char* hnh_host_last_error(void) { return t_error.c_str(); }
+
+int hnh_backend_load(const char* path) {
+    return guarded(nullptr, [&] { hnh::load_backend(path); });
+}
+const char* hnh_host_backend_name(void) {
+    static thread_local std::string name;
+    if (guarded(nullptr, [&] { name = hnh::default_backend()->name; }) != HNH_OK) return "";
+    return name.c_str();
+}
+
+// ------------------------------------------------------------------ worlds
+int hnh_world_create_single(int device, hnh_world** out) {
+    return guarded(nullptr, [&] {
+        auto* h = new hnh_world();
+        h->w.reset(new hnh::SingleWorld(hnh::default_backend(), device));
+        *out = h;
+    });
+}
+int hnh_thread_group_create(int nranks, hnh_thread_group** out) {
+    return guarded(nullptr, [&] {
+        if (nranks < 1) hnh::fatal("Error, a thread group needs at least one rank");
+        auto* h = new hnh_thread_group();
+        h->g = hnh::make_thread_group(nranks);
+        *out = h;
+    });
+}
+int hnh_thread_group_destroy(hnh_thread_group* g) {
+    delete g;
+    return HNH_OK;
+}
+int hnh_world_create_thread(hnh_thread_group* g, int rank, int device, hnh_world** out) {
+    return guarded(nullptr, [&] {
+        auto* h = new hnh_world();
+        h->w.reset(new hnh::ThreadWorld(g->g, rank, hnh::default_backend(), device));
+        *out = h;
+    });
+}
+int hnh_rccl_unique_id(void* id) {
+    return guarded(nullptr, [&] {
+        if (hnh::default_backend()->hnh_comm_unique_id(id) != HNH_OK) hnh::fatal("Error, cannot create an RCCL unique id");
+    });
+}
+int hnh_world_create_rccl(int rank, int nranks, int device, const void* id, hnh_world** out) {
+    return guarded(nullptr, [&] {
+        auto* h = new hnh_world();
+        h->w.reset(new hnh::RcclWorld(rank, nranks, hnh::default_backend(), device, id));
+        *out = h;
+    });
+}
+int hnh_world_create_callback(int rank, int nranks, int device, const hnh_comm_callbacks* cb, hnh_world** out) {
+    return guarded(nullptr, [&] {
+        auto* h = new hnh_world();
+        h->w.reset(new hnh::CallbackWorld(rank, nranks, hnh::default_backend(), device, *cb));
+        *out = h;
+    });
+}
+int hnh_world_destroy(hnh_world* w) {
+    return guarded(nullptr, [&] {
+        if (w && hnh::current_world_or_null() == w->w.get()) hnh::set_current_world(nullptr);
+        delete w;
+    });
+}
+int hnh_world_rank(hnh_world* w) { return w->w->rank; }
+int hnh_world_size(hnh_world* w) { return w->w->size; }
+int hnh_world_barrier(hnh_world* w) {
+    return guarded(w->w.get(), [&] { w->w->barrier(); });
+}
+int hnh_world_sync(hnh_world* w) {
+    return guarded(w->w.get(), [&] { w->w->sync_all(); });
+}
+int hnh_world_set_timing_sync(hnh_world* w, int on) {
+    w->w->timing_sync = on != 0;
+    return HNH_OK;
+}
+void* hnh_world_stream(hnh_world* w, int stream) { return w->w->be->hnh_ctx_stream(w->w->ctx, stream); }
+hnh_ctx* hnh_world_ctx(hnh_world* w) { return w->w->ctx; }
+
+int hnh_world_grid_probe(hnh_world* w, int nr, int nc, int nh, int adjacency, int* out9, int* ok) {
+    return guarded(w->w.get(), [&] {
+        FlexibleGrid g(nr, nc, nh, adjacency);
+        const int vals[9] = {g.i, g.j, g.k, g.rankInRow, g.rankInCol, g.rankInFiber, g.row_world.size(), g.col_world.size(),
+                             g.fiber_world.size()};
+        std::memcpy(out9, vals, sizeof(vals));
+        *ok = g.self_test(false) ? 1 : 0;
+    });
+}
+
+// ------------------------------------------------------------------ sparse input
+int hnh_spmat_create(hnh_world* w, int64_t M, int64_t N, int64_t dist_nnz, int64_t local_nnz, const int64_t* rows,
+                     const int64_t* cols, const double* values, hnh_spmat** out) {
+    return guarded(w->w.get(), [&] {
+        auto* h = new hnh_spmat();
+        h->w = w->w.get();
+        h->s.reset(new SpmatLocal());
+        h->s->M = (uint64_t)M;
+        h->s->N = (uint64_t)N;
+        h->s->dist_nnz = (uint64_t)dist_nnz;
+        h->s->coords.resize((size_t)local_nnz);
+        for (int64_t e = 0; e < local_nnz; e++) {
+            if (rows[e] < 0 || rows[e] >= M || cols[e] < 0 || cols[e] >= N) hnh::fatal("Error, tuple outside the matrix!");
+            h->s->coords[e] = {(uint64_t)rows[e], (uint64_t)cols[e], values ? values[e] : 1.0};
+        }
+        h->s->initialized = true;
+        *out = h;
+    });
+}
+int hnh_spmat_load_tuples(hnh_world* w, int read_from_file, int logM, int nnz_per_row, const char* filename, hnh_spmat** out) {
+    return guarded(w->w.get(), [&] {
+        auto* h = new hnh_spmat();
+        h->w = w->w.get();
+        h->s.reset(new SpmatLocal());
+        h->s->loadTuples(read_from_file != 0, logM, nnz_per_row, filename ? filename : "");
+        *out = h;
+    });
+}
+int hnh_spmat_info(hnh_spmat* s, int64_t out4[4]) {
+    out4[0] = (int64_t)s->s->M;
+    out4[1] = (int64_t)s->s->N;
+    out4[2] = (int64_t)s->s->dist_nnz;
+    out4[3] = (int64_t)s->s->coords.size();
+    return HNH_OK;
+}
+int hnh_spmat_destroy(hnh_spmat* s) {
+    return guarded(s ? s->w : nullptr, [&] { delete s; });
+}
+int hnh_er_generate(uint64_t m, uint64_t n, uint64_t draws, uint64_t seed, void** handle, int64_t* count) {
+    return guarded(nullptr, [&] {
+        auto* k = new ErKeys{n, hnh::erdos_renyi_keys(m, n, draws, seed)};
+        *count = (int64_t)k->keys.size();
+        *handle = k;
+    });
+}
+int hnh_er_fetch(void* handle, int64_t* rows, int64_t* cols) {
+    ErKeys* k = static_cast<ErKeys*>(handle);
+    const uint64_t n = k->n;
+#pragma omp parallel for
+    for (size_t e = 0; e < k->keys.size(); e++) {
+        rows[e] = (int64_t)(k->keys[e] / n);
+        cols[e] = (int64_t)(k->keys[e] % n);
+    }
+    delete k;
+    return HNH_OK;
+}
+
+// ------------------------------------------------------------------ operator
+int hnh_dist_create(hnh_world* w, const char* alg_c, hnh_spmat* s, int R, int c, hnh_dist** out) {
+    return guarded(w->w.get(), [&] {
+        const std::string alg(alg_c ? alg_c : "");
+        std::unique_ptr<hnh_dist> h(new hnh_dist());
+        h->w = w->w.get();
+        h->kernel.reset(new StandardKernel());
+        // name -> class exactly as benchmark_dist.cpp:45-82
+        if (alg == "15d_fusion1") h->d.reset(new Sparse15D_Dense_Shift(s->s.get(), R, c, 1, h->kernel.get()));
+        else if (alg == "15d_fusion2") h->d.reset(new Sparse15D_Dense_Shift(s->s.get(), R, c, 2, h->kernel.get()));
+        else if (alg == "15d_sparse") h->d.reset(new Sparse15D_Sparse_Shift(s->s.get(), R, c, h->kernel.get()));
+        else if (alg == "25d_dense_replicate") h->d.reset(new Sparse25D_Cannon_Dense(s->s.get(), R, c, h->kernel.get()));
+        else if (alg == "25d_sparse_replicate") h->d.reset(new Sparse25D_Cannon_Sparse(s->s.get(), R, c, h->kernel.get()));
+        else hnh::fatal("Error, unknown algorithm name " + alg);
+        *out = h.release();
+    });
+}
+int hnh_dist_destroy(hnh_dist* d) {
+    return guarded(d ? d->w : nullptr, [&] { delete d; });
+}
+int hnh_dist_info(hnh_dist* d, int64_t o[16]) {
+    return guarded(d->w, [&] {
+        Distributed_Sparse* x = d->d.get();
+        o[0] = x->M; o[1] = x->N; o[2] = x->R; o[3] = x->p; o[4] = x->c;
+        o[5] = x->localArows; o[6] = x->localAcols; o[7] = x->localBrows; o[8] = x->localBcols;
+        o[9] = x->like_S_values(0.0).size();
+        o[10] = x->like_ST_values(0.0).size();
+        o[11] = x->r_split ? 1 : 0;
+        o[12] = (int64_t)x->S->dist_nnz;
+        o[13] = x->proc_rank;
+        o[14] = (int64_t)x->aSubmatrices.size();
+        o[15] = (int64_t)x->bSubmatrices.size();
+    });
+}
+int hnh_dist_submatrices(hnh_dist* d, int matmode, int64_t* out, int capacity) {
+    return guarded(d->w, [&] {
+        auto& subs = matmode == HNH_AMAT ? d->d->aSubmatrices : d->d->bSubmatrices;
+        if ((int)subs.size() > capacity) hnh::fatal("Error, submatrix buffer too small");
+        for (size_t i = 0; i < subs.size(); i++) {
+            out[4 * i] = subs[i].topRow; out[4 * i + 1] = subs[i].leftCol;
+            out[4 * i + 2] = subs[i].rowCount; out[4 * i + 3] = subs[i].colCount;
+        }
+    });
+}
+int hnh_dist_set_r(hnh_dist* d, int R) {
+    return guarded(d->w, [&] { d->d->setRValue(R); });
+}
+int hnh_dist_json(hnh_dist* d, int which, char* buf, size_t capacity) {
+    return guarded(d->w, [&] {
+        std::string s = which == 0 ? d->d->json_algorithm_info() : d->d->json_perf_statistics();
+        if (s.size() + 1 > capacity) hnh::fatal("Error, JSON buffer too small");
+        std::memcpy(buf, s.c_str(), s.size() + 1);
+    });
+}
+int hnh_dist_reset_timers(hnh_dist* d) {
+    return guarded(d->w, [&] { d->d->reset_performance_timers(); });
+}
+int hnh_dist_kernel_profile(hnh_dist* d, int enable, double* total_ms, int64_t* launches) {
+    if (total_ms) *total_ms = d->kernel->kernel_ms;
+    if (launches) *launches = d->kernel->kernel_launches;
+    if (enable >= 0) {
+        d->kernel->profile = enable != 0;
+        d->kernel->kernel_ms = 0.0;
+        d->kernel->kernel_launches = 0;
+    }
+    return HNH_OK;
+}
+
+// ------------------------------------------------------------------ dense / vectors
+int hnh_dense_create(hnh_world* w, int64_t rows, int64_t cols, double fill, hnh_dense** out) {
+    return guarded(w->w.get(), [&] {
+        auto* h = new hnh_dense{w->w.get(), DenseMatrix::Constant(rows, cols, fill)};
+        *out = h;
+    });
+}
+int hnh_dense_wrap(hnh_world* w, void* ptr, int64_t rows, int64_t cols, hnh_dense** out) {
+    return guarded(w->w.get(), [&] {
+        auto* h = new hnh_dense{w->w.get(), DenseMatrix::view(static_cast<double*>(ptr), rows, cols)};
+        *out = h;
+    });
+}
+int hnh_dense_like(hnh_dist* d, int matmode, double fill, hnh_dense** out) {
+    return guarded(d->w, [&] {
+        auto* h = new hnh_dense{d->w, matmode == HNH_AMAT ? d->d->like_A_matrix(fill) : d->d->like_B_matrix(fill)};
+        *out = h;
+    });
+}
+int hnh_dense_shape(hnh_dense* m, int64_t o[2]) {
+    o[0] = m->m.rows();
+    o[1] = m->m.cols();
+    return HNH_OK;
+}
+void* hnh_dense_data(hnh_dense* m) { return m->m.data(); }
+int hnh_dense_upload(hnh_dense* m, const double* host) {
+    return guarded(m->w, [&] { m->m.copy_from_host(host); });
+}
+int hnh_dense_download(hnh_dense* m, double* host) {
+    return guarded(m->w, [&] { m->m.copy_to_host(host); });
+}
+int hnh_dense_fill(hnh_dense* m, double v) {
+    return guarded(m->w, [&] { m->m.setConstant(v); });
+}
+int hnh_dense_copy(hnh_dense* dst, hnh_dense* src) {
+    return guarded(dst->w, [&] { dst->m = src->m; });
+}
+int hnh_dense_destroy(hnh_dense* m) {
+    return guarded(m ? m->w : nullptr, [&] { delete m; });
+}
+int hnh_dense_dummy_initialize(hnh_dist* d, hnh_dense* m, int matmode) {
+    return guarded(d->w, [&] { d->d->dummyInitialize(m->m, matmode == HNH_AMAT ? Amat : Bmat); });
+}
+int hnh_vec_create(hnh_world* w, int64_t n, double fill, hnh_vec** out) {
+    return guarded(w->w.get(), [&] {
+        auto* h = new hnh_vec{w->w.get(), VectorXd::Constant(n, fill)};
+        *out = h;
+    });
+}
+int hnh_vec_like(hnh_dist* d, int which, double fill, hnh_vec** out) {
+    return guarded(d->w, [&] {
+        auto* h = new hnh_vec{d->w, which == 0 ? d->d->like_S_values(fill) : d->d->like_ST_values(fill)};
+        *out = h;
+    });
+}
+int64_t hnh_vec_size(hnh_vec* v) { return v->v.size(); }
+void* hnh_vec_data(hnh_vec* v) { return v->v.data(); }
+int hnh_vec_upload(hnh_vec* v, const double* host) {
+    return guarded(v->w, [&] { if (v->v.size()) v->v.copy_from_host(host); });
+}
+int hnh_vec_download(hnh_vec* v, double* host) {
+    return guarded(v->w, [&] { if (v->v.size()) v->v.copy_to_host(host); });
+}
+int hnh_vec_fill(hnh_vec* v, double value) {
+    return guarded(v->w, [&] { v->v.setConstant(value); });
+}
+int hnh_vec_destroy(hnh_vec* v) {
+    return guarded(v ? v->w : nullptr, [&] { delete v; });
+}
+
+// ------------------------------------------------------------------ operations
+static KernelMode kmode(int m) {
+    switch (m) {
+        case HNH_K_SDDMM_A: return k_sddmmA;
+        case HNH_K_SPMM_A: return k_spmmA;
+        case HNH_K_SPMM_B: return k_spmmB;
+        case HNH_K_SDDMM_B: return k_sddmmB;
+    }
+    hnh::fatal("Error, bad kernel mode");
+}
+int hnh_dist_initial_shift(hnh_dist* d, hnh_dense* A, hnh_dense* B, int mode) {
+    return guarded(d->w, [&] { d->d->initial_shift(A ? &A->m : nullptr, B ? &B->m : nullptr, kmode(mode)); });
+}
+int hnh_dist_de_shift(hnh_dist* d, hnh_dense* A, hnh_dense* B, int mode) {
+    return guarded(d->w, [&] { d->d->de_shift(A ? &A->m : nullptr, B ? &B->m : nullptr, kmode(mode)); });
+}
+int hnh_dist_sddmmA(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_vec* result) {
+    return guarded(d->w, [&] { d->d->sddmmA(A->m, B->m, S->v, result->v); });
+}
+int hnh_dist_sddmmB(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_vec* result) {
+    return guarded(d->w, [&] { d->d->sddmmB(A->m, B->m, S->v, result->v); });
+}
+int hnh_dist_spmmA(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S) {
+    return guarded(d->w, [&] { d->d->spmmA(A->m, B->m, S->v); });
+}
+int hnh_dist_spmmB(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S) {
+    return guarded(d->w, [&] { d->d->spmmB(A->m, B->m, S->v); });
+}
+int hnh_dist_fusedSpMM(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_vec* buf, int matmode) {
+    return guarded(d->w, [&] { d->d->fusedSpMM(A->m, B->m, S->v, buf->v, matmode == HNH_AMAT ? Amat : Bmat); });
+}
+int hnh_dist_algorithm(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_vec* result, int mode, int initial_replicate) {
+    return guarded(d->w, [&] { d->d->algorithm(A->m, B->m, S->v, result ? &result->v : nullptr, kmode(mode), initial_replicate != 0); });
+}
+
+}  // extern "C"

@@ -1,0 +1,203 @@
+// 2.5D Cannon schedule replicating a DENSE operand — same class and behaviour as the reference's
+// Sparse25D_Cannon_Dense (25D_cannon_dense.hpp): grid s x s x c with s = sqrt(p/c); one dense operand is
+// all-gathered along the fiber, the other moves along grid columns, the sparse block moves along grid rows
+// (Cannon); the sparse blocks are skewed once in the constructor (:138-145) and the moving dense operand
+// is skewed / un-skewed by initial_shift / de_shift (:169-211).  R is split over the s ranks of a grid row.
+//
+// Differences from the reference that matter for correctness: every shift names its source explicitly
+// (the reference receives from MPI_ANY_SOURCE with a reused tag and can hang) and
+// the constructor skew completes all of its transfers before the block is used (the reference forgets to
+// wait for the COO row indices in `both` mode, Appendix C #1 — our blocks ship rowStart instead).
+#pragma once
+#include <cmath>
+
+#include "distributed_sparse.hpp"
+
+class Block_Cyclic25D : public NonzeroDistribution {
+public:
+    int sqrtpc, c;
+    std::shared_ptr<FlexibleGrid> grid;
+    Block_Cyclic25D(int M, int N, int sqrtpc, int c, std::shared_ptr<FlexibleGrid>& grid) {
+        world = grid->world;
+        this->sqrtpc = sqrtpc;
+        this->c = c;
+        this->grid = grid;
+        rows_in_block = divideAndRoundUp(M, sqrtpc * c) * c;
+        cols_in_block = divideAndRoundUp(N, sqrtpc * c);
+    }
+    int blockOwner(int row_block, int col_block) override { return grid->get_global_rank(row_block, col_block / c, col_block % c); }
+};
+
+class Sparse25D_Cannon_Dense : public Distributed_Sparse {
+public:
+    int sqrtpc;
+    std::vector<int> nnz_in_row_axis, nnz_in_row_axis_tpose;
+    int sparse_shift;
+    DenseMatrix accumulation_buffer;
+    DenseMatrix ring_spare;
+
+    Sparse25D_Cannon_Dense(SpmatLocal* S_input, int R, int c, KernelImplementation* k) : Distributed_Sparse(k) {
+        this->c = c;
+        if (c < 1 || p % c != 0) hnh::fatal("Error, for 2.5D algorithm, p / c must be a perfect square!");
+        sqrtpc = (int)std::lround(std::sqrt((double)(p / c)));
+        if (sqrtpc * sqrtpc * c != p) hnh::fatal("Error, for 2.5D algorithm, p / c must be a perfect square!");
+
+        algorithm_name = "2.5D Cannon's Algorithm Replicating Dense Matrices";
+        proc_grid_names = {"# Rows", "# Cols", "# Layers"};
+        perf_counter_keys = {"Dense Cyclic Shift Time", "Sparse Cyclic Shift Time", "Dense Fiber Communication Time",
+                             "Computation Time", "Setup Shift Time"};
+
+        grid.reset(new FlexibleGrid(sqrtpc, sqrtpc, c, 3));
+        A_R_split_world = grid->row_world;
+        B_R_split_world = grid->row_world;
+        r_split = true;
+
+        this->M = S_input->M;
+        this->N = S_input->N;
+        localArows = divideAndRoundUp((int)this->M, sqrtpc * c);
+        localBrows = divideAndRoundUp((int)this->N, sqrtpc * c);
+        setRValue(R);
+
+        Block_Cyclic25D nonzero_dist((int)M, (int)N, sqrtpc, c, grid);
+        Block_Cyclic25D transpose_dist((int)N, (int)M, sqrtpc, c, grid);
+        S.reset(S_input->redistribute_nonzeros(&nonzero_dist, false, false));
+        ST.reset(S_input->redistribute_nonzeros(&transpose_dist, true, false));
+
+        nnz_in_row_axis.resize(sqrtpc);
+        nnz_in_row_axis_tpose.resize(sqrtpc);
+        int my_nnz = (int)S->coords.size(), my_nnz_tpose = (int)ST->coords.size();
+        world->host_allgather_comm(grid->row_world, &my_nnz, nnz_in_row_axis.data(), sizeof(int));
+        world->host_allgather_comm(grid->row_world, &my_nnz_tpose, nnz_in_row_axis_tpose.data(), sizeof(int));
+        const int max_nnz = *std::max_element(nnz_in_row_axis.begin(), nnz_in_row_axis.end());
+        const int max_nnz_tpose = *std::max_element(nnz_in_row_axis_tpose.begin(), nnz_in_row_axis_tpose.end());
+
+        const uint64_t ar = (uint64_t)localArows * c, br = (uint64_t)localBrows * c;
+#pragma omp parallel for
+        for (size_t e = 0; e < S->coords.size(); e++) {
+            S->coords[e].r %= ar;
+            S->coords[e].c %= (uint64_t)localBrows;
+        }
+#pragma omp parallel for
+        for (size_t e = 0; e < ST->coords.size(); e++) {
+            ST->coords[e].r %= br;
+            ST->coords[e].c %= (uint64_t)localArows;
+        }
+        S->own_all_coordinates();
+        ST->own_all_coordinates();
+        S->monolithBlockColumn();
+        ST->monolithBlockColumn();
+        S->initializeCSRBlocks(localArows * c, localBrows, max_nnz, true);
+        std::vector<spcoord_t>().swap(S->coords);
+        ST->initializeCSRBlocks(localBrows * c, localArows, max_nnz_tpose, true);
+        std::vector<spcoord_t>().swap(ST->coords);
+
+        // Skew the sparse blocks along grid rows in preparation for repeated Cannon passes (:138-145)
+        const int src = pMod(grid->rankInRow + grid->rankInCol, sqrtpc);
+        const int dst = pMod(grid->rankInRow - grid->rankInCol, sqrtpc);
+        sparse_shift = src;
+        S->csr_blocks[0]->shiftCSR(src, dst, grid->row_world, nnz_in_row_axis[src], 0, both, HNH_STREAM_COMPUTE);
+        S->blockStarts[1] = S->csr_blocks[0]->num_coords;
+        ST->csr_blocks[0]->shiftCSR(src, dst, grid->row_world, nnz_in_row_axis_tpose[src], 0, both, HNH_STREAM_COMPUTE);
+        ST->blockStarts[1] = ST->csr_blocks[0]->num_coords;
+        world->sync(HNH_STREAM_COMPUTE);
+        check_initialized();
+    }
+
+    void setRValue(int R) override {
+        this->R = R;
+        localAcols = R / sqrtpc;
+        localBcols = R / sqrtpc;
+        if (localAcols * sqrtpc != R) hnh::fatal("Error, R must be divisible by sqrt(p) / c!");
+        aSubmatrices.clear();
+        bSubmatrices.clear();
+        aSubmatrices.emplace_back(localArows * (grid->k + c * grid->i), localAcols * grid->j, localArows, localAcols);
+        bSubmatrices.emplace_back(localBrows * (grid->k + c * grid->i), localBcols * grid->j, localBrows, localBcols);
+    }
+
+    // Cannon skew of the moving dense operand along its grid column (:169-190) ...
+    void initial_shift(DenseMatrix* localA, DenseMatrix* localB, KernelMode mode) override {
+        auto t = start_clock();
+        DenseMatrix* m = (mode == k_sddmmA || mode == k_spmmA) ? localA : localB;
+        if (m != nullptr) skew(m, -grid->rankInRow);
+        stop_clock_and_add(t, "Setup Shift Time");
+    }
+    // ... and its inverse (:192-211)
+    void de_shift(DenseMatrix* localA, DenseMatrix* localB, KernelMode mode) override {
+        auto t = start_clock();
+        DenseMatrix* m = (mode == k_sddmmA || mode == k_spmmA) ? localA : localB;
+        if (m != nullptr) skew(m, +grid->rankInRow);
+        stop_clock_and_add(t, "Setup Shift Time");
+    }
+
+    VectorXd like_S_values(double value) override { return VectorXd::Constant((int64_t)ST->blockStarts[1], value); }
+    VectorXd like_ST_values(double value) override { return VectorXd::Constant((int64_t)S->blockStarts[1], value); }
+
+    void algorithm(DenseMatrix& localA, DenseMatrix& localB, VectorXd& SValues, VectorXd* sddmm_result_ptr, KernelMode mode,
+                   bool initial_replicate) override {
+        SpmatLocal* choice;
+        DenseMatrix *Arole, *Brole;
+        const std::vector<int>* nnz_in_axis;
+        if (mode == k_spmmA || mode == k_sddmmA) {  // both kernels run on transposed blocks with swapped roles (:235-241)
+            choice = ST.get(); Arole = &localB; Brole = &localA; nnz_in_axis = &nnz_in_row_axis_tpose;
+        } else {
+            choice = S.get(); Arole = &localA; Brole = &localB; nnz_in_axis = &nnz_in_row_axis;
+        }
+        if ((uint64_t)SValues.size() != choice->blockStarts[1]) hnh::fatal("Error, sparse value vector has the wrong length!");
+        const bool is_sddmm = (mode == k_sddmmA || mode == k_sddmmB);
+
+        hnh::BufferPair bBuf(Brole, &ring_spare);
+        {
+            auto t = start_clock();
+            if (is_sddmm) choice->setValuesConstant(0.0);
+            else choice->setCSRValues(SValues);
+            stop_clock_and_add(t, "Computation Time");
+        }
+        if (initial_replicate && c > 1) {
+            auto t = start_clock();
+            if (accumulation_buffer.rows() != Arole->rows() * c || accumulation_buffer.cols() != Arole->cols())
+                accumulation_buffer = DenseMatrix(Arole->rows() * c, Arole->cols());
+            world->allgather(grid->fiber_world, Arole->data(), accumulation_buffer.data(), (size_t)Arole->size() * sizeof(double),
+                             HNH_STREAM_COMPUTE);
+            stop_clock_and_add(t, "Dense Fiber Communication Time");
+        }
+        DenseMatrix& stationary = (c > 1) ? accumulation_buffer : *Arole;
+        CSRLocal* blk = choice->csr_blocks[0];
+
+        for (int i = 0; i < sqrtpc; i++) {
+            auto t = start_clock();
+            kernel->triple_function(mode == k_spmmA ? k_spmmB : mode, *choice, stationary, *bBuf.getActive(), 0, localAcols * grid->j);
+            stop_clock_and_add(t, "Computation Time");
+            if (sqrtpc > 1) {
+                // SDDMM writes the sparse values and SpMM writes the moving dense operand, so both rings
+                // follow this step's kernel; they run back to back on the communication stream.
+                t = start_clock();
+                order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);
+                shiftDenseMatrix(bBuf, grid->col_world, pMod(grid->rankInCol + 1, sqrtpc), pMod(grid->rankInCol - 1, sqrtpc),
+                                 HNH_STREAM_COMM);
+                stop_clock_and_add(t, "Dense Cyclic Shift Time");
+                t = start_clock();
+                const int src = pMod(grid->rankInRow - 1, sqrtpc), dst = pMod(grid->rankInRow + 1, sqrtpc);
+                blk->shiftCSR(src, dst, grid->row_world, (*nnz_in_axis)[pMod(sparse_shift - i - 1, sqrtpc)], 72, is_sddmm ? coo : csr,
+                              HNH_STREAM_COMM);
+                choice->blockStarts[1] = blk->num_coords;
+                order(HNH_STREAM_COMM, HNH_STREAM_COMPUTE, 1);
+                stop_clock_and_add(t, "Sparse Cyclic Shift Time");
+            }
+        }
+        bBuf.sync_active();
+
+        auto t = start_clock();
+        if (is_sddmm) choice->hadamardWithCSRValues(SValues, *sddmm_result_ptr);
+        stop_clock_and_add(t, "Computation Time");
+    }
+
+private:
+    // move `m` by `offset` positions along the grid column (stream-ordered on the compute stream)
+    void skew(DenseMatrix* m, int offset) {
+        if (sqrtpc == 1) return;
+        hnh::BufferPair buf(m, &ring_spare);
+        shiftDenseMatrix(buf, grid->col_world, pMod(grid->rankInCol + offset, sqrtpc), pMod(grid->rankInCol - offset, sqrtpc),
+                         HNH_STREAM_COMPUTE);
+        buf.sync_active();
+    }
+};

@@ -1,0 +1,242 @@
+// 2.5D Cannon schedule replicating the SPARSE matrix — same class and behaviour as the reference's
+// Sparse25D_Cannon_Sparse (25D_cannon_sparse.hpp): grid s x s x c, s = sqrt(p/c).  S is distributed over
+// the s x s floor and broadcast to all c layers (:47-54); each layer owns 1/c of the values
+// (shard_across_layers, :109-110).  Both dense operands move (A along grid rows, B along grid columns) and
+// R is split over s*c (:139-145).  SpMM first all-gathers the value shards over the fiber (:224-233);
+// SDDMM ends with a reduce-scatter of the partial dot products over the fiber (:294-300).
+//
+// Ring steps: SDDMM only reads both moving operands, so both ring transfers of step i are issued on the
+// communication stream as soon as step i's kernel has been enqueued and overlap with it (double
+// buffered); in SpMM the A-role operand is the accumulator, so the transfers follow the kernel.
+#pragma once
+#include <cmath>
+
+#include "distributed_sparse.hpp"
+
+class Floor2D : public NonzeroDistribution {
+public:
+    std::shared_ptr<FlexibleGrid> grid;
+    Floor2D(int M, int N, int sqrtpc, int c, std::shared_ptr<FlexibleGrid>& grid) {
+        (void)c;
+        this->grid = grid;
+        world = grid->world;
+        rows_in_block = divideAndRoundUp(M, sqrtpc);
+        cols_in_block = divideAndRoundUp(N, sqrtpc);
+    }
+    int blockOwner(int row_block, int col_block) override { return grid->get_global_rank(row_block, col_block, 0); }
+};
+
+class Sparse25D_Cannon_Sparse : public Distributed_Sparse {
+public:
+    int sqrtpc;
+    int nnz, nnz_tpose;
+    DenseMatrix spareA[2], spareB[2];
+    VectorXd value_buffer;  // the reference's per-call `accumulation_buffer` (length = all nonzeros of the block)
+
+    void broadcastCoordinatesFromFloor(std::unique_ptr<SpmatLocal>& spmat) {
+        int num_nnz = (int)spmat->coords.size();
+        world->host_bcast(grid->fiber_world, 0, &num_nnz, sizeof(int));
+        if (grid->rankInFiber > 0) spmat->coords.resize(num_nnz);
+        world->host_bcast(grid->fiber_world, 0, spmat->coords.data(), spmat->coords.size() * sizeof(spcoord_t));
+    }
+
+    Sparse25D_Cannon_Sparse(SpmatLocal* S_input, int R, int c, KernelImplementation* k) : Distributed_Sparse(k) {
+        this->c = c;
+        if (c < 1 || p % c != 0) hnh::fatal("Error, for 2.5D algorithm, p / c must be a perfect square!");
+        sqrtpc = (int)std::lround(std::sqrt((double)(p / c)));
+        if (sqrtpc * sqrtpc * c != p) hnh::fatal("Error, for 2.5D algorithm, p / c must be a perfect square!");
+
+        algorithm_name = "2.5D Cannon's Algorithm Replicating Sparse Matrix";
+        proc_grid_names = {"# Rows", "# Cols", "# Layers"};
+        perf_counter_keys = {"Dense Cyclic Shift Time", "Sparse Fiber Communication Time", "Computation Time", "Setup Shift Time"};
+
+        grid.reset(new FlexibleGrid(sqrtpc, sqrtpc, c, 3));
+        A_R_split_world = grid->colfiber_slice;
+        B_R_split_world = grid->colfiber_slice;
+        r_split = true;
+
+        this->M = S_input->M;
+        this->N = S_input->N;
+        localArows = divideAndRoundUp((int)this->M, sqrtpc);
+        localBrows = divideAndRoundUp((int)this->N, sqrtpc);
+        setRValue(R);
+
+        // nonzeros land on the bottom face of the cuboid, then are broadcast up the fibers
+        Floor2D nonzero_dist((int)M, (int)N, sqrtpc, c, grid);
+        Floor2D transpose_dist((int)N, (int)M, sqrtpc, c, grid);
+        S.reset(S_input->redistribute_nonzeros(&nonzero_dist, false, false));
+        ST.reset(S_input->redistribute_nonzeros(&transpose_dist, true, false));
+        broadcastCoordinatesFromFloor(S);
+        broadcastCoordinatesFromFloor(ST);
+
+        // each layer is responsible for a contiguous 1/c of the values
+        S->shard_across_layers(c, grid->k);
+        ST->shard_across_layers(c, grid->k);
+
+#pragma omp parallel for
+        for (size_t e = 0; e < S->coords.size(); e++) {
+            S->coords[e].r %= (uint64_t)localArows;
+            S->coords[e].c %= (uint64_t)localBrows;
+        }
+#pragma omp parallel for
+        for (size_t e = 0; e < ST->coords.size(); e++) {
+            ST->coords[e].r %= (uint64_t)localBrows;
+            ST->coords[e].c %= (uint64_t)localArows;
+        }
+        S->monolithBlockColumn();
+        ST->monolithBlockColumn();
+        S->initializeCSRBlocks(localArows, localBrows, -1, false);
+        nnz = (int)S->coords.size();
+        std::vector<spcoord_t>().swap(S->coords);
+        ST->initializeCSRBlocks(localBrows, localArows, -1, false);
+        nnz_tpose = (int)ST->coords.size();
+        std::vector<spcoord_t>().swap(ST->coords);
+        check_initialized();
+    }
+
+    void setRValue(int R) override {
+        this->R = R;
+        localAcols = R / (sqrtpc * c);
+        localBcols = R / (sqrtpc * c);
+        if (localAcols * sqrtpc * c != R) hnh::fatal("Error, R must be divisible by sqrt(pc)!");
+        const int shift = pMod(grid->j + grid->i, sqrtpc);  // column slices are stored already skewed
+        aSubmatrices.clear();
+        bSubmatrices.clear();
+        aSubmatrices.emplace_back(localArows * grid->i, localAcols * c * shift + grid->k * localAcols, localArows, localAcols);
+        bSubmatrices.emplace_back(localBrows * grid->i, localBcols * c * shift + grid->k * localBcols, localBrows, localBcols);
+    }
+
+    // exchange with the grid-transposed rank (j, i, k); self-inverse (:157-186)
+    void initial_shift(DenseMatrix* localA, DenseMatrix* localB, KernelMode mode) override {
+        auto t = start_clock();
+        DenseMatrix* m = (mode == k_sddmmA || mode == k_spmmA) ? localB : localA;
+        if (m != nullptr && sqrtpc > 1) {
+            const int partner = grid->get_global_rank(grid->j, grid->i, grid->k);
+            hnh::Comm wc = world->world_comm();
+            hnh::BufferPair buf(m, &spareA[0]);
+            shiftDenseMatrix(buf, wc, partner, partner, HNH_STREAM_COMPUTE);
+            buf.sync_active();
+        }
+        stop_clock_and_add(t, "Setup Shift Time");
+    }
+    void de_shift(DenseMatrix* localA, DenseMatrix* localB, KernelMode mode) override { initial_shift(localA, localB, mode); }
+
+    void algorithm(DenseMatrix& localA, DenseMatrix& localB, VectorXd& SValues, VectorXd* sddmm_result_ptr, KernelMode mode,
+                   bool initial_replicate) override {
+        (void)initial_replicate;
+        SpmatLocal* choice;
+        DenseMatrix *Arole, *Brole;
+        int nnz_selection;
+        if (mode == k_spmmA || mode == k_sddmmA) {
+            choice = S.get(); Arole = &localA; Brole = &localB; nnz_selection = nnz;
+        } else {
+            choice = ST.get(); Arole = &localB; Brole = &localA; nnz_selection = nnz_tpose;
+        }
+        if (SValues.size() != choice->owned_coords_end - choice->owned_coords_start)
+            hnh::fatal("Error, sparse value vector has the wrong length!");
+        const bool is_sddmm = (mode == k_sddmmA || mode == k_sddmmB);
+        if (value_buffer.size() != nnz_selection) value_buffer = VectorXd(nnz_selection);
+
+        if (!is_sddmm) {
+            if (c > 1) {
+                auto t = start_clock();
+                world->allgatherv_f64(grid->fiber_world, SValues.data(), (size_t)SValues.size(), value_buffer.data(),
+                                      choice->layer_coords_sizes, choice->layer_coords_start, HNH_STREAM_COMPUTE);
+                choice->setCSRValues(value_buffer);
+                stop_clock_and_add(t, "Sparse Fiber Communication Time");
+            } else {
+                auto t = start_clock();
+                choice->setCSRValues(SValues);
+                stop_clock_and_add(t, "Computation Time");
+            }
+        } else {
+            auto t = start_clock();
+            choice->setValuesConstant(0.0);
+            stop_clock_and_add(t, "Computation Time");
+        }
+
+        const KernelMode temp = (mode == k_sddmmB) ? k_sddmmA : (mode == k_spmmB ? k_spmmA : mode);
+        const int s = sqrtpc;
+        const int rdst = pMod(grid->rankInRow + 1, s), rsrc = pMod(grid->rankInRow - 1, s);
+        const int cdst = pMod(grid->rankInCol + 1, s), csrc = pMod(grid->rankInCol - 1, s);
+
+        if (is_sddmm) {
+            // both operands read-only: triple buffering, s-1 overlapped double shifts, caller buffers untouched
+            if (s > 1) {
+                for (int t = 0; t < 2; t++) {
+                    ensure(spareA[t], Arole->rows(), Arole->cols());
+                    ensure(spareB[t], Brole->rows(), Brole->cols());
+                }
+                order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);
+            }
+            DenseMatrix *curA = Arole, *curB = Brole;
+            const size_t abytes = (size_t)Arole->size() * sizeof(double), bbytes = (size_t)Brole->size() * sizeof(double);
+            for (int i = 0; i < s; i++) {
+                auto t = start_clock();
+                if (i > 0) world->event_wait(event(1 + (i - 1) % 2), HNH_STREAM_COMPUTE);
+                kernel->triple_function(temp, *choice, *curA, *curB, 0, pMod(grid->i + grid->j + i, s) * localAcols);
+                stop_clock_and_add(t, "Computation Time");
+                if (i < s - 1) {
+                    t = start_clock();
+                    world->event_record(event(3 + i % 2), HNH_STREAM_COMPUTE);
+                    if (i >= 2) world->event_wait(event(3 + (i - 1) % 2), HNH_STREAM_COMM);
+                    DenseMatrix *ta = &spareA[i % 2], *tb = &spareB[i % 2];
+                    world->sendrecv(grid->row_world, curA->data(), abytes, rdst, ta->data(), abytes, rsrc, HNH_STREAM_COMM);
+                    world->sendrecv(grid->col_world, curB->data(), bbytes, cdst, tb->data(), bbytes, csrc, HNH_STREAM_COMM);
+                    world->event_record(event(1 + i % 2), HNH_STREAM_COMM);
+                    curA = ta;
+                    curB = tb;
+                    stop_clock_and_add(t, "Dense Cyclic Shift Time");
+                }
+            }
+        } else {
+            // the A-role operand accumulates the SpMM output: s shifts, each after its kernel
+            hnh::BufferPair aBuf(Arole, &spareA[0]);
+            hnh::BufferPair bBuf(Brole, &spareB[0]);
+            for (int i = 0; i < s; i++) {
+                auto t = start_clock();
+                kernel->triple_function(temp, *choice, *aBuf.getActive(), *bBuf.getActive(), 0, pMod(grid->i + grid->j + i, s) * localAcols);
+                stop_clock_and_add(t, "Computation Time");
+                if (s > 1) {
+                    t = start_clock();
+                    order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);
+                    shiftDenseMatrix(aBuf, grid->row_world, rdst, rsrc, HNH_STREAM_COMM);
+                    shiftDenseMatrix(bBuf, grid->col_world, cdst, csrc, HNH_STREAM_COMM);
+                    order(HNH_STREAM_COMM, HNH_STREAM_COMPUTE, 1);
+                    stop_clock_and_add(t, "Dense Cyclic Shift Time");
+                }
+            }
+            auto t = start_clock();
+            aBuf.sync_active();
+            bBuf.sync_active();
+            stop_clock_and_add(t, "Computation Time");
+        }
+
+        if (is_sddmm) {
+            if (c > 1) {
+                auto t = start_clock();
+                CSRLocal* blk = choice->csr_blocks[0];
+                // partial dot products of all nonzeros -> this layer's shard, summed over the fiber
+                if (blk != nullptr)
+                    world->reduce_scatter_v_f64(grid->fiber_world, blk->getActive()->values, sddmm_result_ptr->data(),
+                                                choice->layer_coords_sizes, HNH_STREAM_COMPUTE);
+                stop_clock_and_add(t, "Sparse Fiber Communication Time");
+                t = start_clock();
+                if (SValues.size())
+                    world->check(world->be->hnh_hadamard_f64(world->ctx, sddmm_result_ptr->data(), SValues.data(),
+                                                             sddmm_result_ptr->data(), SValues.size(), HNH_STREAM_COMPUTE),
+                                 "hnh_hadamard_f64");
+                stop_clock_and_add(t, "Computation Time");
+            } else {
+                auto t = start_clock();
+                choice->hadamardWithCSRValues(SValues, *sddmm_result_ptr);
+                stop_clock_and_add(t, "Computation Time");
+            }
+        }
+    }
+
+private:
+    static void ensure(DenseMatrix& m, int64_t rows, int64_t cols) {
+        if (m.rows() != rows || m.cols() != cols) m = DenseMatrix(rows, cols);
+    }
+};

@@ -1,0 +1,272 @@
+// 1.5D dense-shifting schedule — same class and behaviour as the reference's Sparse15D_Dense_Shift
+// (15D_dense_shift.hpp): grid (p/c) x c, S stationary in block rows replicated over the c layers, one
+// dense operand all-gathered over the layer ("row") communicator, the other cyclically shifted around the
+// ring of p/c ranks ("col" communicator).  fusionApproach 1 = replication reuse, 2 = local kernel fusion.
+//
+// Ring step on MI355X.  The reference does  kernel -> MPI_Sendrecv -> MPI_Barrier  per step
+// (:343-356).  Here the moving operand is triple-buffered when it is read-only (SDDMM, and both kernels
+// of approach 2): step i's kernel reads buffer `cur` on the compute stream while the communication
+// stream already sends `cur` to ring rank i+1 and receives step i+1's operand into the next spare buffer
+// (one RCCL send/recv group over one xGMI link per direction).  The caller's matrix is never overwritten,
+// so only n-1 shifts are needed instead of n and nothing is copied back.  When the moving buffer is the
+// SpMM accumulator (approach 1, :331-337) a step's shift has to wait for that step's kernel, so the ring
+// degenerates to kernel -> shift -> kernel, as in the reference, with n shifts and a storage swap at the end.
+#pragma once
+#include "distributed_sparse.hpp"
+
+class ShardedBlockCyclicColumn : public NonzeroDistribution {
+public:
+    int p, c;
+    std::shared_ptr<FlexibleGrid> grid;
+    ShardedBlockCyclicColumn(int M, int N, int p, int c, std::shared_ptr<FlexibleGrid>& grid) {
+        world = grid->world;
+        this->p = p;
+        this->c = c;
+        this->grid = grid;
+        rows_in_block = divideAndRoundUp(M, p) * c;
+        cols_in_block = divideAndRoundUp(N, p);
+    }
+    int blockOwner(int row_block, int col_block) override { return grid->get_global_rank(row_block, col_block % c, 0); }
+};
+
+class Sparse15D_Dense_Shift : public Distributed_Sparse {
+public:
+    int fusionApproach;
+    DenseMatrix accumulation_buffer;  // replicated stationary operand (approach 1) / replicated output (approach 2)
+    DenseMatrix broadcast_buffer;     // approach-2 fused: replicated SDDMM row operand when c > 1
+    DenseMatrix ring_spare[2];        // persistent spare buffers of the moving operand
+
+    Sparse15D_Dense_Shift(SpmatLocal* S_input, int R, int c, int fusionApproach, KernelImplementation* k) : Distributed_Sparse(k) {
+        this->fusionApproach = fusionApproach;
+        this->c = c;
+        if (c < 1 || p % c != 0) hnh::fatal("Error, for 1.5D algorithm, must have c divide num_procs!");
+        if (fusionApproach != 1 && fusionApproach != 2) hnh::fatal("Error, fusion approach must be 1 or 2!");
+
+        algorithm_name = "1.5D Block Row Replicated S Striped AB Cyclic Shift";
+        proc_grid_names = {"# Rows", "# Layers"};
+        perf_counter_keys = {"Replication Time", "Cyclic Shift Time", "Computation Time"};
+
+        grid.reset(new FlexibleGrid(p / c, c, 1, 1));
+        r_split = false;
+        this->M = S_input->M;
+        this->N = S_input->N;
+
+        ShardedBlockCyclicColumn standard_dist((int)M, (int)N, p, c, grid);
+        ShardedBlockCyclicColumn transpose_dist((int)N, (int)M, p, c, grid);
+
+        // private copies of the nonzeros in the layout this schedule wants; the caller's matrix is untouched
+        S.reset(S_input->redistribute_nonzeros(&standard_dist, false, false));
+        ST.reset(S->redistribute_nonzeros(&transpose_dist, true, false));
+
+        localArows = divideAndRoundUp((int)this->M, p);
+        localBrows = divideAndRoundUp((int)this->N, p);
+        setRValue(R);
+
+        const uint64_t arows = (uint64_t)localArows * c, brows = (uint64_t)localBrows * c;
+#pragma omp parallel for
+        for (size_t e = 0; e < S->coords.size(); e++) S->coords[e].r %= arows;
+        S->divideIntoBlockCols(localBrows, p, true);
+#pragma omp parallel for
+        for (size_t e = 0; e < ST->coords.size(); e++) ST->coords[e].r %= brows;
+        ST->divideIntoBlockCols(localArows, p, true);
+
+        S->own_all_coordinates();
+        ST->own_all_coordinates();
+
+        const bool local_tpose = (fusionApproach == 1);
+        S->initializeCSRBlocks(localArows * c, localBrows, -1, local_tpose);
+        std::vector<spcoord_t>().swap(S->coords);
+        ST->initializeCSRBlocks(localBrows * c, localArows, -1, local_tpose);
+        std::vector<spcoord_t>().swap(ST->coords);
+        check_initialized();
+    }
+
+    void setRValue(int R) override {
+        this->R = R;
+        localAcols = R;
+        localBcols = R;
+        aSubmatrices.clear();
+        bSubmatrices.clear();
+        aSubmatrices.emplace_back(localArows * (c * grid->i + grid->j), 0, localArows, localAcols);
+        bSubmatrices.emplace_back(localBrows * (c * grid->i + grid->j), 0, localBrows, localBcols);
+    }
+
+    void initial_shift(DenseMatrix*, DenseMatrix*, KernelMode) override {}  // empty on purpose
+    void de_shift(DenseMatrix*, DenseMatrix*, KernelMode) override {}       // empty on purpose
+
+    VectorXd like_S_values(double value) override {
+        SpmatLocal* s = (fusionApproach == 1) ? ST.get() : S.get();
+        return VectorXd::Constant(s->owned_coords_end - s->owned_coords_start, value);
+    }
+    VectorXd like_ST_values(double value) override {
+        SpmatLocal* s = (fusionApproach == 1) ? S.get() : ST.get();
+        return VectorXd::Constant(s->owned_coords_end - s->owned_coords_start, value);
+    }
+
+    // Block visited at ring step i (15D_dense_shift.hpp:326)
+    int block_at(int i) const { return pMod((grid->rankInCol - i) * c + grid->rankInRow, p); }
+
+    // ---- local kernel fusion (approach 2): SDDMM and SpMM on every visiting block in ONE pass of shifts
+    void fusedSpMM(DenseMatrix& localA, DenseMatrix& localB, VectorXd& Svalues, VectorXd& sddmm_buffer, MatMode mode) override {
+        if (fusionApproach == 1) {
+            Distributed_Sparse::fusedSpMM(localA, localB, Svalues, sddmm_buffer, mode);
+            return;
+        }
+        // NB: like the reference (15D_dense_shift.hpp:189,250-251) this path neither multiplies by Svalues
+        // nor fills sddmm_buffer; it equals the generic path when Svalues == 1 (true in every app/benchmark).
+        DenseMatrix* Arole = (mode == Amat) ? &localA : &localB;
+        DenseMatrix* Brole = (mode == Amat) ? &localB : &localA;
+        SpmatLocal* choice = (mode == Amat) ? S.get() : ST.get();
+        const int n = p / c;
+
+        ensure(accumulation_buffer, Arole->rows() * c, R);
+        DenseMatrix* rowOperand = Arole;
+        if (c > 1) {
+            auto t = start_clock();
+            ensure(broadcast_buffer, Arole->rows() * c, R);
+            world->allgather(grid->row_world, Arole->data(), broadcast_buffer.data(), (size_t)Arole->size() * sizeof(double),
+                             HNH_STREAM_COMPUTE);
+            rowOperand = &broadcast_buffer;
+            stop_clock_and_add(t, "Replication Time");
+        }
+
+        bool out_fresh = true;
+        ring_readonly(Brole, n, [&](int i, DenseMatrix& cur) {
+            auto t = start_clock();
+            const int block_id = block_at(i);
+            if (choice->csr_blocks[block_id] != nullptr) {
+                unsigned flags = HNH_FUSED_VALUES_OVERWRITE | (out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u);
+                kernel->fused_local(*choice, *rowOperand, cur, accumulation_buffer, block_id, flags);
+                out_fresh = false;
+            }
+            stop_clock_and_add(t, "Computation Time");
+        });
+        if (out_fresh) accumulation_buffer.setZero();  // no block on this rank had a nonzero
+
+        if (c > 1) {
+            auto t = start_clock();
+            world->reduce_scatter_f64(grid->row_world, accumulation_buffer.data(), Arole->data(), (size_t)Arole->rows() * R,
+                                      HNH_STREAM_COMPUTE);
+            stop_clock_and_add(t, "Replication Time");
+        } else {
+            auto t = start_clock();
+            if (Arole->owns_storage()) Arole->swap(accumulation_buffer);  // `*Arole = accumulation_buffer` without the copy
+            else *Arole = accumulation_buffer;
+            stop_clock_and_add(t, "Computation Time");
+        }
+    }
+
+    // SDDMM, SpMM with A as the output, or SpMM with B as the output (15D_dense_shift.hpp:276-384)
+    void algorithm(DenseMatrix& localA, DenseMatrix& localB, VectorXd& SValues, VectorXd* sddmm_result_ptr, KernelMode mode,
+                   bool initial_replicate) override {
+        DenseMatrix *Arole, *Brole;
+        SpmatLocal* choice;
+        const bool invert = (fusionApproach == 1);
+        if ((mode == k_spmmA || mode == k_sddmmA) == invert) {
+            Arole = &localB;
+            Brole = &localA;
+            choice = ST.get();
+        } else {
+            Arole = &localA;
+            Brole = &localB;
+            choice = S.get();
+        }
+        const bool is_sddmm = (mode == k_sddmmA || mode == k_sddmmB);
+        const int n = p / c;
+
+        if (initial_replicate && c > 1) {
+            auto t = start_clock();
+            ensure(accumulation_buffer, Arole->rows() * c, R);
+            world->allgather(grid->row_world, Arole->data(), accumulation_buffer.data(), (size_t)Arole->size() * sizeof(double),
+                             HNH_STREAM_COMPUTE);
+            stop_clock_and_add(t, "Replication Time");
+        }
+
+        {
+            auto t = start_clock();
+            if (is_sddmm) choice->setValuesConstant(0.0);
+            else choice->setCSRValues(SValues);
+            stop_clock_and_add(t, "Computation Time");
+        }
+
+        KernelMode mode_temp = mode;
+        if (fusionApproach == 1 && mode == k_spmmA) mode_temp = k_spmmB;
+        if (fusionApproach == 2 && mode == k_spmmB) mode_temp = k_spmmA;
+        DenseMatrix& stationary = (c > 1) ? accumulation_buffer : *Arole;
+
+        auto step = [&](int i, DenseMatrix& cur) {
+            auto t = start_clock();
+            kernel->triple_function(mode_temp, *choice, stationary, cur, block_at(i), 0);
+            stop_clock_and_add(t, "Computation Time");
+        };
+
+        // the moving operand is written only when it is the SpMM accumulator (approach 1)
+        const bool moving_readonly = is_sddmm || fusionApproach == 2;
+        if (moving_readonly) ring_readonly(Brole, n, step);
+        else ring_readwrite(Brole, n, step);
+
+        if (is_sddmm) {
+            auto t = start_clock();
+            choice->hadamardWithCSRValues(SValues, *sddmm_result_ptr);  // result = SValues .* block values
+            stop_clock_and_add(t, "Computation Time");
+        }
+
+        if (fusionApproach == 2 && !is_sddmm && c > 1) {
+            auto t = start_clock();
+            world->reduce_scatter_f64(grid->row_world, accumulation_buffer.data(), Arole->data(), (size_t)Arole->rows() * R,
+                                      HNH_STREAM_COMPUTE);
+            stop_clock_and_add(t, "Replication Time");
+        }
+    }
+
+private:
+    static void ensure(DenseMatrix& m, int64_t rows, int64_t cols) {
+        if (m.rows() != rows || m.cols() != cols) m = DenseMatrix(rows, cols);
+    }
+
+    // n kernel steps over a READ-ONLY moving operand, n-1 overlapped shifts, caller's buffer untouched.
+    template <typename Step>
+    void ring_readonly(DenseMatrix* start, int n, Step&& step) {
+        if (n > 1) {
+            for (auto& s : ring_spare) ensure(s, start->rows(), start->cols());
+            order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // inputs (and earlier readers of the spares) are done
+        }
+        const int dst = pMod(grid->rankInCol + 1, n), src = pMod(grid->rankInCol - 1, n);
+        const size_t bytes = (size_t)start->size() * sizeof(double);
+        DenseMatrix* cur = start;
+        for (int i = 0; i < n; i++) {
+            if (i > 0) world->event_wait(event(1 + (i - 1) % 2), HNH_STREAM_COMPUTE);  // shift i-1 landed
+            step(i, *cur);
+            if (i < n - 1) {
+                auto t = start_clock();
+                world->event_record(event(3 + i % 2), HNH_STREAM_COMPUTE);                 // kernel i enqueued
+                DenseMatrix* target = &ring_spare[i % 2];
+                if (i >= 2) world->event_wait(event(3 + (i - 1) % 2), HNH_STREAM_COMM);    // kernel i-1 last read `target`
+                world->sendrecv(grid->col_world, cur->data(), bytes, dst, target->data(), bytes, src, HNH_STREAM_COMM);
+                world->event_record(event(1 + i % 2), HNH_STREAM_COMM);
+                cur = target;
+                stop_clock_and_add(t, "Cyclic Shift Time");
+            }
+        }
+    }
+
+    // n kernel steps that WRITE the moving operand, n shifts, result handed back to the caller's matrix.
+    template <typename Step>
+    void ring_readwrite(DenseMatrix* start, int n, Step&& step) {
+        hnh::BufferPair bBuf(start, &ring_spare[0]);
+        const int dst = pMod(grid->rankInCol + 1, n), src = pMod(grid->rankInCol - 1, n);
+        for (int i = 0; i < n; i++) {
+            step(i, *bBuf.getActive());
+            if (n > 1) {
+                auto t = start_clock();
+                order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);
+                shiftDenseMatrix(bBuf, grid->col_world, dst, src, HNH_STREAM_COMM);
+                order(HNH_STREAM_COMM, HNH_STREAM_COMPUTE, 5);
+                stop_clock_and_add(t, "Cyclic Shift Time");
+            }
+        }
+        auto t = start_clock();
+        bBuf.sync_active();
+        stop_clock_and_add(t, "Computation Time");
+    }
+};

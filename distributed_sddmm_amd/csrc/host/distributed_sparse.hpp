@@ -1,0 +1,244 @@
+// Operator base class — same public surface as the reference's distributed_sparse.h:32-388:
+//   fields  proc_rank, p, c, algorithm_name, proc_grid_names, perf_counter_keys, call_count, total_time,
+//           M, N, R, localA{rows,cols}, localB{rows,cols}, aSubmatrices, bSubmatrices, S, ST, grid, kernel,
+//           r_split, A_R_split_world, B_R_split_world, verbose
+//   methods setRValue, like_{A,B}_matrix, like_{S,ST}_values, initial_shift, de_shift, sddmmA/B, spmmA/B,
+//           fusedSpMM, algorithm, reset_performance_timers, stop_clock_and_add, json_perf_statistics,
+//           json_algorithm_info, print_*, dummyInitialize, shiftDenseMatrix, check_initialized.
+// Global meaning (row a9 of SURVEY §8): sddmm[e] = Sval[e] * <A[i_e,:], B[j_e,:]>;  spmmA: A = S B;
+// spmmB: B = S^T A;  fusedSpMM(Amat): A <- (Sval .* (A B^T)|_S) B.
+//
+// What differs, deliberately:
+//   * dense operands and value vectors are device resident (dense.hpp); MPI communicators are hnh::Comm;
+//   * the per-step MPI_Barrier(MPI_COMM_WORLD) (e.g. 15D_dense_shift.hpp:355) is gone: ordering between the
+//     local kernel (compute stream) and the ring shift (communication stream) is expressed with HIP events,
+//     which is what lets the two overlap;
+//   * every buffer the reference allocates per call (BufferPair::extra, accumulation_buffer, getCSRValues
+//     temporaries) is allocated once and reused;
+//   * JSON is produced as text (same keys as the reference's nlohmann objects).
+#pragma once
+#include <algorithm>
+#include <cassert>
+#include <iomanip>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "dense.hpp"
+#include "flexible_grid.hpp"
+#include "sparse_kernels.hpp"
+#include "spmat_local.hpp"
+
+class DenseSubmatrix {
+public:
+    int topRow, leftCol, rowCount, colCount;
+    DenseSubmatrix(int tR, int lC, int rC, int cC) : topRow(tR), leftCol(lC), rowCount(rC), colCount(cC) {}
+};
+
+class Distributed_Sparse {
+public:
+    int proc_rank;  // global process rank
+    int p, c;       // total # of processes, replication factor
+
+    std::string algorithm_name;
+    std::vector<std::string> proc_grid_names;
+
+    // performance counting (same key names as the reference so result JSON stays drop-in)
+    std::vector<std::string> perf_counter_keys;
+    std::map<std::string, int> call_count;
+    std::map<std::string, double> total_time;
+
+    int64_t M, N, R;
+    int localArows, localAcols, localBrows, localBcols;
+
+    std::vector<DenseSubmatrix> aSubmatrices;
+    std::vector<DenseSubmatrix> bSubmatrices;
+
+    std::unique_ptr<SpmatLocal> S;
+    std::unique_ptr<SpmatLocal> ST;
+    std::shared_ptr<FlexibleGrid> grid;
+
+    int superclass_constructor_sentinel;
+    KernelImplementation* kernel;  // stored, not owned (distributed_sparse.h:65,84)
+
+    bool r_split;
+    hnh::Comm A_R_split_world, B_R_split_world;
+    bool verbose;
+    std::string debug_msg;
+    hnh::World* world;
+
+    Distributed_Sparse(KernelImplementation* k) {
+        world = hnh::current_world();
+        proc_rank = world->rank;
+        p = world->size;
+        verbose = false;
+        kernel = k;
+        algorithm_name = "";
+        M = N = R = -1;
+        localArows = localAcols = localBrows = localBcols = -1;
+        c = -1;
+        r_split = false;
+        superclass_constructor_sentinel = 3;
+    }
+
+    virtual ~Distributed_Sparse() {
+        if (world) {
+            world->sync_all();
+            for (void* e : events_) world->event_destroy(e);
+        }
+    }
+
+    virtual void setRValue(int R) = 0;
+
+    void check_initialized() {
+        bool ok = algorithm_name != "" && proc_grid_names.size() > 0 && perf_counter_keys.size() > 0 && M != -1 && N != -1 &&
+                  R != -1 && localAcols != -1 && localBcols != -1 && localArows != -1 && localBrows != -1 && c >= 1 &&
+                  superclass_constructor_sentinel == 3 && aSubmatrices.size() > 0 && bSubmatrices.size() > 0 && S &&
+                  ST && S->initialized && ST->initialized && S->coordinate_ownership_initialized &&
+                  ST->coordinate_ownership_initialized && S->blockStarts.size() > 0 && ST->blockStarts.size() > 0 &&
+                  S->csr_initialized && ST->csr_initialized;
+        if (!ok) hnh::fatal("Error, distributed sparse operator was not completely initialized by its subclass!");
+    }
+
+    // ---- reporting (distributed_sparse.h:131-179, 245-261)
+    std::string json_algorithm_info() {
+        std::vector<uint64_t> mine = {(uint64_t)(S->owned_coords_end - S->owned_coords_start),
+                                      (uint64_t)(ST->owned_coords_end - ST->owned_coords_start)};
+        std::vector<uint64_t> all(2 * (size_t)p);
+        world->host_allgather(mine.data(), all.data(), 2 * sizeof(uint64_t));
+        std::ostringstream o;
+        o << "{\"alg_name\": \"" << algorithm_name << "\", \"m\": " << M << ", \"n\": " << N << ", \"nnz\": " << S->dist_nnz
+          << ", \"r\": " << R << ", \"adjacency_mode\": " << grid->adjacency << ", \"p\": " << p << ", \"c\": " << c
+          << ", \"dim_interpretations\": [";
+        for (size_t i = 0; i < proc_grid_names.size(); i++) o << (i ? ", " : "") << "\"" << proc_grid_names[i] << "\"";
+        o << "], \"dim_values\": [";
+        for (size_t i = 0; i < proc_grid_names.size(); i++) o << (i ? ", " : "") << grid->dim_list[i];
+        o << "], \"nnz_procs\": [";
+        for (int r = 0; r < p; r++) o << (r ? ", " : "") << all[2 * r];
+        o << "], \"nnz_tpose_procs\": [";
+        for (int r = 0; r < p; r++) o << (r ? ", " : "") << all[2 * r + 1];
+        o << "], \"transport\": \"" << world->kind() << "\", \"backend\": \"" << world->be->name << "\"}";
+        return o.str();
+    }
+    void print_algorithm_info() { std::cout << json_algorithm_info() << std::endl; }
+    void setVerbose(bool value) { verbose = value; }
+
+    virtual VectorXd like_S_values(double value) { return VectorXd::Constant(S->owned_coords_end - S->owned_coords_start, value); }
+    virtual VectorXd like_ST_values(double value) { return VectorXd::Constant(ST->owned_coords_end - ST->owned_coords_start, value); }
+    DenseMatrix like_A_matrix(double value) { return DenseMatrix::Constant(localArows, localAcols, value); }
+    DenseMatrix like_B_matrix(double value) { return DenseMatrix::Constant(localBrows, localBcols, value); }
+
+    void reset_performance_timers() {
+        for (auto& key : perf_counter_keys) {
+            call_count[key] = 0;
+            total_time[key] = 0.0;
+        }
+    }
+
+    // Wall-clock counters like the reference's.  GPU work is asynchronous: with world->timing_sync the
+    // streams are drained first so that the counters attribute time the way the reference does; without it
+    // they only see the host-side enqueue cost (and the bench times whole calls with events instead).
+    void stop_clock_and_add(my_timer_t& start, const std::string& counter_name) {
+        if (std::find(perf_counter_keys.begin(), perf_counter_keys.end(), counter_name) == perf_counter_keys.end())
+            hnh::fatal("Error, performance counter " + counter_name + " not registered.");
+        if (world->timing_sync) world->sync_all();
+        call_count[counter_name]++;
+        total_time[counter_name] += stop_clock_get_elapsed(start);
+    }
+
+    std::string json_perf_statistics() {  // mean over ranks, as distributed_sparse.h:245-261
+        std::vector<double> vals;
+        for (auto& key : perf_counter_keys) vals.push_back(total_time[key]);
+        world->host_allreduce_sum(vals.data(), vals.size());
+        std::ostringstream o;
+        o << std::setprecision(17) << "{";
+        for (size_t i = 0; i < perf_counter_keys.size(); i++)
+            o << (i ? ", " : "") << "\"" << perf_counter_keys[i] << "\": " << vals[i] / p;
+        o << "}";
+        return o.str();
+    }
+
+    void print_performance_statistics() {
+        if (proc_rank == 0) {
+            std::cout << std::endl << "================================" << std::endl << "==== Performance Statistics ====" << std::endl
+                      << "================================" << std::endl;
+        }
+        std::string info = json_algorithm_info(), stats = json_perf_statistics();
+        if (proc_rank == 0) std::cout << info << std::endl << stats << std::endl << "=================================" << std::endl;
+    }
+
+    // If the input buffers need to be shifted / transposed
+    virtual void initial_shift(DenseMatrix* localA, DenseMatrix* localB, KernelMode op) = 0;
+    virtual void de_shift(DenseMatrix* localA, DenseMatrix* localB, KernelMode op) = 0;
+
+    // ---- the five convenience operations (distributed_sparse.h:274-312)
+    void spmmA(DenseMatrix& localA, DenseMatrix& localB, VectorXd& SValues) {
+        localA.setZero();
+        algorithm(localA, localB, SValues, nullptr, k_spmmA, true);
+    }
+    void spmmB(DenseMatrix& localA, DenseMatrix& localB, VectorXd& SValues) {
+        localB.setZero();
+        algorithm(localA, localB, SValues, nullptr, k_spmmB, true);
+    }
+    void sddmmA(DenseMatrix& localA, DenseMatrix& localB, VectorXd& SValues, VectorXd& sddmm_result) {
+        algorithm(localA, localB, SValues, &sddmm_result, k_sddmmA, true);
+    }
+    void sddmmB(DenseMatrix& localA, DenseMatrix& localB, VectorXd& SValues, VectorXd& sddmm_result) {
+        algorithm(localA, localB, SValues, &sddmm_result, k_sddmmB, true);
+    }
+
+    // FusedMM by replication reuse: the SpMM skips the replication the SDDMM already did.  The user is
+    // responsible for any initial and final shifts (fairness in benchmarking).
+    virtual void fusedSpMM(DenseMatrix& localA, DenseMatrix& localB, VectorXd& Svalues, VectorXd& sddmm_buffer, MatMode mode) {
+        if (mode == Amat) {
+            algorithm(localA, localB, Svalues, &sddmm_buffer, k_sddmmA, true);
+            localA.setZero();
+            algorithm(localA, localB, sddmm_buffer, nullptr, k_spmmA, false);
+        } else if (mode == Bmat) {
+            algorithm(localA, localB, Svalues, &sddmm_buffer, k_sddmmB, true);
+            localB.setZero();
+            algorithm(localA, localB, sddmm_buffer, nullptr, k_spmmB, false);
+        }
+    }
+
+    virtual void algorithm(DenseMatrix& localA, DenseMatrix& localB, VectorXd& SValues, VectorXd* sddmm_result_ptr, KernelMode mode,
+                           bool initial_replicate) = 0;
+
+    // Deterministic test fill: value(row, col) = row * R + col in GLOBAL coordinates, so fingerprints do
+    // not depend on the distribution (distributed_sparse.h:322-346).
+    void dummyInitialize(DenseMatrix& loc, MatMode mode) {
+        std::vector<DenseSubmatrix>& subs = (mode == Amat) ? aSubmatrices : bSubmatrices;
+        std::vector<double> host((size_t)loc.size());
+        double* ptr = host.data();
+        for (auto& s : subs)
+            for (int i = 0; i < s.rowCount; i++)
+                for (int j = 0; j < s.colCount; j++) *ptr++ = (double)(s.topRow + i) * (double)R + s.leftCol + j;
+        loc.copy_from_host(host.data());
+    }
+
+    // ---- dense cyclic shift (distributed_sparse.h:351-361): active buffer -> `send_dst`, the buffer of
+    // `recv_src` -> passive buffer, swap.  Explicit source (the reference receives from MPI_ANY_SOURCE and
+    // races).  Stream-ordered on `stream`.
+    void shiftDenseMatrix(hnh::BufferPair& buf, const hnh::Comm& comm, int send_dst, int recv_src, int stream = HNH_STREAM_COMM) {
+        const size_t bytes = (size_t)buf.getActive()->size() * sizeof(double);
+        world->sendrecv(comm, buf.getActive()->data(), bytes, send_dst, buf.getPassive()->data(), bytes, recv_src, stream);
+        buf.swapActive();
+    }
+
+protected:
+    // small pool of events for compute/communication hand-offs
+    std::vector<void*> events_;
+    void* event(size_t i) {
+        while (events_.size() <= i) events_.push_back(world->event_create());
+        return events_[i];
+    }
+    // make `waiter` stream wait for everything enqueued so far on `signaller`
+    void order(int signaller, int waiter, size_t slot) {
+        void* e = event(slot);
+        world->event_record(e, signaller);
+        world->event_wait(e, waiter);
+    }
+};

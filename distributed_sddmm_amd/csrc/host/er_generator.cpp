@@ -1,0 +1,96 @@
+#include "er_generator.hpp"
+
+#include <parallel/algorithm>
+
+#include <algorithm>
+#include <fstream>
+#include <sstream>
+
+#include "spmat_local.hpp"
+
+namespace hnh {
+
+std::vector<uint64_t> erdos_renyi_keys(uint64_t m, uint64_t n, uint64_t draws, uint64_t seed) {
+    std::vector<uint64_t> keys(draws);
+    const uint64_t G = 0x9E3779B97F4A7C15ull;
+#pragma omp parallel for
+    for (uint64_t k = 0; k < draws; k++) {
+        const uint64_t base = seed + (2 * k) * G;
+        const uint64_t r = splitmix64(base) % m, c = splitmix64(base + G) % n;
+        keys[k] = r * n + c;
+    }
+    __gnu_parallel::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    return keys;
+}
+
+void read_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std::vector<spcoord_t>& tuples) {
+    std::ifstream in(path);
+    if (!in) fatal("Error, cannot open matrix file " + path);
+    std::string line;
+    if (!std::getline(in, line) || line.rfind("%%MatrixMarket", 0) != 0) fatal("Error, " + path + " is not a MatrixMarket file");
+    std::string lower = line;
+    std::transform(lower.begin(), lower.end(), lower.begin(), ::tolower);
+    if (lower.find("coordinate") == std::string::npos) fatal("Error, only coordinate MatrixMarket files are supported");
+    const bool pattern = lower.find("pattern") != std::string::npos;
+    const bool symmetric = lower.find("symmetric") != std::string::npos;
+    while (std::getline(in, line))
+        if (!line.empty() && line[0] != '%') break;
+    uint64_t entries = 0;
+    {
+        std::istringstream hdr(line);
+        if (!(hdr >> m >> n >> entries)) fatal("Error, bad MatrixMarket size line in " + path);
+    }
+    tuples.clear();
+    tuples.reserve(symmetric ? 2 * entries : entries);
+    for (uint64_t e = 0; e < entries; e++) {
+        uint64_t r, c;
+        double v = 1.0;
+        if (!(in >> r >> c)) fatal("Error, truncated MatrixMarket file " + path);
+        if (!pattern && !(in >> v)) fatal("Error, truncated MatrixMarket file " + path);
+        if (r < 1 || r > m || c < 1 || c > n) fatal("Error, MatrixMarket index out of range in " + path);
+        tuples.push_back({r - 1, c - 1, v});
+        if (symmetric && r != c) tuples.push_back({c - 1, r - 1, v});
+    }
+    // duplicates -> maximum
+    std::sort(tuples.begin(), tuples.end(), [](const spcoord_t& a, const spcoord_t& b) { return row_major(a, b); });
+    size_t out = 0;
+    for (size_t e = 0; e < tuples.size(); e++) {
+        if (out > 0 && tuples[out - 1].r == tuples[e].r && tuples[out - 1].c == tuples[e].c)
+            tuples[out - 1].value = std::max(tuples[out - 1].value, tuples[e].value);
+        else
+            tuples[out++] = tuples[e];
+    }
+    tuples.resize(out);
+}
+
+}  // namespace hnh
+
+// SpmatLocal::loadTuples — same signature as SpmatLocal.hpp:467-470.  Synthetic: M = N = 2^logM,
+// M * nnz_per_row draws, seed 12345 (env HNH_ER_SEED overrides), values 1.0.  Every rank evaluates the
+// same generator / reads the same file and keeps the strided slice {e : e % p == rank}.
+void SpmatLocal::loadTuples(bool readFromFile, int logM, int nnz_per_row, std::string filename) {
+    const int p = world->size, rank = world->rank;
+    coords.clear();
+    if (readFromFile) {
+        std::vector<spcoord_t> all;
+        uint64_t m = 0, n = 0;
+        hnh::read_matrix_market(filename, m, n, all);
+        M = m;
+        N = n;
+        dist_nnz = all.size();
+        for (size_t e = rank; e < all.size(); e += p) coords.push_back(all[e]);
+        if (rank == 0) std::cout << "File reader read " << dist_nnz << " nonzeros." << std::endl;
+    } else {
+        const uint64_t m = 1ull << logM;
+        uint64_t seed = 12345;
+        if (const char* s = std::getenv("HNH_ER_SEED")) seed = std::strtoull(s, nullptr, 10);
+        std::vector<uint64_t> keys = hnh::erdos_renyi_keys(m, m, m * (uint64_t)nnz_per_row, seed);
+        M = N = m;
+        dist_nnz = keys.size();
+        coords.reserve(keys.size() / p + 1);
+        for (size_t e = rank; e < keys.size(); e += p) coords.push_back({keys[e] / m, keys[e] % m, 1.0});
+        if (rank == 0) std::cout << "R-mat generator created " << dist_nnz << " nonzeros." << std::endl;
+    }
+    initialized = true;
+}

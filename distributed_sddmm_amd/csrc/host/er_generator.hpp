@@ -1,0 +1,28 @@
+// Deterministic synthetic inputs (replaces CombBLAS GenGraph500Data with initiator {.25,.25,.25,.25},
+// SpmatLocal.hpp:502-505, and its file reader).  Counter-based: draw k of an (m x n, draws, seed) matrix is
+//     row = splitmix64(seed + 2k*G) % m,  col = splitmix64(seed + (2k+1)*G) % n,   G = 0x9E3779B97F4A7C15
+// followed by de-duplication; every rank (and oracle/oracle.py:erdos_renyi_mn, bit for bit) evaluates the
+// same function, so all transports and rank counts see the same global matrix.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "common.hpp"
+
+namespace hnh {
+
+inline uint64_t splitmix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Sorted (row-major), de-duplicated keys row * n + col of the whole matrix.
+std::vector<uint64_t> erdos_renyi_keys(uint64_t m, uint64_t n, uint64_t draws, uint64_t seed);
+
+// MatrixMarket coordinate reader (general / symmetric; pattern, integer or real); duplicates keep the
+// maximum, as the reference's `maximum<double>()` reduction does (SpmatLocal.hpp:487).  Returns all tuples.
+void read_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std::vector<spcoord_t>& tuples);
+
+}  // namespace hnh

@@ -1,0 +1,86 @@
+#include "sparse_kernels.hpp"
+
+// StandardKernel::sddmm_local — sparse_kernels.cpp:13-57 of the reference:
+//   values[i] += <Arow(row_idx[i]), Brow(col_idx[i])>, with A and B swapped when the block is stored
+//   transposed (:29-37); a null block is a no-op (:25-27); always reports 0 nonzeros (:23,56).
+size_t StandardKernel::sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, int block, int offset) {
+    (void)offset;  // ignored by the reference as well (15D_sparse_shift.hpp:245 TODO)
+    if (A.cols() != B.cols()) hnh::fatal("Error, SDDMM operands must have the same number of columns!");
+    size_t processed = 0;
+    CSRLocal* blk = S.csr_blocks[block];
+    if (blk == nullptr || blk->num_coords == 0) return processed;
+    double* Xptr = blk->transpose ? B.data() : A.data();
+    double* Yptr = blk->transpose ? A.data() : B.data();
+    CSRHandle* active = blk->getActive();
+    hnh::World* w = S.world;
+    begin(w);
+    w->check(w->be->hnh_sddmm_csr(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, Xptr, Yptr,
+                                  (int)A.cols(), HNH_STREAM_COMPUTE),
+             "hnh_sddmm_csr");
+    end(w);
+    return processed;
+}
+
+// StandardKernel::spmm_local — sparse_kernels.cpp:59-127: C += S_blk * X with alpha = beta = 1.
+size_t StandardKernel::spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, MatMode mode, int block) {
+    size_t processed = 0;
+    CSRLocal* blk = S.csr_blocks[block];
+    if (blk == nullptr) return processed;
+    if (mode == Amat && blk->transpose) hnh::fatal("Error, local matrix is transposed, can't perform SpmmA");
+    else if (mode == Bmat && !blk->transpose) hnh::fatal("Error, local matrix is not transposed, can't perform SpmmB");
+    if (blk->num_coords == 0) return processed;
+    CSRHandle* active = blk->getActive();
+    hnh::World* w = S.world;
+    const double* X = (mode == Amat) ? B.data() : A.data();
+    double* Out = (mode == Amat) ? A.data() : B.data();
+    begin(w);
+    w->check(w->be->hnh_spmm_csr(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, X, Out, (int)A.cols(),
+                                 HNH_STREAM_COMPUTE),
+             "hnh_spmm_csr");
+    end(w);
+    return processed;
+}
+
+// One pass for the sddmm/spmm pair of 15D_dense_shift.hpp:203-217 (block not transposed: approach 2).
+size_t StandardKernel::fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, DenseMatrix& Out, int block, unsigned flags) {
+    if (A.cols() != B.cols() || Out.cols() != A.cols()) hnh::fatal("Error, fused operands must have the same number of columns!");
+    CSRLocal* blk = S.csr_blocks[block];
+    if (blk == nullptr) return 0;
+    if (blk->transpose) hnh::fatal("Error, local matrix is transposed, can't perform the fused SDDMM+SpMM");
+    if (blk->num_coords == 0) return 0;
+    CSRHandle* active = blk->getActive();
+    hnh::World* w = S.world;
+    begin(w);
+    w->check(w->be->hnh_fused_sddmm_spmm_csr(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, nullptr,
+                                             A.data(), B.data(), Out.data(), (int)A.cols(), flags, HNH_STREAM_COMPUTE),
+             "hnh_fused_sddmm_spmm_csr");
+    end(w);
+    return 0;
+}
+
+void StandardKernel::begin(hnh::World* w) {
+    if (!profile) return;
+    if (!ev0_) {
+        ev0_ = w->event_create();
+        ev1_ = w->event_create();
+        evw_ = w;
+    }
+    w->event_record(ev0_, HNH_STREAM_COMPUTE);
+}
+
+void StandardKernel::end(hnh::World* w) {
+    if (!profile) return;
+    w->event_record(ev1_, HNH_STREAM_COMPUTE);
+    w->check(w->be->hnh_event_sync(w->ctx, ev1_), "hnh_event_sync");
+    float ms = 0.f;
+    w->check(w->be->hnh_event_elapsed_ms(w->ctx, ev0_, ev1_, &ms), "hnh_event_elapsed_ms");
+    kernel_ms += ms;
+    kernel_launches++;
+}
+
+StandardKernel::~StandardKernel() {
+    if (evw_) {
+        evw_->event_destroy(ev0_);
+        evw_->event_destroy(ev1_);
+    }
+}

@@ -1,0 +1,74 @@
+// Local-kernel plugin point — same surface as the reference's sparse_kernels.h:
+//   class KernelImplementation { virtual sddmm_local, virtual spmm_local, triple_function }  (:15-79)
+//   class StandardKernel : KernelImplementation                                              (:84-99)
+// Every schedule receives a KernelImplementation* and calls it only through triple_function()
+// (15D_dense_shift.hpp:343-349 etc.), so user plugins (README.md:17-18) keep working.  StandardKernel's
+// bodies marshal to the hand-written HIP kernels behind the C ABI of include/hnh_kernels.h.
+//
+// One addition: fused_local(), the back-to-back sddmm/spmm pair that the "local kernel fusion" schedule
+// issues per visiting block (15D_dense_shift.hpp:203-217).  The default implementation is literally that
+// pair of virtual calls; StandardKernel overrides it with the single-pass HIP kernel.
+#pragma once
+#include "common.hpp"
+#include "dense.hpp"
+#include "spmat_local.hpp"
+
+using hnh::DenseMatrix;
+using hnh::VectorXd;
+
+class KernelImplementation {
+public:
+    virtual ~KernelImplementation() {}
+
+    // Performs an operation that looks like a local SDDMM and returns the number of nonzeros processed
+    virtual size_t sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, int block, int offset) = 0;
+
+    // S is m x n, A is m x r, B is n x r.  Amat: A += S B.  Bmat: B += S^T A (block stored transposed).
+    virtual size_t spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, MatMode mode, int block) = 0;
+
+    // values(block) += <A rows, B rows>;  Out += S_block(values) * B        (Out must not alias A or B)
+    // flags: HNH_FUSED_VALUES_OVERWRITE / HNH_FUSED_OUT_OVERWRITE tell the implementation that the block's
+    // values / Out are to be treated as zero on entry, so it may overwrite instead of read-modify-write.
+    // Default: literally the two virtual calls the reference makes (15D_dense_shift.hpp:203-217).
+    virtual size_t fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, DenseMatrix& Out, int block, unsigned flags) {
+        CSRLocal* blk = S.csr_blocks[block];
+        if (blk == nullptr) return 0;
+        if (flags & HNH_FUSED_VALUES_OVERWRITE)
+            S.world->check(S.world->be->hnh_fill_f64(S.world->ctx, blk->getActive()->values, blk->num_coords, 0.0, HNH_STREAM_COMPUTE),
+                           "hnh_fill_f64");
+        if (flags & HNH_FUSED_OUT_OVERWRITE) Out.setZero();
+        size_t n = sddmm_local(S, A, B, block, 0);
+        n += spmm_local(S, Out, B, Amat, block);
+        return n;
+    }
+
+    size_t triple_function(KernelMode mode, SpmatLocal& S, DenseMatrix& localA, DenseMatrix& localB, int block, int offset) {
+        size_t nnz_processed = 0;
+        if (mode == k_sddmmA || mode == k_sddmmB) nnz_processed += sddmm_local(S, localA, localB, block, offset);
+        else if (mode == k_spmmA) nnz_processed += spmm_local(S, localA, localB, Amat, block);
+        else if (mode == k_spmmB) nnz_processed += spmm_local(S, localA, localB, Bmat, block);
+        return nnz_processed;
+    }
+};
+
+// Exactly the algebra on the box (sparse_kernels.h:81-83), on the GPU.
+class StandardKernel : public KernelImplementation {
+public:
+    // Accumulated device time of the kernels launched through this object, measured with HIP events on
+    // the compute stream when profiling is enabled (bench.py's roofline leg).
+    bool profile = false;
+    double kernel_ms = 0.0;
+    long kernel_launches = 0;
+
+    size_t sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, int block, int offset) override;
+    size_t spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, MatMode mode, int block) override;
+    size_t fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, DenseMatrix& Out, int block, unsigned flags) override;
+    ~StandardKernel() override;
+
+private:
+    void* ev0_ = nullptr;
+    void* ev1_ = nullptr;
+    hnh::World* evw_ = nullptr;
+    void begin(hnh::World* w);
+    void end(hnh::World* w);
+};

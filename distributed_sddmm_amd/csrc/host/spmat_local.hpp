@@ -1,0 +1,324 @@
+// Local sparse storage + redistribution — same public surface as the reference's SpmatLocal.hpp (L3):
+//   NonzeroDistribution (SpmatLocal.hpp:34-53), CSRHandle (:55-62), CSRLocal (:64-264), SpmatLocal (:267-606).
+//
+// MI355X layout.  A block's three arrays live in HBM:
+//     values   fp64  [max_nnz]      rowStart int32 [rows + 1]      col_idx int32 [max_nnz]
+// (the reference keeps MKL_INT = int64 indices and an MKL handle per buffer; int32 halves the index
+// stream, and per-rank nnz < 2^31 is already required by the reference's `int` counters, :68).  A COO
+// row_idx array is NOT stored: the HIP kernels walk rowStart, and hnh_expand_rowptr can rebuild it.
+// Blocks that never move (dense-shift schedules) hold ONE buffer; blocks that travel around a ring
+// (sparse-shift / Cannon) hold two, padded to the largest block on their ring, exactly like the
+// reference's `buffer[2]` + `max_nnz` (:153-185).
+//
+// COO -> CSR (the reference: mkl_sparse_d_create_coo + mkl_sparse_convert_csr, :117-137) is a host-side
+// counting sort by row followed by a per-row sort by column; it also rewrites the caller's tuples into
+// CSR order in place (and with r/c swapped when transposing) like :139-147 does.
+#pragma once
+#include <parallel/algorithm>
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "dense.hpp"
+#include "world.hpp"
+
+typedef enum { csr, coo, both } ShiftMode;  // kept for API parity; every mode ships values + col_idx + rowStart
+
+class NonzeroDistribution {
+public:
+    hnh::World* world = nullptr;  // the reference's `MPI_Comm world`
+    int rows_in_block = 1, cols_in_block = 1;
+    virtual ~NonzeroDistribution() {}
+    virtual int blockOwner(int row_block, int col_block) = 0;
+    // processor that is supposed to own nonzero (r, c) (SpmatLocal.hpp:45-52)
+    int getOwner(int r, int c, int transpose) {
+        return transpose ? blockOwner(c / rows_in_block, r / cols_in_block) : blockOwner(r / rows_in_block, c / cols_in_block);
+    }
+};
+
+class CSRHandle {
+public:
+    double* values = nullptr;     // device
+    int32_t* col_idx = nullptr;   // device
+    int32_t* rowStart = nullptr;  // device, rows + 1 entries
+    int32_t* row_idx = nullptr;   // device, built on demand by CSRLocal::ensure_row_idx()
+};
+
+class CSRLocal {
+public:
+    int64_t rows, cols;
+    int max_nnz, num_coords;
+    bool transpose;
+    int active;
+    CSRHandle* buffer;  // [2]; buffer[1] has null arrays when the block never shifts
+    bool shifting;
+    hnh::World* world;
+
+    CSRLocal(int64_t blockRows, int64_t blockCols, int64_t max_nnz_in, spcoord_t* coords, int num_coords_in, bool transpose_in,
+             bool shifting_in = true)
+        : rows(blockRows), cols(blockCols), max_nnz((int)max_nnz_in), num_coords(num_coords_in), transpose(transpose_in),
+          active(0), shifting(shifting_in), world(hnh::current_world()) {
+        if (num_coords > max_nnz) hnh::fatal("Error, block holds more nonzeros than its padded capacity!");
+        if (transpose) {
+            std::swap(rows, cols);
+#pragma omp parallel for
+            for (int e = 0; e < num_coords; e++) std::swap(coords[e].r, coords[e].c);
+        }
+        // counting sort by row, then order each row by column
+        std::vector<int32_t> rowStart((size_t)rows + 1, 0);
+        for (int e = 0; e < num_coords; e++) {
+            if ((int64_t)coords[e].r >= rows || (int64_t)coords[e].c >= cols) hnh::fatal("Error, nonzero outside its block!");
+            rowStart[coords[e].r + 1]++;
+        }
+        for (int64_t r = 0; r < rows; r++) rowStart[r + 1] += rowStart[r];
+        std::vector<spcoord_t> sorted((size_t)num_coords);
+        {
+            std::vector<int32_t> cursor(rowStart.begin(), rowStart.end() - 1);
+            for (int e = 0; e < num_coords; e++) sorted[cursor[coords[e].r]++] = coords[e];
+        }
+#pragma omp parallel for schedule(dynamic, 1024)
+        for (int64_t r = 0; r < rows; r++)
+            std::sort(sorted.begin() + rowStart[r], sorted.begin() + rowStart[r + 1],
+                      [](const spcoord_t& a, const spcoord_t& b) { return a.c < b.c; });
+        std::vector<int32_t> col((size_t)std::max(num_coords, 1));
+        std::vector<double> val((size_t)std::max(num_coords, 1));
+#pragma omp parallel for
+        for (int e = 0; e < num_coords; e++) {
+            coords[e] = sorted[e];  // caller's tuples end up in CSR order (SpmatLocal.hpp:139-147)
+            col[e] = (int32_t)sorted[e].c;
+            val[e] = sorted[e].value;
+        }
+
+        buffer = new CSRHandle[2];
+        const size_t cap = (size_t)std::max(max_nnz, 1);
+        for (int t = 0; t < (shifting ? 2 : 1); t++) {
+            // one allocation per buffer: [values | col_idx | rowStart], each part 256-byte aligned
+            buffer[t].values = static_cast<double*>(world->dmalloc(cap * sizeof(double)));
+            buffer[t].col_idx = static_cast<int32_t*>(world->dmalloc(cap * sizeof(int32_t)));
+            buffer[t].rowStart = static_cast<int32_t*>(world->dmalloc(((size_t)rows + 1) * sizeof(int32_t)));
+            world->copy(buffer[t].values, val.data(), (size_t)num_coords * sizeof(double), HNH_COPY_H2D, HNH_STREAM_COMPUTE);
+            world->copy(buffer[t].col_idx, col.data(), (size_t)num_coords * sizeof(int32_t), HNH_COPY_H2D, HNH_STREAM_COMPUTE);
+            world->copy(buffer[t].rowStart, rowStart.data(), ((size_t)rows + 1) * sizeof(int32_t), HNH_COPY_H2D, HNH_STREAM_COMPUTE);
+        }
+        world->sync(HNH_STREAM_COMPUTE);  // host staging vectors die here
+    }
+
+    ~CSRLocal() {
+        world->sync_all();
+        for (int t = 0; t < 2; t++) {
+            world->dfree(buffer[t].values);
+            world->dfree(buffer[t].col_idx);
+            world->dfree(buffer[t].rowStart);
+            world->dfree(buffer[t].row_idx);
+        }
+        delete[] buffer;
+    }
+    CSRLocal(const CSRLocal&) = delete;
+    CSRLocal& operator=(const CSRLocal&) = delete;
+
+    CSRHandle* getActive() { return buffer + active; }
+
+    // COO row indices of the active buffer (only the COO kernel entry point needs them)
+    int32_t* ensure_row_idx(int stream = HNH_STREAM_COMPUTE) {
+        CSRHandle* h = getActive();
+        if (!h->row_idx) h->row_idx = static_cast<int32_t*>(world->dmalloc((size_t)std::max(max_nnz, 1) * sizeof(int32_t)));
+        world->check(world->be->hnh_expand_rowptr(world->ctx, rows, h->rowStart, h->row_idx, stream), "hnh_expand_rowptr");
+        return h->row_idx;
+    }
+
+    // Cyclic shift of the block around a ring (SpmatLocal.hpp:200-259): the active buffer goes to comm
+    // index `dst`, the block of comm index `src` lands in the passive buffer, then the two swap roles.
+    // Stream-ordered on `stream`; `tag` is unused (explicit peers, no wildcard matching).
+    void shiftCSR(int src, int dst, const hnh::Comm& comm, int nnz_to_receive, int tag, ShiftMode mode,
+                  int stream = HNH_STREAM_COMM) {
+        (void)tag;
+        (void)mode;
+        if (!shifting) hnh::fatal("Error, this sparse block was built without a second buffer and cannot shift!");
+        if (nnz_to_receive > max_nnz) hnh::fatal("Error, incoming sparse block exceeds the padded capacity!");
+        CSRHandle* send = buffer + active;
+        CSRHandle* recv = buffer + 1 - active;
+        world->sendrecv(comm, send->values, (size_t)num_coords * sizeof(double), dst, recv->values,
+                        (size_t)nnz_to_receive * sizeof(double), src, stream);
+        world->sendrecv(comm, send->col_idx, (size_t)num_coords * sizeof(int32_t), dst, recv->col_idx,
+                        (size_t)nnz_to_receive * sizeof(int32_t), src, stream);
+        world->sendrecv(comm, send->rowStart, ((size_t)rows + 1) * sizeof(int32_t), dst, recv->rowStart,
+                        ((size_t)rows + 1) * sizeof(int32_t), src, stream);
+        num_coords = nnz_to_receive;
+        active = 1 - active;
+    }
+};
+
+class SpmatLocal {
+public:
+    std::vector<spcoord_t> coords;  // unzipped tuples (host)
+
+    uint64_t M = 0, N = 0, dist_nnz = 0;  // global properties
+    bool initialized;
+
+    int owned_coords_start = 0, owned_coords_end = 0;
+    std::vector<int> layer_coords_start, layer_coords_sizes;
+    bool coordinate_ownership_initialized;
+    bool csr_initialized;
+
+    std::vector<uint64_t> blockStarts;
+    std::vector<CSRLocal*> csr_blocks;
+    hnh::World* world;
+
+    SpmatLocal() : initialized(false), coordinate_ownership_initialized(false), csr_initialized(false), world(hnh::current_world()) {}
+    ~SpmatLocal() {
+        for (CSRLocal* b : csr_blocks) delete b;
+    }
+    SpmatLocal(const SpmatLocal&) = delete;
+    SpmatLocal& operator=(const SpmatLocal&) = delete;
+
+    // One CSRLocal per non-empty block column (max_nnz == -1; stationary), or a single padded block
+    // that will travel around a ring (SpmatLocal.hpp:314-338).
+    void initializeCSRBlocks(int blockRows, int blockCols, int max_nnz, bool transpose) {
+        if (max_nnz == -1) {
+            for (size_t i = 0; i + 1 < blockStarts.size(); i++) {
+                const int n = (int)(blockStarts[i + 1] - blockStarts[i]);
+                csr_blocks.push_back(n > 0 ? new CSRLocal(blockRows, blockCols, n, coords.data() + blockStarts[i], n, transpose, false)
+                                           : nullptr);
+            }
+        } else {
+            const int n = (int)(blockStarts[1] - blockStarts[0]);
+            csr_blocks.push_back(new CSRLocal(blockRows, blockCols, max_nnz, coords.data(), n, transpose, true));
+        }
+        csr_initialized = true;
+    }
+
+    void own_all_coordinates() {
+        owned_coords_start = 0;
+        owned_coords_end = (int)coords.size();
+        layer_coords_start = {0, (int)coords.size()};
+        layer_coords_sizes = {(int)coords.size()};
+        coordinate_ownership_initialized = true;
+    }
+
+    void shard_across_layers(int num_layers, int current_layer) {
+        divideIntoSegments((int)coords.size(), num_layers, layer_coords_start, layer_coords_sizes);
+        owned_coords_start = layer_coords_start[current_layer];
+        owned_coords_end = layer_coords_start[current_layer + 1];
+        coordinate_ownership_initialized = true;
+    }
+
+    // Routes every tuple to its owner under `dist` (optionally transposing), all-to-all, then sorts the
+    // received tuples column-major (SpmatLocal.hpp:389-462).
+    SpmatLocal* redistribute_nonzeros(NonzeroDistribution* dist, bool transpose, bool in_place) {
+        hnh::World* w = dist->world ? dist->world : world;
+        const int p = w->size;
+        std::vector<size_t> sendcounts(p, 0), recvcounts(p, 0);
+        std::vector<int> owner(coords.size());
+#pragma omp parallel for
+        for (size_t e = 0; e < coords.size(); e++) owner[e] = dist->getOwner((int)coords[e].r, (int)coords[e].c, transpose);
+        for (size_t e = 0; e < coords.size(); e++) {
+            if (owner[e] < 0 || owner[e] >= p) hnh::fatal("Error, nonzero distribution produced an invalid owner!");
+            sendcounts[owner[e]]++;
+        }
+        std::vector<size_t> offsets(p + 1, 0);
+        for (int r = 0; r < p; r++) offsets[r + 1] = offsets[r] + sendcounts[r];
+        std::vector<spcoord_t> sendbuf(coords.size());
+        {
+            std::vector<size_t> cursor(offsets.begin(), offsets.end() - 1);
+            for (size_t e = 0; e < coords.size(); e++) {
+                spcoord_t& t = sendbuf[cursor[owner[e]]++];
+                t.r = transpose ? coords[e].c : coords[e].r;
+                t.c = transpose ? coords[e].r : coords[e].c;
+                t.value = coords[e].value;
+            }
+        }
+        std::vector<size_t> all_counts((size_t)p * p);
+        w->host_allgather(sendcounts.data(), all_counts.data(), (size_t)p * sizeof(size_t));
+        for (int r = 0; r < p; r++) recvcounts[r] = all_counts[(size_t)r * p + w->rank];
+        std::vector<size_t> sb(p), sd(p), rb(p), rd(p);
+        size_t total = 0;
+        for (int r = 0; r < p; r++) {
+            sb[r] = sendcounts[r] * sizeof(spcoord_t);
+            sd[r] = offsets[r] * sizeof(spcoord_t);
+            rb[r] = recvcounts[r] * sizeof(spcoord_t);
+            rd[r] = total * sizeof(spcoord_t);
+            total += recvcounts[r];
+        }
+        const uint64_t newM = transpose ? N : M, newN = transpose ? M : N;
+        std::vector<spcoord_t> received(total);
+        w->host_alltoallv(sendbuf.data(), sb, sd, received.data(), rb, rd);
+
+        SpmatLocal* result = in_place ? this : new SpmatLocal();
+        result->M = newM;
+        result->N = newN;
+        result->dist_nnz = dist_nnz;
+        result->initialized = true;
+        result->coords.swap(received);
+        __gnu_parallel::sort(result->coords.begin(), result->coords.end(), column_major);
+        return result;
+    }
+
+    // Synthetic / file input.  The reference uses CombBLAS (GenGraph500Data with initiator .25 x4 = ER,
+    // ParallelReadMM; SpmatLocal.hpp:467-533).  Ours: a counter-based generator that every rank
+    // evaluates identically (see er_generator.hpp), each rank keeping a strided slice — any initial
+    // distribution is legal because redistribute_nonzeros() follows.
+    void loadTuples(bool readFromFile, int logM, int nnz_per_row, std::string filename);
+
+    // Tuples must be column-major sorted.  Splits them into block columns of `blockWidth` and (optionally)
+    // makes column indices block-local (SpmatLocal.hpp:541-563).
+    void divideIntoBlockCols(int blockWidth, int targetDivisions, bool modIndex) {
+        blockStarts.clear();
+        uint64_t currentStart = 0;
+        for (uint64_t i = 0; i < coords.size(); i++) {
+            while (coords[i].c >= currentStart) {
+                blockStarts.push_back(i);
+                currentStart += (uint64_t)blockWidth;
+            }
+            if (modIndex) coords[i].c %= (uint64_t)blockWidth;
+        }
+        if (blockStarts.size() > (size_t)targetDivisions + 1) hnh::fatal("Error, more block columns than expected!");
+        while (blockStarts.size() < (size_t)targetDivisions + 1) blockStarts.push_back(coords.size());
+    }
+
+    void monolithBlockColumn() {
+        blockStarts.clear();
+        blockStarts.push_back(0);
+        blockStarts.push_back(coords.size());
+    }
+
+    // values <-> per-block storage (SpmatLocal.hpp:571-605); device-to-device on the compute stream
+    void setCSRValues(const hnh::VectorXd& values) {
+        for (size_t i = 0; i + 1 < blockStarts.size(); i++)
+            if (csr_blocks[i] != nullptr)
+                world->copy(csr_blocks[i]->getActive()->values, values.data() + blockStarts[i],
+                            sizeof(double) * (blockStarts[i + 1] - blockStarts[i]), HNH_COPY_D2D, HNH_STREAM_COMPUTE);
+    }
+
+    hnh::VectorXd getCSRValues() {
+        hnh::VectorXd values = hnh::VectorXd::Constant((int64_t)blockStarts.back(), 0.0);
+        for (size_t i = 0; i + 1 < blockStarts.size(); i++)
+            if (csr_blocks[i] != nullptr)
+                world->copy(values.data() + blockStarts[i], csr_blocks[i]->getActive()->values,
+                            sizeof(double) * (blockStarts[i + 1] - blockStarts[i]), HNH_COPY_D2D, HNH_STREAM_COMPUTE);
+        return values;
+    }
+
+    void setValuesConstant(double cval) {
+        for (size_t i = 0; i + 1 < blockStarts.size(); i++)
+            if (csr_blocks[i] != nullptr)
+                world->check(world->be->hnh_fill_f64(world->ctx, csr_blocks[i]->getActive()->values,
+                                                     (int64_t)(blockStarts[i + 1] - blockStarts[i]), cval, HNH_STREAM_COMPUTE),
+                             "hnh_fill_f64");
+    }
+
+    // out[e] = svalues[e] * (block values)[e] — the Hadamard step that ends every SDDMM
+    // (`SValues.cwiseProduct(choice->getCSRValues())`, 15D_dense_shift.hpp:366) without the temporary.
+    void hadamardWithCSRValues(const hnh::VectorXd& svalues, hnh::VectorXd& out, int64_t out_offset = 0) {
+        for (size_t i = 0; i + 1 < blockStarts.size(); i++)
+            if (csr_blocks[i] != nullptr && blockStarts[i + 1] > blockStarts[i])
+                world->check(world->be->hnh_hadamard_f64(world->ctx, out.data() + out_offset + blockStarts[i],
+                                                         svalues.data() + out_offset + blockStarts[i],
+                                                         csr_blocks[i]->getActive()->values,
+                                                         (int64_t)(blockStarts[i + 1] - blockStarts[i]), HNH_STREAM_COMPUTE),
+                             "hnh_hadamard_f64");
+    }
+};

@@ -1,0 +1,548 @@
+#include "world.hpp"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+
+namespace hnh {
+
+// ------------------------------------------------------------------------------------------------ errors
+namespace {
+bool g_throw = false;
+}
+void set_throw_on_error(bool on) { g_throw = on; }
+
+void fatal(const std::string& msg) {
+    std::cout << msg << std::endl;  // the reference reports configuration errors on cout
+    if (g_throw) throw Error(msg);
+    std::exit(1);
+}
+
+// ------------------------------------------------------------------------------------------------ backend
+namespace {
+std::mutex g_backend_mu;
+std::map<std::string, Backend*> g_backends;
+Backend* g_default = nullptr;
+
+std::string dir_of_this_library() {
+    Dl_info info;
+    if (dladdr((void*)&dir_of_this_library, &info) && info.dli_fname) {
+        std::string p(info.dli_fname);
+        size_t slash = p.find_last_of('/');
+        if (slash != std::string::npos) return p.substr(0, slash);
+    }
+    return ".";
+}
+}  // namespace
+
+std::string default_backend_path() { return dir_of_this_library() + "/libhnh_kernels.so"; }
+
+Backend* load_backend(const char* path_c) {
+    std::lock_guard<std::mutex> lk(g_backend_mu);
+    std::string path = (path_c && *path_c) ? std::string(path_c) : default_backend_path();
+    auto it = g_backends.find(path);
+    if (it != g_backends.end()) {
+        g_default = it->second;
+        return it->second;
+    }
+    void* dl = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!dl) fatal(std::string("Error, cannot load the kernel library ") + path + ": " + dlerror() +
+                   " (there is no CPU fallback; build it with __graft_entry__.build())");
+    Backend* b = new Backend();
+    b->dl = dl;
+    b->path = path;
+#define HNH_BIND(sym)                                                                  \
+    b->sym = (decltype(b->sym))dlsym(dl, #sym);                                        \
+    if (!b->sym) fatal(std::string("Error, kernel library ") + path + " lacks symbol " #sym);
+    HNH_BIND(hnh_backend_name)
+    HNH_BIND(hnh_ctx_create) HNH_BIND(hnh_ctx_destroy) HNH_BIND(hnh_last_error) HNH_BIND(hnh_ctx_stream)
+    HNH_BIND(hnh_malloc) HNH_BIND(hnh_free) HNH_BIND(hnh_memcpy) HNH_BIND(hnh_memset) HNH_BIND(hnh_stream_sync)
+    HNH_BIND(hnh_event_create) HNH_BIND(hnh_event_destroy) HNH_BIND(hnh_event_record) HNH_BIND(hnh_event_wait)
+    HNH_BIND(hnh_event_sync) HNH_BIND(hnh_event_elapsed_ms)
+    HNH_BIND(hnh_sddmm_coo) HNH_BIND(hnh_sddmm_csr) HNH_BIND(hnh_spmm_csr) HNH_BIND(hnh_fused_sddmm_spmm_csr)
+    HNH_BIND(hnh_fill_f64) HNH_BIND(hnh_hadamard_f64) HNH_BIND(hnh_axpy_f64) HNH_BIND(hnh_expand_rowptr)
+    HNH_BIND(hnh_comm_unique_id) HNH_BIND(hnh_comm_init) HNH_BIND(hnh_comm_split) HNH_BIND(hnh_comm_destroy)
+    HNH_BIND(hnh_comm_sendrecv) HNH_BIND(hnh_comm_allgather) HNH_BIND(hnh_comm_reduce_scatter_f64)
+    HNH_BIND(hnh_comm_allreduce_f64)
+#undef HNH_BIND
+    b->name = b->hnh_backend_name();
+    g_backends[path] = b;
+    g_default = b;
+    return b;
+}
+
+Backend* default_backend() {
+    {
+        std::lock_guard<std::mutex> lk(g_backend_mu);
+        if (g_default) return g_default;
+    }
+    return load_backend(nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------ World base
+namespace {
+thread_local World* t_world = nullptr;
+}
+World* current_world() {
+    if (!t_world) fatal("Error, no current world: create one and call hnh::set_current_world() first");
+    return t_world;
+}
+World* current_world_or_null() { return t_world; }
+void set_current_world(World* w) { t_world = w; }
+
+World::~World() {}
+
+void World::init_device(Backend* backend, int device_ordinal) {
+    be = backend ? backend : default_backend();
+    device = device_ordinal;
+    int st = be->hnh_ctx_create(device_ordinal, &ctx);
+    if (st != HNH_OK || !ctx)
+        fatal("Error, cannot create a device context on device " + std::to_string(device_ordinal) + " with backend " +
+              be->name + " (status " + std::to_string(st) + "): no GPU? There is no CPU fallback.");
+}
+
+void World::destroy_device() {
+    if (ctx) {
+        for (auto& s : scratch_)
+            if (s.first) be->hnh_free(ctx, s.first);
+        scratch_.clear();
+        be->hnh_ctx_destroy(ctx);
+        ctx = nullptr;
+    }
+}
+
+void World::check(int status, const char* what) const {
+    if (status != HNH_OK)
+        fatal(std::string("Error in ") + what + " (status " + std::to_string(status) + "): " + be->hnh_last_error(ctx));
+}
+
+void* World::dmalloc(size_t bytes) {
+    void* p = nullptr;
+    check(be->hnh_malloc(ctx, bytes, &p), "hnh_malloc");
+    return p;
+}
+void World::dfree(void* p) {
+    if (p) check(be->hnh_free(ctx, p), "hnh_free");
+}
+void World::copy(void* dst, const void* src, size_t bytes, int kind, int stream) {
+    if (bytes) check(be->hnh_memcpy(ctx, dst, src, bytes, kind, stream), "hnh_memcpy");
+}
+void World::memset0(void* dst, size_t bytes, int stream) {
+    if (bytes) check(be->hnh_memset(ctx, dst, 0, bytes, stream), "hnh_memset");
+}
+void World::sync(int stream) { check(be->hnh_stream_sync(ctx, stream), "hnh_stream_sync"); }
+void World::sync_all() {
+    sync(HNH_STREAM_COMPUTE);
+    sync(HNH_STREAM_COMM);
+}
+void* World::event_create() {
+    void* e = nullptr;
+    check(be->hnh_event_create(ctx, &e), "hnh_event_create");
+    return e;
+}
+void World::event_destroy(void* e) {
+    if (e) check(be->hnh_event_destroy(ctx, e), "hnh_event_destroy");
+}
+void World::event_record(void* e, int stream) { check(be->hnh_event_record(ctx, e, stream), "hnh_event_record"); }
+void World::event_wait(void* e, int stream) { check(be->hnh_event_wait(ctx, e, stream), "hnh_event_wait"); }
+
+void* World::scratch(int slot, size_t bytes) {
+    if ((int)scratch_.size() <= slot) scratch_.resize(slot + 1, {nullptr, 0});
+    auto& s = scratch_[slot];
+    if (s.second < bytes) {
+        if (s.first) {
+            sync_all();
+            dfree(s.first);
+        }
+        s.first = dmalloc(bytes);
+        s.second = bytes;
+    }
+    return s.first;
+}
+
+Comm World::world_comm() {
+    Comm c;
+    c.ranks.resize(size);
+    for (int i = 0; i < size; i++) c.ranks[i] = i;
+    c.me = rank;
+    return c;
+}
+
+Comm World::split(int color, int key) {
+    // collective: gather (color, key) of every rank, keep my colour, order by (key, world rank)
+    std::vector<int> mine = {color, key}, all(2 * (size_t)size);
+    host_allgather(mine.data(), all.data(), 2 * sizeof(int));
+    std::vector<std::pair<int, int>> members;  // (key, world rank)
+    for (int r = 0; r < size; r++)
+        if (all[2 * r] == color) members.push_back({all[2 * r + 1], r});
+    std::sort(members.begin(), members.end());
+    Comm c;
+    for (size_t i = 0; i < members.size(); i++) {
+        c.ranks.push_back(members[i].second);
+        if (members[i].second == rank) c.me = (int)i;
+    }
+    return c;
+}
+
+void World::free_comm(Comm& c) { c.native = nullptr; }
+
+// Default collectives: (n - 1) rounds of pairwise exchange; round k pairs me -> me + k, me - k -> me.
+void World::allgather(const Comm& comm, const void* sendbuf, void* recvbuf, size_t bytes, int stream) {
+    const int n = comm.size(), me = comm.me;
+    char* out = static_cast<char*>(recvbuf);
+    if (out + (size_t)me * bytes != sendbuf) copy(out + (size_t)me * bytes, sendbuf, bytes, HNH_COPY_D2D, stream);
+    for (int k = 1; k < n; k++) {
+        const int dst = (me + k) % n, src = (me - k + n) % n;
+        sendrecv(comm, out + (size_t)me * bytes, bytes, dst, out + (size_t)src * bytes, bytes, src, stream);
+    }
+}
+
+void World::allgatherv_f64(const Comm& comm, const double* sendbuf, size_t sendcount, double* recvbuf,
+                           const std::vector<int>& counts, const std::vector<int>& displs, int stream) {
+    const int n = comm.size(), me = comm.me;
+    if ((size_t)counts[me] != sendcount) fatal("Error, allgatherv: send count does not match counts[me]");
+    if (recvbuf + displs[me] != sendbuf) copy(recvbuf + displs[me], sendbuf, sendcount * sizeof(double), HNH_COPY_D2D, stream);
+    for (int k = 1; k < n; k++) {
+        const int dst = (me + k) % n, src = (me - k + n) % n;
+        sendrecv(comm, recvbuf + displs[me], sendcount * sizeof(double), dst, recvbuf + displs[src],
+                 (size_t)counts[src] * sizeof(double), src, stream);
+    }
+}
+
+void World::reduce_scatter_v_f64(const Comm& comm, const double* sendbuf, double* recvbuf, const std::vector<int>& counts,
+                                 int stream) {
+    const int n = comm.size(), me = comm.me;
+    std::vector<size_t> displ(n + 1, 0);
+    for (int i = 0; i < n; i++) displ[i + 1] = displ[i] + (size_t)counts[i];
+    const size_t mycount = (size_t)counts[me];
+    copy(recvbuf, sendbuf + displ[me], mycount * sizeof(double), HNH_COPY_D2D, stream);
+    if (n == 1) return;
+    double* tmp = static_cast<double*>(scratch(0, std::max<size_t>(mycount, 1) * sizeof(double)));
+    for (int k = 1; k < n; k++) {
+        const int dst = (me + k) % n, src = (me - k + n) % n;
+        sendrecv(comm, sendbuf + displ[dst], (size_t)counts[dst] * sizeof(double), dst, tmp, mycount * sizeof(double), src, stream);
+        if (mycount) check(be->hnh_axpy_f64(ctx, recvbuf, tmp, 1.0, (int64_t)mycount, stream), "hnh_axpy_f64");
+    }
+}
+
+void World::reduce_scatter_f64(const Comm& comm, const double* sendbuf, double* recvbuf, size_t count, int stream) {
+    std::vector<int> counts(comm.size(), (int)count);
+    reduce_scatter_v_f64(comm, sendbuf, recvbuf, counts, stream);
+}
+
+void World::host_allgather_comm(const Comm& comm, const void* send, void* recv, size_t bytes) {
+    // tiny payloads only (nnz counts): gather over the world, keep the members
+    std::vector<char> all((size_t)size * bytes);
+    host_allgather(send, all.data(), bytes);
+    for (int i = 0; i < comm.size(); i++)
+        std::memcpy(static_cast<char*>(recv) + (size_t)i * bytes, all.data() + (size_t)comm.ranks[i] * bytes, bytes);
+}
+
+void World::host_bcast(const Comm& comm, int root, void* buf, size_t bytes) {
+    // generic: route through alltoallv (the root sends a copy to every other member)
+    std::vector<size_t> sb(size, 0), sd(size, 0), rb(size, 0), rd(size, 0);
+    const bool is_root = (comm.me == root);
+    if (is_root) {
+        for (int i = 0; i < comm.size(); i++)
+            if (i != root) sb[comm.ranks[i]] = bytes;  // all read the same source bytes (displ 0)
+    } else {
+        rb[comm.ranks[root]] = bytes;
+    }
+    std::vector<char> tmp(is_root ? 0 : bytes);
+    host_alltoallv(buf, sb, sd, is_root ? nullptr : tmp.data(), rb, rd);
+    if (!is_root && bytes) std::memcpy(buf, tmp.data(), bytes);
+}
+
+double World::host_allreduce_sum(double v) {
+    host_allreduce_sum(&v, 1);
+    return v;
+}
+
+void World::host_allreduce_sum(double* v, size_t n) {
+    std::vector<double> all((size_t)size * n);
+    host_allgather(v, all.data(), n * sizeof(double));
+    for (size_t j = 0; j < n; j++) {
+        double s = 0.0;
+        for (int r = 0; r < size; r++) s += all[(size_t)r * n + j];
+        v[j] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ SingleWorld
+SingleWorld::SingleWorld(Backend* backend, int device_ordinal) {
+    rank = 0;
+    size = 1;
+    init_device(backend, device_ordinal);
+}
+SingleWorld::~SingleWorld() { destroy_device(); }
+
+void SingleWorld::sendrecv(const Comm&, const void* sendbuf, size_t sendbytes, int, void* recvbuf, size_t recvbytes, int,
+                           int stream) {
+    if (sendbytes != recvbytes) fatal("Error, self send/recv size mismatch");
+    if (sendbuf != recvbuf) copy(recvbuf, sendbuf, sendbytes, HNH_COPY_D2D, stream);
+}
+void SingleWorld::host_allgather(const void* send, void* recv, size_t bytes) { std::memcpy(recv, send, bytes); }
+void SingleWorld::host_alltoallv(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl,
+                                 void* recv, const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl) {
+    if (sendbytes[0] != recvbytes[0]) fatal("Error, alltoallv size mismatch");
+    if (sendbytes[0]) std::memcpy(static_cast<char*>(recv) + recvdispl[0], static_cast<const char*>(send) + senddispl[0], sendbytes[0]);
+}
+
+// ------------------------------------------------------------------------------------------------ ThreadWorld
+struct ThreadGroup {
+    int n = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    // barrier
+    int arrived = 0;
+    uint64_t generation = 0;
+    // pointer publication
+    std::vector<const void*> slots;
+    // point-to-point mailboxes, index src * n + dst
+    struct Msg {
+        const void* ptr = nullptr;
+        size_t bytes = 0;
+        void* ready = nullptr;  // sender's event: data valid
+        void* done = nullptr;   // receiver's event: copy finished
+        bool completed = false;
+    };
+    std::vector<std::deque<Msg*>> box;
+};
+
+std::shared_ptr<ThreadGroup> make_thread_group(int nranks) {
+    auto g = std::make_shared<ThreadGroup>();
+    g->n = nranks;
+    g->slots.assign(nranks, nullptr);
+    g->box.resize((size_t)nranks * nranks);
+    return g;
+}
+
+ThreadWorld::ThreadWorld(std::shared_ptr<ThreadGroup> group, int rank_in_group, Backend* backend, int device_ordinal)
+    : g_(std::move(group)) {
+    rank = rank_in_group;
+    size = g_->n;
+    init_device(backend, device_ordinal);
+}
+ThreadWorld::~ThreadWorld() { destroy_device(); }
+
+void ThreadWorld::barrier() {
+    std::unique_lock<std::mutex> lk(g_->mu);
+    const uint64_t gen = g_->generation;
+    if (++g_->arrived == g_->n) {
+        g_->arrived = 0;
+        g_->generation++;
+        g_->cv.notify_all();
+    } else {
+        g_->cv.wait(lk, [&] { return g_->generation != gen; });
+    }
+}
+
+std::vector<const void*> ThreadWorld::publish(const void* mine) {
+    {
+        std::lock_guard<std::mutex> lk(g_->mu);
+        g_->slots[rank] = mine;
+    }
+    barrier();
+    return g_->slots;  // copy; peers' data stays valid until release()
+}
+void ThreadWorld::release() { barrier(); }
+
+void ThreadWorld::host_allgather(const void* send, void* recv, size_t bytes) {
+    auto all = publish(send);
+    for (int r = 0; r < size; r++) std::memcpy(static_cast<char*>(recv) + (size_t)r * bytes, all[r], bytes);
+    release();
+}
+
+void ThreadWorld::host_alltoallv(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl,
+                                 void* recv, const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl) {
+    struct Desc { const void* base; const size_t* bytes; const size_t* displ; } mine{send, sendbytes.data(), senddispl.data()};
+    auto all = publish(&mine);
+    for (int r = 0; r < size; r++) {
+        const Desc* d = static_cast<const Desc*>(all[r]);
+        if (d->bytes[rank] != recvbytes[r]) fatal("Error, alltoallv size mismatch between ranks");
+        if (recvbytes[r])
+            std::memcpy(static_cast<char*>(recv) + recvdispl[r], static_cast<const char*>(d->base) + d->displ[rank], recvbytes[r]);
+    }
+    release();
+}
+
+void ThreadWorld::sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst_idx, void* recvbuf, size_t recvbytes,
+                           int src_idx, int stream) {
+    const int n = g_->n;
+    ThreadGroup::Msg* out = nullptr;
+    if (sendbytes) {
+        const int dst = comm.ranks[dst_idx];
+        out = new ThreadGroup::Msg();
+        out->ptr = sendbuf;
+        out->bytes = sendbytes;
+        out->ready = event_create();
+        event_record(out->ready, stream);  // everything enqueued so far on `stream` produced sendbuf
+        std::lock_guard<std::mutex> lk(g_->mu);
+        g_->box[(size_t)rank * n + dst].push_back(out);
+        g_->cv.notify_all();
+    }
+    if (recvbytes) {
+        const int src = comm.ranks[src_idx];
+        ThreadGroup::Msg* in = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(g_->mu);
+            auto& q = g_->box[(size_t)src * n + rank];
+            g_->cv.wait(lk, [&] { return !q.empty(); });
+            in = q.front();
+            q.pop_front();
+        }
+        if (in->bytes != recvbytes) fatal("Error, send/recv size mismatch between ranks");
+        event_wait(in->ready, stream);
+        copy(recvbuf, in->ptr, recvbytes, HNH_COPY_D2D, stream);
+        void* done = event_create();
+        event_record(done, stream);
+        {
+            std::lock_guard<std::mutex> lk(g_->mu);
+            in->done = done;
+            in->completed = true;
+            g_->cv.notify_all();
+        }
+    }
+    if (out) {
+        {
+            std::unique_lock<std::mutex> lk(g_->mu);
+            g_->cv.wait(lk, [&] { return out->completed; });
+        }
+        event_wait(out->done, stream);  // do not let later work on `stream` overwrite sendbuf before the peer's copy ran
+        event_destroy(out->done);
+        event_destroy(out->ready);
+        delete out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ RcclWorld
+RcclWorld::RcclWorld(int r, int nranks, Backend* backend, int device_ordinal, const void* unique_id) {
+    rank = r;
+    size = nranks;
+    init_device(backend, device_ordinal);
+    check(be->hnh_comm_init(ctx, nranks, r, unique_id, &comm_), "hnh_comm_init");
+}
+RcclWorld::~RcclWorld() {
+    if (ctx) {
+        sync_all();
+        if (comm_) be->hnh_comm_destroy(ctx, comm_);
+    }
+    destroy_device();
+}
+
+Comm RcclWorld::split(int color, int key) {
+    Comm c = World::split(color, key);
+    check(be->hnh_comm_split(ctx, comm_, color, key, &c.native), "hnh_comm_split");
+    return c;
+}
+void RcclWorld::free_comm(Comm& c) {
+    if (c.native) {
+        sync_all();
+        be->hnh_comm_destroy(ctx, c.native);
+        c.native = nullptr;
+    }
+}
+
+void RcclWorld::sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes,
+                         int src, int stream) {
+    // point-to-point always goes through the world communicator with world ranks: explicit peers
+    check(be->hnh_comm_sendrecv(ctx, comm_, sendbuf, sendbytes, comm.ranks[dst], recvbuf, recvbytes, comm.ranks[src], stream),
+          "hnh_comm_sendrecv");
+}
+void RcclWorld::allgather(const Comm& comm, const void* sendbuf, void* recvbuf, size_t bytes, int stream) {
+    if (comm.size() == 1) {
+        if (sendbuf != recvbuf) copy(recvbuf, sendbuf, bytes, HNH_COPY_D2D, stream);
+        return;
+    }
+    check(be->hnh_comm_allgather(ctx, native_for(comm), sendbuf, recvbuf, bytes, stream), "hnh_comm_allgather");
+}
+void RcclWorld::reduce_scatter_f64(const Comm& comm, const double* sendbuf, double* recvbuf, size_t count, int stream) {
+    if (comm.size() == 1) {
+        copy(recvbuf, sendbuf, count * sizeof(double), HNH_COPY_D2D, stream);
+        return;
+    }
+    check(be->hnh_comm_reduce_scatter_f64(ctx, native_for(comm), sendbuf, recvbuf, count, stream), "hnh_comm_reduce_scatter_f64");
+}
+
+void RcclWorld::barrier() {
+    double* d = static_cast<double*>(scratch(1, sizeof(double)));
+    check(be->hnh_comm_allreduce_f64(ctx, comm_, d, d, 1, HNH_STREAM_COMM), "hnh_comm_allreduce_f64");
+    sync(HNH_STREAM_COMM);
+}
+
+void RcclWorld::host_allgather(const void* send, void* recv, size_t bytes) {
+    // host data is staged through device memory (setup path only)
+    char* d = static_cast<char*>(scratch(1, std::max<size_t>((size_t)size * bytes, 16)));
+    copy(d + (size_t)rank * bytes, send, bytes, HNH_COPY_H2D, HNH_STREAM_COMM);
+    check(be->hnh_comm_allgather(ctx, comm_, d + (size_t)rank * bytes, d, bytes, HNH_STREAM_COMM), "hnh_comm_allgather");
+    copy(recv, d, (size_t)size * bytes, HNH_COPY_D2H, HNH_STREAM_COMM);
+    sync(HNH_STREAM_COMM);
+}
+
+void RcclWorld::host_alltoallv(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl,
+                               void* recv, const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl) {
+    size_t stot = 0, rtot = 0;
+    for (int r = 0; r < size; r++) {
+        stot = std::max(stot, senddispl[r] + sendbytes[r]);
+        rtot = std::max(rtot, recvdispl[r] + recvbytes[r]);
+    }
+    char* ds = static_cast<char*>(dmalloc(std::max<size_t>(stot, 16)));
+    char* dr = static_cast<char*>(dmalloc(std::max<size_t>(rtot, 16)));
+    copy(ds, send, stot, HNH_COPY_H2D, HNH_STREAM_COMM);
+    Comm w = world_comm();
+    for (int k = 0; k < size; k++) {  // round k: send to me + k, receive from me - k
+        const int dst = (rank + k) % size, src = (rank - k + size) % size;
+        if (k == 0) {
+            copy(dr + recvdispl[rank], ds + senddispl[rank], sendbytes[rank], HNH_COPY_D2D, HNH_STREAM_COMM);
+        } else {
+            sendrecv(w, ds + senddispl[dst], sendbytes[dst], dst, dr + recvdispl[src], recvbytes[src], src, HNH_STREAM_COMM);
+        }
+    }
+    if (rtot) copy(recv, dr, rtot, HNH_COPY_D2H, HNH_STREAM_COMM);
+    sync(HNH_STREAM_COMM);
+    dfree(ds);
+    dfree(dr);
+}
+
+// ------------------------------------------------------------------------------------------------ CallbackWorld
+CallbackWorld::CallbackWorld(int r, int nranks, Backend* backend, int device_ordinal, const hnh_comm_callbacks& cb) : cb_(cb) {
+    rank = r;
+    size = nranks;
+    if (!cb_.sendrecv || !cb_.barrier || !cb_.allgather) fatal("Error, callback transport needs sendrecv, barrier and allgather");
+    init_device(backend, device_ordinal);
+}
+CallbackWorld::~CallbackWorld() { destroy_device(); }
+
+void CallbackWorld::sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes,
+                             int src, int stream) {
+    sync(stream);  // the callback moves data now: everything that produced sendbuf must have finished
+    if (cb_.sendrecv(cb_.user, sendbuf, sendbytes, comm.ranks[dst], recvbuf, recvbytes, comm.ranks[src]) != 0)
+        fatal("Error, callback sendrecv failed");
+}
+void CallbackWorld::barrier() {
+    if (cb_.barrier(cb_.user) != 0) fatal("Error, callback barrier failed");
+}
+void CallbackWorld::host_allgather(const void* send, void* recv, size_t bytes) {
+    if (cb_.allgather(cb_.user, send, recv, bytes) != 0) fatal("Error, callback allgather failed");
+}
+void CallbackWorld::host_alltoallv(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl,
+                                   void* recv, const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl) {
+    // host buffers: pairwise rounds straight through the callback (it is given host pointers here)
+    for (int k = 0; k < size; k++) {
+        const int dst = (rank + k) % size, src = (rank - k + size) % size;
+        const char* s = static_cast<const char*>(send) + senddispl[dst];
+        char* r = static_cast<char*>(recv) + recvdispl[src];
+        if (k == 0) {
+            if (sendbytes[rank]) std::memcpy(r, s, sendbytes[rank]);
+        } else if (cb_.sendrecv(cb_.user, s, sendbytes[dst], dst, r, recvbytes[src], src) != 0) {
+            fatal("Error, callback sendrecv failed");
+        }
+    }
+}
+
+}  // namespace hnh

@@ -1,0 +1,176 @@
+// Process-group abstraction that replaces MPI in the reference.
+//
+// One `World` per rank.  A rank is either a process that owns a GPU (RcclWorld: RCCL over xGMI, one
+// process per GPU, the production path), a host thread sharing one GPU with its peers (ThreadWorld:
+// "loopback", device-to-device copies on the communication stream — lets every shift schedule be
+// verified on the single GPU a test box has), or a process whose transport is supplied through
+// callbacks (CallbackWorld: used with torch.distributed/gloo in the CPU tests).
+//
+// Device-buffer operations are STREAM-ORDERED like RCCL: they are enqueued on the selected stream of the
+// rank's hnh_ctx; when the work previously enqueued on that stream has completed, `recvbuf` holds the
+// data and `sendbuf` may be reused.  Host operations block.
+//
+// `hnh::current_world()` is the thread-local analogue of MPI_COMM_WORLD: the reference's classes call
+// MPI_Comm_rank(MPI_COMM_WORLD, ...) in their constructors (distributed_sparse.h:81-82); ours read the
+// current world instead, which keeps the constructor signatures identical.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+#include "backend.hpp"
+#include "hnh_dist.h"
+#include "common.hpp"
+
+namespace hnh {
+
+// An ordered subset of world ranks (MPI_Comm analogue).  `me` is this rank's index, -1 if not a member.
+struct Comm {
+    std::vector<int> ranks;
+    int me = -1;
+    void* native = nullptr;  // RCCL sub-communicator when the world is an RcclWorld
+    int size() const { return (int)ranks.size(); }
+    int rank() const { return me; }
+};
+
+class World {
+public:
+    int rank = 0, size = 1;
+    Backend* be = nullptr;
+    hnh_ctx* ctx = nullptr;
+    int device = 0;
+    bool timing_sync = false;  // when true perf counters synchronise the streams first (reference-like attribution)
+
+    virtual ~World();
+    virtual const char* kind() const = 0;
+
+    // ---- communicators
+    Comm world_comm();
+    virtual Comm split(int color, int key);  // MPI_Comm_split semantics (FlexibleGrid.hpp:80-88)
+    virtual void free_comm(Comm& c);
+
+    // ---- device buffers, stream-ordered.  dst / src are indices INTO `comm`.
+    virtual void sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf,
+                          size_t recvbytes, int src, int stream) = 0;
+    virtual void allgather(const Comm& comm, const void* sendbuf, void* recvbuf, size_t bytes_per_rank, int stream);
+    virtual void reduce_scatter_f64(const Comm& comm, const double* sendbuf, double* recvbuf, size_t count, int stream);
+    // variable counts (25D_cannon_sparse.hpp:224-233,294-300); counts / displs in elements, per comm index
+    virtual void allgatherv_f64(const Comm& comm, const double* sendbuf, size_t sendcount, double* recvbuf,
+                                const std::vector<int>& counts, const std::vector<int>& displs, int stream);
+    virtual void reduce_scatter_v_f64(const Comm& comm, const double* sendbuf, double* recvbuf,
+                                      const std::vector<int>& counts, int stream);
+
+    // ---- host data, blocking, collective over the whole world unless a Comm is given
+    virtual void barrier() = 0;
+    virtual void host_allgather(const void* send, void* recv, size_t bytes_per_rank) = 0;
+    virtual void host_alltoallv(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl,
+                                void* recv, const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl) = 0;
+    virtual void host_bcast(const Comm& comm, int root, void* buf, size_t bytes);
+    void host_allgather_comm(const Comm& comm, const void* send, void* recv, size_t bytes_per_rank);
+    double host_allreduce_sum(double v);
+    void host_allreduce_sum(double* v, size_t n);
+
+    // ---- conveniences over the backend (status -> fatal)
+    void check(int status, const char* what) const;
+    void* dmalloc(size_t bytes);
+    void dfree(void* p);
+    void copy(void* dst, const void* src, size_t bytes, int kind, int stream);
+    void memset0(void* dst, size_t bytes, int stream);
+    void sync(int stream);
+    void sync_all();
+    void* event_create();
+    void event_destroy(void* e);
+    void event_record(void* e, int stream);
+    void event_wait(void* e, int stream);
+    // scratch that persists across calls (grown on demand), one per slot
+    void* scratch(int slot, size_t bytes);
+
+protected:
+    void init_device(Backend* backend, int device_ordinal);
+    void destroy_device();
+    std::vector<std::pair<void*, size_t>> scratch_;
+};
+
+World* current_world();
+World* current_world_or_null();
+void set_current_world(World* w);
+
+// ---- p = 1
+class SingleWorld : public World {
+public:
+    SingleWorld(Backend* backend, int device_ordinal);
+    ~SingleWorld() override;
+    const char* kind() const override { return "single"; }
+    void sendrecv(const Comm&, const void*, size_t, int, void*, size_t, int, int) override;
+    void barrier() override {}
+    void host_allgather(const void* send, void* recv, size_t bytes) override;
+    void host_alltoallv(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl, void* recv,
+                        const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl) override;
+};
+
+// ---- N logical ranks = N host threads on one device ("loopback" transport)
+struct ThreadGroup;
+std::shared_ptr<ThreadGroup> make_thread_group(int nranks);
+
+class ThreadWorld : public World {
+public:
+    ThreadWorld(std::shared_ptr<ThreadGroup> group, int rank_in_group, Backend* backend, int device_ordinal);
+    ~ThreadWorld() override;
+    const char* kind() const override { return "thread-loopback"; }
+    void sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes,
+                  int src, int stream) override;
+    void barrier() override;
+    void host_allgather(const void* send, void* recv, size_t bytes) override;
+    void host_alltoallv(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl, void* recv,
+                        const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl) override;
+
+private:
+    std::shared_ptr<ThreadGroup> g_;
+    std::vector<const void*> publish(const void* mine);  // all ranks' pointers, valid until release()
+    void release();
+};
+
+// ---- one process per GPU, RCCL over xGMI
+class RcclWorld : public World {
+public:
+    RcclWorld(int rank, int nranks, Backend* backend, int device_ordinal, const void* unique_id);
+    ~RcclWorld() override;
+    const char* kind() const override { return "rccl"; }
+    Comm split(int color, int key) override;
+    void free_comm(Comm& c) override;
+    void sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes,
+                  int src, int stream) override;
+    void allgather(const Comm& comm, const void* sendbuf, void* recvbuf, size_t bytes_per_rank, int stream) override;
+    void reduce_scatter_f64(const Comm& comm, const double* sendbuf, double* recvbuf, size_t count, int stream) override;
+    void barrier() override;
+    void host_allgather(const void* send, void* recv, size_t bytes) override;
+    void host_alltoallv(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl, void* recv,
+                        const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl) override;
+
+private:
+    void* comm_ = nullptr;  // world communicator
+    void* native_for(const Comm& comm) const { return comm.native ? comm.native : comm_; }
+    bool is_world(const Comm& comm) const { return comm.native == nullptr; }
+};
+
+// ---- transport supplied by the embedding program (torch.distributed / gloo in tests, MPI, ...).
+// All buffers handed to the callbacks are pointers in the backend's memory space.
+// (struct hnh_comm_callbacks is declared in include/hnh_dist.h)
+class CallbackWorld : public World {
+public:
+    CallbackWorld(int rank, int nranks, Backend* backend, int device_ordinal, const hnh_comm_callbacks& cb);
+    ~CallbackWorld() override;
+    const char* kind() const override { return "callback"; }
+    void sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes,
+                  int src, int stream) override;
+    void barrier() override;
+    void host_allgather(const void* send, void* recv, size_t bytes) override;
+    void host_alltoallv(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl, void* recv,
+                        const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl) override;
+
+private:
+    hnh_comm_callbacks cb_;
+};
+
+}  // namespace hnh

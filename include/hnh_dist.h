@@ -1,0 +1,145 @@
+/*
+ * hnh_dist.h — C ABI of the host layer (libhnh_host.so): the HnH operator surface as opaque handles.
+ *
+ * The host layer itself is C++ and mirrors the reference's classes by name (Distributed_Sparse,
+ * Sparse15D_Dense_Shift, Sparse15D_Sparse_Shift, Sparse25D_Cannon_Dense, Sparse25D_Cannon_Sparse, SpmatLocal,
+ * CSRLocal, StandardKernel, FlexibleGrid, BufferPair — headers under distributed_sddmm_amd/csrc/host/, see
+ * INTEGRATION.md); C++ callers include those headers directly.  This C ABI exposes the same operations
+ * to non-C++ callers (the Python tests and bench.py bind it with ctypes).  Each function cites the
+ * reference member it forwards to (file:line under /root/reference).
+ *
+ * Conventions: int status return (0 == HNH_OK, codes of hnh_kernels.h); no exception crosses the ABI;
+ * hnh_host_last_error() returns the calling thread's last message.  Handles are not thread-safe; every
+ * call must be made by the thread that drives the handle's rank.  All calls of one operation are
+ * collective over the ranks of the world, like the reference's MPI-based methods.
+ */
+#ifndef HNH_DIST_H
+#define HNH_DIST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "hnh_kernels.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hnh_world hnh_world;               /* one rank of a process group (MPI_COMM_WORLD analogue) */
+typedef struct hnh_thread_group hnh_thread_group; /* shared state of an in-process ("loopback") group       */
+typedef struct hnh_spmat hnh_spmat;               /* SpmatLocal                                             */
+typedef struct hnh_dist hnh_dist;                 /* Distributed_Sparse subclass + its StandardKernel       */
+typedef struct hnh_dense hnh_dense;               /* DenseMatrix (device resident)                          */
+typedef struct hnh_vec hnh_vec;                   /* VectorXd   (device resident)                          */
+
+/* KernelMode (sparse_kernels.h:13) and MatMode (common.h:21) */
+#define HNH_K_SDDMM_A 0
+#define HNH_K_SPMM_A 1
+#define HNH_K_SPMM_B 2
+#define HNH_K_SDDMM_B 3
+#define HNH_AMAT 0
+#define HNH_BMAT 1
+
+/* transport callbacks for hnh_world_create_callback (blocking; pointers are in the backend's memory space) */
+#ifndef HNH_COMM_CALLBACKS_DEFINED
+#define HNH_COMM_CALLBACKS_DEFINED
+typedef struct hnh_comm_callbacks {
+    void* user;
+    int (*sendrecv)(void* user, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes, int src);
+    int (*barrier)(void* user);
+    int (*allgather)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+} hnh_comm_callbacks;
+#endif
+
+const char* hnh_host_last_error(void);
+
+/* Selects the library implementing hnh_kernels.h.  NULL / "" = the product HIP library next to
+ * libhnh_host.so.  The product never loads anything else; tests pass the path of the oracle test double. */
+int hnh_backend_load(const char* path);
+const char* hnh_host_backend_name(void);
+
+/* ---- process groups (replace MPI_Init / MPI_COMM_WORLD; benchmark_dist.cpp:35-36) */
+int hnh_world_create_single(int device, hnh_world** out);
+int hnh_thread_group_create(int nranks, hnh_thread_group** out);
+int hnh_thread_group_destroy(hnh_thread_group* g);
+int hnh_world_create_thread(hnh_thread_group* g, int rank, int device, hnh_world** out);
+int hnh_rccl_unique_id(void* id128_host);
+int hnh_world_create_rccl(int rank, int nranks, int device, const void* id128_host, hnh_world** out);
+int hnh_world_create_callback(int rank, int nranks, int device, const hnh_comm_callbacks* cb, hnh_world** out);
+int hnh_world_destroy(hnh_world* w);
+int hnh_world_rank(hnh_world* w);
+int hnh_world_size(hnh_world* w);
+int hnh_world_barrier(hnh_world* w);
+int hnh_world_sync(hnh_world* w);                      /* drain compute + communication streams */
+int hnh_world_set_timing_sync(hnh_world* w, int on);   /* perf counters synchronise first (reference-like attribution) */
+void* hnh_world_stream(hnh_world* w, int stream);      /* raw hipStream_t */
+hnh_ctx* hnh_world_ctx(hnh_world* w);                  /* the rank's kernel-level context */
+/* FlexibleGrid(nr, nc, nh, adjacency) (FlexibleGrid.hpp:41-94): out9 = i, j, k, rankInRow, rankInCol, rankInFiber,
+ * row size, col size, fiber size; *ok = result of the broadcast self test (FlexibleGrid.hpp:169-201). */
+int hnh_world_grid_probe(hnh_world* w, int nr, int nc, int nh, int adjacency, int* out9, int* ok);
+
+/* ---- sparse input (SpmatLocal.hpp:267-606) */
+/* Wraps tuples that this rank holds initially (any distribution; coords / M / N / dist_nnz as the reference's
+ * drivers fill them).  Host arrays, copied. */
+int hnh_spmat_create(hnh_world* w, int64_t M, int64_t N, int64_t dist_nnz, int64_t local_nnz, const int64_t* rows,
+                     const int64_t* cols, const double* values, hnh_spmat** out);
+/* SpmatLocal::loadTuples(readFromFile, logM, nnz_per_row, filename) (SpmatLocal.hpp:467-533) */
+int hnh_spmat_load_tuples(hnh_world* w, int read_from_file, int logM, int nnz_per_row, const char* filename, hnh_spmat** out);
+int hnh_spmat_info(hnh_spmat* s, int64_t out4[4]); /* M, N, dist_nnz, local tuple count */
+int hnh_spmat_destroy(hnh_spmat* s);
+/* the shared synthetic generator (bit-identical to oracle/oracle.py:erdos_renyi_mn) */
+int hnh_er_generate(uint64_t m, uint64_t n, uint64_t draws, uint64_t seed, void** handle, int64_t* count);
+int hnh_er_fetch(void* handle, int64_t* rows, int64_t* cols); /* also frees the handle */
+
+/* ---- operator construction (benchmark_dist.cpp:45-82): alg in
+ *   "15d_fusion1" | "15d_fusion2" | "15d_sparse" | "25d_dense_replicate" | "25d_sparse_replicate" */
+int hnh_dist_create(hnh_world* w, const char* alg, hnh_spmat* s, int R, int c, hnh_dist** out);
+int hnh_dist_destroy(hnh_dist* d);
+/* out16 = M, N, R, p, c, localArows, localAcols, localBrows, localBcols, len(like_S_values), len(like_ST_values),
+ *         r_split, dist_nnz, proc_rank, #aSubmatrices, #bSubmatrices   (distributed_sparse.h:34-76) */
+int hnh_dist_info(hnh_dist* d, int64_t out16[16]);
+/* a/bSubmatrices (distributed_sparse.h:56-57): 4 ints each (topRow, leftCol, rowCount, colCount) */
+int hnh_dist_submatrices(hnh_dist* d, int matmode, int64_t* out, int capacity_entries);
+int hnh_dist_set_r(hnh_dist* d, int R); /* setRValue */
+/* which: 0 = json_algorithm_info (distributed_sparse.h:131-179), 1 = json_perf_statistics (:245-261) */
+int hnh_dist_json(hnh_dist* d, int which, char* buf, size_t capacity);
+int hnh_dist_reset_timers(hnh_dist* d); /* reset_performance_timers */
+/* HIP-event time of the local kernels launched by the operator's StandardKernel since enabling */
+int hnh_dist_kernel_profile(hnh_dist* d, int enable, double* total_ms, int64_t* launches);
+
+/* ---- dense operands / value vectors (device resident) */
+int hnh_dense_create(hnh_world* w, int64_t rows, int64_t cols, double fill, hnh_dense** out);
+int hnh_dense_wrap(hnh_world* w, void* device_ptr, int64_t rows, int64_t cols, hnh_dense** out); /* non-owning */
+int hnh_dense_like(hnh_dist* d, int matmode, double fill, hnh_dense** out); /* like_A_matrix / like_B_matrix (:197-203) */
+int hnh_dense_shape(hnh_dense* m, int64_t out2[2]);
+void* hnh_dense_data(hnh_dense* m); /* device pointer; may change after an operation that hands storage back */
+int hnh_dense_upload(hnh_dense* m, const double* host);
+int hnh_dense_download(hnh_dense* m, double* host);
+int hnh_dense_fill(hnh_dense* m, double value);
+int hnh_dense_copy(hnh_dense* dst, hnh_dense* src);
+int hnh_dense_destroy(hnh_dense* m);
+int hnh_dense_dummy_initialize(hnh_dist* d, hnh_dense* m, int matmode); /* dummyInitialize (:322-346) */
+int hnh_vec_create(hnh_world* w, int64_t n, double fill, hnh_vec** out);
+int hnh_vec_like(hnh_dist* d, int which /* 0 = like_S_values, 1 = like_ST_values (:189-195) */, double fill, hnh_vec** out);
+int64_t hnh_vec_size(hnh_vec* v);
+void* hnh_vec_data(hnh_vec* v);
+int hnh_vec_upload(hnh_vec* v, const double* host);
+int hnh_vec_download(hnh_vec* v, double* host);
+int hnh_vec_fill(hnh_vec* v, double value);
+int hnh_vec_destroy(hnh_vec* v);
+
+/* ---- operations (distributed_sparse.h:268-320) */
+int hnh_dist_initial_shift(hnh_dist* d, hnh_dense* A, hnh_dense* B, int kernel_mode);
+int hnh_dist_de_shift(hnh_dist* d, hnh_dense* A, hnh_dense* B, int kernel_mode);
+int hnh_dist_sddmmA(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_vec* result);
+int hnh_dist_sddmmB(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_vec* result);
+int hnh_dist_spmmA(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S);
+int hnh_dist_spmmB(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S);
+int hnh_dist_fusedSpMM(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_vec* sddmm_buffer, int matmode);
+int hnh_dist_algorithm(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_vec* result_or_null, int kernel_mode,
+                       int initial_replicate);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HNH_DIST_H */

@@ -1,0 +1,171 @@
+/*
+ * TEST INFRASTRUCTURE ONLY — CPU restatement of the reference's local kernels in plain C, exported
+ * through the SAME C ABI as the product's HIP library (include/hnh_kernels.h) so that tests can
+ *   (1) compare it with the golden vectors produced by the reference itself (tests/test_oracle_golden.py)
+ *   (2) stand in for the GPU when the HOST logic (redistribution, block layout, shift schedules,
+ *       transports) is exercised on a machine without one (pytest -m "not gpu").
+ * "Device" pointers are host pointers here; streams and events are no-ops (everything is synchronous).
+ * The product never loads this library: hnh_backend_load() is given its path explicitly by tests only,
+ * and bench.py / smoke() assert that the active backend is "hip-gfx950".
+ *
+ * Restated reference code (file:line under /root/reference):
+ *   hnh_sddmm_coo / hnh_sddmm_csr : StandardKernel::sddmm_local loop, sparse_kernels.cpp:44-55
+ *   hnh_spmm_csr                  : mkl_sparse_d_mm(NON_TRANSPOSE, alpha=1, CSR, ROW_MAJOR, beta=1),
+ *                                   sparse_kernels.cpp:95-107 (Intel MKL 2021.4, third-party: the
+ *                                   documented contract C = alpha*A*B + beta*C is what is restated)
+ *   hnh_fused_sddmm_spmm_csr      : the two calls of 15D_dense_shift.hpp:203-217 back to back
+ *   hnh_fill_f64                  : SpmatLocal::setValuesConstant, SpmatLocal.hpp:595-605
+ *   hnh_hadamard_f64              : SValues.cwiseProduct(getCSRValues()), 15D_dense_shift.hpp:366
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "hnh_kernels.h"
+
+struct hnh_ctx {
+    int device;
+    char err[256];
+};
+
+static int fail(hnh_ctx* c, int code, const char* msg) {
+    if (c) { strncpy(c->err, msg, sizeof(c->err) - 1); c->err[sizeof(c->err) - 1] = 0; }
+    return code;
+}
+
+const char* hnh_backend_name(void) { return "oracle-cpu-test-double"; }
+
+int hnh_ctx_create(int device, hnh_ctx** out) {
+    if (!out) return HNH_ERR_INVALID;
+    hnh_ctx* c = (hnh_ctx*)calloc(1, sizeof(hnh_ctx));
+    if (!c) return HNH_ERR_NOMEM;
+    c->device = device;
+    *out = c;
+    return HNH_OK;
+}
+int hnh_ctx_destroy(hnh_ctx* c) { free(c); return HNH_OK; }
+const char* hnh_last_error(hnh_ctx* c) { return c ? c->err : "null context"; }
+void* hnh_ctx_stream(hnh_ctx* c, int s) { (void)c; (void)s; return NULL; }
+int hnh_malloc(hnh_ctx* c, size_t bytes, void** out) {
+    if (!out) return HNH_ERR_INVALID;
+    *out = malloc(bytes ? bytes : 16);
+    return *out ? HNH_OK : fail(c, HNH_ERR_NOMEM, "malloc failed");
+}
+int hnh_free(hnh_ctx* c, void* p) { (void)c; free(p); return HNH_OK; }
+int hnh_memcpy(hnh_ctx* c, void* dst, const void* src, size_t bytes, int kind, int stream) {
+    (void)c; (void)kind; (void)stream;
+    if (bytes) memmove(dst, src, bytes);
+    return HNH_OK;
+}
+int hnh_memset(hnh_ctx* c, void* dst, int byte, size_t bytes, int stream) {
+    (void)c; (void)stream;
+    if (bytes) memset(dst, byte, bytes);
+    return HNH_OK;
+}
+int hnh_stream_sync(hnh_ctx* c, int s) { (void)c; (void)s; return HNH_OK; }
+int hnh_event_create(hnh_ctx* c, void** e) { (void)c; *e = malloc(1); return HNH_OK; }
+int hnh_event_destroy(hnh_ctx* c, void* e) { (void)c; free(e); return HNH_OK; }
+int hnh_event_record(hnh_ctx* c, void* e, int s) { (void)c; (void)e; (void)s; return HNH_OK; }
+int hnh_event_wait(hnh_ctx* c, void* e, int s) { (void)c; (void)e; (void)s; return HNH_OK; }
+int hnh_event_sync(hnh_ctx* c, void* e) { (void)c; (void)e; return HNH_OK; }
+int hnh_event_elapsed_ms(hnh_ctx* c, void* a, void* b, float* ms) { (void)c; (void)a; (void)b; *ms = 0.f; return HNH_OK; }
+
+/* sparse_kernels.cpp:44-55 */
+int hnh_sddmm_coo(hnh_ctx* c, int64_t nnz, const int32_t* row_idx, const int32_t* col_idx, double* values, const double* X,
+                  const double* Y, int R, int stream) {
+    (void)stream;
+    if (nnz < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad size");
+    for (int64_t i = 0; i < nnz; i++) {
+        const double* Arow = X + (int64_t)R * row_idx[i];
+        const double* Brow = Y + (int64_t)R * col_idx[i];
+        double value = 0.0;
+        for (int k = 0; k < R; k++) value += Arow[k] * Brow[k];
+        values[i] += value;
+    }
+    return HNH_OK;
+}
+
+int hnh_sddmm_csr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values, const double* X,
+                  const double* Y, int R, int stream) {
+    (void)stream;
+    if (rows < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad size");
+    for (int64_t r = 0; r < rows; r++)
+        for (int32_t i = rowptr[r]; i < rowptr[r + 1]; i++) {
+            const double* Arow = X + (int64_t)R * r;
+            const double* Brow = Y + (int64_t)R * col_idx[i];
+            double value = 0.0;
+            for (int k = 0; k < R; k++) value += Arow[k] * Brow[k];
+            values[i] += value;
+        }
+    return HNH_OK;
+}
+
+/* C = 1.0 * S * X + 1.0 * C, row-major, ld = R (sparse_kernels.cpp:95-107) */
+int hnh_spmm_csr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values, const double* X,
+                 double* Out, int R, int stream) {
+    (void)stream;
+    if (rows < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad size");
+    if (X == Out) return fail(c, HNH_ERR_INVALID, "X and Out alias");
+    for (int64_t r = 0; r < rows; r++)
+        for (int32_t i = rowptr[r]; i < rowptr[r + 1]; i++) {
+            const double v = values[i];
+            const double* Xrow = X + (int64_t)R * col_idx[i];
+            double* Crow = Out + (int64_t)R * r;
+            for (int k = 0; k < R; k++) Crow[k] += v * Xrow[k];
+        }
+    return HNH_OK;
+}
+
+/* 15D_dense_shift.hpp:203-217: sddmm on the block, then spmm with the block's (updated) values */
+int hnh_fused_sddmm_spmm_csr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
+                             const double* svalues, const double* X, const double* Y, double* Out, int R, unsigned flags,
+                             int stream) {
+    if (rows < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad size");
+    if (rows == 0) return HNH_OK;
+    const int32_t nnz = rowptr[rows];
+    if (flags & HNH_FUSED_VALUES_OVERWRITE) memset(values, 0, sizeof(double) * (size_t)nnz);
+    if (flags & HNH_FUSED_OUT_OVERWRITE) memset(Out, 0, sizeof(double) * (size_t)rows * (size_t)R);
+    int rc = hnh_sddmm_csr(c, rows, rowptr, col_idx, values, X, Y, R, stream);
+    if (rc != HNH_OK) return rc;
+    if (!svalues) return hnh_spmm_csr(c, rows, rowptr, col_idx, values, Y, Out, R, stream);
+    double* w = (double*)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+    if (!w) return fail(c, HNH_ERR_NOMEM, "malloc failed");
+    for (int32_t i = 0; i < nnz; i++) w[i] = values[i] * svalues[i];
+    rc = hnh_spmm_csr(c, rows, rowptr, col_idx, w, Y, Out, R, stream);
+    free(w);
+    return rc;
+}
+
+int hnh_fill_f64(hnh_ctx* c, double* dst, int64_t n, double v, int stream) {
+    (void)c; (void)stream;
+    for (int64_t i = 0; i < n; i++) dst[i] = v;
+    return HNH_OK;
+}
+int hnh_hadamard_f64(hnh_ctx* c, double* out, const double* a, const double* b, int64_t n, int stream) {
+    (void)c; (void)stream;
+    for (int64_t i = 0; i < n; i++) out[i] = a[i] * b[i];
+    return HNH_OK;
+}
+int hnh_axpy_f64(hnh_ctx* c, double* y, const double* x, double alpha, int64_t n, int stream) {
+    (void)c; (void)stream;
+    for (int64_t i = 0; i < n; i++) y[i] += alpha * x[i];
+    return HNH_OK;
+}
+int hnh_expand_rowptr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, int32_t* row_idx, int stream) {
+    (void)c; (void)stream;
+    for (int64_t r = 0; r < rows; r++)
+        for (int32_t i = rowptr[r]; i < rowptr[r + 1]; i++) row_idx[i] = (int32_t)r;
+    return HNH_OK;
+}
+
+/* no RCCL on the CPU: host-logic tests use the thread-loopback or callback transports */
+#define UNSUP(c) return fail((c), HNH_ERR_UNSUPPORTED, "RCCL transport is not available in the CPU test double")
+int hnh_comm_unique_id(void* id) { (void)id; return HNH_ERR_UNSUPPORTED; }
+int hnh_comm_init(hnh_ctx* c, int n, int r, const void* id, void** comm) { (void)n; (void)r; (void)id; (void)comm; UNSUP(c); }
+int hnh_comm_split(hnh_ctx* c, void* comm, int color, int key, void** nc) { (void)comm; (void)color; (void)key; (void)nc; UNSUP(c); }
+int hnh_comm_destroy(hnh_ctx* c, void* comm) { (void)comm; UNSUP(c); }
+int hnh_comm_sendrecv(hnh_ctx* c, void* comm, const void* s, size_t sb, int dst, void* r, size_t rb, int src, int st) {
+    (void)comm; (void)s; (void)sb; (void)dst; (void)r; (void)rb; (void)src; (void)st; UNSUP(c);
+}
+int hnh_comm_allgather(hnh_ctx* c, void* comm, const void* s, void* r, size_t b, int st) { (void)comm; (void)s; (void)r; (void)b; (void)st; UNSUP(c); }
+int hnh_comm_reduce_scatter_f64(hnh_ctx* c, void* comm, const double* s, double* r, size_t n, int st) { (void)comm; (void)s; (void)r; (void)n; (void)st; UNSUP(c); }
+int hnh_comm_allreduce_f64(hnh_ctx* c, void* comm, const double* s, double* r, size_t n, int st) { (void)comm; (void)s; (void)r; (void)n; (void)st; UNSUP(c); }

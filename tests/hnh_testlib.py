@@ -1,0 +1,206 @@
+"""Shared test harness: drives the operator API exactly the way oracle/ref_driver.cpp drives the reference
+(coordinate-probe SDDMM to key the value slots, global dense fills through a/bSubmatrices, the six
+operations each bracketed by initial_shift / de_shift) and assembles per-rank results into global ones."""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+from distributed_sddmm_amd import api as H
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+ORACLE_BACKEND = os.path.join(ROOT, "oracle", "liboracle_backend.so")
+TOL = 1e-11  # fp64, summation order only
+
+DENSE_OUT = ("spmmA", "spmmB", "fusedA", "fusedB")
+SPARSE_OUT = ("sddmmA", "sddmmB", "fusedA_buf", "fusedB_buf")
+
+
+def golden_cases():
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        return json.load(f)
+
+
+def case_inputs(name: str):
+    """Regenerates the seeded inputs of a golden case (same recipe as tests/golden/make_golden.py)."""
+    meta = golden_cases()[name]
+    m, n, r, seed = meta["M"], meta["N"], meta["R"], meta["seed"]
+    rows, cols = O.erdos_renyi_mn(m, n, meta["draws"], seed)
+    assert len(rows) == meta["nnz"]
+    vals = O.sparse_values(rows, cols, n, seed + 1)
+    return dict(name=name, M=m, N=n, R=r, rows=rows, cols=cols, vals=vals, A=O.dense_fill(m, r, seed + 2), B=O.dense_fill(n, r, seed + 3))
+
+
+def golden_outputs(name: str):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+def rel(x, y):
+    x, y = np.asarray(x), np.asarray(y)
+    if x.size == 0:
+        return 0.0
+    return float(np.max(np.abs(x - y)) / max(float(np.max(np.abs(y))), 1e-300))
+
+
+def valid_config(alg: str, p: int, c: int, r: int, square: bool = True) -> bool:
+    if p % c:
+        return False
+    if alg.startswith("25d"):
+        s = int(round((p // c) ** 0.5))
+        if s * s * c != p:
+            return False
+        return r % (s * (c if alg == "25d_sparse_replicate" else 1)) == 0
+    if alg == "15d_sparse":
+        return r % (p // c) == 0
+    return True
+
+
+def fill_local(subs: np.ndarray, shape, glob: np.ndarray) -> np.ndarray:
+    loc = np.zeros(shape)
+    flat, off = loc.reshape(-1), 0
+    for top, left, rc, cc in subs:
+        blk = np.zeros((rc, cc))
+        keep = max(0, min(rc, glob.shape[0] - top))
+        blk[:keep] = glob[top:top + keep, left:left + cc]
+        flat[off:off + rc * cc] = blk.reshape(-1)
+        off += rc * cc
+    return loc
+
+
+def probe_local(subs: np.ndarray, shape, is_a: bool, n: int) -> np.ndarray:
+    """A[i,:] = (i, 1, 0..), B[j,:] = (N, j, 0..)  =>  <A[i], B[j]> = i*N + j."""
+    loc = np.zeros(shape)
+    flat, off = loc.reshape(-1), 0
+    for top, left, rc, cc in subs:
+        blk = np.zeros((rc, cc))
+        gr = np.arange(top, top + rc, dtype=np.float64)
+        for j in range(cc):
+            gc = left + j
+            if is_a:
+                blk[:, j] = gr if gc == 0 else (1.0 if gc == 1 else 0.0)
+            else:
+                blk[:, j] = float(n) if gc == 0 else (gr if gc == 1 else 0.0)
+        flat[off:off + rc * cc] = blk.reshape(-1)
+        off += rc * cc
+    return loc
+
+
+def run_all_ops(world: H.World, alg: str, c: int, case: dict) -> dict:
+    """Executes on ONE rank; returns this rank's share of every result."""
+    sp = H.SpmatLocal.from_global(world, case["M"], case["N"], case["rows"], case["cols"], case["vals"])
+    d = H.DistributedSparse(world, alg, sp, case["R"], c)
+    info = d.info()
+    subA, subB = d.submatrices(H.AMAT), d.submatrices(H.BMAT)
+    A, B = d.like_A_matrix(0.0), d.like_B_matrix(0.0)
+    shapeA, shapeB = A.shape, B.shape
+    n = case["N"]
+    lookup = dict(zip((case["rows"] * n + case["cols"]).tolist(), case["vals"].tolist()))
+
+    def probe(mode, like):
+        A.upload(probe_local(subA, shapeA, True, n))
+        B.upload(probe_local(subB, shapeB, False, n))
+        ones, res = like(1.0), like(0.0)
+        d.initial_shift(A, B, mode)
+        (d.sddmmA if mode == H.K_SDDMM_A else d.sddmmB)(A, B, ones, res)
+        keys = np.rint(res.download()).astype(np.int64)
+        ones.free(); res.free()
+        return keys
+
+    keysS, keysST = probe(H.K_SDDMM_A, d.like_S_values), probe(H.K_SDDMM_B, d.like_ST_values)
+    S, ST = d.like_S_values(0.0), d.like_ST_values(0.0)
+    S.upload(np.array([lookup[k] for k in keysS.tolist()], dtype=np.float64))
+    ST.upload(np.array([lookup[k] for k in keysST.tolist()], dtype=np.float64))
+
+    def refill():
+        A.upload(fill_local(subA, shapeA, case["A"]))
+        B.upload(fill_local(subB, shapeB, case["B"]))
+
+    out = dict(info=info, subA=subA, subB=subB, keysS=keysS, keysST=keysST)
+    res = d.like_S_values(0.0)
+    refill(); d.initial_shift(A, B, H.K_SDDMM_A); d.sddmmA(A, B, S, res); d.de_shift(A, B, H.K_SDDMM_A)
+    out["sddmmA"] = res.download()
+    # inputs must come back unchanged (the moving operand is shifted and has to be home again on return)
+    out["A_after_sddmmA"], out["B_after_sddmmA"] = A.download(), B.download()
+    out["A_expected"], out["B_expected"] = fill_local(subA, shapeA, case["A"]), fill_local(subB, shapeB, case["B"])
+    res.free()
+    res = d.like_ST_values(0.0)
+    refill(); d.initial_shift(A, B, H.K_SDDMM_B); d.sddmmB(A, B, ST, res); d.de_shift(A, B, H.K_SDDMM_B)
+    out["sddmmB"] = res.download(); res.free()
+    refill(); d.initial_shift(A, B, H.K_SPMM_A); d.spmmA(A, B, S); d.de_shift(A, B, H.K_SPMM_A)
+    out["spmmA"] = A.download()
+    refill(); d.initial_shift(A, B, H.K_SPMM_B); d.spmmB(A, B, ST); d.de_shift(A, B, H.K_SPMM_B)
+    out["spmmB"] = B.download()
+    buf = d.like_S_values(0.0)
+    refill(); d.initial_shift(A, B, H.K_SDDMM_A); d.fusedSpMM(A, B, S, buf, H.AMAT); d.de_shift(A, B, H.K_SDDMM_A)
+    out["fusedA"], out["fusedA_buf"] = A.download(), buf.download(); buf.free()
+    buf = d.like_ST_values(0.0)
+    refill(); d.initial_shift(A, B, H.K_SDDMM_B); d.fusedSpMM(A, B, ST, buf, H.BMAT); d.de_shift(A, B, H.K_SDDMM_B)
+    out["fusedB"], out["fusedB_buf"] = B.download(), buf.download(); buf.free()
+    # scratch.cpp:26-76 fingerprints
+    fps = []
+    for mode, op in ((H.K_SDDMM_A, "sddmm"), (H.K_SPMM_A, "spmmA"), (H.K_SPMM_B, "spmmB")):
+        d.dummyInitialize(A, H.AMAT); d.dummyInitialize(B, H.BMAT)
+        d.initial_shift(A, B, mode)
+        if op == "sddmm":
+            ones, r2 = d.like_S_values(1.0), d.like_S_values(0.0)
+            d.sddmmA(A, B, ones, r2); fps.append(float(np.sum(r2.download() ** 2))); ones.free(); r2.free()
+        elif op == "spmmA":
+            ones = d.like_S_values(1.0); d.spmmA(A, B, ones); fps.append(float(np.sum(A.download() ** 2))); ones.free()
+        else:
+            ones = d.like_ST_values(1.0); d.spmmB(A, B, ones); fps.append(float(np.sum(B.download() ** 2))); ones.free()
+    out["fingerprints"] = np.array(fps)
+    out["alg_info"] = d.json_algorithm_info()
+    out["perf"] = d.json_perf_statistics()
+    for x in (A, B, S, ST):
+        x.free()
+    d.free(); sp.free()
+    return out
+
+
+def assemble(per_rank: list, case: dict) -> dict:
+    m, n, r = case["M"], case["N"], case["R"]
+    glob = {}
+    for name, which, nr in (("spmmA", "subA", m), ("fusedA", "subA", m), ("spmmB", "subB", n), ("fusedB", "subB", n)):
+        g = np.zeros((nr, r))
+        cover = np.zeros((nr, r), dtype=np.int32)
+        for o in per_rank:
+            flat, off = o[name].reshape(-1), 0
+            for top, left, rc, cc in o[which]:
+                blk = flat[off:off + rc * cc].reshape(rc, cc)
+                off += rc * cc
+                keep = max(0, min(rc, nr - top))
+                g[top:top + keep, left:left + cc] = blk[:keep]
+                cover[top:top + keep, left:left + cc] += 1
+        assert np.all(cover == 1), "submatrices of the ranks must partition the dense matrix"
+        glob[name] = g
+    for name, kn in (("sddmmA", "keysS"), ("sddmmB", "keysST"), ("fusedA_buf", "keysS"), ("fusedB_buf", "keysST")):
+        keys = np.concatenate([o[kn] for o in per_rank])
+        vals = np.concatenate([o[name] for o in per_rank])
+        order = np.argsort(keys, kind="stable")
+        glob[name] = (keys[order], vals[order])
+    glob["fingerprints"] = np.sum([o["fingerprints"] for o in per_rank], axis=0)
+    return glob
+
+
+def check_against_golden(glob: dict, per_rank: list, case: dict, alg: str, tol: float = TOL):
+    gold = golden_outputs(case["name"])
+    keys = case["rows"] * case["N"] + case["cols"]
+    fusion2 = (alg == "15d_fusion2")
+    for name in DENSE_OUT:
+        want = gold[name + "_fusion2"] if (fusion2 and name.startswith("fused")) else gold[name]
+        assert rel(glob[name], want) <= tol, (alg, name, rel(glob[name], want))
+    for name in SPARSE_OUT:
+        k, v = glob[name]
+        assert np.array_equal(k, keys), (alg, name, "every nonzero must be owned exactly once")
+        if fusion2 and name.endswith("_buf"):
+            assert np.all(v == 0.0), "local-kernel-fusion fusedSpMM leaves sddmm_buffer untouched, like the reference"
+            continue
+        assert rel(v, gold[name]) <= tol, (alg, name, rel(v, gold[name]))
+    assert rel(glob["fingerprints"], gold["fingerprints"]) <= tol
+    for o in per_rank:  # inputs intact after an SDDMM
+        assert np.array_equal(o["A_after_sddmmA"], o["A_expected"])
+        assert np.array_equal(o["B_after_sddmmA"], o["B_expected"])

@@ -1,0 +1,92 @@
+"""Host logic on CPU: every schedule class (1.5D dense shift approach 1/2, 1.5D sparse shift, 2.5D Cannon
+dense / sparse), every (p, c) up to 8 ranks, through the in-process loopback transport — with the kernel
+ABI served by the oracle's C test double (explicitly loaded here; the product never does that).  Results
+are compared element-wise, by global coordinate, with the golden vectors produced by the reference.
+
+What this covers without a GPU: owner functions and redistribution (a6), block layout and CSR build (a4),
+ring schedules incl. event bookkeeping order (a10-a13), sparse/dense shifts (a5, a8), BufferPair hand-back
+(a7), grid rank maps (a14), value ownership/length quirks (Appendix C #5), fingerprints (scratch.cpp)."""
+import numpy as np
+import pytest
+
+import hnh_testlib as T
+from distributed_sddmm_amd import api as H
+
+GRIDS = [(1, 1), (2, 1), (2, 2), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2), (8, 4), (8, 8)]
+
+
+@pytest.fixture(autouse=True, scope="module")
+def cpu_test_double():
+    assert H.load_backend(T.ORACLE_BACKEND) == "oracle-cpu-test-double"
+    yield
+
+
+def configs(case_name):
+    meta = T.golden_cases()[case_name]
+    return [(alg, p, c) for alg in H.ALGORITHMS for (p, c) in GRIDS if T.valid_config(alg, p, c, meta["R"])]
+
+
+@pytest.mark.parametrize("alg,p,c", configs("er8_r16"))
+def test_er8_all_schedules(alg, p, c):
+    case = T.case_inputs("er8_r16")
+    per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
+    T.check_against_golden(T.assemble(per_rank, case), per_rank, case, alg)
+
+
+@pytest.mark.parametrize("case_name", ["ragged_r8", "rect_r16", "tiny_r8"])
+@pytest.mark.parametrize("alg", H.ALGORITHMS)
+def test_edge_cases(case_name, alg):
+    """M not divisible by p (padded blocks), non-square S, almost-empty S (null blocks)."""
+    case = T.case_inputs(case_name)
+    for p, c in [(1, 1), (4, 1), (4, 2), (8, 2)]:
+        if not T.valid_config(alg, p, c, case["R"]):
+            continue
+        per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
+        T.check_against_golden(T.assemble(per_rank, case), per_rank, case, alg)
+
+
+def test_value_vector_lengths_follow_the_reference():
+    """like_S_values is the ST length under approach 1 and 2.5D dense; json info keys."""
+    case = T.case_inputs("rect_r16")
+
+    def body(w):
+        sp = H.SpmatLocal.from_global(w, case["M"], case["N"], case["rows"], case["cols"], case["vals"])
+        out = {}
+        for alg in ("15d_fusion1", "15d_fusion2"):
+            d = H.DistributedSparse(w, alg, sp, case["R"], 1)
+            out[alg] = (d.info()["nS"], d.info()["nST"], d.json_algorithm_info())
+            d.free()
+        sp.free()
+        return out
+
+    res = H.run_spmd(2, body)
+    total = len(case["rows"])
+    for alg in ("15d_fusion1", "15d_fusion2"):
+        assert sum(r[alg][0] for r in res) == total and sum(r[alg][1] for r in res) == total
+        info = res[0][alg][2]
+        for key in ("alg_name", "m", "n", "nnz", "r", "adjacency_mode", "p", "c", "dim_interpretations", "dim_values",
+                    "nnz_procs", "nnz_tpose_procs"):
+            assert key in info
+        assert info["nnz"] == total and info["p"] == 2 and sum(info["nnz_procs"]) == total
+    # S is split by rows, ST by columns: on a non-square matrix the per-rank counts differ and approach 1 swaps them
+    assert [r["15d_fusion1"][0] for r in res] == [r["15d_fusion2"][1] for r in res]
+
+
+def test_configuration_errors_are_reported():
+    case = T.case_inputs("tiny_r8")
+
+    def body(w):
+        sp = H.SpmatLocal.from_global(w, case["M"], case["N"], case["rows"], case["cols"], case["vals"])
+        errs = []
+        for alg, r, c in (("15d_fusion2", 8, 3), ("25d_dense_replicate", 8, 1), ("15d_sparse", 7, 1), ("nope", 8, 1)):
+            with pytest.raises(H.HnhError) as e:
+                H.DistributedSparse(w, alg, sp, r, c)
+            errs.append(str(e.value))
+        sp.free()
+        return errs
+
+    errs = H.run_spmd(2, body)[0]
+    assert "must have c divide num_procs" in errs[0]        # 15D_dense_shift.hpp:60-65
+    assert "perfect square" in errs[1]                      # 25D_cannon_dense.hpp:61-67
+    assert "divisible by p / c" in errs[2]                  # 15D_sparse_shift.hpp:147-149
+    assert "unknown algorithm" in errs[3]

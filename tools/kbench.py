@@ -1,0 +1,72 @@
+"""Kernel-level micro benchmark (development tool): fused / sddmm / spmm on an ER block, HIP-event timed."""
+import argparse
+import ctypes as C
+import sys
+import time
+import os
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from distributed_sddmm_amd import _kernels as K  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--logm", type=int, default=20)
+    ap.add_argument("--ef", type=int, default=96)
+    ap.add_argument("--r", type=int, default=128)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--ops", default="fused,sddmm,spmm")
+    a = ap.parse_args()
+    t0 = time.time()
+    rows_i, cols_i = O.erdos_renyi(a.logm, a.ef)
+    m = 1 << a.logm
+    nnz = len(rows_i)
+    rowptr = np.zeros(m + 1, np.int64)
+    np.add.at(rowptr, rows_i + 1, 1)
+    rowptr = np.cumsum(rowptr).astype(np.int32)
+    print("generated nnz=%d in %.1fs" % (nnz, time.time() - t0), flush=True)
+    ctx = K.Ctx(0)
+    lib = ctx.lib
+    R = a.r
+    d_rowptr, d_c = ctx.upload(rowptr), ctx.upload(cols_i.astype(np.int32))
+    del rows_i, cols_i
+    dv = K.DevArray(ctx, (nnz,), np.float64)
+    dA, dB, dOut = (K.DevArray(ctx, (m, R), np.float64) for _ in range(3))
+    lib.hnh_fill_f64(ctx.h, dA.ptr, m * R, 0.001, 0)
+    lib.hnh_fill_f64(ctx.h, dB.ptr, m * R, 0.001, 0)
+    lib.hnh_fill_f64(ctx.h, dv.ptr, nnz, 0.0, 0)
+    ev0, ev1 = C.c_void_p(), C.c_void_p()
+    lib.hnh_event_create(ctx.h, C.byref(ev0)); lib.hnh_event_create(ctx.h, C.byref(ev1))
+
+    def timed(fn, name, bytes_alg):
+        fn(); ctx.sync()
+        ts = []
+        for _ in range(a.iters):
+            lib.hnh_event_record(ctx.h, ev0, 0)
+            fn()
+            lib.hnh_event_record(ctx.h, ev1, 0)
+            lib.hnh_event_sync(ctx.h, ev1)
+            ms = C.c_float()
+            lib.hnh_event_elapsed_ms(ctx.h, ev0, ev1, C.byref(ms))
+            ts.append(ms.value)
+        t = float(np.median(ts)) * 1e-3
+        print("%-6s R=%d  %.3f ms  %.3e nnz*R/s  alg %.2f GB -> %.2f TB/s (%.1f%% of 8 TB/s)" % (
+            name, R, t * 1e3, nnz * R / t, bytes_alg / 1e9, bytes_alg / t / 1e12, 100 * bytes_alg / t / 8e12), flush=True)
+
+    ops = a.ops.split(",")
+    if "fused" in ops:
+        timed(lambda: ctx.check(lib.hnh_fused_sddmm_spmm_csr(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, None, dA.ptr, dB.ptr,
+                                                             dOut.ptr, R, 3, 0), "fused"), "fused", nnz * (8 * R + 24) + 16 * R * m)
+    if "sddmm" in ops:
+        timed(lambda: ctx.check(lib.hnh_sddmm_csr(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, dA.ptr, dB.ptr, R, 0), "sddmm"),
+              "sddmm", nnz * (8 * R + 20) + 8 * R * m)
+    if "spmm" in ops:
+        timed(lambda: ctx.check(lib.hnh_spmm_csr(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, dB.ptr, dOut.ptr, R, 0), "spmm"),
+              "spmm", nnz * (8 * R + 12) + 16 * R * m)
+
+
+if __name__ == "__main__":
+    main()
