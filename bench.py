@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fused SDDMM -> SpMM (Distributed_Sparse::fusedSpMM, the reference's
+benchmark_dist.cpp:117-149 loop) on an Erdős–Rényi matrix, nnz*R per second.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N = 1 : BASELINE config 2 — ER 2^20 x 2^20 (edge factor 96, ~1.0066e8 nnz), R = 128, one MI355X, the local
+        fused kernel behind `15d_fusion2` (no shift).  A "step" = one fusedSpMM(A, B, S, buf, Amat) call.
+N > 1 : BASELINE config 3 — the SAME global matrix strong-scaled over N GPUs with the 1.5D dense-shifting
+        schedule (RCCL send/recv ring over xGMI, overlapped with the local kernel), one process per GPU.
+Inputs are resident in HBM before the timed region (A = B = 0.001, S = 1 as benchmark_dist.cpp:102-106).
+
+One JSON line is printed by rank 0.  Extra objects:
+  roofline     — the dominant kernel (fused row pass): algorithmic bytes per launch / average launch
+                 duration measured live with HIP events on the compute stream, against 8.0 TB/s HBM.
+  cpu_baseline — the reference itself (oracle/_ref/ref_driver = unmodified reference sources + MKL/MPICH)
+                 timed on this box's host cores on a bounded sample of the same workload (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--logm", type=int, default=20)
+    ap.add_argument("--edge-factor", type=int, default=96)
+    ap.add_argument("--r", type=int, default=128)
+    ap.add_argument("--alg", default="15d_fusion2")
+    ap.add_argument("--c", type=int, default=1, help="replication factor of the 1.5D/2.5D schedule")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-logm", type=int, default=18, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-trials", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The reference timed on the host cores, bounded sample (ER 2^cpu_logm, same edge factor and R)."""
+    import numpy as np
+    from distributed_sddmm_amd import api as H
+    from oracle import refrun as RR
+    threads = os.cpu_count() or 1
+    m = 1 << args.cpu_logm
+    if RR.available():
+        rows, cols = H.generate_er(m, m, m * args.edge_factor, 12345)
+        res = RR.bench(m, m, rows, cols, args.r, "15d_fusion2", 1, 1, True, args.cpu_trials, threads=threads)
+        comp = res["perf_stats"].get("Computation Time", 0.0)
+        return {"value": res["nnz_R_per_s"], "unit": "nnz*R/s", "cores": threads, "kind": "reference",
+                "sample": "ER 2^%d, edge factor %d (%d nnz), R=%d, 15d_fusion2 fused, %d timed fusedSpMM calls after 1 warm-up, "
+                          "1 MPI rank x %d OpenMP/MKL threads" % (args.cpu_logm, args.edge_factor, len(rows), args.r,
+                                                                  args.cpu_trials, threads),
+                "elapsed_s": res["elapsed"],
+                "kernel_only_value": (len(rows) * args.r * args.cpu_trials / comp) if comp > 0 else None}
+    # no compiled reference on this box: time the numpy port on a smaller sample
+    from oracle import oracle as O
+    m = 1 << 14
+    rows, cols = O.erdos_renyi(14, args.edge_factor)
+    a, b = np.full((m, args.r), 0.001), np.full((m, args.r), 0.001)
+    t0 = time.perf_counter()
+    O.fused_a(rows, cols, np.ones(len(rows)), a, b)
+    dt = time.perf_counter() - t0
+    return {"value": len(rows) * args.r / dt, "unit": "nnz*R/s", "cores": 1, "kind": "port",
+            "sample": "numpy restatement, ER 2^14, edge factor %d (%d nnz), R=%d, one fused call" % (args.edge_factor, len(rows), args.r)}
+
+
+def main():
+    args = parse()
+    import torch  # first: one HIP runtime per process (see distributed_sddmm_amd/_kernels.py)
+    from distributed_sddmm_amd import api as H
+
+    rank = int(os.environ.get("RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n = args.gpus
+    if world_size != n:
+        raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run); got %d" % (n, n, world_size))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    assert H.load_backend(None) == "hip-gfx950"
+    dist = None
+    if n > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=n)  # bootstrap + barriers only; data moves over RCCL
+        ident = [H.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        world = H.World.rccl(rank, n, local_rank, ident[0])
+    else:
+        world = H.World.single(local_rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        world.sync()
+        torch.cuda.synchronize()
+
+    # ---- build: same global matrix on every rank count (strong scaling)
+    t_setup = time.perf_counter()
+    sp = H.SpmatLocal.load_tuples(world, False, args.logm, args.edge_factor)
+    info = sp.info()
+    nnz, m = info["dist_nnz"], info["M"]
+    op = H.DistributedSparse(world, args.alg, sp, args.r, args.c)
+    sp.free()
+    A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
+    S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
+    barrier()
+    t_setup = time.perf_counter() - t_setup
+
+    def step():
+        op.fusedSpMM(A, B, S, buf, H.AMAT)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline leg (outside the timed region): HIP events around every local kernel launch
+    prof_calls = max(2, min(5, args.steps))
+    op.kernel_profile(1)
+    for _ in range(prof_calls):
+        step()
+    world.sync()
+    kern_ms, launches = op.kernel_profile(0)
+    local_nnz = op.info()["nS"]
+    rows_touched = op.info()["localArows"] * args.c * (n // args.c)  # every ring step walks all rows of the block row
+    alg_bytes_per_call = local_nnz * (8 * args.r + 24) + 16 * args.r * rows_touched
+    if dist is not None:
+        t = torch.tensor([kern_ms, float(launches), float(alg_bytes_per_call)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        kern_ms, launches, alg_bytes_per_call = float(t[0]) / n, int(t[1]) // n, float(t[2]) / n
+    barrier()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = nnz * args.r * args.steps / elapsed
+        launches_per_call = max(1, launches // prof_calls)
+        dur = kern_ms / max(1, launches) * 1e-3  # average launch duration, seconds
+        bytes_per_launch = alg_bytes_per_call / launches_per_call
+        achieved = bytes_per_launch / dur if dur > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tf):
+            try:
+                with open(tf) as f:
+                    rec = json.load(f)
+                if rec.get("workload_key") == "er%d_ef%d_r%d_n%d" % (args.logm, args.edge_factor, args.r, n):
+                    traffic = rec.get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "fused SDDMM+SpMM nnz*R/s", "value": value, "unit": "nnz*R/s", "n_gpus": n, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Erdos-Renyi 2^%d x 2^%d, edge factor %d (%d unique nnz), R=%d, fused SDDMM->SpMM (fusedSpMM, Amat), "
+                                   "%s c=%d on %d x MI355X%s" % (args.logm, args.logm, args.edge_factor, nnz, args.r, args.alg, args.c, n,
+                                                                "" if n == 1 else ", RCCL ring over xGMI"),
+                       "nnz": nnz, "M": m, "R": args.r, "algorithm": args.alg, "c": args.c, "transport": "none" if n == 1 else "rccl",
+                       "setup_s": round(t_setup, 2)},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": traffic,
+                         "kernel": "row_kernel<fused> (hnh_fused_sddmm_spmm_csr)", "avg_launch_ms": dur * 1e3,
+                         "launches_per_step": launches_per_call, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "model": "nnz*(8R+24) + 16*R*rows per launch (SURVEY 8d)"},
+        }
+        if n == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args)
+            except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
+                out["cpu_baseline"] = {"value": None, "unit": "nnz*R/s", "cores": os.cpu_count(), "kind": "reference",
+                                       "sample": "FAILED: %s" % str(e)[:300]}
+        print(json.dumps(out), flush=True)
+
+    for x in (A, B, S, buf):
+        x.free()
+    op.free()
+    if dist is not None:
+        dist.barrier()
+    world.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

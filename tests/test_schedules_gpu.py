@@ -66,3 +66,19 @@ def test_cfg1_scale_vs_oracle(alg, p, c):
     assert T.rel(glob["spmmB"], O.spmm_b(rows, cols, vals, case["A"], m)) <= T.TOL
     assert T.rel(glob["fusedA"], O.fused_a(rows, cols, vals, case["A"], case["B"], ign)[0]) <= T.TOL
     assert T.rel(glob["fusedB"], O.fused_b(rows, cols, vals, case["A"], case["B"], ign)[0]) <= T.TOL
+
+
+def test_rccl_world_single_rank():
+    """The RCCL transport with one rank (all a 1-GPU box allows): communicator init from a unique id, sub-communicator
+    split, self send/recv, all-gather / reduce-scatter of size 1, host collectives staged through the device."""
+    case = T.case_inputs("er8_r16")
+    w = H.World.rccl(0, 1, 0, H.rccl_unique_id())
+    try:
+        for alg in H.ALGORITHMS:
+            out = T.run_all_ops(w, alg, 1, case)
+            assert out["alg_info"]["transport"] == "rccl"
+            T.check_against_golden(T.assemble([out], case), [out], case, alg)
+        vals, ok = w.grid_probe(1, 1, 1, 3)
+        assert ok and vals[:3] == [0, 0, 0]
+    finally:
+        w.close()
