@@ -450,6 +450,11 @@ void RcclWorld::free_comm(Comm& c) {
 
 void RcclWorld::sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes,
                          int src, int stream) {
+    if (comm.ranks[dst] == rank && comm.ranks[src] == rank) {  // ring of one: plain copy, no RCCL call
+        if (sendbytes != recvbytes) fatal("Error, self send/recv size mismatch");
+        if (sendbuf != recvbuf) copy(recvbuf, sendbuf, sendbytes, HNH_COPY_D2D, stream);
+        return;
+    }
     // point-to-point always goes through the world communicator with world ranks: explicit peers
     check(be->hnh_comm_sendrecv(ctx, comm_, sendbuf, sendbytes, comm.ranks[dst], recvbuf, recvbytes, comm.ranks[src], stream),
           "hnh_comm_sendrecv");
@@ -520,6 +525,11 @@ CallbackWorld::~CallbackWorld() { destroy_device(); }
 
 void CallbackWorld::sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes,
                              int src, int stream) {
+    if (comm.ranks[dst] == rank && comm.ranks[src] == rank) {  // ring of one: plain copy
+        if (sendbytes != recvbytes) fatal("Error, self send/recv size mismatch");
+        if (sendbuf != recvbuf) copy(recvbuf, sendbuf, sendbytes, HNH_COPY_D2D, stream);
+        return;
+    }
     sync(stream);  // the callback moves data now: everything that produced sendbuf must have finished
     if (cb_.sendrecv(cb_.user, sendbuf, sendbytes, comm.ranks[dst], recvbuf, recvbytes, comm.ranks[src]) != 0)
         fatal("Error, callback sendrecv failed");

@@ -1,0 +1,96 @@
+"""CPU-only checks of host-side pieces that need no kernel at all: C-ABI symbol coverage of the host library,
+the synthetic generator against its numpy restatement, MatrixMarket input, FlexibleGrid rank maps and
+sub-communicators (FlexibleGrid.hpp:41-135) for all six adjacency orders."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import hnh_testlib as T
+from distributed_sddmm_amd import api as H
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(autouse=True, scope="module")
+def cpu_test_double():
+    H.load_backend(T.ORACLE_BACKEND)
+    yield
+
+
+def test_host_library_exports_every_declared_symbol():
+    txt = open(os.path.join(ROOT, "include", "hnh_dist.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    declared = set(re.findall(r"\b(hnh_[a-z0-9_A-Z]+)\s*\(", txt)) - {"hnh_comm_callbacks"}
+    assert declared == set(H.SIGNATURES), declared ^ set(H.SIGNATURES)
+    lib = H.lib()
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+@pytest.mark.parametrize("m,n,draws,seed", [(256, 256, 2048, 12345), (250, 333, 5000, 7), (1 << 14, 1 << 14, 1 << 18, 99), (5, 3, 100, 1)])
+def test_native_generator_is_bit_identical_to_the_oracle(m, n, draws, seed):
+    r1, c1 = H.generate_er(m, n, draws, seed)
+    r2, c2 = O.erdos_renyi_mn(m, n, draws, seed)
+    assert np.array_equal(r1, r2) and np.array_equal(c1, c2)
+    keys = r1 * n + c1
+    assert np.all(np.diff(keys) > 0), "sorted row-major and free of duplicates"
+
+
+def test_load_tuples_partitions_the_generated_matrix():
+    def body(w):
+        sp = H.SpmatLocal.load_tuples(w, False, 8, 8)
+        info = sp.info()
+        sp.free()
+        return info
+
+    infos = H.run_spmd(4, body)
+    rows, _ = O.erdos_renyi(8, 8)
+    assert all(i["dist_nnz"] == len(rows) and i["M"] == 256 and i["N"] == 256 for i in infos)
+    assert sum(i["local_nnz"] for i in infos) == len(rows)
+
+
+def test_matrix_market_reader(tmp_path):
+    path = tmp_path / "m.mtx"
+    path.write_text("%%MatrixMarket matrix coordinate real symmetric\n% comment\n4 4 4\n1 1 2.0\n3 1 5.0\n3 1 7.0\n4 2 1.5\n")
+
+    def body(w):
+        sp = H.SpmatLocal.load_tuples(w, True, -1, -1, str(path))
+        info = sp.info()
+        sp.free()
+        return info
+
+    info = H.run_spmd(1, body)[0]
+    # (1,1) ; (3,1)+(1,3) with duplicate -> max kept ; (4,2)+(2,4)
+    assert info == {"M": 4, "N": 4, "dist_nnz": 5, "local_nnz": 5}
+
+
+@pytest.mark.parametrize("dims,adjacency", [((4, 2, 1), 1), ((2, 2, 2), 3), ((2, 3, 2), 2), ((3, 2, 2), 4), ((2, 2, 3), 5), ((1, 4, 3), 6)])
+def test_flexible_grid(dims, adjacency):
+    nr, nc, nh = dims
+    p = nr * nc * nh
+    res = H.run_spmd(p, lambda w: (w.rank,) + tuple(w.grid_probe(nr, nc, nh, adjacency)))
+    perms = {1: (0, 1, 2), 2: (0, 2, 1), 3: (1, 0, 2), 4: (1, 2, 0), 5: (2, 0, 1), 6: (2, 1, 0)}[adjacency]
+    seen = set()
+    for rank, vals, ok in res:
+        i, j, k, in_row, in_col, in_fiber, rs, cs, fs = vals
+        assert ok, "broadcast self-test (FlexibleGrid.hpp:169-201)"
+        t = [i, j, k]
+        d = [nr, nc, nh]
+        assert rank == t[perms[0]] + t[perms[1]] * d[perms[0]] + t[perms[2]] * d[perms[0]] * d[perms[1]]
+        assert (in_row, in_col, in_fiber) == (j, i, k) and (rs, cs, fs) == (nc, nr, nh)
+        seen.add((i, j, k))
+    assert len(seen) == p
+
+
+def test_product_backend_is_hip_and_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert H.load_backend(None) == "hip-gfx950"  # the library itself loads (no GPU needed to dlopen)
+    with pytest.raises(H.HnhError) as e:
+        H.World.single(0)
+    assert "no GPU" in str(e.value) or "device" in str(e.value)
+    H.load_backend(T.ORACLE_BACKEND)
