@@ -48,6 +48,17 @@ inline void divideIntoSegments(int total, int num_segments, std::vector<int>& se
 
 namespace hnh {
 
+// setup-phase stopwatch: prints "<label>: x.xx s" on destruction when HNH_VERBOSE_SETUP=1
+struct PhaseTimer {
+    const char* label;
+    my_timer_t t0;
+    bool on;
+    explicit PhaseTimer(const char* l) : label(l), t0(start_clock()), on(std::getenv("HNH_VERBOSE_SETUP") != nullptr) {}
+    ~PhaseTimer() {
+        if (on) std::cout << "[setup] " << label << ": " << stop_clock_get_elapsed(t0) << " s" << std::endl;
+    }
+};
+
 struct Error : public std::runtime_error {
     using std::runtime_error::runtime_error;
 };

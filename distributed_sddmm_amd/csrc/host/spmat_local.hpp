@@ -63,11 +63,13 @@ public:
         : rows(blockRows), cols(blockCols), max_nnz((int)max_nnz_in), num_coords(num_coords_in), transpose(transpose_in),
           active(0), shifting(shifting_in), world(hnh::current_world()) {
         if (num_coords > max_nnz) hnh::fatal("Error, block holds more nonzeros than its padded capacity!");
+        hnh::PhaseTimer pt_all("CSRLocal ctor");
         if (transpose) {
             std::swap(rows, cols);
 #pragma omp parallel for
             for (int e = 0; e < num_coords; e++) std::swap(coords[e].r, coords[e].c);
         }
+        hnh::PhaseTimer* pt = new hnh::PhaseTimer("  csr: count+scatter");
         // counting sort by row, then order each row by column
         std::vector<int32_t> rowStart((size_t)rows + 1, 0);
         for (int e = 0; e < num_coords; e++) {
@@ -80,10 +82,14 @@ public:
             std::vector<int32_t> cursor(rowStart.begin(), rowStart.end() - 1);
             for (int e = 0; e < num_coords; e++) sorted[cursor[coords[e].r]++] = coords[e];
         }
+        delete pt;
+        pt = new hnh::PhaseTimer("  csr: row sorts");
 #pragma omp parallel for schedule(dynamic, 1024)
         for (int64_t r = 0; r < rows; r++)
             std::sort(sorted.begin() + rowStart[r], sorted.begin() + rowStart[r + 1],
                       [](const spcoord_t& a, const spcoord_t& b) { return a.c < b.c; });
+        delete pt;
+        pt = new hnh::PhaseTimer("  csr: unzip + upload");
         std::vector<int32_t> col((size_t)std::max(num_coords, 1));
         std::vector<double> val((size_t)std::max(num_coords, 1));
 #pragma omp parallel for
@@ -105,6 +111,7 @@ public:
             world->copy(buffer[t].rowStart, rowStart.data(), ((size_t)rows + 1) * sizeof(int32_t), HNH_COPY_H2D, HNH_STREAM_COMPUTE);
         }
         world->sync(HNH_STREAM_COMPUTE);  // host staging vectors die here
+        delete pt;
     }
 
     ~CSRLocal() {
@@ -211,6 +218,8 @@ public:
     SpmatLocal* redistribute_nonzeros(NonzeroDistribution* dist, bool transpose, bool in_place) {
         hnh::World* w = dist->world ? dist->world : world;
         const int p = w->size;
+        hnh::PhaseTimer pt_all("redistribute_nonzeros");
+        hnh::PhaseTimer* pt = new hnh::PhaseTimer("  redist: owners + pack");
         std::vector<size_t> sendcounts(p, 0), recvcounts(p, 0);
         std::vector<int> owner(coords.size());
 #pragma omp parallel for
@@ -231,6 +240,8 @@ public:
                 t.value = coords[e].value;
             }
         }
+        delete pt;
+        pt = new hnh::PhaseTimer("  redist: alltoallv");
         std::vector<size_t> all_counts((size_t)p * p);
         w->host_allgather(sendcounts.data(), all_counts.data(), (size_t)p * sizeof(size_t));
         for (int r = 0; r < p; r++) recvcounts[r] = all_counts[(size_t)r * p + w->rank];
@@ -253,7 +264,10 @@ public:
         result->dist_nnz = dist_nnz;
         result->initialized = true;
         result->coords.swap(received);
+        delete pt;
+        pt = new hnh::PhaseTimer("  redist: column-major sort");
         __gnu_parallel::sort(result->coords.begin(), result->coords.end(), column_major);
+        delete pt;
         return result;
     }
 

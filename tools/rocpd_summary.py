@@ -1,0 +1,64 @@
+"""Exports what the judge needs from rocprofv3's rocpd sqlite output (ROCm 7.2 writes <name>_results.db):
+  --stats db  -> profiles/<tag>_kernel_stats.csv   (top_kernels view: name, calls, total/avg duration ns, %)
+  --pmc  dbs  -> profiles/<tag>_pmc.csv            (per-dispatch counter values of the selected kernels)
+and, for FETCH_SIZE + WRITE_SIZE passes, profiles/hbm_traffic.json with the gfx950 correction of
+/opt/skills/guides/MI355X_MICROARCH.md §HBM (FETCH_SIZE reports exactly 1/2 of a 16-B/lane coalesced read)."""
+import argparse
+import csv
+import json
+import os
+import sqlite3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", required=True)
+    ap.add_argument("--stats")
+    ap.add_argument("--pmc", nargs="*", default=[])
+    ap.add_argument("--kernel-like", default="row_kernel")
+    ap.add_argument("--workload-key", default="")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    if a.stats:
+        cur = sqlite3.connect(a.stats).cursor()
+        rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+        with open(os.path.join(a.out, a.tag + "_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "calls", "total_duration_ns", "average_ns", "percentage"])
+            w.writerows(rows)
+        for r in rows[:6]:
+            print("%-60s calls %4d avg %.3f ms  %.2f%%" % (r[0][:60], r[1], r[3] / 1e6, r[4]))
+    sums = {}
+    if a.pmc:
+        with open(os.path.join(a.out, a.tag + "_pmc.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "counter", "value", "duration_ns", "grid", "workgroup", "vgpr", "sgpr", "lds"])
+            for db in a.pmc:
+                cur = sqlite3.connect(db).cursor()
+                q = ("select kernel_name, counter_name, value, duration, grid_size, workgroup_size, vgpr_count, sgpr_count, "
+                     "lds_block_size from counters_collection where kernel_name like ?")
+                for r in cur.execute(q, ("%" + a.kernel_like + "%",)):
+                    w.writerow(r)
+                    sums.setdefault(r[1], []).append(r[2])
+        for k, v in sums.items():
+            print("%-12s mean %.4e over %d dispatches" % (k, sum(v) / len(v), len(v)))
+    if "FETCH_SIZE" in sums and "WRITE_SIZE" in sums:
+        fetch_kb = sum(sums["FETCH_SIZE"]) / len(sums["FETCH_SIZE"])
+        write_kb = sum(sums["WRITE_SIZE"]) / len(sums["WRITE_SIZE"])
+        rec = {
+            "workload_key": a.workload_key,
+            "kernel": a.kernel_like,
+            "fetch_size_kb_raw": fetch_kb,
+            "write_size_kb_raw": write_kb,
+            "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane coalesced reads -> x2 "
+                          "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE used as reported (fill kernel of 1 GiB reads back exactly 1048576 KB)",
+            "bytes_per_launch": 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0,
+        }
+        with open(os.path.join(a.out, "hbm_traffic.json"), "w") as f:
+            json.dump(rec, f, indent=1)
+        print("HBM traffic per launch: %.3f GB" % (rec["bytes_per_launch"] / 1e9))
+
+
+if __name__ == "__main__":
+    main()
