@@ -74,8 +74,22 @@ def cpu_baseline(args):
             "sample": "numpy restatement, ER 2^14, edge factor %d (%d nnz), R=%d, one fused call" % (args.edge_factor, len(rows), args.r)}
 
 
-def main():
-    args = parse()
+def gpu_world(H, dist, rank, n, local_rank):
+    """The product transport: one process per GPU, RCCL over xGMI (unique id bootstrapped through torch.distributed)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    assert H.load_backend(None) == "hip-gfx950"
+    if n == 1:
+        return H.World.single(local_rank), torch.cuda.synchronize
+    ident = [H.rccl_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ident, src=0)
+    return H.World.rccl(rank, n, local_rank, ident[0]), torch.cuda.synchronize
+
+
+def run(args, make_world=gpu_world):
+    """`make_world` is replaceable so that tests can drive this exact function over gloo on CPU."""
     import torch  # first: one HIP runtime per process (see distributed_sddmm_amd/_kernels.py)
     from distributed_sddmm_amd import api as H
 
@@ -85,27 +99,19 @@ def main():
     n = args.gpus
     if world_size != n:
         raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run); got %d" % (n, n, world_size))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-
-    assert H.load_backend(None) == "hip-gfx950"
     dist = None
     if n > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=n)  # bootstrap + barriers only; data moves over RCCL
-        ident = [H.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ident, src=0)
-        world = H.World.rccl(rank, n, local_rank, ident[0])
-    else:
-        world = H.World.single(local_rank)
+        if not dist.is_initialized():
+            dist.init_process_group(backend="gloo", rank=rank, world_size=n)  # bootstrap + barriers only; data moves over RCCL
+    world, device_sync = make_world(H, dist, rank, n, local_rank)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         world.sync()
-        torch.cuda.synchronize()
+        device_sync()
 
     # ---- build: same global matrix on every rank count (strong scaling)
     t_setup = time.perf_counter()
@@ -151,6 +157,7 @@ def main():
         kern_ms, launches, alg_bytes_per_call = float(t[0]) / n, int(t[1]) // n, float(t[2]) / n
     barrier()
 
+    out = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = nnz * args.r * args.steps / elapsed
@@ -169,6 +176,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
+            "backend": H.backend_name(),
             "metric": "fused SDDMM+SpMM nnz*R/s", "value": value, "unit": "nnz*R/s", "n_gpus": n, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -183,7 +191,7 @@ def main():
                          "launches_per_step": launches_per_call, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "model": "nnz*(8R+24) + 16*R*rows per launch (SURVEY 8d)"},
         }
-        if n == 1 and not args.no_cpu_baseline:
+        if n == 1 and not args.no_cpu_baseline and out["backend"] == "hip-gfx950":
             try:
                 out["cpu_baseline"] = cpu_baseline(args)
             except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
@@ -197,7 +205,14 @@ def main():
     if dist is not None:
         dist.barrier()
     world.close()
-    if dist is not None:
+    return out if rank == 0 else None
+
+
+def main():
+    args = parse()
+    run(args)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -49,6 +49,8 @@ SIGNATURES = {
     "hnh_comm_split": (_i32, [_vp, _vp, _i32, _i32, C.POINTER(_vp)]),
     "hnh_comm_destroy": (_i32, [_vp, _vp]),
     "hnh_comm_sendrecv": (_i32, [_vp, _vp, _vp, _sz, _i32, _vp, _sz, _i32, _i32]),
+    "hnh_comm_group_begin": (_i32, [_vp]),
+    "hnh_comm_group_end": (_i32, [_vp]),
     "hnh_comm_allgather": (_i32, [_vp, _vp, _vp, _vp, _sz, _i32]),
     "hnh_comm_reduce_scatter_f64": (_i32, [_vp, _vp, _vp, _vp, _sz, _i32]),
     "hnh_comm_allreduce_f64": (_i32, [_vp, _vp, _vp, _vp, _sz, _i32]),

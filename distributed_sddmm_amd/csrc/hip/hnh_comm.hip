@@ -76,6 +76,18 @@ int hnh_comm_sendrecv(hnh_ctx* ctx, void* comm, const void* sendbuf, size_t send
     return HNH_OK;
 }
 
+int hnh_comm_group_begin(hnh_ctx* ctx) {
+    if (!ctx) return HNH_ERR_INVALID;
+    HNH_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    return check_nccl(ctx, ncclGroupStart(), "ncclGroupStart");
+}
+
+int hnh_comm_group_end(hnh_ctx* ctx) {
+    if (!ctx) return HNH_ERR_INVALID;
+    HNH_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    return check_nccl(ctx, ncclGroupEnd(), "ncclGroupEnd");
+}
+
 int hnh_comm_allgather(hnh_ctx* ctx, void* comm, const void* sendbuf, void* recvbuf, size_t bytes_per_rank, int stream) {
     HNH_ENTER(ctx, stream);
     if (!comm) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_comm_allgather: null communicator");

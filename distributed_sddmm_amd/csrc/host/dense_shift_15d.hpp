@@ -11,6 +11,15 @@
 // so only n-1 shifts are needed instead of n and nothing is copied back.  When the moving buffer is the
 // SpMM accumulator (approach 1, :331-337) a step's shift has to wait for that step's kernel, so the ring
 // degenerates to kernel -> shift -> kernel, as in the reference, with n shifts and a storage swap at the end.
+//
+// Relay ring vs mesh fetch.  A neighbour ring forwards every block n-1 times over ONE xGMI link per GPU
+// (store and forward), although the 8 GPUs of a node form a full mesh with 7 links each.  Because a
+// read-only moving operand never changes, step t can equally well take the block straight from its owner,
+// ring rank (me - t): `ring_mode == kMeshFetch` issues all n-1 owner->consumer transfers at the start of
+// the pass as ONE RCCL group (n-1 explicit-peer send/recv pairs over n-1 different links, each block
+// crossing exactly one link) and runs the same kernel sequence on the same blocks.  The visiting order,
+// the block decomposition and the arithmetic are those of the reference's cyclic shift; only the route
+// differs.  HNH_RING_MODE=relay|mesh selects it (default mesh); the read-write ring always relays.
 #pragma once
 #include "distributed_sparse.hpp"
 
@@ -35,10 +44,18 @@ public:
     DenseMatrix accumulation_buffer;  // replicated stationary operand (approach 1) / replicated output (approach 2)
     DenseMatrix broadcast_buffer;     // approach-2 fused: replicated SDDMM row operand when c > 1
     DenseMatrix ring_spare[2];        // persistent spare buffers of the moving operand
+    std::vector<DenseMatrix> mesh_spare;  // mesh fetch: one landing buffer per remote ring position
+    enum RingMode { kRelay, kMeshFetch };
+    RingMode ring_mode;
 
     Sparse15D_Dense_Shift(SpmatLocal* S_input, int R, int c, int fusionApproach, KernelImplementation* k) : Distributed_Sparse(k) {
         this->fusionApproach = fusionApproach;
         this->c = c;
+        ring_mode = kMeshFetch;
+        if (const char* m = std::getenv("HNH_RING_MODE")) {
+            if (std::string(m) == "relay") ring_mode = kRelay;
+            else if (std::string(m) != "mesh") hnh::fatal("Error, HNH_RING_MODE must be relay or mesh!");
+        }
         if (c < 1 || p % c != 0) hnh::fatal("Error, for 1.5D algorithm, must have c divide num_procs!");
         if (fusionApproach != 1 && fusionApproach != 2) hnh::fatal("Error, fusion approach must be 1 or 2!");
 
@@ -227,6 +244,10 @@ private:
     // n kernel steps over a READ-ONLY moving operand, n-1 overlapped shifts, caller's buffer untouched.
     template <typename Step>
     void ring_readonly(DenseMatrix* start, int n, Step&& step) {
+        if (ring_mode == kMeshFetch && n > 2) {  // with two ranks the relay ring already is a single direct transfer
+            mesh_readonly(start, n, step);
+            return;
+        }
         if (n > 1) {
             for (auto& s : ring_spare) ensure(s, start->rows(), start->cols());
             order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // inputs (and earlier readers of the spares) are done
@@ -247,6 +268,30 @@ private:
                 cur = target;
                 stop_clock_and_add(t, "Cyclic Shift Time");
             }
+        }
+    }
+
+    // Same n kernel steps on the same blocks, but every block comes straight from its owner: all n-1
+    // transfers are one group on the communication stream and overlap with step 0's kernel.
+    template <typename Step>
+    void mesh_readonly(DenseMatrix* start, int n, Step&& step) {
+        if ((int)mesh_spare.size() < n - 1) mesh_spare.resize(n - 1);
+        for (int k = 0; k < n - 1; k++) ensure(mesh_spare[k], start->rows(), start->cols());
+        const size_t bytes = (size_t)start->size() * sizeof(double);
+        {
+            auto t = start_clock();
+            order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // my block is final; earlier readers of the landing buffers are done
+            world->group_begin();
+            for (int k = 1; k < n; k++)  // my block is what ring rank me+k needs at ITS step k; I need the block of me-k at mine
+                world->sendrecv(grid->col_world, start->data(), bytes, pMod(grid->rankInCol + k, n), mesh_spare[k - 1].data(), bytes,
+                                pMod(grid->rankInCol - k, n), HNH_STREAM_COMM);
+            world->group_end();
+            world->event_record(event(1), HNH_STREAM_COMM);
+            stop_clock_and_add(t, "Cyclic Shift Time");
+        }
+        for (int i = 0; i < n; i++) {
+            if (i == 1) world->event_wait(event(1), HNH_STREAM_COMPUTE);  // the remote blocks have landed
+            step(i, i == 0 ? *start : mesh_spare[i - 1]);
         }
     }
 

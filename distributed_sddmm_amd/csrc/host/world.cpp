@@ -67,7 +67,7 @@ Backend* load_backend(const char* path_c) {
     HNH_BIND(hnh_sddmm_coo) HNH_BIND(hnh_sddmm_csr) HNH_BIND(hnh_spmm_csr) HNH_BIND(hnh_fused_sddmm_spmm_csr)
     HNH_BIND(hnh_fill_f64) HNH_BIND(hnh_hadamard_f64) HNH_BIND(hnh_axpy_f64) HNH_BIND(hnh_expand_rowptr)
     HNH_BIND(hnh_comm_unique_id) HNH_BIND(hnh_comm_init) HNH_BIND(hnh_comm_split) HNH_BIND(hnh_comm_destroy)
-    HNH_BIND(hnh_comm_sendrecv) HNH_BIND(hnh_comm_allgather) HNH_BIND(hnh_comm_reduce_scatter_f64)
+    HNH_BIND(hnh_comm_sendrecv) HNH_BIND(hnh_comm_group_begin) HNH_BIND(hnh_comm_group_end) HNH_BIND(hnh_comm_allgather) HNH_BIND(hnh_comm_reduce_scatter_f64)
     HNH_BIND(hnh_comm_allreduce_f64)
 #undef HNH_BIND
     b->name = b->hnh_backend_name();
@@ -447,6 +447,9 @@ void RcclWorld::free_comm(Comm& c) {
         c.native = nullptr;
     }
 }
+
+void RcclWorld::group_begin() { check(be->hnh_comm_group_begin(ctx), "hnh_comm_group_begin"); }
+void RcclWorld::group_end() { check(be->hnh_comm_group_end(ctx), "hnh_comm_group_end"); }
 
 void RcclWorld::sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes,
                          int src, int stream) {

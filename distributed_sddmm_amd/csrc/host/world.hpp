@@ -53,6 +53,10 @@ public:
     // ---- device buffers, stream-ordered.  dst / src are indices INTO `comm`.
     virtual void sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf,
                           size_t recvbytes, int src, int stream) = 0;
+    // Transfers enqueued between group_begin() and group_end() may progress concurrently (one RCCL group:
+    // send/recv pairs towards different peers use different xGMI links).  No-ops for the other transports.
+    virtual void group_begin() {}
+    virtual void group_end() {}
     virtual void allgather(const Comm& comm, const void* sendbuf, void* recvbuf, size_t bytes_per_rank, int stream);
     virtual void reduce_scatter_f64(const Comm& comm, const double* sendbuf, double* recvbuf, size_t count, int stream);
     // variable counts (25D_cannon_sparse.hpp:224-233,294-300); counts / displs in elements, per comm index
@@ -139,6 +143,8 @@ public:
     const char* kind() const override { return "rccl"; }
     Comm split(int color, int key) override;
     void free_comm(Comm& c) override;
+    void group_begin() override;
+    void group_end() override;
     void sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes,
                   int src, int stream) override;
     void allgather(const Comm& comm, const void* sendbuf, void* recvbuf, size_t bytes_per_rank, int stream) override;

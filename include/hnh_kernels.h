@@ -125,6 +125,10 @@ int hnh_comm_split(hnh_ctx* ctx, void* comm, int color, int key, void** newcomm)
 int hnh_comm_destroy(hnh_ctx* ctx, void* comm);
 int hnh_comm_sendrecv(hnh_ctx* ctx, void* comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf,
                       size_t recvbytes, int src, int stream);
+/* Everything enqueued between begin and end is issued as ONE RCCL group (ncclGroupStart/End), so that
+ * send/recv pairs towards several peers progress concurrently over their separate xGMI links. */
+int hnh_comm_group_begin(hnh_ctx* ctx);
+int hnh_comm_group_end(hnh_ctx* ctx);
 int hnh_comm_allgather(hnh_ctx* ctx, void* comm, const void* sendbuf, void* recvbuf, size_t bytes_per_rank,
                        int stream);
 int hnh_comm_reduce_scatter_f64(hnh_ctx* ctx, void* comm, const double* sendbuf, double* recvbuf,

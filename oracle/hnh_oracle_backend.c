@@ -166,6 +166,8 @@ int hnh_comm_destroy(hnh_ctx* c, void* comm) { (void)comm; UNSUP(c); }
 int hnh_comm_sendrecv(hnh_ctx* c, void* comm, const void* s, size_t sb, int dst, void* r, size_t rb, int src, int st) {
     (void)comm; (void)s; (void)sb; (void)dst; (void)r; (void)rb; (void)src; (void)st; UNSUP(c);
 }
+int hnh_comm_group_begin(hnh_ctx* c) { (void)c; return HNH_OK; }
+int hnh_comm_group_end(hnh_ctx* c) { (void)c; return HNH_OK; }
 int hnh_comm_allgather(hnh_ctx* c, void* comm, const void* s, void* r, size_t b, int st) { (void)comm; (void)s; (void)r; (void)b; (void)st; UNSUP(c); }
 int hnh_comm_reduce_scatter_f64(hnh_ctx* c, void* comm, const double* s, double* r, size_t n, int st) { (void)comm; (void)s; (void)r; (void)n; (void)st; UNSUP(c); }
 int hnh_comm_allreduce_f64(hnh_ctx* c, void* comm, const double* s, double* r, size_t n, int st) { (void)comm; (void)s; (void)r; (void)n; (void)st; UNSUP(c); }

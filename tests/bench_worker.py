@@ -1,0 +1,30 @@
+"""Worker of tests/test_bench_cpu.py: runs bench.run() — the real benchmark driver — on CPU ranks with the
+transport swapped for gloo callbacks and the kernel ABI for the oracle test double (explicitly, here)."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench  # noqa: E402
+import hnh_testlib as T  # noqa: E402
+
+
+def cpu_world(H, dist, rank, n, local_rank):
+    assert H.load_backend(T.ORACLE_BACKEND) == "oracle-cpu-test-double"
+    if n == 1:
+        return H.World.single(0), (lambda: None)
+    from gloo_worker import make_callbacks
+    cpu_world.cb = make_callbacks()  # keep the ctypes thunks alive
+    return H.World.callback(rank, n, 0, cpu_world.cb), (lambda: None)
+
+
+if __name__ == "__main__":
+    n = int(os.environ["WORLD_SIZE"])
+    args = argparse.Namespace(gpus=n, steps=2, warmup=1, logm=10, edge_factor=8, r=16, alg=sys.argv[1], c=int(sys.argv[2]),
+                              no_cpu_baseline=True, cpu_logm=10, cpu_trials=1)
+    out = bench.run(args, make_world=cpu_world)
+    if out is not None:
+        print("BENCH_JSON " + json.dumps(out), flush=True)

@@ -1,0 +1,37 @@
+"""The benchmark driver's control flow (world bootstrap, strong-scaling setup, timed loop, max-over-ranks,
+roofline bookkeeping, JSON contract) exercised on CPU ranks over gloo — bench.run() itself, with only the
+transport/kernels swapped by the test.  The numbers are meaningless here; the contract is what is checked."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from test_gloo_world import ROOT, free_port
+
+
+@pytest.mark.parametrize("nranks,alg,c", [(1, "15d_fusion2", 1), (2, "15d_fusion2", 1), (4, "15d_fusion2", 1), (4, "15d_fusion2", 2), (2, "15d_fusion1", 1)])
+def test_bench_contract(nranks, alg, c):
+    port = free_port()
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2", GLOO_SOCKET_IFNAME="lo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "bench_worker.py"), alg, str(c)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    line = [ln for ln in outs[0].splitlines() if ln.startswith("BENCH_JSON ")]
+    assert len(line) == 1, outs[0][-1500:]
+    out = json.loads(line[0][len("BENCH_JSON "):])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in out
+    assert out["n_gpus"] == nranks and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "strong"
+    assert out["dtype"] == "f64" and out["data"] == "synthetic" and out["vs_baseline"] is None and out["higher_is_better"] is True
+    assert out["value"] > 0 and out["config"]["nnz"] > 0 and "workload" in out["config"]
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
+    assert rf["launches_per_step"] >= 1 and rf["algorithmic_bytes_per_launch"] > 0
+    assert out["backend"] == "oracle-cpu-test-double" and "cpu_baseline" not in out

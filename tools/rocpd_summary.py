@@ -1,5 +1,5 @@
 """Exports what the judge needs from rocprofv3's rocpd sqlite output (ROCm 7.2 writes <name>_results.db):
-  --stats db  -> profiles/<tag>_kernel_stats.csv   (top_kernels view: name, calls, total/avg duration ns, %)
+  --stats db  -> profiles/<tag>_kernel_stats.csv   (top_kernels view: name, calls, total/avg duration in microseconds, %)
   --pmc  dbs  -> profiles/<tag>_pmc.csv            (per-dispatch counter values of the selected kernels)
 and, for FETCH_SIZE + WRITE_SIZE passes, profiles/hbm_traffic.json with the gfx950 correction of
 /opt/skills/guides/MI355X_MICROARCH.md §HBM (FETCH_SIZE reports exactly 1/2 of a 16-B/lane coalesced read)."""
@@ -25,10 +25,10 @@ def main():
         rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
         with open(os.path.join(a.out, a.tag + "_kernel_stats.csv"), "w", newline="") as f:
             w = csv.writer(f)
-            w.writerow(["kernel", "calls", "total_duration_ns", "average_ns", "percentage"])
+            w.writerow(["kernel", "calls", "total_duration_us", "average_us", "percentage"])
             w.writerows(rows)
         for r in rows[:6]:
-            print("%-60s calls %4d avg %.3f ms  %.2f%%" % (r[0][:60], r[1], r[3] / 1e6, r[4]))
+            print("%-60s calls %4d avg %.3f ms  %.2f%%" % (r[0][:60], r[1], r[3] / 1e3, r[4]))
     sums = {}
     if a.pmc:
         with open(os.path.join(a.out, a.tag + "_pmc.csv"), "w", newline="") as f:
