@@ -76,7 +76,7 @@ def load(path: str | None = None) -> C.CDLL:
             import torch  # noqa: F401
         except ImportError:
             pass
-    lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(p)  # RTLD_LOCAL: the oracle test double exports the same symbol names
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args

@@ -118,7 +118,7 @@ def lib() -> C.CDLL:
                     import torch  # noqa: F401
                 except ImportError:
                     pass
-            l = C.CDLL(HOST_LIB, mode=C.RTLD_GLOBAL)
+            l = C.CDLL(HOST_LIB)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(l, name)
                 fn.restype, fn.argtypes = res, args

@@ -8,4 +8,4 @@ mkdir -p "$HERE/../lib"
 g++ -O2 -g -std=c++17 -fopenmp -fPIC -shared -Wall -Wno-sign-compare -Wno-unused-variable \
     -I"$ROOT/include" -I"$HERE/host" \
     "$HERE/host/world.cpp" "$HERE/host/sparse_kernels.cpp" "$HERE/host/er_generator.cpp" "$HERE/host/c_api.cpp" \
-    -o "$HERE/../lib/libhnh_host.so" -ldl -lpthread
+    -o "$HERE/../lib/libhnh_host.so" -ldl -lpthread -Wl,-Bsymbolic

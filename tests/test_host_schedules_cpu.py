@@ -90,3 +90,13 @@ def test_configuration_errors_are_reported():
     assert "perfect square" in errs[1]                      # 25D_cannon_dense.hpp:61-67
     assert "divisible by p / c" in errs[2]                  # 15D_sparse_shift.hpp:147-149
     assert "unknown algorithm" in errs[3]
+
+
+@pytest.mark.parametrize("mode", ["relay", "mesh"])
+@pytest.mark.parametrize("alg,p,c", [("15d_fusion2", 4, 1), ("15d_fusion2", 8, 1), ("15d_fusion2", 8, 2), ("15d_fusion1", 8, 1), ("15d_fusion1", 4, 1)])
+def test_relay_ring_and_mesh_fetch_agree_with_the_reference(monkeypatch, mode, alg, p, c):
+    """HNH_RING_MODE: neighbour relay ring vs owner->consumer mesh fetch of the read-only moving operand."""
+    monkeypatch.setenv("HNH_RING_MODE", mode)
+    case = T.case_inputs("er8_r16")
+    per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
+    T.check_against_golden(T.assemble(per_rank, case), per_rank, case, alg)
