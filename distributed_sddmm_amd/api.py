@@ -61,6 +61,7 @@ SIGNATURES = {
     "hnh_spmat_info": (_i32, [_vp, _pi64]),
     "hnh_spmat_destroy": (_i32, [_vp]),
     "hnh_er_generate": (_i32, [_u64, _u64, _u64, _u64, _pvp, _pi64]),
+    "hnh_rmat_generate": (_i32, [_i32, _u64, _dbl, _dbl, _dbl, _u64, _i32, _pvp, _pi64]),
     "hnh_er_fetch": (_i32, [_vp, _vp, _vp]),
     "hnh_dist_create": (_i32, [_vp, C.c_char_p, _vp, _i32, _i32, _pvp]),
     "hnh_dist_destroy": (_i32, [_vp]),
@@ -146,6 +147,15 @@ def generate_er(m: int, n: int, draws: int, seed: int = 12345):
     """The shared synthetic generator (native, OpenMP); bit-identical to oracle.erdos_renyi_mn."""
     h, cnt = _vp(), _i64()
     _check(lib().hnh_er_generate(m, n, draws, seed, C.byref(h), C.byref(cnt)), "hnh_er_generate")
+    rows, cols = np.empty(cnt.value, np.int64), np.empty(cnt.value, np.int64)
+    _check(lib().hnh_er_fetch(h, rows.ctypes.data, cols.ctypes.data), "hnh_er_fetch")
+    return rows, cols
+
+
+def generate_rmat(logm: int, edges: int, a: float = 0.57, b: float = 0.19, c: float = 0.19, seed: int = 12345, scramble: bool = True):
+    """Graph500-style R-MAT (skewed degrees), de-duplicated and sorted row-major; twin of oracle.rmat."""
+    h, cnt = _vp(), _i64()
+    _check(lib().hnh_rmat_generate(logm, edges, a, b, c, seed, int(scramble), C.byref(h), C.byref(cnt)), "hnh_rmat_generate")
     rows, cols = np.empty(cnt.value, np.int64), np.empty(cnt.value, np.int64)
     _check(lib().hnh_er_fetch(h, rows.ctypes.data, cols.ctypes.data), "hnh_er_fetch")
     return rows, cols

@@ -196,6 +196,15 @@ int hnh_er_generate(uint64_t m, uint64_t n, uint64_t draws, uint64_t seed, void*
         *handle = k;
     });
 }
+int hnh_rmat_generate(int logm, uint64_t edges, double a, double b, double c, uint64_t seed, int scramble, void** handle,
+                      int64_t* count) {
+    return guarded(nullptr, [&] {
+        if (logm < 1 || logm > 31 || a < 0 || b < 0 || c < 0 || a + b + c > 1.0) hnh::fatal("Error, bad R-MAT parameters");
+        auto* k = new ErKeys{1ull << logm, hnh::rmat_keys(logm, edges, a, b, c, seed, scramble != 0)};
+        *count = (int64_t)k->keys.size();
+        *handle = k;
+    });
+}
 int hnh_er_fetch(void* handle, int64_t* rows, int64_t* cols) {
     ErKeys* k = static_cast<ErKeys*>(handle);
     const uint64_t n = k->n;

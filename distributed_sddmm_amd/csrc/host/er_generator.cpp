@@ -24,6 +24,31 @@ std::vector<uint64_t> erdos_renyi_keys(uint64_t m, uint64_t n, uint64_t draws, u
     return keys;
 }
 
+std::vector<uint64_t> rmat_keys(int logm, uint64_t edges, double a, double b, double c, uint64_t seed, bool scramble) {
+    std::vector<uint64_t> keys(edges);
+    const uint64_t G = 0x9E3779B97F4A7C15ull, n = 1ull << logm, mask = n - 1;
+    const double ab = a + b, abc = a + b + c;
+#pragma omp parallel for
+    for (uint64_t k = 0; k < edges; k++) {
+        uint64_t r = 0, col = 0;
+        for (int l = 0; l < logm; l++) {
+            const double u = (double)(splitmix64(seed + (k * (uint64_t)logm + (uint64_t)l) * G) >> 11) * 0x1.0p-53;
+            const uint64_t rb = (u >= ab) ? 1 : 0;
+            const uint64_t cb = (u >= a && u < ab) || (u >= abc) ? 1 : 0;
+            r = (r << 1) | rb;
+            col = (col << 1) | cb;
+        }
+        if (scramble) {
+            r = (r * 0x9E3779B1ull + 0x7F4A7C15ull) & mask;
+            col = (col * 0x9E3779B1ull + 0x7F4A7C15ull) & mask;
+        }
+        keys[k] = r * n + col;
+    }
+    __gnu_parallel::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    return keys;
+}
+
 void read_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std::vector<spcoord_t>& tuples) {
     std::ifstream in(path);
     if (!in) fatal("Error, cannot open matrix file " + path);

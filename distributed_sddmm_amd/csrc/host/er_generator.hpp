@@ -21,6 +21,14 @@ inline uint64_t splitmix64(uint64_t x) {
 // Sorted (row-major), de-duplicated keys row * n + col of the whole matrix.
 std::vector<uint64_t> erdos_renyi_keys(uint64_t m, uint64_t n, uint64_t draws, uint64_t seed);
 
+// Skewed stand-in for real graphs (BASELINE config 4 names com-Orkut, which is not available offline):
+// Graph500-style R-MAT on 2^logm vertices with initiator (a, b, c, 1-a-b-c).  Edge k, level l draws
+//     u = (splitmix64(seed + (k*logm + l)*G) >> 11) * 2^-53   and picks the quadrant by thresholds;
+// with `scramble` vertex v is renamed to (v * 0x9E3779B1 + 0x7F4A7C15) mod 2^logm (a bijection), the
+// counterpart of the reference's PermEdges/RenameVertices load-balancing step (SpmatLocal.hpp:506-507).
+// Bit-identical twin: oracle/oracle.py:rmat.
+std::vector<uint64_t> rmat_keys(int logm, uint64_t edges, double a, double b, double c, uint64_t seed, bool scramble);
+
 // MatrixMarket coordinate reader (general / symmetric; pattern, integer or real); duplicates keep the
 // maximum, as the reference's `maximum<double>()` reduction does (SpmatLocal.hpp:487).  Returns all tuples.
 void read_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std::vector<spcoord_t>& tuples);

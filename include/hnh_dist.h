@@ -89,6 +89,9 @@ int hnh_spmat_info(hnh_spmat* s, int64_t out4[4]); /* M, N, dist_nnz, local tupl
 int hnh_spmat_destroy(hnh_spmat* s);
 /* the shared synthetic generator (bit-identical to oracle/oracle.py:erdos_renyi_mn) */
 int hnh_er_generate(uint64_t m, uint64_t n, uint64_t draws, uint64_t seed, void** handle, int64_t* count);
+/* skewed R-MAT stand-in for real graphs (initiator a, b, c, 1-a-b-c; twin: oracle/oracle.py:rmat) */
+int hnh_rmat_generate(int logm, uint64_t edges, double a, double b, double c, uint64_t seed, int scramble, void** handle,
+                      int64_t* count);
 int hnh_er_fetch(void* handle, int64_t* rows, int64_t* cols); /* also frees the handle */
 
 /* ---- operator construction (benchmark_dist.cpp:45-82): alg in

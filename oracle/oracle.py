@@ -68,6 +68,27 @@ def erdos_renyi(log_m: int, edge_factor: int, seed: int = 12345):
     return erdos_renyi_mn(m, m, m * edge_factor, seed)
 
 
+def rmat(log_m: int, edges: int, a: float = 0.57, b: float = 0.19, c: float = 0.19, seed: int = 12345, scramble: bool = True):
+    """Graph500-style R-MAT stand-in for skewed real graphs (BASELINE config 4); twin of hnh::rmat_keys."""
+    n = np.uint64(1 << log_m)
+    with np.errstate(over="ignore"):
+        k = np.arange(edges, dtype=np.uint64)
+        r = np.zeros(edges, dtype=np.uint64)
+        col = np.zeros(edges, dtype=np.uint64)
+        for lvl in range(log_m):
+            h = splitmix64(np.uint64(seed) + (k * np.uint64(log_m) + np.uint64(lvl)) * _GOLDEN)
+            u = (h >> np.uint64(11)).astype(np.float64) * (2.0 ** -53)
+            rb = (u >= a + b).astype(np.uint64)
+            cb = (((u >= a) & (u < a + b)) | (u >= a + b + c)).astype(np.uint64)
+            r = (r << np.uint64(1)) | rb
+            col = (col << np.uint64(1)) | cb
+        if scramble:
+            r = (r * np.uint64(0x9E3779B1) + np.uint64(0x7F4A7C15)) & (n - np.uint64(1))
+            col = (col * np.uint64(0x9E3779B1) + np.uint64(0x7F4A7C15)) & (n - np.uint64(1))
+        keys = np.unique(r * n + col)
+    return (keys // n).astype(np.int64), (keys % n).astype(np.int64)
+
+
 def hashed_uniform(keys: np.ndarray, seed: int) -> np.ndarray:
     """uniform(-1, 1) fp64 as a pure function of (key, seed)."""
     with np.errstate(over="ignore"):

@@ -60,7 +60,12 @@ def main():
     cb = make_callbacks()
     world = H.World.callback(rank, n, 0, cb)
     case_name, configs = sys.argv[1], sys.argv[2]
-    case = T.case_inputs(case_name)
+    if case_name == "cfg1":  # BASELINE config 1: ER 2^16 x 2^16, edge factor 16, R = 16 (checked against the oracle)
+        from oracle import oracle as O
+        rows, cols = O.erdos_renyi(16, 16)
+        case = T.make_case("cfg1", 1 << 16, 1 << 16, 16, rows, cols)
+    else:
+        case = T.case_inputs(case_name)
     failures = []
     for item in configs.split(";"):
         alg, c = item.split(":")
@@ -69,7 +74,10 @@ def main():
         dist.all_gather_object(gathered, out)
         if rank == 0:
             try:
-                T.check_against_golden(T.assemble(gathered, case), gathered, case, alg)
+                if case_name == "cfg1":
+                    T.check_against_oracle(T.assemble(gathered, case), case, alg)
+                else:
+                    T.check_against_golden(T.assemble(gathered, case), gathered, case, alg)
                 assert gathered[0]["alg_info"]["transport"] == "callback"
             except AssertionError as e:
                 failures.append("%s c=%s: %r" % (alg, c, e))

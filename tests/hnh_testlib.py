@@ -204,3 +204,29 @@ def check_against_golden(glob: dict, per_rank: list, case: dict, alg: str, tol: 
     for o in per_rank:  # inputs intact after an SDDMM
         assert np.array_equal(o["A_after_sddmmA"], o["A_expected"])
         assert np.array_equal(o["B_after_sddmmA"], o["B_expected"])
+
+
+def make_case(name, m, n, r, rows, cols, seed=11):
+    """A case with hashed S values / dense fills, for inputs that have no golden fixture (checked vs the oracle)."""
+    return dict(name=name, M=m, N=n, R=r, rows=rows, cols=cols, vals=O.sparse_values(rows, cols, n, seed),
+                A=O.dense_fill(m, r, seed + 1), B=O.dense_fill(n, r, seed + 2))
+
+
+def check_against_oracle(glob: dict, case: dict, alg: str, tol: float = TOL):
+    """Same checks as check_against_golden, against oracle/oracle.py (itself pinned to the reference by
+    tests/test_oracle_golden.py) — for sizes / matrices that have no committed fixture."""
+    rows, cols, vals, a, b, m, n = case["rows"], case["cols"], case["vals"], case["A"], case["B"], case["M"], case["N"]
+    keys = rows * n + cols
+    ign = alg == "15d_fusion2"
+    want_sddmm = O.sddmm(rows, cols, vals, a, b)
+    for name in ("sddmmA", "sddmmB"):
+        assert np.array_equal(glob[name][0], keys), (alg, name)
+        assert rel(glob[name][1], want_sddmm) <= tol, (alg, name, rel(glob[name][1], want_sddmm))
+    assert rel(glob["spmmA"], O.spmm_a(rows, cols, vals, b, m)) <= tol
+    assert rel(glob["spmmB"], O.spmm_b(rows, cols, vals, a, n)) <= tol
+    fa, mid = O.fused_a(rows, cols, vals, a, b, ign)
+    fb, _ = O.fused_b(rows, cols, vals, a, b, ign)
+    assert rel(glob["fusedA"], fa) <= tol and rel(glob["fusedB"], fb) <= tol
+    if not ign:
+        assert rel(glob["fusedA_buf"][1], mid) <= tol and rel(glob["fusedB_buf"][1], mid) <= tol
+    assert rel(glob["fingerprints"], np.array(O.fingerprints(rows, cols, m, n, case["R"]))) <= tol

@@ -1,0 +1,40 @@
+"""BASELINE.json configurations as parity-test cases on CPU ranks (host logic + transports; kernels served by
+the oracle test double):  config 1 exactly (ER 2^16, ~1e6 nnz, R = 16, 1.5D sparse shift, world = 2 over gloo) and
+the shape of config 4 (skewed graph, 2.5D dense-replicate, p = 8, c = 2) on an R-MAT stand-in."""
+import numpy as np
+import pytest
+
+import hnh_testlib as T
+from distributed_sddmm_amd import api as H
+from oracle import oracle as O
+from test_gloo_world import launch
+
+
+@pytest.fixture(autouse=True, scope="module")
+def cpu_test_double():
+    H.load_backend(T.ORACLE_BACKEND)
+    yield
+
+
+def test_rmat_generator_twin_and_skew():
+    r1, c1 = H.generate_rmat(12, 4096 * 16)
+    r2, c2 = O.rmat(12, 4096 * 16)
+    assert np.array_equal(r1, r2) and np.array_equal(c1, c2)
+    deg = np.bincount(r1, minlength=4096)
+    assert deg.max() > 20 * deg.mean(), "R-MAT must be skewed (hub rows)"
+
+
+def test_config1_sparse_shift_world2_gloo():
+    procs, outs = launch(2, "cfg1", "15d_sparse:1", timeout=600)
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    assert "GLOO_OK" in outs[0], outs[0][-2000:]
+
+
+@pytest.mark.parametrize("alg,p,c", [("25d_dense_replicate", 8, 2), ("25d_sparse_replicate", 8, 2), ("15d_fusion2", 8, 2), ("15d_sparse", 4, 1)])
+def test_config4_shape_skewed_graph(alg, p, c):
+    rows, cols = H.generate_rmat(10, 1024 * 12)
+    case = T.make_case("rmat10", 1024, 1024, 32, rows, cols)
+    per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
+    imbalance = per_rank[0]["alg_info"]["nnz_procs"]
+    assert sum(imbalance) == len(rows) * (c if alg == "25d_sparse_replicate" else 1) or sum(imbalance) == len(rows)
+    T.check_against_oracle(T.assemble(per_rank, case), case, alg)
