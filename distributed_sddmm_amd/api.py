@@ -98,6 +98,15 @@ SIGNATURES = {
     "hnh_dist_spmmB": (_i32, [_vp, _vp, _vp, _vp]),
     "hnh_dist_fusedSpMM": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32]),
     "hnh_dist_algorithm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32]),
+    "hnh_als_create": (_i32, [_vp, _i32, _u64, _pvp]),
+    "hnh_als_destroy": (_i32, [_vp]),
+    "hnh_als_set_ground_truth": (_i32, [_vp, _vp, _vp]),
+    "hnh_als_initialize_embeddings": (_i32, [_vp]),
+    "hnh_als_set_embeddings": (_i32, [_vp, _vp, _vp]),
+    "hnh_als_get_embeddings": (_i32, [_vp, _vp, _vp]),
+    "hnh_als_cg_optimizer": (_i32, [_vp, _i32, _i32]),
+    "hnh_als_run_cg": (_i32, [_vp, _i32]),
+    "hnh_als_compute_residual": (_i32, [_vp, _pdbl]),
 }
 
 _lib = None
@@ -481,4 +490,41 @@ class DistributedSparse:
     def free(self):
         if self.h:
             _check(lib().hnh_dist_destroy(self.h), "dist_destroy")
+            self.h = None
+
+
+class DistributedALS:
+    """Distributed_ALS (als_conjugate_gradients.{h,cpp}): ALS by batched CG around fusedSpMM."""
+
+    def __init__(self, op: DistributedSparse, artificial_groundtruth: bool = False, seed: int = 2022):
+        self.op = op
+        self.h = _vp()
+        _check(lib().hnh_als_create(op.h, int(artificial_groundtruth), seed, C.byref(self.h)), "als_create")
+
+    def set_ground_truth(self, gt_s: Vec, gt_st: Vec):
+        _check(lib().hnh_als_set_ground_truth(self.h, gt_s.h, gt_st.h), "als_set_ground_truth")
+
+    def initializeEmbeddings(self):
+        _check(lib().hnh_als_initialize_embeddings(self.h), "initializeEmbeddings")
+
+    def set_embeddings(self, a: Dense, b: Dense):
+        _check(lib().hnh_als_set_embeddings(self.h, a.h, b.h), "als_set_embeddings")
+
+    def get_embeddings(self, a: Dense, b: Dense):
+        _check(lib().hnh_als_get_embeddings(self.h, a.h, b.h), "als_get_embeddings")
+
+    def cg_optimizer(self, matmode: int, cg_max_iter: int):
+        _check(lib().hnh_als_cg_optimizer(self.h, matmode, cg_max_iter), "cg_optimizer")
+
+    def run_cg(self, steps: int):
+        _check(lib().hnh_als_run_cg(self.h, steps), "run_cg")
+
+    def computeResidual(self) -> float:
+        out = C.c_double()
+        _check(lib().hnh_als_compute_residual(self.h, C.byref(out)), "computeResidual")
+        return out.value
+
+    def free(self):
+        if self.h:
+            _check(lib().hnh_als_destroy(self.h), "als_destroy")
             self.h = None

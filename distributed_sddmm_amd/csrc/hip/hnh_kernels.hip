@@ -295,6 +295,58 @@ __global__ __launch_bounds__(kBlock) void expand_rowptr_kernel(int64_t rows, con
     for (int e = rowptr[row] + lane; e < rowptr[row + 1]; e += 64) rowidx[e] = (int32_t)row;
 }
 
+// out[i] = <A[i,:], B[i,:]>; a group of LPR lanes per row, 16-byte loads when W == 2
+template <int LPR, int W>
+__global__ __launch_bounds__(kBlock) void rowdot_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                        double* __restrict__ out, int64_t rows, int R) {
+    constexpr int GROUPS = kBlock / LPR;
+    const int lig = threadIdx.x % LPR;
+    const int64_t row = (int64_t)blockIdx.x * GROUPS + threadIdx.x / LPR;
+    if (row >= rows) return;
+    const double* a = A + row * R;
+    const double* b = B + row * R;
+    double s = 0.0;
+    for (int c = lig * W; c < R; c += LPR * W) {
+        double x[W], y[W];
+        load_w<W>(x, a + c);
+        load_w<W>(y, b + c);
+#pragma unroll
+        for (int w = 0; w < W; w++) s = fma(x[w], y[w], s);
+    }
+#pragma unroll
+    for (int m = LPR / 2; m >= 1; m >>= 1) s += shfl_xor_f64(s, m);
+    if (lig == 0) out[row] = s;
+}
+
+// Y[i,:] = ya * yv[i] * Y[i,:] + xa * xv[i] * X[i,:]   (null vector = ones); grid-stride over elements
+template <int W>
+__global__ __launch_bounds__(kBlock) void row_scale_add_kernel(double* __restrict__ Y, const double* __restrict__ yv, double ya,
+                                                               const double* __restrict__ X, const double* __restrict__ xv,
+                                                               double xa, int64_t rows, int R) {
+    const int64_t total = rows * (int64_t)R / W;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
+        const int64_t e = i * W, row = e / R;
+        const double fy = ya * (yv ? yv[row] : 1.0), fx = xa * (xv ? xv[row] : 1.0);
+        double y[W], x[W];
+        load_w<W>(y, Y + e);
+        load_w<W>(x, X + e);
+#pragma unroll
+        for (int w = 0; w < W; w++) y[w] = fy * y[w] + fx * x[w];
+        store_w<W>(Y + e, y);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void vec_add_scalar_kernel(double* v, double c, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) v[i] += c;
+}
+
+__global__ __launch_bounds__(kBlock) void vec_div_kernel(double* out, const double* num, const double* den, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = num[i] / den[i];
+}
+
 int ew_grid(int64_t n) {
     int64_t blocks = (n + kBlock - 1) / kBlock;
     if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 resident blocks, grid-stride the rest
@@ -490,6 +542,58 @@ int hnh_axpy_f64(hnh_ctx* ctx, double* y, const double* x, double alpha, int64_t
     if (!y || !x) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_axpy_f64: null pointer");
     hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, ctx->streams[stream], y, x, alpha, n);
     return hnh::check_hip(ctx, hipGetLastError(), "axpy_kernel launch");
+}
+
+int hnh_rowdot_f64(hnh_ctx* ctx, const double* A, const double* B, double* out, int64_t rows, int R, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (int rc = check_common(ctx, rows, R, "hnh_rowdot_f64")) return rc;
+    if (rows == 0) return HNH_OK;
+    if (!A || !B || !out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_rowdot_f64: null pointer");
+    hipStream_t st = ctx->streams[stream];
+    const bool w2 = (R % 2 == 0) && aligned16(A) && aligned16(B);
+    const int chunks = w2 ? R / 2 : R;
+#define HNH_RD(L)                                                                                                   \
+    {                                                                                                               \
+        const int64_t blocks = (rows + (kBlock / L) - 1) / (kBlock / L);                                            \
+        if (w2) hipLaunchKernelGGL((rowdot_kernel<L, 2>), dim3((unsigned)blocks), dim3(kBlock), 0, st, A, B, out, rows, R); \
+        else hipLaunchKernelGGL((rowdot_kernel<L, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, A, B, out, rows, R);   \
+    }
+    if (chunks >= 64) HNH_RD(64) else if (chunks >= 32) HNH_RD(32) else if (chunks >= 16) HNH_RD(16) else if (chunks >= 8) HNH_RD(8)
+    else if (chunks >= 4) HNH_RD(4) else if (chunks >= 2) HNH_RD(2) else HNH_RD(1)
+#undef HNH_RD
+    return hnh::check_hip(ctx, hipGetLastError(), "rowdot_kernel launch");
+}
+
+int hnh_row_scale_add_f64(hnh_ctx* ctx, double* Y, const double* yv, double ya, const double* X, const double* xv, double xa,
+                          int64_t rows, int R, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (int rc = check_common(ctx, rows, R, "hnh_row_scale_add_f64")) return rc;
+    if (rows == 0) return HNH_OK;
+    if (!Y || !X) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_row_scale_add_f64: null pointer");
+    hipStream_t st = ctx->streams[stream];
+    if ((R % 2 == 0) && aligned16(Y) && aligned16(X))
+        hipLaunchKernelGGL((row_scale_add_kernel<2>), dim3(ew_grid(rows * R / 2)), dim3(kBlock), 0, st, Y, yv, ya, X, xv, xa, rows, R);
+    else
+        hipLaunchKernelGGL((row_scale_add_kernel<1>), dim3(ew_grid(rows * R)), dim3(kBlock), 0, st, Y, yv, ya, X, xv, xa, rows, R);
+    return hnh::check_hip(ctx, hipGetLastError(), "row_scale_add_kernel launch");
+}
+
+int hnh_vec_add_scalar_f64(hnh_ctx* ctx, double* v, double c, int64_t n, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (n < 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_vec_add_scalar_f64: negative size");
+    if (n == 0) return HNH_OK;
+    if (!v) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_vec_add_scalar_f64: null pointer");
+    hipLaunchKernelGGL(vec_add_scalar_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, ctx->streams[stream], v, c, n);
+    return hnh::check_hip(ctx, hipGetLastError(), "vec_add_scalar_kernel launch");
+}
+
+int hnh_vec_div_f64(hnh_ctx* ctx, double* out, const double* num, const double* den, int64_t n, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (n < 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_vec_div_f64: negative size");
+    if (n == 0) return HNH_OK;
+    if (!out || !num || !den) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_vec_div_f64: null pointer");
+    hipLaunchKernelGGL(vec_div_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, ctx->streams[stream], out, num, den, n);
+    return hnh::check_hip(ctx, hipGetLastError(), "vec_div_kernel launch");
 }
 
 int hnh_expand_rowptr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, int32_t* row_idx, int stream) {

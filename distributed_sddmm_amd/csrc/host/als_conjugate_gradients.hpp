@@ -1,0 +1,202 @@
+// ALS by batched conjugate gradients on the normal equations — same classes and algorithm as the
+// reference's als_conjugate_gradients.{h,cpp}:  ALS_CG (abstract: cg_optimizer, run_cg, allreduceVector) and
+// Distributed_ALS (computeRHS, computeQueries, computeResidual, initializeEmbeddings).
+//
+// One CG iteration = one fusedSpMM (computeQueries, .cpp:265-301) + three row-wise dot products and three
+// row-scaled updates (.cpp:82-139).  All of it stays on the GPU: the row-wise helpers are HIP kernels behind
+// hnh_rowdot_f64 / hnh_row_scale_add_f64 / hnh_vec_* and the Allreduce of the R-split schedules
+// (.cpp:31-36) is an RCCL all-reduce on the schedule's R-split communicator.
+//
+// Differences, deliberate: the reference initialises embeddings and the artificial ground truth with
+// Eigen's setRandom() on LOCAL buffers (.cpp:143-146), which makes results depend on the distribution; here
+// every random fill is a hash of the GLOBAL (row, column), so the factorisation is the same for every
+// schedule and rank count (and can be compared with the reference driven through public members).
+#pragma once
+#include "distributed_sparse.hpp"
+#include "er_generator.hpp"
+
+class ALS_CG {
+public:
+    Distributed_Sparse* d_ops = nullptr;
+    DenseMatrix A, B;
+    hnh::Comm A_R_split_world, B_R_split_world;
+    int proc_rank = 0;
+    double application_communication_time = 0.0;
+
+    virtual void computeRHS(MatMode matrix_to_optimize, DenseMatrix& rhs) = 0;
+    virtual void computeQueries(DenseMatrix& A, DenseMatrix& B, MatMode matrix_to_optimize, DenseMatrix& result) = 0;
+    virtual double computeResidual() = 0;
+    virtual void initializeEmbeddings() = 0;
+    virtual ~ALS_CG() {}
+
+    void allreduceVector(VectorXd& vec, const hnh::Comm& comm) {
+        auto t = start_clock();
+        d_ops->world->allreduce_f64(comm, vec.data(), (size_t)vec.size(), HNH_STREAM_COMPUTE);
+        if (d_ops->world->timing_sync) d_ops->world->sync_all();
+        application_communication_time += stop_clock_get_elapsed(t);
+    }
+
+    // batched CG, one independent system per row (als_conjugate_gradients.cpp:38-141)
+    void cg_optimizer(MatMode matrix_to_optimize, int cg_max_iter) {
+        const double nan_avoidance_constant = 1e-8;
+        hnh::World* w = d_ops->world;
+        hnh::Backend* be = w->be;
+        const hnh::Comm& reduction_world = (matrix_to_optimize == Amat) ? A_R_split_world : B_R_split_world;
+        DenseMatrix& X = (matrix_to_optimize == Amat) ? A : B;
+        const int64_t nrows = X.rows();
+        const int ncols = (int)A.cols();
+
+        DenseMatrix rhs(nrows, ncols), Mx(nrows, ncols), Mp(nrows, ncols);
+        rhs.setZero();
+        computeRHS(matrix_to_optimize, rhs);
+        computeQueries(A, B, matrix_to_optimize, Mx);
+
+        auto rowdot = [&](DenseMatrix& x, DenseMatrix& y, VectorXd& out) {
+            w->check(be->hnh_rowdot_f64(w->ctx, x.data(), y.data(), out.data(), nrows, ncols, HNH_STREAM_COMPUTE), "hnh_rowdot_f64");
+        };
+        auto row_update = [&](DenseMatrix& y, const double* yv, double ya, DenseMatrix& x, const double* xv, double xa) {
+            w->check(be->hnh_row_scale_add_f64(w->ctx, y.data(), yv, ya, x.data(), xv, xa, nrows, ncols, HNH_STREAM_COMPUTE),
+                     "hnh_row_scale_add_f64");
+        };
+
+        DenseMatrix r = rhs;                       // r = rhs - Mx
+        row_update(r, nullptr, 1.0, Mx, nullptr, -1.0);
+        DenseMatrix p = r;
+        VectorXd rsold(nrows), alpha(nrows), coeffs(nrows), bdot(nrows), rsnew(nrows);
+        rowdot(r, r, rsold);
+        if (d_ops->r_split) allreduceVector(rsold, reduction_world);
+
+        for (int cg_iter = 0; cg_iter < cg_max_iter; cg_iter++) {
+            if (matrix_to_optimize == Amat) computeQueries(p, B, Amat, Mp);
+            else computeQueries(A, p, Bmat, Mp);
+
+            rowdot(p, Mp, bdot);
+            if (d_ops->r_split) allreduceVector(bdot, reduction_world);
+
+            // the reference adds the constant to BOTH vectors in place (.cpp:99-100); rsold keeps it
+            w->check(be->hnh_vec_add_scalar_f64(w->ctx, bdot.data(), nan_avoidance_constant, nrows, HNH_STREAM_COMPUTE), "vec_add");
+            w->check(be->hnh_vec_add_scalar_f64(w->ctx, rsold.data(), nan_avoidance_constant, nrows, HNH_STREAM_COMPUTE), "vec_add");
+            w->check(be->hnh_vec_div_f64(w->ctx, alpha.data(), rsold.data(), bdot.data(), nrows, HNH_STREAM_COMPUTE), "vec_div");
+
+            row_update(X, nullptr, 1.0, p, alpha.data(), 1.0);    // X += alpha .* p
+            row_update(r, nullptr, 1.0, Mp, alpha.data(), -1.0);  // r -= alpha .* Mp
+
+            rowdot(r, r, rsnew);
+            if (d_ops->r_split) allreduceVector(rsnew, reduction_world);
+
+            w->check(be->hnh_vec_div_f64(w->ctx, coeffs.data(), rsnew.data(), rsold.data(), nrows, HNH_STREAM_COMPUTE), "vec_div");
+            row_update(p, coeffs.data(), 1.0, r, nullptr, 1.0);   // p = r + coeffs .* p
+            std::swap(rsold, rsnew);                              // rsold = rsnew
+        }
+    }
+
+    void run_cg(int n_alternating_steps) {  // als_conjugate_gradients.cpp:235-263
+        initializeEmbeddings();
+        if (proc_rank == 0) std::cout << "Embeddings initialized +" << std::endl;
+        for (int i = 0; i < n_alternating_steps; i++) {
+            cg_optimizer(Amat, 10);
+            cg_optimizer(Bmat, 10);
+            if (proc_rank == 0 && i < n_alternating_steps - 1) std::cout << "Completed step " << i << std::endl;
+        }
+    }
+};
+
+class Distributed_ALS : public ALS_CG {
+public:
+    VectorXd ground_truth, ground_truth_transpose;
+    uint64_t seed = 2022;
+
+    // artificial_groundtruth: ground truth = SDDMM of two hashed random factor matrices with S = 1
+    // (als_conjugate_gradients.cpp:157-184); otherwise the caller sets ground_truth{,_transpose}.
+    Distributed_ALS(Distributed_Sparse* d_ops, bool artificial_groundtruth, uint64_t seed_in = 2022) {
+        seed = seed_in;
+        this->d_ops = d_ops;
+        proc_rank = d_ops->proc_rank;
+        A_R_split_world = d_ops->A_R_split_world;
+        B_R_split_world = d_ops->B_R_split_world;
+        if (artificial_groundtruth) {
+            DenseMatrix Agt = d_ops->like_A_matrix(0.0), Bgt = d_ops->like_B_matrix(0.0);
+            hashed_fill(Agt, Amat, seed + 1, 1.0 / ((double)d_ops->R * (double)d_ops->M * (double)d_ops->R));
+            hashed_fill(Bgt, Bmat, seed + 2, 1.0 / ((double)d_ops->R * (double)d_ops->N * (double)d_ops->R));
+            VectorXd ones = d_ops->like_S_values(1.0);
+            ground_truth = d_ops->like_S_values(0.0);
+            d_ops->initial_shift(&Agt, &Bgt, k_sddmmA);
+            d_ops->sddmmA(Agt, Bgt, ones, ground_truth);
+            d_ops->de_shift(&Agt, &Bgt, k_sddmmA);
+            ones = d_ops->like_ST_values(1.0);
+            ground_truth_transpose = d_ops->like_ST_values(0.0);
+            d_ops->initial_shift(&Agt, &Bgt, k_sddmmB);
+            d_ops->sddmmB(Agt, Bgt, ones, ground_truth_transpose);
+            d_ops->de_shift(&Agt, &Bgt, k_sddmmB);
+        }
+    }
+
+    void computeRHS(MatMode matrix_to_optimize, DenseMatrix& rhs) override {  // .cpp:186-199
+        if (matrix_to_optimize == Amat) {
+            d_ops->initial_shift(&rhs, &B, k_spmmA);
+            d_ops->spmmA(rhs, B, ground_truth);
+            d_ops->de_shift(&rhs, &B, k_spmmA);
+        } else {
+            d_ops->initial_shift(&A, &rhs, k_spmmB);
+            d_ops->spmmB(A, rhs, ground_truth_transpose);
+            d_ops->de_shift(&A, &rhs, k_spmmB);
+        }
+    }
+
+    double computeResidual() override {  // .cpp:201-219
+        VectorXd ones = d_ops->like_S_values(1.0), sddmm_result = d_ops->like_S_values(0.0);
+        d_ops->initial_shift(&A, &B, k_sddmmA);
+        d_ops->sddmmA(A, B, ones, sddmm_result);
+        d_ops->de_shift(&A, &B, k_sddmmA);
+        std::vector<double> x = sddmm_result.to_host(), g = ground_truth.to_host();
+        double sqnorm = 0.0;
+        for (size_t e = 0; e < x.size(); e++) sqnorm += (x[e] - g[e]) * (x[e] - g[e]);
+        return std::sqrt(d_ops->world->host_allreduce_sum(sqnorm));
+    }
+
+    void initializeEmbeddings() override {  // .cpp:221-233: random/R, then A *= 1.4, B /= 1.3
+        A = d_ops->like_A_matrix(0.0);
+        B = d_ops->like_B_matrix(0.0);
+        hashed_fill(A, Amat, seed + 3, 1.4 / (double)d_ops->R);
+        hashed_fill(B, Bmat, seed + 4, 1.0 / (1.3 * (double)d_ops->R));
+    }
+
+    // result = (S .* (X Y^T)|_S) Y + lambda X  with S == 1 (.cpp:265-301)
+    void computeQueries(DenseMatrix& A_in, DenseMatrix& B_in, MatMode matrix_to_optimize, DenseMatrix& result) override {
+        const double lambda = 1e-13;
+        hnh::World* w = d_ops->world;
+        if (matrix_to_optimize == Amat) {
+            VectorXd ones = d_ops->like_S_values(1.0), sddmm_result = d_ops->like_S_values(0.0);
+            result = A_in;
+            d_ops->initial_shift(&result, &B_in, k_sddmmA);
+            d_ops->fusedSpMM(result, B_in, ones, sddmm_result, Amat);
+            d_ops->de_shift(&result, &B_in, k_sddmmA);
+            w->check(w->be->hnh_row_scale_add_f64(w->ctx, result.data(), nullptr, 1.0, A_in.data(), nullptr, lambda, result.rows(),
+                                                  (int)result.cols(), HNH_STREAM_COMPUTE), "hnh_row_scale_add_f64");
+        } else {
+            VectorXd ones = d_ops->like_ST_values(1.0), sddmm_result = d_ops->like_ST_values(0.0);
+            result = B_in;
+            d_ops->initial_shift(&A_in, &result, k_sddmmB);
+            d_ops->fusedSpMM(A_in, result, ones, sddmm_result, Bmat);
+            d_ops->de_shift(&A_in, &result, k_sddmmB);
+            w->check(w->be->hnh_row_scale_add_f64(w->ctx, result.data(), nullptr, 1.0, B_in.data(), nullptr, lambda, result.rows(),
+                                                  (int)result.cols(), HNH_STREAM_COMPUTE), "hnh_row_scale_add_f64");
+        }
+    }
+
+    // uniform(-1, 1) * scale keyed by the GLOBAL (row, col) through the operator's submatrix descriptors
+    void hashed_fill(DenseMatrix& loc, MatMode mode, uint64_t fill_seed, double scale) {
+        std::vector<DenseSubmatrix>& subs = (mode == Amat) ? d_ops->aSubmatrices : d_ops->bSubmatrices;
+        std::vector<double> host((size_t)loc.size());
+        double* ptr = host.data();
+        const uint64_t G = 0x9E3779B97F4A7C15ull, Rg = (uint64_t)d_ops->R;
+        for (auto& s : subs)
+            for (int i = 0; i < s.rowCount; i++)
+                for (int j = 0; j < s.colCount; j++) {
+                    const uint64_t key = (uint64_t)(s.topRow + i) * Rg + (uint64_t)(s.leftCol + j);
+                    const uint64_t h = hnh::splitmix64(fill_seed * 0xD1342543DE82EF95ull + key * G);
+                    *ptr++ = ((double)(h >> 11) * 0x1.0p-52 - 1.0) * scale;
+                }
+        loc.copy_from_host(host.data());
+    }
+};

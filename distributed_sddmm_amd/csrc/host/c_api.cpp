@@ -3,6 +3,7 @@
 #include <memory>
 #include <string>
 
+#include "als_conjugate_gradients.hpp"
 #include "cannon_dense_25d.hpp"
 #include "cannon_sparse_25d.hpp"
 #include "dense_shift_15d.hpp"
@@ -32,6 +33,11 @@ struct hnh_dist {
     hnh::World* w;
     std::unique_ptr<StandardKernel> kernel;
     std::unique_ptr<Distributed_Sparse> d;
+};
+
+struct hnh_als {
+    hnh::World* w;
+    std::unique_ptr<Distributed_ALS> a;
 };
 
 namespace {
@@ -388,6 +394,53 @@ int hnh_dist_fusedSpMM(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_
 }
 int hnh_dist_algorithm(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_vec* result, int mode, int initial_replicate) {
     return guarded(d->w, [&] { d->d->algorithm(A->m, B->m, S->v, result ? &result->v : nullptr, kmode(mode), initial_replicate != 0); });
+}
+
+// ------------------------------------------------------------------ ALS-CG
+int hnh_als_create(hnh_dist* d, int artificial_groundtruth, uint64_t seed, hnh_als** out) {
+    return guarded(d->w, [&] {
+        std::unique_ptr<hnh_als> h(new hnh_als());
+        h->w = d->w;
+        h->a.reset(new Distributed_ALS(d->d.get(), artificial_groundtruth != 0, seed));
+        *out = h.release();
+    });
+}
+int hnh_als_destroy(hnh_als* a) {
+    return guarded(a ? a->w : nullptr, [&] { delete a; });
+}
+int hnh_als_set_ground_truth(hnh_als* a, hnh_vec* gs, hnh_vec* gst) {
+    return guarded(a->w, [&] {
+        VectorXd s = a->a->d_ops->like_S_values(0.0), st = a->a->d_ops->like_ST_values(0.0);
+        if (gs->v.size() != s.size() || gst->v.size() != st.size()) hnh::fatal("Error, ground truth vectors have the wrong length!");
+        a->w->copy(s.data(), gs->v.data(), (size_t)s.size() * sizeof(double), HNH_COPY_D2D, HNH_STREAM_COMPUTE);
+        a->w->copy(st.data(), gst->v.data(), (size_t)st.size() * sizeof(double), HNH_COPY_D2D, HNH_STREAM_COMPUTE);
+        a->a->ground_truth = std::move(s);
+        a->a->ground_truth_transpose = std::move(st);
+    });
+}
+int hnh_als_initialize_embeddings(hnh_als* a) {
+    return guarded(a->w, [&] { a->a->initializeEmbeddings(); });
+}
+int hnh_als_set_embeddings(hnh_als* a, hnh_dense* A, hnh_dense* B) {
+    return guarded(a->w, [&] {
+        a->a->A = A->m;
+        a->a->B = B->m;
+    });
+}
+int hnh_als_get_embeddings(hnh_als* a, hnh_dense* A, hnh_dense* B) {
+    return guarded(a->w, [&] {
+        if (A) A->m = a->a->A;
+        if (B) B->m = a->a->B;
+    });
+}
+int hnh_als_cg_optimizer(hnh_als* a, int matmode, int cg_max_iter) {
+    return guarded(a->w, [&] { a->a->cg_optimizer(matmode == HNH_AMAT ? Amat : Bmat, cg_max_iter); });
+}
+int hnh_als_run_cg(hnh_als* a, int steps) {
+    return guarded(a->w, [&] { a->a->run_cg(steps); });
+}
+int hnh_als_compute_residual(hnh_als* a, double* out) {
+    return guarded(a->w, [&] { *out = a->a->computeResidual(); });
 }
 
 }  // extern "C"

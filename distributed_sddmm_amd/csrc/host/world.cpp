@@ -66,6 +66,7 @@ Backend* load_backend(const char* path_c) {
     HNH_BIND(hnh_event_sync) HNH_BIND(hnh_event_elapsed_ms)
     HNH_BIND(hnh_sddmm_coo) HNH_BIND(hnh_sddmm_csr) HNH_BIND(hnh_spmm_csr) HNH_BIND(hnh_fused_sddmm_spmm_csr)
     HNH_BIND(hnh_fill_f64) HNH_BIND(hnh_hadamard_f64) HNH_BIND(hnh_axpy_f64) HNH_BIND(hnh_expand_rowptr)
+    HNH_BIND(hnh_rowdot_f64) HNH_BIND(hnh_row_scale_add_f64) HNH_BIND(hnh_vec_add_scalar_f64) HNH_BIND(hnh_vec_div_f64)
     HNH_BIND(hnh_comm_unique_id) HNH_BIND(hnh_comm_init) HNH_BIND(hnh_comm_split) HNH_BIND(hnh_comm_destroy)
     HNH_BIND(hnh_comm_sendrecv) HNH_BIND(hnh_comm_group_begin) HNH_BIND(hnh_comm_group_end) HNH_BIND(hnh_comm_allgather) HNH_BIND(hnh_comm_reduce_scatter_f64)
     HNH_BIND(hnh_comm_allreduce_f64)
@@ -170,6 +171,7 @@ Comm World::world_comm() {
     c.ranks.resize(size);
     for (int i = 0; i < size; i++) c.ranks[i] = i;
     c.me = rank;
+    c.is_world = true;
     return c;
 }
 
@@ -182,6 +184,8 @@ Comm World::split(int color, int key) {
         if (all[2 * r] == color) members.push_back({all[2 * r + 1], r});
     std::sort(members.begin(), members.end());
     Comm c;
+    c.color = color;
+    c.key = key;
     for (size_t i = 0; i < members.size(); i++) {
         c.ranks.push_back(members[i].second);
         if (members[i].second == rank) c.me = (int)i;
@@ -233,6 +237,16 @@ void World::reduce_scatter_v_f64(const Comm& comm, const double* sendbuf, double
 void World::reduce_scatter_f64(const Comm& comm, const double* sendbuf, double* recvbuf, size_t count, int stream) {
     std::vector<int> counts(comm.size(), (int)count);
     reduce_scatter_v_f64(comm, sendbuf, recvbuf, counts, stream);
+}
+
+void World::allreduce_f64(const Comm& comm, double* buf, size_t count, int stream) {
+    const int n = comm.size();
+    if (n == 1 || count == 0) return;
+    // gather every member's vector, then add them up in member order (deterministic)
+    double* all = static_cast<double*>(scratch(2, (size_t)n * count * sizeof(double)));
+    allgather(comm, buf, all, count * sizeof(double), stream);
+    memset0(buf, count * sizeof(double), stream);
+    for (int i = 0; i < n; i++) check(be->hnh_axpy_f64(ctx, buf, all + (size_t)i * count, 1.0, (int64_t)count, stream), "hnh_axpy_f64");
 }
 
 void World::host_allgather_comm(const Comm& comm, const void* send, void* recv, size_t bytes) {
@@ -435,10 +449,15 @@ RcclWorld::~RcclWorld() {
     destroy_device();
 }
 
-Comm RcclWorld::split(int color, int key) {
-    Comm c = World::split(color, key);
-    check(be->hnh_comm_split(ctx, comm_, color, key, &c.native), "hnh_comm_split");
-    return c;
+Comm RcclWorld::split(int color, int key) { return World::split(color, key); }
+
+// ncclCommSplit is collective over the world, and every schedule is SPMD-symmetric (when one rank runs a
+// collective on its row/fiber communicator, every rank does on its own), so the RCCL sub-communicator can be
+// created at first use.  Schedules that never run a collective (c = 1) never split at all.
+void* RcclWorld::native_for(const Comm& comm) {
+    if (comm.is_world) return comm_;
+    if (!comm.native) check(be->hnh_comm_split(ctx, comm_, comm.color, comm.key, &comm.native), "hnh_comm_split");
+    return comm.native;
 }
 void RcclWorld::free_comm(Comm& c) {
     if (c.native) {
@@ -475,6 +494,11 @@ void RcclWorld::reduce_scatter_f64(const Comm& comm, const double* sendbuf, doub
         return;
     }
     check(be->hnh_comm_reduce_scatter_f64(ctx, native_for(comm), sendbuf, recvbuf, count, stream), "hnh_comm_reduce_scatter_f64");
+}
+
+void RcclWorld::allreduce_f64(const Comm& comm, double* buf, size_t count, int stream) {
+    if (comm.size() == 1 || count == 0) return;
+    check(be->hnh_comm_allreduce_f64(ctx, native_for(comm), buf, buf, count, stream), "hnh_comm_allreduce_f64");
 }
 
 void RcclWorld::barrier() {

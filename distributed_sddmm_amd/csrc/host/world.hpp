@@ -29,7 +29,9 @@ namespace hnh {
 struct Comm {
     std::vector<int> ranks;
     int me = -1;
-    void* native = nullptr;  // RCCL sub-communicator when the world is an RcclWorld
+    mutable void* native = nullptr;  // RCCL sub-communicator (RcclWorld), created on first collective use
+    int color = 0, key = 0;          // what it was split with (MPI_Comm_split arguments)
+    bool is_world = false;
     int size() const { return (int)ranks.size(); }
     int rank() const { return me; }
 };
@@ -59,6 +61,8 @@ public:
     virtual void group_end() {}
     virtual void allgather(const Comm& comm, const void* sendbuf, void* recvbuf, size_t bytes_per_rank, int stream);
     virtual void reduce_scatter_f64(const Comm& comm, const double* sendbuf, double* recvbuf, size_t count, int stream);
+    // in-place sum over the members of `comm` (MPI_Allreduce(MPI_IN_PLACE), als_conjugate_gradients.cpp:31-36)
+    virtual void allreduce_f64(const Comm& comm, double* buf, size_t count, int stream);
     // variable counts (25D_cannon_sparse.hpp:224-233,294-300); counts / displs in elements, per comm index
     virtual void allgatherv_f64(const Comm& comm, const double* sendbuf, size_t sendcount, double* recvbuf,
                                 const std::vector<int>& counts, const std::vector<int>& displs, int stream);
@@ -149,6 +153,7 @@ public:
                   int src, int stream) override;
     void allgather(const Comm& comm, const void* sendbuf, void* recvbuf, size_t bytes_per_rank, int stream) override;
     void reduce_scatter_f64(const Comm& comm, const double* sendbuf, double* recvbuf, size_t count, int stream) override;
+    void allreduce_f64(const Comm& comm, double* buf, size_t count, int stream) override;
     void barrier() override;
     void host_allgather(const void* send, void* recv, size_t bytes) override;
     void host_alltoallv(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl, void* recv,
@@ -156,8 +161,7 @@ public:
 
 private:
     void* comm_ = nullptr;  // world communicator
-    void* native_for(const Comm& comm) const { return comm.native ? comm.native : comm_; }
-    bool is_world(const Comm& comm) const { return comm.native == nullptr; }
+    void* native_for(const Comm& comm);
 };
 
 // ---- transport supplied by the embedding program (torch.distributed / gloo in tests, MPI, ...).

@@ -142,6 +142,19 @@ int hnh_dist_fusedSpMM(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_
 int hnh_dist_algorithm(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_vec* result_or_null, int kernel_mode,
                        int initial_replicate);
 
+/* ---- ALS by batched conjugate gradients around fusedSpMM (als_conjugate_gradients.{h,cpp}; BASELINE config 5) */
+typedef struct hnh_als hnh_als; /* Distributed_ALS */
+/* Distributed_ALS(d_ops, artificial_groundtruth) (.cpp:148-184); random fills are hashes of global coordinates */
+int hnh_als_create(hnh_dist* d, int artificial_groundtruth, uint64_t seed, hnh_als** out);
+int hnh_als_destroy(hnh_als* a);
+int hnh_als_set_ground_truth(hnh_als* a, hnh_vec* gt_S_order, hnh_vec* gt_ST_order); /* members ground_truth{,_transpose} */
+int hnh_als_initialize_embeddings(hnh_als* a);                                         /* initializeEmbeddings (.cpp:221-233) */
+int hnh_als_set_embeddings(hnh_als* a, hnh_dense* A, hnh_dense* B);                   /* members A, B (copied in)   */
+int hnh_als_get_embeddings(hnh_als* a, hnh_dense* A, hnh_dense* B);                   /* members A, B (copied out)  */
+int hnh_als_cg_optimizer(hnh_als* a, int matmode, int cg_max_iter);                    /* cg_optimizer (.cpp:38-141) */
+int hnh_als_run_cg(hnh_als* a, int n_alternating_steps);                               /* run_cg (.cpp:235-263)      */
+int hnh_als_compute_residual(hnh_als* a, double* out);                                 /* computeResidual (.cpp:201-219) */
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,17 @@ int hnh_hadamard_f64(hnh_ctx* ctx, double* out, const double* a, const double* b
 int hnh_axpy_f64(hnh_ctx* ctx, double* y, const double* x, double alpha, int64_t n, int stream);
 int hnh_expand_rowptr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, int32_t* row_idx, int stream);
 
+/* ---- row-wise dense helpers of the ALS-CG application around fusedSpMM (als_conjugate_gradients.cpp) -----------
+ * hnh_rowdot_f64         — batch_dot_product (:9-11):  out[i] = sum_j A[i,j] * B[i,j]
+ * hnh_row_scale_add_f64  — scale_matrix_rows + matrix add/sub (:13-29, :117-123, :137):
+ *                            Y[i,:] = ya * (yv ? yv[i] : 1) * Y[i,:]  +  xa * (xv ? xv[i] : 1) * X[i,:]
+ * hnh_vec_add_scalar_f64 — `v.array() += c` (:99-100);  hnh_vec_div_f64 — cwiseQuotient (:102,136) */
+int hnh_rowdot_f64(hnh_ctx* ctx, const double* A, const double* B, double* out, int64_t rows, int R, int stream);
+int hnh_row_scale_add_f64(hnh_ctx* ctx, double* Y, const double* yv, double ya, const double* X, const double* xv, double xa,
+                          int64_t rows, int R, int stream);
+int hnh_vec_add_scalar_f64(hnh_ctx* ctx, double* v, double c, int64_t n, int stream);
+int hnh_vec_div_f64(hnh_ctx* ctx, double* out, const double* num, const double* den, int64_t n, int stream);
+
 /* ---- RCCL ring / collectives over xGMI ---------------------------------------------------------------
  * Replace the MPI calls of the shift schedules:
  *   hnh_comm_sendrecv        — MPI_Sendrecv in shiftDenseMatrix (distributed_sparse.h:351-361) and the

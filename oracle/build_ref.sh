@@ -30,13 +30,13 @@ LIBS="-Wl,--no-as-needed $TMP/deps/libmpi.so $TMP/deps/libmkl_intel_ilp64.so $TM
 
 # (1) unmodified reference
 g++ $CXXFLAGS -I"$HERE/stubs" -I"$TMP/inc" -I"$REF" \
-    "$HERE/ref_driver.cpp" "$REF/sparse_kernels.cpp" "$REF/common.cpp" $LIBS -o "$OUT/ref_driver"
+    "$HERE/ref_driver.cpp" "$REF/sparse_kernels.cpp" "$REF/common.cpp" "$REF/als_conjugate_gradients.cpp" $LIBS -o "$OUT/ref_driver"
 
 # (2) patched private copy for 2.5D dense-replicate only: all headers must come from one directory
 #     because the reference includes them with quotes, so mirror the headers into $TMP/patched.
 for f in common.h common.cpp sparse_kernels.h sparse_kernels.cpp SpmatLocal.hpp FlexibleGrid.hpp distributed_sparse.h \
          15D_dense_shift.hpp 15D_sparse_shift.hpp 25D_cannon_dense.hpp 25D_cannon_sparse.hpp \
-         als_conjugate_gradients.h json.hpp; do cp "$REF/$f" "$TMP/patched/"; done
+         als_conjugate_gradients.h als_conjugate_gradients.cpp json.hpp; do cp "$REF/$f" "$TMP/patched/"; done
 python3 - "$TMP/patched/SpmatLocal.hpp" <<'PY'
 import sys, re
 p = sys.argv[1]; s = open(p).read()
@@ -45,7 +45,7 @@ assert s.count(old) == 1, "patch anchor not found"
 open(p, "w").write(s.replace(old, "if (mode == coo || mode == both) {\n\t\t\tMPI_Wait(&rRequestSend"))
 PY
 g++ $CXXFLAGS -I"$HERE/stubs" -I"$TMP/inc" -I"$TMP/patched" \
-    "$HERE/ref_driver.cpp" "$TMP/patched/sparse_kernels.cpp" "$TMP/patched/common.cpp" $LIBS -o "$OUT/ref_driver_patched"
+    "$HERE/ref_driver.cpp" "$TMP/patched/sparse_kernels.cpp" "$TMP/patched/common.cpp" "$TMP/patched/als_conjugate_gradients.cpp" $LIBS -o "$OUT/ref_driver_patched"
 
 # (3) MKL ABI known-answer test (enum values / argument order of the hand-written mkl_spblas.h)
 g++ -O1 -std=c++17 -DMKL_ILP64 -I"$HERE/stubs" "$HERE/mkl_kat.cpp" $LIBS -o "$OUT/mkl_kat"

@@ -157,6 +157,37 @@ int hnh_expand_rowptr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, int32_t* 
     return HNH_OK;
 }
 
+/* als_conjugate_gradients.cpp:9-11 */
+int hnh_rowdot_f64(hnh_ctx* c, const double* A, const double* B, double* out, int64_t rows, int R, int stream) {
+    (void)c; (void)stream;
+    for (int64_t i = 0; i < rows; i++) {
+        double s = 0.0;
+        for (int j = 0; j < R; j++) s += A[i * R + j] * B[i * R + j];
+        out[i] = s;
+    }
+    return HNH_OK;
+}
+/* scale_matrix_rows + add (als_conjugate_gradients.cpp:13-29,117-123,137) */
+int hnh_row_scale_add_f64(hnh_ctx* c, double* Y, const double* yv, double ya, const double* X, const double* xv, double xa,
+                          int64_t rows, int R, int stream) {
+    (void)c; (void)stream;
+    for (int64_t i = 0; i < rows; i++) {
+        const double fy = ya * (yv ? yv[i] : 1.0), fx = xa * (xv ? xv[i] : 1.0);
+        for (int j = 0; j < R; j++) Y[i * R + j] = fy * Y[i * R + j] + fx * X[i * R + j];
+    }
+    return HNH_OK;
+}
+int hnh_vec_add_scalar_f64(hnh_ctx* c, double* v, double s, int64_t n, int stream) {
+    (void)c; (void)stream;
+    for (int64_t i = 0; i < n; i++) v[i] += s;
+    return HNH_OK;
+}
+int hnh_vec_div_f64(hnh_ctx* c, double* out, const double* num, const double* den, int64_t n, int stream) {
+    (void)c; (void)stream;
+    for (int64_t i = 0; i < n; i++) out[i] = num[i] / den[i];
+    return HNH_OK;
+}
+
 /* no RCCL on the CPU: host-logic tests use the thread-loopback or callback transports */
 #define UNSUP(c) return fail((c), HNH_ERR_UNSUPPORTED, "RCCL transport is not available in the CPU test double")
 int hnh_comm_unique_id(void* id) { (void)id; return HNH_ERR_UNSUPPORTED; }

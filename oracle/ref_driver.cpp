@@ -18,6 +18,9 @@
 //   ref_driver dump  <case.bin> <alg> <c> <outprefix>     element-wise results, all ops
 //   ref_driver fp    <case.bin> <alg> <c>                 scratch.cpp:26-76 style fingerprints
 //   ref_driver bench <case.bin> <alg> <c> <fused> <trials> benchmark_dist.cpp:102-162 timing loop
+//   ref_driver als   <case.bin> <alg> <c> <outprefix> <steps> <cg_iters>   ALS-CG (als_conjugate_gradients.cpp):
+//        ground truth = the input S values (keyed by coordinate), embeddings initialised from the case's A, B,
+//        `steps` x { cg_optimizer(Amat, cg_iters); cg_optimizer(Bmat, cg_iters) } (= run_cg, :235-263), dumps A, B
 // <alg> in {15d_fusion1, 15d_fusion2, 15d_sparse, 25d_dense_replicate, 25d_sparse_replicate}.
 #include "15D_dense_shift.hpp"
 #include "15D_sparse_shift.hpp"
@@ -260,6 +263,43 @@ void run_bench(const Case& cs, Distributed_Sparse* d, const std::string& name, b
     }
 }
 
+// ALS-CG on the reference's own Distributed_ALS (als_conjugate_gradients.cpp:148-301).  The random
+// initialisations (:143-146, :225-233) are replaced by the case's keyed fills through public members.
+void run_als(const Case& cs, Distributed_Sparse* d, const std::string& prefix, int steps, int cg_iters) {
+    const int rank = d->proc_rank;
+    DenseMatrix A = d->like_A_matrix(0.0), B = d->like_B_matrix(0.0);
+    VectorXd onesS = d->like_S_values(1.0), onesST = d->like_ST_values(1.0);
+    VectorXd probeS = d->like_S_values(0.0), probeST = d->like_ST_values(0.0);
+    fill_probe(d, A, Amat, cs.N); fill_probe(d, B, Bmat, cs.N);
+    d->initial_shift(&A, &B, k_sddmmA); MPI_Barrier(MPI_COMM_WORLD);
+    d->sddmmA(A, B, onesS, probeS);
+    fill_probe(d, A, Amat, cs.N); fill_probe(d, B, Bmat, cs.N);
+    d->initial_shift(&A, &B, k_sddmmB); MPI_Barrier(MPI_COMM_WORLD);
+    d->sddmmB(A, B, onesST, probeST);
+
+    Distributed_ALS als(d, false);
+    als.ground_truth = svals_for(cs, keys_of(probeS));
+    als.ground_truth_transpose = svals_for(cs, keys_of(probeST));
+    als.A = d->like_A_matrix(0.0);
+    als.B = d->like_B_matrix(0.0);
+    fill_local(d, als.A, Amat, cs.A.data(), cs.M, cs.R);
+    fill_local(d, als.B, Bmat, cs.B.data(), cs.N, cs.R);
+    std::vector<double> residuals;
+    residuals.push_back(als.computeResidual());
+    for (int s = 0; s < steps; s++) {
+        als.cg_optimizer(Amat, cg_iters);
+        als.cg_optimizer(Bmat, cg_iters);
+        residuals.push_back(als.computeResidual());
+    }
+    int64_t dims[8] = {d->localArows, d->localAcols, d->localBrows, d->localBcols, d->p, d->c, cs.M, cs.N};
+    dump(prefix, rank, "dims.i64", dims, sizeof(dims));
+    dump_subs(prefix, rank, "subA.i64", d->aSubmatrices);
+    dump_subs(prefix, rank, "subB.i64", d->bSubmatrices);
+    dump(prefix, rank, "alsA.f64", als.A.data(), als.A.size() * 8);
+    dump(prefix, rank, "alsB.f64", als.B.data(), als.B.size() * 8);
+    dump(prefix, rank, "residuals.f64", residuals.data(), residuals.size() * 8);
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -271,7 +311,7 @@ int main(int argc, char** argv) {
     if (argc < 5) die("usage: ref_driver dump|fp|bench <case.bin> <alg> <c> [...]");
     std::string mode = argv[1], alg = argv[3];
     int c = std::atoi(argv[4]);
-    Case cs = load_case(argv[2], mode == "dump");
+    Case cs = load_case(argv[2], mode == "dump" || mode == "als");
     {
         SpmatLocal S;
         inject(S, cs, rank, p);
@@ -280,6 +320,9 @@ int main(int argc, char** argv) {
         if (mode == "dump") {
             if (argc < 6) die("dump needs <outprefix>");
             run_dump(cs, d, argv[5]);
+        } else if (mode == "als") {
+            if (argc < 8) die("als needs <outprefix> <steps> <cg_iters>");
+            run_als(cs, d, argv[5], std::atoi(argv[6]), std::atoi(argv[7]));
         } else if (mode == "fp") {
             run_fp(d, alg);
         } else if (mode == "bench") {

@@ -138,3 +138,15 @@ def bench(m, n, rows, cols, r, alg: str, p: int, c: int, fused: bool, trials: in
         write_case(case, m, n, rows, cols, np.ones(len(rows)), r)
         out = run(["bench", case, alg, c, int(fused), trials], p, alg, threads=threads, timeout=timeout)
         return json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+
+
+def als(m, n, rows, cols, vals, r, a, b, alg: str, p: int, c: int, steps: int, cg_iters: int, timeout: float = 300.0) -> dict:
+    """ALS-CG of the reference (als_conjugate_gradients.cpp) with ground truth = `vals`, embeddings initialised
+    from (a, b): returns the global A, B after `steps` alternating steps and the residual history."""
+    with tempfile.TemporaryDirectory(prefix="hnh_ref_") as td:
+        case = os.path.join(td, "case.bin")
+        write_case(case, m, n, rows, cols, vals, r, a, b)
+        prefix = os.path.join(td, "out")
+        run(["als", case, alg, c, prefix, steps, cg_iters], p, alg, timeout=timeout)
+        return {"A": _assemble_dense(prefix, p, "alsA.f64", "A", m, r), "B": _assemble_dense(prefix, p, "alsB.f64", "B", n, r),
+                "residuals": np.fromfile(prefix + ".r0.residuals.f64", dtype=np.float64)}

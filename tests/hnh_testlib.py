@@ -230,3 +230,64 @@ def check_against_oracle(glob: dict, case: dict, alg: str, tol: float = TOL):
     if not ign:
         assert rel(glob["fusedA_buf"][1], mid) <= tol and rel(glob["fusedB_buf"][1], mid) <= tol
     assert rel(glob["fingerprints"], np.array(O.fingerprints(rows, cols, m, n, case["R"]))) <= tol
+
+
+ALS_TOL = 1e-9  # CG amplifies summation-order differences: the reference's own schedules differ by up to 1.2e-11 (als_manifest.json)
+
+
+def run_als(world: H.World, alg: str, c: int, case: dict, steps: int, iters: int) -> dict:
+    """ALS-CG driven like oracle/ref_driver.cpp's `als` mode: ground truth = the case's S values (keyed through
+    the coordinate probe), embeddings from the case's A, B, then `steps` alternating CG solves."""
+    sp = H.SpmatLocal.from_global(world, case["M"], case["N"], case["rows"], case["cols"], case["vals"])
+    d = H.DistributedSparse(world, alg, sp, case["R"], c)
+    subA, subB = d.submatrices(H.AMAT), d.submatrices(H.BMAT)
+    A, B = d.like_A_matrix(0.0), d.like_B_matrix(0.0)
+    n = case["N"]
+    lookup = dict(zip((case["rows"] * n + case["cols"]).tolist(), case["vals"].tolist()))
+    gts = []
+    for mode, like in ((H.K_SDDMM_A, d.like_S_values), (H.K_SDDMM_B, d.like_ST_values)):
+        A.upload(probe_local(subA, A.shape, True, n)); B.upload(probe_local(subB, B.shape, False, n))
+        ones, res = like(1.0), like(0.0)
+        d.initial_shift(A, B, mode)
+        (d.sddmmA if mode == H.K_SDDMM_A else d.sddmmB)(A, B, ones, res)
+        keys = np.rint(res.download()).astype(np.int64)
+        res.upload(np.array([lookup[k] for k in keys.tolist()], dtype=np.float64))
+        gts.append(res); ones.free()
+    als = H.DistributedALS(d, False)
+    als.set_ground_truth(gts[0], gts[1])
+    A.upload(fill_local(subA, A.shape, case["A"])); B.upload(fill_local(subB, B.shape, case["B"]))
+    als.set_embeddings(A, B)
+    residuals = [als.computeResidual()]
+    for _ in range(steps):
+        als.cg_optimizer(H.AMAT, iters)
+        als.cg_optimizer(H.BMAT, iters)
+        residuals.append(als.computeResidual())
+    als.get_embeddings(A, B)
+    out = dict(subA=subA, subB=subB, alsA=A.download(), alsB=B.download(), residuals=np.array(residuals))
+    als.free()
+    for x in (A, B, gts[0], gts[1]):
+        x.free()
+    d.free(); sp.free()
+    return out
+
+
+def assemble_dense(per_rank, name, which, nrows, r):
+    g = np.zeros((nrows, r))
+    for o in per_rank:
+        flat, off = o[name].reshape(-1), 0
+        for top, left, rc, cc in o[which]:
+            blk = flat[off:off + rc * cc].reshape(rc, cc)
+            off += rc * cc
+            keep = max(0, min(rc, nrows - top))
+            g[top:top + keep, left:left + cc] = blk[:keep]
+    return g
+
+
+def check_als_against_golden(per_rank, case):
+    gold = dict(np.load(os.path.join(GOLDEN, "als_%s.npz" % case["name"])))
+    a = assemble_dense(per_rank, "alsA", "subA", case["M"], case["R"])
+    b = assemble_dense(per_rank, "alsB", "subB", case["N"], case["R"])
+    assert rel(a, gold["A"]) <= ALS_TOL, rel(a, gold["A"])
+    assert rel(b, gold["B"]) <= ALS_TOL, rel(b, gold["B"])
+    assert rel(per_rank[0]["residuals"], gold["residuals"]) <= ALS_TOL
+    assert gold["residuals"][-1] < 0.2 * gold["residuals"][0], "ALS must reduce the residual"

@@ -161,3 +161,25 @@ def test_elementwise(ctx):
     dr, di = ctx.upload(rowptr), ctx.upload(np.full(len(ridx), -1, np.int32))
     ctx.check(lib.hnh_expand_rowptr(ctx.h, rows, dr.ptr, di.ptr, 0), "expand")
     assert np.array_equal(di.get(), ridx)
+
+
+@pytest.mark.parametrize("R", [1, 3, 8, 16, 64, 128, 130, 256])
+def test_rowwise_als_helpers(ctx, R):
+    """hnh_rowdot_f64 / hnh_row_scale_add_f64 / hnh_vec_* against numpy (als_conjugate_gradients.cpp:9-29,99-137)."""
+    lib = ctx.lib
+    rows = 1237
+    rng = np.random.default_rng(R)
+    A, B = rng.uniform(-1, 1, (rows, R)), rng.uniform(-1, 1, (rows, R))
+    yv, xv = rng.uniform(-1, 1, rows), rng.uniform(0.5, 1.5, rows)
+    dA, dB, dyv, dxv, dout = ctx.upload(A), ctx.upload(B), ctx.upload(yv), ctx.upload(xv), ctx.upload(np.zeros(rows))
+    ctx.check(lib.hnh_rowdot_f64(ctx.h, dA.ptr, dB.ptr, dout.ptr, rows, R, 0), "rowdot")
+    assert rel(dout.get(), np.einsum("ij,ij->i", A, B)) <= 1e-14
+    ctx.check(lib.hnh_row_scale_add_f64(ctx.h, dA.ptr, dyv.ptr, 0.5, dB.ptr, dxv.ptr, -2.0, rows, R, 0), "row_scale_add")
+    assert rel(dA.get(), 0.5 * yv[:, None] * A - 2.0 * xv[:, None] * B) <= 1e-15
+    dA.set(A)
+    ctx.check(lib.hnh_row_scale_add_f64(ctx.h, dA.ptr, None, 1.0, dB.ptr, None, 1e-13, rows, R, 0), "row_scale_add lambda")
+    assert rel(dA.get(), A + 1e-13 * B) <= 1e-15
+    ctx.check(lib.hnh_vec_add_scalar_f64(ctx.h, dyv.ptr, 1e-8, rows, 0), "vec_add")
+    assert np.array_equal(dyv.get(), yv + 1e-8)
+    ctx.check(lib.hnh_vec_div_f64(ctx.h, dout.ptr, dyv.ptr, dxv.ptr, rows, 0), "vec_div")
+    assert np.array_equal(dout.get(), (yv + 1e-8) / xv)

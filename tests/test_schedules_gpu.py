@@ -92,3 +92,21 @@ def test_relay_ring_and_mesh_fetch_agree_with_the_reference(monkeypatch, mode, a
     case = T.case_inputs("er8_r16")
     per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
     T.check_against_golden(T.assemble(per_rank, case), per_rank, case, alg)
+
+
+@pytest.mark.parametrize("alg,p,c", [("15d_fusion2", 1, 1), ("15d_fusion2", 4, 2), ("15d_fusion1", 4, 1), ("15d_sparse", 4, 1),
+                                     ("25d_dense_replicate", 8, 2), ("25d_sparse_replicate", 8, 2)])
+def test_als_cg_matches_reference_hip(alg, p, c):
+    """BASELINE config 5 (ALS-CG iteration around fusedSpMM) on the GPU vs the reference's own ALS code."""
+    case = T.case_inputs("er8_r16")
+    per_rank = H.run_spmd(p, lambda w: T.run_als(w, alg, c, case, 1, 5))
+    T.check_als_against_golden(per_rank, case)
+
+
+@pytest.mark.parametrize("alg,p,c", [("25d_dense_replicate", 8, 2), ("15d_fusion2", 4, 1), ("15d_sparse", 4, 1)])
+def test_config4_shape_skewed_graph_hip(alg, p, c):
+    """Shape of BASELINE config 4: skewed (R-MAT) graph, R = 256, 2.5D dense-replicate on 8 ranks with c = 2."""
+    rows, cols = H.generate_rmat(13, 8192 * 16)
+    case = T.make_case("rmat13", 8192, 8192, 256, rows, cols)
+    per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
+    T.check_against_oracle(T.assemble(per_rank, case), case, alg)
