@@ -110,3 +110,25 @@ def test_config4_shape_skewed_graph_hip(alg, p, c):
     case = T.make_case("rmat13", 8192, 8192, 256, rows, cols)
     per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
     T.check_against_oracle(T.assemble(per_rank, case), case, alg)
+
+
+def test_cpp_dropin_driver(tmp_path):
+    """examples/bench_er.cpp — the reference's bench_erdos_renyi.cpp + benchmark_dist.cpp re-written against our class
+    headers — runs end to end and appends JSON records with the reference's keys (benchmark_dist.cpp:151-162)."""
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(T.ROOT, "examples", "bench_er")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    out = tmp_path / "results.json"
+    for alg, fused in (("15d", "fused"), ("25d", "fused"), ("15d_sparse", "unfused")):
+        r = subprocess.run([exe, "12", "8", alg, "32", "1", str(out), fused], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    recs = json.loads("[" + out.read_text().rstrip().rstrip(",") + "]")
+    assert [r["alg_name"] for r in recs] == ["15d_fusion1", "15d_fusion2", "25d_sparse_replicate", "25d_dense_replicate", "15d_sparse"]
+    for r in recs:
+        for key in ("elapsed", "overall_throughput", "fused", "num_trials", "alg_name", "alg_info", "application_communication_time", "perf_stats"):
+            assert key in r
+        assert r["num_trials"] == 5 and r["alg_info"]["backend"] == "hip-gfx950" and "Computation Time" in r["perf_stats"]
+    r = subprocess.run([exe, "10", "8", "15d_fusion2", "16", "1", str(out), "fused", "als"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
