@@ -31,10 +31,7 @@ public:
         std::swap(w_, o.w_); std::swap(p_, o.p_); std::swap(bytes_, o.bytes_); std::swap(owned_, o.owned_);
     }
     void reset() {
-        if (p_ && owned_ && w_) {
-            w_->sync_all();  // nothing in flight may still touch it
-            w_->dfree(p_);
-        }
+        if (p_ && owned_ && w_) w_->dfree(p_);  // stream-ordered: the world's pool parks it behind events
         p_ = nullptr; bytes_ = 0; owned_ = false;
     }
     void* ptr() const { return p_; }

@@ -115,7 +115,6 @@ public:
     }
 
     ~CSRLocal() {
-        world->sync_all();
         for (int t = 0; t < 2; t++) {
             world->dfree(buffer[t].values);
             world->dfree(buffer[t].col_idx);

@@ -101,6 +101,7 @@ World::~World() {}
 void World::init_device(Backend* backend, int device_ordinal) {
     be = backend ? backend : default_backend();
     device = device_ordinal;
+    if (const char* lim = std::getenv("HNH_POOL_LIMIT_GB")) pool_limit_ = (size_t)std::strtoull(lim, nullptr, 10) << 30;
     int st = be->hnh_ctx_create(device_ordinal, &ctx);
     if (st != HNH_OK || !ctx)
         fatal("Error, cannot create a device context on device " + std::to_string(device_ordinal) + " with backend " +
@@ -110,8 +111,9 @@ void World::init_device(Backend* backend, int device_ordinal) {
 void World::destroy_device() {
     if (ctx) {
         for (auto& s : scratch_)
-            if (s.first) be->hnh_free(ctx, s.first);
+            if (s.first) dfree(s.first);
         scratch_.clear();
+        drain_pool();
         be->hnh_ctx_destroy(ctx);
         ctx = nullptr;
     }
@@ -123,12 +125,58 @@ void World::check(int status, const char* what) const {
 }
 
 void* World::dmalloc(size_t bytes) {
+    bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+    auto it = pool_.find(bytes);
+    if (it != pool_.end()) {
+        Parked e = it->second;
+        pool_.erase(it);
+        pooled_bytes_ -= bytes;
+        // the new owner may touch the block on either stream: order it after the old owner's last use on the other one
+        event_wait(e.ev[HNH_STREAM_COMPUTE], HNH_STREAM_COMM);
+        event_wait(e.ev[HNH_STREAM_COMM], HNH_STREAM_COMPUTE);
+        event_destroy(e.ev[0]);
+        event_destroy(e.ev[1]);
+        live_[e.ptr] = bytes;
+        return e.ptr;
+    }
     void* p = nullptr;
-    check(be->hnh_malloc(ctx, bytes, &p), "hnh_malloc");
+    int st = be->hnh_malloc(ctx, bytes, &p);
+    if (st == HNH_ERR_NOMEM && !pool_.empty()) {  // give parked memory back and retry once
+        drain_pool();
+        st = be->hnh_malloc(ctx, bytes, &p);
+    }
+    check(st, "hnh_malloc");
+    live_[p] = bytes;
     return p;
 }
+
 void World::dfree(void* p) {
-    if (p) check(be->hnh_free(ctx, p), "hnh_free");
+    if (!p) return;
+    auto it = live_.find(p);
+    if (it == live_.end()) fatal("Error, freeing a device pointer this world did not allocate");
+    const size_t bytes = it->second;
+    live_.erase(it);
+    if (pooled_bytes_ + bytes <= pool_limit_) {
+        Parked e{p, {event_create(), event_create()}};
+        event_record(e.ev[HNH_STREAM_COMPUTE], HNH_STREAM_COMPUTE);
+        event_record(e.ev[HNH_STREAM_COMM], HNH_STREAM_COMM);
+        pool_.insert({bytes, e});
+        pooled_bytes_ += bytes;
+        return;
+    }
+    sync_all();
+    check(be->hnh_free(ctx, p), "hnh_free");
+}
+
+void World::drain_pool() {
+    sync_all();
+    for (auto& kv : pool_) {
+        be->hnh_event_destroy(ctx, kv.second.ev[0]);
+        be->hnh_event_destroy(ctx, kv.second.ev[1]);
+        be->hnh_free(ctx, kv.second.ptr);
+    }
+    pool_.clear();
+    pooled_bytes_ = 0;
 }
 void World::copy(void* dst, const void* src, size_t bytes, int kind, int stream) {
     if (bytes) check(be->hnh_memcpy(ctx, dst, src, bytes, kind, stream), "hnh_memcpy");
@@ -156,10 +204,7 @@ void* World::scratch(int slot, size_t bytes) {
     if ((int)scratch_.size() <= slot) scratch_.resize(slot + 1, {nullptr, 0});
     auto& s = scratch_[slot];
     if (s.second < bytes) {
-        if (s.first) {
-            sync_all();
-            dfree(s.first);
-        }
+        if (s.first) dfree(s.first);
         s.first = dmalloc(bytes);
         s.second = bytes;
     }

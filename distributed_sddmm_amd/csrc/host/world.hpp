@@ -16,8 +16,10 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <map>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include "backend.hpp"
 #include "hnh_dist.h"
@@ -98,6 +100,19 @@ protected:
     void init_device(Backend* backend, int device_ordinal);
     void destroy_device();
     std::vector<std::pair<void*, size_t>> scratch_;
+
+    // Caching allocator.  hipMalloc / hipFree synchronise the device, and the reference's call pattern creates
+    // and drops temporaries on every call (like_S_values in computeQueries, als_conjugate_gradients.cpp:276-277).
+    // Freed blocks are parked with one event per stream; a block handed out again makes each stream wait for
+    // the other stream's last use, so no host synchronisation is needed.  Bounded by HNH_POOL_LIMIT_GB (default 16).
+    struct Parked {
+        void* ptr;
+        void* ev[2];
+    };
+    std::multimap<size_t, Parked> pool_;
+    std::unordered_map<void*, size_t> live_;
+    size_t pooled_bytes_ = 0, pool_limit_ = (size_t)16 << 30;
+    void drain_pool();
 };
 
 World* current_world();
