@@ -107,6 +107,14 @@ SIGNATURES = {
     "hnh_als_cg_optimizer": (_i32, [_vp, _i32, _i32]),
     "hnh_als_run_cg": (_i32, [_vp, _i32]),
     "hnh_als_compute_residual": (_i32, [_vp, _pdbl]),
+    "hnh_gat_create": (_i32, [_vp, _i32, _pi32, _dbl, _pvp]),
+    "hnh_gat_destroy": (_i32, [_vp]),
+    "hnh_gat_weight_shape": (_i32, [_vp, _i32, _i32, _pi64]),
+    "hnh_gat_set_weight": (_i32, [_vp, _i32, _i32, _vp]),
+    "hnh_gat_set_input": (_i32, [_vp, _vp]),
+    "hnh_gat_get_output": (_i32, [_vp, _vp]),
+    "hnh_gat_buffer_shape": (_i32, [_vp, _i32, _pi64]),
+    "hnh_gat_forward": (_i32, [_vp]),
 }
 
 _lib = None
@@ -527,4 +535,43 @@ class DistributedALS:
     def free(self):
         if self.h:
             _check(lib().hnh_als_destroy(self.h), "als_destroy")
+            self.h = None
+
+
+class GAT:
+    """GAT (gat.hpp): multi-head graph-attention forward pass on top of a DistributedSparse."""
+
+    def __init__(self, op: DistributedSparse, layers, leaky_relu_alpha: float = 0.2):
+        self.op, self.layers = op, [tuple(l) for l in layers]
+        spec = (C.c_int * (3 * len(layers)))(*[x for l in self.layers for x in l])
+        self.h = _vp()
+        _check(lib().hnh_gat_create(op.h, len(layers), spec, leaky_relu_alpha, C.byref(self.h)), "gat_create")
+
+    def weight_shape(self, layer: int, head: int):
+        o = (C.c_int64 * 2)()
+        _check(lib().hnh_gat_weight_shape(self.h, layer, head, o), "gat_weight_shape")
+        return int(o[0]), int(o[1])
+
+    def set_weight(self, layer: int, head: int, w: np.ndarray):
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        assert w.shape == self.weight_shape(layer, head)
+        _check(lib().hnh_gat_set_weight(self.h, layer, head, w.ctypes.data), "gat_set_weight")
+
+    def buffer_shape(self, index: int):
+        o = (C.c_int64 * 2)()
+        _check(lib().hnh_gat_buffer_shape(self.h, index, o), "gat_buffer_shape")
+        return int(o[0]), int(o[1])
+
+    def set_input(self, x: Dense):
+        _check(lib().hnh_gat_set_input(self.h, x.h), "gat_set_input")
+
+    def get_output(self, out: Dense):
+        _check(lib().hnh_gat_get_output(self.h, out.h), "gat_get_output")
+
+    def forwardPass(self):
+        _check(lib().hnh_gat_forward(self.h), "forwardPass")
+
+    def free(self):
+        if self.h:
+            _check(lib().hnh_gat_destroy(self.h), "gat_destroy")
             self.h = None

@@ -347,6 +347,71 @@ __global__ __launch_bounds__(kBlock) void vec_div_kernel(double* out, const doub
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = num[i] / den[i];
 }
 
+// ---------------------------------------------------------------- fp64 GEMM on the matrix cores (GAT's X * W)
+// Block tile 64 x 64, K step 16, 4 waves; wave w owns rows [16w, 16w+16) x 64 columns = four 16x16 accumulators.
+// v_mfma_f64_16x16x4_f64 fragment layout (cdna_hip_programming.md, "f64 MFMA does NOT use these maps"):
+//   A: lane l holds A[i = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][j = l & 15];
+//   C/D: register r of lane l is C[row = (l >> 4) + 4 r][col = l & 15].
+typedef double d4_t __attribute__((ext_vector_type(4)));
+constexpr int kGemmBM = 64, kGemmBN = 64, kGemmBK = 16;
+
+__global__ __launch_bounds__(kBlock) void gemm_f64_kernel(int64_t M, int64_t N, int64_t K, const double* __restrict__ A,
+                                                          const double* __restrict__ B, double* __restrict__ C) {
+    __shared__ double As[kGemmBM][kGemmBK + 1];
+    __shared__ double Bs[kGemmBK][kGemmBN + 2];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t row0 = (int64_t)blockIdx.y * kGemmBM, col0 = (int64_t)blockIdx.x * kGemmBN;
+    d4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    const int ar = tid >> 2, ac = (tid & 3) * 4;   // A tile: 64 rows x 16 cols, 4 doubles per thread
+    const int br = tid >> 4, bc = (tid & 15) * 4;  // B tile: 16 rows x 64 cols, 4 doubles per thread
+    for (int64_t k0 = 0; k0 < K; k0 += kGemmBK) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int64_t gr = row0 + ar, gc = k0 + ac + q;
+            As[ar][ac + q] = (gr < M && gc < K) ? A[gr * K + gc] : 0.0;
+            const int64_t hr = k0 + br, hc = col0 + bc + q;
+            Bs[br][bc + q] = (hr < K && hc < N) ? B[hr * N + hc] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < kGemmBK; kk += 4) {
+            const double a = As[wave * 16 + (lane & 15)][kk + (lane >> 4)];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const double b = Bs[kk + (lane >> 4)][t * 16 + (lane & 15)];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int64_t row = row0 + wave * 16 + (lane >> 4) + 4 * r, col = col0 + t * 16 + (lane & 15);
+            if (row < M && col < N) C[row * N + col] = acc[t][r];
+        }
+}
+
+__global__ __launch_bounds__(kBlock) void leaky_relu_kernel(double* v, double alpha, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const double x = v[i];
+        v[i] = fmax(x, 0.0) + fmin(x, 0.0) * alpha;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void relu_store_cols_kernel(double* __restrict__ dst, int64_t ld, int64_t col0,
+                                                                 const double* __restrict__ src, int64_t rows, int64_t cols) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock, total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / cols, c = i % cols;
+        dst[r * ld + col0 + c] = fmax(src[i], 0.0);
+    }
+}
+
 int ew_grid(int64_t n) {
     int64_t blocks = (n + kBlock - 1) / kBlock;
     if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 resident blocks, grid-stride the rest
@@ -594,6 +659,37 @@ int hnh_vec_div_f64(hnh_ctx* ctx, double* out, const double* num, const double* 
     if (!out || !num || !den) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_vec_div_f64: null pointer");
     hipLaunchKernelGGL(vec_div_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, ctx->streams[stream], out, num, den, n);
     return hnh::check_hip(ctx, hipGetLastError(), "vec_div_kernel launch");
+}
+
+int hnh_gemm_f64(hnh_ctx* ctx, int64_t M, int64_t N, int64_t K, const double* A, const double* B, double* C, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (M < 0 || N < 0 || K < 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_gemm_f64: negative size");
+    if (M == 0 || N == 0) return HNH_OK;
+    if (!C || (K > 0 && (!A || !B))) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_gemm_f64: null pointer");
+    const int64_t gy = (M + kGemmBM - 1) / kGemmBM, gx = (N + kGemmBN - 1) / kGemmBN;
+    if (gy > 65535 * 1024LL || gx > 0x7fffffffLL) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "hnh_gemm_f64: matrix too large");
+    hipLaunchKernelGGL(gemm_f64_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, ctx->streams[stream], M, N, K, A, B, C);
+    return hnh::check_hip(ctx, hipGetLastError(), "gemm_f64_kernel launch");
+}
+
+int hnh_leaky_relu_f64(hnh_ctx* ctx, double* v, double alpha, int64_t n, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (n < 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_leaky_relu_f64: negative size");
+    if (n == 0) return HNH_OK;
+    if (!v) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_leaky_relu_f64: null pointer");
+    hipLaunchKernelGGL(leaky_relu_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, ctx->streams[stream], v, alpha, n);
+    return hnh::check_hip(ctx, hipGetLastError(), "leaky_relu_kernel launch");
+}
+
+int hnh_relu_store_cols_f64(hnh_ctx* ctx, double* dst, int64_t ld_dst, int64_t col0, const double* src, int64_t rows,
+                            int64_t cols, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (rows < 0 || cols < 0 || col0 < 0 || col0 + cols > ld_dst) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_relu_store_cols_f64: bad shape");
+    if (rows == 0 || cols == 0) return HNH_OK;
+    if (!dst || !src) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_relu_store_cols_f64: null pointer");
+    hipLaunchKernelGGL(relu_store_cols_kernel, dim3(ew_grid(rows * cols)), dim3(kBlock), 0, ctx->streams[stream], dst, ld_dst, col0,
+                       src, rows, cols);
+    return hnh::check_hip(ctx, hipGetLastError(), "relu_store_cols_kernel launch");
 }
 
 int hnh_expand_rowptr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, int32_t* row_idx, int stream) {

@@ -8,6 +8,7 @@
 #include "cannon_sparse_25d.hpp"
 #include "dense_shift_15d.hpp"
 #include "er_generator.hpp"
+#include "gat.hpp"
 #include "hnh_dist.h"
 #include "sparse_shift_15d.hpp"
 
@@ -38,6 +39,11 @@ struct hnh_dist {
 struct hnh_als {
     hnh::World* w;
     std::unique_ptr<Distributed_ALS> a;
+};
+
+struct hnh_gat {
+    hnh::World* w;
+    std::unique_ptr<GAT> g;
 };
 
 namespace {
@@ -441,6 +447,52 @@ int hnh_als_run_cg(hnh_als* a, int steps) {
 }
 int hnh_als_compute_residual(hnh_als* a, double* out) {
     return guarded(a->w, [&] { *out = a->a->computeResidual(); });
+}
+
+// ------------------------------------------------------------------ GAT
+int hnh_gat_create(hnh_dist* d, int nlayers, const int* spec3, double alpha, hnh_gat** out) {
+    return guarded(d->w, [&] {
+        std::vector<GATLayer> layers;
+        for (int l = 0; l < nlayers; l++) layers.emplace_back(spec3[3 * l], spec3[3 * l + 1], spec3[3 * l + 2]);
+        std::unique_ptr<hnh_gat> h(new hnh_gat());
+        h->w = d->w;
+        h->g.reset(new GAT(layers, d->d.get()));
+        h->g->leaky_relu_alpha = alpha;
+        *out = h.release();
+    });
+}
+int hnh_gat_destroy(hnh_gat* g) {
+    return guarded(g ? g->w : nullptr, [&] { delete g; });
+}
+int hnh_gat_weight_shape(hnh_gat* g, int layer, int head, int64_t o[2]) {
+    return guarded(g->w, [&] {
+        DenseMatrix& W = g->g->layers.at(layer).wMats.at(head);
+        o[0] = W.rows();
+        o[1] = W.cols();
+    });
+}
+int hnh_gat_set_weight(hnh_gat* g, int layer, int head, const double* host) {
+    return guarded(g->w, [&] { g->g->layers.at(layer).wMats.at(head).copy_from_host(host); });
+}
+int hnh_gat_set_input(hnh_gat* g, hnh_dense* X) {
+    return guarded(g->w, [&] {
+        DenseMatrix& b = g->g->buffers.at(0);
+        if (b.rows() != X->m.rows() || b.cols() != X->m.cols()) hnh::fatal("Error, GAT input has the wrong shape!");
+        b = X->m;
+    });
+}
+int hnh_gat_get_output(hnh_gat* g, hnh_dense* out) {
+    return guarded(g->w, [&] { out->m = g->g->buffers.back(); });
+}
+int hnh_gat_buffer_shape(hnh_gat* g, int index, int64_t o[2]) {
+    return guarded(g->w, [&] {
+        DenseMatrix& b = g->g->buffers.at(index);
+        o[0] = b.rows();
+        o[1] = b.cols();
+    });
+}
+int hnh_gat_forward(hnh_gat* g) {
+    return guarded(g->w, [&] { g->g->forwardPass(); });
 }
 
 }  // extern "C"

@@ -155,6 +155,18 @@ int hnh_als_cg_optimizer(hnh_als* a, int matmode, int cg_max_iter);             
 int hnh_als_run_cg(hnh_als* a, int n_alternating_steps);                               /* run_cg (.cpp:235-263)      */
 int hnh_als_compute_residual(hnh_als* a, double* out);                                 /* computeResidual (.cpp:201-219) */
 
+/* ---- GAT forward pass (gat.hpp; BASELINE config 5's second application) */
+typedef struct hnh_gat hnh_gat; /* GAT */
+/* GAT(layers, d_ops) (gat.hpp:57-81): spec3 = {input_features, features_per_head, num_heads} per layer */
+int hnh_gat_create(hnh_dist* d, int nlayers, const int* spec3, double leaky_relu_alpha, hnh_gat** out);
+int hnh_gat_destroy(hnh_gat* g);
+int hnh_gat_weight_shape(hnh_gat* g, int layer, int head, int64_t out2[2]);       /* layers[l].wMats[h] */
+int hnh_gat_set_weight(hnh_gat* g, int layer, int head, const double* host);      /* row-major, host */
+int hnh_gat_set_input(hnh_gat* g, hnh_dense* X);                                  /* buffers[0] (copied in)  */
+int hnh_gat_get_output(hnh_gat* g, hnh_dense* out);                               /* buffers.back() (copied) */
+int hnh_gat_buffer_shape(hnh_gat* g, int index, int64_t out2[2]);                 /* buffers[index]          */
+int hnh_gat_forward(hnh_gat* g);                                                  /* forwardPass (gat.hpp:106-112) */
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,6 +120,16 @@ int hnh_row_scale_add_f64(hnh_ctx* ctx, double* Y, const double* yv, double ya, 
 int hnh_vec_add_scalar_f64(hnh_ctx* ctx, double* v, double c, int64_t n, int stream);
 int hnh_vec_div_f64(hnh_ctx* ctx, double* out, const double* num, const double* den, int64_t n, int stream);
 
+/* ---- dense helpers of the GAT application (gat.hpp:83-104) -----------------------------------------------------
+ * hnh_gemm_f64            — `buffers[i] * wMats[j]` (gat.hpp:88): C[M x N] = A[M x K] * B[K x N], row-major, on the fp64
+ *                           matrix cores (v_mfma_f64_16x16x4_f64): the one true dense contraction of the path
+ * hnh_leaky_relu_f64      — `x.max(0) + x.min(0) * alpha` on the SDDMM values (gat.hpp:96-97), in place
+ * hnh_relu_store_cols_f64 — `dst.middleCols(col0, cols) = src.array().max(0)` (gat.hpp:103) */
+int hnh_gemm_f64(hnh_ctx* ctx, int64_t M, int64_t N, int64_t K, const double* A, const double* B, double* C, int stream);
+int hnh_leaky_relu_f64(hnh_ctx* ctx, double* v, double alpha, int64_t n, int stream);
+int hnh_relu_store_cols_f64(hnh_ctx* ctx, double* dst, int64_t ld_dst, int64_t col0, const double* src, int64_t rows,
+                            int64_t cols, int stream);
+
 /* ---- RCCL ring / collectives over xGMI ---------------------------------------------------------------
  * Replace the MPI calls of the shift schedules:
  *   hnh_comm_sendrecv        — MPI_Sendrecv in shiftDenseMatrix (distributed_sparse.h:351-361) and the

@@ -36,7 +36,7 @@ g++ $CXXFLAGS -I"$HERE/stubs" -I"$TMP/inc" -I"$REF" \
 #     because the reference includes them with quotes, so mirror the headers into $TMP/patched.
 for f in common.h common.cpp sparse_kernels.h sparse_kernels.cpp SpmatLocal.hpp FlexibleGrid.hpp distributed_sparse.h \
          15D_dense_shift.hpp 15D_sparse_shift.hpp 25D_cannon_dense.hpp 25D_cannon_sparse.hpp \
-         als_conjugate_gradients.h als_conjugate_gradients.cpp json.hpp; do cp "$REF/$f" "$TMP/patched/"; done
+         als_conjugate_gradients.h als_conjugate_gradients.cpp gat.hpp json.hpp; do cp "$REF/$f" "$TMP/patched/"; done
 python3 - "$TMP/patched/SpmatLocal.hpp" <<'PY'
 import sys, re
 p = sys.argv[1]; s = open(p).read()

@@ -188,6 +188,30 @@ int hnh_vec_div_f64(hnh_ctx* c, double* out, const double* num, const double* de
     return HNH_OK;
 }
 
+/* gat.hpp:88 (Eigen dense product), :96-97, :103 */
+int hnh_gemm_f64(hnh_ctx* c, int64_t M, int64_t N, int64_t K, const double* A, const double* B, double* C, int stream) {
+    (void)c; (void)stream;
+    for (int64_t i = 0; i < M; i++) {
+        for (int64_t j = 0; j < N; j++) C[i * N + j] = 0.0;
+        for (int64_t k = 0; k < K; k++) {
+            const double a = A[i * K + k];
+            for (int64_t j = 0; j < N; j++) C[i * N + j] += a * B[k * N + j];
+        }
+    }
+    return HNH_OK;
+}
+int hnh_leaky_relu_f64(hnh_ctx* c, double* v, double alpha, int64_t n, int stream) {
+    (void)c; (void)stream;
+    for (int64_t i = 0; i < n; i++) v[i] = (v[i] > 0.0 ? v[i] : 0.0) + (v[i] < 0.0 ? v[i] : 0.0) * alpha;
+    return HNH_OK;
+}
+int hnh_relu_store_cols_f64(hnh_ctx* c, double* dst, int64_t ld, int64_t col0, const double* src, int64_t rows, int64_t cols, int stream) {
+    (void)c; (void)stream;
+    for (int64_t i = 0; i < rows; i++)
+        for (int64_t j = 0; j < cols; j++) dst[i * ld + col0 + j] = src[i * cols + j] > 0.0 ? src[i * cols + j] : 0.0;
+    return HNH_OK;
+}
+
 /* no RCCL on the CPU: host-logic tests use the thread-loopback or callback transports */
 #define UNSUP(c) return fail((c), HNH_ERR_UNSUPPORTED, "RCCL transport is not available in the CPU test double")
 int hnh_comm_unique_id(void* id) { (void)id; return HNH_ERR_UNSUPPORTED; }

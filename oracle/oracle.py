@@ -157,6 +157,31 @@ def fingerprints(rows, cols, m, n, r):
     return f1, f2, f3
 
 
+# ------------------------------------------------------------------ GAT forward (gat.hpp:83-112)
+
+def gat_weight(layer: int, head: int, k: int, n: int, seed: int = 31) -> np.ndarray:
+    """W(layer, head) of shape (k, n): hashed uniform(-1, 1) / k — what oracle/ref_driver.cpp's gat mode installs."""
+    kk, jj = np.meshgrid(np.arange(k, dtype=np.uint64), np.arange(n, dtype=np.uint64), indexing="ij")
+    keys = ((np.uint64(layer * 64 + head) * np.uint64(65536) + kk) * np.uint64(65536) + jj)
+    return hashed_uniform(keys.reshape(-1), seed).reshape(k, n) / k
+
+
+def gat_forward(rows, cols, m, x, layers, alpha: float, seed: int = 31) -> np.ndarray:
+    """gat.hpp:83-112 for schedules that do not split R.  Per head: A = X W (:88); e = SDDMM(A, A) with S = 1
+    (:92); LeakyReLU(e) (:96-97); H = SpMM(e, A) (:100); output columns of the head = ReLU(H) (:103)."""
+    ones = np.ones(len(rows))
+    for li, (fin, fph, heads) in enumerate(layers):
+        assert x.shape[1] == fin
+        out = np.zeros((m, fph * heads))
+        for h in range(heads):
+            a = x @ gat_weight(li, h, fin, fph, seed)
+            e = sddmm(rows, cols, ones, a, a)
+            e = np.maximum(e, 0.0) + np.minimum(e, 0.0) * alpha
+            out[:, h * fph:(h + 1) * fph] = np.maximum(spmm_a(rows, cols, e, a, m), 0.0)
+        x = out
+    return x
+
+
 # ------------------------------------------------------------------ kernel-level semantics (rows a1/a2)
 
 def sddmm_local(row_idx, col_idx, values, x, y) -> np.ndarray:

@@ -21,11 +21,15 @@
 //   ref_driver als   <case.bin> <alg> <c> <outprefix> <steps> <cg_iters>   ALS-CG (als_conjugate_gradients.cpp):
 //        ground truth = the input S values (keyed by coordinate), embeddings initialised from the case's A, B,
 //        `steps` x { cg_optimizer(Amat, cg_iters); cg_optimizer(Bmat, cg_iters) } (= run_cg, :235-263), dumps A, B
+//   ref_driver gat   <case.bin> <alg> <c> <outprefix> <alpha> <in:fph:heads>[,<in:fph:heads>...]   GAT forward pass
+//        (gat.hpp:106-112) with input features = the case's A, weights W(layer, head)[k][j] = hashed uniform / K and
+//        leaky_relu_alpha = <alpha> set through public members (the reference leaves both unset)
 // <alg> in {15d_fusion1, 15d_fusion2, 15d_sparse, 25d_dense_replicate, 25d_sparse_replicate}.
 #include "15D_dense_shift.hpp"
 #include "15D_sparse_shift.hpp"
 #include "25D_cannon_dense.hpp"
 #include "25D_cannon_sparse.hpp"
+#include "gat.hpp"
 
 #include <omp.h>
 #include <cstdio>
@@ -300,6 +304,51 @@ void run_als(const Case& cs, Distributed_Sparse* d, const std::string& prefix, i
     dump(prefix, rank, "residuals.f64", residuals.data(), residuals.size() * 8);
 }
 
+double hashed_uniform(uint64_t key, uint64_t seed) {  // twin of oracle/oracle.py:hashed_uniform
+    auto mix = [](uint64_t x) {
+        uint64_t z = x + 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    const uint64_t h = mix(seed * 0xD1342543DE82EF95ull + key * 0x9E3779B97F4A7C15ull);
+    return (double)(h >> 11) * 0x1.0p-52 - 1.0;
+}
+
+// GAT forward pass on the reference's own gat.hpp.  Only meaningful for schedules that do not split R
+// (the reference multiplies LOCAL column slices by W without reducing, gat.hpp:88).
+void run_gat(const Case& cs, Distributed_Sparse* d, const std::string& prefix, double alpha, const std::string& spec) {
+    const int rank = d->proc_rank;
+    std::vector<GATLayer> layers;
+    size_t pos = 0;
+    while (pos < spec.size()) {
+        size_t end = spec.find(',', pos);
+        if (end == std::string::npos) end = spec.size();
+        int in = 0, fph = 0, heads = 0;
+        if (std::sscanf(spec.substr(pos, end - pos).c_str(), "%d:%d:%d", &in, &fph, &heads) != 3) die("bad layer spec");
+        layers.emplace_back(in, fph, heads);
+        pos = end + 1;
+    }
+    GAT gnn(layers, d);
+    gnn.leaky_relu_alpha = alpha;
+    d->setRValue(gnn.layers[0].input_features);
+    fill_local(d, gnn.buffers[0], Bmat, cs.A.data(), cs.N, cs.R);
+    for (size_t l = 0; l < gnn.layers.size(); l++)
+        for (int h = 0; h < gnn.layers[l].num_heads; h++) {
+            DenseMatrix& W = gnn.layers[l].wMats[h];
+            for (long k = 0; k < W.rows(); k++)
+                for (long j = 0; j < W.cols(); j++)
+                    W(k, j) = hashed_uniform((((uint64_t)l * 64 + (uint64_t)h) * 65536 + (uint64_t)k) * 65536 + (uint64_t)j, 31) / (double)W.rows();
+        }
+    gnn.forwardPass();
+    const GATLayer& last = gnn.layers.back();
+    d->setRValue(last.features_per_head * last.num_heads);
+    int64_t dims[8] = {d->localArows, d->localAcols, d->localBrows, d->localBcols, d->p, d->c, cs.M, cs.N};
+    dump(prefix, rank, "dims.i64", dims, sizeof(dims));
+    dump_subs(prefix, rank, "subA.i64", d->aSubmatrices);
+    dump(prefix, rank, "gat.f64", gnn.buffers.back().data(), gnn.buffers.back().size() * 8);
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -311,7 +360,7 @@ int main(int argc, char** argv) {
     if (argc < 5) die("usage: ref_driver dump|fp|bench <case.bin> <alg> <c> [...]");
     std::string mode = argv[1], alg = argv[3];
     int c = std::atoi(argv[4]);
-    Case cs = load_case(argv[2], mode == "dump" || mode == "als");
+    Case cs = load_case(argv[2], mode == "dump" || mode == "als" || mode == "gat");
     {
         SpmatLocal S;
         inject(S, cs, rank, p);
@@ -323,6 +372,9 @@ int main(int argc, char** argv) {
         } else if (mode == "als") {
             if (argc < 8) die("als needs <outprefix> <steps> <cg_iters>");
             run_als(cs, d, argv[5], std::atoi(argv[6]), std::atoi(argv[7]));
+        } else if (mode == "gat") {
+            if (argc < 8) die("gat needs <outprefix> <alpha> <layers>");
+            run_gat(cs, d, argv[5], std::atof(argv[6]), argv[7]);
         } else if (mode == "fp") {
             run_fp(d, alg);
         } else if (mode == "bench") {

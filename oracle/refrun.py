@@ -150,3 +150,15 @@ def als(m, n, rows, cols, vals, r, a, b, alg: str, p: int, c: int, steps: int, c
         run(["als", case, alg, c, prefix, steps, cg_iters], p, alg, timeout=timeout)
         return {"A": _assemble_dense(prefix, p, "alsA.f64", "A", m, r), "B": _assemble_dense(prefix, p, "alsB.f64", "B", n, r),
                 "residuals": np.fromfile(prefix + ".r0.residuals.f64", dtype=np.float64)}
+
+
+def gat(m, rows, cols, r_in, a, alg: str, p: int, c: int, alpha: float, layers, timeout: float = 300.0):
+    """GAT forward pass of the reference (gat.hpp:106-112) on a square graph: input features `a` (m x r_in),
+    layers = [(in, features_per_head, heads), ...]; returns the final global feature matrix."""
+    with tempfile.TemporaryDirectory(prefix="hnh_ref_") as td:
+        case = os.path.join(td, "case.bin")
+        write_case(case, m, m, rows, cols, np.ones(len(rows)), r_in, a, a)
+        prefix = os.path.join(td, "out")
+        spec = ",".join("%d:%d:%d" % tuple(l) for l in layers)
+        run(["gat", case, alg, c, prefix, repr(float(alpha)), spec], p, alg, timeout=timeout)
+        return _assemble_dense(prefix, p, "gat.f64", "A", m, layers[-1][1] * layers[-1][2])

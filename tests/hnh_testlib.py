@@ -291,3 +291,33 @@ def check_als_against_golden(per_rank, case):
     assert rel(b, gold["B"]) <= ALS_TOL, rel(b, gold["B"])
     assert rel(per_rank[0]["residuals"], gold["residuals"]) <= ALS_TOL
     assert gold["residuals"][-1] < 0.2 * gold["residuals"][0], "ALS must reduce the residual"
+
+
+GAT_LAYERS = [(16, 8, 2), (16, 4, 3)]  # (input_features, features_per_head, num_heads)
+GAT_ALPHA = 0.2
+GAT_INPUT_SCALE = 50.0
+
+
+def run_gat(world: H.World, alg: str, c: int, case: dict, layers=None, alpha: float = GAT_ALPHA) -> dict:
+    """GAT forward pass driven like oracle/ref_driver.cpp's `gat` mode (same hashed weights, input = case A)."""
+    layers = layers or GAT_LAYERS
+    sp = H.SpmatLocal.from_global(world, case["M"], case["N"], case["rows"], case["cols"], np.ones(len(case["rows"])))
+    d = H.DistributedSparse(world, alg, sp, case["R"], c)
+    gnn = H.GAT(d, layers, alpha)
+    for li, (fin, fph, heads) in enumerate(layers):
+        for h in range(heads):
+            k, n = gnn.weight_shape(li, h)
+            gnn.set_weight(li, h, O.gat_weight(li, h, k, n))
+    d.setRValue(layers[0][0])
+    subB = d.submatrices(H.BMAT)
+    x = H.Dense.create(world, *gnn.buffer_shape(0))
+    x.upload(fill_local(subB, x.shape, case["A"] * GAT_INPUT_SCALE))
+    gnn.set_input(x)
+    gnn.forwardPass()
+    d.setRValue(layers[-1][1] * layers[-1][2])
+    subA = d.submatrices(H.AMAT)
+    out = H.Dense.create(world, *gnn.buffer_shape(len(layers)))
+    gnn.get_output(out)
+    res = dict(subA=subA, gat=out.download())
+    x.free(); out.free(); gnn.free(); d.free(); sp.free()
+    return res

@@ -183,3 +183,30 @@ def test_rowwise_als_helpers(ctx, R):
     assert np.array_equal(dyv.get(), yv + 1e-8)
     ctx.check(lib.hnh_vec_div_f64(ctx.h, dout.ptr, dyv.ptr, dxv.ptr, rows, 0), "vec_div")
     assert np.array_equal(dout.get(), (yv + 1e-8) / xv)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (100, 37, 29), (513, 130, 70), (1000, 256, 256), (16, 8, 1024), (5, 3, 1)])
+def test_gemm_f64_mfma(ctx, M, N, K):
+    """hnh_gemm_f64 (v_mfma_f64_16x16x4_f64, gat.hpp:88) vs numpy; asymmetric operands catch row/col swaps."""
+    lib = ctx.lib
+    rng = np.random.default_rng(M * 7 + N)
+    A, B = rng.uniform(-1, 1, (M, K)), rng.uniform(-1, 1, (K, N))
+    B[0, :] += np.arange(N)  # asymmetric on purpose
+    dA, dB, dC = ctx.upload(A), ctx.upload(B), ctx.upload(np.full((M, N), 7.0))
+    ctx.check(lib.hnh_gemm_f64(ctx.h, M, N, K, dA.ptr, dB.ptr, dC.ptr, 0), "gemm")
+    assert rel(dC.get(), A @ B) <= 1e-13
+
+
+def test_gat_elementwise(ctx):
+    lib = ctx.lib
+    rng = np.random.default_rng(1)
+    v = rng.uniform(-1, 1, 10007)
+    dv = ctx.upload(v)
+    ctx.check(lib.hnh_leaky_relu_f64(ctx.h, dv.ptr, 0.2, len(v), 0), "leaky")
+    assert np.array_equal(dv.get(), np.maximum(v, 0) + np.minimum(v, 0) * 0.2)
+    src = rng.uniform(-1, 1, (33, 5))
+    dst0 = rng.uniform(-1, 1, (33, 12))
+    dsrc, ddst = ctx.upload(src), ctx.upload(dst0)
+    ctx.check(lib.hnh_relu_store_cols_f64(ctx.h, ddst.ptr, 12, 4, dsrc.ptr, 33, 5, 0), "relu cols")
+    want = dst0.copy(); want[:, 4:9] = np.maximum(src, 0)
+    assert np.array_equal(ddst.get(), want)

@@ -132,3 +132,14 @@ def test_cpp_dropin_driver(tmp_path):
         assert r["num_trials"] == 5 and r["alg_info"]["backend"] == "hip-gfx950" and "Computation Time" in r["perf_stats"]
     r = subprocess.run([exe, "10", "8", "15d_fusion2", "16", "1", str(out), "fused", "als"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("alg,p,c", [("15d_fusion1", 1, 1), ("15d_fusion1", 4, 2), ("15d_fusion2", 1, 1), ("15d_fusion2", 4, 1)])
+def test_gat_forward_matches_reference_hip(alg, p, c):
+    """GAT head = MFMA fp64 GEMM + SDDMM + LeakyReLU + SpMM + ReLU on the GPU vs the reference's own gat.hpp."""
+    import os
+    case = T.case_inputs("er8_r16")
+    per_rank = H.run_spmd(p, lambda w: T.run_gat(w, alg, c, case))
+    out = T.assemble_dense(per_rank, "gat", "subA", case["M"], T.GAT_LAYERS[-1][1] * T.GAT_LAYERS[-1][2])
+    gold = dict(np.load(os.path.join(T.GOLDEN, "gat_er8_r16.npz")))["out"]
+    assert T.rel(out, gold) <= T.TOL
