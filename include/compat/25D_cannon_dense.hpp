@@ -1,0 +1,4 @@
+// Forwarding header: lets code written against the reference's include names build against this engine
+// (add -I include/compat -I distributed_sddmm_amd/csrc/host -I include).  See INTEGRATION.md section A.
+#pragma once
+#include "../../distributed_sddmm_amd/csrc/host/cannon_dense_25d.hpp"

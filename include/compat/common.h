@@ -1,0 +1,8 @@
+// Forwarding header: lets code written against the reference's include names build against this engine
+// (add -I include/compat -I distributed_sddmm_amd/csrc/host -I include).  See INTEGRATION.md section A.
+#pragma once
+#include "../../distributed_sddmm_amd/csrc/host/common.hpp"
+#include "../../distributed_sddmm_amd/csrc/host/dense.hpp"
+using hnh::BufferPair;
+using hnh::DenseMatrix;
+using hnh::VectorXd;

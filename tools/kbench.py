@@ -19,9 +19,17 @@ def main():
     ap.add_argument("--r", type=int, default=128)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--ops", default="fused,sddmm,spmm")
+    ap.add_argument("--rmat", action="store_true", help="skewed R-MAT graph instead of Erdos-Renyi")
     a = ap.parse_args()
     t0 = time.time()
-    rows_i, cols_i = O.erdos_renyi(a.logm, a.ef)
+    if a.rmat:
+        from distributed_sddmm_amd import api as H
+        rows_i, cols_i = H.generate_rmat(a.logm, (1 << a.logm) * a.ef)
+        deg = np.bincount(rows_i, minlength=1 << a.logm)
+        print("R-MAT: max row degree %d, mean %.1f, rows with > 4096 nnz: %d" % (deg.max(), deg.mean(), int((deg > 4096).sum())), flush=True)
+    else:
+        from distributed_sddmm_amd import api as H
+        rows_i, cols_i = H.generate_er(1 << a.logm, 1 << a.logm, (1 << a.logm) * a.ef)
     m = 1 << a.logm
     nnz = len(rows_i)
     rowptr = np.zeros(m + 1, np.int64)
