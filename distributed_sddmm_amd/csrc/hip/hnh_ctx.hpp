@@ -8,6 +8,10 @@ struct hnh_ctx {
     int device = 0;
     hipStream_t streams[2] = {nullptr, nullptr};  // [HNH_STREAM_COMPUTE], [HNH_STREAM_COMM]
     std::string last_error;
+    // work list of the long-row pass (one per stream): items = (row, segment), count lives on the device
+    void* long_items[2] = {nullptr, nullptr};
+    int* long_count[2] = {nullptr, nullptr};
+    size_t long_cap[2] = {0, 0};
 };
 
 namespace hnh {

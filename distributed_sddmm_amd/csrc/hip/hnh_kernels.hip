@@ -116,30 +116,25 @@ enum class Op { kSddmm, kSpmm, kFused };
 // ---------------------------------------------------------------- the row kernel (sddmm / spmm / fused)
 //
 // Columns handled: [col0, col0 + ncols) of rows of length `ld`; EXACT means ncols == W*LPR*VEC.
+//
+// Long rows.  Real graphs have hub rows (an R-MAT stand-in at 2^20 vertices has rows of > 80 000 nonzeros);
+// a single group walking such a row serialises the whole launch behind it (measured: 27 % of the roofline
+// instead of 81 %).  Rows longer than kLongRow are therefore skipped by the row kernel and cut into segments
+// of kLongSeg nonzeros that are spread over the whole chip by a second, small launch (`long_row_kernel`);
+// SDDMM segments are independent, SpMM / fused segments combine their partial output rows with hardware fp64
+// atomics (global_atomic_add_f64).  Callers that know the block's longest row (the host layer does) pass it
+// as a hint and short-row matrices never pay for any of this.
+constexpr int kLongRow = 1024;
+constexpr int kLongSeg = 256;
+constexpr unsigned kInternalSplitLong = 0x100u;  // flag bit, never set by callers
+
 template <Op OP, int LPR, int VEC, int W, bool EXACT>
-__global__ __launch_bounds__(kBlock) void row_kernel(int64_t rows, const int32_t* __restrict__ rowptr,
-                                                     const int32_t* __restrict__ colidx, double* values,
-                                                     const double* __restrict__ svalues,
-                                                     const double* __restrict__ X, const double* __restrict__ Y,
-                                                     double* __restrict__ Out, int64_t ld, int col0, int ncols,
-                                                     unsigned flags) {
+__device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool atomic_out, const int32_t* __restrict__ colidx,
+                                            double* values, const double* __restrict__ svalues, const double* __restrict__ X,
+                                            const double* __restrict__ Y, double* __restrict__ Out, int64_t ld, int col0,
+                                            int ncols, unsigned flags, int lig) {
     constexpr int U = Unroll<LPR, VEC>::value;
     constexpr int SUB = LPR / U;  // lanes that end up holding the same reduced value
-    constexpr int GROUPS = kBlock / LPR;
-    const int tid = threadIdx.x;
-    const int lig = tid % LPR;
-    int64_t row = (int64_t)blockIdx.x * GROUPS + tid / LPR;
-    if constexpr (LPR == 64) row = ((int64_t)blockIdx.x * GROUPS) + __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (row >= rows) return;
-
-    int beg = rowptr[row];
-    int end = rowptr[row + 1];
-    if constexpr (LPR == 64) {
-        beg = __builtin_amdgcn_readfirstlane(beg);
-        end = __builtin_amdgcn_readfirstlane(end);
-    }
-    if (OP == Op::kSddmm && beg == end) return;
-
     bool act[VEC];
     int64_t coff[VEC];
 #pragma unroll
@@ -158,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void row_kernel(int64_t rows, const int32_t
         if (act[v]) {
             if constexpr (OP != Op::kSpmm) load_w<W>(x[v], X + row * ld + coff[v]);
             if constexpr (OP != Op::kSddmm) {
-                if (!(flags & HNH_FUSED_OUT_OVERWRITE)) load_w<W>(acc[v], Out + row * ld + coff[v]);
+                if (!atomic_out && !(flags & HNH_FUSED_OUT_OVERWRITE)) load_w<W>(acc[v], Out + row * ld + coff[v]);
             }
         }
     }
@@ -223,9 +218,97 @@ __global__ __launch_bounds__(kBlock) void row_kernel(int64_t rows, const int32_t
 
     if constexpr (OP != Op::kSddmm) {
 #pragma unroll
-        for (int v = 0; v < VEC; v++)
-            if (act[v]) store_w<W>(Out + row * ld + coff[v], acc[v]);
+        for (int v = 0; v < VEC; v++) {
+            if (!act[v]) continue;
+            if (atomic_out) {
+#pragma unroll
+                for (int w = 0; w < W; w++) unsafeAtomicAdd(Out + row * ld + coff[v] + w, acc[v][w]);
+            } else {
+                store_w<W>(Out + row * ld + coff[v], acc[v]);
+            }
+        }
     }
+}
+
+template <Op OP, int LPR, int VEC, int W, bool EXACT>
+__global__ __launch_bounds__(kBlock) void row_kernel(int64_t rows, const int32_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ colidx, double* values,
+                                                     const double* __restrict__ svalues,
+                                                     const double* __restrict__ X, const double* __restrict__ Y,
+                                                     double* __restrict__ Out, int64_t ld, int col0, int ncols,
+                                                     unsigned flags) {
+    constexpr int GROUPS = kBlock / LPR;
+    const int tid = threadIdx.x;
+    const int lig = tid % LPR;
+    int64_t row = (int64_t)blockIdx.x * GROUPS + tid / LPR;
+    if constexpr (LPR == 64) row = ((int64_t)blockIdx.x * GROUPS) + __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (row >= rows) return;
+
+    int beg = rowptr[row];
+    int end = rowptr[row + 1];
+    if constexpr (LPR == 64) {
+        beg = __builtin_amdgcn_readfirstlane(beg);
+        end = __builtin_amdgcn_readfirstlane(end);
+    }
+    if (OP == Op::kSddmm && beg == end) return;
+    if ((flags & kInternalSplitLong) && end - beg > kLongRow) {
+        // left to long_row_kernel; it adds atomically, so an overwritten output row has to start from zero
+        if (OP != Op::kSddmm && (flags & HNH_FUSED_OUT_OVERWRITE)) end = beg;
+        else return;
+    }
+    process_row<OP, LPR, VEC, W, EXACT>(row, beg, end, false, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, lig);
+}
+
+// One work item = kLongSeg consecutive nonzeros of a long row; items are listed by build_long_list_kernel.
+template <Op OP, int LPR, int VEC, int W, bool EXACT>
+__global__ __launch_bounds__(kBlock) void long_row_kernel(const int2* __restrict__ items, const int* __restrict__ item_count,
+                                                          int capacity, const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ colidx, double* values,
+                                                          const double* __restrict__ svalues, const double* __restrict__ X,
+                                                          const double* __restrict__ Y, double* __restrict__ Out, int64_t ld,
+                                                          int col0, int ncols, unsigned flags) {
+    constexpr int GROUPS = kBlock / LPR;
+    const int tid = threadIdx.x;
+    const int lig = tid % LPR;
+    int count = *item_count;
+    if (count > capacity) count = capacity;
+    const int ngroups = (int)gridDim.x * GROUPS;
+    for (int it = (int)blockIdx.x * GROUPS + tid / LPR; it < count; it += ngroups) {
+        const int2 item = items[it];
+        const int64_t row = item.x;
+        const int rbeg = rowptr[row], rend = rowptr[row + 1];
+        const int beg = rbeg + item.y * kLongSeg;
+        const int end = (beg + kLongSeg < rend) ? beg + kLongSeg : rend;
+        process_row<OP, LPR, VEC, W, EXACT>(row, beg, end, true, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, lig);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void build_long_list_kernel(int64_t rows, const int32_t* __restrict__ rowptr,
+                                                                 int2* __restrict__ items, int* __restrict__ item_count,
+                                                                 int capacity) {
+    const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= rows) return;
+    const int len = rowptr[row + 1] - rowptr[row];
+    if (len <= kLongRow) return;
+    const int nseg = (len + kLongSeg - 1) / kLongSeg;
+    const int base = atomicAdd(item_count, nseg);
+    for (int s2 = 0; s2 < nseg; s2++)
+        if (base + s2 < capacity) items[base + s2] = make_int2((int)row, s2);
+}
+
+__global__ __launch_bounds__(kBlock) void max_row_nnz_kernel(int64_t rows, const int32_t* __restrict__ rowptr, int* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int m = 0;
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < rows; row += stride) {
+        const int len = rowptr[row + 1] - rowptr[row];
+        m = len > m ? len : m;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int o = __shfl_xor(m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
 // ---------------------------------------------------------------- COO SDDMM (no rowptr available)
@@ -443,26 +526,75 @@ Shape pick_shape(int R, bool vec_ok) {
     return s;
 }
 
+struct LongCtl {
+    bool enabled = false;
+    int2* items = nullptr;
+    int* count = nullptr;
+    int capacity = 0;
+};
+
+// Decides whether this call needs the long-row pass and, if so, builds the (row, segment) work list on the
+// device.  max_row_nnz: the caller's knowledge of the longest row (< 0 = unknown -> the list is always built);
+// nnz: number of nonzeros (< 0 = unknown -> read back from rowptr[rows], one 4-byte synchronous copy).
+int prepare_long(hnh_ctx* ctx, hipStream_t st, int sidx, int64_t rows, const int32_t* rowptr, int64_t nnz, int max_row_nnz,
+                 LongCtl* lc) {
+    if (max_row_nnz >= 0 && max_row_nnz <= kLongRow) return HNH_OK;
+    if (nnz < 0) {
+        int last = 0;
+        HNH_TRY_HIP(ctx, hipMemcpyAsync(&last, rowptr + rows, sizeof(int), hipMemcpyDeviceToHost, st));
+        HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
+        nnz = last;
+    }
+    if (nnz <= kLongRow) return HNH_OK;
+    const size_t cap = (size_t)(nnz / kLongSeg + nnz / kLongRow + 16);
+    if (ctx->long_cap[sidx] < cap) {
+        HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
+        if (ctx->long_items[sidx]) HNH_TRY_HIP(ctx, hipFree(ctx->long_items[sidx]));
+        ctx->long_items[sidx] = nullptr;
+        HNH_TRY_HIP(ctx, hipMalloc(&ctx->long_items[sidx], cap * sizeof(int2)));
+        ctx->long_cap[sidx] = cap;
+    }
+    if (!ctx->long_count[sidx]) HNH_TRY_HIP(ctx, hipMalloc((void**)&ctx->long_count[sidx], sizeof(int)));
+    lc->items = static_cast<int2*>(ctx->long_items[sidx]);
+    lc->count = ctx->long_count[sidx];
+    lc->capacity = (int)cap;
+    lc->enabled = true;
+    HNH_TRY_HIP(ctx, hipMemsetAsync(lc->count, 0, sizeof(int), st));
+    const int64_t blocks = (rows + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(build_long_list_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, rowptr, lc->items, lc->count, lc->capacity);
+    return hnh::check_hip(ctx, hipGetLastError(), "build_long_list_kernel launch");
+}
+
 template <Op OP, int LPR, int VEC, int W, bool EXACT>
-int launch_row(hnh_ctx* ctx, hipStream_t st, int64_t rows, const int32_t* rowptr, const int32_t* colidx,
+int launch_row(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, int64_t rows, const int32_t* rowptr, const int32_t* colidx,
                double* values, const double* svalues, const double* X, const double* Y, double* Out, int64_t ld,
                int col0, int ncols, unsigned flags) {
     constexpr int GROUPS = kBlock / LPR;
     const int64_t blocks = (rows + GROUPS - 1) / GROUPS;
     if (blocks <= 0) return HNH_OK;
     if (blocks > 0x7fffffffLL) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "too many rows for one launch");
+    if (lc.enabled) flags |= kInternalSplitLong;
     hipLaunchKernelGGL((row_kernel<OP, LPR, VEC, W, EXACT>), dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, rowptr,
                        colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags);
-    return hnh::check_hip(ctx, hipGetLastError(), "row_kernel launch");
+    if (int rc = hnh::check_hip(ctx, hipGetLastError(), "row_kernel launch")) return rc;
+    if (lc.enabled) {
+        // 256 CUs x 4 resident workgroups; items are spread round-robin over all groups of the grid
+        hipLaunchKernelGGL((long_row_kernel<OP, LPR, VEC, W, EXACT>), dim3(1024), dim3(kBlock), 0, st, lc.items, lc.count,
+                           lc.capacity, rowptr, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags);
+        return hnh::check_hip(ctx, hipGetLastError(), "long_row_kernel launch");
+    }
+    return HNH_OK;
 }
 
 template <Op OP>
-int dispatch_row(hnh_ctx* ctx, hipStream_t st, const Shape& s, int64_t rows, const int32_t* rowptr,
-                 const int32_t* colidx, double* values, const double* svalues, const double* X, const double* Y,
-                 double* Out, int R, unsigned flags) {
+int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t rows, int64_t nnz, int max_row_nnz,
+                 const int32_t* rowptr, const int32_t* colidx, double* values, const double* svalues, const double* X,
+                 const double* Y, double* Out, int R, unsigned flags) {
+    LongCtl lc;
+    if (int rc = prepare_long(ctx, st, sidx, rows, rowptr, nnz, max_row_nnz, &lc)) return rc;
 #define HNH_CASE(L, V)                                                                                         \
     if (s.lpr == L && s.vec == V)                                                                              \
-        return launch_row<OP, L, V, 2, true>(ctx, st, rows, rowptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags);
+        return launch_row<OP, L, V, 2, true>(ctx, st, lc, rows, rowptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags);
     if (s.exact) {
         HNH_CASE(1, 1) HNH_CASE(2, 1) HNH_CASE(4, 1) HNH_CASE(8, 1) HNH_CASE(16, 1) HNH_CASE(32, 1) HNH_CASE(64, 1)
         HNH_CASE(64, 2) HNH_CASE(64, 3) HNH_CASE(64, 4) HNH_CASE(32, 3) HNH_CASE(32, 5) HNH_CASE(32, 7)
@@ -476,9 +608,9 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, const Shape& s, int64_t rows, con
         const int ncols = (R - col0 < tile) ? (R - col0) : tile;
         int rc;
         if (s.w == 2)
-            rc = launch_row<OP, 64, 1, 2, false>(ctx, st, rows, rowptr, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags);
+            rc = launch_row<OP, 64, 1, 2, false>(ctx, st, lc, rows, rowptr, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags);
         else
-            rc = launch_row<OP, 64, 1, 1, false>(ctx, st, rows, rowptr, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags);
+            rc = launch_row<OP, 64, 1, 1, false>(ctx, st, lc, rows, rowptr, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags);
         if (rc != HNH_OK) return rc;
     }
     return HNH_OK;
@@ -507,31 +639,48 @@ int check_common(hnh_ctx* ctx, int64_t n, int R, const char* who) {
 
 extern "C" {
 
-int hnh_sddmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
-                  const double* X, const double* Y, int R, int stream) {
+int hnh_sddmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
+                     const double* X, const double* Y, int R, int64_t nnz, int max_row_nnz, int stream) {
     HNH_ENTER(ctx, stream);
     if (int rc = check_common(ctx, rows, R, "hnh_sddmm_csr")) return rc;
     if (rows == 0) return HNH_OK;
     if (!rowptr || !col_idx || !values || !X || !Y) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sddmm_csr: null pointer");
     const Shape s = pick_shape(R, aligned16(X) && aligned16(Y));
-    return dispatch_row<Op::kSddmm>(ctx, ctx->streams[stream], s, rows, rowptr, col_idx, values, nullptr, X, Y, nullptr, R, 0u);
+    return dispatch_row<Op::kSddmm>(ctx, ctx->streams[stream], stream, s, rows, nnz, max_row_nnz, rowptr, col_idx, values, nullptr, X,
+                                    Y, nullptr, R, 0u);
+}
+
+int hnh_sddmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
+                  const double* X, const double* Y, int R, int stream) {
+    return hnh_sddmm_csr_ex(ctx, rows, rowptr, col_idx, values, X, Y, R, -1, -1, stream);
 }
 
 int hnh_spmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values,
                  const double* X, double* Out, int R, int stream) {
+    return hnh_spmm_csr_ex(ctx, rows, rowptr, col_idx, values, X, Out, R, -1, -1, stream);
+}
+
+int hnh_spmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values,
+                    const double* X, double* Out, int R, int64_t nnz, int max_row_nnz, int stream) {
     HNH_ENTER(ctx, stream);
     if (int rc = check_common(ctx, rows, R, "hnh_spmm_csr")) return rc;
     if (rows == 0) return HNH_OK;
     if (!rowptr || !col_idx || !values || !X || !Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_spmm_csr: null pointer");
     if (X == Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_spmm_csr: X and Out alias");
     const Shape s = pick_shape(R, aligned16(X) && aligned16(Out));
-    return dispatch_row<Op::kSpmm>(ctx, ctx->streams[stream], s, rows, rowptr, col_idx, const_cast<double*>(values), nullptr,
-                                   X, nullptr, Out, R, 0u);
+    return dispatch_row<Op::kSpmm>(ctx, ctx->streams[stream], stream, s, rows, nnz, max_row_nnz, rowptr, col_idx,
+                                   const_cast<double*>(values), nullptr, X, nullptr, Out, R, 0u);
 }
 
 int hnh_fused_sddmm_spmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
                              const double* svalues, const double* X, const double* Y, double* Out, int R,
                              unsigned flags, int stream) {
+    return hnh_fused_sddmm_spmm_csr_ex(ctx, rows, rowptr, col_idx, values, svalues, X, Y, Out, R, flags, -1, -1, stream);
+}
+
+int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
+                                const double* svalues, const double* X, const double* Y, double* Out, int R,
+                                unsigned flags, int64_t nnz_in, int max_row_nnz, int stream) {
     HNH_ENTER(ctx, stream);
     if (int rc = check_common(ctx, rows, R, "hnh_fused_sddmm_spmm_csr")) return rc;
     if (rows == 0) return HNH_OK;
@@ -543,16 +692,22 @@ int hnh_fused_sddmm_spmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, 
     hipStream_t st = ctx->streams[stream];
     const Shape s = pick_shape(R, aligned16(X) && aligned16(Y) && aligned16(Out));
     if (s.exact)
-        return dispatch_row<Op::kFused>(ctx, st, s, rows, rowptr, col_idx, values, svalues, X, Y, Out, R, flags);
+        return dispatch_row<Op::kFused>(ctx, st, stream, s, rows, nnz_in, max_row_nnz, rowptr, col_idx, values, svalues, X, Y, Out, R,
+                                        flags);
     // Tiled fallback (R odd or not a supported multiple): the dot product needs the whole row before the
     // axpy can start, so compose the two column-tiled passes; same arithmetic, one extra gather.
-    int nnz = 0;
-    HNH_TRY_HIP(ctx, hipMemcpyAsync(&nnz, rowptr + rows, sizeof(int), hipMemcpyDeviceToHost, st));
-    HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
+    int64_t nnz = nnz_in;
+    if (nnz < 0) {
+        int last = 0;
+        HNH_TRY_HIP(ctx, hipMemcpyAsync(&last, rowptr + rows, sizeof(int), hipMemcpyDeviceToHost, st));
+        HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
+        nnz = last;
+    }
     if (flags & HNH_FUSED_VALUES_OVERWRITE) HNH_TRY_HIP(ctx, hipMemsetAsync(values, 0, sizeof(double) * (size_t)nnz, st));
     if (flags & HNH_FUSED_OUT_OVERWRITE) HNH_TRY_HIP(ctx, hipMemsetAsync(Out, 0, sizeof(double) * (size_t)rows * R, st));
-    if (int rc = dispatch_row<Op::kSddmm>(ctx, st, s, rows, rowptr, col_idx, values, nullptr, X, Y, nullptr, R, 0u)) return rc;
-    return dispatch_row<Op::kSpmm>(ctx, st, s, rows, rowptr, col_idx, values, svalues, Y, nullptr, Out, R, 0u);
+    if (int rc = dispatch_row<Op::kSddmm>(ctx, st, stream, s, rows, nnz, max_row_nnz, rowptr, col_idx, values, nullptr, X, Y, nullptr, R, 0u))
+        return rc;
+    return dispatch_row<Op::kSpmm>(ctx, st, stream, s, rows, nnz, max_row_nnz, rowptr, col_idx, values, svalues, Y, nullptr, Out, R, 0u);
 }
 
 int hnh_sddmm_coo(hnh_ctx* ctx, int64_t nnz, const int32_t* row_idx, const int32_t* col_idx, double* values,
@@ -690,6 +845,21 @@ int hnh_relu_store_cols_f64(hnh_ctx* ctx, double* dst, int64_t ld_dst, int64_t c
     hipLaunchKernelGGL(relu_store_cols_kernel, dim3(ew_grid(rows * cols)), dim3(kBlock), 0, ctx->streams[stream], dst, ld_dst, col0,
                        src, rows, cols);
     return hnh::check_hip(ctx, hipGetLastError(), "relu_store_cols_kernel launch");
+}
+
+int hnh_csr_max_row_nnz(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, int* out_host, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (rows < 0 || !out_host) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_csr_max_row_nnz: bad argument");
+    *out_host = 0;
+    if (rows == 0) return HNH_OK;
+    if (!rowptr) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_csr_max_row_nnz: null pointer");
+    hipStream_t st = ctx->streams[stream];
+    if (!ctx->long_count[stream]) HNH_TRY_HIP(ctx, hipMalloc((void**)&ctx->long_count[stream], sizeof(int)));
+    HNH_TRY_HIP(ctx, hipMemsetAsync(ctx->long_count[stream], 0, sizeof(int), st));
+    hipLaunchKernelGGL(max_row_nnz_kernel, dim3(ew_grid(rows)), dim3(kBlock), 0, st, rows, rowptr, ctx->long_count[stream]);
+    HNH_TRY_HIP(ctx, hipGetLastError());
+    HNH_TRY_HIP(ctx, hipMemcpyAsync(out_host, ctx->long_count[stream], sizeof(int), hipMemcpyDeviceToHost, st));
+    return hnh::check_hip(ctx, hipStreamSynchronize(st), "hipStreamSynchronize");
 }
 
 int hnh_expand_rowptr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, int32_t* row_idx, int stream) {

@@ -32,6 +32,8 @@ int hnh_ctx_destroy(hnh_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (int s = 0; s < 2; s++) {
         if (ctx->streams[s]) { (void)hipStreamSynchronize(ctx->streams[s]); (void)hipStreamDestroy(ctx->streams[s]); }
+        if (ctx->long_items[s]) (void)hipFree(ctx->long_items[s]);
+        if (ctx->long_count[s]) (void)hipFree(ctx->long_count[s]);
     }
     delete ctx;
     return HNH_OK;

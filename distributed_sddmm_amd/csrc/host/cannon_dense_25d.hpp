@@ -91,6 +91,8 @@ public:
         ST->initializeCSRBlocks(localBrows * c, localArows, max_nnz_tpose, true);
         std::vector<spcoord_t>().swap(ST->coords);
 
+        publish_ring_max_row(S.get(), grid->row_world);
+        publish_ring_max_row(ST.get(), grid->row_world);
         // Skew the sparse blocks along grid rows in preparation for repeated Cannon passes (:138-145)
         const int src = pMod(grid->rankInRow + grid->rankInCol, sqrtpc);
         const int dst = pMod(grid->rankInRow - grid->rankInCol, sqrtpc);

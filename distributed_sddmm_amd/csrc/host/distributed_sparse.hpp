@@ -229,6 +229,16 @@ public:
     }
 
 protected:
+    // Travelling blocks: every rank of the ring must know the longest row of ANY block that will visit it
+    // (the kernels' long-row hint); one int all-gathered over the ring at construction.
+    void publish_ring_max_row(SpmatLocal* s, const hnh::Comm& ring) {
+        CSRLocal* blk = s->csr_blocks[0];
+        int mine = blk ? blk->max_row_nnz : 0;
+        std::vector<int> all(ring.size(), 0);
+        world->host_allgather_comm(ring, &mine, all.data(), sizeof(int));
+        if (blk) blk->ring_max_row_nnz = *std::max_element(all.begin(), all.end());
+    }
+
     // small pool of events for compute/communication hand-offs
     std::vector<void*> events_;
     void* event(size_t i) {

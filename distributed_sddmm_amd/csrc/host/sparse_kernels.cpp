@@ -14,8 +14,8 @@ size_t StandardKernel::sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
     CSRHandle* active = blk->getActive();
     hnh::World* w = S.world;
     begin(w);
-    w->check(w->be->hnh_sddmm_csr(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, Xptr, Yptr,
-                                  (int)A.cols(), HNH_STREAM_COMPUTE),
+    w->check(w->be->hnh_sddmm_csr_ex(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, Xptr, Yptr,
+                                     (int)A.cols(), blk->num_coords, blk->row_hint(), HNH_STREAM_COMPUTE),
              "hnh_sddmm_csr");
     end(w);
     return processed;
@@ -34,8 +34,8 @@ size_t StandardKernel::spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B,
     const double* X = (mode == Amat) ? B.data() : A.data();
     double* Out = (mode == Amat) ? A.data() : B.data();
     begin(w);
-    w->check(w->be->hnh_spmm_csr(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, X, Out, (int)A.cols(),
-                                 HNH_STREAM_COMPUTE),
+    w->check(w->be->hnh_spmm_csr_ex(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, X, Out, (int)A.cols(),
+                                    blk->num_coords, blk->row_hint(), HNH_STREAM_COMPUTE),
              "hnh_spmm_csr");
     end(w);
     return processed;
@@ -51,8 +51,9 @@ size_t StandardKernel::fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
     CSRHandle* active = blk->getActive();
     hnh::World* w = S.world;
     begin(w);
-    w->check(w->be->hnh_fused_sddmm_spmm_csr(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, nullptr,
-                                             A.data(), B.data(), Out.data(), (int)A.cols(), flags, HNH_STREAM_COMPUTE),
+    w->check(w->be->hnh_fused_sddmm_spmm_csr_ex(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, nullptr,
+                                                A.data(), B.data(), Out.data(), (int)A.cols(), flags, blk->num_coords,
+                                                blk->row_hint(), HNH_STREAM_COMPUTE),
              "hnh_fused_sddmm_spmm_csr");
     end(w);
     return 0;

@@ -86,6 +86,8 @@ public:
         std::vector<spcoord_t>().swap(S->coords);
         ST->initializeCSRBlocks(blockBwidth, localArows * c, max_nnz_tpose, false);
         std::vector<spcoord_t>().swap(ST->coords);
+        publish_ring_max_row(S.get(), grid->col_world);
+        publish_ring_max_row(ST.get(), grid->col_world);
         check_initialized();
     }
 

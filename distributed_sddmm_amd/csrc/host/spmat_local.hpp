@@ -57,6 +57,10 @@ public:
     CSRHandle* buffer;  // [2]; buffer[1] has null arrays when the block never shifts
     bool shifting;
     hnh::World* world;
+    // Longest row of this block, and an upper bound over every block that can occupy these buffers after a
+    // shift (set by the schedule from a ring all-gather).  Passed to the kernels as the long-row hint.
+    int max_row_nnz = 0, ring_max_row_nnz = 0;
+    int row_hint() const { return shifting ? ring_max_row_nnz : max_row_nnz; }
 
     CSRLocal(int64_t blockRows, int64_t blockCols, int64_t max_nnz_in, spcoord_t* coords, int num_coords_in, bool transpose_in,
              bool shifting_in = true)
@@ -76,7 +80,11 @@ public:
             if ((int64_t)coords[e].r >= rows || (int64_t)coords[e].c >= cols) hnh::fatal("Error, nonzero outside its block!");
             rowStart[coords[e].r + 1]++;
         }
-        for (int64_t r = 0; r < rows; r++) rowStart[r + 1] += rowStart[r];
+        for (int64_t r = 0; r < rows; r++) {
+            max_row_nnz = std::max(max_row_nnz, (int)rowStart[r + 1]);
+            rowStart[r + 1] += rowStart[r];
+        }
+        ring_max_row_nnz = max_row_nnz;
         std::vector<spcoord_t> sorted((size_t)num_coords);
         {
             std::vector<int32_t> cursor(rowStart.begin(), rowStart.end() - 1);

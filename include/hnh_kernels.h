@@ -99,6 +99,20 @@ int hnh_fused_sddmm_spmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, 
                              double* values, const double* svalues, const double* X, const double* Y,
                              double* Out, int R, unsigned flags, int stream);
 
+/* Variants for callers that know the block: `nnz` = rowptr[rows] and `max_row_nnz` = its longest row (either may
+ * be -1 = unknown).  Rows longer than 1024 nonzeros (hub vertices of real graphs) are cut into 256-nonzero
+ * segments that a second small launch spreads over the whole chip (SpMM / fused segments combine with fp64
+ * atomics); with max_row_nnz <= 1024 none of that machinery runs.  The plain entry points above pass -1, -1.
+ * hnh_csr_max_row_nnz computes the hint (one device reduction + 4-byte synchronous copy). */
+int hnh_sddmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
+                     const double* X, const double* Y, int R, int64_t nnz, int max_row_nnz, int stream);
+int hnh_spmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values,
+                    const double* X, double* Out, int R, int64_t nnz, int max_row_nnz, int stream);
+int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx,
+                                double* values, const double* svalues, const double* X, const double* Y, double* Out,
+                                int R, unsigned flags, int64_t nnz, int max_row_nnz, int stream);
+int hnh_csr_max_row_nnz(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, int* out_host, int stream);
+
 /* ---- element-wise helpers (K3-K5 of SURVEY §2.4) ----------------------------------------------------
  * hnh_fill_f64      — SpmatLocal::setValuesConstant (SpmatLocal.hpp:595-605), DenseMatrix::setZero
  * hnh_hadamard_f64  — `SValues.cwiseProduct(choice->getCSRValues())` (15D_dense_shift.hpp:366)

@@ -99,6 +99,12 @@ int hnh_sddmm_csr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t
     return HNH_OK;
 }
 
+int hnh_sddmm_csr_ex(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values, const double* X,
+                     const double* Y, int R, int64_t nnz, int max_row_nnz, int stream) {
+    (void)nnz; (void)max_row_nnz;  /* hints only */
+    return hnh_sddmm_csr(c, rows, rowptr, col_idx, values, X, Y, R, stream);
+}
+
 /* C = 1.0 * S * X + 1.0 * C, row-major, ld = R (sparse_kernels.cpp:95-107) */
 int hnh_spmm_csr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values, const double* X,
                  double* Out, int R, int stream) {
@@ -113,6 +119,12 @@ int hnh_spmm_csr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t*
             for (int k = 0; k < R; k++) Crow[k] += v * Xrow[k];
         }
     return HNH_OK;
+}
+
+int hnh_spmm_csr_ex(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values, const double* X,
+                    double* Out, int R, int64_t nnz, int max_row_nnz, int stream) {
+    (void)nnz; (void)max_row_nnz;
+    return hnh_spmm_csr(c, rows, rowptr, col_idx, values, X, Out, R, stream);
 }
 
 /* 15D_dense_shift.hpp:203-217: sddmm on the block, then spmm with the block's (updated) values */
@@ -133,6 +145,20 @@ int hnh_fused_sddmm_spmm_csr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, co
     rc = hnh_spmm_csr(c, rows, rowptr, col_idx, w, Y, Out, R, stream);
     free(w);
     return rc;
+}
+
+int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
+                                const double* svalues, const double* X, const double* Y, double* Out, int R, unsigned flags,
+                                int64_t nnz, int max_row_nnz, int stream) {
+    (void)nnz; (void)max_row_nnz;
+    return hnh_fused_sddmm_spmm_csr(c, rows, rowptr, col_idx, values, svalues, X, Y, Out, R, flags, stream);
+}
+int hnh_csr_max_row_nnz(hnh_ctx* c, int64_t rows, const int32_t* rowptr, int* out_host, int stream) {
+    (void)c; (void)stream;
+    int m = 0;
+    for (int64_t r = 0; r < rows; r++) if (rowptr[r + 1] - rowptr[r] > m) m = rowptr[r + 1] - rowptr[r];
+    *out_host = m;
+    return HNH_OK;
 }
 
 int hnh_fill_f64(hnh_ctx* c, double* dst, int64_t n, double v, int stream) {

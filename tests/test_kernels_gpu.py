@@ -210,3 +210,46 @@ def test_gat_elementwise(ctx):
     ctx.check(lib.hnh_relu_store_cols_f64(ctx.h, ddst.ptr, 12, 4, dsrc.ptr, 33, 5, 0), "relu cols")
     want = dst0.copy(); want[:, 4:9] = np.maximum(src, 0)
     assert np.array_equal(ddst.get(), want)
+
+
+@pytest.mark.parametrize("R", [16, 128, 100])
+@pytest.mark.parametrize("hinted", [False, True])
+def test_hub_rows_are_split_and_still_exact(ctx, R, hinted):
+    """Rows longer than 1024 nonzeros take the segmented long-row pass (SpMM / fused combine with fp64 atomics)."""
+    import ctypes as C
+    from distributed_sddmm_amd import _kernels as K
+    lib = ctx.lib
+    rows, cols = 60, 9000
+    rng = np.random.default_rng(R)
+    lens = rng.integers(0, 40, rows)
+    lens[7], lens[31], lens[59] = 5000, 1025, 2600      # three hubs, one just over the threshold
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cidx = np.concatenate([np.sort(rng.choice(cols, n, replace=False)) for n in lens]).astype(np.int32)
+    ridx = np.repeat(np.arange(rows, dtype=np.int32), lens)
+    nnz = len(cidx)
+    X, Y = rng.uniform(-1, 1, (rows, R)), rng.uniform(-1, 1, (cols, R))
+    v0, out0 = rng.uniform(-1, 1, nnz), rng.uniform(-1, 1, (rows, R))
+    d_rp, d_c, dv, dX, dY, dOut = ctx.upload(rowptr), ctx.upload(cidx), ctx.upload(v0), ctx.upload(X), ctx.upload(Y), ctx.upload(out0)
+    mx = C.c_int()
+    ctx.check(lib.hnh_csr_max_row_nnz(ctx.h, rows, d_rp.ptr, C.byref(mx), 0), "max_row")
+    assert mx.value == 5000
+    h_nnz, h_max = (nnz, mx.value) if hinted else (-1, -1)
+    ctx.check(lib.hnh_sddmm_csr_ex(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, dX.ptr, dY.ptr, R, h_nnz, h_max, 0), "sddmm")
+    assert rel(dv.get(), O.sddmm_local(ridx, cidx, v0, X, Y)) <= TOL
+    dv.set(v0)
+    ctx.check(lib.hnh_spmm_csr_ex(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, dY.ptr, dOut.ptr, R, h_nnz, h_max, 0), "spmm")
+    assert rel(dOut.get(), O.spmm_local(rowptr, cidx, v0, Y, out0)) <= TOL
+    for flags in (0, K.FUSED_VALUES_OVERWRITE | K.FUSED_OUT_OVERWRITE):
+        dv.set(v0); dOut.set(out0)
+        vbase = v0 if flags == 0 else np.zeros(nnz)
+        obase = out0 if flags == 0 else np.zeros((rows, R))
+        ctx.check(lib.hnh_fused_sddmm_spmm_csr_ex(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, None, dX.ptr, dY.ptr, dOut.ptr, R, flags,
+                                                  h_nnz, h_max, 0), "fused")
+        vals = O.sddmm_local(ridx, cidx, vbase, X, Y)
+        assert rel(dv.get(), vals) <= TOL
+        assert rel(dOut.get(), O.spmm_local(rowptr, cidx, vals, Y, obase)) <= TOL
+    # a wrong "no long rows" hint is the caller's bug, a correct one for a short-row block skips the machinery
+    short_rp = np.arange(0, 11, dtype=np.int32) * 3
+    d_srp = ctx.upload(short_rp)
+    ctx.check(lib.hnh_csr_max_row_nnz(ctx.h, 10, d_srp.ptr, C.byref(mx), 0), "max_row")
+    assert mx.value == 3
