@@ -52,6 +52,7 @@ SIGNATURES = {
     "hnh_row_scale_add_f64": (_i32, [_vp, _vp, _vp, _dbl, _vp, _vp, _dbl, _i64, _i32, _i32]),
     "hnh_vec_add_scalar_f64": (_i32, [_vp, _vp, _dbl, _i64, _i32]),
     "hnh_vec_div_f64": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32]),
+    "hnh_fill_hashed_f64": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, C.c_uint64, _dbl, _i32]),
     "hnh_gemm_f64": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32]),
     "hnh_leaky_relu_f64": (_i32, [_vp, _vp, _dbl, _i64, _i32]),
     "hnh_relu_store_cols_f64": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i32]),

@@ -425,6 +425,23 @@ __global__ __launch_bounds__(kBlock) void vec_add_scalar_kernel(double* v, doubl
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) v[i] += c;
 }
 
+__device__ __forceinline__ unsigned long long splitmix64_dev(unsigned long long x) {
+    unsigned long long z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(kBlock) void fill_hashed_kernel(double* __restrict__ dst, int64_t rows, int64_t cols, int64_t top_row,
+                                                             int64_t left_col, int64_t rg, unsigned long long seed, double scale) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock, total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
+        const unsigned long long key = (unsigned long long)((top_row + i / cols) * rg + left_col + i % cols);
+        const unsigned long long h = splitmix64_dev(seed * 0xD1342543DE82EF95ull + key * 0x9E3779B97F4A7C15ull);
+        dst[i] = ((double)(h >> 11) * 0x1.0p-52 - 1.0) * scale;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void vec_div_kernel(double* out, const double* num, const double* den, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = num[i] / den[i];
@@ -805,6 +822,17 @@ int hnh_vec_add_scalar_f64(hnh_ctx* ctx, double* v, double c, int64_t n, int str
     if (!v) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_vec_add_scalar_f64: null pointer");
     hipLaunchKernelGGL(vec_add_scalar_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, ctx->streams[stream], v, c, n);
     return hnh::check_hip(ctx, hipGetLastError(), "vec_add_scalar_kernel launch");
+}
+
+int hnh_fill_hashed_f64(hnh_ctx* ctx, double* dst, int64_t rows, int64_t cols, int64_t top_row, int64_t left_col, int64_t R_global,
+                        uint64_t seed, double scale, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (rows < 0 || cols < 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fill_hashed_f64: negative size");
+    if (rows == 0 || cols == 0) return HNH_OK;
+    if (!dst) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fill_hashed_f64: null pointer");
+    hipLaunchKernelGGL(fill_hashed_kernel, dim3(ew_grid(rows * cols)), dim3(kBlock), 0, ctx->streams[stream], dst, rows, cols, top_row,
+                       left_col, R_global, (unsigned long long)seed, scale);
+    return hnh::check_hip(ctx, hipGetLastError(), "fill_hashed_kernel launch");
 }
 
 int hnh_vec_div_f64(hnh_ctx* ctx, double* out, const double* num, const double* den, int64_t n, int stream) {

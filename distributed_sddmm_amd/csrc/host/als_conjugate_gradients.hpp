@@ -184,22 +184,17 @@ public:
         }
     }
 
-    // uniform(-1, 1) * scale keyed by the GLOBAL (row, col) through the operator's submatrix descriptors
+    // uniform(-1, 1) * scale keyed by the GLOBAL (row, col) through the operator's submatrix descriptors; generated
+    // on the device (hnh_fill_hashed_f64), one launch per submatrix
     void hashed_fill(DenseMatrix& loc, MatMode mode, uint64_t fill_seed, double scale) {
         std::vector<DenseSubmatrix>& subs = (mode == Amat) ? d_ops->aSubmatrices : d_ops->bSubmatrices;
-        std::vector<double> host((size_t)loc.size());
-        const uint64_t G = 0x9E3779B97F4A7C15ull, Rg = (uint64_t)d_ops->R;
-        size_t base = 0;
+        hnh::World* w = d_ops->world;
+        double* ptr = loc.data();
         for (auto& s : subs) {
-#pragma omp parallel for
-            for (int i = 0; i < s.rowCount; i++)
-                for (int j = 0; j < s.colCount; j++) {
-                    const uint64_t key = (uint64_t)(s.topRow + i) * Rg + (uint64_t)(s.leftCol + j);
-                    const uint64_t h = hnh::splitmix64(fill_seed * 0xD1342543DE82EF95ull + key * G);
-                    host[base + (size_t)i * s.colCount + j] = ((double)(h >> 11) * 0x1.0p-52 - 1.0) * scale;
-                }
-            base += (size_t)s.rowCount * s.colCount;
+            w->check(w->be->hnh_fill_hashed_f64(w->ctx, ptr, s.rowCount, s.colCount, s.topRow, s.leftCol, d_ops->R, fill_seed, scale,
+                                                HNH_STREAM_COMPUTE),
+                     "hnh_fill_hashed_f64");
+            ptr += (size_t)s.rowCount * s.colCount;
         }
-        loc.copy_from_host(host.data());
     }
 };

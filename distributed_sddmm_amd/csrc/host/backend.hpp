@@ -23,7 +23,7 @@ struct Backend {
     HNH_FN(hnh_sddmm_coo) HNH_FN(hnh_sddmm_csr) HNH_FN(hnh_spmm_csr) HNH_FN(hnh_fused_sddmm_spmm_csr)
     HNH_FN(hnh_sddmm_csr_ex) HNH_FN(hnh_spmm_csr_ex) HNH_FN(hnh_fused_sddmm_spmm_csr_ex) HNH_FN(hnh_csr_max_row_nnz)
     HNH_FN(hnh_fill_f64) HNH_FN(hnh_hadamard_f64) HNH_FN(hnh_axpy_f64) HNH_FN(hnh_expand_rowptr)
-    HNH_FN(hnh_rowdot_f64) HNH_FN(hnh_row_scale_add_f64) HNH_FN(hnh_vec_add_scalar_f64) HNH_FN(hnh_vec_div_f64)
+    HNH_FN(hnh_rowdot_f64) HNH_FN(hnh_row_scale_add_f64) HNH_FN(hnh_vec_add_scalar_f64) HNH_FN(hnh_vec_div_f64) HNH_FN(hnh_fill_hashed_f64)
     HNH_FN(hnh_gemm_f64) HNH_FN(hnh_leaky_relu_f64) HNH_FN(hnh_relu_store_cols_f64)
     HNH_FN(hnh_comm_unique_id) HNH_FN(hnh_comm_init) HNH_FN(hnh_comm_split) HNH_FN(hnh_comm_destroy)
     HNH_FN(hnh_comm_sendrecv) HNH_FN(hnh_comm_group_begin) HNH_FN(hnh_comm_group_end) HNH_FN(hnh_comm_allgather) HNH_FN(hnh_comm_reduce_scatter_f64)

@@ -132,6 +132,12 @@ int hnh_rowdot_f64(hnh_ctx* ctx, const double* A, const double* B, double* out, 
 int hnh_row_scale_add_f64(hnh_ctx* ctx, double* Y, const double* yv, double ya, const double* X, const double* xv, double xa,
                           int64_t rows, int R, int stream);
 int hnh_vec_add_scalar_f64(hnh_ctx* ctx, double* v, double c, int64_t n, int stream);
+/* hnh_fill_hashed_f64 — distribution-independent stand-in for Eigen's setRandom() (als_conjugate_gradients.cpp:143-146):
+ *   dst[i, j] = scale * uniform(-1, 1) hashed from the GLOBAL element (top_row + i, left_col + j) of an R_global-wide matrix:
+ *   key = (top_row + i) * R_global + left_col + j;  h = splitmix64(seed * 0xD1342543DE82EF95 + key * 0x9E3779B97F4A7C15);
+ *   value = ((h >> 11) * 2^-52 - 1) * scale      (twin: oracle/oracle.py:hashed_uniform) */
+int hnh_fill_hashed_f64(hnh_ctx* ctx, double* dst, int64_t rows, int64_t cols, int64_t top_row, int64_t left_col, int64_t R_global,
+                        uint64_t seed, double scale, int stream);
 int hnh_vec_div_f64(hnh_ctx* ctx, double* out, const double* num, const double* den, int64_t n, int stream);
 
 /* ---- dense helpers of the GAT application (gat.hpp:83-104) -----------------------------------------------------

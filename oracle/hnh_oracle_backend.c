@@ -208,6 +208,19 @@ int hnh_vec_add_scalar_f64(hnh_ctx* c, double* v, double s, int64_t n, int strea
     for (int64_t i = 0; i < n; i++) v[i] += s;
     return HNH_OK;
 }
+int hnh_fill_hashed_f64(hnh_ctx* c, double* dst, int64_t rows, int64_t cols, int64_t top_row, int64_t left_col, int64_t rg,
+                        uint64_t seed, double scale, int stream) {
+    (void)c; (void)stream;
+    for (int64_t i = 0; i < rows; i++)
+        for (int64_t j = 0; j < cols; j++) {
+            uint64_t z = seed * 0xD1342543DE82EF95ull + (uint64_t)((top_row + i) * rg + left_col + j) * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z = z ^ (z >> 31);
+            dst[i * cols + j] = ((double)(z >> 11) * 0x1.0p-52 - 1.0) * scale;
+        }
+    return HNH_OK;
+}
 int hnh_vec_div_f64(hnh_ctx* c, double* out, const double* num, const double* den, int64_t n, int stream) {
     (void)c; (void)stream;
     for (int64_t i = 0; i < n; i++) out[i] = num[i] / den[i];

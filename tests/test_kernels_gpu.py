@@ -253,3 +253,14 @@ def test_hub_rows_are_split_and_still_exact(ctx, R, hinted):
     d_srp = ctx.upload(short_rp)
     ctx.check(lib.hnh_csr_max_row_nnz(ctx.h, 10, d_srp.ptr, C.byref(mx), 0), "max_row")
     assert mx.value == 3
+
+
+def test_fill_hashed_matches_the_oracle_hash(ctx):
+    """hnh_fill_hashed_f64 = oracle.hashed_uniform keyed by the global (row, col) of a sub-block."""
+    lib = ctx.lib
+    rows, cols, top, left, rg, seed = 37, 5, 1000, 3, 16, 2025
+    d = ctx.upload(np.zeros((rows, cols)))
+    ctx.check(lib.hnh_fill_hashed_f64(ctx.h, d.ptr, rows, cols, top, left, rg, seed, 0.25, 0), "fill_hashed")
+    ii, jj = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
+    keys = ((top + ii) * rg + left + jj).astype(np.uint64).reshape(-1)
+    assert np.array_equal(d.get().reshape(-1), O.hashed_uniform(keys, seed) * 0.25)
