@@ -50,16 +50,26 @@ def cpu_baseline(args):
     import numpy as np
     from distributed_sddmm_amd import api as H
     from oracle import refrun as RR
-    threads = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
     m = 1 << args.cpu_logm
     if RR.available():
         rows, cols = H.generate_er(m, m, m * args.edge_factor, 12345)
-        res = RR.bench(m, m, rows, cols, args.r, "15d_fusion2", 1, 1, True, args.cpu_trials, threads=threads)
+        # The reference does not scale with the thread count on big hosts (measured on 2 x EPYC 9575F: 32 threads
+        # beat 64/128/256, and 1 MPI rank beats 4..32, profiles/r01_cpu_baseline_sweep.log), so a few counts are
+        # tried on the same sample and the best one is reported; `cores` is the thread count of that run.
+        tried, best = [], None
+        for threads in sorted({min(ncpu, 16), min(ncpu, 32), min(ncpu, 64), ncpu}):
+            res = RR.bench(m, m, rows, cols, args.r, "15d_fusion2", 1, 1, True, args.cpu_trials, threads=threads)
+            tried.append((threads, res["nnz_R_per_s"]))
+            if best is None or res["nnz_R_per_s"] > best[1]["nnz_R_per_s"]:
+                best = (threads, res)
+        threads, res = best
         comp = res["perf_stats"].get("Computation Time", 0.0)
         return {"value": res["nnz_R_per_s"], "unit": "nnz*R/s", "cores": threads, "kind": "reference",
                 "sample": "ER 2^%d, edge factor %d (%d nnz), R=%d, 15d_fusion2 fused, %d timed fusedSpMM calls after 1 warm-up, "
-                          "1 MPI rank x %d OpenMP/MKL threads" % (args.cpu_logm, args.edge_factor, len(rows), args.r,
-                                                                  args.cpu_trials, threads),
+                          "1 MPI rank x %d OpenMP/MKL threads (best of %s on %d hardware threads)"
+                          % (args.cpu_logm, args.edge_factor, len(rows), args.r, args.cpu_trials, threads,
+                             ", ".join("%d: %.2e" % t for t in tried), ncpu),
                 "elapsed_s": res["elapsed"],
                 "kernel_only_value": (len(rows) * args.r * args.cpu_trials / comp) if comp > 0 else None}
     # no compiled reference on this box: time the numpy port on a smaller sample
@@ -103,6 +113,7 @@ def run(args, make_world=gpu_world):
     if n > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: never depend on the container hostname resolving
         if not dist.is_initialized():
             dist.init_process_group(backend="gloo", rank=rank, world_size=n)  # bootstrap + barriers only; data moves over RCCL
     world, device_sync = make_world(H, dist, rank, n, local_rank)
