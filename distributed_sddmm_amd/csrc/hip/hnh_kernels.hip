@@ -618,7 +618,14 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
         return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "no kernel instance for this shape");
     }
 #undef HNH_CASE
-    // tiled fallback: any R; SDDMM partial dot products accumulate into `values` tile by tile
+    // Widths that are not a supported exact multiple: one bounds-checked pass when the row fits the widest
+    // instance (R <= 512 even / 256 odd) ...
+#define HNH_NX(V, WW)                                                                                              \
+    if (s.w == WW && R <= 64 * WW * V)                                                                             \
+        return launch_row<OP, 64, V, WW, false>(ctx, st, lc, rows, rowptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags);
+    HNH_NX(1, 2) HNH_NX(2, 2) HNH_NX(4, 2) HNH_NX(1, 1) HNH_NX(2, 1) HNH_NX(4, 1)
+#undef HNH_NX
+    // ... else column tiles; SDDMM partial dot products accumulate into `values` tile by tile
     if (OP == Op::kFused) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "fused fallback is composed by the caller");
     const int tile = 64 * s.w;
     for (int col0 = 0; col0 < R; col0 += tile) {
@@ -708,7 +715,7 @@ int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowpt
         return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr: unknown flag");
     hipStream_t st = ctx->streams[stream];
     const Shape s = pick_shape(R, aligned16(X) && aligned16(Y) && aligned16(Out));
-    if (s.exact)
+    if (s.exact || R <= 256 * s.w)  // one pass: an exact instance, or a bounds-checked one wide enough for the whole row
         return dispatch_row<Op::kFused>(ctx, st, stream, s, rows, nnz_in, max_row_nnz, rowptr, col_idx, values, svalues, X, Y, Out, R,
                                         flags);
     // Tiled fallback (R odd or not a supported multiple): the dot product needs the whole row before the

@@ -100,3 +100,38 @@ def test_relay_ring_and_mesh_fetch_agree_with_the_reference(monkeypatch, mode, a
     case = T.case_inputs("er8_r16")
     per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
     T.check_against_golden(T.assemble(per_rank, case), per_rank, case, alg)
+
+
+def test_perf_counter_keys_match_the_reference():
+    """Counter names are the result-file "wire format" (15D_*.hpp:70-74, 25D_cannon_dense.hpp:72-78,
+    25D_cannon_sparse.hpp:71-76); with timing_sync the counters are filled with device-complete times."""
+    case = T.case_inputs("tiny_r8")
+    expect = {
+        "15d_fusion1": {"Replication Time", "Cyclic Shift Time", "Computation Time"},
+        "15d_fusion2": {"Replication Time", "Cyclic Shift Time", "Computation Time"},
+        "15d_sparse": {"Replication Time", "Cyclic Shift Time", "Computation Time"},
+        "25d_dense_replicate": {"Dense Cyclic Shift Time", "Sparse Cyclic Shift Time", "Dense Fiber Communication Time",
+                                "Computation Time", "Setup Shift Time"},
+        "25d_sparse_replicate": {"Dense Cyclic Shift Time", "Sparse Fiber Communication Time", "Computation Time", "Setup Shift Time"},
+    }
+
+    def body(w):
+        w.set_timing_sync(True)
+        out = {}
+        for alg in H.ALGORITHMS:
+            sp = H.SpmatLocal.from_global(w, case["M"], case["N"], case["rows"], case["cols"], case["vals"])
+            d = H.DistributedSparse(w, alg, sp, case["R"], 1)
+            d.reset_performance_timers()
+            A, B, S, buf = d.like_A_matrix(0.001), d.like_B_matrix(0.001), d.like_S_values(1.0), d.like_S_values(0.0)
+            d.initial_shift(A, B, H.K_SDDMM_A)
+            d.fusedSpMM(A, B, S, buf, H.AMAT)
+            out[alg] = d.json_perf_statistics()
+            for x in (A, B, S, buf):
+                x.free()
+            d.free(); sp.free()
+        return out
+
+    res = H.run_spmd(4, body)[0]
+    for alg, keys in expect.items():
+        assert set(res[alg]) == keys, (alg, res[alg])
+        assert res[alg]["Computation Time"] > 0

@@ -42,7 +42,7 @@ def random_block(rows, cols, nnz_target, seed, empty_rows=True):
     return rowptr, r, c
 
 
-RS = [1, 2, 3, 4, 8, 16, 17, 32, 64, 100, 128, 192, 256, 320, 384, 448, 512, 130]
+RS = [1, 2, 3, 4, 8, 16, 17, 32, 64, 100, 128, 192, 256, 320, 384, 448, 512, 130, 200, 257, 301, 600]
 
 
 @pytest.mark.parametrize("R", RS)
