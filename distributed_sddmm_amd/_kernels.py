@@ -44,6 +44,7 @@ SIGNATURES = {
     "hnh_spmm_csr_ex": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32]),
     "hnh_fused_sddmm_spmm_csr_ex": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _i64, _i32, _i32]),
     "hnh_csr_max_row_nnz": (_i32, [_vp, _i64, _vp, C.POINTER(C.c_int), _i32]),
+    "hnh_fused_sddmm_spmm_csr_multi": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, C.c_uint, _i32]),
     "hnh_fill_f64": (_i32, [_vp, _vp, _i64, _dbl, _i32]),
     "hnh_hadamard_f64": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32]),
     "hnh_axpy_f64": (_i32, [_vp, _vp, _vp, _dbl, _i64, _i32]),
@@ -67,6 +68,11 @@ SIGNATURES = {
     "hnh_comm_reduce_scatter_f64": (_i32, [_vp, _vp, _vp, _vp, _sz, _i32]),
     "hnh_comm_allreduce_f64": (_i32, [_vp, _vp, _vp, _vp, _sz, _i32]),
 }
+
+class CsrBlock(C.Structure):
+    """struct hnh_csr_block"""
+    _fields_ = [("rowptr", _vp), ("col_idx", _vp), ("values", _vp), ("Y", _vp), ("nnz", _i64), ("max_row_nnz", _i32)]
+
 
 _lib = None
 

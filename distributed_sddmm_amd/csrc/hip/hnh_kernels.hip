@@ -259,6 +259,103 @@ __global__ __launch_bounds__(kBlock) void row_kernel(int64_t rows, const int32_t
     process_row<OP, LPR, VEC, W, EXACT>(row, beg, end, false, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, lig);
 }
 
+// ---------------------------------------------------------------- fused pass over SEVERAL blocks of one block row
+// The mesh-fetch schedule has all ring blocks resident at once; walking them in ONE launch keeps the row operand
+// X[i,:] and the output accumulator in registers across blocks (a per-block launch re-reads X and read-modify-
+// writes Out for every block: 3 KiB per row per block at R = 128) and gives the gather pipeline longer rows.
+constexpr int kMaxMultiBlocks = 8;
+struct MultiBlocks {
+    const int32_t* rowptr[kMaxMultiBlocks];
+    const int32_t* colidx[kMaxMultiBlocks];
+    double* values[kMaxMultiBlocks];
+    const double* Y[kMaxMultiBlocks];
+    int n;
+};
+
+template <int LPR, int VEC, int W, bool EXACT>
+__global__ __launch_bounds__(kBlock) void fused_multi_kernel(int64_t rows, MultiBlocks mb, const double* __restrict__ X,
+                                                             double* __restrict__ Out, int64_t ld, int ncols, unsigned flags) {
+    constexpr int U = Unroll<LPR, VEC>::value;
+    constexpr int SUB = LPR / U;
+    constexpr int GROUPS = kBlock / LPR;
+    const int tid = threadIdx.x;
+    const int lig = tid % LPR;
+    int64_t row = (int64_t)blockIdx.x * GROUPS + tid / LPR;
+    if constexpr (LPR == 64) row = ((int64_t)blockIdx.x * GROUPS) + __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (row >= rows) return;
+
+    bool act[VEC];
+    int64_t coff[VEC];
+    double x[VEC][W], acc[VEC][W];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) {
+        const int c = (v * LPR + lig) * W;
+        act[v] = EXACT ? true : (c < ncols);
+        coff[v] = c;
+#pragma unroll
+        for (int w = 0; w < W; w++) { x[v][w] = 0.0; acc[v][w] = 0.0; }
+        if (act[v]) {
+            load_w<W>(x[v], X + row * ld + coff[v]);
+            if (!(flags & HNH_FUSED_OUT_OVERWRITE)) load_w<W>(acc[v], Out + row * ld + coff[v]);
+        }
+    }
+
+    for (int b = 0; b < mb.n; b++) {
+        const int32_t* __restrict__ colidx = mb.colidx[b];
+        double* values = mb.values[b];
+        const double* __restrict__ Y = mb.Y[b];
+        int beg = mb.rowptr[b][row], end = mb.rowptr[b][row + 1];
+        if constexpr (LPR == 64) {
+            beg = __builtin_amdgcn_readfirstlane(beg);
+            end = __builtin_amdgcn_readfirstlane(end);
+        }
+        for (int e = beg; e < end; e += U) {
+            int c[U];
+            double y[U][VEC][W];
+#pragma unroll
+            for (int u = 0; u < U; u++) c[u] = (e + u < end) ? colidx[e + u] : -1;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+#pragma unroll
+                for (int v = 0; v < VEC; v++) {
+#pragma unroll
+                    for (int w = 0; w < W; w++) y[u][v][w] = 0.0;
+                    if (c[u] >= 0 && act[v]) load_w<W>(y[u][v], Y + (int64_t)c[u] * ld + coff[v]);
+                }
+            }
+            double d[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                double sdot = 0.0;
+#pragma unroll
+                for (int v = 0; v < VEC; v++)
+#pragma unroll
+                    for (int w = 0; w < W; w++) sdot = fma(x[v][w], y[u][v][w], sdot);
+                d[u] = sdot;
+            }
+            double wgt = group_multi_reduce<LPR, U>(d, lig);
+            const int mine = e + lig / SUB;
+            if (mine < end) {
+                if (!(flags & HNH_FUSED_VALUES_OVERWRITE)) wgt += values[mine];
+                if (lig % SUB == 0) values[mine] = wgt;
+            } else {
+                wgt = 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const double wu = group_bcast<LPR>(wgt, u * SUB);
+#pragma unroll
+                for (int v = 0; v < VEC; v++)
+#pragma unroll
+                    for (int w = 0; w < W; w++) acc[v][w] = fma(wu, y[u][v][w], acc[v][w]);
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; v++)
+        if (act[v]) store_w<W>(Out + row * ld + coff[v], acc[v]);
+}
+
 // One work item = kLongSeg consecutive nonzeros of a long row; items are listed by build_long_list_kernel.
 template <Op OP, int LPR, int VEC, int W, bool EXACT>
 __global__ __launch_bounds__(kBlock) void long_row_kernel(const int2* __restrict__ items, const int* __restrict__ item_count,
@@ -732,6 +829,72 @@ int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowpt
     if (int rc = dispatch_row<Op::kSddmm>(ctx, st, stream, s, rows, nnz, max_row_nnz, rowptr, col_idx, values, nullptr, X, Y, nullptr, R, 0u))
         return rc;
     return dispatch_row<Op::kSpmm>(ctx, st, stream, s, rows, nnz, max_row_nnz, rowptr, col_idx, values, svalues, Y, nullptr, Out, R, 0u);
+}
+
+int hnh_fused_sddmm_spmm_csr_multi(hnh_ctx* ctx, int64_t rows, int nblocks, const hnh_csr_block* blocks, const double* X, double* Out,
+                                   int R, unsigned flags, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (int rc = check_common(ctx, rows, R, "hnh_fused_sddmm_spmm_csr_multi")) return rc;
+    if (nblocks < 0 || (nblocks > 0 && !blocks)) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr_multi: bad block list");
+    if (flags & ~(HNH_FUSED_VALUES_OVERWRITE | HNH_FUSED_OUT_OVERWRITE))
+        return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr_multi: unknown flag");
+    if (rows == 0 || nblocks == 0) return HNH_OK;
+    if (!X || !Out || X == Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr_multi: bad operand");
+    bool vec_ok = aligned16(X) && aligned16(Out), simple = true;
+    for (int b = 0; b < nblocks; b++) {
+        if (!blocks[b].rowptr || !blocks[b].col_idx || !blocks[b].values || !blocks[b].Y || blocks[b].Y == Out)
+            return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr_multi: null pointer in block");
+        vec_ok = vec_ok && aligned16(blocks[b].Y);
+        if (blocks[b].max_row_nnz < 0 || blocks[b].max_row_nnz > kLongRow) simple = false;  // hub rows: per-block path splits them
+    }
+    const Shape s = pick_shape(R, vec_ok);
+    const bool one_pass = s.exact || R <= 256 * s.w;
+    hipStream_t st = ctx->streams[stream];
+    if (!simple || !one_pass) {  // same arithmetic, block by block
+        for (int b = 0; b < nblocks; b++) {
+            const unsigned f = (b == 0) ? flags : (flags & ~HNH_FUSED_OUT_OVERWRITE);
+            if (int rc = hnh_fused_sddmm_spmm_csr_ex(ctx, rows, blocks[b].rowptr, blocks[b].col_idx, blocks[b].values, nullptr, X,
+                                                     blocks[b].Y, Out, R, f, blocks[b].nnz, blocks[b].max_row_nnz, stream))
+                return rc;
+        }
+        return HNH_OK;
+    }
+    for (int b0 = 0; b0 < nblocks; b0 += kMaxMultiBlocks) {
+        MultiBlocks mb;
+        mb.n = (nblocks - b0 < kMaxMultiBlocks) ? nblocks - b0 : kMaxMultiBlocks;
+        for (int b = 0; b < mb.n; b++) {
+            mb.rowptr[b] = blocks[b0 + b].rowptr; mb.colidx[b] = blocks[b0 + b].col_idx;
+            mb.values[b] = blocks[b0 + b].values; mb.Y[b] = blocks[b0 + b].Y;
+        }
+        const unsigned f = (b0 == 0) ? flags : (flags & ~HNH_FUSED_OUT_OVERWRITE);
+#define HNH_MULTI(L, V, WW, EX)                                                                                     \
+    {                                                                                                               \
+        const int64_t nb = (rows + (kBlock / L) - 1) / (kBlock / L);                                                \
+        hipLaunchKernelGGL((fused_multi_kernel<L, V, WW, EX>), dim3((unsigned)nb), dim3(kBlock), 0, st, rows, mb, X, Out, (int64_t)R, R, f); \
+    }
+        if (s.exact) {
+            if (s.lpr == 64 && s.vec == 1) HNH_MULTI(64, 1, 2, true)
+            else if (s.lpr == 64 && s.vec == 2) HNH_MULTI(64, 2, 2, true)
+            else if (s.lpr == 64 && s.vec == 3) HNH_MULTI(64, 3, 2, true)
+            else if (s.lpr == 64 && s.vec == 4) HNH_MULTI(64, 4, 2, true)
+            else if (s.lpr == 32 && s.vec == 1) HNH_MULTI(32, 1, 2, true)
+            else if (s.lpr == 32 && s.vec == 3) HNH_MULTI(32, 3, 2, true)
+            else if (s.lpr == 32 && s.vec == 5) HNH_MULTI(32, 5, 2, true)
+            else if (s.lpr == 32 && s.vec == 7) HNH_MULTI(32, 7, 2, true)
+            else if (s.lpr == 16) HNH_MULTI(16, 1, 2, true)
+            else if (s.lpr == 8) HNH_MULTI(8, 1, 2, true)
+            else if (s.lpr == 4) HNH_MULTI(4, 1, 2, true)
+            else if (s.lpr == 2) HNH_MULTI(2, 1, 2, true)
+            else HNH_MULTI(1, 1, 2, true)
+        } else if (s.w == 2) {
+            if (R <= 128) HNH_MULTI(64, 1, 2, false) else if (R <= 256) HNH_MULTI(64, 2, 2, false) else HNH_MULTI(64, 4, 2, false)
+        } else {
+            if (R <= 64) HNH_MULTI(64, 1, 1, false) else if (R <= 128) HNH_MULTI(64, 2, 1, false) else HNH_MULTI(64, 4, 1, false)
+        }
+#undef HNH_MULTI
+        if (int rc = hnh::check_hip(ctx, hipGetLastError(), "fused_multi_kernel launch")) return rc;
+    }
+    return HNH_OK;
 }
 
 int hnh_sddmm_coo(hnh_ctx* ctx, int64_t nnz, const int32_t* row_idx, const int32_t* col_idx, double* values,

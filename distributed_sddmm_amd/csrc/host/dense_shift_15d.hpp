@@ -148,16 +148,40 @@ public:
         }
 
         bool out_fresh = true;
-        ring_readonly(Brole, n, [&](int i, DenseMatrix& cur) {
+        if (ring_mode == kMeshFetch && n > 2) {
+            // every remote block lands at once: local block while they fly, then ALL the others in one launch
+            std::vector<DenseMatrix*> fetched = mesh_fetch_all(Brole, n);
             auto t = start_clock();
-            const int block_id = block_at(i);
-            if (choice->csr_blocks[block_id] != nullptr) {
-                unsigned flags = HNH_FUSED_VALUES_OVERWRITE | (out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u);
-                kernel->fused_local(*choice, *rowOperand, cur, accumulation_buffer, block_id, flags);
+            if (choice->csr_blocks[block_at(0)] != nullptr) {
+                kernel->fused_local(*choice, *rowOperand, *Brole, accumulation_buffer, block_at(0),
+                                    HNH_FUSED_VALUES_OVERWRITE | HNH_FUSED_OUT_OVERWRITE);
+                out_fresh = false;
+            }
+            world->event_wait(event(1), HNH_STREAM_COMPUTE);  // the remote blocks have landed
+            std::vector<int> ids;
+            bool any = false;
+            for (int i = 1; i < n; i++) {
+                ids.push_back(block_at(i));
+                any = any || choice->csr_blocks[block_at(i)] != nullptr;
+            }
+            if (any) {
+                kernel->fused_multi_local(*choice, *rowOperand, fetched, accumulation_buffer, ids,
+                                          HNH_FUSED_VALUES_OVERWRITE | (out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u));
                 out_fresh = false;
             }
             stop_clock_and_add(t, "Computation Time");
-        });
+        } else {
+            ring_readonly(Brole, n, [&](int i, DenseMatrix& cur) {
+                auto t = start_clock();
+                const int block_id = block_at(i);
+                if (choice->csr_blocks[block_id] != nullptr) {
+                    unsigned flags = HNH_FUSED_VALUES_OVERWRITE | (out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u);
+                    kernel->fused_local(*choice, *rowOperand, cur, accumulation_buffer, block_id, flags);
+                    out_fresh = false;
+                }
+                stop_clock_and_add(t, "Computation Time");
+            });
+        }
         if (out_fresh) accumulation_buffer.setZero();  // no block on this rank had a nonzero
 
         if (c > 1) {
@@ -271,27 +295,34 @@ private:
         }
     }
 
-    // Same n kernel steps on the same blocks, but every block comes straight from its owner: all n-1
-    // transfers are one group on the communication stream and overlap with step 0's kernel.
-    template <typename Step>
-    void mesh_readonly(DenseMatrix* start, int n, Step&& step) {
+    // Issues all n-1 owner->consumer transfers of a read-only moving operand as one group on the communication
+    // stream and records event(1) behind them; returns the landing buffers in visiting order (step 1 .. n-1).
+    std::vector<DenseMatrix*> mesh_fetch_all(DenseMatrix* start, int n) {
         if ((int)mesh_spare.size() < n - 1) mesh_spare.resize(n - 1);
         for (int k = 0; k < n - 1; k++) ensure(mesh_spare[k], start->rows(), start->cols());
         const size_t bytes = (size_t)start->size() * sizeof(double);
-        {
-            auto t = start_clock();
-            order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // my block is final; earlier readers of the landing buffers are done
-            world->group_begin();
-            for (int k = 1; k < n; k++)  // my block is what ring rank me+k needs at ITS step k; I need the block of me-k at mine
-                world->sendrecv(grid->col_world, start->data(), bytes, pMod(grid->rankInCol + k, n), mesh_spare[k - 1].data(), bytes,
-                                pMod(grid->rankInCol - k, n), HNH_STREAM_COMM);
-            world->group_end();
-            world->event_record(event(1), HNH_STREAM_COMM);
-            stop_clock_and_add(t, "Cyclic Shift Time");
-        }
+        auto t = start_clock();
+        order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // my block is final; earlier readers of the landing buffers are done
+        world->group_begin();
+        for (int k = 1; k < n; k++)  // my block is what ring rank me+k needs at ITS step k; I need the block of me-k at mine
+            world->sendrecv(grid->col_world, start->data(), bytes, pMod(grid->rankInCol + k, n), mesh_spare[k - 1].data(), bytes,
+                            pMod(grid->rankInCol - k, n), HNH_STREAM_COMM);
+        world->group_end();
+        world->event_record(event(1), HNH_STREAM_COMM);
+        stop_clock_and_add(t, "Cyclic Shift Time");
+        std::vector<DenseMatrix*> out;
+        for (int k = 0; k < n - 1; k++) out.push_back(&mesh_spare[k]);
+        return out;
+    }
+
+    // Same n kernel steps on the same blocks, but every block comes straight from its owner: the transfers
+    // overlap with step 0's kernel.
+    template <typename Step>
+    void mesh_readonly(DenseMatrix* start, int n, Step&& step) {
+        std::vector<DenseMatrix*> fetched = mesh_fetch_all(start, n);
         for (int i = 0; i < n; i++) {
             if (i == 1) world->event_wait(event(1), HNH_STREAM_COMPUTE);  // the remote blocks have landed
-            step(i, i == 0 ? *start : mesh_spare[i - 1]);
+            step(i, i == 0 ? *start : *fetched[i - 1]);
         }
     }
 

@@ -9,6 +9,8 @@
 // issues per visiting block (15D_dense_shift.hpp:203-217).  The default implementation is literally that
 // pair of virtual calls; StandardKernel overrides it with the single-pass HIP kernel.
 #pragma once
+#include <vector>
+
 #include "common.hpp"
 #include "dense.hpp"
 #include "spmat_local.hpp"
@@ -42,6 +44,21 @@ public:
         return n;
     }
 
+    // The same fused pair over several blocks that share their rows (one per gathered operand Bs[k]), in the order
+    // given.  Default: block after block through fused_local; StandardKernel walks them in a single launch.
+    virtual size_t fused_multi_local(SpmatLocal& S, DenseMatrix& A, const std::vector<DenseMatrix*>& Bs, DenseMatrix& Out,
+                                     const std::vector<int>& blocks, unsigned flags) {
+        size_t n = 0;
+        bool first = true;
+        for (size_t k = 0; k < blocks.size(); k++) {
+            if (S.csr_blocks[blocks[k]] == nullptr) continue;
+            n += fused_local(S, A, *Bs[k], Out, blocks[k], first ? flags : (flags & ~HNH_FUSED_OUT_OVERWRITE));
+            first = false;
+        }
+        if (first && (flags & HNH_FUSED_OUT_OVERWRITE)) Out.setZero();
+        return n;
+    }
+
     size_t triple_function(KernelMode mode, SpmatLocal& S, DenseMatrix& localA, DenseMatrix& localB, int block, int offset) {
         size_t nnz_processed = 0;
         if (mode == k_sddmmA || mode == k_sddmmB) nnz_processed += sddmm_local(S, localA, localB, block, offset);
@@ -63,6 +80,8 @@ public:
     size_t sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, int block, int offset) override;
     size_t spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, MatMode mode, int block) override;
     size_t fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, DenseMatrix& Out, int block, unsigned flags) override;
+    size_t fused_multi_local(SpmatLocal& S, DenseMatrix& A, const std::vector<DenseMatrix*>& Bs, DenseMatrix& Out,
+                             const std::vector<int>& blocks, unsigned flags) override;
     ~StandardKernel() override;
 
 private:

@@ -113,6 +113,22 @@ int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowpt
                                 int R, unsigned flags, int64_t nnz, int max_row_nnz, int stream);
 int hnh_csr_max_row_nnz(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, int* out_host, int stream);
 
+/* hnh_fused_sddmm_spmm_csr_multi — the fused pass over SEVERAL blocks that share their rows (the p/c blocks one rank
+ *   visits in 15D_dense_shift.hpp:199-227), each with its own gathered operand Y_b, in ONE launch: the row operand
+ *   X[i,:] and the output accumulator stay in registers across blocks instead of being re-read / read-modify-
+ *   written per block.  Same arithmetic and flags as calling hnh_fused_sddmm_spmm_csr block after block (which is
+ *   what it does when a block has hub rows).  `blocks` is a HOST array of device pointers. */
+typedef struct hnh_csr_block {
+    const int32_t* rowptr;
+    const int32_t* col_idx;
+    double* values;
+    const double* Y;
+    int64_t nnz;     /* rowptr[rows], or -1 */
+    int max_row_nnz; /* longest row, or -1 */
+} hnh_csr_block;
+int hnh_fused_sddmm_spmm_csr_multi(hnh_ctx* ctx, int64_t rows, int nblocks, const hnh_csr_block* blocks, const double* X,
+                                   double* Out, int R, unsigned flags, int stream);
+
 /* ---- element-wise helpers (K3-K5 of SURVEY §2.4) ----------------------------------------------------
  * hnh_fill_f64      — SpmatLocal::setValuesConstant (SpmatLocal.hpp:595-605), DenseMatrix::setZero
  * hnh_hadamard_f64  — `SValues.cwiseProduct(choice->getCSRValues())` (15D_dense_shift.hpp:366)

@@ -153,6 +153,15 @@ int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* c, int64_t rows, const int32_t* rowptr,
     (void)nnz; (void)max_row_nnz;
     return hnh_fused_sddmm_spmm_csr(c, rows, rowptr, col_idx, values, svalues, X, Y, Out, R, flags, stream);
 }
+int hnh_fused_sddmm_spmm_csr_multi(hnh_ctx* c, int64_t rows, int nblocks, const hnh_csr_block* blocks, const double* X, double* Out,
+                                   int R, unsigned flags, int stream) {
+    for (int b = 0; b < nblocks; b++) {  /* block after block: 15D_dense_shift.hpp:199-227 */
+        const unsigned f = (b == 0) ? flags : (flags & ~HNH_FUSED_OUT_OVERWRITE);
+        int rc = hnh_fused_sddmm_spmm_csr(c, rows, blocks[b].rowptr, blocks[b].col_idx, blocks[b].values, NULL, X, blocks[b].Y, Out, R, f, stream);
+        if (rc != HNH_OK) return rc;
+    }
+    return HNH_OK;
+}
 int hnh_csr_max_row_nnz(hnh_ctx* c, int64_t rows, const int32_t* rowptr, int* out_host, int stream) {
     (void)c; (void)stream;
     int m = 0;

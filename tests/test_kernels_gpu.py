@@ -264,3 +264,43 @@ def test_fill_hashed_matches_the_oracle_hash(ctx):
     ii, jj = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
     keys = ((top + ii) * rg + left + jj).astype(np.uint64).reshape(-1)
     assert np.array_equal(d.get().reshape(-1), O.hashed_uniform(keys, seed) * 0.25)
+
+
+@pytest.mark.parametrize("R", [16, 128, 100, 256])
+def test_fused_multi_block_equals_block_after_block(ctx, R):
+    """hnh_fused_sddmm_spmm_csr_multi: several blocks sharing their rows, each with its own gathered operand, in ONE
+    launch == the per-block sequence of 15D_dense_shift.hpp:199-227 (incl. one block with a hub row -> per-block path)."""
+    import ctypes as C
+    from distributed_sddmm_amd import _kernels as K
+    lib = ctx.lib
+    rows, cols, nb = 203, 150, 5
+    rng = np.random.default_rng(R + 3)
+    X = rng.uniform(-1, 1, (rows, R))
+    out0 = rng.uniform(-1, 1, (rows, R))
+    dX = ctx.upload(X)
+    for hub in (False, True):
+        blocks, keep, want_out = [], [], out0.copy()
+        for b in range(nb):
+            rowptr, ridx, cidx = random_block(rows, cols, 900 + 100 * b, seed=R * 10 + b)
+            if hub and b == 2:  # one block with a long row
+                lens = np.diff(rowptr); lens[5] = 0
+                extra = np.sort(rng.choice(cols * 20, 1500, replace=False)) % cols
+                cidx = np.concatenate([cidx[:rowptr[5]], extra.astype(np.int32), cidx[rowptr[6]:]])
+                lens[5] = 1500
+                rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+                ridx = np.repeat(np.arange(rows, dtype=np.int32), lens)
+            Y = rng.uniform(-1, 1, (cols, R))
+            v0 = rng.uniform(-1, 1, len(cidx))
+            d = (ctx.upload(rowptr), ctx.upload(cidx), ctx.upload(v0), ctx.upload(Y))
+            keep.append(d)
+            vals = O.sddmm_local(ridx, cidx, v0, X, Y)
+            want_out = O.spmm_local(rowptr, cidx, vals, Y, want_out)
+            blocks.append((d, vals, int(np.diff(rowptr).max()), len(cidx)))
+        arr = (K.CsrBlock * nb)()
+        for b, (d, _, mx, nnz) in enumerate(blocks):
+            arr[b] = K.CsrBlock(d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, nnz, mx)
+        dOut = ctx.upload(out0)
+        ctx.check(lib.hnh_fused_sddmm_spmm_csr_multi(ctx.h, rows, nb, C.byref(arr), dX.ptr, dOut.ptr, R, 0, 0), "multi")
+        assert rel(dOut.get(), want_out) <= TOL
+        for d, vals, _, _ in blocks:
+            assert rel(d[2].get(), vals) <= TOL
