@@ -27,14 +27,23 @@ for P in [int(x) for x in a.panels.split(",")]:
         r, c = rows_i[sel], cols_i[sel]
         rp = np.zeros(m + 1, np.int64); np.add.at(rp, r + 1, 1); rp = np.cumsum(rp).astype(np.int32)
         blocks.append((ctx.upload(rp), ctx.upload(c.astype(np.int32)), K.DevArray(ctx, (max(len(c), 1),), np.float64)))
-    def run():
+    arr = (K.CsrBlock * P)()
+    for p, (drp, dc, dv) in enumerate(blocks):
+        arr[p] = K.CsrBlock(drp.ptr, dc.ptr, dv.ptr, dB.ptr, dv.shape[0], 200)
+
+    def run_blocks():
         for p, (drp, dc, dv) in enumerate(blocks):
-            ctx.check(lib.hnh_fused_sddmm_spmm_csr(ctx.h, m, drp.ptr, dc.ptr, dv.ptr, None, dA.ptr, dB.ptr, dOut.ptr, R, 1 | (2 if p == 0 else 0), 0), "fused")
+            ctx.check(lib.hnh_fused_sddmm_spmm_csr_ex(ctx.h, m, drp.ptr, dc.ptr, dv.ptr, None, dA.ptr, dB.ptr, dOut.ptr, R, 1 | (2 if p == 0 else 0), dv.shape[0], 200, 0), "fused")
+
+    def run_multi():
+        ctx.check(lib.hnh_fused_sddmm_spmm_csr_multi(ctx.h, m, P, C.byref(arr), dA.ptr, dOut.ptr, R, 3, 0), "multi")
+
+    run = run_multi if os.environ.get("PROBE_MULTI") == "1" else run_blocks
     run(); ctx.sync(); ts = []
     for _ in range(a.iters):
         lib.hnh_event_record(ctx.h, ev0, 0); run(); lib.hnh_event_record(ctx.h, ev1, 0); lib.hnh_event_sync(ctx.h, ev1)
         ms = C.c_float(); lib.hnh_event_elapsed_ms(ctx.h, ev0, ev1, C.byref(ms)); ts.append(ms.value)
     t = float(np.median(ts)) * 1e-3
-    print("panels %3d (%.0f MiB of B each): %.3f ms  %.3e nnz*R/s  %.1f%% of 8TB/s (algorithmic)" % (P, w * R * 8 / 2**20, t * 1e3, nnz * R / t, 100 * alg / t / 8e12), flush=True)
+    print(("multi  " if os.environ.get("PROBE_MULTI") == "1" else "blocks ") + "panels %3d (%.0f MiB of B each): %.3f ms  %.3e nnz*R/s  %.1f%% of 8TB/s (algorithmic)" % (P, w * R * 8 / 2**20, t * 1e3, nnz * R / t, 100 * alg / t / 8e12), flush=True)
     for b in blocks:
         for d in b: d.free()
