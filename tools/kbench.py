@@ -9,7 +9,6 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distributed_sddmm_amd import _kernels as K  # noqa: E402
-from oracle import oracle as O  # noqa: E402
 
 
 def main():
