@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libhnh_kernels.so")
+LIB_PATH = os.environ.get("HNH_KERNEL_LIB_DEV") or os.path.join(HERE, "lib", "libhnh_kernels.so")  # override: kernel tuning experiments only
 
 OK = 0
 STREAM_COMPUTE, STREAM_COMM = 0, 1

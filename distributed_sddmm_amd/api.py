@@ -59,6 +59,7 @@ SIGNATURES = {
     "hnh_spmat_create": (_i32, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _pvp]),
     "hnh_spmat_load_tuples": (_i32, [_vp, _i32, _i32, _i32, C.c_char_p, _pvp]),
     "hnh_spmat_info": (_i32, [_vp, _pi64]),
+    "hnh_spmat_permute": (_i32, [_vp, _u64]),
     "hnh_spmat_destroy": (_i32, [_vp]),
     "hnh_er_generate": (_i32, [_u64, _u64, _u64, _u64, _pvp, _pi64]),
     "hnh_rmat_generate": (_i32, [_i32, _u64, _dbl, _dbl, _dbl, _u64, _i32, _pvp, _pi64]),
@@ -393,6 +394,10 @@ class SpmatLocal:
         _check(lib().hnh_spmat_load_tuples(world.h, int(read_from_file), log_m, nnz_per_row, filename.encode(), C.byref(h)),
                "spmat_load_tuples")
         return cls(world, h)
+
+    def permute(self, seed: int):
+        """Seeded random relabelling of rows/columns (load balance on real graphs)."""
+        _check(lib().hnh_spmat_permute(self.h, seed), "spmat_permute")
 
     def info(self):
         o = (C.c_int64 * 4)()

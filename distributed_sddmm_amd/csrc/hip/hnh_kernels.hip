@@ -105,9 +105,12 @@ __device__ __forceinline__ double group_multi_reduce(double (&d)[U], int lig) {
 }
 
 // nonzeros in flight per group
+#ifndef HNH_UNROLL1
+#define HNH_UNROLL1 8  // nonzeros in flight per group when one 16-byte chunk per lane covers the row (tuning knob)
+#endif
 template <int LPR, int VEC>
 struct Unroll {
-    static constexpr int byvec = VEC == 1 ? 8 : (VEC == 2 ? 4 : (VEC <= 4 ? 2 : 1));
+    static constexpr int byvec = VEC == 1 ? HNH_UNROLL1 : (VEC == 2 ? 4 : (VEC <= 4 ? 2 : 1));
     static constexpr int value = byvec < LPR ? byvec : LPR;
 };
 

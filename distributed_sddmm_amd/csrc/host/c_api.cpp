@@ -198,6 +198,9 @@ int hnh_spmat_info(hnh_spmat* s, int64_t out4[4]) {
     out4[3] = (int64_t)s->s->coords.size();
     return HNH_OK;
 }
+int hnh_spmat_permute(hnh_spmat* s, uint64_t seed) {
+    return guarded(s->w, [&] { s->s->permuteVertices(seed); });
+}
 int hnh_spmat_destroy(hnh_spmat* s) {
     return guarded(s ? s->w : nullptr, [&] { delete s; });
 }

@@ -49,6 +49,18 @@ std::vector<uint64_t> rmat_keys(int logm, uint64_t edges, double a, double b, do
     return keys;
 }
 
+std::vector<uint64_t> vertex_permutation(uint64_t n, uint64_t seed) {
+    std::vector<std::pair<uint64_t, uint64_t>> order(n);
+    const uint64_t G = 0x9E3779B97F4A7C15ull;
+#pragma omp parallel for
+    for (uint64_t v = 0; v < n; v++) order[v] = {splitmix64(seed + v * G), v};
+    __gnu_parallel::sort(order.begin(), order.end());
+    std::vector<uint64_t> label(n);
+#pragma omp parallel for
+    for (uint64_t k = 0; k < n; k++) label[order[k].second] = k;
+    return label;
+}
+
 void read_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std::vector<spcoord_t>& tuples) {
     std::ifstream in(path);
     if (!in) fatal("Error, cannot open matrix file " + path);
@@ -118,4 +130,17 @@ void SpmatLocal::loadTuples(bool readFromFile, int logM, int nnz_per_row, std::s
         if (rank == 0) std::cout << "R-mat generator created " << dist_nnz << " nonzeros." << std::endl;
     }
     initialized = true;
+    if (const char* ps = std::getenv("HNH_PERMUTE_SEED")) permuteVertices(std::strtoull(ps, nullptr, 10));
+}
+
+// Relabels rows and columns with a seeded random permutation (one permutation for both when the matrix is square,
+// like RenameVertices on a graph).  Every rank derives the same permutation, so it is applied to local tuples only.
+void SpmatLocal::permuteVertices(uint64_t seed) {
+    std::vector<uint64_t> rp = hnh::vertex_permutation(M, seed);
+    std::vector<uint64_t> cp = (M == N) ? rp : hnh::vertex_permutation(N, seed + 1);
+#pragma omp parallel for
+    for (size_t e = 0; e < coords.size(); e++) {
+        coords[e].r = rp[coords[e].r];
+        coords[e].c = cp[coords[e].c];
+    }
 }

@@ -29,6 +29,12 @@ std::vector<uint64_t> erdos_renyi_keys(uint64_t m, uint64_t n, uint64_t draws, u
 // Bit-identical twin: oracle/oracle.py:rmat.
 std::vector<uint64_t> rmat_keys(int logm, uint64_t edges, double a, double b, double c, uint64_t seed, bool scramble);
 
+// Seeded random relabelling of n vertices for load balance on real graphs (the reference applies CombBLAS's
+// PermEdges / RenameVertices to generated graphs, SpmatLocal.hpp:506-507, and ships random_permute.cpp for files):
+// new_label[v] = position of v when vertices are ordered by splitmix64(seed + v * G) (ties by v).
+// Twin: oracle/oracle.py:vertex_permutation.
+std::vector<uint64_t> vertex_permutation(uint64_t n, uint64_t seed);
+
 // MatrixMarket coordinate reader (general / symmetric; pattern, integer or real); duplicates keep the
 // maximum, as the reference's `maximum<double>()` reduction does (SpmatLocal.hpp:487).  Returns all tuples.
 void read_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std::vector<spcoord_t>& tuples);

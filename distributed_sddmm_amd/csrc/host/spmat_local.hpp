@@ -283,6 +283,9 @@ public:
     // evaluates identically (see er_generator.hpp), each rank keeping a strided slice — any initial
     // distribution is legal because redistribute_nonzeros() follows.
     void loadTuples(bool readFromFile, int logM, int nnz_per_row, std::string filename);
+    // Seeded random relabelling of rows / columns for load balance (random_permute.cpp, SpmatLocal.hpp:506-507);
+    // also applied by loadTuples when HNH_PERMUTE_SEED is set.
+    void permuteVertices(uint64_t seed);
 
     // Tuples must be column-major sorted.  Splits them into block columns of `blockWidth` and (optionally)
     // makes column indices block-local (SpmatLocal.hpp:541-563).

@@ -86,6 +86,8 @@ int hnh_spmat_create(hnh_world* w, int64_t M, int64_t N, int64_t dist_nnz, int64
 /* SpmatLocal::loadTuples(readFromFile, logM, nnz_per_row, filename) (SpmatLocal.hpp:467-533) */
 int hnh_spmat_load_tuples(hnh_world* w, int read_from_file, int logM, int nnz_per_row, const char* filename, hnh_spmat** out);
 int hnh_spmat_info(hnh_spmat* s, int64_t out4[4]); /* M, N, dist_nnz, local tuple count */
+/* seeded random relabelling of rows/columns for load balance (random_permute.cpp; twin: oracle.vertex_permutation) */
+int hnh_spmat_permute(hnh_spmat* s, uint64_t seed);
 int hnh_spmat_destroy(hnh_spmat* s);
 /* the shared synthetic generator (bit-identical to oracle/oracle.py:erdos_renyi_mn) */
 int hnh_er_generate(uint64_t m, uint64_t n, uint64_t draws, uint64_t seed, void** handle, int64_t* count);

@@ -89,6 +89,16 @@ def rmat(log_m: int, edges: int, a: float = 0.57, b: float = 0.19, c: float = 0.
     return (keys // n).astype(np.int64), (keys % n).astype(np.int64)
 
 
+def vertex_permutation(n: int, seed: int) -> np.ndarray:
+    """new_label[v] = position of v when vertices are ordered by splitmix64(seed + v*G); twin of hnh::vertex_permutation."""
+    with np.errstate(over="ignore"):
+        h = splitmix64(np.uint64(seed) + np.arange(n, dtype=np.uint64) * _GOLDEN)
+    order = np.argsort(h, kind="stable")
+    label = np.empty(n, dtype=np.int64)
+    label[order] = np.arange(n)
+    return label
+
+
 def hashed_uniform(keys: np.ndarray, seed: int) -> np.ndarray:
     """uniform(-1, 1) fp64 as a pure function of (key, seed)."""
     with np.errstate(over="ignore"):

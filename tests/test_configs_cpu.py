@@ -38,3 +38,39 @@ def test_config4_shape_skewed_graph(alg, p, c):
     imbalance = per_rank[0]["alg_info"]["nnz_procs"]
     assert sum(imbalance) == len(rows) * (c if alg == "25d_sparse_replicate" else 1) or sum(imbalance) == len(rows)
     T.check_against_oracle(T.assemble(per_rank, case), case, alg)
+
+
+def test_vertex_permutation_balances_a_skewed_graph_and_commutes_with_the_operator():
+    """SpmatLocal::permuteVertices (the reference's random_permute.cpp / RenameVertices step): P S P^T.  The operator
+    on the relabelled matrix with relabelled dense operands gives the relabelled result, and the per-rank nonzero
+    counts of a skewed graph get closer to uniform."""
+    rows, cols = H.generate_rmat(10, 1024 * 12, scramble=False)  # hubs clustered at small vertex ids
+    m, r, seed = 1024, 16, 77
+    case = T.make_case("rmat10", m, m, r, rows, cols)
+    perm = O.vertex_permutation(m, seed)
+
+    def body(permute):
+        def f(w):
+            sp = H.SpmatLocal.from_global(w, m, m, rows, cols, case["vals"])
+            if permute:
+                sp.permute(seed)
+            d = H.DistributedSparse(w, "15d_fusion2", sp, r, 1)
+            A, B, S = d.like_A_matrix(0.0), d.like_B_matrix(0.0), d.like_S_values(1.0)
+            subA, subB = d.submatrices(H.AMAT), d.submatrices(H.BMAT)
+            bg = case["B"]
+            if permute:
+                bg = np.empty_like(case["B"]); bg[perm] = case["B"]
+            B.upload(T.fill_local(subB, B.shape, bg))
+            d.spmmA(A, B, S)
+            out = dict(subA=subA, spmmA=A.download(), nnz=d.json_algorithm_info()["nnz_procs"])
+            d.free(); sp.free()
+            return out
+        return f
+
+    plain = H.run_spmd(4, body(False))
+    shuf = H.run_spmd(4, body(True))
+    a0 = T.assemble_dense(plain, "spmmA", "subA", m, r)
+    a1 = T.assemble_dense(shuf, "spmmA", "subA", m, r)
+    assert T.rel(a1[perm], a0) <= T.TOL  # (P S P^T)(P B) = P (S B)
+    imb = lambda c: max(c) / (sum(c) / len(c))  # noqa: E731
+    assert imb(shuf[0]["nnz"]) < imb(plain[0]["nnz"])

@@ -143,3 +143,34 @@ def test_gat_forward_matches_reference_hip(alg, p, c):
     out = T.assemble_dense(per_rank, "gat", "subA", case["M"], T.GAT_LAYERS[-1][1] * T.GAT_LAYERS[-1][2])
     gold = dict(np.load(os.path.join(T.GOLDEN, "gat_er8_r16.npz")))["out"]
     assert T.rel(out, gold) <= T.TOL
+
+
+def test_operands_in_torch_memory():
+    """hnh_dense_wrap: operands that live in PyTorch-owned HBM (non-owning views).  The fused schedule hands its
+    result back by copying into the caller's tensor instead of swapping storage (common.h:88-92 semantics)."""
+    import torch
+    from oracle import oracle as O
+    case = T.case_inputs("er8_r16")
+    m, r = case["M"], 128
+    a, b = O.dense_fill(m, r, 21), O.dense_fill(m, r, 22)
+    ta = torch.from_numpy(a).to("cuda:0")
+    tb = torch.from_numpy(b).to("cuda:0")
+    torch.cuda.synchronize()
+    w = H.World.single(0)
+    sp = H.SpmatLocal.from_global(w, m, m, case["rows"], case["cols"], np.ones(len(case["rows"])))
+    for alg in ("15d_fusion2", "15d_fusion1", "25d_dense_replicate"):
+        op = H.DistributedSparse(w, alg, sp, r, 1)
+        ta.copy_(torch.from_numpy(a)); torch.cuda.synchronize()
+        A, B = H.Dense.wrap(w, ta.data_ptr(), m, r), H.Dense.wrap(w, tb.data_ptr(), m, r)
+        S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
+        op.initial_shift(A, B, H.K_SDDMM_A)
+        op.fusedSpMM(A, B, S, buf, H.AMAT)
+        op.de_shift(A, B, H.K_SDDMM_A)
+        w.sync()
+        want, _ = O.fused_a(case["rows"], case["cols"], np.ones(len(case["rows"])), a, b)
+        assert T.rel(ta.cpu().numpy(), want) <= T.TOL, alg
+        assert np.array_equal(tb.cpu().numpy(), b), "the other operand must come back unchanged"
+        for x in (A, B, S, buf):
+            x.free()
+        op.free()
+    sp.free(); w.close()
