@@ -160,8 +160,10 @@ def run(args, make_world=gpu_world):
     world.sync()
     kern_ms, launches = op.kernel_profile(0)
     local_nnz = op.info()["nS"]
-    rows_touched = op.info()["localArows"] * args.c * (n // args.c)  # every ring step walks all rows of the block row
-    alg_bytes_per_call = local_nnz * (8 * args.r + 24) + 16 * args.r * rows_touched
+    launches_per_call_local = max(1, launches // prof_calls)
+    # per nonzero 8R + 24 bytes; per row and launch 16R (row operand read + output row written); every
+    # launch of this rank walks the localArows*c rows of its block row
+    alg_bytes_per_call = local_nnz * (8 * args.r + 24) + 16 * args.r * op.info()["localArows"] * args.c * launches_per_call_local
     if dist is not None:
         t = torch.tensor([kern_ms, float(launches), float(alg_bytes_per_call)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
