@@ -100,6 +100,10 @@ def gpu_world(H, dist, rank, n, local_rank):
 
 def run(args, make_world=gpu_world):
     """`make_world` is replaceable so that tests can drive this exact function over gloo on CPU."""
+    if args.gpus > 1 and "HNH_KEEP_OMP" not in os.environ:
+        # torch.distributed.run pins OMP_NUM_THREADS=1 per worker; the host-side setup (generator, sorts, CSR build)
+        # is OpenMP code, so give every rank its share of the host cores instead (must happen before libgomp starts)
+        os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // args.gpus))
     import torch  # first: one HIP runtime per process (see distributed_sddmm_amd/_kernels.py)
     from distributed_sddmm_amd import api as H
 
