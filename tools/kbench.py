@@ -70,6 +70,21 @@ def main():
     if "sddmm" in ops:
         timed(lambda: ctx.check(lib.hnh_sddmm_csr(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, dA.ptr, dB.ptr, R, 0), "sddmm"),
               "sddmm", nnz * (8 * R + 20) + 8 * R * m)
+    if "coo" in ops:
+        d_r = K.DevArray(ctx, (nnz,), np.int32)
+        ctx.check(lib.hnh_expand_rowptr(ctx.h, m, d_rowptr.ptr, d_r.ptr, 0), "expand")
+        timed(lambda: ctx.check(lib.hnh_sddmm_coo(ctx.h, nnz, d_r.ptr, d_c.ptr, dv.ptr, dA.ptr, dB.ptr, R, 0), "coo"),
+              "coo", nnz * (16 * R + 24))
+    if "ew" in ops:
+        n = m * R
+        timed(lambda: ctx.check(lib.hnh_fill_f64(ctx.h, dOut.ptr, n, 1.5, 0), "fill"), "fill", 8 * n)
+        timed(lambda: ctx.check(lib.hnh_hadamard_f64(ctx.h, dOut.ptr, dA.ptr, dB.ptr, n, 0), "hadamard"), "hadam", 24 * n)
+        timed(lambda: ctx.check(lib.hnh_axpy_f64(ctx.h, dOut.ptr, dA.ptr, 0.5, n, 0), "axpy"), "axpy", 24 * n)
+        dvec = K.DevArray(ctx, (m,), np.float64)
+        timed(lambda: ctx.check(lib.hnh_rowdot_f64(ctx.h, dA.ptr, dB.ptr, dvec.ptr, m, R, 0), "rowdot"), "rowdot", 16 * n)
+        timed(lambda: ctx.check(lib.hnh_row_scale_add_f64(ctx.h, dOut.ptr, None, 1.0, dA.ptr, dvec.ptr, -1.0, m, R, 0), "rsa"), "rsadd", 24 * n)
+        timed(lambda: ctx.check(lib.hnh_memcpy(ctx.h, dOut.ptr, dA.ptr, 8 * n, K.D2D, 0), "copy"), "d2dcp", 16 * n)
+        timed(lambda: ctx.check(lib.hnh_memset(ctx.h, dOut.ptr, 0, 8 * n, 0), "memset"), "mset", 8 * n)
     if "spmm" in ops:
         timed(lambda: ctx.check(lib.hnh_spmm_csr(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, dB.ptr, dOut.ptr, R, 0), "spmm"),
               "spmm", nnz * (8 * R + 12) + 16 * R * m)
