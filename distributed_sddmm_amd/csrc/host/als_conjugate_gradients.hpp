@@ -105,6 +105,7 @@ class Distributed_ALS : public ALS_CG {
 public:
     VectorXd ground_truth, ground_truth_transpose;
     uint64_t seed = 2022;
+    VectorXd ones_S, scratch_S, ones_ST, scratch_ST;  // persistent arguments of computeQueries
 
     // artificial_groundtruth: ground truth = SDDMM of two hashed random factor matrices with S = 1
     // (als_conjugate_gradients.cpp:157-184); otherwise the caller sets ground_truth{,_transpose}.
@@ -165,8 +166,11 @@ public:
     void computeQueries(DenseMatrix& A_in, DenseMatrix& B_in, MatMode matrix_to_optimize, DenseMatrix& result) override {
         const double lambda = 1e-13;
         hnh::World* w = d_ops->world;
+        // the all-ones S values and the SDDMM scratch vector are the same for every call: keep them
+        // (the reference re-creates both per call, .cpp:276-277,289-290)
         if (matrix_to_optimize == Amat) {
-            VectorXd ones = d_ops->like_S_values(1.0), sddmm_result = d_ops->like_S_values(0.0);
+            if (ones_S.size() == 0) { ones_S = d_ops->like_S_values(1.0); scratch_S = d_ops->like_S_values(0.0); }
+            VectorXd &ones = ones_S, &sddmm_result = scratch_S;
             result = A_in;
             d_ops->initial_shift(&result, &B_in, k_sddmmA);
             d_ops->fusedSpMM(result, B_in, ones, sddmm_result, Amat);
@@ -174,7 +178,8 @@ public:
             w->check(w->be->hnh_row_scale_add_f64(w->ctx, result.data(), nullptr, 1.0, A_in.data(), nullptr, lambda, result.rows(),
                                                   (int)result.cols(), HNH_STREAM_COMPUTE), "hnh_row_scale_add_f64");
         } else {
-            VectorXd ones = d_ops->like_ST_values(1.0), sddmm_result = d_ops->like_ST_values(0.0);
+            if (ones_ST.size() == 0) { ones_ST = d_ops->like_ST_values(1.0); scratch_ST = d_ops->like_ST_values(0.0); }
+            VectorXd &ones = ones_ST, &sddmm_result = scratch_ST;
             result = B_in;
             d_ops->initial_shift(&A_in, &result, k_sddmmB);
             d_ops->fusedSpMM(A_in, result, ones, sddmm_result, Bmat);
