@@ -233,6 +233,7 @@ Comm World::split(int color, int key) {
     Comm c;
     c.color = color;
     c.key = key;
+    c.native_slot = std::make_shared<void*>(nullptr);
     for (size_t i = 0; i < members.size(); i++) {
         c.ranks.push_back(members[i].second);
         if (members[i].second == rank) c.me = (int)i;
@@ -240,7 +241,7 @@ Comm World::split(int color, int key) {
     return c;
 }
 
-void World::free_comm(Comm& c) { c.native = nullptr; }
+void World::free_comm(Comm& c) { c.native_slot.reset(); }
 
 // Default collectives: (n - 1) rounds of pairwise exchange; round k pairs me -> me + k, me - k -> me.
 void World::allgather(const Comm& comm, const void* sendbuf, void* recvbuf, size_t bytes, int stream) {
@@ -502,16 +503,17 @@ Comm RcclWorld::split(int color, int key) { return World::split(color, key); }
 // collective on its row/fiber communicator, every rank does on its own), so the RCCL sub-communicator can be
 // created at first use.  Schedules that never run a collective (c = 1) never split at all.
 void* RcclWorld::native_for(const Comm& comm) {
-    if (comm.is_world) return comm_;
-    if (!comm.native) check(be->hnh_comm_split(ctx, comm_, comm.color, comm.key, &comm.native), "hnh_comm_split");
-    return comm.native;
+    if (comm.is_world || !comm.native_slot) return comm_;
+    if (!*comm.native_slot) check(be->hnh_comm_split(ctx, comm_, comm.color, comm.key, comm.native_slot.get()), "hnh_comm_split");
+    return *comm.native_slot;
 }
 void RcclWorld::free_comm(Comm& c) {
-    if (c.native) {
+    if (c.native_slot && *c.native_slot) {
         sync_all();
-        be->hnh_comm_destroy(ctx, c.native);
-        c.native = nullptr;
+        be->hnh_comm_destroy(ctx, *c.native_slot);
+        *c.native_slot = nullptr;
     }
+    c.native_slot.reset();
 }
 
 void RcclWorld::group_begin() { check(be->hnh_comm_group_begin(ctx), "hnh_comm_group_begin"); }

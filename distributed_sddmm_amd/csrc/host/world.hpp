@@ -31,8 +31,10 @@ namespace hnh {
 struct Comm {
     std::vector<int> ranks;
     int me = -1;
-    mutable void* native = nullptr;  // RCCL sub-communicator (RcclWorld), created on first collective use
-    int color = 0, key = 0;          // what it was split with (MPI_Comm_split arguments)
+    // RCCL sub-communicator (RcclWorld), created on first collective use; the slot is shared by every copy of
+    // this Comm (schedules copy their grid's communicators into A_R_split_world etc.), so it is created once
+    std::shared_ptr<void*> native_slot;
+    int color = 0, key = 0;  // what it was split with (MPI_Comm_split arguments)
     bool is_world = false;
     int size() const { return (int)ranks.size(); }
     int rank() const { return me; }
