@@ -228,6 +228,37 @@ public:
         buf.swapActive();
     }
 
+    // The reference's four-argument form (distributed_sparse.h:351): every caller shifts by the same distance on
+    // every rank, so the source is the rank symmetric to `send_dst`; `tag` is unused (no wildcard matching here).
+    void shiftDenseMatrix(hnh::BufferPair& buf, const hnh::Comm& comm, int send_dst, int tag) {
+        (void)tag;
+        shiftDenseMatrix(buf, comm, send_dst, pMod(2 * comm.me - send_dst, comm.size()), HNH_STREAM_COMPUTE);
+    }
+
+    // Rank-by-rank dump of grid position, local tuples (while they still exist) and the local dense operands
+    // (distributed_sparse.h:363-387); debugging aid, downloads the matrices.
+    void print_nonzero_distribution(DenseMatrix& localA, DenseMatrix& localB) {
+        for (int i = 0; i < p; i++) {
+            if (proc_rank == i) {
+                std::cout << "==================================" << std::endl << "Process " << i << ":" << std::endl
+                          << "Rank in Row: " << grid->rankInRow << std::endl << "Rank in Column: " << grid->rankInCol << std::endl
+                          << "Rank in Fiber: " << grid->rankInFiber << std::endl;
+                for (auto& t : S->coords) std::cout << t.string_rep() << std::endl;
+                for (int which = 0; which < 2; which++) {
+                    DenseMatrix& m = which == 0 ? localA : localB;
+                    std::cout << "==================" << std::endl << (which == 0 ? "A matrix: " : "B matrix: ") << std::endl;
+                    std::vector<double> h = m.to_host();
+                    for (int64_t r = 0; r < m.rows(); r++) {
+                        for (int64_t c2 = 0; c2 < m.cols(); c2++) std::cout << h[(size_t)(r * m.cols() + c2)] << (c2 + 1 < m.cols() ? " " : "");
+                        std::cout << std::endl;
+                    }
+                }
+                std::cout << "==================================" << std::endl;
+            }
+            world->barrier();
+        }
+    }
+
 protected:
     // Travelling blocks: every rank of the ring must know the longest row of ANY block that will visit it
     // (the kernels' long-row hint); one int all-gathered over the ring at construction.
