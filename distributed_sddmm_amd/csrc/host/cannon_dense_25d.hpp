@@ -174,6 +174,7 @@ public:
                 // follow this step's kernel; they run back to back on the communication stream.
                 t = start_clock();
                 order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);
+                world->group_begin();  // dense (grid column) and sparse (grid row) rings use different xGMI links: one group
                 shiftDenseMatrix(bBuf, grid->col_world, pMod(grid->rankInCol + 1, sqrtpc), pMod(grid->rankInCol - 1, sqrtpc),
                                  HNH_STREAM_COMM);
                 stop_clock_and_add(t, "Dense Cyclic Shift Time");
@@ -182,6 +183,7 @@ public:
                 blk->shiftCSR(src, dst, grid->row_world, (*nnz_in_axis)[pMod(sparse_shift - i - 1, sqrtpc)], 72, is_sddmm ? coo : csr,
                               HNH_STREAM_COMM);
                 choice->blockStarts[1] = blk->num_coords;
+                world->group_end();
                 order(HNH_STREAM_COMM, HNH_STREAM_COMPUTE, 1);
                 stop_clock_and_add(t, "Sparse Cyclic Shift Time");
             }

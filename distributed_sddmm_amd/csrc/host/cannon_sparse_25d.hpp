@@ -181,8 +181,10 @@ public:
                     world->event_record(event(3 + i % 2), HNH_STREAM_COMPUTE);
                     if (i >= 2) world->event_wait(event(3 + (i - 1) % 2), HNH_STREAM_COMM);
                     DenseMatrix *ta = &spareA[i % 2], *tb = &spareB[i % 2];
+                    world->group_begin();  // row ring and column ring: different peers, different links, one group
                     world->sendrecv(grid->row_world, curA->data(), abytes, rdst, ta->data(), abytes, rsrc, HNH_STREAM_COMM);
                     world->sendrecv(grid->col_world, curB->data(), bbytes, cdst, tb->data(), bbytes, csrc, HNH_STREAM_COMM);
+                    world->group_end();
                     world->event_record(event(1 + i % 2), HNH_STREAM_COMM);
                     curA = ta;
                     curB = tb;
@@ -200,8 +202,10 @@ public:
                 if (s > 1) {
                     t = start_clock();
                     order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);
+                    world->group_begin();
                     shiftDenseMatrix(aBuf, grid->row_world, rdst, rsrc, HNH_STREAM_COMM);
                     shiftDenseMatrix(bBuf, grid->col_world, cdst, csrc, HNH_STREAM_COMM);
+                    world->group_end();
                     order(HNH_STREAM_COMM, HNH_STREAM_COMPUTE, 1);
                     stop_clock_and_add(t, "Dense Cyclic Shift Time");
                 }

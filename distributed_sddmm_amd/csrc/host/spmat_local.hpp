@@ -155,12 +155,14 @@ public:
         if (nnz_to_receive > max_nnz) hnh::fatal("Error, incoming sparse block exceeds the padded capacity!");
         CSRHandle* send = buffer + active;
         CSRHandle* recv = buffer + 1 - active;
+        world->group_begin();  // the three arrays travel as one RCCL group
         world->sendrecv(comm, send->values, (size_t)num_coords * sizeof(double), dst, recv->values,
                         (size_t)nnz_to_receive * sizeof(double), src, stream);
         world->sendrecv(comm, send->col_idx, (size_t)num_coords * sizeof(int32_t), dst, recv->col_idx,
                         (size_t)nnz_to_receive * sizeof(int32_t), src, stream);
         world->sendrecv(comm, send->rowStart, ((size_t)rows + 1) * sizeof(int32_t), dst, recv->rowStart,
                         ((size_t)rows + 1) * sizeof(int32_t), src, stream);
+        world->group_end();
         num_coords = nnz_to_receive;
         active = 1 - active;
     }
