@@ -93,13 +93,17 @@ public:
 
         publish_ring_max_row(S.get(), grid->row_world);
         publish_ring_max_row(ST.get(), grid->row_world);
+        if (std::getenv("HNH_SHIP_INDICES") == nullptr) {  // default: the ring's sparsity structure stays resident, values travel
+            S->csr_blocks[0]->replicate_ring_indices(grid->row_world, nnz_in_row_axis);
+            ST->csr_blocks[0]->replicate_ring_indices(grid->row_world, nnz_in_row_axis_tpose);
+        }
         // Skew the sparse blocks along grid rows in preparation for repeated Cannon passes (:138-145)
         const int src = pMod(grid->rankInRow + grid->rankInCol, sqrtpc);
         const int dst = pMod(grid->rankInRow - grid->rankInCol, sqrtpc);
         sparse_shift = src;
-        S->csr_blocks[0]->shiftCSR(src, dst, grid->row_world, nnz_in_row_axis[src], 0, both, HNH_STREAM_COMPUTE);
+        S->csr_blocks[0]->shiftCSR(src, dst, grid->row_world, nnz_in_row_axis[src], 0, both, HNH_STREAM_COMPUTE, src);
         S->blockStarts[1] = S->csr_blocks[0]->num_coords;
-        ST->csr_blocks[0]->shiftCSR(src, dst, grid->row_world, nnz_in_row_axis_tpose[src], 0, both, HNH_STREAM_COMPUTE);
+        ST->csr_blocks[0]->shiftCSR(src, dst, grid->row_world, nnz_in_row_axis_tpose[src], 0, both, HNH_STREAM_COMPUTE, src);
         ST->blockStarts[1] = ST->csr_blocks[0]->num_coords;
         world->sync(HNH_STREAM_COMPUTE);
         check_initialized();
@@ -181,7 +185,7 @@ public:
                 t = start_clock();
                 const int src = pMod(grid->rankInRow - 1, sqrtpc), dst = pMod(grid->rankInRow + 1, sqrtpc);
                 blk->shiftCSR(src, dst, grid->row_world, (*nnz_in_axis)[pMod(sparse_shift - i - 1, sqrtpc)], 72, is_sddmm ? coo : csr,
-                              HNH_STREAM_COMM);
+                              HNH_STREAM_COMM, pMod(sparse_shift - i - 1, sqrtpc));
                 choice->blockStarts[1] = blk->num_coords;
                 world->group_end();
                 order(HNH_STREAM_COMM, HNH_STREAM_COMPUTE, 1);

@@ -88,6 +88,10 @@ public:
         std::vector<spcoord_t>().swap(ST->coords);
         publish_ring_max_row(S.get(), grid->col_world);
         publish_ring_max_row(ST.get(), grid->col_world);
+        if (std::getenv("HNH_SHIP_INDICES") == nullptr) {  // default: the ring's sparsity structure stays resident, values travel
+            S->csr_blocks[0]->replicate_ring_indices(grid->col_world, nnz_in_row_axis);
+            ST->csr_blocks[0]->replicate_ring_indices(grid->col_world, nnz_in_row_axis_tpose);
+        }
         check_initialized();
     }
 
@@ -171,7 +175,7 @@ public:
                 if (is_sddmm) world->event_wait(event(3 + i % 2), HNH_STREAM_COMM);
                 else if (i >= 1) world->event_wait(event(3 + (i - 1) % 2), HNH_STREAM_COMM);
                 blk->shiftCSR(src, dst, grid->col_world, (*nnz_in_axis)[pMod(grid->i - i - 1, n)], 72, is_sddmm ? coo : csr,
-                              HNH_STREAM_COMM);
+                              HNH_STREAM_COMM, pMod(grid->i - i - 1, n));
                 choice->blockStarts[1] = blk->num_coords;
                 world->event_record(event(1 + i % 2), HNH_STREAM_COMM);
                 stop_clock_and_add(t, "Cyclic Shift Time");

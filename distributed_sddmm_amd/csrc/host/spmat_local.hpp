@@ -62,6 +62,17 @@ public:
     int max_row_nnz = 0, ring_max_row_nnz = 0;
     int row_hint() const { return shifting ? ring_max_row_nnz : max_row_nnz; }
 
+    // Ring-resident sparsity structure.  The pattern never changes, and a GPU has room for the col_idx / rowStart
+    // arrays of EVERY block of its ring (config 3 sized: 8 x 6.8 MB), so a travelling block can leave its indices
+    // at home: after replicate_ring_indices() each shift moves `values` only (8 B per nonzero instead of 12 B plus
+    // a row pointer array) and just re-points the active handle at the resident indices of the arriving block.
+    struct RingIndex {
+        int32_t* col_idx = nullptr;
+        int32_t* rowStart = nullptr;
+        int nnz = 0;
+    };
+    std::vector<RingIndex> ring_index;  // by ring position of the block's origin; empty = indices travel (reference behaviour)
+
     CSRLocal(int64_t blockRows, int64_t blockCols, int64_t max_nnz_in, spcoord_t* coords, int num_coords_in, bool transpose_in,
              bool shifting_in = true)
         : rows(blockRows), cols(blockCols), max_nnz((int)max_nnz_in), num_coords(num_coords_in), transpose(transpose_in),
@@ -125,11 +136,48 @@ public:
     ~CSRLocal() {
         for (int t = 0; t < 2; t++) {
             world->dfree(buffer[t].values);
-            world->dfree(buffer[t].col_idx);
-            world->dfree(buffer[t].rowStart);
+            if (ring_index.empty()) {  // otherwise the handles point into ring_index
+                world->dfree(buffer[t].col_idx);
+                world->dfree(buffer[t].rowStart);
+            }
             world->dfree(buffer[t].row_idx);
         }
+        for (RingIndex& ri : ring_index) {
+            world->dfree(ri.col_idx);
+            world->dfree(ri.rowStart);
+        }
         delete[] buffer;
+    }
+
+    // One-time exchange at construction: every rank of `ring` receives the index arrays of every other rank's
+    // block (all transfers in one group).  nnz_per_slot[s] = nonzeros of the block owned by ring position s.
+    void replicate_ring_indices(const hnh::Comm& ring, const std::vector<int>& nnz_per_slot) {
+        if (!shifting) hnh::fatal("Error, only travelling blocks keep ring-resident indices!");
+        const int n = ring.size(), me = ring.me;
+        const size_t rp_bytes = ((size_t)rows + 1) * sizeof(int32_t);
+        ring_index.resize(n);
+        for (int s2 = 0; s2 < n; s2++) {
+            ring_index[s2].nnz = nnz_per_slot[s2];
+            ring_index[s2].col_idx = static_cast<int32_t*>(world->dmalloc((size_t)std::max(nnz_per_slot[s2], 1) * sizeof(int32_t)));
+            ring_index[s2].rowStart = static_cast<int32_t*>(world->dmalloc(rp_bytes));
+        }
+        world->copy(ring_index[me].col_idx, buffer[0].col_idx, (size_t)num_coords * sizeof(int32_t), HNH_COPY_D2D, HNH_STREAM_COMPUTE);
+        world->copy(ring_index[me].rowStart, buffer[0].rowStart, rp_bytes, HNH_COPY_D2D, HNH_STREAM_COMPUTE);
+        world->group_begin();
+        for (int k = 1; k < n; k++) {
+            const int dst = (me + k) % n, src = (me - k + n) % n;
+            world->sendrecv(ring, buffer[0].col_idx, (size_t)num_coords * sizeof(int32_t), dst, ring_index[src].col_idx,
+                            (size_t)nnz_per_slot[src] * sizeof(int32_t), src, HNH_STREAM_COMPUTE);
+            world->sendrecv(ring, buffer[0].rowStart, rp_bytes, dst, ring_index[src].rowStart, rp_bytes, src, HNH_STREAM_COMPUTE);
+        }
+        world->group_end();
+        world->sync(HNH_STREAM_COMPUTE);
+        for (int t = 0; t < 2; t++) {  // the per-buffer index arrays are no longer needed
+            world->dfree(buffer[t].col_idx);
+            world->dfree(buffer[t].rowStart);
+            buffer[t].col_idx = ring_index[me].col_idx;
+            buffer[t].rowStart = ring_index[me].rowStart;
+        }
     }
     CSRLocal(const CSRLocal&) = delete;
     CSRLocal& operator=(const CSRLocal&) = delete;
@@ -148,13 +196,24 @@ public:
     // index `dst`, the block of comm index `src` lands in the passive buffer, then the two swap roles.
     // Stream-ordered on `stream`; `tag` is unused (explicit peers, no wildcard matching).
     void shiftCSR(int src, int dst, const hnh::Comm& comm, int nnz_to_receive, int tag, ShiftMode mode,
-                  int stream = HNH_STREAM_COMM) {
+                  int stream = HNH_STREAM_COMM, int incoming_slot = -1) {
         (void)tag;
         (void)mode;
         if (!shifting) hnh::fatal("Error, this sparse block was built without a second buffer and cannot shift!");
         if (nnz_to_receive > max_nnz) hnh::fatal("Error, incoming sparse block exceeds the padded capacity!");
         CSRHandle* send = buffer + active;
         CSRHandle* recv = buffer + 1 - active;
+        if (!ring_index.empty()) {  // indices are resident: only the values travel
+            if (incoming_slot < 0 || incoming_slot >= (int)ring_index.size()) hnh::fatal("Error, shiftCSR needs the arriving block's ring position!");
+            if (ring_index[incoming_slot].nnz != nnz_to_receive) hnh::fatal("Error, arriving block does not match its resident indices!");
+            world->sendrecv(comm, send->values, (size_t)num_coords * sizeof(double), dst, recv->values,
+                            (size_t)nnz_to_receive * sizeof(double), src, stream);
+            recv->col_idx = ring_index[incoming_slot].col_idx;
+            recv->rowStart = ring_index[incoming_slot].rowStart;
+            num_coords = nnz_to_receive;
+            active = 1 - active;
+            return;
+        }
         world->group_begin();  // the three arrays travel as one RCCL group
         world->sendrecv(comm, send->values, (size_t)num_coords * sizeof(double), dst, recv->values,
                         (size_t)nnz_to_receive * sizeof(double), src, stream);
