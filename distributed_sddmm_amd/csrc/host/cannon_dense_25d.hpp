@@ -35,6 +35,7 @@ public:
     int sparse_shift;
     DenseMatrix accumulation_buffer;
     DenseMatrix ring_spare;
+    DenseMatrix dense_spare[2];  // landing buffers of the read-only (SDDMM) dense ring
 
     Sparse25D_Cannon_Dense(SpmatLocal* S_input, int R, int c, KernelImplementation* k) : Distributed_Sparse(k) {
         this->c = c;
@@ -151,7 +152,6 @@ public:
         if ((uint64_t)SValues.size() != choice->blockStarts[1]) hnh::fatal("Error, sparse value vector has the wrong length!");
         const bool is_sddmm = (mode == k_sddmmA || mode == k_sddmmB);
 
-        hnh::BufferPair bBuf(Brole, &ring_spare);
         {
             auto t = start_clock();
             if (is_sddmm) choice->setValuesConstant(0.0);
@@ -168,31 +168,73 @@ public:
         }
         DenseMatrix& stationary = (c > 1) ? accumulation_buffer : *Arole;
         CSRLocal* blk = choice->csr_blocks[0];
+        const int s = sqrtpc;
+        const int ddst = pMod(grid->rankInCol + 1, s), dsrc = pMod(grid->rankInCol - 1, s);
+        const int ssrc = pMod(grid->rankInRow - 1, s), sdst = pMod(grid->rankInRow + 1, s);
+        const KernelMode kmode = (mode == k_spmmA) ? k_spmmB : mode;
+        if (s > 1) order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);
 
-        for (int i = 0; i < sqrtpc; i++) {
-            auto t = start_clock();
-            kernel->triple_function(mode == k_spmmA ? k_spmmB : mode, *choice, stationary, *bBuf.getActive(), 0, localAcols * grid->j);
-            stop_clock_and_add(t, "Computation Time");
-            if (sqrtpc > 1) {
-                // SDDMM writes the sparse values and SpMM writes the moving dense operand, so both rings
-                // follow this step's kernel; they run back to back on the communication stream.
-                t = start_clock();
-                order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);
-                world->group_begin();  // dense (grid column) and sparse (grid row) rings use different xGMI links: one group
-                shiftDenseMatrix(bBuf, grid->col_world, pMod(grid->rankInCol + 1, sqrtpc), pMod(grid->rankInCol - 1, sqrtpc),
-                                 HNH_STREAM_COMM);
-                stop_clock_and_add(t, "Dense Cyclic Shift Time");
-                t = start_clock();
-                const int src = pMod(grid->rankInRow - 1, sqrtpc), dst = pMod(grid->rankInRow + 1, sqrtpc);
-                blk->shiftCSR(src, dst, grid->row_world, (*nnz_in_axis)[pMod(sparse_shift - i - 1, sqrtpc)], 72, is_sddmm ? coo : csr,
-                              HNH_STREAM_COMM, pMod(sparse_shift - i - 1, sqrtpc));
-                choice->blockStarts[1] = blk->num_coords;
-                world->group_end();
-                order(HNH_STREAM_COMM, HNH_STREAM_COMPUTE, 1);
-                stop_clock_and_add(t, "Sparse Cyclic Shift Time");
+        // Each step moves two things: the dense operand down its grid column and the sparse block along its grid row.
+        // Whatever the kernel only READS can travel while the kernel runs; whatever it WRITES has to wait for it:
+        //   SDDMM writes the sparse values  -> dense shift overlaps the kernel (triple buffered, caller's matrix
+        //                                      untouched, s-1 shifts), sparse shift follows it;
+        //   SpMM  writes the dense operand  -> sparse shift overlaps the kernel (double buffered), dense shift follows it.
+        if (is_sddmm) {
+            if (s > 1)
+                for (auto& sp : dense_spare)
+                    if (sp.rows() != Brole->rows() || sp.cols() != Brole->cols()) sp = DenseMatrix(Brole->rows(), Brole->cols());
+            const size_t bytes = (size_t)Brole->size() * sizeof(double);
+            DenseMatrix* cur = Brole;
+            for (int i = 0; i < s; i++) {
+                auto t = start_clock();
+                if (i > 0) world->event_wait(event(1 + (i - 1) % 2), HNH_STREAM_COMPUTE);  // both shifts of step i-1 landed
+                kernel->triple_function(kmode, *choice, stationary, *cur, 0, localAcols * grid->j);
+                stop_clock_and_add(t, "Computation Time");
+                if (s > 1) {
+                    t = start_clock();
+                    world->event_record(event(3 + i % 2), HNH_STREAM_COMPUTE);
+                    if (i < s - 1) {
+                        DenseMatrix* target = &dense_spare[i % 2];
+                        if (i >= 2) world->event_wait(event(3 + (i - 1) % 2), HNH_STREAM_COMM);  // kernel i-1 last read `target`
+                        world->sendrecv(grid->col_world, cur->data(), bytes, ddst, target->data(), bytes, dsrc, HNH_STREAM_COMM);
+                        cur = target;
+                    }
+                    stop_clock_and_add(t, "Dense Cyclic Shift Time");
+                    t = start_clock();
+                    world->event_wait(event(3 + i % 2), HNH_STREAM_COMM);  // kernel i wrote the travelling values
+                    blk->shiftCSR(ssrc, sdst, grid->row_world, (*nnz_in_axis)[pMod(sparse_shift - i - 1, s)], 72, coo, HNH_STREAM_COMM,
+                                  pMod(sparse_shift - i - 1, s));
+                    choice->blockStarts[1] = blk->num_coords;
+                    world->event_record(event(1 + i % 2), HNH_STREAM_COMM);
+                    stop_clock_and_add(t, "Sparse Cyclic Shift Time");
+                }
             }
+            if (s > 1) world->event_wait(event(1 + (s - 1) % 2), HNH_STREAM_COMPUTE);  // the sparse block is home again
+        } else {
+            hnh::BufferPair bBuf(Brole, &ring_spare);
+            for (int i = 0; i < s; i++) {
+                auto t = start_clock();
+                if (i > 0) world->event_wait(event(1 + (i - 1) % 2), HNH_STREAM_COMPUTE);
+                kernel->triple_function(kmode, *choice, stationary, *bBuf.getActive(), 0, localAcols * grid->j);
+                stop_clock_and_add(t, "Computation Time");
+                if (s > 1) {
+                    t = start_clock();
+                    world->event_record(event(3 + i % 2), HNH_STREAM_COMPUTE);
+                    if (i >= 1) world->event_wait(event(3 + (i - 1) % 2), HNH_STREAM_COMM);  // kernel i-1 released the passive sparse buffer
+                    blk->shiftCSR(ssrc, sdst, grid->row_world, (*nnz_in_axis)[pMod(sparse_shift - i - 1, s)], 72, csr, HNH_STREAM_COMM,
+                                  pMod(sparse_shift - i - 1, s));
+                    choice->blockStarts[1] = blk->num_coords;
+                    stop_clock_and_add(t, "Sparse Cyclic Shift Time");
+                    t = start_clock();
+                    world->event_wait(event(3 + i % 2), HNH_STREAM_COMM);  // kernel i wrote the moving dense operand
+                    shiftDenseMatrix(bBuf, grid->col_world, ddst, dsrc, HNH_STREAM_COMM);
+                    world->event_record(event(1 + i % 2), HNH_STREAM_COMM);
+                    stop_clock_and_add(t, "Dense Cyclic Shift Time");
+                }
+            }
+            if (s > 1) world->event_wait(event(1 + (s - 1) % 2), HNH_STREAM_COMPUTE);
+            bBuf.sync_active();
         }
-        bBuf.sync_active();
 
         auto t = start_clock();
         if (is_sddmm) choice->hadamardWithCSRValues(SValues, *sddmm_result_ptr);
