@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("HNH_KERNEL_LIB_DEV") or os.path.join(HERE, "lib", "li
 OK = 0
 STREAM_COMPUTE, STREAM_COMM = 0, 1
 H2D, D2H, D2D = 0, 1, 2
-FUSED_VALUES_OVERWRITE, FUSED_OUT_OVERWRITE = 1, 2
+FUSED_VALUES_OVERWRITE, FUSED_OUT_OVERWRITE, FUSED_LEAKY_RELU = 1, 2, 4
 UNIQUE_ID_BYTES = 128
 
 _vp, _i32, _i64, _dbl, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
@@ -45,6 +45,10 @@ SIGNATURES = {
     "hnh_fused_sddmm_spmm_csr_ex": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _i64, _i32, _i32]),
     "hnh_csr_max_row_nnz": (_i32, [_vp, _i64, _vp, C.POINTER(C.c_int), _i32]),
     "hnh_fused_sddmm_spmm_csr_multi": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, C.c_uint, _i32]),
+    "hnh_fused_sddmm_spmm_csr_x": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _i64, _i32, _vp, _i32]),
+    "hnh_fused_sddmm_spmm_csr_multi_x": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, C.c_uint, _vp, _i32]),
+    "hnh_row_epilogue_f64": (_i32, [_vp, _vp, _vp, C.c_double, _vp, _i64, _i32, _i32]),
+    "hnh_cg_step_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "hnh_fill_f64": (_i32, [_vp, _vp, _i64, _dbl, _i32]),
     "hnh_hadamard_f64": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32]),
     "hnh_axpy_f64": (_i32, [_vp, _vp, _vp, _dbl, _i64, _i32]),
@@ -68,6 +72,11 @@ SIGNATURES = {
     "hnh_comm_reduce_scatter_f64": (_i32, [_vp, _vp, _vp, _vp, _sz, _i32]),
     "hnh_comm_allreduce_f64": (_i32, [_vp, _vp, _vp, _vp, _sz, _i32]),
 }
+
+class FusedExtras(C.Structure):
+    """struct hnh_fused_extras"""
+    _fields_ = [("leaky_alpha", C.c_double), ("x_scale", C.c_double), ("rowdot", C.c_void_p)]
+
 
 class CsrBlock(C.Structure):
     """struct hnh_csr_block"""

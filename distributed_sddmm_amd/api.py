@@ -99,6 +99,7 @@ SIGNATURES = {
     "hnh_dist_spmmB": (_i32, [_vp, _vp, _vp, _vp]),
     "hnh_dist_fusedSpMM": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32]),
     "hnh_dist_algorithm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32]),
+    "hnh_dist_fusedSpMM_out": (_i32, [_vp, _vp, _vp, _i32, _vp, _i32, C.c_double, C.c_double, _vp, C.POINTER(C.c_int)]),
     "hnh_als_create": (_i32, [_vp, _i32, _u64, _pvp]),
     "hnh_als_destroy": (_i32, [_vp]),
     "hnh_als_set_ground_truth": (_i32, [_vp, _vp, _vp]),
@@ -477,6 +478,13 @@ class DistributedSparse:
 
     def fusedSpMM(self, a, b, s, buf, matmode: int):
         _check(lib().hnh_dist_fusedSpMM(self.h, a.h, b.h, s.h, buf.h, matmode), "fusedSpMM")
+
+    def fusedSpMM_out(self, a, b, matmode: int, out, leaky_alpha=None, x_scale: float = 0.0, rowdot=None) -> bool:
+        """Distributed_Sparse::fusedSpMM_out; False (nothing done) when the schedule has no single fused pass."""
+        ok = C.c_int(0)
+        _check(lib().hnh_dist_fusedSpMM_out(self.h, a.h, b.h, matmode, out.h, int(leaky_alpha is not None), float(leaky_alpha or 0.0),
+                                            float(x_scale), rowdot.h if rowdot else None, C.byref(ok)), "fusedSpMM_out")
+        return bool(ok.value)
 
     def algorithm(self, a, b, s, result, mode: int, initial_replicate: bool):
         _check(lib().hnh_dist_algorithm(self.h, a.h, b.h, s.h, result.h if result else None, mode, int(initial_replicate)), "algorithm")

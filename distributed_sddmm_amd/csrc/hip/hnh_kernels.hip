@@ -130,12 +130,27 @@ enum class Op { kSddmm, kSpmm, kFused };
 constexpr int kLongRow = 1024;
 constexpr int kLongSeg = 256;
 constexpr unsigned kInternalSplitLong = 0x100u;  // flag bit, never set by callers
+constexpr unsigned kInternalEpilogue = 0x200u;   // flag bit: apply Extras::x_scale / rowdot when the output row is stored
+
+// Optional extras of the fused pass (hnh_fused_extras): an activation between the two halves and a row epilogue.
+struct Extras {
+    double leaky_alpha = 0.0;  // HNH_FUSED_LEAKY_RELU: weight = dot > 0 ? dot : leaky_alpha * dot
+    double x_scale = 0.0;      // epilogue: Out[i,:] += x_scale * X[i,:]
+    double* rowdot = nullptr;  // epilogue: rowdot[i] = <X[i,:], Out[i,:]>
+};
+
+template <int LPR>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+    for (int m = LPR / 2; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
+    return v;
+}
 
 template <Op OP, int LPR, int VEC, int W, bool EXACT>
 __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool atomic_out, const int32_t* __restrict__ colidx,
                                             double* values, const double* __restrict__ svalues, const double* __restrict__ X,
                                             const double* __restrict__ Y, double* __restrict__ Out, int64_t ld, int col0,
-                                            int ncols, unsigned flags, int lig) {
+                                            int ncols, unsigned flags, int lig, const Extras& ex) {
     constexpr int U = Unroll<LPR, VEC>::value;
     constexpr int SUB = LPR / U;  // lanes that end up holding the same reduced value
     bool act[VEC];
@@ -200,8 +215,14 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
             if (mine < end) {
                 const bool overwrite = (OP == Op::kFused) && (flags & HNH_FUSED_VALUES_OVERWRITE);
                 if (!overwrite) wgt += values[mine];
-                if (lig % SUB == 0) values[mine] = wgt;
-                if (OP == Op::kFused && svalues != nullptr) wgt *= svalues[mine];
+                if (OP == Op::kFused && (flags & HNH_FUSED_LEAKY_RELU)) {  // the activated weight is what gets stored
+                    if (svalues != nullptr) wgt *= svalues[mine];
+                    wgt = wgt > 0.0 ? wgt : ex.leaky_alpha * wgt;
+                    if (lig % SUB == 0) values[mine] = wgt;
+                } else {
+                    if (lig % SUB == 0) values[mine] = wgt;
+                    if (OP == Op::kFused && svalues != nullptr) wgt *= svalues[mine];
+                }
             } else {
                 wgt = 0.0;
             }
@@ -220,6 +241,20 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
     }
 
     if constexpr (OP != Op::kSddmm) {
+        if (OP == Op::kFused && (flags & kInternalEpilogue) && !atomic_out) {  // the row is complete in this launch
+            double part = 0.0;
+#pragma unroll
+            for (int v = 0; v < VEC; v++)
+#pragma unroll
+                for (int w = 0; w < W; w++) {
+                    acc[v][w] = fma(ex.x_scale, x[v][w], acc[v][w]);
+                    part = fma(x[v][w], acc[v][w], part);
+                }
+            if (ex.rowdot != nullptr) {
+                part = group_sum<LPR>(part);
+                if (lig == 0) ex.rowdot[row] = part;
+            }
+        }
 #pragma unroll
         for (int v = 0; v < VEC; v++) {
             if (!act[v]) continue;
@@ -239,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void row_kernel(int64_t rows, const int32_t
                                                      const double* __restrict__ svalues,
                                                      const double* __restrict__ X, const double* __restrict__ Y,
                                                      double* __restrict__ Out, int64_t ld, int col0, int ncols,
-                                                     unsigned flags) {
+                                                     unsigned flags, Extras ex) {
     constexpr int GROUPS = kBlock / LPR;
     const int tid = threadIdx.x;
     const int lig = tid % LPR;
@@ -259,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void row_kernel(int64_t rows, const int32_t
         if (OP != Op::kSddmm && (flags & HNH_FUSED_OUT_OVERWRITE)) end = beg;
         else return;
     }
-    process_row<OP, LPR, VEC, W, EXACT>(row, beg, end, false, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, lig);
+    process_row<OP, LPR, VEC, W, EXACT>(row, beg, end, false, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, lig, ex);
 }
 
 // ---------------------------------------------------------------- fused pass over SEVERAL blocks of one block row
@@ -277,7 +312,8 @@ struct MultiBlocks {
 
 template <int LPR, int VEC, int W, bool EXACT>
 __global__ __launch_bounds__(kBlock) void fused_multi_kernel(int64_t rows, MultiBlocks mb, const double* __restrict__ X,
-                                                             double* __restrict__ Out, int64_t ld, int ncols, unsigned flags) {
+                                                             double* __restrict__ Out, int64_t ld, int ncols, unsigned flags,
+                                                             Extras ex) {
     constexpr int U = Unroll<LPR, VEC>::value;
     constexpr int SUB = LPR / U;
     constexpr int GROUPS = kBlock / LPR;
@@ -340,6 +376,7 @@ __global__ __launch_bounds__(kBlock) void fused_multi_kernel(int64_t rows, Multi
             const int mine = e + lig / SUB;
             if (mine < end) {
                 if (!(flags & HNH_FUSED_VALUES_OVERWRITE)) wgt += values[mine];
+                if (flags & HNH_FUSED_LEAKY_RELU) wgt = wgt > 0.0 ? wgt : ex.leaky_alpha * wgt;
                 if (lig % SUB == 0) values[mine] = wgt;
             } else {
                 wgt = 0.0;
@@ -354,6 +391,20 @@ __global__ __launch_bounds__(kBlock) void fused_multi_kernel(int64_t rows, Multi
             }
         }
     }
+    if (flags & kInternalEpilogue) {
+        double part = 0.0;
+#pragma unroll
+        for (int v = 0; v < VEC; v++)
+#pragma unroll
+            for (int w = 0; w < W; w++) {
+                acc[v][w] = fma(ex.x_scale, x[v][w], acc[v][w]);
+                part = fma(x[v][w], acc[v][w], part);
+            }
+        if (ex.rowdot != nullptr) {
+            part = group_sum<LPR>(part);
+            if (lig == 0) ex.rowdot[row] = part;
+        }
+    }
 #pragma unroll
     for (int v = 0; v < VEC; v++)
         if (act[v]) store_w<W>(Out + row * ld + coff[v], acc[v]);
@@ -366,7 +417,7 @@ __global__ __launch_bounds__(kBlock) void long_row_kernel(const int2* __restrict
                                                           const int32_t* __restrict__ colidx, double* values,
                                                           const double* __restrict__ svalues, const double* __restrict__ X,
                                                           const double* __restrict__ Y, double* __restrict__ Out, int64_t ld,
-                                                          int col0, int ncols, unsigned flags) {
+                                                          int col0, int ncols, unsigned flags, Extras ex) {
     constexpr int GROUPS = kBlock / LPR;
     const int tid = threadIdx.x;
     const int lig = tid % LPR;
@@ -379,7 +430,7 @@ __global__ __launch_bounds__(kBlock) void long_row_kernel(const int2* __restrict
         const int rbeg = rowptr[row], rend = rowptr[row + 1];
         const int beg = rbeg + item.y * kLongSeg;
         const int end = (beg + kLongSeg < rend) ? beg + kLongSeg : rend;
-        process_row<OP, LPR, VEC, W, EXACT>(row, beg, end, true, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, lig);
+        process_row<OP, LPR, VEC, W, EXACT>(row, beg, end, true, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, lig, ex);
     }
 }
 
@@ -559,6 +610,64 @@ __global__ __launch_bounds__(kBlock) void rowdot_kernel(const double* __restrict
 #pragma unroll
     for (int m = LPR / 2; m >= 1; m >>= 1) s += shfl_xor_f64(s, m);
     if (lig == 0) out[row] = s;
+}
+
+// Out[i,:] += x_scale * X[i,:];  rowdot[i] = <X[i,:], Out[i,:]>  — the fused pass's row epilogue as its own launch
+template <int LPR, int W>
+__global__ __launch_bounds__(kBlock) void row_epilogue_kernel(double* __restrict__ Out, const double* __restrict__ X, double x_scale,
+                                                              double* __restrict__ rowdot, int64_t rows, int R) {
+    constexpr int GROUPS = kBlock / LPR;
+    const int lig = threadIdx.x % LPR;
+    const int64_t row = (int64_t)blockIdx.x * GROUPS + threadIdx.x / LPR;
+    if (row >= rows) return;
+    double* o = Out + row * R;
+    const double* xr = X + row * R;
+    double s = 0.0;
+    for (int c = lig * W; c < R; c += LPR * W) {
+        double x[W], y[W];
+        load_w<W>(x, xr + c);
+        load_w<W>(y, o + c);
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            y[w] = fma(x_scale, x[w], y[w]);
+            s = fma(x[w], y[w], s);
+        }
+        if (x_scale != 0.0) store_w<W>(o + c, y);
+    }
+    s = group_sum<LPR>(s);
+    if (lig == 0 && rowdot != nullptr) rowdot[row] = s;
+}
+
+// One CG update (als_conjugate_gradients.cpp:117-127):  X[i,:] += alpha[i] P[i,:];  Rm[i,:] -= alpha[i] MP[i,:];
+// rsnew[i] = <Rm[i,:], Rm[i,:]>  — three dense passes of the reference in one
+template <int LPR, int W>
+__global__ __launch_bounds__(kBlock) void cg_step_kernel(double* __restrict__ X, double* __restrict__ Rm, const double* __restrict__ P,
+                                                         const double* __restrict__ MP, const double* __restrict__ alpha,
+                                                         double* __restrict__ rsnew, int64_t rows, int R) {
+    constexpr int GROUPS = kBlock / LPR;
+    const int lig = threadIdx.x % LPR;
+    const int64_t row = (int64_t)blockIdx.x * GROUPS + threadIdx.x / LPR;
+    if (row >= rows) return;
+    const double a = alpha[row];
+    const int64_t base = row * R;
+    double s = 0.0;
+    for (int c = lig * W; c < R; c += LPR * W) {
+        double x[W], r[W], p[W], mp[W];
+        load_w<W>(x, X + base + c);
+        load_w<W>(r, Rm + base + c);
+        load_w<W>(p, P + base + c);
+        load_w<W>(mp, MP + base + c);
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            x[w] = x[w] + a * p[w];
+            r[w] = r[w] - a * mp[w];
+            s = fma(r[w], r[w], s);
+        }
+        store_w<W>(X + base + c, x);
+        store_w<W>(Rm + base + c, r);
+    }
+    s = group_sum<LPR>(s);
+    if (lig == 0) rsnew[row] = s;
 }
 
 // Y[i,:] = ya * yv[i] * Y[i,:] + xa * xv[i] * X[i,:]   (null vector = ones); kEwUnroll chunks in flight per thread
@@ -758,19 +867,19 @@ int prepare_long(hnh_ctx* ctx, hipStream_t st, int sidx, int64_t rows, const int
 template <Op OP, int LPR, int VEC, int W, bool EXACT>
 int launch_row(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, int64_t rows, const int32_t* rowptr, const int32_t* colidx,
                double* values, const double* svalues, const double* X, const double* Y, double* Out, int64_t ld,
-               int col0, int ncols, unsigned flags) {
+               int col0, int ncols, unsigned flags, const Extras& ex) {
     constexpr int GROUPS = kBlock / LPR;
     const int64_t blocks = (rows + GROUPS - 1) / GROUPS;
     if (blocks <= 0) return HNH_OK;
     if (blocks > 0x7fffffffLL) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "too many rows for one launch");
     if (lc.enabled) flags |= kInternalSplitLong;
     hipLaunchKernelGGL((row_kernel<OP, LPR, VEC, W, EXACT>), dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, rowptr,
-                       colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags);
+                       colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, ex);
     if (int rc = hnh::check_hip(ctx, hipGetLastError(), "row_kernel launch")) return rc;
     if (lc.enabled) {
         // 256 CUs x 4 resident workgroups; items are spread round-robin over all groups of the grid
         hipLaunchKernelGGL((long_row_kernel<OP, LPR, VEC, W, EXACT>), dim3(1024), dim3(kBlock), 0, st, lc.items, lc.count,
-                           lc.capacity, rowptr, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags);
+                           lc.capacity, rowptr, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, ex);
         return hnh::check_hip(ctx, hipGetLastError(), "long_row_kernel launch");
     }
     return HNH_OK;
@@ -779,12 +888,18 @@ int launch_row(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, int64_t rows, co
 template <Op OP>
 int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t rows, int64_t nnz, int max_row_nnz,
                  const int32_t* rowptr, const int32_t* colidx, double* values, const double* svalues, const double* X,
-                 const double* Y, double* Out, int R, unsigned flags) {
+                 const double* Y, double* Out, int R, unsigned flags, const Extras& ex = Extras(), bool* epilogue_done = nullptr) {
     LongCtl lc;
     if (int rc = prepare_long(ctx, st, sidx, rows, rowptr, nnz, max_row_nnz, &lc)) return rc;
+    // the row epilogue runs inside the launch only when every output row is completed by ONE group (no hub-row
+    // segments adding atomically afterwards, no column tiles); otherwise the caller appends row_epilogue_kernel
+    if (epilogue_done != nullptr) {
+        *epilogue_done = !lc.enabled && (s.exact || R <= 64 * s.w * 4);
+        if (*epilogue_done) flags |= kInternalEpilogue;
+    }
 #define HNH_CASE(L, V)                                                                                         \
     if (s.lpr == L && s.vec == V)                                                                              \
-        return launch_row<OP, L, V, 2, true>(ctx, st, lc, rows, rowptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags);
+        return launch_row<OP, L, V, 2, true>(ctx, st, lc, rows, rowptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags, ex);
     if (s.exact) {
         HNH_CASE(1, 1) HNH_CASE(2, 1) HNH_CASE(4, 1) HNH_CASE(8, 1) HNH_CASE(16, 1) HNH_CASE(32, 1) HNH_CASE(64, 1)
         HNH_CASE(64, 2) HNH_CASE(64, 3) HNH_CASE(64, 4) HNH_CASE(32, 3) HNH_CASE(32, 5) HNH_CASE(32, 7)
@@ -795,7 +910,7 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
     // instance (R <= 512 even / 256 odd) ...
 #define HNH_NX(V, WW)                                                                                              \
     if (s.w == WW && R <= 64 * WW * V)                                                                             \
-        return launch_row<OP, 64, V, WW, false>(ctx, st, lc, rows, rowptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags);
+        return launch_row<OP, 64, V, WW, false>(ctx, st, lc, rows, rowptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags, ex);
     HNH_NX(1, 2) HNH_NX(2, 2) HNH_NX(4, 2) HNH_NX(1, 1) HNH_NX(2, 1) HNH_NX(4, 1)
 #undef HNH_NX
     // ... else column tiles; SDDMM partial dot products accumulate into `values` tile by tile
@@ -805,9 +920,9 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
         const int ncols = (R - col0 < tile) ? (R - col0) : tile;
         int rc;
         if (s.w == 2)
-            rc = launch_row<OP, 64, 1, 2, false>(ctx, st, lc, rows, rowptr, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags);
+            rc = launch_row<OP, 64, 1, 2, false>(ctx, st, lc, rows, rowptr, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags, ex);
         else
-            rc = launch_row<OP, 64, 1, 1, false>(ctx, st, lc, rows, rowptr, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags);
+            rc = launch_row<OP, 64, 1, 1, false>(ctx, st, lc, rows, rowptr, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags, ex);
         if (rc != HNH_OK) return rc;
     }
     return HNH_OK;
@@ -878,19 +993,67 @@ int hnh_fused_sddmm_spmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, 
 int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
                                 const double* svalues, const double* X, const double* Y, double* Out, int R,
                                 unsigned flags, int64_t nnz_in, int max_row_nnz, int stream) {
+    return hnh_fused_sddmm_spmm_csr_x(ctx, rows, rowptr, col_idx, values, svalues, X, Y, Out, R, flags, nnz_in, max_row_nnz, nullptr, stream);
+}
+
+}  // extern "C"
+
+namespace {
+// the row epilogue as its own launch (hub rows / column tiles / several launches per output row)
+int launch_row_epilogue(hnh_ctx* ctx, hipStream_t st, double* Out, const double* X, double x_scale, double* rowdot, int64_t rows, int R) {
+    if (rows == 0 || (x_scale == 0.0 && rowdot == nullptr)) return HNH_OK;
+    const bool w2 = (R % 2 == 0) && aligned16(Out) && aligned16(X);
+    const int chunks = w2 ? R / 2 : R;
+#define HNH_EP(L)                                                                                                          \
+    {                                                                                                                      \
+        const int64_t blocks = (rows + (kBlock / L) - 1) / (kBlock / L);                                                   \
+        if (w2) hipLaunchKernelGGL((row_epilogue_kernel<L, 2>), dim3((unsigned)blocks), dim3(kBlock), 0, st, Out, X, x_scale, rowdot, rows, R); \
+        else hipLaunchKernelGGL((row_epilogue_kernel<L, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, Out, X, x_scale, rowdot, rows, R);   \
+    }
+    if (chunks >= 64) HNH_EP(64) else if (chunks >= 16) HNH_EP(16) else if (chunks >= 4) HNH_EP(4) else HNH_EP(1)
+#undef HNH_EP
+    return hnh::check_hip(ctx, hipGetLastError(), "row_epilogue_kernel launch");
+}
+
+int check_extras(hnh_ctx* ctx, unsigned flags, const hnh_fused_extras* extras, Extras* ex, bool* want_epilogue, const char* who) {
+    if (flags & ~(HNH_FUSED_VALUES_OVERWRITE | HNH_FUSED_OUT_OVERWRITE | HNH_FUSED_LEAKY_RELU))
+        return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": unknown flag");
+    if ((flags & HNH_FUSED_LEAKY_RELU) && !extras)
+        return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": HNH_FUSED_LEAKY_RELU needs extras->leaky_alpha");
+    if (extras) {
+        ex->leaky_alpha = extras->leaky_alpha;
+        ex->x_scale = extras->x_scale;
+        ex->rowdot = extras->rowdot;
+    }
+    *want_epilogue = extras && (extras->x_scale != 0.0 || extras->rowdot != nullptr);
+    return HNH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
+                               const double* svalues, const double* X, const double* Y, double* Out, int R, unsigned flags,
+                               int64_t nnz_in, int max_row_nnz, const hnh_fused_extras* extras, int stream) {
     HNH_ENTER(ctx, stream);
     if (int rc = check_common(ctx, rows, R, "hnh_fused_sddmm_spmm_csr")) return rc;
+    Extras ex;
+    bool want_epilogue = false;
+    if (int rc = check_extras(ctx, flags, extras, &ex, &want_epilogue, "hnh_fused_sddmm_spmm_csr")) return rc;
     if (rows == 0) return HNH_OK;
     if (!rowptr || !col_idx || !values || !X || !Y || !Out)
         return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr: null pointer");
     if (X == Out || Y == Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr: Out aliases an input");
-    if (flags & ~(HNH_FUSED_VALUES_OVERWRITE | HNH_FUSED_OUT_OVERWRITE))
-        return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr: unknown flag");
     hipStream_t st = ctx->streams[stream];
     const Shape s = pick_shape(R, aligned16(X) && aligned16(Y) && aligned16(Out));
-    if (s.exact || R <= 256 * s.w)  // one pass: an exact instance, or a bounds-checked one wide enough for the whole row
-        return dispatch_row<Op::kFused>(ctx, st, stream, s, rows, nnz_in, max_row_nnz, rowptr, col_idx, values, svalues, X, Y, Out, R,
-                                        flags);
+    if (s.exact || R <= 256 * s.w) {  // one pass: an exact instance, or a bounds-checked one wide enough for the whole row
+        bool done = false;
+        if (int rc = dispatch_row<Op::kFused>(ctx, st, stream, s, rows, nnz_in, max_row_nnz, rowptr, col_idx, values, svalues, X, Y, Out, R,
+                                              flags, ex, want_epilogue ? &done : nullptr))
+            return rc;
+        if (want_epilogue && !done) return launch_row_epilogue(ctx, st, Out, X, ex.x_scale, ex.rowdot, rows, R);
+        return HNH_OK;
+    }
     // Tiled fallback (R odd or not a supported multiple): the dot product needs the whole row before the
     // axpy can start, so compose the two column-tiled passes; same arithmetic, one extra gather.
     int64_t nnz = nnz_in;
@@ -904,17 +1067,68 @@ int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowpt
     if (flags & HNH_FUSED_OUT_OVERWRITE) HNH_TRY_HIP(ctx, hipMemsetAsync(Out, 0, sizeof(double) * (size_t)rows * R, st));
     if (int rc = dispatch_row<Op::kSddmm>(ctx, st, stream, s, rows, nnz, max_row_nnz, rowptr, col_idx, values, nullptr, X, Y, nullptr, R, 0u))
         return rc;
-    return dispatch_row<Op::kSpmm>(ctx, st, stream, s, rows, nnz, max_row_nnz, rowptr, col_idx, values, svalues, Y, nullptr, Out, R, 0u);
+    if (flags & HNH_FUSED_LEAKY_RELU) {
+        if (svalues) {
+            hipLaunchKernelGGL(hadamard_kernel, dim3(ew_grid(nnz)), dim3(kBlock), 0, st, values, values, svalues, nnz, false);
+            svalues = nullptr;
+        }
+        hipLaunchKernelGGL(leaky_relu_kernel, dim3(ew_grid(nnz)), dim3(kBlock), 0, st, values, ex.leaky_alpha, nnz);
+        if (int rc = hnh::check_hip(ctx, hipGetLastError(), "leaky_relu_kernel launch")) return rc;
+    }
+    if (int rc = dispatch_row<Op::kSpmm>(ctx, st, stream, s, rows, nnz, max_row_nnz, rowptr, col_idx, values, svalues, Y, nullptr, Out, R, 0u))
+        return rc;
+    if (want_epilogue) return launch_row_epilogue(ctx, st, Out, X, ex.x_scale, ex.rowdot, rows, R);
+    return HNH_OK;
+}
+
+int hnh_row_epilogue_f64(hnh_ctx* ctx, double* Out, const double* X, double x_scale, double* rowdot, int64_t rows, int R, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (int rc = check_common(ctx, rows, R, "hnh_row_epilogue_f64")) return rc;
+    if (rows == 0) return HNH_OK;
+    if (!Out || !X || Out == X) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_row_epilogue_f64: bad operand");
+    return launch_row_epilogue(ctx, ctx->streams[stream], Out, X, x_scale, rowdot, rows, R);
+}
+
+int hnh_cg_step_f64(hnh_ctx* ctx, double* X, double* Rm, const double* P, const double* MP, const double* alpha, double* rsnew,
+                    int64_t rows, int R, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (int rc = check_common(ctx, rows, R, "hnh_cg_step_f64")) return rc;
+    if (rows == 0) return HNH_OK;
+    if (!X || !Rm || !P || !MP || !alpha || !rsnew) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_cg_step_f64: null pointer");
+    hipStream_t st = ctx->streams[stream];
+    const bool w2 = (R % 2 == 0) && aligned16(X) && aligned16(Rm) && aligned16(P) && aligned16(MP);
+    const int chunks = w2 ? R / 2 : R;
+#define HNH_CG(L)                                                                                                          \
+    {                                                                                                                      \
+        const int64_t blocks = (rows + (kBlock / L) - 1) / (kBlock / L);                                                   \
+        if (w2) hipLaunchKernelGGL((cg_step_kernel<L, 2>), dim3((unsigned)blocks), dim3(kBlock), 0, st, X, Rm, P, MP, alpha, rsnew, rows, R); \
+        else hipLaunchKernelGGL((cg_step_kernel<L, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, X, Rm, P, MP, alpha, rsnew, rows, R);   \
+    }
+    if (chunks >= 64) HNH_CG(64) else if (chunks >= 16) HNH_CG(16) else if (chunks >= 4) HNH_CG(4) else HNH_CG(1)
+#undef HNH_CG
+    return hnh::check_hip(ctx, hipGetLastError(), "cg_step_kernel launch");
 }
 
 int hnh_fused_sddmm_spmm_csr_multi(hnh_ctx* ctx, int64_t rows, int nblocks, const hnh_csr_block* blocks, const double* X, double* Out,
                                    int R, unsigned flags, int stream) {
+    return hnh_fused_sddmm_spmm_csr_multi_x(ctx, rows, nblocks, blocks, X, Out, R, flags, nullptr, stream);
+}
+
+int hnh_fused_sddmm_spmm_csr_multi_x(hnh_ctx* ctx, int64_t rows, int nblocks, const hnh_csr_block* blocks, const double* X, double* Out,
+                                     int R, unsigned flags, const hnh_fused_extras* extras, int stream) {
     HNH_ENTER(ctx, stream);
     if (int rc = check_common(ctx, rows, R, "hnh_fused_sddmm_spmm_csr_multi")) return rc;
     if (nblocks < 0 || (nblocks > 0 && !blocks)) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr_multi: bad block list");
-    if (flags & ~(HNH_FUSED_VALUES_OVERWRITE | HNH_FUSED_OUT_OVERWRITE))
-        return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr_multi: unknown flag");
-    if (rows == 0 || nblocks == 0) return HNH_OK;
+    Extras ex;
+    bool want_epilogue = false;
+    if (int rc = check_extras(ctx, flags, extras, &ex, &want_epilogue, "hnh_fused_sddmm_spmm_csr_multi")) return rc;
+    if (rows == 0) return HNH_OK;
+    if (nblocks == 0) {  // nothing to add; the epilogue still applies to the existing output rows
+        if (!want_epilogue) return HNH_OK;
+        if (!X || !Out || X == Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr_multi: bad operand");
+        if (flags & HNH_FUSED_OUT_OVERWRITE) HNH_TRY_HIP(ctx, hipMemsetAsync(Out, 0, sizeof(double) * (size_t)rows * R, ctx->streams[stream]));
+        return launch_row_epilogue(ctx, ctx->streams[stream], Out, X, ex.x_scale, ex.rowdot, rows, R);
+    }
     if (!X || !Out || X == Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr_multi: bad operand");
     bool vec_ok = aligned16(X) && aligned16(Out), simple = true;
     for (int b = 0; b < nblocks; b++) {
@@ -927,14 +1141,17 @@ int hnh_fused_sddmm_spmm_csr_multi(hnh_ctx* ctx, int64_t rows, int nblocks, cons
     const bool one_pass = s.exact || R <= 256 * s.w;
     hipStream_t st = ctx->streams[stream];
     if (!simple || !one_pass) {  // same arithmetic, block by block
+        hnh_fused_extras act_only = {ex.leaky_alpha, 0.0, nullptr};
         for (int b = 0; b < nblocks; b++) {
             const unsigned f = (b == 0) ? flags : (flags & ~HNH_FUSED_OUT_OVERWRITE);
-            if (int rc = hnh_fused_sddmm_spmm_csr_ex(ctx, rows, blocks[b].rowptr, blocks[b].col_idx, blocks[b].values, nullptr, X,
-                                                     blocks[b].Y, Out, R, f, blocks[b].nnz, blocks[b].max_row_nnz, stream))
+            if (int rc = hnh_fused_sddmm_spmm_csr_x(ctx, rows, blocks[b].rowptr, blocks[b].col_idx, blocks[b].values, nullptr, X,
+                                                    blocks[b].Y, Out, R, f, blocks[b].nnz, blocks[b].max_row_nnz, &act_only, stream))
                 return rc;
         }
+        if (want_epilogue) return launch_row_epilogue(ctx, st, Out, X, ex.x_scale, ex.rowdot, rows, R);
         return HNH_OK;
     }
+    const bool epilogue_inside = want_epilogue && nblocks <= kMaxMultiBlocks;  // one launch completes every output row
     for (int b0 = 0; b0 < nblocks; b0 += kMaxMultiBlocks) {
         MultiBlocks mb;
         mb.n = (nblocks - b0 < kMaxMultiBlocks) ? nblocks - b0 : kMaxMultiBlocks;
@@ -942,11 +1159,11 @@ int hnh_fused_sddmm_spmm_csr_multi(hnh_ctx* ctx, int64_t rows, int nblocks, cons
             mb.rowptr[b] = blocks[b0 + b].rowptr; mb.colidx[b] = blocks[b0 + b].col_idx;
             mb.values[b] = blocks[b0 + b].values; mb.Y[b] = blocks[b0 + b].Y;
         }
-        const unsigned f = (b0 == 0) ? flags : (flags & ~HNH_FUSED_OUT_OVERWRITE);
+        const unsigned f = ((b0 == 0) ? flags : (flags & ~HNH_FUSED_OUT_OVERWRITE)) | (epilogue_inside ? kInternalEpilogue : 0u);
 #define HNH_MULTI(L, V, WW, EX)                                                                                     \
     {                                                                                                               \
         const int64_t nb = (rows + (kBlock / L) - 1) / (kBlock / L);                                                \
-        hipLaunchKernelGGL((fused_multi_kernel<L, V, WW, EX>), dim3((unsigned)nb), dim3(kBlock), 0, st, rows, mb, X, Out, (int64_t)R, R, f); \
+        hipLaunchKernelGGL((fused_multi_kernel<L, V, WW, EX>), dim3((unsigned)nb), dim3(kBlock), 0, st, rows, mb, X, Out, (int64_t)R, R, f, ex); \
     }
         if (s.exact) {
             if (s.lpr == 64 && s.vec == 1) HNH_MULTI(64, 1, 2, true)
@@ -970,6 +1187,7 @@ int hnh_fused_sddmm_spmm_csr_multi(hnh_ctx* ctx, int64_t rows, int nblocks, cons
 #undef HNH_MULTI
         if (int rc = hnh::check_hip(ctx, hipGetLastError(), "fused_multi_kernel launch")) return rc;
     }
+    if (want_epilogue && !epilogue_inside) return launch_row_epilogue(ctx, st, Out, X, ex.x_scale, ex.rowdot, rows, R);
     return HNH_OK;
 }
 

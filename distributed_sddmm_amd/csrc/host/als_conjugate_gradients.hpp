@@ -3,9 +3,11 @@
 // Distributed_ALS (computeRHS, computeQueries, computeResidual, initializeEmbeddings).
 //
 // One CG iteration = one fusedSpMM (computeQueries, .cpp:265-301) + three row-wise dot products and three
-// row-scaled updates (.cpp:82-139).  All of it stays on the GPU: the row-wise helpers are HIP kernels behind
-// hnh_rowdot_f64 / hnh_row_scale_add_f64 / hnh_vec_* and the Allreduce of the R-split schedules
-// (.cpp:31-36) is an RCCL all-reduce on the schedule's R-split communicator.
+// row-scaled updates (.cpp:82-139).  All of it stays on the GPU, and the dense passes around the fused call are
+// folded together: `+ lambda x` and <p, Mp> ride in the fused kernel's row epilogue where the schedule has a single
+// fused pass (Distributed_Sparse::fusedSpMM_out; otherwise one hnh_row_epilogue_f64 launch), and x += alpha p,
+// r -= alpha Mp, <r, r> are one launch (hnh_cg_step_f64) — 17 matrix-sized HBM passes per iteration become 9.  The
+// Allreduce of the R-split schedules (.cpp:31-36) is an RCCL all-reduce on the schedule's R-split communicator.
 //
 // Differences, deliberate: the reference initialises embeddings and the artificial ground truth with
 // Eigen's setRandom() on LOCAL buffers (.cpp:143-146), which makes results depend on the distribution; here
@@ -25,6 +27,14 @@ public:
 
     virtual void computeRHS(MatMode matrix_to_optimize, DenseMatrix& rhs) = 0;
     virtual void computeQueries(DenseMatrix& A, DenseMatrix& B, MatMode matrix_to_optimize, DenseMatrix& result) = 0;
+    // computeQueries plus dot[i] = <x[i,:], result[i,:]> with x the operand being optimised (the pair the CG loop
+    // always issues together, als_conjugate_gradients.cpp:89-93); subclasses may produce both in one pass
+    virtual void computeQueriesDot(DenseMatrix& A, DenseMatrix& B, MatMode matrix_to_optimize, DenseMatrix& result, VectorXd& dot) {
+        computeQueries(A, B, matrix_to_optimize, result);
+        DenseMatrix& x = (matrix_to_optimize == Amat) ? A : B;
+        hnh::World* w = d_ops->world;
+        w->check(w->be->hnh_rowdot_f64(w->ctx, x.data(), result.data(), dot.data(), x.rows(), (int)x.cols(), HNH_STREAM_COMPUTE), "hnh_rowdot_f64");
+    }
     virtual double computeResidual() = 0;
     virtual void initializeEmbeddings() = 0;
     virtual ~ALS_CG() {}
@@ -67,10 +77,8 @@ public:
         if (d_ops->r_split) allreduceVector(rsold, reduction_world);
 
         for (int cg_iter = 0; cg_iter < cg_max_iter; cg_iter++) {
-            if (matrix_to_optimize == Amat) computeQueries(p, B, Amat, Mp);
-            else computeQueries(A, p, Bmat, Mp);
-
-            rowdot(p, Mp, bdot);
+            if (matrix_to_optimize == Amat) computeQueriesDot(p, B, Amat, Mp, bdot);  // Mp and bdot = <p, Mp> row-wise
+            else computeQueriesDot(A, p, Bmat, Mp, bdot);
             if (d_ops->r_split) allreduceVector(bdot, reduction_world);
 
             // the reference adds the constant to BOTH vectors in place (.cpp:99-100); rsold keeps it
@@ -78,10 +86,9 @@ public:
             w->check(be->hnh_vec_add_scalar_f64(w->ctx, rsold.data(), nan_avoidance_constant, nrows, HNH_STREAM_COMPUTE), "vec_add");
             w->check(be->hnh_vec_div_f64(w->ctx, alpha.data(), rsold.data(), bdot.data(), nrows, HNH_STREAM_COMPUTE), "vec_div");
 
-            row_update(X, nullptr, 1.0, p, alpha.data(), 1.0);    // X += alpha .* p
-            row_update(r, nullptr, 1.0, Mp, alpha.data(), -1.0);  // r -= alpha .* Mp
-
-            rowdot(r, r, rsnew);
+            // X += alpha .* p;  r -= alpha .* Mp;  rsnew = <r, r> row-wise  (.cpp:117-127, one pass)
+            w->check(be->hnh_cg_step_f64(w->ctx, X.data(), r.data(), p.data(), Mp.data(), alpha.data(), rsnew.data(), nrows, ncols,
+                                         HNH_STREAM_COMPUTE), "hnh_cg_step_f64");
             if (d_ops->r_split) allreduceVector(rsnew, reduction_world);
 
             w->check(be->hnh_vec_div_f64(w->ctx, coeffs.data(), rsnew.data(), rsold.data(), nrows, HNH_STREAM_COMPUTE), "vec_div");
@@ -164,8 +171,22 @@ public:
 
     // result = (S .* (X Y^T)|_S) Y + lambda X  with S == 1 (.cpp:265-301)
     void computeQueries(DenseMatrix& A_in, DenseMatrix& B_in, MatMode matrix_to_optimize, DenseMatrix& result) override {
+        queries(A_in, B_in, matrix_to_optimize, result, nullptr);
+    }
+    void computeQueriesDot(DenseMatrix& A_in, DenseMatrix& B_in, MatMode matrix_to_optimize, DenseMatrix& result, VectorXd& dot) override {
+        queries(A_in, B_in, matrix_to_optimize, result, &dot);
+    }
+
+    void queries(DenseMatrix& A_in, DenseMatrix& B_in, MatMode matrix_to_optimize, DenseMatrix& result, VectorXd* dot) {
         const double lambda = 1e-13;
         hnh::World* w = d_ops->world;
+        DenseMatrix& x = (matrix_to_optimize == Amat) ? A_in : B_in;
+        // Schedules with a single fused pass take the + lambda x and the row-wise <x, result> in the same launch and
+        // write `result` directly (no `result = x` copy); the 1.5D dense schedule's shifts are empty (.cpp:280,284).
+        if (result.rows() != x.rows() || result.cols() != x.cols()) result = DenseMatrix(x.rows(), x.cols());
+        hnh_fused_extras ex = {0.0, lambda, dot ? dot->data() : nullptr};
+        if (d_ops->fusedSpMM_out(A_in, B_in, matrix_to_optimize, result, false, ex)) return;
+
         // the all-ones S values and the SDDMM scratch vector are the same for every call: keep them
         // (the reference re-creates both per call, .cpp:276-277,289-290)
         if (matrix_to_optimize == Amat) {
@@ -175,8 +196,6 @@ public:
             d_ops->initial_shift(&result, &B_in, k_sddmmA);
             d_ops->fusedSpMM(result, B_in, ones, sddmm_result, Amat);
             d_ops->de_shift(&result, &B_in, k_sddmmA);
-            w->check(w->be->hnh_row_scale_add_f64(w->ctx, result.data(), nullptr, 1.0, A_in.data(), nullptr, lambda, result.rows(),
-                                                  (int)result.cols(), HNH_STREAM_COMPUTE), "hnh_row_scale_add_f64");
         } else {
             if (ones_ST.size() == 0) { ones_ST = d_ops->like_ST_values(1.0); scratch_ST = d_ops->like_ST_values(0.0); }
             VectorXd &ones = ones_ST, &sddmm_result = scratch_ST;
@@ -184,9 +203,9 @@ public:
             d_ops->initial_shift(&A_in, &result, k_sddmmB);
             d_ops->fusedSpMM(A_in, result, ones, sddmm_result, Bmat);
             d_ops->de_shift(&A_in, &result, k_sddmmB);
-            w->check(w->be->hnh_row_scale_add_f64(w->ctx, result.data(), nullptr, 1.0, B_in.data(), nullptr, lambda, result.rows(),
-                                                  (int)result.cols(), HNH_STREAM_COMPUTE), "hnh_row_scale_add_f64");
         }
+        w->check(w->be->hnh_row_epilogue_f64(w->ctx, result.data(), x.data(), lambda, dot ? dot->data() : nullptr, result.rows(),
+                                             (int)result.cols(), HNH_STREAM_COMPUTE), "hnh_row_epilogue_f64");
     }
 
     // uniform(-1, 1) * scale keyed by the GLOBAL (row, col) through the operator's submatrix descriptors; generated

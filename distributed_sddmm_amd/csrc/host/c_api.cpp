@@ -401,6 +401,14 @@ int hnh_dist_spmmB(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S) {
 int hnh_dist_fusedSpMM(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_vec* buf, int matmode) {
     return guarded(d->w, [&] { d->d->fusedSpMM(A->m, B->m, S->v, buf->v, matmode == HNH_AMAT ? Amat : Bmat); });
 }
+int hnh_dist_fusedSpMM_out(hnh_dist* d, hnh_dense* A, hnh_dense* B, int matmode, hnh_dense* Out, int leaky, double leaky_alpha,
+                           double x_scale, hnh_vec* rowdot, int* supported) {
+    return guarded(d->w, [&] {
+        hnh_fused_extras ex = {leaky_alpha, x_scale, rowdot ? rowdot->v.data() : nullptr};
+        const bool ok = d->d->fusedSpMM_out(A->m, B->m, matmode == HNH_AMAT ? Amat : Bmat, Out->m, leaky != 0, ex);
+        if (supported) *supported = ok ? 1 : 0;
+    });
+}
 int hnh_dist_algorithm(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_vec* result, int mode, int initial_replicate) {
     return guarded(d->w, [&] { d->d->algorithm(A->m, B->m, S->v, result ? &result->v : nullptr, kmode(mode), initial_replicate != 0); });
 }

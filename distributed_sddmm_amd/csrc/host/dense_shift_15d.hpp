@@ -131,12 +131,38 @@ public:
         }
         // NB: like the reference (15D_dense_shift.hpp:189,250-251) this path neither multiplies by Svalues
         // nor fills sddmm_buffer; it equals the generic path when Svalues == 1 (true in every app/benchmark).
-        DenseMatrix* Arole = (mode == Amat) ? &localA : &localB;
-        DenseMatrix* Brole = (mode == Amat) ? &localB : &localA;
-        SpmatLocal* choice = (mode == Amat) ? S.get() : ST.get();
-        const int n = p / c;
+        fused_pass(mode == Amat ? localA : localB, mode == Amat ? localB : localA, mode == Amat ? S.get() : ST.get(), nullptr, 0u, nullptr);
+    }
 
-        ensure(accumulation_buffer, Arole->rows() * c, R);
+    bool fusedSpMM_out(DenseMatrix& localA, DenseMatrix& localB, MatMode mode, DenseMatrix& Out, bool leaky,
+                       const hnh_fused_extras& extras) override {
+        if (fusionApproach != 2) return false;
+        DenseMatrix& Xin = (mode == Amat) ? localA : localB;
+        if (Out.rows() != Xin.rows() || Out.cols() != Xin.cols() || Out.data() == Xin.data())
+            hnh::fatal("Error, fusedSpMM_out needs a separate output of the input's shape!");
+        fused_pass(Xin, mode == Amat ? localB : localA, mode == Amat ? S.get() : ST.get(), &Out, leaky ? HNH_FUSED_LEAKY_RELU : 0u, &extras);
+        return true;
+    }
+
+private:
+    // One pass of shifts with the fused kernel on every visiting block.  target == nullptr: the result replaces
+    // Xin (the reference's in-place fusedSpMM); otherwise it is written to *target and Xin survives.
+    void fused_pass(DenseMatrix& Xin, DenseMatrix& moving, SpmatLocal* choice, DenseMatrix* target, unsigned act_flag,
+                    const hnh_fused_extras* extras) {
+        DenseMatrix* Arole = &Xin;
+        DenseMatrix* Brole = &moving;
+        const int n = p / c;
+        const bool epilogue = KernelImplementation::wants_epilogue(extras);
+        if (epilogue && target == nullptr) hnh::fatal("Error, a row epilogue needs the input rows: use fusedSpMM_out!");
+        hnh_fused_extras act_only = {extras ? extras->leaky_alpha : 0.0, 0.0, nullptr};
+        const hnh_fused_extras* act = act_flag ? &act_only : nullptr;
+        // c == 1: every output row is finished by this rank's own launches, so the last of them also runs the
+        // epilogue; c > 1: the partial outputs are reduce-scattered first
+        const hnh_fused_extras* last = (c == 1 && epilogue) ? extras : act;
+
+        // with c == 1 and a target the kernels accumulate straight into it
+        DenseMatrix* accum = (c == 1 && target != nullptr) ? target : &accumulation_buffer;
+        if (accum == &accumulation_buffer) ensure(accumulation_buffer, Arole->rows() * c, R);
         DenseMatrix* rowOperand = Arole;
         if (c > 1) {
             auto t = start_clock();
@@ -147,14 +173,14 @@ public:
             stop_clock_and_add(t, "Replication Time");
         }
 
+        const unsigned base = HNH_FUSED_VALUES_OVERWRITE | act_flag;
         bool out_fresh = true;
         if (ring_mode == kMeshFetch && n > 2) {
             // every remote block lands at once: local block while they fly, then ALL the others in one launch
             std::vector<DenseMatrix*> fetched = mesh_fetch_all(Brole, n);
             auto t = start_clock();
             if (choice->csr_blocks[block_at(0)] != nullptr) {
-                kernel->fused_local(*choice, *rowOperand, *Brole, accumulation_buffer, block_at(0),
-                                    HNH_FUSED_VALUES_OVERWRITE | HNH_FUSED_OUT_OVERWRITE);
+                kernel->fused_local(*choice, *rowOperand, *Brole, *accum, block_at(0), base | HNH_FUSED_OUT_OVERWRITE, act);
                 out_fresh = false;
             }
             world->event_wait(event(1), HNH_STREAM_COMPUTE);  // the remote blocks have landed
@@ -164,9 +190,8 @@ public:
                 ids.push_back(block_at(i));
                 any = any || choice->csr_blocks[block_at(i)] != nullptr;
             }
-            if (any) {
-                kernel->fused_multi_local(*choice, *rowOperand, fetched, accumulation_buffer, ids,
-                                          HNH_FUSED_VALUES_OVERWRITE | (out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u));
+            if (any || last != act) {
+                kernel->fused_multi_local(*choice, *rowOperand, fetched, *accum, ids, base | (out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u), last);
                 out_fresh = false;
             }
             stop_clock_and_add(t, "Computation Time");
@@ -174,22 +199,25 @@ public:
             ring_readonly(Brole, n, [&](int i, DenseMatrix& cur) {
                 auto t = start_clock();
                 const int block_id = block_at(i);
-                if (choice->csr_blocks[block_id] != nullptr) {
-                    unsigned flags = HNH_FUSED_VALUES_OVERWRITE | (out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u);
-                    kernel->fused_local(*choice, *rowOperand, cur, accumulation_buffer, block_id, flags);
+                const hnh_fused_extras* ex = (i == n - 1) ? last : act;
+                if (choice->csr_blocks[block_id] != nullptr || ex != act) {
+                    kernel->fused_local(*choice, *rowOperand, cur, *accum, block_id, base | (out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u), ex);
                     out_fresh = false;
                 }
                 stop_clock_and_add(t, "Computation Time");
             });
         }
-        if (out_fresh) accumulation_buffer.setZero();  // no block on this rank had a nonzero
+        if (out_fresh) accum->setZero();  // no block on this rank had a nonzero
 
         if (c > 1) {
             auto t = start_clock();
-            world->reduce_scatter_f64(grid->row_world, accumulation_buffer.data(), Arole->data(), (size_t)Arole->rows() * R,
-                                      HNH_STREAM_COMPUTE);
+            DenseMatrix* dest = target ? target : Arole;
+            world->reduce_scatter_f64(grid->row_world, accumulation_buffer.data(), dest->data(), (size_t)Arole->rows() * R, HNH_STREAM_COMPUTE);
             stop_clock_and_add(t, "Replication Time");
-        } else {
+            t = start_clock();
+            if (epilogue) KernelImplementation::row_epilogue(world, *Arole, *dest, extras);
+            stop_clock_and_add(t, "Computation Time");
+        } else if (target == nullptr) {
             auto t = start_clock();
             if (Arole->owns_storage()) Arole->swap(accumulation_buffer);  // `*Arole = accumulation_buffer` without the copy
             else *Arole = accumulation_buffer;
@@ -197,6 +225,7 @@ public:
         }
     }
 
+public:
     // SDDMM, SpMM with A as the output, or SpMM with B as the output (15D_dense_shift.hpp:276-384)
     void algorithm(DenseMatrix& localA, DenseMatrix& localB, VectorXd& SValues, VectorXd* sddmm_result_ptr, KernelMode mode,
                    bool initial_replicate) override {

@@ -204,6 +204,21 @@ public:
         }
     }
 
+    // Out-of-place fusedSpMM with the applications' surrounding work folded in (an addition; hnh_fused_extras in
+    // hnh_kernels.h).  With X = localA for Amat (localB for Bmat) and Y the other operand:
+    //     w_e        = <X[i_e,:], Y[j_e,:]>,  LeakyReLU'd when `leaky`                (gat.hpp:96-99)
+    //     Out[i,:]   = sum_e w_e Y[j_e,:]  +  extras.x_scale * X[i,:]                 (als_conjugate_gradients.cpp:282,295)
+    //     rowdot[i]  = <X[i,:], Out[i,:]>   when extras.rowdot != nullptr             (als_conjugate_gradients.cpp:93)
+    // X and Y are left untouched (the in-place fusedSpMM forces callers to copy X first).  Svalues are taken as 1
+    // and sddmm_buffer is not filled, like the local-kernel-fusion fusedSpMM this extends (15D_dense_shift.hpp:189).
+    // Returns false — having done nothing — when the schedule has no such single pass; callers then compose the
+    // public calls as the reference does.
+    virtual bool fusedSpMM_out(DenseMatrix& localA, DenseMatrix& localB, MatMode mode, DenseMatrix& Out, bool leaky,
+                               const hnh_fused_extras& extras) {
+        (void)localA; (void)localB; (void)mode; (void)Out; (void)leaky; (void)extras;
+        return false;
+    }
+
     virtual void algorithm(DenseMatrix& localA, DenseMatrix& localB, VectorXd& SValues, VectorXd* sddmm_result_ptr, KernelMode mode,
                            bool initial_replicate) = 0;
 

@@ -50,13 +50,27 @@ public:
     void computeSelfAttentionHead(int i, int j) {
         hnh::World* w = d_ops->world;
         d_ops->setRValue(layers[i].features_per_head);
-        VectorXd Svalues = d_ops->like_S_values(1.0);
-        VectorXd sddmm_buffer = d_ops->like_S_values(1.0);
         DenseMatrix& X = buffers[i];
         DenseMatrix& W = layers[i].wMats[j];
         if (X.cols() != W.rows()) hnh::fatal("Error, GAT weight shape does not match the layer input!");
         DenseMatrix A(X.rows(), W.cols());
         w->check(w->be->hnh_gemm_f64(w->ctx, X.rows(), W.cols(), X.cols(), X.data(), W.data(), A.data(), HNH_STREAM_COMPUTE), "hnh_gemm_f64");
+        DenseMatrix& out = buffers[i + 1];
+
+        // Schedules with a single fused pass (1.5D dense shift, local kernel fusion, c = 1: its shifts are empty and
+        // the attention matrix is not exported) do SDDMM, LeakyReLU and SpMM in ONE gather of the neighbours' rows.
+        if (d_ops->c == 1) {
+            DenseMatrix H(A.rows(), A.cols());
+            hnh_fused_extras ex = {leaky_relu_alpha, 0.0, nullptr};
+            if (d_ops->fusedSpMM_out(A, A, Amat, H, true, ex)) {
+                w->check(w->be->hnh_relu_store_cols_f64(w->ctx, out.data(), out.cols(), (int64_t)j * H.cols(), H.data(), H.rows(), H.cols(),
+                                                        HNH_STREAM_COMPUTE), "hnh_relu_store_cols_f64");
+                return;
+            }
+        }
+
+        VectorXd Svalues = d_ops->like_S_values(1.0);
+        VectorXd sddmm_buffer = d_ops->like_S_values(1.0);
         DenseMatrix B = A;
         d_ops->de_shift(&B, nullptr, k_spmmA);
 
@@ -65,7 +79,6 @@ public:
         w->check(w->be->hnh_leaky_relu_f64(w->ctx, sddmm_buffer.data(), leaky_relu_alpha, sddmm_buffer.size(), HNH_STREAM_COMPUTE),
                  "hnh_leaky_relu_f64");
         d_ops->algorithm(A, B, sddmm_buffer, nullptr, k_spmmA, false);   // SpMM phase, replication reused
-        DenseMatrix& out = buffers[i + 1];
         w->check(w->be->hnh_relu_store_cols_f64(w->ctx, out.data(), out.cols(), (int64_t)j * A.cols(), A.data(), A.rows(), A.cols(),
                                                 HNH_STREAM_COMPUTE),
                  "hnh_relu_store_cols_f64");

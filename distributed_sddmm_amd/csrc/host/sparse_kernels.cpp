@@ -42,18 +42,25 @@ size_t StandardKernel::spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B,
 }
 
 // One pass for the sddmm/spmm pair of 15D_dense_shift.hpp:203-217 (block not transposed: approach 2).
-size_t StandardKernel::fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, DenseMatrix& Out, int block, unsigned flags) {
+size_t StandardKernel::fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, DenseMatrix& Out, int block, unsigned flags,
+                                   const hnh_fused_extras* extras) {
     if (A.cols() != B.cols() || Out.cols() != A.cols()) hnh::fatal("Error, fused operands must have the same number of columns!");
+    if ((flags & HNH_FUSED_LEAKY_RELU) && !extras) hnh::fatal("Error, HNH_FUSED_LEAKY_RELU needs extras!");
     CSRLocal* blk = S.csr_blocks[block];
-    if (blk == nullptr) return 0;
-    if (blk->transpose) hnh::fatal("Error, local matrix is transposed, can't perform the fused SDDMM+SpMM");
-    if (blk->num_coords == 0) return 0;
-    CSRHandle* active = blk->getActive();
     hnh::World* w = S.world;
+    if (blk == nullptr || blk->num_coords == 0) {  // nothing to multiply; the row epilogue still applies
+        if (wants_epilogue(extras)) {
+            if (flags & HNH_FUSED_OUT_OVERWRITE) Out.setZero();
+            row_epilogue(w, A, Out, extras);
+        }
+        return 0;
+    }
+    if (blk->transpose) hnh::fatal("Error, local matrix is transposed, can't perform the fused SDDMM+SpMM");
+    CSRHandle* active = blk->getActive();
     begin(w);
-    w->check(w->be->hnh_fused_sddmm_spmm_csr_ex(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, nullptr,
-                                                A.data(), B.data(), Out.data(), (int)A.cols(), flags, blk->num_coords,
-                                                blk->row_hint(), HNH_STREAM_COMPUTE),
+    w->check(w->be->hnh_fused_sddmm_spmm_csr_x(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, nullptr, A.data(),
+                                               B.data(), Out.data(), (int)A.cols(), flags, blk->num_coords, blk->row_hint(), extras,
+                                               HNH_STREAM_COMPUTE),
              "hnh_fused_sddmm_spmm_csr");
     end(w);
     return 0;
@@ -61,8 +68,9 @@ size_t StandardKernel::fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
 
 // All visiting blocks of the block row in one launch (hnh_fused_sddmm_spmm_csr_multi).
 size_t StandardKernel::fused_multi_local(SpmatLocal& S, DenseMatrix& A, const std::vector<DenseMatrix*>& Bs, DenseMatrix& Out,
-                                         const std::vector<int>& blocks, unsigned flags) {
+                                         const std::vector<int>& blocks, unsigned flags, const hnh_fused_extras* extras) {
     if (Bs.size() != blocks.size()) hnh::fatal("Error, fused_multi_local needs one dense operand per block!");
+    if ((flags & HNH_FUSED_LEAKY_RELU) && !extras) hnh::fatal("Error, HNH_FUSED_LEAKY_RELU needs extras!");
     std::vector<hnh_csr_block> list;
     int64_t rows = -1;
     for (size_t k = 0; k < blocks.size(); k++) {
@@ -75,14 +83,15 @@ size_t StandardKernel::fused_multi_local(SpmatLocal& S, DenseMatrix& A, const st
         CSRHandle* h = blk->getActive();
         list.push_back(hnh_csr_block{h->rowStart, h->col_idx, h->values, Bs[k]->data(), blk->num_coords, blk->row_hint()});
     }
+    hnh::World* w = S.world;
     if (list.empty()) {
         if (flags & HNH_FUSED_OUT_OVERWRITE) Out.setZero();
+        row_epilogue(w, A, Out, extras);
         return 0;
     }
-    hnh::World* w = S.world;
     begin(w);
-    w->check(w->be->hnh_fused_sddmm_spmm_csr_multi(w->ctx, rows, (int)list.size(), list.data(), A.data(), Out.data(), (int)A.cols(), flags,
-                                                   HNH_STREAM_COMPUTE),
+    w->check(w->be->hnh_fused_sddmm_spmm_csr_multi_x(w->ctx, rows, (int)list.size(), list.data(), A.data(), Out.data(), (int)A.cols(), flags,
+                                                     extras, HNH_STREAM_COMPUTE),
              "hnh_fused_sddmm_spmm_csr_multi");
     end(w);
     return 0;

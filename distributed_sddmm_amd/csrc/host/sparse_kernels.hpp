@@ -31,32 +31,52 @@ public:
     // values(block) += <A rows, B rows>;  Out += S_block(values) * B        (Out must not alias A or B)
     // flags: HNH_FUSED_VALUES_OVERWRITE / HNH_FUSED_OUT_OVERWRITE tell the implementation that the block's
     // values / Out are to be treated as zero on entry, so it may overwrite instead of read-modify-write.
+    // extras (optional, hnh_kernels.h): with HNH_FUSED_LEAKY_RELU the block's values are activated between the two
+    // halves; x_scale / rowdot are applied to the finished rows of Out — ALWAYS, also when the block is absent —
+    // so a schedule hands them to exactly one call: the last one that touches Out.
     // Default: literally the two virtual calls the reference makes (15D_dense_shift.hpp:203-217).
-    virtual size_t fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, DenseMatrix& Out, int block, unsigned flags) {
+    virtual size_t fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, DenseMatrix& Out, int block, unsigned flags,
+                               const hnh_fused_extras* extras = nullptr) {
+        hnh::World* w = S.world;
         CSRLocal* blk = S.csr_blocks[block];
-        if (blk == nullptr) return 0;
-        if (flags & HNH_FUSED_VALUES_OVERWRITE)
-            S.world->check(S.world->be->hnh_fill_f64(S.world->ctx, blk->getActive()->values, blk->num_coords, 0.0, HNH_STREAM_COMPUTE),
-                           "hnh_fill_f64");
+        size_t n = 0;
         if (flags & HNH_FUSED_OUT_OVERWRITE) Out.setZero();
-        size_t n = sddmm_local(S, A, B, block, 0);
-        n += spmm_local(S, Out, B, Amat, block);
+        if (blk != nullptr) {
+            if (flags & HNH_FUSED_VALUES_OVERWRITE)
+                w->check(w->be->hnh_fill_f64(w->ctx, blk->getActive()->values, blk->num_coords, 0.0, HNH_STREAM_COMPUTE), "hnh_fill_f64");
+            n += sddmm_local(S, A, B, block, 0);
+            if (flags & HNH_FUSED_LEAKY_RELU)
+                w->check(w->be->hnh_leaky_relu_f64(w->ctx, blk->getActive()->values, extras->leaky_alpha, blk->num_coords, HNH_STREAM_COMPUTE),
+                         "hnh_leaky_relu_f64");
+            n += spmm_local(S, Out, B, Amat, block);
+        }
+        row_epilogue(w, A, Out, extras);
         return n;
     }
 
     // The same fused pair over several blocks that share their rows (one per gathered operand Bs[k]), in the order
     // given.  Default: block after block through fused_local; StandardKernel walks them in a single launch.
     virtual size_t fused_multi_local(SpmatLocal& S, DenseMatrix& A, const std::vector<DenseMatrix*>& Bs, DenseMatrix& Out,
-                                     const std::vector<int>& blocks, unsigned flags) {
+                                     const std::vector<int>& blocks, unsigned flags, const hnh_fused_extras* extras = nullptr) {
         size_t n = 0;
         bool first = true;
+        hnh_fused_extras act_only = {extras ? extras->leaky_alpha : 0.0, 0.0, nullptr};
         for (size_t k = 0; k < blocks.size(); k++) {
             if (S.csr_blocks[blocks[k]] == nullptr) continue;
-            n += fused_local(S, A, *Bs[k], Out, blocks[k], first ? flags : (flags & ~HNH_FUSED_OUT_OVERWRITE));
+            n += fused_local(S, A, *Bs[k], Out, blocks[k], first ? flags : (flags & ~HNH_FUSED_OUT_OVERWRITE), &act_only);
             first = false;
         }
         if (first && (flags & HNH_FUSED_OUT_OVERWRITE)) Out.setZero();
+        row_epilogue(S.world, A, Out, extras);
         return n;
+    }
+
+    static bool wants_epilogue(const hnh_fused_extras* extras) { return extras && (extras->x_scale != 0.0 || extras->rowdot != nullptr); }
+    static void row_epilogue(hnh::World* w, DenseMatrix& X, DenseMatrix& Out, const hnh_fused_extras* extras) {
+        if (!wants_epilogue(extras)) return;
+        w->check(w->be->hnh_row_epilogue_f64(w->ctx, Out.data(), X.data(), extras->x_scale, extras->rowdot, Out.rows(), (int)Out.cols(),
+                                             HNH_STREAM_COMPUTE),
+                 "hnh_row_epilogue_f64");
     }
 
     size_t triple_function(KernelMode mode, SpmatLocal& S, DenseMatrix& localA, DenseMatrix& localB, int block, int offset) {
@@ -79,9 +99,10 @@ public:
 
     size_t sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, int block, int offset) override;
     size_t spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, MatMode mode, int block) override;
-    size_t fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, DenseMatrix& Out, int block, unsigned flags) override;
+    size_t fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, DenseMatrix& Out, int block, unsigned flags,
+                       const hnh_fused_extras* extras = nullptr) override;
     size_t fused_multi_local(SpmatLocal& S, DenseMatrix& A, const std::vector<DenseMatrix*>& Bs, DenseMatrix& Out,
-                             const std::vector<int>& blocks, unsigned flags) override;
+                             const std::vector<int>& blocks, unsigned flags, const hnh_fused_extras* extras = nullptr) override;
     ~StandardKernel() override;
 
 private:

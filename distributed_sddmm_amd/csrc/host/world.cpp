@@ -66,6 +66,7 @@ Backend* load_backend(const char* path_c) {
     HNH_BIND(hnh_event_sync) HNH_BIND(hnh_event_elapsed_ms)
     HNH_BIND(hnh_sddmm_coo) HNH_BIND(hnh_sddmm_csr) HNH_BIND(hnh_spmm_csr) HNH_BIND(hnh_fused_sddmm_spmm_csr)
     HNH_BIND(hnh_sddmm_csr_ex) HNH_BIND(hnh_spmm_csr_ex) HNH_BIND(hnh_fused_sddmm_spmm_csr_ex) HNH_BIND(hnh_csr_max_row_nnz) HNH_BIND(hnh_fused_sddmm_spmm_csr_multi)
+    HNH_BIND(hnh_fused_sddmm_spmm_csr_x) HNH_BIND(hnh_fused_sddmm_spmm_csr_multi_x) HNH_BIND(hnh_row_epilogue_f64) HNH_BIND(hnh_cg_step_f64)
     HNH_BIND(hnh_fill_f64) HNH_BIND(hnh_hadamard_f64) HNH_BIND(hnh_axpy_f64) HNH_BIND(hnh_expand_rowptr)
     HNH_BIND(hnh_rowdot_f64) HNH_BIND(hnh_row_scale_add_f64) HNH_BIND(hnh_vec_add_scalar_f64) HNH_BIND(hnh_vec_div_f64) HNH_BIND(hnh_fill_hashed_f64)
     HNH_BIND(hnh_gemm_f64) HNH_BIND(hnh_leaky_relu_f64) HNH_BIND(hnh_relu_store_cols_f64)

@@ -141,6 +141,11 @@ int hnh_dist_sddmmB(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_vec
 int hnh_dist_spmmA(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S);
 int hnh_dist_spmmB(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S);
 int hnh_dist_fusedSpMM(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_vec* sddmm_buffer, int matmode);
+/* Distributed_Sparse::fusedSpMM_out (an addition): out-of-place fusedSpMM with the applications' surrounding work in the
+ * same pass — LeakyReLU between the halves (gat.hpp:96-99), Out += x_scale * X and rowdot[i] = <X[i,:], Out[i,:]>
+ * (als_conjugate_gradients.cpp:93,282,295).  *supported = 0 and nothing done when the schedule has no single fused pass. */
+int hnh_dist_fusedSpMM_out(hnh_dist* d, hnh_dense* A, hnh_dense* B, int matmode, hnh_dense* Out, int leaky, double leaky_alpha,
+                           double x_scale, hnh_vec* rowdot_or_null, int* supported);
 int hnh_dist_algorithm(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_vec* result_or_null, int kernel_mode,
                        int initial_replicate);
 

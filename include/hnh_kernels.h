@@ -45,6 +45,7 @@ extern "C" {
 /* flags of hnh_fused_sddmm_spmm_csr */
 #define HNH_FUSED_VALUES_OVERWRITE 1u /* values[e]  = dot  instead of  values[e] += dot (caller knows they are zero) */
 #define HNH_FUSED_OUT_OVERWRITE 2u    /* Out[i,:]   = sum  instead of  Out[i,:] += sum  (caller knows it is zero)    */
+#define HNH_FUSED_LEAKY_RELU 4u       /* _x entry points: activation between the two halves, see hnh_fused_extras     */
 
 typedef struct hnh_ctx hnh_ctx; /* opaque, one per rank: device ordinal, two streams, scratch */
 
@@ -113,6 +114,25 @@ int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowpt
                                 int R, unsigned flags, int64_t nnz, int max_row_nnz, int stream);
 int hnh_csr_max_row_nnz(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, int* out_host, int stream);
 
+/* Extras of the fused pass — what the reference's applications do immediately around their SDDMM->SpMM pair,
+ * folded into the same launch while the operands are still in registers:
+ *   leaky_alpha  with HNH_FUSED_LEAKY_RELU: the SpMM half uses (and values[] keeps)
+ *                w = LeakyReLU(svalues[e] * (values[e] + <X[i,:],Y[j,:]>))   — gat.hpp:96-99 (SDDMM, activation, SpMM)
+ *   x_scale      != 0:  Out[i,:] += x_scale * X[i,:]                         — als_conjugate_gradients.cpp:282,295 (+ lambda * X)
+ *   rowdot       != NULL: rowdot[i] = <X[i,:], Out[i,:]> of the FINAL row     — als_conjugate_gradients.cpp:93 (batch_dot_product(p, Mp))
+ * The epilogue (x_scale, rowdot) runs inside the launch when one group completes the output row; with hub rows
+ * (atomically combined segments), column tiles or more blocks than one launch takes it is appended as a row-wise
+ * launch — same result either way.  hnh_row_epilogue_f64 is that launch on its own. */
+typedef struct hnh_fused_extras {
+    double leaky_alpha;
+    double x_scale;
+    double* rowdot;
+} hnh_fused_extras;
+int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
+                               const double* svalues, const double* X, const double* Y, double* Out, int R, unsigned flags,
+                               int64_t nnz, int max_row_nnz, const hnh_fused_extras* extras, int stream);
+int hnh_row_epilogue_f64(hnh_ctx* ctx, double* Out, const double* X, double x_scale, double* rowdot, int64_t rows, int R, int stream);
+
 /* hnh_fused_sddmm_spmm_csr_multi — the fused pass over SEVERAL blocks that share their rows (the p/c blocks one rank
  *   visits in 15D_dense_shift.hpp:199-227), each with its own gathered operand Y_b, in ONE launch: the row operand
  *   X[i,:] and the output accumulator stay in registers across blocks instead of being re-read / read-modify-
@@ -128,6 +148,8 @@ typedef struct hnh_csr_block {
 } hnh_csr_block;
 int hnh_fused_sddmm_spmm_csr_multi(hnh_ctx* ctx, int64_t rows, int nblocks, const hnh_csr_block* blocks, const double* X,
                                    double* Out, int R, unsigned flags, int stream);
+int hnh_fused_sddmm_spmm_csr_multi_x(hnh_ctx* ctx, int64_t rows, int nblocks, const hnh_csr_block* blocks, const double* X,
+                                     double* Out, int R, unsigned flags, const hnh_fused_extras* extras, int stream);
 
 /* ---- element-wise helpers (K3-K5 of SURVEY §2.4) ----------------------------------------------------
  * hnh_fill_f64      — SpmatLocal::setValuesConstant (SpmatLocal.hpp:595-605), DenseMatrix::setZero
@@ -148,6 +170,10 @@ int hnh_rowdot_f64(hnh_ctx* ctx, const double* A, const double* B, double* out, 
 int hnh_row_scale_add_f64(hnh_ctx* ctx, double* Y, const double* yv, double ya, const double* X, const double* xv, double xa,
                           int64_t rows, int R, int stream);
 int hnh_vec_add_scalar_f64(hnh_ctx* ctx, double* v, double c, int64_t n, int stream);
+/* hnh_cg_step_f64 — the three dense passes in the middle of one CG iteration (:117-127) as one:
+ *   X[i,:] += alpha[i] * P[i,:];   Rm[i,:] -= alpha[i] * MP[i,:];   rsnew[i] = <Rm[i,:], Rm[i,:]> */
+int hnh_cg_step_f64(hnh_ctx* ctx, double* X, double* Rm, const double* P, const double* MP, const double* alpha, double* rsnew,
+                    int64_t rows, int R, int stream);
 /* hnh_fill_hashed_f64 — distribution-independent stand-in for Eigen's setRandom() (als_conjugate_gradients.cpp:143-146):
  *   dst[i, j] = scale * uniform(-1, 1) hashed from the GLOBAL element (top_row + i, left_col + j) of an R_global-wide matrix:
  *   key = (top_row + i) * R_global + left_col + j;  h = splitmix64(seed * 0xD1342543DE82EF95 + key * 0x9E3779B97F4A7C15);

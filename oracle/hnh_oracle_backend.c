@@ -153,12 +153,82 @@ int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* c, int64_t rows, const int32_t* rowptr,
     (void)nnz; (void)max_row_nnz;
     return hnh_fused_sddmm_spmm_csr(c, rows, rowptr, col_idx, values, svalues, X, Y, Out, R, flags, stream);
 }
-int hnh_fused_sddmm_spmm_csr_multi(hnh_ctx* c, int64_t rows, int nblocks, const hnh_csr_block* blocks, const double* X, double* Out,
-                                   int R, unsigned flags, int stream) {
+
+/* als_conjugate_gradients.cpp:282,295 (+ lambda * X) and :93 (batch_dot_product(p, Mp)) on a finished output */
+int hnh_row_epilogue_f64(hnh_ctx* c, double* Out, const double* X, double x_scale, double* rowdot, int64_t rows, int R, int stream) {
+    (void)stream;
+    if (rows < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad size");
+    for (int64_t i = 0; i < rows; i++) {
+        double s = 0.0;
+        for (int j = 0; j < R; j++) {
+            Out[i * R + j] += x_scale * X[i * R + j];
+            s += X[i * R + j] * Out[i * R + j];
+        }
+        if (rowdot) rowdot[i] = s;
+    }
+    return HNH_OK;
+}
+
+/* gat.hpp:96-99: SDDMM, LeakyReLU on the values, SpMM with them; then the row epilogue */
+int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
+                               const double* svalues, const double* X, const double* Y, double* Out, int R, unsigned flags,
+                               int64_t nnz_hint, int max_row_nnz, const hnh_fused_extras* ex, int stream) {
+    (void)nnz_hint; (void)max_row_nnz;
+    if (rows < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad size");
+    if ((flags & HNH_FUSED_LEAKY_RELU) && !ex) return fail(c, HNH_ERR_INVALID, "HNH_FUSED_LEAKY_RELU needs extras");
+    if (rows == 0) return HNH_OK;
+    int rc;
+    if (flags & HNH_FUSED_LEAKY_RELU) {
+        const int32_t nnz = rowptr[rows];
+        if (flags & HNH_FUSED_VALUES_OVERWRITE) memset(values, 0, sizeof(double) * (size_t)nnz);
+        if (flags & HNH_FUSED_OUT_OVERWRITE) memset(Out, 0, sizeof(double) * (size_t)rows * (size_t)R);
+        rc = hnh_sddmm_csr(c, rows, rowptr, col_idx, values, X, Y, R, stream);
+        if (rc != HNH_OK) return rc;
+        for (int32_t i = 0; i < nnz; i++) {
+            const double v = values[i] * (svalues ? svalues[i] : 1.0);
+            values[i] = v > 0.0 ? v : ex->leaky_alpha * v;
+        }
+        rc = hnh_spmm_csr(c, rows, rowptr, col_idx, values, Y, Out, R, stream);
+    } else {
+        rc = hnh_fused_sddmm_spmm_csr(c, rows, rowptr, col_idx, values, svalues, X, Y, Out, R, flags, stream);
+    }
+    if (rc != HNH_OK) return rc;
+    if (ex && (ex->x_scale != 0.0 || ex->rowdot)) return hnh_row_epilogue_f64(c, Out, X, ex->x_scale, ex->rowdot, rows, R, stream);
+    return HNH_OK;
+}
+
+int hnh_fused_sddmm_spmm_csr_multi_x(hnh_ctx* c, int64_t rows, int nblocks, const hnh_csr_block* blocks, const double* X, double* Out,
+                                     int R, unsigned flags, const hnh_fused_extras* ex, int stream) {
+    if ((flags & HNH_FUSED_LEAKY_RELU) && !ex) return fail(c, HNH_ERR_INVALID, "HNH_FUSED_LEAKY_RELU needs extras");
+    hnh_fused_extras act_only = {ex ? ex->leaky_alpha : 0.0, 0.0, NULL};
+    if (nblocks == 0 && (flags & HNH_FUSED_OUT_OVERWRITE) && ex && (ex->x_scale != 0.0 || ex->rowdot))
+        memset(Out, 0, sizeof(double) * (size_t)rows * (size_t)R);
     for (int b = 0; b < nblocks; b++) {  /* block after block: 15D_dense_shift.hpp:199-227 */
         const unsigned f = (b == 0) ? flags : (flags & ~HNH_FUSED_OUT_OVERWRITE);
-        int rc = hnh_fused_sddmm_spmm_csr(c, rows, blocks[b].rowptr, blocks[b].col_idx, blocks[b].values, NULL, X, blocks[b].Y, Out, R, f, stream);
+        int rc = hnh_fused_sddmm_spmm_csr_x(c, rows, blocks[b].rowptr, blocks[b].col_idx, blocks[b].values, NULL, X, blocks[b].Y, Out, R, f,
+                                            -1, -1, &act_only, stream);
         if (rc != HNH_OK) return rc;
+    }
+    if (ex && (ex->x_scale != 0.0 || ex->rowdot)) return hnh_row_epilogue_f64(c, Out, X, ex->x_scale, ex->rowdot, rows, R, stream);
+    return HNH_OK;
+}
+int hnh_fused_sddmm_spmm_csr_multi(hnh_ctx* c, int64_t rows, int nblocks, const hnh_csr_block* blocks, const double* X, double* Out,
+                                   int R, unsigned flags, int stream) {
+    return hnh_fused_sddmm_spmm_csr_multi_x(c, rows, nblocks, blocks, X, Out, R, flags, NULL, stream);
+}
+
+/* als_conjugate_gradients.cpp:117-127 */
+int hnh_cg_step_f64(hnh_ctx* c, double* X, double* Rm, const double* P, const double* MP, const double* alpha, double* rsnew,
+                    int64_t rows, int R, int stream) {
+    (void)c; (void)stream;
+    for (int64_t i = 0; i < rows; i++) {
+        double s = 0.0;
+        for (int j = 0; j < R; j++) {
+            X[i * R + j] += alpha[i] * P[i * R + j];
+            Rm[i * R + j] -= alpha[i] * MP[i * R + j];
+            s += Rm[i * R + j] * Rm[i * R + j];
+        }
+        rsnew[i] = s;
     }
     return HNH_OK;
 }

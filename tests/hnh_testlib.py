@@ -321,3 +321,56 @@ def run_gat(world: H.World, alg: str, c: int, case: dict, layers=None, alpha: fl
     res = dict(subA=subA, gat=out.download())
     x.free(); out.free(); gnn.free(); d.free(); sp.free()
     return res
+
+
+# ---------------------------------------------------------------------------------------------- fusedSpMM_out
+def run_fused_out(world: H.World, alg: str, c: int, case: dict, matmode: int, leaky_alpha, x_scale: float, want_rowdot: bool) -> dict:
+    """Distributed_Sparse::fusedSpMM_out on ONE rank; returns this rank's rows of Out / rowdot and the untouched inputs."""
+    sp = H.SpmatLocal.from_global(world, case["M"], case["N"], case["rows"], case["cols"], np.ones(len(case["rows"])))
+    d = H.DistributedSparse(world, alg, sp, case["R"], c)
+    subA, subB = d.submatrices(H.AMAT), d.submatrices(H.BMAT)
+    A, B = d.like_A_matrix(0.0), d.like_B_matrix(0.0)
+    A.upload(fill_local(subA, A.shape, case["A"])); B.upload(fill_local(subB, B.shape, case["B"]))
+    x = A if matmode == H.AMAT else B
+    out = H.Dense.create(world, *x.shape); out.fill(7.0)  # must be overwritten, not accumulated into
+    dot = H.Vec.create(world, x.shape[0]) if want_rowdot else None
+    ok = d.fusedSpMM_out(A, B, matmode, out, leaky_alpha=leaky_alpha, x_scale=x_scale, rowdot=dot)
+    res = dict(supported=ok, subA=subA, subB=subB)
+    if ok:
+        res.update(out=out.download(), rowdot=dot.download() if dot else None, A_after=A.download(), B_after=B.download(),
+                   A_expected=fill_local(subA, A.shape, case["A"]), B_expected=fill_local(subB, B.shape, case["B"]))
+    for h in (A, B, out, dot):
+        if h is not None:
+            h.free()
+    d.free(); sp.free()
+    return res
+
+
+def fused_out_expected(case: dict, matmode: int, leaky_alpha, x_scale: float):
+    """numpy restatement: w = LeakyReLU(<X_i, Y_j>), Out = sum_e w_e Y_j + x_scale X, rowdot = <X_i, Out_i> (S == 1)."""
+    rows, cols = (case["rows"], case["cols"]) if matmode == H.AMAT else (case["cols"], case["rows"])
+    X, Y = (case["A"], case["B"]) if matmode == H.AMAT else (case["B"], case["A"])
+    w = np.einsum("ij,ij->i", X[rows], Y[cols])
+    if leaky_alpha is not None:
+        w = np.where(w > 0, w, leaky_alpha * w)
+    out = np.zeros_like(X)
+    np.add.at(out, rows, w[:, None] * Y[cols])
+    out = out + x_scale * X
+    return out, np.einsum("ij,ij->i", X, out)
+
+
+def check_fused_out(per_rank, case, matmode, leaky_alpha, x_scale, want_rowdot):
+    which, nrows = ("subA", case["M"]) if matmode == H.AMAT else ("subB", case["N"])
+    got = assemble_dense(per_rank, "out", which, nrows, case["R"])
+    want, want_dot = fused_out_expected(case, matmode, leaky_alpha, x_scale)
+    assert rel(got, want) <= TOL
+    for o in per_rank:  # inputs untouched (the moving operand is only read)
+        assert np.array_equal(o["A_after"], o["A_expected"]) and np.array_equal(o["B_after"], o["B_expected"])
+    if want_rowdot:
+        scale = float(np.max(np.abs(want_dot))) or 1.0
+        for o in per_rank:  # one entry per local row, rows listed by the submatrix descriptors
+            off = 0
+            for top, left, rc, cc in o[which]:
+                keep = max(0, min(rc, nrows - top))
+                assert np.max(np.abs(o["rowdot"][off:off + keep] - want_dot[top:top + keep])) <= TOL * scale
+                off += rc

@@ -304,3 +304,117 @@ def test_fused_multi_block_equals_block_after_block(ctx, R):
         assert rel(dOut.get(), want_out) <= TOL
         for d, vals, _, _ in blocks:
             assert rel(d[2].get(), vals) <= TOL
+
+
+def _extras_expected(rowptr, ridx, cidx, v0, sv, X, Y, out0, flags, alpha, x_scale):
+    """numpy statement of hnh_fused_sddmm_spmm_csr_x (include/hnh_kernels.h)."""
+    from distributed_sddmm_amd import _kernels as K
+    nnz, (rows, R) = len(cidx), X.shape
+    vbase = np.zeros(nnz) if flags & K.FUSED_VALUES_OVERWRITE else v0
+    obase = np.zeros((rows, R)) if flags & K.FUSED_OUT_OVERWRITE else out0
+    vals = O.sddmm_local(ridx, cidx, vbase, X, Y)
+    if flags & K.FUSED_LEAKY_RELU:
+        vals = vals * (sv if sv is not None else 1.0)
+        vals = np.where(vals > 0, vals, alpha * vals)
+        w = vals
+    else:
+        w = vals * (sv if sv is not None else 1.0)
+    out = O.spmm_local(rowptr, cidx, w, Y, obase) + x_scale * X
+    return vals, out, np.einsum("ij,ij->i", X, out)
+
+
+@pytest.mark.parametrize("R", [1, 2, 7, 16, 64, 100, 128, 192, 256, 301, 512, 600])
+def test_fused_extras_activation_and_row_epilogue(ctx, R):
+    """LeakyReLU between the halves (gat.hpp:96-99) and the `+ x_scale X`, <X, Out> row epilogue
+    (als_conjugate_gradients.cpp:93,282) inside the fused launch; every kernel shape incl. the tiled fallback."""
+    from distributed_sddmm_amd import _kernels as K
+    lib = ctx.lib
+    rows, cols = 211, 190
+    rowptr, ridx, cidx = random_block(rows, cols, 3000, seed=R + 77)
+    nnz = len(cidx)
+    rng = np.random.default_rng(R + 5)
+    X, Y = rng.uniform(-1, 1, (rows, R)), rng.uniform(-1, 1, (cols, R))
+    v0, out0, sv = rng.uniform(-1, 1, nnz), rng.uniform(-1, 1, (rows, R)), rng.uniform(-1, 1, nnz)
+    d_rp, d_c, dv, dX, dY, dOut, dsv = (ctx.upload(a) for a in (rowptr, cidx, v0, X, Y, out0, sv))
+    ddot = ctx.upload(np.full(rows, 9.0))
+    OW = K.FUSED_VALUES_OVERWRITE | K.FUSED_OUT_OVERWRITE
+    for flags, use_sv, alpha, xs, want_dot in [(OW | K.FUSED_LEAKY_RELU, False, 0.2, 0.0, False), (K.FUSED_LEAKY_RELU, True, 0.01, 0.5, True),
+                                               (OW, False, 0.0, 1e-3, True), (0, True, 0.0, -2.0, True), (OW, False, 0.0, 0.0, True)]:
+        dv.set(v0); dOut.set(out0); ddot.set(np.full(rows, 9.0))
+        ex = K.FusedExtras(alpha, xs, ddot.ptr if want_dot else None)
+        ctx.check(lib.hnh_fused_sddmm_spmm_csr_x(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, dsv.ptr if use_sv else None, dX.ptr, dY.ptr,
+                                                 dOut.ptr, R, flags, nnz, int(np.diff(rowptr).max()), C.byref(ex), 0), "fused_x")
+        vals, out, dot = _extras_expected(rowptr, ridx, cidx, v0, sv if use_sv else None, X, Y, out0, flags, alpha, xs)
+        assert rel(dv.get(), vals) <= TOL
+        assert rel(dOut.get(), out) <= TOL
+        if want_dot:
+            assert rel(ddot.get(), dot) <= TOL
+    # the flag without extras is a caller error
+    assert lib.hnh_fused_sddmm_spmm_csr_x(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, None, dX.ptr, dY.ptr, dOut.ptr, R, K.FUSED_LEAKY_RELU, -1, -1,
+                                          None, 0) != 0
+    # standalone epilogue and the CG update
+    dOut.set(out0)
+    ctx.check(lib.hnh_row_epilogue_f64(ctx.h, dOut.ptr, dX.ptr, 0.25, ddot.ptr, rows, R, 0), "row_epilogue")
+    assert rel(dOut.get(), out0 + 0.25 * X) <= TOL and rel(ddot.get(), np.einsum("ij,ij->i", X, out0 + 0.25 * X)) <= TOL
+    Xm, Rm, P, MP = (rng.uniform(-1, 1, (rows, R)) for _ in range(4))
+    al = rng.uniform(-1, 1, rows)
+    dXm, dRm, dP, dMP, dal = (ctx.upload(a) for a in (Xm, Rm, P, MP, al))
+    ctx.check(lib.hnh_cg_step_f64(ctx.h, dXm.ptr, dRm.ptr, dP.ptr, dMP.ptr, dal.ptr, ddot.ptr, rows, R, 0), "cg_step")
+    r_new = Rm - al[:, None] * MP
+    assert rel(dXm.get(), Xm + al[:, None] * P) <= TOL and rel(dRm.get(), r_new) <= TOL
+    assert rel(ddot.get(), np.einsum("ij,ij->i", r_new, r_new)) <= TOL
+    for d in (d_rp, d_c, dv, dX, dY, dOut, dsv, ddot, dXm, dRm, dP, dMP, dal):
+        d.free()
+
+
+@pytest.mark.parametrize("R", [16, 128, 100])
+def test_fused_extras_with_hub_rows_and_many_blocks(ctx, R):
+    """Epilogue appended as its own launch when rows are completed by several groups (hub-row segments) or several
+    launches (more blocks than one multi-block launch takes); same numbers as the in-launch epilogue."""
+    from distributed_sddmm_amd import _kernels as K
+    lib = ctx.lib
+    rng = np.random.default_rng(R + 11)
+    # (1) hub rows, single block
+    rows, cols = 40, 6000
+    lens = rng.integers(0, 30, rows); lens[3], lens[20] = 3000, 1100
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cidx = np.concatenate([np.sort(rng.choice(cols, n, replace=False)) for n in lens]).astype(np.int32)
+    ridx = np.repeat(np.arange(rows, dtype=np.int32), lens)
+    X, Y = rng.uniform(-1, 1, (rows, R)), rng.uniform(-1, 1, (cols, R))
+    v0, out0 = rng.uniform(-1, 1, len(cidx)), rng.uniform(-1, 1, (rows, R))
+    d_rp, d_c, dv, dX, dY, dOut, ddot = (ctx.upload(a) for a in (rowptr, cidx, v0, X, Y, out0, np.zeros(rows)))
+    flags = K.FUSED_VALUES_OVERWRITE | K.FUSED_OUT_OVERWRITE | K.FUSED_LEAKY_RELU
+    ex = K.FusedExtras(0.2, 1e-2, ddot.ptr)
+    ctx.check(lib.hnh_fused_sddmm_spmm_csr_x(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, None, dX.ptr, dY.ptr, dOut.ptr, R, flags, -1, -1,
+                                             C.byref(ex), 0), "fused_x hub")
+    vals, out, dot = _extras_expected(rowptr, ridx, cidx, v0, None, X, Y, out0, flags, 0.2, 1e-2)
+    assert rel(dv.get(), vals) <= TOL and rel(dOut.get(), out) <= TOL and rel(ddot.get(), dot) <= TOL
+    for d in (d_rp, d_c, dv, dX, dY, dOut, ddot):
+        d.free()
+    # (2) multi-block: 3 blocks (one launch) and 11 blocks (two launches + appended epilogue)
+    rows, cols = 150, 90
+    X = rng.uniform(-1, 1, (rows, R)); dX = ctx.upload(X)
+    for nb in (3, 11):
+        keep, want = [], np.zeros((rows, R))
+        arr = (K.CsrBlock * nb)()
+        for b in range(nb):
+            rowptr, ridx, cidx = random_block(rows, cols, 500, seed=R * 100 + b)
+            Yb, vb = rng.uniform(-1, 1, (cols, R)), rng.uniform(-1, 1, len(cidx))
+            d = [ctx.upload(a) for a in (rowptr, cidx, vb, Yb)]
+            vals = O.sddmm_local(ridx, cidx, np.zeros(len(cidx)), X, Yb)
+            vals = np.where(vals > 0, vals, 0.3 * vals)
+            want = O.spmm_local(rowptr, cidx, vals, Yb, want)
+            keep.append((d, vals))
+            arr[b].rowptr, arr[b].col_idx, arr[b].values, arr[b].Y = d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr
+            arr[b].nnz, arr[b].max_row_nnz = len(cidx), int(np.diff(rowptr).max())
+        want = want + 0.5 * X
+        dOut, ddot = ctx.upload(rng.uniform(-1, 1, (rows, R))), ctx.upload(np.zeros(rows))
+        ex = K.FusedExtras(0.3, 0.5, ddot.ptr)
+        ctx.check(lib.hnh_fused_sddmm_spmm_csr_multi_x(ctx.h, rows, nb, arr, dX.ptr, dOut.ptr, R, flags, C.byref(ex), 0), "multi_x")
+        assert rel(dOut.get(), want) <= TOL and rel(ddot.get(), np.einsum("ij,ij->i", X, want)) <= TOL
+        for d, vals in keep:
+            assert rel(d[2].get(), vals) <= TOL
+            for h in d:
+                h.free()
+        dOut.free(); ddot.free()
+    dX.free()

@@ -174,3 +174,17 @@ def test_operands_in_torch_memory():
             x.free()
         op.free()
     sp.free(); w.close()
+
+
+@pytest.mark.parametrize("mode", ["relay", "mesh"])
+@pytest.mark.parametrize("p,c", [(1, 1), (2, 1), (4, 1), (4, 2), (8, 1), (8, 2)])
+def test_fused_out_with_extras_hip(monkeypatch, mode, p, c):
+    """Distributed_Sparse::fusedSpMM_out on the HIP kernels: LeakyReLU between the halves, `+ x_scale X` and the row-wise
+    <X, Out> in the launch that completes the rows (or appended after the reduce-scatter for c > 1)."""
+    monkeypatch.setenv("HNH_RING_MODE", mode)
+    for name in ("er8_r16", "rect_r16", "tiny_r8"):
+        case = T.case_inputs(name)
+        for matmode, alpha, xs, dot in [(H.AMAT, 0.2, 0.0, False), (H.BMAT, None, 1e-3, True), (H.AMAT, 0.05, -0.5, True)]:
+            per_rank = H.run_spmd(p, lambda w: T.run_fused_out(w, "15d_fusion2", c, case, matmode, alpha, xs, dot))
+            assert all(o["supported"] for o in per_rank)
+            T.check_fused_out(per_rank, case, matmode, alpha, xs, dot)
