@@ -730,51 +730,109 @@ __global__ __launch_bounds__(kBlock) void vec_div_kernel(double* out, const doub
 }
 
 // ---------------------------------------------------------------- fp64 GEMM on the matrix cores (GAT's X * W)
-// Block tile 64 x 64, K step 16, 4 waves; wave w owns rows [16w, 16w+16) x 64 columns = four 16x16 accumulators.
-// v_mfma_f64_16x16x4_f64 fragment layout (cdna_hip_programming.md, "f64 MFMA does NOT use these maps"):
+// C[M x N] = A[M x K] * B[K x N], all row-major.  Block tile 128 x 128, K step 16, 4 waves in a 2 x 2 grid; each wave
+// owns 64 x 64 = 4 x 4 accumulators of v_mfma_f64_16x16x4_f64, so one k-step of 4 feeds 16 MFMAs from 8 LDS reads
+// (4 A fragments + 4 B fragments) — the LDS port, not the matrix core, is what a small wave tile saturates.
+// Fragment layout (cdna_hip_programming.md, "f64 MFMA does NOT use these maps"):
 //   A: lane l holds A[i = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][j = l & 15];
 //   C/D: register r of lane l is C[row = (l >> 4) + 4 r][col = l & 15].
+// Both tiles sit in LDS k-major ([k][m], [k][n]) so the 16 lanes of a fragment row read 128 contiguous bytes.
+// Pipeline: the next K tile is fetched from global memory into registers while the MFMAs of the current one run, then
+// stored into the other LDS buffer — one barrier per K tile.
+// Launch: 1-D grid; consecutive slots of one XCD (blockIdx.x % 8) are the column blocks of the SAME row block, so the
+// A panel is read from HBM once and served from that XCD's L2 for the other column blocks.
 typedef double d4_t __attribute__((ext_vector_type(4)));
-constexpr int kGemmBM = 64, kGemmBN = 64, kGemmBK = 16;
+constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 16, kGemmLd = 128 + 4;
+constexpr int kXcds = 8;
 
 __global__ __launch_bounds__(kBlock) void gemm_f64_kernel(int64_t M, int64_t N, int64_t K, const double* __restrict__ A,
-                                                          const double* __restrict__ B, double* __restrict__ C) {
-    __shared__ double As[kGemmBM][kGemmBK + 1];
-    __shared__ double Bs[kGemmBK][kGemmBN + 2];
+                                                          const double* __restrict__ B, double* __restrict__ C, int64_t row_blocks,
+                                                          int col_blocks, bool vec_ok) {
+    __shared__ double As[2][kGemmBK][kGemmLd];
+    __shared__ double Bs[2][kGemmBK][kGemmLd];
+    // XCD-aware tile assignment
+    const int64_t id = blockIdx.x;
+    const int64_t xcd = id % kXcds, slot = id / kXcds;
+    const int64_t rb = (slot / col_blocks) * kXcds + xcd;
+    const int cb = (int)(slot % col_blocks);
+    if (rb >= row_blocks) return;
+    const int64_t row0 = rb * kGemmBM, col0 = (int64_t)cb * kGemmBN;
+
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int64_t row0 = (int64_t)blockIdx.y * kGemmBM, col0 = (int64_t)blockIdx.x * kGemmBN;
-    d4_t acc[4];
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    d4_t acc[4][4];
 #pragma unroll
-    for (int t = 0; t < 4; t++) acc[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
-    const int ar = tid >> 2, ac = (tid & 3) * 4;   // A tile: 64 rows x 16 cols, 4 doubles per thread
-    const int br = tid >> 4, bc = (tid & 15) * 4;  // B tile: 16 rows x 64 cols, 4 doubles per thread
-    for (int64_t k0 = 0; k0 < K; k0 += kGemmBK) {
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int64_t gr = row0 + ar, gc = k0 + ac + q;
-            As[ar][ac + q] = (gr < M && gc < K) ? A[gr * K + gc] : 0.0;
-            const int64_t hr = k0 + br, hc = col0 + bc + q;
-            Bs[br][bc + q] = (hr < K && hc < N) ? B[hr * N + hc] : 0.0;
-        }
-        __syncthreads();
+        for (int j = 0; j < 4; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+    // global -> register staging: A: row am, 8 consecutive k;  B: row bk, 8 consecutive n
+    const int am = tid & 127, ak = (tid >> 7) * 8;
+    const int bk = tid >> 4, bn = (tid & 15) * 8;
+    const bool interior = vec_ok && row0 + kGemmBM <= M && col0 + kGemmBN <= N;
+    double ra[8], rbv[8];
+    auto fetch = [&](int64_t k0) {
+        if (interior && k0 + kGemmBK <= K) {
+            const double* ap = A + (row0 + am) * K + k0 + ak;
+            const double* bp = B + (k0 + bk) * N + col0 + bn;
 #pragma unroll
-        for (int kk = 0; kk < kGemmBK; kk += 4) {
-            const double a = As[wave * 16 + (lane & 15)][kk + (lane >> 4)];
+            for (int q = 0; q < 8; q += 2) {
+                const double2 va = *reinterpret_cast<const double2*>(ap + q);
+                const double2 vb = *reinterpret_cast<const double2*>(bp + q);
+                ra[q] = va.x; ra[q + 1] = va.y;
+                rbv[q] = vb.x; rbv[q + 1] = vb.y;
+            }
+        } else {
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const double b = Bs[kk + (lane >> 4)][t * 16 + (lane & 15)];
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+            for (int q = 0; q < 8; q++) {
+                const int64_t gr = row0 + am, gk = k0 + ak + q;
+                ra[q] = (gr < M && gk < K) ? A[gr * K + gk] : 0.0;
+                const int64_t hk = k0 + bk, hc = col0 + bn + q;
+                rbv[q] = (hk < K && hc < N) ? B[hk * N + hc] : 0.0;
             }
         }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) As[buf][ak + q][am] = ra[q];
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) *reinterpret_cast<double2*>(&Bs[buf][bk][bn + q]) = make_double2(rbv[q], rbv[q + 1]);
+    };
+
+    const int64_t ktiles = (K + kGemmBK - 1) / kGemmBK;
+    if (ktiles > 0) {
+        fetch(0);
+        stage(0);
+    }
+    __syncthreads();
+    const int fr = lane & 15, fk = lane >> 4;
+    for (int64_t t = 0; t < ktiles; t++) {
+        const int buf = (int)(t & 1);
+        if (t + 1 < ktiles) fetch((t + 1) * kGemmBK);  // in flight during the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < kGemmBK; kk += 4) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = As[buf][kk + fk][wm + i * 16 + fr];
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[j] = Bs[buf][kk + fk][wn + j * 16 + fr];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < ktiles) stage(buf ^ 1);  // the other buffer: its readers finished before the previous barrier
         __syncthreads();
     }
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int64_t row = row0 + wave * 16 + (lane >> 4) + 4 * r, col = col0 + t * 16 + (lane & 15);
-            if (row < M && col < N) C[row * N + col] = acc[t][r];
-        }
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int64_t row = row0 + wm + i * 16 + fk + 4 * r, col = col0 + wn + j * 16 + fr;
+                if (row < M && col < N) C[row * N + col] = acc[i][j][r];
+            }
 }
 
 __global__ __launch_bounds__(kBlock) void leaky_relu_kernel(double* v, double alpha, int64_t n) {
@@ -1315,9 +1373,12 @@ int hnh_gemm_f64(hnh_ctx* ctx, int64_t M, int64_t N, int64_t K, const double* A,
     if (M < 0 || N < 0 || K < 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_gemm_f64: negative size");
     if (M == 0 || N == 0) return HNH_OK;
     if (!C || (K > 0 && (!A || !B))) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_gemm_f64: null pointer");
-    const int64_t gy = (M + kGemmBM - 1) / kGemmBM, gx = (N + kGemmBN - 1) / kGemmBN;
-    if (gy > 65535 * 1024LL || gx > 0x7fffffffLL) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "hnh_gemm_f64: matrix too large");
-    hipLaunchKernelGGL(gemm_f64_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, ctx->streams[stream], M, N, K, A, B, C);
+    const int64_t row_blocks = (M + kGemmBM - 1) / kGemmBM, col_blocks = (N + kGemmBN - 1) / kGemmBN;
+    const int64_t grid = ((row_blocks + kXcds - 1) / kXcds) * kXcds * col_blocks;  // row blocks padded to whole XCD rounds
+    if (grid > 0x7fffffffLL || col_blocks > 0x7fffffffLL) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "hnh_gemm_f64: matrix too large");
+    const bool vec_ok = (K % 2 == 0) && (N % 2 == 0) && aligned16(A) && aligned16(B);
+    hipLaunchKernelGGL(gemm_f64_kernel, dim3((unsigned)grid), dim3(kBlock), 0, ctx->streams[stream], M, N, K, A, B, C, row_blocks,
+                       (int)col_blocks, vec_ok);
     return hnh::check_hip(ctx, hipGetLastError(), "gemm_f64_kernel launch");
 }
 

@@ -185,7 +185,7 @@ def test_rowwise_als_helpers(ctx, R):
     assert np.array_equal(dout.get(), (yv + 1e-8) / xv)
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (100, 37, 29), (513, 130, 70), (1000, 256, 256), (16, 8, 1024), (5, 3, 1)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (100, 37, 29), (513, 130, 70), (1000, 256, 256), (16, 8, 1024), (5, 3, 1), (2100, 300, 72), (4096, 256, 1024), (129, 129, 17)])
 def test_gemm_f64_mfma(ctx, M, N, K):
     """hnh_gemm_f64 (v_mfma_f64_16x16x4_f64, gat.hpp:88) vs numpy; asymmetric operands catch row/col swaps."""
     lib = ctx.lib
