@@ -49,6 +49,10 @@ SIGNATURES = {
     "hnh_fused_sddmm_spmm_csr_multi_x": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, C.c_uint, _vp, _i32]),
     "hnh_row_epilogue_f64": (_i32, [_vp, _vp, _vp, C.c_double, _vp, _i64, _i32, _i32]),
     "hnh_cg_step_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
+    "hnh_tuples_sort": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32]),
+    "hnh_tuples_bucket_starts": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i32]),
+    "hnh_tuples_transform": (_i32, [_vp, _vp, _i64, _i32, C.c_uint64, C.c_uint64, _i32]),
+    "hnh_tuples_to_csr": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(C.c_int), _i32]),
     "hnh_fill_f64": (_i32, [_vp, _vp, _i64, _dbl, _i32]),
     "hnh_hadamard_f64": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32]),
     "hnh_axpy_f64": (_i32, [_vp, _vp, _vp, _dbl, _i64, _i32]),
@@ -76,6 +80,16 @@ SIGNATURES = {
 class FusedExtras(C.Structure):
     """struct hnh_fused_extras"""
     _fields_ = [("leaky_alpha", C.c_double), ("x_scale", C.c_double), ("rowdot", C.c_void_p)]
+
+
+class TupleKey(C.Structure):
+    """struct hnh_tuple_key"""
+    _fields_ = [("kind", C.c_int), ("transpose", C.c_int), ("rows_in_block", C.c_int64), ("cols_in_block", C.c_int64),
+                ("n_col_blocks", C.c_int64), ("owner_table", C.c_void_p), ("div", C.c_int64)]
+
+
+KEY_ROW_COL, KEY_COL_ROW, KEY_OWNER, KEY_COL_DIV = 0, 1, 2, 3
+TUPLE_DTYPE = [("r", "<u8"), ("c", "<u8"), ("value", "<f8")]  # struct hnh_tuple
 
 
 class CsrBlock(C.Structure):

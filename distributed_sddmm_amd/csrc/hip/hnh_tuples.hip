@@ -1,0 +1,252 @@
+// Setup pipeline on the device: the (row, col, value) tuples of the sparse matrix are routed, ordered and turned
+// into CSR blocks without going back to the host (hnh_tuples_* of include/hnh_kernels.h).
+//
+// What this replaces in the reference (all host code, SpmatLocal.hpp): getOwner + the Alltoallv pack (:45-52,
+// :404-420), std::sort(column_major) (:454), divideIntoBlockCols (:541-563), and the MKL COO -> CSR conversion in the
+// CSRLocal constructor (:117-147).  At config-2 size (1e8 tuples, twice: S and S^T) those are ~9 s of host time on a
+// 256-thread box; here they are radix sorts over 64-bit keys (rocPRIM, ~10 ms each on MI355X), a few streaming
+// kernels, and binary searches for the bucket boundaries.
+//
+// Sorting 24-byte tuples: sort (key, index) pairs, then gather the tuples through the permutation — the radix
+// passes then move 12 bytes per element instead of 32.  Every sort is stable (LSD radix), which is what lets the
+// callers compose orders (e.g. CSR order inside column blocks).
+#include <cstring>  // rocPRIM's texture iterator uses memset without including it
+
+#include <rocprim/rocprim.hpp>
+
+#include "hnh_ctx.hpp"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct KeyDesc {
+    int kind, transpose;
+    long long rows_in_block, cols_in_block, n_col_blocks, div;
+    const int32_t* owner_table;
+};
+
+__device__ __forceinline__ unsigned long long key_of(const hnh_tuple& t, const KeyDesc& k) {
+    switch (k.kind) {
+        case HNH_KEY_ROW_COL: return (t.r << 32) | (t.c & 0xffffffffull);
+        case HNH_KEY_COL_ROW: return (t.c << 32) | (t.r & 0xffffffffull);
+        case HNH_KEY_OWNER: {
+            const unsigned long long rb = (k.transpose ? t.c : t.r) / (unsigned long long)k.rows_in_block;
+            const unsigned long long cb = (k.transpose ? t.r : t.c) / (unsigned long long)k.cols_in_block;
+            return (unsigned long long)(unsigned)k.owner_table[rb * (unsigned long long)k.n_col_blocks + cb];
+        }
+        default: return t.c / (unsigned long long)k.div;  // HNH_KEY_COL_DIV
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void make_keys_kernel(const hnh_tuple* __restrict__ t, long long n, KeyDesc k,
+                                                           unsigned long long* __restrict__ keys, unsigned* __restrict__ idx,
+                                                           int* __restrict__ bad) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const hnh_tuple v = t[i];
+        if ((k.kind == HNH_KEY_ROW_COL || k.kind == HNH_KEY_COL_ROW) && ((v.r >> 32) != 0 || (v.c >> 32) != 0)) *bad = 1;
+        keys[i] = key_of(v, k);
+        idx[i] = (unsigned)i;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void gather_kernel(const hnh_tuple* __restrict__ src, const unsigned* __restrict__ perm, long long n,
+                                                        hnh_tuple* __restrict__ dst) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) dst[i] = src[perm[i]];
+}
+
+// starts[b] = first index whose key is >= b, b = 0 .. nbuckets (keys non-decreasing)
+__global__ __launch_bounds__(kBlock) void bucket_starts_kernel(const hnh_tuple* __restrict__ t, long long n, KeyDesc k, long long nbuckets,
+                                                               long long* __restrict__ starts) {
+    const long long b = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (b > nbuckets) return;
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (key_of(t[mid], k) < (unsigned long long)b) lo = mid + 1;
+        else hi = mid;
+    }
+    starts[b] = lo;
+}
+
+__global__ __launch_bounds__(kBlock) void transform_kernel(hnh_tuple* t, long long n, int swap_rc, unsigned long long rmod,
+                                                           unsigned long long cmod) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        hnh_tuple v = t[i];
+        if (swap_rc) { const unsigned long long x = v.r; v.r = v.c; v.c = x; }
+        if (rmod) v.r %= rmod;
+        if (cmod) v.c %= cmod;
+        t[i] = v;
+    }
+}
+
+// tuples in (row, col) order -> col_idx / values; rowptr[r] = first tuple of row >= r (binary search per row);
+// max_row[0] = longest row; bad[0] = 1 when a tuple lies outside rows x cols
+__global__ __launch_bounds__(kBlock) void unzip_kernel(const hnh_tuple* __restrict__ t, long long n, long long rows, long long cols,
+                                                       int32_t* __restrict__ col_idx, double* __restrict__ values, int* __restrict__ bad) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const hnh_tuple v = t[i];
+        if ((long long)v.r >= rows || (long long)v.c >= cols) *bad = 1;
+        col_idx[i] = (int32_t)v.c;
+        values[i] = v.value;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void rowptr_kernel(const hnh_tuple* __restrict__ t, long long n, long long rows,
+                                                        int32_t* __restrict__ rowptr) {
+    const long long r = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (r > rows) return;
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if ((long long)t[mid].r < r) lo = mid + 1;
+        else hi = mid;
+    }
+    rowptr[r] = (int32_t)lo;
+}
+
+__global__ __launch_bounds__(kBlock) void max_row_kernel(const int32_t* __restrict__ rowptr, long long rows, int* __restrict__ out) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    int m = 0;
+    for (long long r = (long long)blockIdx.x * kBlock + threadIdx.x; r < rows; r += stride) m = max(m, rowptr[r + 1] - rowptr[r]);
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+}
+
+unsigned grid_for(long long n) {
+    long long b = (n + kBlock - 1) / kBlock;
+    if (b < 1) b = 1;
+    if (b > 256 * 32) b = 256 * 32;  // grid-stride beyond 32 workgroups per CU
+    return (unsigned)b;
+}
+
+int desc_from(hnh_ctx* ctx, const hnh_tuple_key* key, KeyDesc* d, const char* who) {
+    if (!key) return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": null key");
+    d->kind = key->kind; d->transpose = key->transpose;
+    d->rows_in_block = key->rows_in_block; d->cols_in_block = key->cols_in_block; d->n_col_blocks = key->n_col_blocks;
+    d->div = key->div; d->owner_table = key->owner_table;
+    switch (key->kind) {
+        case HNH_KEY_ROW_COL: case HNH_KEY_COL_ROW: return HNH_OK;
+        case HNH_KEY_OWNER:
+            if (key->rows_in_block <= 0 || key->cols_in_block <= 0 || key->n_col_blocks <= 0 || !key->owner_table)
+                return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": incomplete owner key");
+            return HNH_OK;
+        case HNH_KEY_COL_DIV:
+            if (key->div <= 0) return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": column divisor must be positive");
+            return HNH_OK;
+        default: return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": unknown key kind");
+    }
+}
+
+struct Scratch {  // frees on scope exit (setup path: plain hipMalloc / hipFree, synchronised by the caller's stream sync)
+    void* p = nullptr;
+    ~Scratch() { if (p) (void)hipFree(p); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int hnh_tuples_sort(hnh_ctx* ctx, hnh_tuple* tuples, int64_t n, const hnh_tuple_key* key, int key_bits, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (n < 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_sort: negative size");
+    KeyDesc d;
+    if (int rc = desc_from(ctx, key, &d, "hnh_tuples_sort")) return rc;
+    if (n <= 1) return HNH_OK;
+    if (!tuples) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_sort: null pointer");
+    if (n > 0xffffffffLL) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "hnh_tuples_sort: more than 2^32 tuples in one call");
+    if (key_bits <= 0 || key_bits > 64) key_bits = 64;
+    hipStream_t st = ctx->streams[stream];
+    const size_t un = (size_t)n;
+    size_t tmp_bytes = 0;
+    HNH_TRY_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                               (unsigned*)nullptr, (unsigned*)nullptr, un, 0, (unsigned)key_bits, st));
+    // one allocation: keys in/out, index in/out, flag, radix scratch, tuple copy
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_k0 = 0, o_k1 = o_k0 + align(un * 8), o_i0 = o_k1 + align(un * 8), o_i1 = o_i0 + align(un * 4), o_bad = o_i1 + align(un * 4),
+                 o_tmp = o_bad + 256, o_cp = o_tmp + align(tmp_bytes), total = o_cp + align(un * sizeof(hnh_tuple));
+    Scratch s;
+    HNH_TRY_HIP(ctx, hipMalloc(&s.p, total));
+    char* base = static_cast<char*>(s.p);
+    auto* k0 = reinterpret_cast<unsigned long long*>(base + o_k0);
+    auto* k1 = reinterpret_cast<unsigned long long*>(base + o_k1);
+    auto* i0 = reinterpret_cast<unsigned*>(base + o_i0);
+    auto* i1 = reinterpret_cast<unsigned*>(base + o_i1);
+    int* bad = reinterpret_cast<int*>(base + o_bad);
+    auto* cp = reinterpret_cast<hnh_tuple*>(base + o_cp);
+    HNH_TRY_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(int), st));
+    hipLaunchKernelGGL(make_keys_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, tuples, (long long)n, d, k0, i0, bad);
+    HNH_TRY_HIP(ctx, hipGetLastError());
+    HNH_TRY_HIP(ctx, rocprim::radix_sort_pairs(base + o_tmp, tmp_bytes, k0, k1, i0, i1, un, 0, (unsigned)key_bits, st));
+    HNH_TRY_HIP(ctx, hipMemcpyAsync(cp, tuples, un * sizeof(hnh_tuple), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(gather_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, cp, i1, (long long)n, tuples);
+    HNH_TRY_HIP(ctx, hipGetLastError());
+    int h_bad = 0;
+    HNH_TRY_HIP(ctx, hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    HNH_TRY_HIP(ctx, hipStreamSynchronize(st));  // scratch dies with this scope
+    if (h_bad) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "hnh_tuples_sort: a row or column index does not fit 32 bits");
+    return HNH_OK;
+}
+
+int hnh_tuples_bucket_starts(hnh_ctx* ctx, const hnh_tuple* sorted, int64_t n, const hnh_tuple_key* key, int64_t nbuckets,
+                             int64_t* starts_host, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (n < 0 || nbuckets < 0 || !starts_host) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_bucket_starts: bad argument");
+    KeyDesc d;
+    if (int rc = desc_from(ctx, key, &d, "hnh_tuples_bucket_starts")) return rc;
+    if (n == 0) {
+        for (int64_t b = 0; b <= nbuckets; b++) starts_host[b] = 0;
+        return HNH_OK;
+    }
+    if (!sorted) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_bucket_starts: null pointer");
+    hipStream_t st = ctx->streams[stream];
+    Scratch s;
+    HNH_TRY_HIP(ctx, hipMalloc(&s.p, (size_t)(nbuckets + 1) * sizeof(long long)));
+    hipLaunchKernelGGL(bucket_starts_kernel, dim3((unsigned)((nbuckets + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sorted, (long long)n,
+                       d, (long long)nbuckets, static_cast<long long*>(s.p));
+    HNH_TRY_HIP(ctx, hipGetLastError());
+    static_assert(sizeof(long long) == sizeof(int64_t), "int64_t layout");
+    HNH_TRY_HIP(ctx, hipMemcpyAsync(starts_host, s.p, (size_t)(nbuckets + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    return hnh::check_hip(ctx, hipStreamSynchronize(st), "hipStreamSynchronize");
+}
+
+int hnh_tuples_transform(hnh_ctx* ctx, hnh_tuple* tuples, int64_t n, int swap_rc, uint64_t rmod, uint64_t cmod, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (n < 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_transform: negative size");
+    if (n == 0 || (!swap_rc && !rmod && !cmod)) return HNH_OK;
+    if (!tuples) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_transform: null pointer");
+    hipLaunchKernelGGL(transform_kernel, dim3(grid_for(n)), dim3(kBlock), 0, ctx->streams[stream], tuples, (long long)n, swap_rc,
+                       (unsigned long long)rmod, (unsigned long long)cmod);
+    return hnh::check_hip(ctx, hipGetLastError(), "transform_kernel launch");
+}
+
+int hnh_tuples_to_csr(hnh_ctx* ctx, const hnh_tuple* sorted, int64_t n, int64_t rows, int64_t cols, int32_t* rowptr, int32_t* col_idx,
+                      double* values, int* max_row_nnz_host, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (n < 0 || rows < 0 || cols < 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_to_csr: negative size");
+    if (n > 0x7fffffffLL) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "hnh_tuples_to_csr: block has more than 2^31 nonzeros");
+    if (!rowptr || (n > 0 && (!sorted || !col_idx || !values))) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_to_csr: null pointer");
+    hipStream_t st = ctx->streams[stream];
+    Scratch s;
+    HNH_TRY_HIP(ctx, hipMalloc(&s.p, 2 * sizeof(int)));
+    int* flags = static_cast<int*>(s.p);  // [0] = bad tuple, [1] = longest row
+    HNH_TRY_HIP(ctx, hipMemsetAsync(flags, 0, 2 * sizeof(int), st));
+    if (n > 0) hipLaunchKernelGGL(unzip_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, sorted, (long long)n, (long long)rows, (long long)cols,
+                                  col_idx, values, flags);
+    hipLaunchKernelGGL(rowptr_kernel, dim3((unsigned)((rows + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sorted, (long long)n,
+                       (long long)rows, rowptr);
+    if (rows > 0) hipLaunchKernelGGL(max_row_kernel, dim3(grid_for(rows)), dim3(kBlock), 0, st, rowptr, (long long)rows, flags + 1);
+    HNH_TRY_HIP(ctx, hipGetLastError());
+    int h[2] = {0, 0};
+    HNH_TRY_HIP(ctx, hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, st));
+    HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
+    if (h[0]) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_to_csr: nonzero outside its block");
+    if (max_row_nnz_host) *max_row_nnz_host = h[1];
+    return HNH_OK;
+}
+
+}  // extern "C"

@@ -66,31 +66,23 @@ public:
 
         nnz_in_row_axis.resize(sqrtpc);
         nnz_in_row_axis_tpose.resize(sqrtpc);
-        int my_nnz = (int)S->coords.size(), my_nnz_tpose = (int)ST->coords.size();
+        int my_nnz = (int)S->num_tuples(), my_nnz_tpose = (int)ST->num_tuples();
         world->host_allgather_comm(grid->row_world, &my_nnz, nnz_in_row_axis.data(), sizeof(int));
         world->host_allgather_comm(grid->row_world, &my_nnz_tpose, nnz_in_row_axis_tpose.data(), sizeof(int));
         const int max_nnz = *std::max_element(nnz_in_row_axis.begin(), nnz_in_row_axis.end());
         const int max_nnz_tpose = *std::max_element(nnz_in_row_axis_tpose.begin(), nnz_in_row_axis_tpose.end());
 
         const uint64_t ar = (uint64_t)localArows * c, br = (uint64_t)localBrows * c;
-#pragma omp parallel for
-        for (size_t e = 0; e < S->coords.size(); e++) {
-            S->coords[e].r %= ar;
-            S->coords[e].c %= (uint64_t)localBrows;
-        }
-#pragma omp parallel for
-        for (size_t e = 0; e < ST->coords.size(); e++) {
-            ST->coords[e].r %= br;
-            ST->coords[e].c %= (uint64_t)localArows;
-        }
+        S->localize(ar, (uint64_t)localBrows);
+        ST->localize(br, (uint64_t)localArows);
         S->own_all_coordinates();
         ST->own_all_coordinates();
         S->monolithBlockColumn();
         ST->monolithBlockColumn();
         S->initializeCSRBlocks(localArows * c, localBrows, max_nnz, true);
-        std::vector<spcoord_t>().swap(S->coords);
+        S->release_tuples();
         ST->initializeCSRBlocks(localBrows * c, localArows, max_nnz_tpose, true);
-        std::vector<spcoord_t>().swap(ST->coords);
+        ST->release_tuples();
 
         publish_ring_max_row(S.get(), grid->row_world);
         publish_ring_max_row(ST.get(), grid->row_world);

@@ -34,10 +34,7 @@ public:
     VectorXd value_buffer;  // the reference's per-call `accumulation_buffer` (length = all nonzeros of the block)
 
     void broadcastCoordinatesFromFloor(std::unique_ptr<SpmatLocal>& spmat) {
-        int num_nnz = (int)spmat->coords.size();
-        world->host_bcast(grid->fiber_world, 0, &num_nnz, sizeof(int));
-        if (grid->rankInFiber > 0) spmat->coords.resize(num_nnz);
-        world->host_bcast(grid->fiber_world, 0, spmat->coords.data(), spmat->coords.size() * sizeof(spcoord_t));
+        spmat->broadcast_tuples(grid->fiber_world, 0);
     }
 
     Sparse25D_Cannon_Sparse(SpmatLocal* S_input, int R, int c, KernelImplementation* k) : Distributed_Sparse(k) {
@@ -73,24 +70,16 @@ public:
         S->shard_across_layers(c, grid->k);
         ST->shard_across_layers(c, grid->k);
 
-#pragma omp parallel for
-        for (size_t e = 0; e < S->coords.size(); e++) {
-            S->coords[e].r %= (uint64_t)localArows;
-            S->coords[e].c %= (uint64_t)localBrows;
-        }
-#pragma omp parallel for
-        for (size_t e = 0; e < ST->coords.size(); e++) {
-            ST->coords[e].r %= (uint64_t)localBrows;
-            ST->coords[e].c %= (uint64_t)localArows;
-        }
+        S->localize((uint64_t)localArows, (uint64_t)localBrows);
+        ST->localize((uint64_t)localBrows, (uint64_t)localArows);
         S->monolithBlockColumn();
         ST->monolithBlockColumn();
         S->initializeCSRBlocks(localArows, localBrows, -1, false);
-        nnz = (int)S->coords.size();
-        std::vector<spcoord_t>().swap(S->coords);
+        nnz = (int)S->num_tuples();
+        S->release_tuples();
         ST->initializeCSRBlocks(localBrows, localArows, -1, false);
-        nnz_tpose = (int)ST->coords.size();
-        std::vector<spcoord_t>().swap(ST->coords);
+        nnz_tpose = (int)ST->num_tuples();
+        ST->release_tuples();
         check_initialized();
     }
 

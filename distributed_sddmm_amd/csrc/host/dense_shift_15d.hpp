@@ -80,11 +80,9 @@ public:
         setRValue(R);
 
         const uint64_t arows = (uint64_t)localArows * c, brows = (uint64_t)localBrows * c;
-#pragma omp parallel for
-        for (size_t e = 0; e < S->coords.size(); e++) S->coords[e].r %= arows;
+        S->localize(arows, 0);
         S->divideIntoBlockCols(localBrows, p, true);
-#pragma omp parallel for
-        for (size_t e = 0; e < ST->coords.size(); e++) ST->coords[e].r %= brows;
+        ST->localize(brows, 0);
         ST->divideIntoBlockCols(localArows, p, true);
 
         S->own_all_coordinates();
@@ -92,9 +90,9 @@ public:
 
         const bool local_tpose = (fusionApproach == 1);
         S->initializeCSRBlocks(localArows * c, localBrows, -1, local_tpose);
-        std::vector<spcoord_t>().swap(S->coords);
+        S->release_tuples();
         ST->initializeCSRBlocks(localBrows * c, localArows, -1, local_tpose);
-        std::vector<spcoord_t>().swap(ST->coords);
+        ST->release_tuples();
         check_initialized();
     }
 

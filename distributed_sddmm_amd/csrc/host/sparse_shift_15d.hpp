@@ -60,15 +60,13 @@ public:
         localBrows = blockBwidth * p / c;
         setRValue(R);
 
-#pragma omp parallel for
-        for (size_t e = 0; e < S->coords.size(); e++) S->coords[e].r %= (uint64_t)blockAwidth;
-#pragma omp parallel for
-        for (size_t e = 0; e < ST->coords.size(); e++) ST->coords[e].r %= (uint64_t)blockBwidth;
+        S->localize((uint64_t)blockAwidth, 0);
+        ST->localize((uint64_t)blockBwidth, 0);
 
         const int n = p / c;
         nnz_in_row_axis.resize(n);
         nnz_in_row_axis_tpose.resize(n);
-        int my_nnz = (int)S->coords.size(), my_nnz_tpose = (int)ST->coords.size();
+        int my_nnz = (int)S->num_tuples(), my_nnz_tpose = (int)ST->num_tuples();
         world->host_allgather_comm(grid->col_world, &my_nnz, nnz_in_row_axis.data(), sizeof(int));
         world->host_allgather_comm(grid->col_world, &my_nnz_tpose, nnz_in_row_axis_tpose.data(), sizeof(int));
         const int max_nnz = *std::max_element(nnz_in_row_axis.begin(), nnz_in_row_axis.end());
@@ -83,9 +81,9 @@ public:
         // passes localArows / localBrows the other way round, which is only right for square S —
         // 15D_sparse_shift.hpp:132,134, SURVEY Appendix C #7.)
         S->initializeCSRBlocks(blockAwidth, localBrows * c, max_nnz, false);
-        std::vector<spcoord_t>().swap(S->coords);
+        S->release_tuples();
         ST->initializeCSRBlocks(blockBwidth, localArows * c, max_nnz_tpose, false);
-        std::vector<spcoord_t>().swap(ST->coords);
+        ST->release_tuples();
         publish_ring_max_row(S.get(), grid->col_world);
         publish_ring_max_row(ST.get(), grid->col_world);
         if (std::getenv("HNH_SHIP_INDICES") == nullptr) {  // default: the ring's sparsity structure stays resident, values travel

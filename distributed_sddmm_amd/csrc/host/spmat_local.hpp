@@ -73,6 +73,50 @@ public:
     };
     std::vector<RingIndex> ring_index;  // by ring position of the block's origin; empty = indices travel (reference behaviour)
 
+    // Device build (the default): `dev_tuples` are this block's tuples in DEVICE memory, in any order.  One
+    // radix sort into CSR order and one unzip pass; like the reference's constructor, the caller's tuples end up in CSR
+    // order (and transposed when `transpose`), SpmatLocal.hpp:139-147.
+    struct FromDevice {};
+    CSRLocal(FromDevice, int64_t blockRows, int64_t blockCols, int64_t max_nnz_in, spcoord_t* dev_tuples, int num_coords_in,
+             bool transpose_in, bool shifting_in = true)
+        : rows(blockRows), cols(blockCols), max_nnz((int)max_nnz_in), num_coords(num_coords_in), transpose(transpose_in),
+          active(0), shifting(shifting_in), world(hnh::current_world()) {
+        if (num_coords > max_nnz) hnh::fatal("Error, block holds more nonzeros than its padded capacity!");
+        hnh::PhaseTimer pt_all("CSRLocal ctor (device)");
+        hnh::Backend* be = world->be;
+        hnh_tuple* t = reinterpret_cast<hnh_tuple*>(dev_tuples);
+        if (transpose) {
+            std::swap(rows, cols);
+            world->check(be->hnh_tuples_transform(world->ctx, t, num_coords, 1, 0, 0, HNH_STREAM_COMPUTE), "hnh_tuples_transform");
+        }
+        hnh_tuple_key key{};
+        key.kind = HNH_KEY_ROW_COL;
+        int row_bits = 1;
+        while (row_bits < 32 && ((int64_t)1 << row_bits) < rows) row_bits++;
+        world->check(be->hnh_tuples_sort(world->ctx, t, num_coords, &key, 32 + row_bits, HNH_STREAM_COMPUTE), "hnh_tuples_sort");
+        allocate_buffers();
+        world->check(be->hnh_tuples_to_csr(world->ctx, t, num_coords, rows, cols, buffer[0].rowStart, buffer[0].col_idx, buffer[0].values,
+                                           &max_row_nnz, HNH_STREAM_COMPUTE),
+                     "hnh_tuples_to_csr (nonzero outside its block?)");
+        ring_max_row_nnz = max_row_nnz;
+        if (shifting) {
+            world->copy(buffer[1].values, buffer[0].values, (size_t)num_coords * sizeof(double), HNH_COPY_D2D, HNH_STREAM_COMPUTE);
+            world->copy(buffer[1].col_idx, buffer[0].col_idx, (size_t)num_coords * sizeof(int32_t), HNH_COPY_D2D, HNH_STREAM_COMPUTE);
+            world->copy(buffer[1].rowStart, buffer[0].rowStart, ((size_t)rows + 1) * sizeof(int32_t), HNH_COPY_D2D, HNH_STREAM_COMPUTE);
+        }
+    }
+
+    void allocate_buffers() {
+        buffer = new CSRHandle[2];
+        const size_t cap = (size_t)std::max(max_nnz, 1);
+        for (int t = 0; t < (shifting ? 2 : 1); t++) {
+            buffer[t].values = static_cast<double*>(world->dmalloc(cap * sizeof(double)));
+            buffer[t].col_idx = static_cast<int32_t*>(world->dmalloc(cap * sizeof(int32_t)));
+            buffer[t].rowStart = static_cast<int32_t*>(world->dmalloc(((size_t)rows + 1) * sizeof(int32_t)));
+        }
+    }
+
+    // Host build (HNH_HOST_SETUP=1; the reference's constructor restated): `coords` are HOST tuples.
     CSRLocal(int64_t blockRows, int64_t blockCols, int64_t max_nnz_in, spcoord_t* coords, int num_coords_in, bool transpose_in,
              bool shifting_in = true)
         : rows(blockRows), cols(blockCols), max_nnz((int)max_nnz_in), num_coords(num_coords_in), transpose(transpose_in),
@@ -118,13 +162,8 @@ public:
             val[e] = sorted[e].value;
         }
 
-        buffer = new CSRHandle[2];
-        const size_t cap = (size_t)std::max(max_nnz, 1);
+        allocate_buffers();
         for (int t = 0; t < (shifting ? 2 : 1); t++) {
-            // one allocation per buffer: [values | col_idx | rowStart], each part 256-byte aligned
-            buffer[t].values = static_cast<double*>(world->dmalloc(cap * sizeof(double)));
-            buffer[t].col_idx = static_cast<int32_t*>(world->dmalloc(cap * sizeof(int32_t)));
-            buffer[t].rowStart = static_cast<int32_t*>(world->dmalloc(((size_t)rows + 1) * sizeof(int32_t)));
             world->copy(buffer[t].values, val.data(), (size_t)num_coords * sizeof(double), HNH_COPY_H2D, HNH_STREAM_COMPUTE);
             world->copy(buffer[t].col_idx, col.data(), (size_t)num_coords * sizeof(int32_t), HNH_COPY_H2D, HNH_STREAM_COMPUTE);
             world->copy(buffer[t].rowStart, rowStart.data(), ((size_t)rows + 1) * sizeof(int32_t), HNH_COPY_H2D, HNH_STREAM_COMPUTE);
@@ -229,7 +268,60 @@ public:
 
 class SpmatLocal {
 public:
-    std::vector<spcoord_t> coords;  // unzipped tuples (host)
+    std::vector<spcoord_t> coords;  // unzipped tuples (host): what loaders / generators fill, and the HNH_HOST_SETUP=1 pipeline
+
+    // Setup on the device (default).  redistribute_nonzeros() uploads the input's tuples once and its
+    // result is DEVICE-RESIDENT: owner routing, the all-to-all, the column-major sort, the block-column split, index
+    // localisation and the CSR conversion all run on the GPU (hnh_tuples_* of hnh_kernels.h) and `coords` stays empty.
+    hnh::DeviceArray dcoords;
+    bool resident = false;
+    size_t n_resident = 0;
+    size_t num_tuples() const { return resident ? n_resident : coords.size(); }
+    hnh_tuple* dptr() const { return static_cast<hnh_tuple*>(dcoords.ptr()); }
+    static bool device_setup() { return std::getenv("HNH_HOST_SETUP") == nullptr; }
+    static_assert(sizeof(spcoord_t) == sizeof(hnh_tuple), "spcoord_t must have the layout of hnh_tuple");
+
+    // r %= rmod, c %= cmod (0 = leave): the "make indices block-local" loops of the schedule constructors
+    // (15D_dense_shift.hpp:96-100, 25D_cannon_dense.hpp:117-125)
+    void localize(uint64_t rmod, uint64_t cmod) {
+        if (resident) {
+            world->check(world->be->hnh_tuples_transform(world->ctx, dptr(), (int64_t)n_resident, 0, rmod, cmod, HNH_STREAM_COMPUTE),
+                         "hnh_tuples_transform");
+            return;
+        }
+#pragma omp parallel for
+        for (size_t e = 0; e < coords.size(); e++) {
+            if (rmod) coords[e].r %= rmod;
+            if (cmod) coords[e].c %= cmod;
+        }
+    }
+
+    // the schedules drop the tuples once the CSR blocks exist
+    void release_tuples() {
+        std::vector<spcoord_t>().swap(coords);
+        if (resident) world->sync(HNH_STREAM_COMPUTE);
+        dcoords.reset();
+        resident = false;
+        n_resident = 0;
+    }
+
+    // Replicates root's tuples over `comm` (2.5D sparse replication: bottom face -> fibers, 25D_cannon_sparse.hpp:67-77)
+    void broadcast_tuples(const hnh::Comm& comm, int root) {
+        hnh::World* w = world;
+        int n = (int)num_tuples();
+        w->host_bcast(comm, root, &n, sizeof(int));
+        if (resident) {
+            if (comm.me != root) {
+                dcoords = hnh::DeviceArray(w, (size_t)n * sizeof(spcoord_t));
+                n_resident = (size_t)n;
+            }
+            w->sync(HNH_STREAM_COMPUTE);
+            w->device_bcast(comm, root, dcoords.ptr(), (size_t)n * sizeof(spcoord_t), HNH_STREAM_COMM);
+        } else {
+            if (comm.me != root) coords.resize((size_t)n);
+            w->host_bcast(comm, root, coords.data(), coords.size() * sizeof(spcoord_t));
+        }
+    }
 
     uint64_t M = 0, N = 0, dist_nnz = 0;  // global properties
     bool initialized;
@@ -253,6 +345,22 @@ public:
     // One CSRLocal per non-empty block column (max_nnz == -1; stationary), or a single padded block
     // that will travel around a ring (SpmatLocal.hpp:314-338).
     void initializeCSRBlocks(int blockRows, int blockCols, int max_nnz, bool transpose) {
+        if (resident) {
+            if (max_nnz == -1) {
+                for (size_t i = 0; i + 1 < blockStarts.size(); i++) {
+                    const int n = (int)(blockStarts[i + 1] - blockStarts[i]);
+                    csr_blocks.push_back(n > 0 ? new CSRLocal(CSRLocal::FromDevice(), blockRows, blockCols, n,
+                                                              reinterpret_cast<spcoord_t*>(dptr() + blockStarts[i]), n, transpose, false)
+                                               : nullptr);
+                }
+            } else {
+                const int n = (int)(blockStarts[1] - blockStarts[0]);
+                csr_blocks.push_back(new CSRLocal(CSRLocal::FromDevice(), blockRows, blockCols, max_nnz, reinterpret_cast<spcoord_t*>(dptr()), n,
+                                                  transpose, true));
+            }
+            csr_initialized = true;
+            return;
+        }
         if (max_nnz == -1) {
             for (size_t i = 0; i + 1 < blockStarts.size(); i++) {
                 const int n = (int)(blockStarts[i + 1] - blockStarts[i]);
@@ -268,14 +376,14 @@ public:
 
     void own_all_coordinates() {
         owned_coords_start = 0;
-        owned_coords_end = (int)coords.size();
-        layer_coords_start = {0, (int)coords.size()};
-        layer_coords_sizes = {(int)coords.size()};
+        owned_coords_end = (int)num_tuples();
+        layer_coords_start = {0, (int)num_tuples()};
+        layer_coords_sizes = {(int)num_tuples()};
         coordinate_ownership_initialized = true;
     }
 
     void shard_across_layers(int num_layers, int current_layer) {
-        divideIntoSegments((int)coords.size(), num_layers, layer_coords_start, layer_coords_sizes);
+        divideIntoSegments((int)num_tuples(), num_layers, layer_coords_start, layer_coords_sizes);
         owned_coords_start = layer_coords_start[current_layer];
         owned_coords_end = layer_coords_start[current_layer + 1];
         coordinate_ownership_initialized = true;
@@ -284,6 +392,8 @@ public:
     // Routes every tuple to its owner under `dist` (optionally transposing), all-to-all, then sorts the
     // received tuples column-major (SpmatLocal.hpp:389-462).
     SpmatLocal* redistribute_nonzeros(NonzeroDistribution* dist, bool transpose, bool in_place) {
+        if (device_setup()) return redistribute_on_device(dist, transpose, in_place);
+        if (resident) hnh::fatal("Error, the host setup path cannot take device-resident tuples!");
         hnh::World* w = dist->world ? dist->world : world;
         const int p = w->size;
         hnh::PhaseTimer pt_all("redistribute_nonzeros");
@@ -339,6 +449,90 @@ public:
         return result;
     }
 
+    // The same routing on the GPU.  The owner of a tuple is a table lookup (the distribution's blockOwner() evaluated once
+    // per block on the host); tuples are radix-sorted by owner, which is the Alltoallv pack; boundaries between owners
+    // come from binary searches; the exchange moves device buffers peer to peer; the received tuples are radix-sorted
+    // column-major.  The input (host tuples of a loader, or an already resident matrix) is left untouched.
+    SpmatLocal* redistribute_on_device(NonzeroDistribution* dist, bool transpose, bool in_place) {
+        hnh::World* w = dist->world ? dist->world : world;
+        hnh::Backend* be = w->be;
+        const int p = w->size;
+        hnh::PhaseTimer pt_all("redistribute_nonzeros (device)");
+        hnh::PhaseTimer* pt = new hnh::PhaseTimer("  redist: upload + owner sort");
+        const size_t n = num_tuples();
+        const uint64_t newM = transpose ? N : M, newN = transpose ? M : N;
+
+        hnh::DeviceArray work(w, std::max<size_t>(n, 1) * sizeof(spcoord_t));
+        if (n) w->copy(work.ptr(), resident ? dcoords.ptr() : (const void*)coords.data(), n * sizeof(spcoord_t),
+                       resident ? HNH_COPY_D2D : HNH_COPY_H2D, HNH_STREAM_COMPUTE);
+        hnh_tuple* wt = static_cast<hnh_tuple*>(work.ptr());
+
+        const int64_t rib = dist->rows_in_block, cib = dist->cols_in_block;
+        if (rib <= 0 || cib <= 0) hnh::fatal("Error, nonzero distribution has empty blocks!");
+        const int64_t nrb = std::max<int64_t>(1, ((int64_t)newM + rib - 1) / rib), ncb = std::max<int64_t>(1, ((int64_t)newN + cib - 1) / cib);
+        std::vector<int32_t> table((size_t)(nrb * ncb));
+        for (int64_t rb = 0; rb < nrb; rb++)
+            for (int64_t cb = 0; cb < ncb; cb++) {
+                const int o = dist->blockOwner((int)rb, (int)cb);
+                if (o < 0 || o >= p) hnh::fatal("Error, nonzero distribution produced an invalid owner!");
+                table[(size_t)(rb * ncb + cb)] = o;
+            }
+        hnh::DeviceArray dtable(w, table.size() * sizeof(int32_t));
+        w->copy(dtable.ptr(), table.data(), table.size() * sizeof(int32_t), HNH_COPY_H2D, HNH_STREAM_COMPUTE);
+
+        hnh_tuple_key okey{};
+        okey.kind = HNH_KEY_OWNER;
+        okey.transpose = transpose ? 1 : 0;
+        okey.rows_in_block = rib; okey.cols_in_block = cib; okey.n_col_blocks = ncb;
+        okey.owner_table = static_cast<const int32_t*>(dtable.ptr());
+        int owner_bits = 1;
+        while ((1 << owner_bits) < p) owner_bits++;
+        w->check(be->hnh_tuples_sort(w->ctx, wt, (int64_t)n, &okey, owner_bits, HNH_STREAM_COMPUTE), "hnh_tuples_sort (owner)");
+        std::vector<int64_t> starts((size_t)p + 1, 0);
+        w->check(be->hnh_tuples_bucket_starts(w->ctx, wt, (int64_t)n, &okey, p, starts.data(), HNH_STREAM_COMPUTE), "hnh_tuples_bucket_starts");
+        if ((size_t)starts[p] != n) hnh::fatal("Error, nonzero distribution produced an invalid owner!");
+        if (transpose) w->check(be->hnh_tuples_transform(w->ctx, wt, (int64_t)n, 1, 0, 0, HNH_STREAM_COMPUTE), "hnh_tuples_transform");
+        w->sync(HNH_STREAM_COMPUTE);
+        delete pt;
+
+        pt = new hnh::PhaseTimer("  redist: alltoallv (device)");
+        std::vector<size_t> sendcounts(p), recvcounts(p), all_counts((size_t)p * p);
+        for (int r = 0; r < p; r++) sendcounts[r] = (size_t)(starts[r + 1] - starts[r]);
+        w->host_allgather(sendcounts.data(), all_counts.data(), (size_t)p * sizeof(size_t));
+        std::vector<size_t> sb(p), sd(p), rb(p), rd(p);
+        size_t total = 0;
+        for (int r = 0; r < p; r++) {
+            recvcounts[r] = all_counts[(size_t)r * p + w->rank];
+            sb[r] = sendcounts[r] * sizeof(spcoord_t);
+            sd[r] = (size_t)starts[r] * sizeof(spcoord_t);
+            rb[r] = recvcounts[r] * sizeof(spcoord_t);
+            rd[r] = total * sizeof(spcoord_t);
+            total += recvcounts[r];
+        }
+        hnh::DeviceArray received(w, std::max<size_t>(total, 1) * sizeof(spcoord_t));
+        w->device_alltoallv(work.ptr(), sb, sd, received.ptr(), rb, rd, HNH_STREAM_COMM);
+        work.reset();
+        delete pt;
+
+        pt = new hnh::PhaseTimer("  redist: column-major sort (device)");
+        SpmatLocal* result = in_place ? this : new SpmatLocal();
+        result->M = newM;
+        result->N = newN;
+        result->dist_nnz = dist_nnz;
+        result->initialized = true;
+        std::vector<spcoord_t>().swap(result->coords);
+        result->dcoords = std::move(received);
+        result->resident = true;
+        result->n_resident = total;
+        hnh_tuple_key ckey{};
+        ckey.kind = HNH_KEY_COL_ROW;
+        int col_bits = 1;
+        while (col_bits < 32 && ((uint64_t)1 << col_bits) < newN) col_bits++;
+        w->check(be->hnh_tuples_sort(w->ctx, result->dptr(), (int64_t)total, &ckey, 32 + col_bits, HNH_STREAM_COMPUTE), "hnh_tuples_sort (column-major)");
+        delete pt;
+        return result;
+    }
+
     // Synthetic / file input.  The reference uses CombBLAS (GenGraph500Data with initiator .25 x4 = ER,
     // ParallelReadMM; SpmatLocal.hpp:467-533).  Ours: a counter-based generator that every rank
     // evaluates identically (see er_generator.hpp), each rank keeping a strided slice — any initial
@@ -351,6 +545,18 @@ public:
     // Tuples must be column-major sorted.  Splits them into block columns of `blockWidth` and (optionally)
     // makes column indices block-local (SpmatLocal.hpp:541-563).
     void divideIntoBlockCols(int blockWidth, int targetDivisions, bool modIndex) {
+        if (resident) {  // boundaries by binary search over the column-major tuples, then c %= blockWidth in one pass
+            hnh_tuple_key key{};
+            key.kind = HNH_KEY_COL_DIV;
+            key.div = blockWidth;
+            std::vector<int64_t> starts((size_t)targetDivisions + 1, 0);
+            world->check(world->be->hnh_tuples_bucket_starts(world->ctx, dptr(), (int64_t)n_resident, &key, targetDivisions, starts.data(),
+                                                             HNH_STREAM_COMPUTE), "hnh_tuples_bucket_starts");
+            if ((size_t)starts[(size_t)targetDivisions] != n_resident) hnh::fatal("Error, more block columns than expected!");
+            blockStarts.assign(starts.begin(), starts.end());
+            if (modIndex) localize(0, (uint64_t)blockWidth);
+            return;
+        }
         blockStarts.clear();
         uint64_t currentStart = 0;
         for (uint64_t i = 0; i < coords.size(); i++) {
@@ -367,7 +573,7 @@ public:
     void monolithBlockColumn() {
         blockStarts.clear();
         blockStarts.push_back(0);
-        blockStarts.push_back(coords.size());
+        blockStarts.push_back(num_tuples());
     }
 
     // values <-> per-block storage (SpmatLocal.hpp:571-605); device-to-device on the compute stream

@@ -67,6 +67,7 @@ Backend* load_backend(const char* path_c) {
     HNH_BIND(hnh_sddmm_coo) HNH_BIND(hnh_sddmm_csr) HNH_BIND(hnh_spmm_csr) HNH_BIND(hnh_fused_sddmm_spmm_csr)
     HNH_BIND(hnh_sddmm_csr_ex) HNH_BIND(hnh_spmm_csr_ex) HNH_BIND(hnh_fused_sddmm_spmm_csr_ex) HNH_BIND(hnh_csr_max_row_nnz) HNH_BIND(hnh_fused_sddmm_spmm_csr_multi)
     HNH_BIND(hnh_fused_sddmm_spmm_csr_x) HNH_BIND(hnh_fused_sddmm_spmm_csr_multi_x) HNH_BIND(hnh_row_epilogue_f64) HNH_BIND(hnh_cg_step_f64)
+    HNH_BIND(hnh_tuples_sort) HNH_BIND(hnh_tuples_bucket_starts) HNH_BIND(hnh_tuples_transform) HNH_BIND(hnh_tuples_to_csr)
     HNH_BIND(hnh_fill_f64) HNH_BIND(hnh_hadamard_f64) HNH_BIND(hnh_axpy_f64) HNH_BIND(hnh_expand_rowptr)
     HNH_BIND(hnh_rowdot_f64) HNH_BIND(hnh_row_scale_add_f64) HNH_BIND(hnh_vec_add_scalar_f64) HNH_BIND(hnh_vec_div_f64) HNH_BIND(hnh_fill_hashed_f64)
     HNH_BIND(hnh_gemm_f64) HNH_BIND(hnh_leaky_relu_f64) HNH_BIND(hnh_relu_store_cols_f64)
@@ -319,6 +320,35 @@ void World::host_bcast(const Comm& comm, int root, void* buf, size_t bytes) {
     std::vector<char> tmp(is_root ? 0 : bytes);
     host_alltoallv(buf, sb, sd, is_root ? nullptr : tmp.data(), rb, rd);
     if (!is_root && bytes) std::memcpy(buf, tmp.data(), bytes);
+}
+
+void World::device_alltoallv(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl, void* recv,
+                             const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl, int stream) {
+    Comm w = world_comm();
+    const char* s = static_cast<const char*>(send);
+    char* r = static_cast<char*>(recv);
+    for (int k = 0; k < size; k++) {  // round k: send to me + k, receive from me - k
+        const int dst = (rank + k) % size, src = (rank - k + size) % size;
+        if (k == 0) {
+            if (sendbytes[rank] != recvbytes[rank]) fatal("Error, self send/recv size mismatch");
+            if (sendbytes[rank]) copy(r + recvdispl[rank], s + senddispl[rank], sendbytes[rank], HNH_COPY_D2D, stream);
+        } else if (sendbytes[dst] || recvbytes[src]) {
+            sendrecv(w, s + senddispl[dst], sendbytes[dst], dst, r + recvdispl[src], recvbytes[src], src, stream);
+        }
+    }
+    sync(stream);
+}
+
+void World::device_bcast(const Comm& comm, int root, void* buf, size_t bytes, int stream) {
+    std::vector<size_t> sb(size, 0), sd(size, 0), rb(size, 0), rd(size, 0);
+    const bool is_root = (comm.me == root);
+    if (is_root) {
+        for (int i = 0; i < comm.size(); i++)
+            if (i != root) sb[comm.ranks[i]] = bytes;  // every member reads the same source bytes (displ 0)
+    } else {
+        rb[comm.ranks[root]] = bytes;
+    }
+    device_alltoallv(buf, sb, sd, buf, rb, rd, stream);
 }
 
 double World::host_allreduce_sum(double v) {

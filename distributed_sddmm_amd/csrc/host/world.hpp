@@ -79,6 +79,11 @@ public:
     virtual void host_alltoallv(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl,
                                 void* recv, const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl) = 0;
     virtual void host_bcast(const Comm& comm, int root, void* buf, size_t bytes);
+    // The same two exchanges for DEVICE buffers (setup pipeline: tuples never visit the host): pairwise rounds of
+    // sendrecv over the world communicator on `stream`, drained before returning.
+    void device_alltoallv(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl, void* recv,
+                          const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl, int stream);
+    void device_bcast(const Comm& comm, int root, void* buf, size_t bytes, int stream);
     void host_allgather_comm(const Comm& comm, const void* send, void* recv, size_t bytes_per_rank);
     double host_allreduce_sum(double v);
     void host_allreduce_sum(double* v, size_t n);

@@ -161,6 +161,48 @@ int hnh_hadamard_f64(hnh_ctx* ctx, double* out, const double* a, const double* b
 int hnh_axpy_f64(hnh_ctx* ctx, double* y, const double* x, double alpha, int64_t n, int stream);
 int hnh_expand_rowptr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, int32_t* row_idx, int stream);
 
+/* ---- setup on the device: routing, ordering and CSR conversion of the matrix's (row, col, value) tuples ---------------
+ * Replaces host code of the reference's SpmatLocal.hpp: getOwner + the Alltoallv pack (:45-52, :404-420), the
+ * column-major std::sort (:454), divideIntoBlockCols (:541-563) and the MKL COO->CSR conversion in CSRLocal's
+ * constructor (:117-147).  `hnh_tuple` is the reference's spcoord_t (common.h:27-33); arrays of it live in DEVICE memory.
+ *
+ * A key maps a tuple to an unsigned integer:
+ *   HNH_KEY_ROW_COL  (r << 32) | c   — CSR order;   HNH_KEY_COL_ROW  (c << 32) | r — column-major (indices must fit 32 bits)
+ *   HNH_KEY_OWNER    owner_table[(R / rows_in_block) * n_col_blocks + (C / cols_in_block)] with (R, C) = (r, c), or (c, r)
+ *                    when `transpose` — NonzeroDistribution::getOwner; owner_table is a DEVICE array
+ *   HNH_KEY_COL_DIV  c / div         — block column of divideIntoBlockCols
+ * hnh_tuples_sort          stable in-place sort by key (LSD radix sort of (key, index) pairs + one gather); key_bits =
+ *                          number of significant key bits (<= 0: 64), fewer bits = fewer radix passes
+ * hnh_tuples_bucket_starts for tuples whose keys are non-decreasing: starts_host[b] = first index with key >= b,
+ *                          b = 0..nbuckets (send counts per owner, block-column boundaries); synchronous
+ * hnh_tuples_transform     r <-> c when swap_rc, then r %= rmod, c %= cmod (0 = leave): transposition and the
+ *                          "make indices block-local" loops of the schedule constructors (15D_dense_shift.hpp:96-100)
+ * hnh_tuples_to_csr        tuples in HNH_KEY_ROW_COL order -> rowptr (rows + 1), col_idx, values of one block; reports the
+ *                          longest row; HNH_ERR_INVALID when a tuple lies outside rows x cols; synchronous */
+typedef struct hnh_tuple {
+    uint64_t r, c;
+    double value;
+} hnh_tuple;
+#define HNH_KEY_ROW_COL 0
+#define HNH_KEY_COL_ROW 1
+#define HNH_KEY_OWNER 2
+#define HNH_KEY_COL_DIV 3
+typedef struct hnh_tuple_key {
+    int kind;
+    int transpose;               /* HNH_KEY_OWNER */
+    int64_t rows_in_block;       /* HNH_KEY_OWNER */
+    int64_t cols_in_block;       /* HNH_KEY_OWNER */
+    int64_t n_col_blocks;        /* HNH_KEY_OWNER */
+    const int32_t* owner_table;  /* HNH_KEY_OWNER, device */
+    int64_t div;                 /* HNH_KEY_COL_DIV */
+} hnh_tuple_key;
+int hnh_tuples_sort(hnh_ctx* ctx, hnh_tuple* tuples, int64_t n, const hnh_tuple_key* key, int key_bits, int stream);
+int hnh_tuples_bucket_starts(hnh_ctx* ctx, const hnh_tuple* sorted, int64_t n, const hnh_tuple_key* key, int64_t nbuckets,
+                             int64_t* starts_host, int stream);
+int hnh_tuples_transform(hnh_ctx* ctx, hnh_tuple* tuples, int64_t n, int swap_rc, uint64_t rmod, uint64_t cmod, int stream);
+int hnh_tuples_to_csr(hnh_ctx* ctx, const hnh_tuple* sorted, int64_t n, int64_t rows, int64_t cols, int32_t* rowptr,
+                      int32_t* col_idx, double* values, int* max_row_nnz_host, int stream);
+
 /* ---- row-wise dense helpers of the ALS-CG application around fusedSpMM (als_conjugate_gradients.cpp) -----------
  * hnh_rowdot_f64         — batch_dot_product (:9-11):  out[i] = sum_j A[i,j] * B[i,j]
  * hnh_row_scale_add_f64  — scale_matrix_rows + matrix add/sub (:13-29, :117-123, :137):

@@ -330,6 +330,100 @@ int hnh_relu_store_cols_f64(hnh_ctx* c, double* dst, int64_t ld, int64_t col0, c
     return HNH_OK;
 }
 
+/* ---- setup primitives: the host code they stand for (SpmatLocal.hpp:45-52,404-420,454,541-563,117-147), literally ---- */
+static uint64_t tuple_key(const hnh_tuple* t, const hnh_tuple_key* k) {
+    switch (k->kind) {
+        case HNH_KEY_ROW_COL: return (t->r << 32) | (t->c & 0xffffffffull);
+        case HNH_KEY_COL_ROW: return (t->c << 32) | (t->r & 0xffffffffull);
+        case HNH_KEY_OWNER: {
+            const uint64_t rb = (k->transpose ? t->c : t->r) / (uint64_t)k->rows_in_block;
+            const uint64_t cb = (k->transpose ? t->r : t->c) / (uint64_t)k->cols_in_block;
+            return (uint64_t)(uint32_t)k->owner_table[rb * (uint64_t)k->n_col_blocks + cb];
+        }
+        default: return t->c / (uint64_t)k->div;
+    }
+}
+static int key_ok(hnh_ctx* c, const hnh_tuple_key* k) {
+    if (!k) return fail(c, HNH_ERR_INVALID, "null key");
+    if (k->kind == HNH_KEY_OWNER && (k->rows_in_block <= 0 || k->cols_in_block <= 0 || k->n_col_blocks <= 0 || !k->owner_table))
+        return fail(c, HNH_ERR_INVALID, "incomplete owner key");
+    if (k->kind == HNH_KEY_COL_DIV && k->div <= 0) return fail(c, HNH_ERR_INVALID, "column divisor must be positive");
+    if (k->kind < HNH_KEY_ROW_COL || k->kind > HNH_KEY_COL_DIV) return fail(c, HNH_ERR_INVALID, "unknown key kind");
+    return HNH_OK;
+}
+typedef struct { uint64_t key; int64_t idx; } keyed_t;
+static int keyed_cmp(const void* a, const void* b) {
+    const keyed_t *x = (const keyed_t*)a, *y = (const keyed_t*)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0); /* stable */
+}
+int hnh_tuples_sort(hnh_ctx* c, hnh_tuple* t, int64_t n, const hnh_tuple_key* k, int key_bits, int stream) {
+    (void)stream; (void)key_bits;
+    if (n < 0) return fail(c, HNH_ERR_INVALID, "negative size");
+    int rc = key_ok(c, k);
+    if (rc != HNH_OK) return rc;
+    if (n <= 1) return HNH_OK;
+    keyed_t* ks = (keyed_t*)malloc(sizeof(keyed_t) * (size_t)n);
+    hnh_tuple* cp = (hnh_tuple*)malloc(sizeof(hnh_tuple) * (size_t)n);
+    if (!ks || !cp) { free(ks); free(cp); return fail(c, HNH_ERR_NOMEM, "malloc failed"); }
+    for (int64_t i = 0; i < n; i++) {
+        if ((k->kind == HNH_KEY_ROW_COL || k->kind == HNH_KEY_COL_ROW) && ((t[i].r >> 32) || (t[i].c >> 32))) {
+            free(ks); free(cp);
+            return fail(c, HNH_ERR_UNSUPPORTED, "a row or column index does not fit 32 bits");
+        }
+        ks[i].key = tuple_key(&t[i], k);
+        ks[i].idx = i;
+    }
+    qsort(ks, (size_t)n, sizeof(keyed_t), keyed_cmp);
+    memcpy(cp, t, sizeof(hnh_tuple) * (size_t)n);
+    for (int64_t i = 0; i < n; i++) t[i] = cp[ks[i].idx];
+    free(ks); free(cp);
+    return HNH_OK;
+}
+int hnh_tuples_bucket_starts(hnh_ctx* c, const hnh_tuple* t, int64_t n, const hnh_tuple_key* k, int64_t nbuckets, int64_t* starts,
+                             int stream) {
+    (void)stream;
+    if (n < 0 || nbuckets < 0 || !starts) return fail(c, HNH_ERR_INVALID, "bad argument");
+    int rc = key_ok(c, k);
+    if (rc != HNH_OK) return rc;
+    int64_t i = 0;
+    for (int64_t b = 0; b <= nbuckets; b++) {
+        while (i < n && tuple_key(&t[i], k) < (uint64_t)b) i++;
+        starts[b] = i;
+    }
+    return HNH_OK;
+}
+int hnh_tuples_transform(hnh_ctx* c, hnh_tuple* t, int64_t n, int swap_rc, uint64_t rmod, uint64_t cmod, int stream) {
+    (void)c; (void)stream;
+    for (int64_t i = 0; i < n; i++) {
+        if (swap_rc) { const uint64_t x = t[i].r; t[i].r = t[i].c; t[i].c = x; }
+        if (rmod) t[i].r %= rmod;
+        if (cmod) t[i].c %= cmod;
+    }
+    return HNH_OK;
+}
+int hnh_tuples_to_csr(hnh_ctx* c, const hnh_tuple* t, int64_t n, int64_t rows, int64_t cols, int32_t* rowptr, int32_t* col_idx,
+                      double* values, int* max_row, int stream) {
+    (void)stream;
+    if (n < 0 || rows < 0 || cols < 0 || !rowptr) return fail(c, HNH_ERR_INVALID, "bad argument");
+    for (int64_t r = 0; r <= rows; r++) rowptr[r] = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if ((int64_t)t[i].r >= rows || (int64_t)t[i].c >= cols) return fail(c, HNH_ERR_INVALID, "nonzero outside its block");
+        if (i > 0 && ((t[i].r < t[i - 1].r) || (t[i].r == t[i - 1].r && t[i].c < t[i - 1].c)))
+            return fail(c, HNH_ERR_INVALID, "tuples are not in (row, col) order");
+        rowptr[t[i].r + 1]++;
+        col_idx[i] = (int32_t)t[i].c;
+        values[i] = t[i].value;
+    }
+    int m = 0;
+    for (int64_t r = 0; r < rows; r++) {
+        if (rowptr[r + 1] > m) m = rowptr[r + 1];
+        rowptr[r + 1] += rowptr[r];
+    }
+    if (max_row) *max_row = m;
+    return HNH_OK;
+}
+
 /* no RCCL on the CPU: host-logic tests use the thread-loopback or callback transports */
 #define UNSUP(c) return fail((c), HNH_ERR_UNSUPPORTED, "RCCL transport is not available in the CPU test double")
 int hnh_comm_unique_id(void* id) { (void)id; return HNH_ERR_UNSUPPORTED; }

@@ -1,0 +1,57 @@
+"""hnh_tuples_* (the setup pipeline's primitives) of the oracle's C test double, against numpy — the same body runs on
+the GPU in test_tuples_gpu.py; and the HNH_HOST_SETUP=1 pipeline (the reference's host algorithm restated) must give
+the same operator results as the device pipeline."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import hnh_testlib as T
+import tuples_common
+from distributed_sddmm_amd import _kernels as K
+from distributed_sddmm_amd import api as H
+
+
+class HostArray:
+    def __init__(self, a):
+        self.a = np.ascontiguousarray(a).copy()
+        self.ptr = self.a.ctypes.data_as(C.c_void_p)
+
+    def get(self):
+        return self.a
+
+    def free(self):
+        pass
+
+
+class DoubleApi:
+    def __init__(self):
+        self.lib = C.CDLL(T.ORACLE_BACKEND)
+        for name, (res, args) in K.SIGNATURES.items():
+            f = getattr(self.lib, name)
+            f.restype, f.argtypes = res, args
+        self.h = C.c_void_p()
+        assert self.lib.hnh_ctx_create(0, C.byref(self.h)) == 0
+
+    def upload(self, a):
+        return HostArray(a)
+
+    def check(self, rc, what):
+        assert rc == 0, what
+
+
+def test_c_test_double_tuple_primitives():
+    tuples_common.run(DoubleApi())
+
+
+@pytest.mark.parametrize("alg,p,c", [("15d_fusion2", 4, 2), ("15d_fusion1", 4, 1), ("15d_sparse", 4, 2), ("25d_dense_replicate", 8, 2),
+                                     ("25d_sparse_replicate", 8, 2)])
+def test_host_setup_pipeline_still_matches_the_reference(monkeypatch, alg, p, c):
+    H.load_backend(T.ORACLE_BACKEND)
+    monkeypatch.setenv("HNH_HOST_SETUP", "1")
+    for name in ("er8_r16", "rect_r16"):
+        case = T.case_inputs(name)
+        if not T.valid_config(alg, p, c, case["R"]):
+            continue
+        per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
+        T.check_against_golden(T.assemble(per_rank, case), per_rank, case, alg)

@@ -1,0 +1,84 @@
+"""Shared body of the setup-primitive tests (hnh_tuples_* of include/hnh_kernels.h): the same checks run against the
+oracle's C test double on the CPU and against the HIP library on the GPU; expectations are plain numpy."""
+import ctypes as C
+
+import numpy as np
+
+from distributed_sddmm_amd import _kernels as K
+
+
+def make_tuples(n, rows, cols, seed):
+    rng = np.random.default_rng(seed)
+    t = np.zeros(n, dtype=K.TUPLE_DTYPE)
+    t["r"], t["c"] = rng.integers(0, rows, n), rng.integers(0, cols, n)
+    t["value"] = rng.uniform(-1, 1, n)
+    return t
+
+
+def key_of(t, kind, **kw):
+    r, c = t["r"].astype(np.uint64), t["c"].astype(np.uint64)
+    if kind == K.KEY_ROW_COL:
+        return (r << np.uint64(32)) | c
+    if kind == K.KEY_COL_ROW:
+        return (c << np.uint64(32)) | r
+    if kind == K.KEY_OWNER:
+        rr, cc = (c, r) if kw["transpose"] else (r, c)
+        return kw["table"][(rr // np.uint64(kw["rib"])) * np.uint64(kw["ncb"]) + cc // np.uint64(kw["cib"])].astype(np.uint64)
+    return c // np.uint64(kw["div"])
+
+
+def run(api):
+    """api: object with upload(np)->handle(.ptr,.get(),.free()), lib, ctx handle `h`, check(rc, what)."""
+    lib, h = api.lib, api.h
+    rows, cols, n = 1000, 777, 50000
+    t0 = make_tuples(n, rows, cols, 3)
+    table = np.random.default_rng(4).integers(0, 8, 10 * 7).astype(np.int32)  # 10 x 7 blocks of 100 x 111, 8 owners
+    dtab = api.upload(table)
+    cases = [(K.KEY_ROW_COL, {}, 64), (K.KEY_COL_ROW, {}, 32 + 10), (K.KEY_COL_DIV, dict(div=100), 4),
+             (K.KEY_OWNER, dict(transpose=0, rib=100, cib=111, ncb=7, table=table), 3),
+             (K.KEY_OWNER, dict(transpose=1, rib=111, cib=100, ncb=10, table=table), 3)]
+    for kind, kw, bits in cases:
+        if kind == K.KEY_OWNER and kw["transpose"]:  # 7 x 10 blocks over the transposed matrix
+            kw["table"] = table[:70]
+        key = K.TupleKey(kind, kw.get("transpose", 0), kw.get("rib", 0), kw.get("cib", 0), kw.get("ncb", 0), dtab.ptr, kw.get("div", 0))
+        d = api.upload(t0)
+        api.check(lib.hnh_tuples_sort(h, d.ptr, n, C.byref(key), bits, 0), "tuples_sort")
+        got = d.get().view(K.TUPLE_DTYPE).reshape(-1)
+        order = np.argsort(key_of(t0, kind, **kw), kind="stable")   # the sort is stable
+        assert np.array_equal(got, t0[order]), "kind %d" % kind
+        # boundaries
+        nb = int(key_of(t0, kind, **kw).max()) + 1 if kind in (K.KEY_OWNER, K.KEY_COL_DIV) else 5
+        starts = np.zeros(nb + 1, dtype=np.int64)
+        api.check(lib.hnh_tuples_bucket_starts(h, d.ptr, n, C.byref(key), nb, starts.ctypes.data_as(C.c_void_p), 0), "bucket_starts")
+        want = np.searchsorted(key_of(got, kind, **kw), np.arange(nb + 1, dtype=np.uint64), side="left")
+        assert np.array_equal(starts, want)
+        d.free()
+    # transform: swap, then mod
+    d = api.upload(t0)
+    api.check(lib.hnh_tuples_transform(h, d.ptr, n, 1, 13, 0, 0), "transform")
+    got = d.get().view(K.TUPLE_DTYPE).reshape(-1)
+    assert np.array_equal(got["r"], t0["c"] % 13) and np.array_equal(got["c"], t0["r"]) and np.array_equal(got["value"], t0["value"])
+    d.free()
+    # to_csr on de-duplicated (row, col)-ordered tuples, with empty rows and one hub row
+    keys = np.unique(np.concatenate([key_of(t0, K.KEY_ROW_COL)[t0["r"] % 7 != 3], (np.uint64(5) << np.uint64(32)) | np.arange(cols, dtype=np.uint64)]))
+    ts = np.zeros(len(keys), dtype=K.TUPLE_DTYPE)
+    ts["r"], ts["c"], ts["value"] = keys >> np.uint64(32), keys & np.uint64(0xffffffff), np.arange(len(keys)) * 0.5
+    d = api.upload(ts)
+    drp, dci, dv = api.upload(np.zeros(rows + 1, np.int32)), api.upload(np.zeros(len(ts), np.int32)), api.upload(np.zeros(len(ts)))
+    mx = C.c_int(-1)
+    api.check(lib.hnh_tuples_to_csr(h, d.ptr, len(ts), rows, cols, drp.ptr, dci.ptr, dv.ptr, C.byref(mx), 0), "to_csr")
+    want_rp = np.searchsorted(ts["r"], np.arange(rows + 1), side="left").astype(np.int32)
+    assert np.array_equal(drp.get().reshape(-1), want_rp) and np.array_equal(dci.get().reshape(-1), ts["c"].astype(np.int32))
+    assert np.array_equal(dv.get().reshape(-1), ts["value"]) and mx.value == int(np.diff(want_rp).max()) == cols
+    # a tuple outside the block is an error, like the reference's MKL call would be
+    assert lib.hnh_tuples_to_csr(h, d.ptr, len(ts), rows, cols - 1, drp.ptr, dci.ptr, dv.ptr, C.byref(mx), 0) != 0
+    # empty input
+    api.check(lib.hnh_tuples_to_csr(h, None, 0, 4, 4, drp.ptr, None, None, C.byref(mx), 0), "to_csr empty")
+    assert np.array_equal(drp.get().reshape(-1)[:5], np.zeros(5, np.int32)) and mx.value == 0
+    api.check(lib.hnh_tuples_sort(h, None, 0, C.byref(K.TupleKey(K.KEY_ROW_COL, 0, 0, 0, 0, None, 0)), 64, 0), "sort empty")
+    # indices beyond 32 bits cannot be keyed
+    big = t0[:10].copy(); big["r"][3] = 1 << 33
+    db = api.upload(big)
+    assert lib.hnh_tuples_sort(h, db.ptr, 10, C.byref(K.TupleKey(K.KEY_ROW_COL, 0, 0, 0, 0, None, 0)), 64, 0) != 0
+    for x in (d, drp, dci, dv, dtab, db):
+        x.free()
