@@ -99,6 +99,7 @@ SIGNATURES = {
     "hnh_dist_spmmB": (_i32, [_vp, _vp, _vp, _vp]),
     "hnh_dist_fusedSpMM": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32]),
     "hnh_dist_algorithm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32]),
+    "hnh_dist_hold_moving_operand": (_i32, [_vp, _vp]),
     "hnh_dist_fusedSpMM_out": (_i32, [_vp, _vp, _vp, _i32, _vp, _i32, C.c_double, C.c_double, _vp, C.POINTER(C.c_int)]),
     "hnh_als_create": (_i32, [_vp, _i32, _u64, _pvp]),
     "hnh_als_destroy": (_i32, [_vp]),
@@ -478,6 +479,10 @@ class DistributedSparse:
 
     def fusedSpMM(self, a, b, s, buf, matmode: int):
         _check(lib().hnh_dist_fusedSpMM(self.h, a.h, b.h, s.h, buf.h, matmode), "fusedSpMM")
+
+    def hold_moving_operand(self, m=None):
+        """Distributed_Sparse::hold_moving_operand(m) / release_moving_operand() (m = None)."""
+        _check(lib().hnh_dist_hold_moving_operand(self.h, m.h if m else None), "hold_moving_operand")
 
     def fusedSpMM_out(self, a, b, matmode: int, out, leaky_alpha=None, x_scale: float = 0.0, rowdot=None) -> bool:
         """Distributed_Sparse::fusedSpMM_out; False (nothing done) when the schedule has no single fused pass."""

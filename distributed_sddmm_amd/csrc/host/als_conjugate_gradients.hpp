@@ -56,6 +56,14 @@ public:
         const int64_t nrows = X.rows();
         const int ncols = (int)A.cols();
 
+        // the other factor is fixed for this whole half-step (rhs + 1 + cg_max_iter fused calls): schedules that fetch
+        // its blocks from other ranks may keep them
+        struct Hold {
+            Distributed_Sparse* d;
+            Hold(Distributed_Sparse* d_in, const DenseMatrix* m) : d(d_in) { d->hold_moving_operand(m); }
+            ~Hold() { d->release_moving_operand(); }
+        } hold(d_ops, matrix_to_optimize == Amat ? &B : &A);
+
         DenseMatrix rhs(nrows, ncols), Mx(nrows, ncols), Mp(nrows, ncols);
         rhs.setZero();
         computeRHS(matrix_to_optimize, rhs);

@@ -401,6 +401,12 @@ int hnh_dist_spmmB(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S) {
 int hnh_dist_fusedSpMM(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_vec* buf, int matmode) {
     return guarded(d->w, [&] { d->d->fusedSpMM(A->m, B->m, S->v, buf->v, matmode == HNH_AMAT ? Amat : Bmat); });
 }
+int hnh_dist_hold_moving_operand(hnh_dist* d, hnh_dense* m) {
+    return guarded(d->w, [&] {
+        if (m) d->d->hold_moving_operand(&m->m);
+        else d->d->release_moving_operand();
+    });
+}
 int hnh_dist_fusedSpMM_out(hnh_dist* d, hnh_dense* A, hnh_dense* B, int matmode, hnh_dense* Out, int leaky, double leaky_alpha,
                            double x_scale, hnh_vec* rowdot, int* supported) {
     return guarded(d->w, [&] {

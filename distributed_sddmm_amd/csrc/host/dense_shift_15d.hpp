@@ -47,6 +47,18 @@ public:
     std::vector<DenseMatrix> mesh_spare;  // mesh fetch: one landing buffer per remote ring position
     enum RingMode { kRelay, kMeshFetch };
     RingMode ring_mode;
+    // hold_moving_operand(): the remote blocks of this matrix stay valid in mesh_spare / ring_spare[0] between calls
+    const double* held_ptr = nullptr;
+    bool held_fetched = false;
+
+    void hold_moving_operand(const DenseMatrix* m) override {
+        held_ptr = m ? m->data() : nullptr;
+        held_fetched = false;
+    }
+    void release_moving_operand() override {
+        held_ptr = nullptr;
+        held_fetched = false;
+    }
 
     Sparse15D_Dense_Shift(SpmatLocal* S_input, int R, int c, int fusionApproach, KernelImplementation* k) : Distributed_Sparse(k) {
         this->fusionApproach = fusionApproach;
@@ -314,7 +326,10 @@ private:
                 world->event_record(event(3 + i % 2), HNH_STREAM_COMPUTE);                 // kernel i enqueued
                 DenseMatrix* target = &ring_spare[i % 2];
                 if (i >= 2) world->event_wait(event(3 + (i - 1) % 2), HNH_STREAM_COMM);    // kernel i-1 last read `target`
-                world->sendrecv(grid->col_world, cur->data(), bytes, dst, target->data(), bytes, src, HNH_STREAM_COMM);
+                const bool held = (n == 2 && held_ptr == start->data());  // a ring of two: the one remote block can stay
+                if (!(held && held_fetched))
+                    world->sendrecv(grid->col_world, cur->data(), bytes, dst, target->data(), bytes, src, HNH_STREAM_COMM);
+                if (held) held_fetched = true;
                 world->event_record(event(1 + i % 2), HNH_STREAM_COMM);
                 cur = target;
                 stop_clock_and_add(t, "Cyclic Shift Time");
@@ -330,11 +345,15 @@ private:
         const size_t bytes = (size_t)start->size() * sizeof(double);
         auto t = start_clock();
         order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // my block is final; earlier readers of the landing buffers are done
-        world->group_begin();
-        for (int k = 1; k < n; k++)  // my block is what ring rank me+k needs at ITS step k; I need the block of me-k at mine
-            world->sendrecv(grid->col_world, start->data(), bytes, pMod(grid->rankInCol + k, n), mesh_spare[k - 1].data(), bytes,
-                            pMod(grid->rankInCol - k, n), HNH_STREAM_COMM);
-        world->group_end();
+        const bool held = (held_ptr == start->data());
+        if (!(held && held_fetched)) {  // a held operand's blocks are still in the landing buffers from the previous call
+            world->group_begin();
+            for (int k = 1; k < n; k++)  // my block is what ring rank me+k needs at ITS step k; I need the block of me-k at mine
+                world->sendrecv(grid->col_world, start->data(), bytes, pMod(grid->rankInCol + k, n), mesh_spare[k - 1].data(), bytes,
+                                pMod(grid->rankInCol - k, n), HNH_STREAM_COMM);
+            world->group_end();
+        }
+        if (held) held_fetched = true;
         world->event_record(event(1), HNH_STREAM_COMM);
         stop_clock_and_add(t, "Cyclic Shift Time");
         std::vector<DenseMatrix*> out;

@@ -204,6 +204,12 @@ public:
         }
     }
 
+    // Hint (an addition): between hold_moving_operand(&m) and release_moving_operand() the CONTENTS of dense matrix m do
+    // not change (the fixed factor of an ALS half-step: 1 + cg_max_iter fused calls, als_conjugate_gradients.cpp:38-141).
+    // A schedule that fetches m's blocks from other ranks on every call may then keep what it fetched.  Default: ignored.
+    virtual void hold_moving_operand(const DenseMatrix* m) { (void)m; }
+    virtual void release_moving_operand() {}
+
     // Out-of-place fusedSpMM with the applications' surrounding work folded in (an addition; hnh_fused_extras in
     // hnh_kernels.h).  With X = localA for Amat (localB for Bmat) and Y the other operand:
     //     w_e        = <X[i_e,:], Y[j_e,:]>,  LeakyReLU'd when `leaky`                (gat.hpp:96-99)

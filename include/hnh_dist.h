@@ -141,6 +141,10 @@ int hnh_dist_sddmmB(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_vec
 int hnh_dist_spmmA(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S);
 int hnh_dist_spmmB(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S);
 int hnh_dist_fusedSpMM(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_vec* sddmm_buffer, int matmode);
+/* Distributed_Sparse::hold_moving_operand / release_moving_operand (an addition): a promise that the CONTENTS of `m` stay
+ * the same until released (m = NULL), so a schedule may keep the blocks of it that it fetched from other ranks (the fixed
+ * factor of an ALS half-step, als_conjugate_gradients.cpp:38-141).  Ignored by schedules that cannot use it. */
+int hnh_dist_hold_moving_operand(hnh_dist* d, hnh_dense* m_or_null);
 /* Distributed_Sparse::fusedSpMM_out (an addition): out-of-place fusedSpMM with the applications' surrounding work in the
  * same pass — LeakyReLU between the halves (gat.hpp:96-99), Out += x_scale * X and rowdot[i] = <X[i,:], Out[i,:]>
  * (als_conjugate_gradients.cpp:93,282,295).  *supported = 0 and nothing done when the schedule has no single fused pass. */

@@ -90,3 +90,53 @@ def test_c_test_double_extras_follow_the_numpy_statement():
     rn = Rm - al[:, None] * MP
     assert T.rel(x2, Xm + al[:, None] * P) <= T.TOL and T.rel(r2, rn) <= T.TOL and T.rel(rs, np.einsum("ij,ij->i", rn, rn)) <= T.TOL
     lib.hnh_ctx_destroy(ctx)
+
+
+@pytest.mark.parametrize("alg", ["15d_fusion2", "15d_fusion1"])
+@pytest.mark.parametrize("p,ring", [(2, "mesh"), (4, "mesh"), (4, "relay"), (8, "mesh")])
+def test_held_operand_is_fetched_once(alg, p, ring, monkeypatch):
+    """hold_moving_operand: repeated calls give the same results as without the hint; and the hint really is used — when
+    the caller breaks the promise (changes the held matrix) the remote blocks of the FIRST fetch are what later calls see
+    (mesh fetch, or a ring of two), while the relay ring of more than two ranks ignores the hint."""
+    monkeypatch.setenv("HNH_RING_MODE", ring)
+    case = T.case_inputs("er8_r16")
+
+    def body(w):
+        sp = H.SpmatLocal.from_global(w, case["M"], case["N"], case["rows"], case["cols"], np.ones(len(case["rows"])))
+        d = H.DistributedSparse(w, alg, sp, case["R"], 1)
+        subA, subB = d.submatrices(H.AMAT), d.submatrices(H.BMAT)
+        A, B = d.like_A_matrix(0.0), d.like_B_matrix(0.0)
+        ones, buf = d.like_S_values(1.0), d.like_S_values(0.0)
+        a0, b0 = T.fill_local(subA, A.shape, case["A"]), T.fill_local(subB, B.shape, case["B"])
+        outs = []
+        B.upload(b0)
+        for step in range(4):
+            if step == 1:
+                d.hold_moving_operand(B)
+            if step == 3:
+                B.upload(2.0 * b0)  # promise broken on purpose: remote ranks keep seeing the blocks fetched at step 1
+            A.upload(a0)
+            d.fusedSpMM(A, B, ones, buf, H.AMAT)
+            outs.append(A.download())
+        d.hold_moving_operand(None)
+        B.upload(2.0 * b0); A.upload(a0)
+        d.fusedSpMM(A, B, ones, buf, H.AMAT)
+        outs.append(A.download())
+        for h in (A, B, ones, buf):
+            h.free()
+        d.free(); sp.free()
+        return dict(subA=subA, outs=outs)
+
+    per_rank = H.run_spmd(p, body)
+    glob = [T.assemble_dense([dict(subA=o["subA"], x=o["outs"][k]) for o in per_rank], "x", "subA", case["M"], case["R"]) for k in range(5)]
+    want1, _ = T.fused_out_expected(case, H.AMAT, None, 0.0)
+    case2 = dict(case, B=2.0 * case["B"])
+    want2, _ = T.fused_out_expected(case2, H.AMAT, None, 0.0)
+    for k in range(3):
+        assert T.rel(glob[k], want1) <= T.TOL
+    assert T.rel(glob[4], want2) <= T.TOL           # released: fresh fetch
+    uses_hint = (alg == "15d_fusion2") and (ring == "mesh" or p == 2)
+    if uses_hint:
+        assert T.rel(glob[3], want2) > 1e-3 and T.rel(glob[3], want1) > 1e-3  # own block new, remote blocks held
+    elif alg == "15d_fusion2":
+        assert T.rel(glob[3], want2) <= T.TOL       # relay ring of > 2 ranks: hint ignored
