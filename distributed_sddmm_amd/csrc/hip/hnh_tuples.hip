@@ -117,6 +117,47 @@ __global__ __launch_bounds__(kBlock) void max_row_kernel(const int32_t* __restri
     if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
 }
 
+__device__ __forceinline__ unsigned long long splitmix64_dev(unsigned long long x) {
+    unsigned long long z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// draw k of the counter-based Erdos-Renyi generator (er_generator.hpp): key = row * n + col
+__global__ __launch_bounds__(kBlock) void er_keys_kernel(unsigned long long m, unsigned long long n, unsigned long long draws,
+                                                         unsigned long long seed, unsigned long long* __restrict__ keys) {
+    const unsigned long long G = 0x9E3779B97F4A7C15ull;
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; k < draws; k += stride) {
+        const unsigned long long base = seed + (2 * k) * G;
+        keys[k] = (splitmix64_dev(base) % m) * n + splitmix64_dev(base + G) % n;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void tuples_from_keys_kernel(const unsigned long long* __restrict__ keys, unsigned long long ncols,
+                                                                  long long first, long long stride_keys, double value,
+                                                                  hnh_tuple* __restrict__ out, long long n_out) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n_out; i += stride) {
+        const unsigned long long key = keys[first + i * stride_keys];
+        hnh_tuple t;
+        t.r = key / ncols; t.c = key % ncols; t.value = value;
+        out[i] = t;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void relabel_kernel(hnh_tuple* t, long long n, const unsigned long long* __restrict__ row_label,
+                                                         const unsigned long long* __restrict__ col_label) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        hnh_tuple v = t[i];
+        v.r = row_label[v.r];
+        v.c = col_label[v.c];
+        t[i] = v;
+    }
+}
+
 unsigned grid_for(long long n) {
     long long b = (n + kBlock - 1) / kBlock;
     if (b < 1) b = 1;
@@ -247,6 +288,65 @@ int hnh_tuples_to_csr(hnh_ctx* ctx, const hnh_tuple* sorted, int64_t n, int64_t 
     if (h[0]) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_to_csr: nonzero outside its block");
     if (max_row_nnz_host) *max_row_nnz_host = h[1];
     return HNH_OK;
+}
+
+int hnh_generate_er_keys(hnh_ctx* ctx, uint64_t m, uint64_t n, uint64_t draws, uint64_t seed, uint64_t* keys, int64_t* n_unique_host,
+                         int stream) {
+    HNH_ENTER(ctx, stream);
+    if (!n_unique_host || m == 0 || n == 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_generate_er_keys: bad argument");
+    *n_unique_host = 0;
+    if (draws == 0) return HNH_OK;
+    if (!keys) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_generate_er_keys: null pointer");
+    if (m > (~0ull) / n) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "hnh_generate_er_keys: m * n overflows 64 bits");
+    hipStream_t st = ctx->streams[stream];
+    const size_t un = (size_t)draws;
+    unsigned bits = 1;
+    while (bits < 64 && (1ull << bits) < m * n) bits++;
+    size_t sort_bytes = 0, uniq_bytes = 0;
+    HNH_TRY_HIP(ctx, rocprim::radix_sort_keys(nullptr, sort_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, un, 0, bits, st));
+    HNH_TRY_HIP(ctx, rocprim::unique(nullptr, uniq_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t*)nullptr, un,
+                                     rocprim::equal_to<unsigned long long>(), st));
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t tmp_bytes = sort_bytes > uniq_bytes ? sort_bytes : uniq_bytes;
+    const size_t o_alt = 0, o_cnt = o_alt + align(un * 8), o_tmp = o_cnt + 256, total = o_tmp + align(tmp_bytes);
+    Scratch s;
+    HNH_TRY_HIP(ctx, hipMalloc(&s.p, total));
+    char* base = static_cast<char*>(s.p);
+    auto* alt = reinterpret_cast<unsigned long long*>(base + o_alt);
+    auto* cnt = reinterpret_cast<size_t*>(base + o_cnt);
+    auto* k = reinterpret_cast<unsigned long long*>(keys);
+    hipLaunchKernelGGL(er_keys_kernel, dim3(grid_for((long long)draws)), dim3(kBlock), 0, st, (unsigned long long)m, (unsigned long long)n,
+                       (unsigned long long)draws, (unsigned long long)seed, k);
+    HNH_TRY_HIP(ctx, hipGetLastError());
+    HNH_TRY_HIP(ctx, rocprim::radix_sort_keys(base + o_tmp, sort_bytes, k, alt, un, 0, bits, st));
+    HNH_TRY_HIP(ctx, rocprim::unique(base + o_tmp, uniq_bytes, alt, k, cnt, un, rocprim::equal_to<unsigned long long>(), st));
+    size_t h_cnt = 0;
+    HNH_TRY_HIP(ctx, hipMemcpyAsync(&h_cnt, cnt, sizeof(size_t), hipMemcpyDeviceToHost, st));
+    HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
+    *n_unique_host = (int64_t)h_cnt;
+    return HNH_OK;
+}
+
+int hnh_tuples_from_keys(hnh_ctx* ctx, const uint64_t* keys, uint64_t ncols, int64_t first, int64_t stride_keys, double value,
+                         hnh_tuple* out, int64_t n_out, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (n_out < 0 || first < 0 || stride_keys <= 0 || ncols == 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_from_keys: bad argument");
+    if (n_out == 0) return HNH_OK;
+    if (!keys || !out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_from_keys: null pointer");
+    hipLaunchKernelGGL(tuples_from_keys_kernel, dim3(grid_for(n_out)), dim3(kBlock), 0, ctx->streams[stream],
+                       reinterpret_cast<const unsigned long long*>(keys), (unsigned long long)ncols, (long long)first, (long long)stride_keys,
+                       value, out, (long long)n_out);
+    return hnh::check_hip(ctx, hipGetLastError(), "tuples_from_keys_kernel launch");
+}
+
+int hnh_tuples_relabel(hnh_ctx* ctx, hnh_tuple* tuples, int64_t n, const uint64_t* row_label, const uint64_t* col_label, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (n < 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_relabel: negative size");
+    if (n == 0) return HNH_OK;
+    if (!tuples || !row_label || !col_label) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_relabel: null pointer");
+    hipLaunchKernelGGL(relabel_kernel, dim3(grid_for(n)), dim3(kBlock), 0, ctx->streams[stream], tuples, (long long)n,
+                       reinterpret_cast<const unsigned long long*>(row_label), reinterpret_cast<const unsigned long long*>(col_label));
+    return hnh::check_hip(ctx, hipGetLastError(), "relabel_kernel launch");
 }
 
 }  // extern "C"

@@ -195,7 +195,7 @@ int hnh_spmat_info(hnh_spmat* s, int64_t out4[4]) {
     out4[0] = (int64_t)s->s->M;
     out4[1] = (int64_t)s->s->N;
     out4[2] = (int64_t)s->s->dist_nnz;
-    out4[3] = (int64_t)s->s->coords.size();
+    out4[3] = (int64_t)s->s->num_tuples();
     return HNH_OK;
 }
 int hnh_spmat_permute(hnh_spmat* s, uint64_t seed) {

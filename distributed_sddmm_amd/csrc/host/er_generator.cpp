@@ -122,6 +122,27 @@ void SpmatLocal::loadTuples(bool readFromFile, int logM, int nnz_per_row, std::s
         const uint64_t m = 1ull << logM;
         uint64_t seed = 12345;
         if (const char* s = std::getenv("HNH_ER_SEED")) seed = std::strtoull(s, nullptr, 10);
+        if (device_setup()) {
+            // the same generator evaluated on this rank's GPU: draws, radix sort, de-duplication, strided slice — the
+            // tuples are born device-resident (hnh_generate_er_keys / hnh_tuples_from_keys)
+            const uint64_t draws = m * (uint64_t)nnz_per_row;
+            hnh::DeviceArray keys(world, std::max<uint64_t>(draws, 1) * sizeof(uint64_t));
+            int64_t unique = 0;
+            world->check(world->be->hnh_generate_er_keys(world->ctx, m, m, draws, seed, static_cast<uint64_t*>(keys.ptr()), &unique,
+                                                         HNH_STREAM_COMPUTE), "hnh_generate_er_keys");
+            M = N = m;
+            dist_nnz = (uint64_t)unique;
+            n_resident = unique > rank ? (size_t)((unique - rank + p - 1) / p) : 0;
+            dcoords = hnh::DeviceArray(world, std::max<size_t>(n_resident, 1) * sizeof(spcoord_t));
+            world->check(world->be->hnh_tuples_from_keys(world->ctx, static_cast<const uint64_t*>(keys.ptr()), m, rank, p, 1.0, dptr(),
+                                                         (int64_t)n_resident, HNH_STREAM_COMPUTE), "hnh_tuples_from_keys");
+            world->sync(HNH_STREAM_COMPUTE);
+            resident = true;
+            if (rank == 0) std::cout << "R-mat generator created " << dist_nnz << " nonzeros." << std::endl;
+            initialized = true;
+            if (const char* ps = std::getenv("HNH_PERMUTE_SEED")) permuteVertices(std::strtoull(ps, nullptr, 10));
+            return;
+        }
         std::vector<uint64_t> keys = hnh::erdos_renyi_keys(m, m, m * (uint64_t)nnz_per_row, seed);
         M = N = m;
         dist_nnz = keys.size();
@@ -138,6 +159,15 @@ void SpmatLocal::loadTuples(bool readFromFile, int logM, int nnz_per_row, std::s
 void SpmatLocal::permuteVertices(uint64_t seed) {
     std::vector<uint64_t> rp = hnh::vertex_permutation(M, seed);
     std::vector<uint64_t> cp = (M == N) ? rp : hnh::vertex_permutation(N, seed + 1);
+    if (resident) {
+        hnh::DeviceArray drp(world, rp.size() * sizeof(uint64_t)), dcp(world, cp.size() * sizeof(uint64_t));
+        world->copy(drp.ptr(), rp.data(), rp.size() * sizeof(uint64_t), HNH_COPY_H2D, HNH_STREAM_COMPUTE);
+        world->copy(dcp.ptr(), cp.data(), cp.size() * sizeof(uint64_t), HNH_COPY_H2D, HNH_STREAM_COMPUTE);
+        world->check(world->be->hnh_tuples_relabel(world->ctx, dptr(), (int64_t)n_resident, static_cast<const uint64_t*>(drp.ptr()),
+                                                   static_cast<const uint64_t*>(dcp.ptr()), HNH_STREAM_COMPUTE), "hnh_tuples_relabel");
+        world->sync(HNH_STREAM_COMPUTE);  // the label tables die here
+        return;
+    }
 #pragma omp parallel for
     for (size_t e = 0; e < coords.size(); e++) {
         coords[e].r = rp[coords[e].r];

@@ -202,6 +202,18 @@ int hnh_tuples_bucket_starts(hnh_ctx* ctx, const hnh_tuple* sorted, int64_t n, c
 int hnh_tuples_transform(hnh_ctx* ctx, hnh_tuple* tuples, int64_t n, int swap_rc, uint64_t rmod, uint64_t cmod, int stream);
 int hnh_tuples_to_csr(hnh_ctx* ctx, const hnh_tuple* sorted, int64_t n, int64_t rows, int64_t cols, int32_t* rowptr,
                       int32_t* col_idx, double* values, int* max_row_nnz_host, int stream);
+/* Synthetic input on the device (replaces CombBLAS GenGraph500Data with initiator {.25,.25,.25,.25}, SpmatLocal.hpp:502-505):
+ * hnh_generate_er_keys   the counter-based Erdos-Renyi generator of er_generator.hpp / oracle.py:erdos_renyi_mn, bit for bit:
+ *                        draw k -> key = (splitmix64(seed + 2kG) % m) * n + splitmix64(seed + (2k+1)G) % n; `keys` (device,
+ *                        capacity `draws`) receives the SORTED, DE-DUPLICATED keys, their count goes to *n_unique_host; synchronous
+ * hnh_tuples_from_keys   out[i] = (key / ncols, key % ncols, value) for key = keys[first + i * stride]: a rank's strided slice
+ * hnh_tuples_relabel     r = row_label[r], c = col_label[c]: random vertex relabelling for load balance
+ *                        (PermEdges / RenameVertices, SpmatLocal.hpp:506-507; random_permute.cpp) */
+int hnh_generate_er_keys(hnh_ctx* ctx, uint64_t m, uint64_t n, uint64_t draws, uint64_t seed, uint64_t* keys, int64_t* n_unique_host,
+                         int stream);
+int hnh_tuples_from_keys(hnh_ctx* ctx, const uint64_t* keys, uint64_t ncols, int64_t first, int64_t stride, double value,
+                         hnh_tuple* out, int64_t n_out, int stream);
+int hnh_tuples_relabel(hnh_ctx* ctx, hnh_tuple* tuples, int64_t n, const uint64_t* row_label, const uint64_t* col_label, int stream);
 
 /* ---- row-wise dense helpers of the ALS-CG application around fusedSpMM (als_conjugate_gradients.cpp) -----------
  * hnh_rowdot_f64         — batch_dot_product (:9-11):  out[i] = sum_j A[i,j] * B[i,j]

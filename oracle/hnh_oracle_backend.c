@@ -424,6 +424,47 @@ int hnh_tuples_to_csr(hnh_ctx* c, const hnh_tuple* t, int64_t n, int64_t rows, i
     return HNH_OK;
 }
 
+static uint64_t splitmix64_c(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static int u64_cmp(const void* a, const void* b) {
+    const uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+int hnh_generate_er_keys(hnh_ctx* c, uint64_t m, uint64_t n, uint64_t draws, uint64_t seed, uint64_t* keys, int64_t* n_unique, int stream) {
+    (void)stream;
+    if (!n_unique || m == 0 || n == 0) return fail(c, HNH_ERR_INVALID, "bad argument");
+    const uint64_t G = 0x9E3779B97F4A7C15ull;
+    for (uint64_t k = 0; k < draws; k++) {
+        const uint64_t base = seed + (2 * k) * G;
+        keys[k] = (splitmix64_c(base) % m) * n + splitmix64_c(base + G) % n;
+    }
+    qsort(keys, (size_t)draws, sizeof(uint64_t), u64_cmp);
+    uint64_t out = 0;
+    for (uint64_t k = 0; k < draws; k++)
+        if (out == 0 || keys[out - 1] != keys[k]) keys[out++] = keys[k];
+    *n_unique = (int64_t)out;
+    return HNH_OK;
+}
+int hnh_tuples_from_keys(hnh_ctx* c, const uint64_t* keys, uint64_t ncols, int64_t first, int64_t stride, double value, hnh_tuple* out,
+                         int64_t n_out, int stream) {
+    (void)stream;
+    if (n_out < 0 || first < 0 || stride <= 0 || ncols == 0) return fail(c, HNH_ERR_INVALID, "bad argument");
+    for (int64_t i = 0; i < n_out; i++) {
+        const uint64_t key = keys[first + i * stride];
+        out[i].r = key / ncols; out[i].c = key % ncols; out[i].value = value;
+    }
+    return HNH_OK;
+}
+int hnh_tuples_relabel(hnh_ctx* c, hnh_tuple* t, int64_t n, const uint64_t* row_label, const uint64_t* col_label, int stream) {
+    (void)c; (void)stream;
+    for (int64_t i = 0; i < n; i++) { t[i].r = row_label[t[i].r]; t[i].c = col_label[t[i].c]; }
+    return HNH_OK;
+}
+
 /* no RCCL on the CPU: host-logic tests use the thread-loopback or callback transports */
 #define UNSUP(c) return fail((c), HNH_ERR_UNSUPPORTED, "RCCL transport is not available in the CPU test double")
 int hnh_comm_unique_id(void* id) { (void)id; return HNH_ERR_UNSUPPORTED; }

@@ -74,3 +74,34 @@ def test_vertex_permutation_balances_a_skewed_graph_and_commutes_with_the_operat
     assert T.rel(a1[perm], a0) <= T.TOL  # (P S P^T)(P B) = P (S B)
     imb = lambda c: max(c) / (sum(c) / len(c))  # noqa: E731
     assert imb(shuf[0]["nnz"]) < imb(plain[0]["nnz"])
+
+
+@pytest.mark.parametrize("host_setup", [False, True])
+def test_generated_and_relabelled_input_equals_the_oracle_generator(host_setup, monkeypatch):
+    """SpmatLocal::loadTuples + permuteVertices (device-resident by default, host with HNH_HOST_SETUP=1) describe the same
+    matrix as oracle.erdos_renyi_mn + oracle.vertex_permutation: same nonzero count, same operator result."""
+    if host_setup:
+        monkeypatch.setenv("HNH_HOST_SETUP", "1")
+    logm, ef, r, seed = 8, 8, 8, 5
+    m = 1 << logm
+    rows, cols = O.erdos_renyi_mn(m, m, m * ef, 12345)
+    perm = O.vertex_permutation(m, seed)
+    case = T.make_case("gen8", m, m, r, perm[rows], perm[cols])
+
+    def f(w):
+        sp = H.SpmatLocal.load_tuples(w, False, logm, ef)
+        info = sp.info()
+        sp.permute(seed)
+        d = H.DistributedSparse(w, "15d_fusion2", sp, r, 1)
+        A, B, S = d.like_A_matrix(0.0), d.like_B_matrix(0.0), d.like_S_values(1.0)
+        subA, subB = d.submatrices(H.AMAT), d.submatrices(H.BMAT)
+        B.upload(T.fill_local(subB, B.shape, case["B"]))
+        d.spmmA(A, B, S)
+        out = dict(subA=subA, spmmA=A.download(), info=info)
+        d.free(); sp.free()
+        return out
+
+    per_rank = H.run_spmd(4, f)
+    assert per_rank[0]["info"]["dist_nnz"] == len(rows) and sum(o["info"]["local_nnz"] for o in per_rank) == len(rows)
+    got = T.assemble_dense(per_rank, "spmmA", "subA", m, r)
+    assert T.rel(got, O.spmm_a(case["rows"], case["cols"], np.ones(len(rows)), case["B"], m)) <= T.TOL

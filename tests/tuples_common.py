@@ -82,3 +82,33 @@ def run(api):
     assert lib.hnh_tuples_sort(h, db.ptr, 10, C.byref(K.TupleKey(K.KEY_ROW_COL, 0, 0, 0, 0, None, 0)), 64, 0) != 0
     for x in (d, drp, dci, dv, dtab, db):
         x.free()
+    run_generator(api)
+
+
+def run_generator(api):
+    """hnh_generate_er_keys / hnh_tuples_from_keys / hnh_tuples_relabel against oracle.py (the generator's numpy twin)."""
+    from oracle import oracle as O
+    lib, h = api.lib, api.h
+    m, n, draws, seed = 300, 170, 4000, 99
+    rows, cols = O.erdos_renyi_mn(m, n, draws, seed)
+    dk = api.upload(np.zeros(draws, dtype=np.uint64))
+    cnt = C.c_int64(-1)
+    api.check(lib.hnh_generate_er_keys(h, m, n, draws, seed, dk.ptr, C.byref(cnt), 0), "generate_er_keys")
+    assert cnt.value == len(rows) < draws  # duplicates were dropped
+    keys = dk.get().reshape(-1)[:cnt.value]
+    assert np.array_equal(keys, rows.astype(np.uint64) * np.uint64(n) + cols.astype(np.uint64))
+    for rank, p in ((0, 1), (1, 3), (2, 3)):
+        cnt_local = (cnt.value - rank + p - 1) // p
+        dt = api.upload(np.zeros(cnt_local, dtype=K.TUPLE_DTYPE))
+        api.check(lib.hnh_tuples_from_keys(h, dk.ptr, n, rank, p, 1.0, dt.ptr, cnt_local, 0), "tuples_from_keys")
+        t = dt.get().view(K.TUPLE_DTYPE).reshape(-1)
+        assert np.array_equal(t["r"], rows[rank::p].astype(np.uint64)) and np.array_equal(t["c"], cols[rank::p].astype(np.uint64))
+        assert np.all(t["value"] == 1.0)
+        rl, cl = O.vertex_permutation(m, 7).astype(np.uint64), O.vertex_permutation(n, 8).astype(np.uint64)
+        drl, dcl = api.upload(rl), api.upload(cl)
+        api.check(lib.hnh_tuples_relabel(h, dt.ptr, cnt_local, drl.ptr, dcl.ptr, 0), "tuples_relabel")
+        t2 = dt.get().view(K.TUPLE_DTYPE).reshape(-1)
+        assert np.array_equal(t2["r"], rl[rows[rank::p]]) and np.array_equal(t2["c"], cl[cols[rank::p]])
+        for x in (dt, drl, dcl):
+            x.free()
+    dk.free()
