@@ -52,6 +52,7 @@ public:
     bool held_fetched = false;
 
     void hold_moving_operand(const DenseMatrix* m) override {
+        if (std::getenv("HNH_NO_HOLD") != nullptr) return;  // A/B switch for measurements
         held_ptr = m ? m->data() : nullptr;
         held_fetched = false;
     }
