@@ -16,12 +16,25 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--p", type=int, default=8); ap.add_argument("--c", type=int, default=1); ap.add_argument("--alg", default="15d_fusion2")
 ap.add_argument("--logm", type=int, default=20); ap.add_argument("--ef", type=int, default=96); ap.add_argument("--r", type=int, default=128)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--rmat-edges", type=int, default=0, help="> 0: skewed R-MAT graph on 2^logm vertices with this many edge draws "
+                "(BASELINE config 4's stand-in for com-Orkut) instead of the ER matrix")
 a = ap.parse_args()
 assert H.load_backend(None) == "hip-gfx950"
 
 
+RMAT = None
+if a.rmat_edges > 0:
+    t_gen = time.time()
+    RMAT = H.generate_rmat(a.logm, a.rmat_edges)
+    print("R-MAT 2^%d vertices, %d unique nonzeros, longest row %d (generated on the host in %.0f s)"
+          % (a.logm, len(RMAT[0]), int(np.bincount(RMAT[0]).max()), time.time() - t_gen))
+
+
 def body(w):
-    sp = H.SpmatLocal.load_tuples(w, False, a.logm, a.ef)
+    if RMAT is not None:
+        sp = H.SpmatLocal.from_global(w, 1 << a.logm, 1 << a.logm, RMAT[0], RMAT[1], None)
+    else:
+        sp = H.SpmatLocal.load_tuples(w, False, a.logm, a.ef)
     nnz = sp.info()["dist_nnz"]
     op = H.DistributedSparse(w, a.alg, sp, a.r, a.c)
     sp.free()
