@@ -88,10 +88,10 @@ class FusedExtras(C.Structure):
 class TupleKey(C.Structure):
     """struct hnh_tuple_key"""
     _fields_ = [("kind", C.c_int), ("transpose", C.c_int), ("rows_in_block", C.c_int64), ("cols_in_block", C.c_int64),
-                ("n_col_blocks", C.c_int64), ("owner_table", C.c_void_p), ("div", C.c_int64)]
+                ("n_col_blocks", C.c_int64), ("owner_table", C.c_void_p), ("div", C.c_int64), ("sub_div", C.c_int64), ("n_sub", C.c_int64)]
 
 
-KEY_ROW_COL, KEY_COL_ROW, KEY_OWNER, KEY_COL_DIV = 0, 1, 2, 3
+KEY_ROW_COL, KEY_COL_ROW, KEY_OWNER, KEY_COL_DIV, KEY_COL_DIV2 = 0, 1, 2, 3, 4
 TUPLE_DTYPE = [("r", "<u8"), ("c", "<u8"), ("value", "<f8")]  # struct hnh_tuple
 
 

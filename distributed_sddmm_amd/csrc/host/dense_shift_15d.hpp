@@ -47,18 +47,24 @@ public:
     std::vector<DenseMatrix> mesh_spare;  // mesh fetch: one landing buffer per remote ring position
     enum RingMode { kRelay, kMeshFetch };
     RingMode ring_mode;
+    // Chunked mesh fetch (approach 2): every block column of S is cut into `chunks` column ranges = row ranges of the
+    // visiting dense block, so the fetch can be issued chunk by chunk and the kernels of chunk q run while chunk q+1
+    // is still on the links (HNH_MESH_CHUNKS, default 4; 1 = whole blocks).  Sub-block (b, q) is csr_blocks[b*chunks+q].
+    int chunks = 1;
+    int chunkA = 0, chunkB = 0;  // rows per chunk of a visiting A / B block
+
     // hold_moving_operand(): the remote blocks of this matrix stay valid in mesh_spare / ring_spare[0] between calls
     const double* held_ptr = nullptr;
-    bool held_fetched = false;
+    bool held_in_mesh = false, held_in_ring = false;  // which landing buffers currently hold its remote blocks
 
     void hold_moving_operand(const DenseMatrix* m) override {
         if (std::getenv("HNH_NO_HOLD") != nullptr) return;  // A/B switch for measurements
         held_ptr = m ? m->data() : nullptr;
-        held_fetched = false;
+        held_in_mesh = held_in_ring = false;
     }
     void release_moving_operand() override {
         held_ptr = nullptr;
-        held_fetched = false;
+        held_in_mesh = held_in_ring = false;
     }
 
     Sparse15D_Dense_Shift(SpmatLocal* S_input, int R, int c, int fusionApproach, KernelImplementation* k) : Distributed_Sparse(k) {
@@ -92,19 +98,27 @@ public:
         localBrows = divideAndRoundUp((int)this->N, p);
         setRValue(R);
 
+        if (fusionApproach == 2 && p / c > 1) {
+            chunks = 4;
+            if (const char* q = std::getenv("HNH_MESH_CHUNKS")) chunks = std::atoi(q);
+            if (chunks < 1 || chunks > 8) hnh::fatal("Error, HNH_MESH_CHUNKS must be between 1 and 8!");
+        }
+        chunkA = divideAndRoundUp(localArows, chunks);
+        chunkB = divideAndRoundUp(localBrows, chunks);
+
         const uint64_t arows = (uint64_t)localArows * c, brows = (uint64_t)localBrows * c;
         S->localize(arows, 0);
-        S->divideIntoBlockCols(localBrows, p, true);
+        S->divideIntoBlockCols(localBrows, p, true, chunks, chunkB);
         ST->localize(brows, 0);
-        ST->divideIntoBlockCols(localArows, p, true);
+        ST->divideIntoBlockCols(localArows, p, true, chunks, chunkA);
 
         S->own_all_coordinates();
         ST->own_all_coordinates();
 
         const bool local_tpose = (fusionApproach == 1);
-        S->initializeCSRBlocks(localArows * c, localBrows, -1, local_tpose);
+        S->initializeCSRBlocks(localArows * c, chunkB, -1, local_tpose);
         S->release_tuples();
-        ST->initializeCSRBlocks(localBrows * c, localArows, -1, local_tpose);
+        ST->initializeCSRBlocks(localBrows * c, chunkA, -1, local_tpose);
         ST->release_tuples();
         check_initialized();
     }
@@ -185,35 +199,53 @@ private:
         }
 
         const unsigned base = HNH_FUSED_VALUES_OVERWRITE | act_flag;
+        const int cw = (choice == S.get()) ? chunkB : chunkA;  // rows per chunk of the visiting blocks
         bool out_fresh = true;
-        if (ring_mode == kMeshFetch && n > 2) {
-            // every remote block lands at once: local block while they fly, then ALL the others in one launch
-            std::vector<DenseMatrix*> fetched = mesh_fetch_all(Brole, n);
-            auto t = start_clock();
-            if (choice->csr_blocks[block_at(0)] != nullptr) {
-                kernel->fused_local(*choice, *rowOperand, *Brole, *accum, block_at(0), base | HNH_FUSED_OUT_OVERWRITE, act);
-                out_fresh = false;
-            }
-            world->event_wait(event(1), HNH_STREAM_COMPUTE);  // the remote blocks have landed
+        // the fused kernel on the sub-blocks (ring step i, chunk q) of `steps` x `qs`, all in ONE launch
+        auto launch = [&](const std::vector<std::pair<int, DenseMatrix*>>& steps, int q_begin, int q_end, const hnh_fused_extras* ex) {
+            std::vector<DenseMatrix> views;
+            std::vector<DenseMatrix*> Ys;
             std::vector<int> ids;
+            views.reserve(steps.size() * (size_t)(q_end - q_begin));
             bool any = false;
-            for (int i = 1; i < n; i++) {
-                ids.push_back(block_at(i));
-                any = any || choice->csr_blocks[block_at(i)] != nullptr;
-            }
-            if (any || last != act) {
-                kernel->fused_multi_local(*choice, *rowOperand, fetched, *accum, ids, base | (out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u), last);
-                out_fresh = false;
+            for (auto& st : steps)
+                for (int q = q_begin; q < q_end; q++) {
+                    const int id = block_at(st.first) * chunks + q;
+                    views.push_back(chunk_view(*st.second, q, cw));
+                    Ys.push_back(&views.back());
+                    ids.push_back(id);
+                    any = any || choice->csr_blocks[id] != nullptr;
+                }
+            if (!any && ex == act) return;  // nothing to multiply and no epilogue to run
+            kernel->fused_multi_local(*choice, *rowOperand, Ys, *accum, ids, base | (out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u), ex);
+            out_fresh = false;
+        };
+
+        if (ring_mode == kMeshFetch && n > 1) {
+            // the remote blocks arrive chunk by chunk over all links at once: local block while chunk 0 flies, then
+            // chunk q of ALL remote blocks in one launch while chunk q+1 is still on the links
+            std::vector<DenseMatrix*> fetched = mesh_fetch_chunked(Brole, n, cw);
+            auto t = start_clock();
+            launch({{0, Brole}}, 0, chunks, act);
+            std::vector<std::pair<int, DenseMatrix*>> remote;
+            for (int i = 1; i < n; i++) remote.push_back({i, fetched[i - 1]});
+            for (int q = 0; q < chunks; q++) {
+                world->event_wait(event(8 + q), HNH_STREAM_COMPUTE);  // chunk q of every remote block has landed
+                launch(remote, q, q + 1, q == chunks - 1 ? last : act);
             }
             stop_clock_and_add(t, "Computation Time");
         } else {
             ring_readonly(Brole, n, [&](int i, DenseMatrix& cur) {
                 auto t = start_clock();
-                const int block_id = block_at(i);
                 const hnh_fused_extras* ex = (i == n - 1) ? last : act;
-                if (choice->csr_blocks[block_id] != nullptr || ex != act) {
-                    kernel->fused_local(*choice, *rowOperand, cur, *accum, block_id, base | (out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u), ex);
-                    out_fresh = false;
+                if (chunks == 1) {  // one block per step: the plain row kernel
+                    const int block_id = block_at(i);
+                    if (choice->csr_blocks[block_id] != nullptr || ex != act) {
+                        kernel->fused_local(*choice, *rowOperand, cur, *accum, block_id, base | (out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u), ex);
+                        out_fresh = false;
+                    }
+                } else {
+                    launch({{i, &cur}}, 0, chunks, ex);
                 }
                 stop_clock_and_add(t, "Computation Time");
             });
@@ -275,9 +307,17 @@ public:
         if (fusionApproach == 2 && mode == k_spmmB) mode_temp = k_spmmA;
         DenseMatrix& stationary = (c > 1) ? accumulation_buffer : *Arole;
 
+        const int cw = (choice == S.get()) ? chunkB : chunkA;
         auto step = [&](int i, DenseMatrix& cur) {
             auto t = start_clock();
-            kernel->triple_function(mode_temp, *choice, stationary, cur, block_at(i), 0);
+            if (chunks == 1) {
+                kernel->triple_function(mode_temp, *choice, stationary, cur, block_at(i), 0);
+            } else {  // approach 2 keeps S in column chunks of each block: same kernels on each chunk's rows of `cur`
+                for (int q = 0; q < chunks; q++) {
+                    DenseMatrix part = chunk_view(cur, q, cw);
+                    kernel->triple_function(mode_temp, *choice, stationary, part, block_at(i) * chunks + q, 0);
+                }
+            }
             stop_clock_and_add(t, "Computation Time");
         };
 
@@ -328,14 +368,48 @@ private:
                 DenseMatrix* target = &ring_spare[i % 2];
                 if (i >= 2) world->event_wait(event(3 + (i - 1) % 2), HNH_STREAM_COMM);    // kernel i-1 last read `target`
                 const bool held = (n == 2 && held_ptr == start->data());  // a ring of two: the one remote block can stay
-                if (!(held && held_fetched))
+                if (!(held && held_in_ring))
                     world->sendrecv(grid->col_world, cur->data(), bytes, dst, target->data(), bytes, src, HNH_STREAM_COMM);
-                if (held) held_fetched = true;
+                if (held) held_in_ring = true;
                 world->event_record(event(1 + i % 2), HNH_STREAM_COMM);
                 cur = target;
                 stop_clock_and_add(t, "Cyclic Shift Time");
             }
         }
+    }
+
+    // rows [q * cw, (q + 1) * cw) of a visiting block (clipped; possibly empty)
+    static DenseMatrix chunk_view(DenseMatrix& block, int q, int cw) {
+        const int64_t r0 = std::min<int64_t>((int64_t)q * cw, block.rows());
+        const int64_t r1 = std::min<int64_t>(r0 + cw, block.rows());
+        return DenseMatrix::view(block.data() + r0 * block.cols(), r1 - r0, block.cols());
+    }
+
+    // mesh_fetch_all in `chunks` row ranges: group q moves rows [q*cw, (q+1)*cw) of every remote block (all n-1 links
+    // busy in every group) and event(8 + q) is recorded behind it, so consumers can start on chunk q while q+1 flies.
+    std::vector<DenseMatrix*> mesh_fetch_chunked(DenseMatrix* start, int n, int cw) {
+        if ((int)mesh_spare.size() < n - 1) mesh_spare.resize(n - 1);
+        for (int k = 0; k < n - 1; k++) ensure(mesh_spare[k], start->rows(), start->cols());
+        auto t = start_clock();
+        order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // my block is final; earlier readers of the landing buffers are done
+        const bool held = (held_ptr == start->data());
+        for (int q = 0; q < chunks; q++) {
+            const int64_t r0 = std::min<int64_t>((int64_t)q * cw, start->rows()), r1 = std::min<int64_t>(r0 + cw, start->rows());
+            const size_t off = (size_t)r0 * start->cols(), bytes = (size_t)(r1 - r0) * start->cols() * sizeof(double);
+            if (bytes > 0 && !(held && held_in_mesh)) {  // a held operand's blocks are still in the landing buffers
+                world->group_begin();
+                for (int k = 1; k < n; k++)  // my block is what ring rank me+k needs at ITS step k; I need the block of me-k at mine
+                    world->sendrecv(grid->col_world, start->data() + off, bytes, pMod(grid->rankInCol + k, n), mesh_spare[k - 1].data() + off,
+                                    bytes, pMod(grid->rankInCol - k, n), HNH_STREAM_COMM);
+                world->group_end();
+            }
+            world->event_record(event(8 + q), HNH_STREAM_COMM);
+        }
+        if (held) held_in_mesh = true;
+        stop_clock_and_add(t, "Cyclic Shift Time");
+        std::vector<DenseMatrix*> out;
+        for (int k = 0; k < n - 1; k++) out.push_back(&mesh_spare[k]);
+        return out;
     }
 
     // Issues all n-1 owner->consumer transfers of a read-only moving operand as one group on the communication
@@ -347,14 +421,14 @@ private:
         auto t = start_clock();
         order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // my block is final; earlier readers of the landing buffers are done
         const bool held = (held_ptr == start->data());
-        if (!(held && held_fetched)) {  // a held operand's blocks are still in the landing buffers from the previous call
+        if (!(held && held_in_mesh)) {  // a held operand's blocks are still in the landing buffers from the previous call
             world->group_begin();
             for (int k = 1; k < n; k++)  // my block is what ring rank me+k needs at ITS step k; I need the block of me-k at mine
                 world->sendrecv(grid->col_world, start->data(), bytes, pMod(grid->rankInCol + k, n), mesh_spare[k - 1].data(), bytes,
                                 pMod(grid->rankInCol - k, n), HNH_STREAM_COMM);
             world->group_end();
         }
-        if (held) held_fetched = true;
+        if (held) held_in_mesh = true;
         world->event_record(event(1), HNH_STREAM_COMM);
         stop_clock_and_add(t, "Cyclic Shift Time");
         std::vector<DenseMatrix*> out;

@@ -171,6 +171,8 @@ int hnh_expand_rowptr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, int32_t
  *   HNH_KEY_OWNER    owner_table[(R / rows_in_block) * n_col_blocks + (C / cols_in_block)] with (R, C) = (r, c), or (c, r)
  *                    when `transpose` — NonzeroDistribution::getOwner; owner_table is a DEVICE array
  *   HNH_KEY_COL_DIV  c / div         — block column of divideIntoBlockCols
+ *   HNH_KEY_COL_DIV2 (c / div) * n_sub + (c % div) / sub_div — block column, then one of n_sub column chunks inside it
+ *                    (the chunked mesh fetch of the 1.5D dense-shift schedule pipelines on these)
  * hnh_tuples_sort          stable in-place sort by key (LSD radix sort of (key, index) pairs + one gather); key_bits =
  *                          number of significant key bits (<= 0: 64), fewer bits = fewer radix passes
  * hnh_tuples_bucket_starts for tuples whose keys are non-decreasing: starts_host[b] = first index with key >= b,
@@ -187,6 +189,7 @@ typedef struct hnh_tuple {
 #define HNH_KEY_COL_ROW 1
 #define HNH_KEY_OWNER 2
 #define HNH_KEY_COL_DIV 3
+#define HNH_KEY_COL_DIV2 4
 typedef struct hnh_tuple_key {
     int kind;
     int transpose;               /* HNH_KEY_OWNER */
@@ -194,7 +197,9 @@ typedef struct hnh_tuple_key {
     int64_t cols_in_block;       /* HNH_KEY_OWNER */
     int64_t n_col_blocks;        /* HNH_KEY_OWNER */
     const int32_t* owner_table;  /* HNH_KEY_OWNER, device */
-    int64_t div;                 /* HNH_KEY_COL_DIV */
+    int64_t div;                 /* HNH_KEY_COL_DIV, HNH_KEY_COL_DIV2 */
+    int64_t sub_div;             /* HNH_KEY_COL_DIV2 */
+    int64_t n_sub;               /* HNH_KEY_COL_DIV2 */
 } hnh_tuple_key;
 int hnh_tuples_sort(hnh_ctx* ctx, hnh_tuple* tuples, int64_t n, const hnh_tuple_key* key, int key_bits, int stream);
 int hnh_tuples_bucket_starts(hnh_ctx* ctx, const hnh_tuple* sorted, int64_t n, const hnh_tuple_key* key, int64_t nbuckets,

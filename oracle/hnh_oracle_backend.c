@@ -340,6 +340,7 @@ static uint64_t tuple_key(const hnh_tuple* t, const hnh_tuple_key* k) {
             const uint64_t cb = (k->transpose ? t->r : t->c) / (uint64_t)k->cols_in_block;
             return (uint64_t)(uint32_t)k->owner_table[rb * (uint64_t)k->n_col_blocks + cb];
         }
+        case HNH_KEY_COL_DIV2: return (t->c / (uint64_t)k->div) * (uint64_t)k->n_sub + (t->c % (uint64_t)k->div) / (uint64_t)k->sub_div;
         default: return t->c / (uint64_t)k->div;
     }
 }
@@ -348,7 +349,9 @@ static int key_ok(hnh_ctx* c, const hnh_tuple_key* k) {
     if (k->kind == HNH_KEY_OWNER && (k->rows_in_block <= 0 || k->cols_in_block <= 0 || k->n_col_blocks <= 0 || !k->owner_table))
         return fail(c, HNH_ERR_INVALID, "incomplete owner key");
     if (k->kind == HNH_KEY_COL_DIV && k->div <= 0) return fail(c, HNH_ERR_INVALID, "column divisor must be positive");
-    if (k->kind < HNH_KEY_ROW_COL || k->kind > HNH_KEY_COL_DIV) return fail(c, HNH_ERR_INVALID, "unknown key kind");
+    if (k->kind == HNH_KEY_COL_DIV2 && (k->div <= 0 || k->sub_div <= 0 || k->n_sub <= 0 || k->sub_div * k->n_sub < k->div))
+        return fail(c, HNH_ERR_INVALID, "chunks must be positive and cover the block column");
+    if (k->kind < HNH_KEY_ROW_COL || k->kind > HNH_KEY_COL_DIV2) return fail(c, HNH_ERR_INVALID, "unknown key kind");
     return HNH_OK;
 }
 typedef struct { uint64_t key; int64_t idx; } keyed_t;

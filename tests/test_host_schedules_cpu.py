@@ -135,3 +135,22 @@ def test_perf_counter_keys_match_the_reference():
     for alg, keys in expect.items():
         assert set(res[alg]) == keys, (alg, res[alg])
         assert res[alg]["Computation Time"] > 0
+
+
+@pytest.mark.parametrize("chunks", [1, 3, 8])
+@pytest.mark.parametrize("ring", ["mesh", "relay"])
+def test_chunked_mesh_fetch_any_chunk_count(chunks, ring, monkeypatch):
+    """Local kernel fusion keeps S in column chunks of each block so that the fetch of the visiting dense blocks can be
+    pipelined chunk by chunk (HNH_MESH_CHUNKS; default 4 everywhere else in this suite): same results for 1 (whole
+    blocks), a count that does not divide the block (ragged last chunk, empty chunks on tiny blocks) and the maximum."""
+    monkeypatch.setenv("HNH_MESH_CHUNKS", str(chunks))
+    monkeypatch.setenv("HNH_RING_MODE", ring)
+    for name in ("er8_r16", "ragged_r8", "tiny_r8"):
+        case = T.case_inputs(name)
+        for p, c in [(2, 1), (4, 2), (8, 1)]:
+            per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, "15d_fusion2", c, case))
+            T.check_against_golden(T.assemble(per_rank, case), per_rank, case, "15d_fusion2")
+    case = T.case_inputs("rect_r16")
+    for matmode in (H.AMAT, H.BMAT):
+        per_rank = H.run_spmd(4, lambda w: T.run_fused_out(w, "15d_fusion2", 1, case, matmode, 0.2, 0.5, True))
+        T.check_fused_out(per_rank, case, matmode, 0.2, 0.5, True)

@@ -24,6 +24,8 @@ def key_of(t, kind, **kw):
     if kind == K.KEY_OWNER:
         rr, cc = (c, r) if kw["transpose"] else (r, c)
         return kw["table"][(rr // np.uint64(kw["rib"])) * np.uint64(kw["ncb"]) + cc // np.uint64(kw["cib"])].astype(np.uint64)
+    if kind == K.KEY_COL_DIV2:
+        return (c // np.uint64(kw["div"])) * np.uint64(kw["n_sub"]) + (c % np.uint64(kw["div"])) // np.uint64(kw["sub_div"])
     return c // np.uint64(kw["div"])
 
 
@@ -35,19 +37,21 @@ def run(api):
     table = np.random.default_rng(4).integers(0, 8, 10 * 7).astype(np.int32)  # 10 x 7 blocks of 100 x 111, 8 owners
     dtab = api.upload(table)
     cases = [(K.KEY_ROW_COL, {}, 64), (K.KEY_COL_ROW, {}, 32 + 10), (K.KEY_COL_DIV, dict(div=100), 4),
+             (K.KEY_COL_DIV2, dict(div=100, sub_div=34, n_sub=3), 5),
              (K.KEY_OWNER, dict(transpose=0, rib=100, cib=111, ncb=7, table=table), 3),
              (K.KEY_OWNER, dict(transpose=1, rib=111, cib=100, ncb=10, table=table), 3)]
     for kind, kw, bits in cases:
         if kind == K.KEY_OWNER and kw["transpose"]:  # 7 x 10 blocks over the transposed matrix
             kw["table"] = table[:70]
-        key = K.TupleKey(kind, kw.get("transpose", 0), kw.get("rib", 0), kw.get("cib", 0), kw.get("ncb", 0), dtab.ptr, kw.get("div", 0))
+        key = K.TupleKey(kind, kw.get("transpose", 0), kw.get("rib", 0), kw.get("cib", 0), kw.get("ncb", 0), dtab.ptr, kw.get("div", 0),
+                         kw.get("sub_div", 0), kw.get("n_sub", 0))
         d = api.upload(t0)
         api.check(lib.hnh_tuples_sort(h, d.ptr, n, C.byref(key), bits, 0), "tuples_sort")
         got = d.get().view(K.TUPLE_DTYPE).reshape(-1)
         order = np.argsort(key_of(t0, kind, **kw), kind="stable")   # the sort is stable
         assert np.array_equal(got, t0[order]), "kind %d" % kind
         # boundaries
-        nb = int(key_of(t0, kind, **kw).max()) + 1 if kind in (K.KEY_OWNER, K.KEY_COL_DIV) else 5
+        nb = int(key_of(t0, kind, **kw).max()) + 1 if kind in (K.KEY_OWNER, K.KEY_COL_DIV, K.KEY_COL_DIV2) else 5
         starts = np.zeros(nb + 1, dtype=np.int64)
         api.check(lib.hnh_tuples_bucket_starts(h, d.ptr, n, C.byref(key), nb, starts.ctypes.data_as(C.c_void_p), 0), "bucket_starts")
         want = np.searchsorted(key_of(got, kind, **kw), np.arange(nb + 1, dtype=np.uint64), side="left")
@@ -75,11 +79,11 @@ def run(api):
     # empty input
     api.check(lib.hnh_tuples_to_csr(h, None, 0, 4, 4, drp.ptr, None, None, C.byref(mx), 0), "to_csr empty")
     assert np.array_equal(drp.get().reshape(-1)[:5], np.zeros(5, np.int32)) and mx.value == 0
-    api.check(lib.hnh_tuples_sort(h, None, 0, C.byref(K.TupleKey(K.KEY_ROW_COL, 0, 0, 0, 0, None, 0)), 64, 0), "sort empty")
+    api.check(lib.hnh_tuples_sort(h, None, 0, C.byref(K.TupleKey(K.KEY_ROW_COL, 0, 0, 0, 0, None, 0, 0, 0)), 64, 0), "sort empty")
     # indices beyond 32 bits cannot be keyed
     big = t0[:10].copy(); big["r"][3] = 1 << 33
     db = api.upload(big)
-    assert lib.hnh_tuples_sort(h, db.ptr, 10, C.byref(K.TupleKey(K.KEY_ROW_COL, 0, 0, 0, 0, None, 0)), 64, 0) != 0
+    assert lib.hnh_tuples_sort(h, db.ptr, 10, C.byref(K.TupleKey(K.KEY_ROW_COL, 0, 0, 0, 0, None, 0, 0, 0)), 64, 0) != 0
     for x in (d, drp, dci, dv, dtab, db):
         x.free()
     run_generator(api)
