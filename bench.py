@@ -204,7 +204,9 @@ def run(args, make_world=gpu_world):
                        "setup_s": round(t_setup, 2)},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "kernel": "row_kernel<fused> (hnh_fused_sddmm_spmm_csr)", "avg_launch_ms": dur * 1e3,
+                         "kernel": "row_kernel<fused> (hnh_fused_sddmm_spmm_csr)" if launches_per_call == 1 else
+                                   "fused_multi_kernel (hnh_fused_sddmm_spmm_csr_multi), local block + one launch per fetched chunk",
+                         "avg_launch_ms": dur * 1e3,
                          "launches_per_step": launches_per_call, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "model": "nnz*(8R+24) + 16*R*rows per launch (SURVEY 8d)"},
         }
