@@ -15,7 +15,7 @@ def main():
     ap.add_argument("--tag", required=True)
     ap.add_argument("--stats")
     ap.add_argument("--pmc", nargs="*", default=[])
-    ap.add_argument("--kernel-like", default="row_kernel")
+    ap.add_argument("--kernel-like", default="::row_kernel<")  # not max_row_kernel of the setup pipeline
     ap.add_argument("--workload-key", default="")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))
     a = ap.parse_args()
