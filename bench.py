@@ -165,9 +165,9 @@ def run(args, make_world=gpu_world):
     kern_ms, launches = op.kernel_profile(0)
     local_nnz = op.info()["nS"]
     launches_per_call_local = max(1, launches // prof_calls)
-    # per nonzero 8R + 24 bytes; per row and launch 16R (row operand read + output row written); every
-    # launch of this rank walks the localArows*c rows of its block row
-    alg_bytes_per_call = local_nnz * (8 * args.r + 24) + 16 * args.r * op.info()["localArows"] * args.c * launches_per_call_local
+    # SURVEY 8(d), per fused call of this rank: per nonzero 8R + 24 bytes, per output row 16R (row operand read + output
+    # row written ONCE) — however many launches the implementation uses (it re-reads rows per launch; that is its cost)
+    alg_bytes_per_call = local_nnz * (8 * args.r + 24) + 16 * args.r * op.info()["localArows"] * args.c
     if dist is not None:
         t = torch.tensor([kern_ms, float(launches), float(alg_bytes_per_call)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -204,11 +204,11 @@ def run(args, make_world=gpu_world):
                        "setup_s": round(t_setup, 2)},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "kernel": "row_kernel<fused> (hnh_fused_sddmm_spmm_csr)" if launches_per_call == 1 else
-                                   "fused_multi_kernel (hnh_fused_sddmm_spmm_csr_multi), local block + one launch per fetched chunk",
+                         "kernel": ("row_kernel<fused> (hnh_fused_sddmm_spmm_csr), one launch per Infinity-Cache panel of B" if n == 1 else
+                                    "fused_multi_kernel (hnh_fused_sddmm_spmm_csr_multi), local block + one launch per fetched chunk"),
                          "avg_launch_ms": dur * 1e3,
                          "launches_per_step": launches_per_call, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "model": "nnz*(8R+24) + 16*R*rows per launch (SURVEY 8d)"},
+                         "model": "per fused call nnz*(8R+24) + 16*R*rows (SURVEY 8d), divided evenly over its launches"},
         }
         if n == 1 and not args.no_cpu_baseline and out["backend"] == "hip-gfx950":
             try:

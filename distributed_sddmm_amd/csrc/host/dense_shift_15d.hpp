@@ -47,9 +47,15 @@ public:
     std::vector<DenseMatrix> mesh_spare;  // mesh fetch: one landing buffer per remote ring position
     enum RingMode { kRelay, kMeshFetch };
     RingMode ring_mode;
-    // Chunked mesh fetch (approach 2): every block column of S is cut into `chunks` column ranges = row ranges of the
-    // visiting dense block, so the fetch can be issued chunk by chunk and the kernels of chunk q run while chunk q+1
-    // is still on the links (HNH_MESH_CHUNKS, default 4; 1 = whole blocks).  Sub-block (b, q) is csr_blocks[b*chunks+q].
+    // Column chunks (approach 2): every block column of S is cut into `chunks` column ranges = row ranges of the visiting
+    // dense block; sub-block (b, q) is csr_blocks[b * chunks + q].  Two uses:
+    //  * several ranks: the fetch is issued chunk by chunk and the kernels of chunk q run while chunk q+1 is still on the
+    //    links (default 4 chunks);
+    //  * one rank per ring (p == c, e.g. a single GPU): one launch per chunk, so the rows of the gathered operand that a
+    //    launch touches (a 512 MiB panel by default) mostly stay in the 256 MiB Infinity Cache — measured 16.8 -> 14.8 ms
+    //    at config 2 (R = 128: 2 panels), 35.6 -> 31.3 ms at R = 256 (4 panels), no gain below 512 MiB
+    //    (profiles/r01_panel_probe_same_box.log).
+    // HNH_MESH_CHUNKS overrides the count (1 = whole blocks).
     int chunks = 1;
     int chunkA = 0, chunkB = 0;  // rows per chunk of a visiting A / B block
 
@@ -98,8 +104,14 @@ public:
         localBrows = divideAndRoundUp((int)this->N, p);
         setRValue(R);
 
-        if (fusionApproach == 2 && p / c > 1) {
-            chunks = 4;
+        if (fusionApproach == 2) {
+            if (p / c > 1) {
+                chunks = 4;
+            } else {  // Infinity-Cache panels of ~512 MiB of the gathered operand
+                const double panel = 512.0 * 1024.0 * 1024.0;
+                const double bytes = (double)std::max(localArows, localBrows) * (double)R * sizeof(double);
+                chunks = std::max(1, std::min(8, (int)std::lround(bytes / panel)));
+            }
             if (const char* q = std::getenv("HNH_MESH_CHUNKS")) chunks = std::atoi(q);
             if (chunks < 1 || chunks > 8) hnh::fatal("Error, HNH_MESH_CHUNKS must be between 1 and 8!");
         }
@@ -238,10 +250,15 @@ private:
             ring_readonly(Brole, n, [&](int i, DenseMatrix& cur) {
                 auto t = start_clock();
                 const hnh_fused_extras* ex = (i == n - 1) ? last : act;
-                if (chunks == 1) {  // one block per step: the plain row kernel
-                    const int block_id = block_at(i);
-                    if (choice->csr_blocks[block_id] != nullptr || ex != act) {
-                        kernel->fused_local(*choice, *rowOperand, cur, *accum, block_id, base | (out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u), ex);
+                if (chunks == 1 || n == 1) {
+                    // the plain row kernel, one launch per block — or, on a ring of one, per column chunk: the panel of
+                    // `cur` that a launch gathers from then fits the Infinity Cache
+                    for (int q = 0; q < chunks; q++) {
+                        const int block_id = block_at(i) * chunks + q;
+                        const hnh_fused_extras* exq = (q == chunks - 1) ? ex : act;
+                        if (choice->csr_blocks[block_id] == nullptr && exq == act) continue;
+                        DenseMatrix part = chunk_view(cur, q, cw);
+                        kernel->fused_local(*choice, *rowOperand, part, *accum, block_id, base | (out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u), exq);
                         out_fresh = false;
                     }
                 } else {

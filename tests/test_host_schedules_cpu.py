@@ -147,10 +147,11 @@ def test_chunked_mesh_fetch_any_chunk_count(chunks, ring, monkeypatch):
     monkeypatch.setenv("HNH_RING_MODE", ring)
     for name in ("er8_r16", "ragged_r8", "tiny_r8"):
         case = T.case_inputs(name)
-        for p, c in [(2, 1), (4, 2), (8, 1)]:
+        for p, c in [(1, 1), (2, 1), (2, 2), (4, 2), (8, 1)]:
             per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, "15d_fusion2", c, case))
             T.check_against_golden(T.assemble(per_rank, case), per_rank, case, "15d_fusion2")
     case = T.case_inputs("rect_r16")
-    for matmode in (H.AMAT, H.BMAT):
-        per_rank = H.run_spmd(4, lambda w: T.run_fused_out(w, "15d_fusion2", 1, case, matmode, 0.2, 0.5, True))
-        T.check_fused_out(per_rank, case, matmode, 0.2, 0.5, True)
+    for p in (1, 4):  # a ring of one launches once per chunk (cache panels), several ranks pipeline the fetch on them
+        for matmode in (H.AMAT, H.BMAT):
+            per_rank = H.run_spmd(p, lambda w: T.run_fused_out(w, "15d_fusion2", 1, case, matmode, 0.2, 0.5, True))
+            T.check_fused_out(per_rank, case, matmode, 0.2, 0.5, True)

@@ -188,3 +188,15 @@ def test_fused_out_with_extras_hip(monkeypatch, mode, p, c):
             per_rank = H.run_spmd(p, lambda w: T.run_fused_out(w, "15d_fusion2", c, case, matmode, alpha, xs, dot))
             assert all(o["supported"] for o in per_rank)
             T.check_fused_out(per_rank, case, matmode, alpha, xs, dot)
+
+
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_column_chunks_hip(monkeypatch, chunks):
+    """Column chunks of S under local kernel fusion (Infinity-Cache panels on a ring of one, pipelined fetch on several
+    ranks): same results for any chunk count, incl. one that does not divide the block."""
+    monkeypatch.setenv("HNH_MESH_CHUNKS", str(chunks))
+    for name in ("er8_r16", "ragged_r8"):
+        case = T.case_inputs(name)
+        for p, c in [(1, 1), (2, 2), (4, 1), (8, 2)]:
+            per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, "15d_fusion2", c, case))
+            T.check_against_golden(T.assemble(per_rank, case), per_rank, case, "15d_fusion2")
