@@ -53,6 +53,54 @@ __device__ __forceinline__ void store_w(double* __restrict__ p, const double (&s
     }
 }
 
+// Streaming (use-once) data — the row operand, the output row, the per-nonzero values — can be marked non-temporal so
+// that it does not displace the gathered operand's rows from L2 / the Infinity Cache (tuning knob HNH_NT_STREAM).
+#ifndef HNH_NT_STREAM
+#define HNH_NT_STREAM 0
+#endif
+typedef double d2_t __attribute__((ext_vector_type(2)));
+template <int W>
+__device__ __forceinline__ void load_w_stream(double (&dst)[W], const double* __restrict__ p) {
+#if HNH_NT_STREAM
+    if constexpr (W == 2) {
+        const d2_t t = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(p));
+        dst[0] = t.x;
+        dst[1] = t.y;
+    } else {
+        dst[0] = __builtin_nontemporal_load(p);
+    }
+#else
+    load_w<W>(dst, p);
+#endif
+}
+template <int W>
+__device__ __forceinline__ void store_w_stream(double* __restrict__ p, const double (&src)[W]) {
+#if HNH_NT_STREAM
+    if constexpr (W == 2) {
+        d2_t t; t.x = src[0]; t.y = src[1];
+        __builtin_nontemporal_store(t, reinterpret_cast<d2_t*>(p));
+    } else {
+        __builtin_nontemporal_store(src[0], p);
+    }
+#else
+    store_w<W>(p, src);
+#endif
+}
+__device__ __forceinline__ double load_stream(const double* p) {
+#if HNH_NT_STREAM
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void store_stream(double* p, double v) {
+#if HNH_NT_STREAM
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
 
 // Broadcast the value held by lane `src` of each LPR-lane group to the whole group.
@@ -169,9 +217,9 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
 #pragma unroll
         for (int w = 0; w < W; w++) { x[v][w] = 0.0; acc[v][w] = 0.0; }
         if (act[v]) {
-            if constexpr (OP != Op::kSpmm) load_w<W>(x[v], X + row * ld + coff[v]);
+            if constexpr (OP != Op::kSpmm) load_w_stream<W>(x[v], X + row * ld + coff[v]);
             if constexpr (OP != Op::kSddmm) {
-                if (!atomic_out && !(flags & HNH_FUSED_OUT_OVERWRITE)) load_w<W>(acc[v], Out + row * ld + coff[v]);
+                if (!atomic_out && !(flags & HNH_FUSED_OUT_OVERWRITE)) load_w_stream<W>(acc[v], Out + row * ld + coff[v]);
             }
         }
     }
@@ -198,7 +246,7 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
         double wgt;  // weight of nonzero (e + lig / SUB), valid in every lane of its SUB-lane subgroup
         const int mine = e + lig / SUB;
         if constexpr (OP == Op::kSpmm) {
-            wgt = (mine < end) ? values[mine] : 0.0;
+            wgt = (mine < end) ? load_stream(values + mine) : 0.0;
             if (svalues != nullptr && mine < end) wgt *= svalues[mine];
         } else {
             double d[U];
@@ -214,13 +262,13 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
             wgt = group_multi_reduce<LPR, U>(d, lig);
             if (mine < end) {
                 const bool overwrite = (OP == Op::kFused) && (flags & HNH_FUSED_VALUES_OVERWRITE);
-                if (!overwrite) wgt += values[mine];
+                if (!overwrite) wgt += load_stream(values + mine);
                 if (OP == Op::kFused && (flags & HNH_FUSED_LEAKY_RELU)) {  // the activated weight is what gets stored
                     if (svalues != nullptr) wgt *= svalues[mine];
                     wgt = wgt > 0.0 ? wgt : ex.leaky_alpha * wgt;
-                    if (lig % SUB == 0) values[mine] = wgt;
+                    if (lig % SUB == 0) store_stream(values + mine, wgt);
                 } else {
-                    if (lig % SUB == 0) values[mine] = wgt;
+                    if (lig % SUB == 0) store_stream(values + mine, wgt);
                     if (OP == Op::kFused && svalues != nullptr) wgt *= svalues[mine];
                 }
             } else {
@@ -262,7 +310,7 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
 #pragma unroll
                 for (int w = 0; w < W; w++) unsafeAtomicAdd(Out + row * ld + coff[v] + w, acc[v][w]);
             } else {
-                store_w<W>(Out + row * ld + coff[v], acc[v]);
+                store_w_stream<W>(Out + row * ld + coff[v], acc[v]);
             }
         }
     }
