@@ -12,6 +12,11 @@ struct hnh_ctx {
     void* long_items[2] = {nullptr, nullptr};
     int* long_count[2] = {nullptr, nullptr};
     size_t long_cap[2] = {0, 0};
+    // per-row panel boundaries of the Infinity-Cache panels (one per stream): (panels - 1) x rows int32
+    void* panel_split[2] = {nullptr, nullptr};
+    size_t panel_cap[2] = {0, 0};
+    bool no_panels = false;  // HNH_NO_PANELS=1: A/B switch
+    double panel_bytes = 512.0 * 1024.0 * 1024.0;  // bytes of the gathered operand per panel (HNH_PANEL_BYTES; tests shrink it)
 };
 
 namespace hnh {

@@ -317,7 +317,8 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
 }
 
 template <Op OP, int LPR, int VEC, int W, bool EXACT>
-__global__ __launch_bounds__(kBlock) void row_kernel(int64_t rows, const int32_t* __restrict__ rowptr,
+__global__ __launch_bounds__(kBlock) void row_kernel(int64_t rows, const int32_t* __restrict__ beg_ptr,
+                                                     const int32_t* __restrict__ end_ptr,
                                                      const int32_t* __restrict__ colidx, double* values,
                                                      const double* __restrict__ svalues,
                                                      const double* __restrict__ X, const double* __restrict__ Y,
@@ -330,8 +331,10 @@ __global__ __launch_bounds__(kBlock) void row_kernel(int64_t rows, const int32_t
     if constexpr (LPR == 64) row = ((int64_t)blockIdx.x * GROUPS) + __builtin_amdgcn_readfirstlane(tid >> 6);
     if (row >= rows) return;
 
-    int beg = rowptr[row];
-    int end = rowptr[row + 1];
+    // the row's nonzeros handled by this launch: the whole row (beg_ptr = rowptr, end_ptr = rowptr + 1) or the part of it
+    // that falls into one column panel (per-row boundaries from panel_split_kernel)
+    int beg = beg_ptr[row];
+    int end = end_ptr[row];
     if constexpr (LPR == 64) {
         beg = __builtin_amdgcn_readfirstlane(beg);
         end = __builtin_amdgcn_readfirstlane(end);
@@ -456,6 +459,30 @@ __global__ __launch_bounds__(kBlock) void fused_multi_kernel(int64_t rows, Multi
 #pragma unroll
     for (int v = 0; v < VEC; v++)
         if (act[v]) store_w<W>(Out + row * ld + coff[v], acc[v]);
+}
+
+// Infinity-Cache panels.  A launch that gathers from ALL rows of the dense operand revisits them at random across a
+// working set several times the 256 MiB memory-side cache; restricting a launch to the nonzeros of one column panel
+// (~512 MiB of the operand) lets about half of its gathers hit that cache (measured -12 % at config 2).  Column indices
+// are sorted within a CSR row, so a panel is a contiguous piece of every row: split[(q-1) * rows + r] = first nonzero
+// of row r with column >= q * width, q = 1 .. panels-1; launch q works on [split[q-1][r], split[q][r]).
+__global__ __launch_bounds__(kBlock) void panel_split_kernel(int64_t rows, const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ colidx, int panels, int width,
+                                                             int32_t* __restrict__ split) {
+    const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= rows) return;
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    int lo = beg;
+    for (int q = 1; q < panels; q++) {
+        const int bound = q * width;
+        int hi = end;  // boundaries are non-decreasing in q: continue from the previous one
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (colidx[mid] < bound) lo = mid + 1;
+            else hi = mid;
+        }
+        split[(int64_t)(q - 1) * rows + row] = lo;
+    }
 }
 
 // One work item = kLongSeg consecutive nonzeros of a long row; items are listed by build_long_list_kernel.
@@ -971,15 +998,15 @@ int prepare_long(hnh_ctx* ctx, hipStream_t st, int sidx, int64_t rows, const int
 }
 
 template <Op OP, int LPR, int VEC, int W, bool EXACT>
-int launch_row(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, int64_t rows, const int32_t* rowptr, const int32_t* colidx,
-               double* values, const double* svalues, const double* X, const double* Y, double* Out, int64_t ld,
-               int col0, int ncols, unsigned flags, const Extras& ex) {
+int launch_row(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, int64_t rows, const int32_t* rowptr, const int32_t* beg_ptr,
+               const int32_t* end_ptr, const int32_t* colidx, double* values, const double* svalues, const double* X, const double* Y,
+               double* Out, int64_t ld, int col0, int ncols, unsigned flags, const Extras& ex) {
     constexpr int GROUPS = kBlock / LPR;
     const int64_t blocks = (rows + GROUPS - 1) / GROUPS;
     if (blocks <= 0) return HNH_OK;
     if (blocks > 0x7fffffffLL) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "too many rows for one launch");
     if (lc.enabled) flags |= kInternalSplitLong;
-    hipLaunchKernelGGL((row_kernel<OP, LPR, VEC, W, EXACT>), dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, rowptr,
+    hipLaunchKernelGGL((row_kernel<OP, LPR, VEC, W, EXACT>), dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, beg_ptr, end_ptr,
                        colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, ex);
     if (int rc = hnh::check_hip(ctx, hipGetLastError(), "row_kernel launch")) return rc;
     if (lc.enabled) {
@@ -991,21 +1018,15 @@ int launch_row(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, int64_t rows, co
     return HNH_OK;
 }
 
+// one launch of the instance that fits (shape, R) over the row pieces [beg_ptr[r], end_ptr[r]); returns -1 when R needs
+// column tiles instead
 template <Op OP>
-int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t rows, int64_t nnz, int max_row_nnz,
-                 const int32_t* rowptr, const int32_t* colidx, double* values, const double* svalues, const double* X,
-                 const double* Y, double* Out, int R, unsigned flags, const Extras& ex = Extras(), bool* epilogue_done = nullptr) {
-    LongCtl lc;
-    if (int rc = prepare_long(ctx, st, sidx, rows, rowptr, nnz, max_row_nnz, &lc)) return rc;
-    // the row epilogue runs inside the launch only when every output row is completed by ONE group (no hub-row
-    // segments adding atomically afterwards, no column tiles); otherwise the caller appends row_epilogue_kernel
-    if (epilogue_done != nullptr) {
-        *epilogue_done = !lc.enabled && (s.exact || R <= 64 * s.w * 4);
-        if (*epilogue_done) flags |= kInternalEpilogue;
-    }
-#define HNH_CASE(L, V)                                                                                         \
-    if (s.lpr == L && s.vec == V)                                                                              \
-        return launch_row<OP, L, V, 2, true>(ctx, st, lc, rows, rowptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags, ex);
+int launch_shape(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, const Shape& s, int64_t rows, const int32_t* rowptr,
+                 const int32_t* beg_ptr, const int32_t* end_ptr, const int32_t* colidx, double* values, const double* svalues,
+                 const double* X, const double* Y, double* Out, int R, unsigned flags, const Extras& ex) {
+#define HNH_CASE(L, V)                                                                                                     \
+    if (s.lpr == L && s.vec == V)                                                                                          \
+        return launch_row<OP, L, V, 2, true>(ctx, st, lc, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags, ex);
     if (s.exact) {
         HNH_CASE(1, 1) HNH_CASE(2, 1) HNH_CASE(4, 1) HNH_CASE(8, 1) HNH_CASE(16, 1) HNH_CASE(32, 1) HNH_CASE(64, 1)
         HNH_CASE(64, 2) HNH_CASE(64, 3) HNH_CASE(64, 4) HNH_CASE(32, 3) HNH_CASE(32, 5) HNH_CASE(32, 7)
@@ -1013,12 +1034,63 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
     }
 #undef HNH_CASE
     // Widths that are not a supported exact multiple: one bounds-checked pass when the row fits the widest
-    // instance (R <= 512 even / 256 odd) ...
-#define HNH_NX(V, WW)                                                                                              \
-    if (s.w == WW && R <= 64 * WW * V)                                                                             \
-        return launch_row<OP, 64, V, WW, false>(ctx, st, lc, rows, rowptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags, ex);
+    // instance (R <= 512 even / 256 odd)
+#define HNH_NX(V, WW)                                                                                                      \
+    if (s.w == WW && R <= 64 * WW * V)                                                                                     \
+        return launch_row<OP, 64, V, WW, false>(ctx, st, lc, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags, ex);
     HNH_NX(1, 2) HNH_NX(2, 2) HNH_NX(4, 2) HNH_NX(1, 1) HNH_NX(2, 1) HNH_NX(4, 1)
 #undef HNH_NX
+    return -1;
+}
+
+constexpr int kMaxPanels = 8;
+
+// cols: number of rows of the gathered operand (= columns of the sparse block), or < 0 when unknown (no panels)
+template <Op OP>
+int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t rows, int64_t nnz, int max_row_nnz, int64_t cols,
+                 const int32_t* rowptr, const int32_t* colidx, double* values, const double* svalues, const double* X,
+                 const double* Y, double* Out, int R, unsigned flags, const Extras& ex = Extras(), bool* epilogue_done = nullptr) {
+    LongCtl lc;
+    if (int rc = prepare_long(ctx, st, sidx, rows, rowptr, nnz, max_row_nnz, &lc)) return rc;
+    const bool single_pass = s.exact || R <= 64 * s.w * 4;
+    // the row epilogue runs inside the launch only when every output row is completed by ONE group (no hub-row
+    // segments adding atomically afterwards, no column tiles); otherwise the caller appends row_epilogue_kernel
+    if (epilogue_done != nullptr) *epilogue_done = !lc.enabled && single_pass;
+    const unsigned epi = (epilogue_done != nullptr && *epilogue_done) ? kInternalEpilogue : 0u;
+
+    // Infinity-Cache panels (see panel_split_kernel): only for plain short-row blocks and single-pass widths
+    int panels = 1;
+    if (cols > 0 && !lc.enabled && single_pass && !ctx->no_panels) {
+        const long p = std::lround((double)cols * (double)R * sizeof(double) / ctx->panel_bytes);
+        panels = (int)(p < 1 ? 1 : (p > kMaxPanels ? kMaxPanels : p));
+    }
+    if (panels > 1) {
+        const size_t need = (size_t)(panels - 1) * (size_t)rows * sizeof(int32_t);
+        if (ctx->panel_cap[sidx] < need) {
+            HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
+            if (ctx->panel_split[sidx]) HNH_TRY_HIP(ctx, hipFree(ctx->panel_split[sidx]));
+            ctx->panel_split[sidx] = nullptr;
+            HNH_TRY_HIP(ctx, hipMalloc(&ctx->panel_split[sidx], need));
+            ctx->panel_cap[sidx] = need;
+        }
+        int32_t* split = static_cast<int32_t*>(ctx->panel_split[sidx]);
+        const int width = (int)((cols + panels - 1) / panels);
+        hipLaunchKernelGGL(panel_split_kernel, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, rows, rowptr, colidx, panels,
+                           width, split);
+        if (int rc = hnh::check_hip(ctx, hipGetLastError(), "panel_split_kernel launch")) return rc;
+        for (int q = 0; q < panels; q++) {
+            const int32_t* beg_ptr = (q == 0) ? rowptr : split + (size_t)(q - 1) * rows;
+            const int32_t* end_ptr = (q == panels - 1) ? rowptr + 1 : split + (size_t)q * rows;
+            unsigned f = flags;
+            if (q > 0) f &= ~HNH_FUSED_OUT_OVERWRITE;  // later panels add to the rows the first one wrote
+            if (q == panels - 1) f |= epi;             // the last panel completes the rows
+            if (int rc = launch_shape<OP>(ctx, st, lc, s, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, f, ex)) return rc;
+        }
+        return HNH_OK;
+    }
+
+    const int rc1 = launch_shape<OP>(ctx, st, lc, s, rows, rowptr, rowptr, rowptr + 1, colidx, values, svalues, X, Y, Out, R, flags | epi, ex);
+    if (rc1 != -1) return rc1;
     // ... else column tiles; SDDMM partial dot products accumulate into `values` tile by tile
     if (OP == Op::kFused) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "fused fallback is composed by the caller");
     const int tile = 64 * s.w;
@@ -1026,9 +1098,9 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
         const int ncols = (R - col0 < tile) ? (R - col0) : tile;
         int rc;
         if (s.w == 2)
-            rc = launch_row<OP, 64, 1, 2, false>(ctx, st, lc, rows, rowptr, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags, ex);
+            rc = launch_row<OP, 64, 1, 2, false>(ctx, st, lc, rows, rowptr, rowptr, rowptr + 1, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags, ex);
         else
-            rc = launch_row<OP, 64, 1, 1, false>(ctx, st, lc, rows, rowptr, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags, ex);
+            rc = launch_row<OP, 64, 1, 1, false>(ctx, st, lc, rows, rowptr, rowptr, rowptr + 1, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags, ex);
         if (rc != HNH_OK) return rc;
     }
     return HNH_OK;
@@ -1058,48 +1130,48 @@ int check_common(hnh_ctx* ctx, int64_t n, int R, const char* who) {
 extern "C" {
 
 int hnh_sddmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
-                     const double* X, const double* Y, int R, int64_t nnz, int max_row_nnz, int stream) {
+                     const double* X, const double* Y, int R, int64_t nnz, int max_row_nnz, int64_t cols, int stream) {
     HNH_ENTER(ctx, stream);
     if (int rc = check_common(ctx, rows, R, "hnh_sddmm_csr")) return rc;
     if (rows == 0) return HNH_OK;
     if (!rowptr || !col_idx || !values || !X || !Y) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sddmm_csr: null pointer");
     const Shape s = pick_shape(R, aligned16(X) && aligned16(Y));
-    return dispatch_row<Op::kSddmm>(ctx, ctx->streams[stream], stream, s, rows, nnz, max_row_nnz, rowptr, col_idx, values, nullptr, X,
+    return dispatch_row<Op::kSddmm>(ctx, ctx->streams[stream], stream, s, rows, nnz, max_row_nnz, cols, rowptr, col_idx, values, nullptr, X,
                                     Y, nullptr, R, 0u);
 }
 
 int hnh_sddmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
                   const double* X, const double* Y, int R, int stream) {
-    return hnh_sddmm_csr_ex(ctx, rows, rowptr, col_idx, values, X, Y, R, -1, -1, stream);
+    return hnh_sddmm_csr_ex(ctx, rows, rowptr, col_idx, values, X, Y, R, -1, -1, -1, stream);
 }
 
 int hnh_spmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values,
                  const double* X, double* Out, int R, int stream) {
-    return hnh_spmm_csr_ex(ctx, rows, rowptr, col_idx, values, X, Out, R, -1, -1, stream);
+    return hnh_spmm_csr_ex(ctx, rows, rowptr, col_idx, values, X, Out, R, -1, -1, -1, stream);
 }
 
 int hnh_spmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values,
-                    const double* X, double* Out, int R, int64_t nnz, int max_row_nnz, int stream) {
+                    const double* X, double* Out, int R, int64_t nnz, int max_row_nnz, int64_t cols, int stream) {
     HNH_ENTER(ctx, stream);
     if (int rc = check_common(ctx, rows, R, "hnh_spmm_csr")) return rc;
     if (rows == 0) return HNH_OK;
     if (!rowptr || !col_idx || !values || !X || !Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_spmm_csr: null pointer");
     if (X == Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_spmm_csr: X and Out alias");
     const Shape s = pick_shape(R, aligned16(X) && aligned16(Out));
-    return dispatch_row<Op::kSpmm>(ctx, ctx->streams[stream], stream, s, rows, nnz, max_row_nnz, rowptr, col_idx,
+    return dispatch_row<Op::kSpmm>(ctx, ctx->streams[stream], stream, s, rows, nnz, max_row_nnz, cols, rowptr, col_idx,
                                    const_cast<double*>(values), nullptr, X, nullptr, Out, R, 0u);
 }
 
 int hnh_fused_sddmm_spmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
                              const double* svalues, const double* X, const double* Y, double* Out, int R,
                              unsigned flags, int stream) {
-    return hnh_fused_sddmm_spmm_csr_ex(ctx, rows, rowptr, col_idx, values, svalues, X, Y, Out, R, flags, -1, -1, stream);
+    return hnh_fused_sddmm_spmm_csr_ex(ctx, rows, rowptr, col_idx, values, svalues, X, Y, Out, R, flags, -1, -1, -1, stream);
 }
 
 int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
                                 const double* svalues, const double* X, const double* Y, double* Out, int R,
-                                unsigned flags, int64_t nnz_in, int max_row_nnz, int stream) {
-    return hnh_fused_sddmm_spmm_csr_x(ctx, rows, rowptr, col_idx, values, svalues, X, Y, Out, R, flags, nnz_in, max_row_nnz, nullptr, stream);
+                                unsigned flags, int64_t nnz_in, int max_row_nnz, int64_t cols, int stream) {
+    return hnh_fused_sddmm_spmm_csr_x(ctx, rows, rowptr, col_idx, values, svalues, X, Y, Out, R, flags, nnz_in, max_row_nnz, cols, nullptr, stream);
 }
 
 }  // extern "C"
@@ -1140,7 +1212,7 @@ extern "C" {
 
 int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
                                const double* svalues, const double* X, const double* Y, double* Out, int R, unsigned flags,
-                               int64_t nnz_in, int max_row_nnz, const hnh_fused_extras* extras, int stream) {
+                               int64_t nnz_in, int max_row_nnz, int64_t cols, const hnh_fused_extras* extras, int stream) {
     HNH_ENTER(ctx, stream);
     if (int rc = check_common(ctx, rows, R, "hnh_fused_sddmm_spmm_csr")) return rc;
     Extras ex;
@@ -1154,7 +1226,7 @@ int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr
     const Shape s = pick_shape(R, aligned16(X) && aligned16(Y) && aligned16(Out));
     if (s.exact || R <= 256 * s.w) {  // one pass: an exact instance, or a bounds-checked one wide enough for the whole row
         bool done = false;
-        if (int rc = dispatch_row<Op::kFused>(ctx, st, stream, s, rows, nnz_in, max_row_nnz, rowptr, col_idx, values, svalues, X, Y, Out, R,
+        if (int rc = dispatch_row<Op::kFused>(ctx, st, stream, s, rows, nnz_in, max_row_nnz, cols, rowptr, col_idx, values, svalues, X, Y, Out, R,
                                               flags, ex, want_epilogue ? &done : nullptr))
             return rc;
         if (want_epilogue && !done) return launch_row_epilogue(ctx, st, Out, X, ex.x_scale, ex.rowdot, rows, R);
@@ -1171,7 +1243,7 @@ int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr
     }
     if (flags & HNH_FUSED_VALUES_OVERWRITE) HNH_TRY_HIP(ctx, hipMemsetAsync(values, 0, sizeof(double) * (size_t)nnz, st));
     if (flags & HNH_FUSED_OUT_OVERWRITE) HNH_TRY_HIP(ctx, hipMemsetAsync(Out, 0, sizeof(double) * (size_t)rows * R, st));
-    if (int rc = dispatch_row<Op::kSddmm>(ctx, st, stream, s, rows, nnz, max_row_nnz, rowptr, col_idx, values, nullptr, X, Y, nullptr, R, 0u))
+    if (int rc = dispatch_row<Op::kSddmm>(ctx, st, stream, s, rows, nnz, max_row_nnz, cols, rowptr, col_idx, values, nullptr, X, Y, nullptr, R, 0u))
         return rc;
     if (flags & HNH_FUSED_LEAKY_RELU) {
         if (svalues) {
@@ -1181,7 +1253,7 @@ int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr
         hipLaunchKernelGGL(leaky_relu_kernel, dim3(ew_grid(nnz)), dim3(kBlock), 0, st, values, ex.leaky_alpha, nnz);
         if (int rc = hnh::check_hip(ctx, hipGetLastError(), "leaky_relu_kernel launch")) return rc;
     }
-    if (int rc = dispatch_row<Op::kSpmm>(ctx, st, stream, s, rows, nnz, max_row_nnz, rowptr, col_idx, values, svalues, Y, nullptr, Out, R, 0u))
+    if (int rc = dispatch_row<Op::kSpmm>(ctx, st, stream, s, rows, nnz, max_row_nnz, cols, rowptr, col_idx, values, svalues, Y, nullptr, Out, R, 0u))
         return rc;
     if (want_epilogue) return launch_row_epilogue(ctx, st, Out, X, ex.x_scale, ex.rowdot, rows, R);
     return HNH_OK;
@@ -1251,7 +1323,7 @@ int hnh_fused_sddmm_spmm_csr_multi_x(hnh_ctx* ctx, int64_t rows, int nblocks, co
         for (int b = 0; b < nblocks; b++) {
             const unsigned f = (b == 0) ? flags : (flags & ~HNH_FUSED_OUT_OVERWRITE);
             if (int rc = hnh_fused_sddmm_spmm_csr_x(ctx, rows, blocks[b].rowptr, blocks[b].col_idx, blocks[b].values, nullptr, X,
-                                                    blocks[b].Y, Out, R, f, blocks[b].nnz, blocks[b].max_row_nnz, &act_only, stream))
+                                                    blocks[b].Y, Out, R, f, blocks[b].nnz, blocks[b].max_row_nnz, -1, &act_only, stream))
                 return rc;
         }
         if (want_epilogue) return launch_row_epilogue(ctx, st, Out, X, ex.x_scale, ex.rowdot, rows, R);

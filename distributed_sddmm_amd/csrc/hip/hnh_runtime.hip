@@ -1,6 +1,8 @@
 // Context / memory / stream / event entry points of include/hnh_kernels.h (gfx950, HIP runtime only).
 #include <hip/hip_runtime.h>
 #include <new>
+#include <cstdlib>
+
 #include "hnh_ctx.hpp"
 
 extern "C" {
@@ -17,6 +19,11 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
     hnh_ctx* ctx = new (std::nothrow) hnh_ctx();
     if (!ctx) return HNH_ERR_NOMEM;
     ctx->device = device;
+    ctx->no_panels = std::getenv("HNH_NO_PANELS") != nullptr;
+    if (const char* pb = std::getenv("HNH_PANEL_BYTES")) {
+        const double v = std::atof(pb);
+        if (v >= 1.0) ctx->panel_bytes = v;
+    }
     for (int s = 0; s < 2; s++) {
         if (hipStreamCreateWithFlags(&ctx->streams[s], hipStreamNonBlocking) != hipSuccess) {
             delete ctx;
@@ -34,6 +41,7 @@ int hnh_ctx_destroy(hnh_ctx* ctx) {
         if (ctx->streams[s]) { (void)hipStreamSynchronize(ctx->streams[s]); (void)hipStreamDestroy(ctx->streams[s]); }
         if (ctx->long_items[s]) (void)hipFree(ctx->long_items[s]);
         if (ctx->long_count[s]) (void)hipFree(ctx->long_count[s]);
+        if (ctx->panel_split[s]) (void)hipFree(ctx->panel_split[s]);
     }
     delete ctx;
     return HNH_OK;

@@ -15,7 +15,7 @@ size_t StandardKernel::sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
     hnh::World* w = S.world;
     begin(w);
     w->check(w->be->hnh_sddmm_csr_ex(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, Xptr, Yptr,
-                                     (int)A.cols(), blk->num_coords, blk->row_hint(), HNH_STREAM_COMPUTE),
+                                     (int)A.cols(), blk->num_coords, blk->row_hint(), blk->cols, HNH_STREAM_COMPUTE),
              "hnh_sddmm_csr");
     end(w);
     return processed;
@@ -35,7 +35,7 @@ size_t StandardKernel::spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B,
     double* Out = (mode == Amat) ? A.data() : B.data();
     begin(w);
     w->check(w->be->hnh_spmm_csr_ex(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, X, Out, (int)A.cols(),
-                                    blk->num_coords, blk->row_hint(), HNH_STREAM_COMPUTE),
+                                    blk->num_coords, blk->row_hint(), blk->cols, HNH_STREAM_COMPUTE),
              "hnh_spmm_csr");
     end(w);
     return processed;
@@ -59,7 +59,7 @@ size_t StandardKernel::fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
     CSRHandle* active = blk->getActive();
     begin(w);
     w->check(w->be->hnh_fused_sddmm_spmm_csr_x(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, nullptr, A.data(),
-                                               B.data(), Out.data(), (int)A.cols(), flags, blk->num_coords, blk->row_hint(), extras,
+                                               B.data(), Out.data(), (int)A.cols(), flags, blk->num_coords, blk->row_hint(), blk->cols, extras,
                                                HNH_STREAM_COMPUTE),
              "hnh_fused_sddmm_spmm_csr");
     end(w);

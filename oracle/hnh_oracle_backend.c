@@ -100,8 +100,8 @@ int hnh_sddmm_csr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t
 }
 
 int hnh_sddmm_csr_ex(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values, const double* X,
-                     const double* Y, int R, int64_t nnz, int max_row_nnz, int stream) {
-    (void)nnz; (void)max_row_nnz;  /* hints only */
+                     const double* Y, int R, int64_t nnz, int max_row_nnz, int64_t cols, int stream) {
+    (void)nnz; (void)max_row_nnz; (void)cols;  /* hints only */
     return hnh_sddmm_csr(c, rows, rowptr, col_idx, values, X, Y, R, stream);
 }
 
@@ -122,8 +122,8 @@ int hnh_spmm_csr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t*
 }
 
 int hnh_spmm_csr_ex(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values, const double* X,
-                    double* Out, int R, int64_t nnz, int max_row_nnz, int stream) {
-    (void)nnz; (void)max_row_nnz;
+                    double* Out, int R, int64_t nnz, int max_row_nnz, int64_t cols, int stream) {
+    (void)nnz; (void)max_row_nnz; (void)cols;
     return hnh_spmm_csr(c, rows, rowptr, col_idx, values, X, Out, R, stream);
 }
 
@@ -149,8 +149,8 @@ int hnh_fused_sddmm_spmm_csr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, co
 
 int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
                                 const double* svalues, const double* X, const double* Y, double* Out, int R, unsigned flags,
-                                int64_t nnz, int max_row_nnz, int stream) {
-    (void)nnz; (void)max_row_nnz;
+                                int64_t nnz, int max_row_nnz, int64_t cols, int stream) {
+    (void)nnz; (void)max_row_nnz; (void)cols;
     return hnh_fused_sddmm_spmm_csr(c, rows, rowptr, col_idx, values, svalues, X, Y, Out, R, flags, stream);
 }
 
@@ -172,8 +172,8 @@ int hnh_row_epilogue_f64(hnh_ctx* c, double* Out, const double* X, double x_scal
 /* gat.hpp:96-99: SDDMM, LeakyReLU on the values, SpMM with them; then the row epilogue */
 int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
                                const double* svalues, const double* X, const double* Y, double* Out, int R, unsigned flags,
-                               int64_t nnz_hint, int max_row_nnz, const hnh_fused_extras* ex, int stream) {
-    (void)nnz_hint; (void)max_row_nnz;
+                               int64_t nnz_hint, int max_row_nnz, int64_t cols, const hnh_fused_extras* ex, int stream) {
+    (void)nnz_hint; (void)max_row_nnz; (void)cols;
     if (rows < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad size");
     if ((flags & HNH_FUSED_LEAKY_RELU) && !ex) return fail(c, HNH_ERR_INVALID, "HNH_FUSED_LEAKY_RELU needs extras");
     if (rows == 0) return HNH_OK;
@@ -206,7 +206,7 @@ int hnh_fused_sddmm_spmm_csr_multi_x(hnh_ctx* c, int64_t rows, int nblocks, cons
     for (int b = 0; b < nblocks; b++) {  /* block after block: 15D_dense_shift.hpp:199-227 */
         const unsigned f = (b == 0) ? flags : (flags & ~HNH_FUSED_OUT_OVERWRITE);
         int rc = hnh_fused_sddmm_spmm_csr_x(c, rows, blocks[b].rowptr, blocks[b].col_idx, blocks[b].values, NULL, X, blocks[b].Y, Out, R, f,
-                                            -1, -1, &act_only, stream);
+                                            -1, -1, -1, &act_only, stream);
         if (rc != HNH_OK) return rc;
     }
     if (ex && (ex->x_scale != 0.0 || ex->rowdot)) return hnh_row_epilogue_f64(c, Out, X, ex->x_scale, ex->rowdot, rows, R, stream);

@@ -71,7 +71,7 @@ def test_c_test_double_extras_follow_the_numpy_statement():
         v, out, dot = v0.copy(), out0.copy(), np.zeros(rows)
         ex = K.FusedExtras(alpha, xs, dot.ctypes.data)
         assert lib.hnh_fused_sddmm_spmm_csr_x(ctx, C.c_int64(rows), p(rowptr), p(cidx), p(v), p(sv) if use_sv else None, p(X), p(Y), p(out),
-                                              R, C.c_uint(flags), C.c_int64(-1), -1, C.byref(ex), 0) == 0
+                                              R, C.c_uint(flags), C.c_int64(-1), -1, C.c_int64(-1), C.byref(ex), 0) == 0
         vb = np.zeros(len(keys)) if flags & 1 else v0
         ob = np.zeros((rows, R)) if flags & 2 else out0
         vals = O.sddmm_local(ridx, cidx, vb, X, Y)

@@ -234,17 +234,17 @@ def test_hub_rows_are_split_and_still_exact(ctx, R, hinted):
     ctx.check(lib.hnh_csr_max_row_nnz(ctx.h, rows, d_rp.ptr, C.byref(mx), 0), "max_row")
     assert mx.value == 5000
     h_nnz, h_max = (nnz, mx.value) if hinted else (-1, -1)
-    ctx.check(lib.hnh_sddmm_csr_ex(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, dX.ptr, dY.ptr, R, h_nnz, h_max, 0), "sddmm")
+    ctx.check(lib.hnh_sddmm_csr_ex(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, dX.ptr, dY.ptr, R, h_nnz, h_max, cols, 0), "sddmm")
     assert rel(dv.get(), O.sddmm_local(ridx, cidx, v0, X, Y)) <= TOL
     dv.set(v0)
-    ctx.check(lib.hnh_spmm_csr_ex(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, dY.ptr, dOut.ptr, R, h_nnz, h_max, 0), "spmm")
+    ctx.check(lib.hnh_spmm_csr_ex(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, dY.ptr, dOut.ptr, R, h_nnz, h_max, cols, 0), "spmm")
     assert rel(dOut.get(), O.spmm_local(rowptr, cidx, v0, Y, out0)) <= TOL
     for flags in (0, K.FUSED_VALUES_OVERWRITE | K.FUSED_OUT_OVERWRITE):
         dv.set(v0); dOut.set(out0)
         vbase = v0 if flags == 0 else np.zeros(nnz)
         obase = out0 if flags == 0 else np.zeros((rows, R))
         ctx.check(lib.hnh_fused_sddmm_spmm_csr_ex(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, None, dX.ptr, dY.ptr, dOut.ptr, R, flags,
-                                                  h_nnz, h_max, 0), "fused")
+                                                  h_nnz, h_max, cols, 0), "fused")
         vals = O.sddmm_local(ridx, cidx, vbase, X, Y)
         assert rel(dv.get(), vals) <= TOL
         assert rel(dOut.get(), O.spmm_local(rowptr, cidx, vals, Y, obase)) <= TOL
@@ -343,7 +343,7 @@ def test_fused_extras_activation_and_row_epilogue(ctx, R):
         dv.set(v0); dOut.set(out0); ddot.set(np.full(rows, 9.0))
         ex = K.FusedExtras(alpha, xs, ddot.ptr if want_dot else None)
         ctx.check(lib.hnh_fused_sddmm_spmm_csr_x(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, dsv.ptr if use_sv else None, dX.ptr, dY.ptr,
-                                                 dOut.ptr, R, flags, nnz, int(np.diff(rowptr).max()), C.byref(ex), 0), "fused_x")
+                                                 dOut.ptr, R, flags, nnz, int(np.diff(rowptr).max()), cols, C.byref(ex), 0), "fused_x")
         vals, out, dot = _extras_expected(rowptr, ridx, cidx, v0, sv if use_sv else None, X, Y, out0, flags, alpha, xs)
         assert rel(dv.get(), vals) <= TOL
         assert rel(dOut.get(), out) <= TOL
@@ -351,7 +351,7 @@ def test_fused_extras_activation_and_row_epilogue(ctx, R):
             assert rel(ddot.get(), dot) <= TOL
     # the flag without extras is a caller error
     assert lib.hnh_fused_sddmm_spmm_csr_x(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, None, dX.ptr, dY.ptr, dOut.ptr, R, K.FUSED_LEAKY_RELU, -1, -1,
-                                          None, 0) != 0
+                                          -1, None, 0) != 0
     # standalone epilogue and the CG update
     dOut.set(out0)
     ctx.check(lib.hnh_row_epilogue_f64(ctx.h, dOut.ptr, dX.ptr, 0.25, ddot.ptr, rows, R, 0), "row_epilogue")
@@ -386,7 +386,7 @@ def test_fused_extras_with_hub_rows_and_many_blocks(ctx, R):
     flags = K.FUSED_VALUES_OVERWRITE | K.FUSED_OUT_OVERWRITE | K.FUSED_LEAKY_RELU
     ex = K.FusedExtras(0.2, 1e-2, ddot.ptr)
     ctx.check(lib.hnh_fused_sddmm_spmm_csr_x(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, None, dX.ptr, dY.ptr, dOut.ptr, R, flags, -1, -1,
-                                             C.byref(ex), 0), "fused_x hub")
+                                             cols, C.byref(ex), 0), "fused_x hub")
     vals, out, dot = _extras_expected(rowptr, ridx, cidx, v0, None, X, Y, out0, flags, 0.2, 1e-2)
     assert rel(dv.get(), vals) <= TOL and rel(dOut.get(), out) <= TOL and rel(ddot.get(), dot) <= TOL
     for d in (d_rp, d_c, dv, dX, dY, dOut, ddot):
@@ -418,3 +418,38 @@ def test_fused_extras_with_hub_rows_and_many_blocks(ctx, R):
                 h.free()
         dOut.free(); ddot.free()
     dX.free()
+
+
+@pytest.mark.parametrize("R", [8, 128, 100, 256])
+@pytest.mark.parametrize("panel_bytes", [20000, 150000])
+def test_infinity_cache_panels_do_not_change_results(monkeypatch, R, panel_bytes):
+    """With the `cols` hint a pass runs as one launch per column panel of the block (a contiguous piece of every CSR row);
+    the panel size is shrunk here so that small blocks get 2..8 panels.  sddmm / spmm / fused (+ extras) must match."""
+    monkeypatch.setenv("HNH_PANEL_BYTES", str(panel_bytes))
+    from distributed_sddmm_amd import _kernels as K
+    c = K.Ctx(0)
+    lib = c.lib
+    rows, cols = 257, 300
+    rowptr, ridx, cidx = random_block(rows, cols, 6000, seed=R + 1)
+    nnz = len(cidx)
+    rng = np.random.default_rng(R)
+    X, Y = rng.uniform(-1, 1, (rows, R)), rng.uniform(-1, 1, (cols, R))
+    v0, out0 = rng.uniform(-1, 1, nnz), rng.uniform(-1, 1, (rows, R))
+    d_rp, d_c, dv, dX, dY, dOut, ddot = (c.upload(a) for a in (rowptr, cidx, v0, X, Y, out0, np.zeros(rows)))
+    mx = int(np.diff(rowptr).max())
+    c.check(lib.hnh_sddmm_csr_ex(c.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, dX.ptr, dY.ptr, R, nnz, mx, cols, 0), "sddmm")
+    assert rel(dv.get(), O.sddmm_local(ridx, cidx, v0, X, Y)) <= TOL
+    dv.set(v0)
+    c.check(lib.hnh_spmm_csr_ex(c.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, dY.ptr, dOut.ptr, R, nnz, mx, cols, 0), "spmm")
+    assert rel(dOut.get(), O.spmm_local(rowptr, cidx, v0, Y, out0)) <= TOL
+    OW = K.FUSED_VALUES_OVERWRITE | K.FUSED_OUT_OVERWRITE
+    for flags, alpha, xs in [(OW | K.FUSED_LEAKY_RELU, 0.2, 0.0), (OW, 0.0, 1e-3), (0, 0.0, -2.0), (K.FUSED_LEAKY_RELU, 0.1, 0.5)]:
+        dv.set(v0); dOut.set(out0)
+        ex = K.FusedExtras(alpha, xs, ddot.ptr)
+        c.check(lib.hnh_fused_sddmm_spmm_csr_x(c.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, None, dX.ptr, dY.ptr, dOut.ptr, R, flags, nnz, mx, cols,
+                                               C.byref(ex), 0), "fused_x")
+        vals, out, dot = _extras_expected(rowptr, ridx, cidx, v0, None, X, Y, out0, flags, alpha, xs)
+        assert rel(dv.get(), vals) <= TOL and rel(dOut.get(), out) <= TOL and rel(ddot.get(), dot) <= TOL
+    for d in (d_rp, d_c, dv, dX, dY, dOut, ddot):
+        d.free()
+    c.close()

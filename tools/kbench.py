@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--ops", default="fused,sddmm,spmm")
     ap.add_argument("--rmat", action="store_true", help="skewed R-MAT graph instead of Erdos-Renyi")
+    ap.add_argument("--panels", action="store_true", help="pass the hints (nnz, longest row, cols) so that the library may "
+                    "run the pass as Infinity-Cache panels")
     a = ap.parse_args()
     t0 = time.time()
     if a.rmat:
@@ -64,6 +66,15 @@ def main():
             name, R, t * 1e3, nnz * R / t, bytes_alg / 1e9, bytes_alg / t / 1e12, 100 * bytes_alg / t / 8e12), flush=True)
 
     ops = a.ops.split(",")
+    if a.panels:
+        mx = C.c_int()
+        ctx.check(lib.hnh_csr_max_row_nnz(ctx.h, m, d_rowptr.ptr, C.byref(mx), 0), "max_row")
+        timed(lambda: ctx.check(lib.hnh_fused_sddmm_spmm_csr_ex(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, None, dA.ptr, dB.ptr, dOut.ptr, R, 3,
+                                                                nnz, mx.value, m, 0), "fused"), "fusedP", nnz * (8 * R + 24) + 16 * R * m)
+        timed(lambda: ctx.check(lib.hnh_sddmm_csr_ex(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, dA.ptr, dB.ptr, R, nnz, mx.value, m, 0), "sddmm"),
+              "sddmmP", nnz * (8 * R + 20) + 8 * R * m)
+        timed(lambda: ctx.check(lib.hnh_spmm_csr_ex(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, dB.ptr, dOut.ptr, R, nnz, mx.value, m, 0), "spmm"),
+              "spmmP", nnz * (8 * R + 12) + 16 * R * m)
     if "fused" in ops:
         timed(lambda: ctx.check(lib.hnh_fused_sddmm_spmm_csr(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, None, dA.ptr, dB.ptr,
                                                              dOut.ptr, R, 3, 0), "fused"), "fused", nnz * (8 * R + 24) + 16 * R * m)

@@ -33,7 +33,7 @@ for P in [int(x) for x in a.panels.split(",")]:
 
     def run_blocks():
         for p, (drp, dc, dv) in enumerate(blocks):
-            ctx.check(lib.hnh_fused_sddmm_spmm_csr_ex(ctx.h, m, drp.ptr, dc.ptr, dv.ptr, None, dA.ptr, dB.ptr, dOut.ptr, R, 1 | (2 if p == 0 else 0), dv.shape[0], 200, 0), "fused")
+            ctx.check(lib.hnh_fused_sddmm_spmm_csr_ex(ctx.h, m, drp.ptr, dc.ptr, dv.ptr, None, dA.ptr, dB.ptr, dOut.ptr, R, 1 | (2 if p == 0 else 0), dv.shape[0], 200, -1, 0), "fused")
 
     def run_multi():
         ctx.check(lib.hnh_fused_sddmm_spmm_csr_multi(ctx.h, m, P, C.byref(arr), dA.ptr, dOut.ptr, R, 3, 0), "multi")
