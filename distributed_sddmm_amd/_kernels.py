@@ -43,6 +43,7 @@ SIGNATURES = {
     "hnh_sddmm_csr_ex": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i64, _i32]),
     "hnh_spmm_csr_ex": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i64, _i32]),
     "hnh_fused_sddmm_spmm_csr_ex": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _i64, _i32, _i64, _i32]),
+    "hnh_panel_count": (_i32, [_vp, _i64, _i32, _i32]),
     "hnh_csr_max_row_nnz": (_i32, [_vp, _i64, _vp, C.POINTER(C.c_int), _i32]),
     "hnh_fused_sddmm_spmm_csr_multi": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, C.c_uint, _i32]),
     "hnh_fused_sddmm_spmm_csr_x": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _i64, _i32, _i64, _vp, _i32]),

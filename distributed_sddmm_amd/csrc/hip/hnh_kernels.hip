@@ -1044,6 +1044,11 @@ int launch_shape(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, const Shape& s
 }
 
 constexpr int kMaxPanels = 8;
+int panel_count(const hnh_ctx* ctx, int64_t cols, int R) {
+    if (cols <= 0 || ctx->no_panels) return 1;
+    const long p = std::lround((double)cols * (double)R * sizeof(double) / ctx->panel_bytes);
+    return (int)(p < 1 ? 1 : (p > kMaxPanels ? kMaxPanels : p));
+}
 
 // cols: number of rows of the gathered operand (= columns of the sparse block), or < 0 when unknown (no panels)
 template <Op OP>
@@ -1059,11 +1064,7 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
     const unsigned epi = (epilogue_done != nullptr && *epilogue_done) ? kInternalEpilogue : 0u;
 
     // Infinity-Cache panels (see panel_split_kernel): only for plain short-row blocks and single-pass widths
-    int panels = 1;
-    if (cols > 0 && !lc.enabled && single_pass && !ctx->no_panels) {
-        const long p = std::lround((double)cols * (double)R * sizeof(double) / ctx->panel_bytes);
-        panels = (int)(p < 1 ? 1 : (p > kMaxPanels ? kMaxPanels : p));
-    }
+    const int panels = (!lc.enabled && single_pass) ? panel_count(ctx, cols, R) : 1;
     if (panels > 1) {
         const size_t need = (size_t)(panels - 1) * (size_t)rows * sizeof(int32_t);
         if (ctx->panel_cap[sidx] < need) {
@@ -1128,6 +1129,14 @@ int check_common(hnh_ctx* ctx, int64_t n, int R, const char* who) {
 }  // namespace
 
 extern "C" {
+
+int hnh_panel_count(hnh_ctx* ctx, int64_t cols, int R, int max_row_nnz) {
+    if (!ctx || R <= 0) return 1;
+    if (max_row_nnz < 0 || max_row_nnz > kLongRow) return 1;  // hub rows (or unknown): the long-row pass, no panels
+    const Shape s = pick_shape(R, true);
+    if (!(s.exact || R <= 64 * s.w * 4)) return 1;
+    return panel_count(ctx, cols, R);
+}
 
 int hnh_sddmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
                      const double* X, const double* Y, int R, int64_t nnz, int max_row_nnz, int64_t cols, int stream) {

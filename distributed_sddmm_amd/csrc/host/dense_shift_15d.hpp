@@ -51,10 +51,10 @@ public:
     // dense block; sub-block (b, q) is csr_blocks[b * chunks + q].  Two uses:
     //  * several ranks: the fetch is issued chunk by chunk and the kernels of chunk q run while chunk q+1 is still on the
     //    links (default 4 chunks);
-    //  * one rank per ring (p == c, e.g. a single GPU): one launch per chunk, so the rows of the gathered operand that a
-    //    launch touches (a 512 MiB panel by default) mostly stay in the 256 MiB Infinity Cache — measured 16.8 -> 14.8 ms
-    //    at config 2 (R = 128: 2 panels), 35.6 -> 31.3 ms at R = 256 (4 panels), no gain below 512 MiB
-    //    (profiles/r01_panel_probe_same_box.log).
+    //  * one rank per ring (p == c, e.g. a single GPU), only when forced with HNH_MESH_CHUNKS: one launch per chunk.  This is
+    //    how the Infinity-Cache panel effect was found (16.8 -> 14.8 ms at config 2 with 2 chunks,
+    //    profiles/r01_panel_probe_same_box.log); by default a ring of one keeps whole blocks and the kernel library cuts
+    //    the same panels itself from the sorted CSR rows (hnh_kernels.h, `cols` hint), for every schedule.
     // HNH_MESH_CHUNKS overrides the count (1 = whole blocks).
     int chunks = 1;
     int chunkA = 0, chunkB = 0;  // rows per chunk of a visiting A / B block
@@ -105,13 +105,7 @@ public:
         setRValue(R);
 
         if (fusionApproach == 2) {
-            if (p / c > 1) {
-                chunks = 4;
-            } else {  // Infinity-Cache panels of ~512 MiB of the gathered operand
-                const double panel = 512.0 * 1024.0 * 1024.0;
-                const double bytes = (double)std::max(localArows, localBrows) * (double)R * sizeof(double);
-                chunks = std::max(1, std::min(8, (int)std::lround(bytes / panel)));
-            }
+            if (p / c > 1) chunks = 4;  // a ring of one keeps whole blocks: the kernel library cuts its own cache panels
             if (const char* q = std::getenv("HNH_MESH_CHUNKS")) chunks = std::atoi(q);
             if (chunks < 1 || chunks > 8) hnh::fatal("Error, HNH_MESH_CHUNKS must be between 1 and 8!");
         }

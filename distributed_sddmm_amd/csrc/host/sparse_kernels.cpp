@@ -17,7 +17,7 @@ size_t StandardKernel::sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
     w->check(w->be->hnh_sddmm_csr_ex(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, Xptr, Yptr,
                                      (int)A.cols(), blk->num_coords, blk->row_hint(), blk->cols, HNH_STREAM_COMPUTE),
              "hnh_sddmm_csr");
-    end(w);
+    end(w, profile ? w->be->hnh_panel_count(w->ctx, blk->cols, (int)A.cols(), blk->row_hint()) : 1);
     return processed;
 }
 
@@ -37,7 +37,7 @@ size_t StandardKernel::spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B,
     w->check(w->be->hnh_spmm_csr_ex(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, X, Out, (int)A.cols(),
                                     blk->num_coords, blk->row_hint(), blk->cols, HNH_STREAM_COMPUTE),
              "hnh_spmm_csr");
-    end(w);
+    end(w, profile ? w->be->hnh_panel_count(w->ctx, blk->cols, (int)A.cols(), blk->row_hint()) : 1);
     return processed;
 }
 
@@ -62,7 +62,7 @@ size_t StandardKernel::fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
                                                B.data(), Out.data(), (int)A.cols(), flags, blk->num_coords, blk->row_hint(), blk->cols, extras,
                                                HNH_STREAM_COMPUTE),
              "hnh_fused_sddmm_spmm_csr");
-    end(w);
+    end(w, profile ? w->be->hnh_panel_count(w->ctx, blk->cols, (int)A.cols(), blk->row_hint()) : 1);
     return 0;
 }
 
@@ -107,14 +107,14 @@ void StandardKernel::begin(hnh::World* w) {
     w->event_record(ev0_, HNH_STREAM_COMPUTE);
 }
 
-void StandardKernel::end(hnh::World* w) {
+void StandardKernel::end(hnh::World* w, long launches) {
     if (!profile) return;
     w->event_record(ev1_, HNH_STREAM_COMPUTE);
     w->check(w->be->hnh_event_sync(w->ctx, ev1_), "hnh_event_sync");
     float ms = 0.f;
     w->check(w->be->hnh_event_elapsed_ms(w->ctx, ev0_, ev1_, &ms), "hnh_event_elapsed_ms");
     kernel_ms += ms;
-    kernel_launches++;
+    kernel_launches += launches;  // a row pass may run as several column-panel launches (hnh_panel_count)
 }
 
 StandardKernel::~StandardKernel() {

@@ -110,5 +110,5 @@ private:
     void* ev1_ = nullptr;
     hnh::World* evw_ = nullptr;
     void begin(hnh::World* w);
-    void end(hnh::World* w);
+    void end(hnh::World* w, long launches = 1);
 };

@@ -118,6 +118,8 @@ int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowpt
                                 double* values, const double* svalues, const double* X, const double* Y, double* Out,
                                 int R, unsigned flags, int64_t nnz, int max_row_nnz, int64_t cols, int stream);
 int hnh_csr_max_row_nnz(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, int* out_host, int stream);
+/* number of kernel launches (column panels) a row pass with these hints is run as; 1 = a single launch (profiling aid) */
+int hnh_panel_count(hnh_ctx* ctx, int64_t cols, int R, int max_row_nnz);
 
 /* Extras of the fused pass — what the reference's applications do immediately around their SDDMM->SpMM pair,
  * folded into the same launch while the operands are still in registers:
