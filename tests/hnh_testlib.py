@@ -372,5 +372,6 @@ def check_fused_out(per_rank, case, matmode, leaky_alpha, x_scale, want_rowdot):
             off = 0
             for top, left, rc, cc in o[which]:
                 keep = max(0, min(rc, nrows - top))
-                assert np.max(np.abs(o["rowdot"][off:off + keep] - want_dot[top:top + keep])) <= TOL * scale
+                if keep > 0:  # a rank whose rows are all padding (M < p * rows per rank) has nothing to compare
+                    assert np.max(np.abs(o["rowdot"][off:off + keep] - want_dot[top:top + keep])) <= TOL * scale
                 off += rc

@@ -1,0 +1,72 @@
+"""Randomised differential test of the host logic (CPU ranks + the oracle's C test double) against the numpy oracle:
+random schedule, grid, sizes (incl. M < p, non-square, 1-nonzero matrices), chunk counts, ring modes and both set-up
+pipelines.  A fixed seed keeps the suite deterministic; `python tests/test_fuzz_cpu.py SEED COUNT` explores further."""
+import os
+import random
+import sys
+
+import pytest
+
+import hnh_testlib as T
+from distributed_sddmm_amd import api as H
+from oracle import oracle as O
+
+GRIDS = [(1, 1), (2, 1), (2, 2), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2), (8, 4), (8, 8)]
+KNOBS = ("HNH_MESH_CHUNKS", "HNH_RING_MODE", "HNH_HOST_SETUP")
+
+
+def one(rng, it):
+    alg = rng.choice(H.ALGORITHMS)
+    p, c = rng.choice(GRIDS)
+    r = rng.choice([4, 8, 12, 16, 24])
+    if not T.valid_config(alg, p, c, r):
+        return None
+    m = rng.choice([5, 9, 17, 40, 64, 100, 130])
+    n = m if rng.random() < 0.5 else rng.choice([7, 23, 64, 90, 150])
+    draws = rng.choice([1, 10, m * 3, m * 8])
+    os.environ["HNH_MESH_CHUNKS"] = str(rng.choice([1, 2, 3, 4, 8]))
+    os.environ["HNH_RING_MODE"] = rng.choice(["mesh", "relay"])
+    if rng.random() < 0.3:
+        os.environ["HNH_HOST_SETUP"] = "1"
+    else:
+        os.environ.pop("HNH_HOST_SETUP", None)
+    rows, cols = O.erdos_renyi_mn(m, n, draws, 1000 + it)
+    case = T.make_case("fz%d" % it, m, n, r, rows, cols, seed=it)
+    tag = "%s p=%d c=%d R=%d %dx%d nnz=%d %s" % (alg, p, c, r, m, n, len(rows), {k: os.environ.get(k) for k in KNOBS})
+    per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
+    T.check_against_oracle(T.assemble(per_rank, case), case, alg)
+    if alg == "15d_fusion2":
+        for mm in (H.AMAT, H.BMAT):
+            pr = H.run_spmd(p, lambda w: T.run_fused_out(w, alg, c, case, mm, 0.3, 0.7, True))
+            T.check_fused_out(pr, case, mm, 0.3, 0.7, True)
+    return tag
+
+
+def sweep(seed, count):
+    saved = {k: os.environ.get(k) for k in KNOBS}
+    rng = random.Random(seed)
+    done = []
+    try:
+        for it in range(count):
+            tag = one(rng, it)
+            if tag:
+                done.append(tag)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return done
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_configurations_match_the_oracle(seed):
+    H.load_backend(T.ORACLE_BACKEND)
+    assert len(sweep(seed, 14)) >= 6
+
+
+if __name__ == "__main__":
+    H.load_backend(T.ORACLE_BACKEND)
+    for t in sweep(int(sys.argv[1]) if len(sys.argv) > 1 else 1, int(sys.argv[2]) if len(sys.argv) > 2 else 40):
+        print("ok", t)
