@@ -88,6 +88,16 @@ public:
     World* world() const { return buf_.world(); }
 
     void setZero() { if (size()) world()->memset0(data(), (size_t)size() * sizeof(double), HNH_STREAM_COMPUTE); }
+    // the slices of Eigen's interface that code written against the reference uses on its dense matrices
+    // (`tmp *= 0.0`, 15D_sparse_shift.hpp:236; `localA.middleRows(start, n)` as r- and l-value, :233,248)
+    DenseMatrix& operator*=(double s) {
+        if (size()) world()->check(world()->be->hnh_axpy_f64(world()->ctx, data(), data(), s - 1.0, size(), HNH_STREAM_COMPUTE), "hnh_axpy_f64");
+        return *this;
+    }
+    DenseMatrix middleRows(int64_t start, int64_t n) const {  // a view: assigning to it writes through
+        if (start < 0 || n < 0 || start + n > rows_) fatal("Error, middleRows out of range!");
+        return view(data() + start * cols_, n, cols_);
+    }
     void setConstant(double v) {
         if (size()) world()->check(world()->be->hnh_fill_f64(world()->ctx, data(), size(), v, HNH_STREAM_COMPUTE), "hnh_fill_f64");
     }

@@ -94,3 +94,16 @@ def test_product_backend_is_hip_and_fails_loudly_without_gpu():
         H.World.single(0)
     assert "no GPU" in str(e.value) or "device" in str(e.value)
     H.load_backend(T.ORACLE_BACKEND)
+
+
+def test_custom_kernel_plugin_drives_every_schedule():
+    """The reference's extension point (README.md:17-18): a KernelImplementation subclass with only sddmm_local and
+    spmm_local (examples/custom_kernel.cpp) handed to every schedule constructor — here over the oracle's C test double;
+    the local-kernel-fusion schedule then runs on the default fused_local(), the reference's own call pair."""
+    import subprocess
+    exe = os.path.join(T.ROOT, "examples", "custom_kernel")
+    r = subprocess.run(["make", "-C", os.path.join(T.ROOT, "examples"), "custom_kernel"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    r = subprocess.run([exe, T.ORACLE_BACKEND, "8", "8", "16"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all schedules ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.stdout.count(" ok") >= 5

@@ -134,6 +134,17 @@ def test_cpp_dropin_driver(tmp_path):
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
 
 
+def test_custom_kernel_plugin_hip():
+    """examples/custom_kernel.cpp: a user KernelImplementation that implements only the reference's two pure virtuals
+    drives all five schedules on the GPU and reproduces StandardKernel's results (the documented extension point)."""
+    import os
+    import subprocess
+    exe = os.path.join(T.ROOT, "examples", "custom_kernel")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    r = subprocess.run([exe, "", "12", "8", "32"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all schedules ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 @pytest.mark.parametrize("alg,p,c", [("15d_fusion1", 1, 1), ("15d_fusion1", 4, 2), ("15d_fusion2", 1, 1), ("15d_fusion2", 4, 1)])
 def test_gat_forward_matches_reference_hip(alg, p, c):
     """GAT head = MFMA fp64 GEMM + SDDMM + LeakyReLU + SpMM + ReLU on the GPU vs the reference's own gat.hpp."""
