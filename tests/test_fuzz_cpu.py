@@ -7,9 +7,10 @@ import sys
 
 import pytest
 
-import hnh_testlib as T
-from distributed_sddmm_amd import api as H
-from oracle import oracle as O
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # stand-alone use: python tests/test_fuzz_cpu.py
+import hnh_testlib as T  # noqa: E402
+from distributed_sddmm_amd import api as H  # noqa: E402
+from oracle import oracle as O  # noqa: E402
 
 GRIDS = [(1, 1), (2, 1), (2, 2), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2), (8, 4), (8, 8)]
 KNOBS = ("HNH_MESH_CHUNKS", "HNH_RING_MODE", "HNH_HOST_SETUP")
