@@ -211,3 +211,39 @@ def test_column_chunks_hip(monkeypatch, chunks):
         for p, c in [(1, 1), (2, 2), (4, 1), (8, 2)]:
             per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, "15d_fusion2", c, case))
             T.check_against_golden(T.assemble(per_rank, case), per_rank, case, "15d_fusion2")
+
+
+@pytest.mark.parametrize("alg", ["15d_fusion2", "15d_fusion1"])
+def test_fingerprints_at_scale_against_the_compiled_reference(alg):
+    """The HIP path against the REFERENCE ITSELF (oracle/_ref/ref_driver = its unmodified sources + MKL, run on this box's
+    host cores) at 8.4e6 nonzeros, R = 128: the scratch.cpp fingerprints (squared norms of SDDMM, SpMM-A, SpMM-B under the
+    dummyInitialize fill).  Skipped where the compiled reference did not travel."""
+    from oracle import oracle as O
+    from oracle import refrun as RR
+    if not RR.available():
+        pytest.skip("compiled reference not available on this box")
+    logm, ef, r = 18, 32, 128
+    m = 1 << logm
+    rows, cols = O.erdos_renyi_mn(m, m, m * ef, 12345)
+    ref = RR.fingerprints(m, m, rows, cols, r, alg, 1, 1, timeout=900)
+    w = H.World.single(0)
+    sp = H.SpmatLocal.load_tuples(w, False, logm, ef)   # the same generator, evaluated on the GPU
+    assert sp.info()["dist_nnz"] == len(rows)
+    d = H.DistributedSparse(w, alg, sp, r, 1)
+    A, B = d.like_A_matrix(0.0), d.like_B_matrix(0.0)
+    got = []
+    for mode in ("sddmm", "spmmA", "spmmB"):
+        d.dummyInitialize(A, H.AMAT); d.dummyInitialize(B, H.BMAT)
+        if mode == "sddmm":
+            ones, res = d.like_S_values(1.0), d.like_S_values(0.0)
+            d.sddmmA(A, B, ones, res); x = res.download(); ones.free(); res.free()
+        elif mode == "spmmA":
+            ones = d.like_S_values(1.0); d.spmmA(A, B, ones); x = A.download(); ones.free()
+        else:
+            ones = d.like_ST_values(1.0); d.spmmB(A, B, ones); x = B.download(); ones.free()
+        got.append(float(np.sum(x.astype(np.float64) ** 2)))
+    want = [ref["sddmm"], ref["spmmA"], ref["spmmB"]]
+    assert T.rel(np.array(got), np.array(want)) <= T.TOL, (got, want)
+    for h in (A, B):
+        h.free()
+    d.free(); sp.free(); w.close()
