@@ -181,27 +181,39 @@ public:
                 }
             }
         } else {
-            // the A-role operand accumulates the SpMM output: s shifts, each after its kernel
+            // The A-role operand accumulates the SpMM output: s shifts, each after its kernel.  The B-role operand is only
+            // read: its shift for step i+1 is issued while kernel i runs (triple buffered, s-1 shifts, caller's matrix
+            // untouched), so only A's transfer sits between two kernels.
             hnh::BufferPair aBuf(Arole, &spareA[0]);
-            hnh::BufferPair bBuf(Brole, &spareB[0]);
+            if (s > 1) {
+                for (int t = 0; t < 2; t++) ensure(spareB[t], Brole->rows(), Brole->cols());
+                order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);
+            }
+            DenseMatrix* curB = Brole;
+            const size_t bbytes = (size_t)Brole->size() * sizeof(double);
             for (int i = 0; i < s; i++) {
                 auto t = start_clock();
-                kernel->triple_function(temp, *choice, *aBuf.getActive(), *bBuf.getActive(), 0, pMod(grid->i + grid->j + i, s) * localAcols);
+                if (i > 0) world->event_wait(event(1 + (i - 1) % 2), HNH_STREAM_COMPUTE);  // both shifts of step i-1 landed
+                kernel->triple_function(temp, *choice, *aBuf.getActive(), *curB, 0, pMod(grid->i + grid->j + i, s) * localAcols);
                 stop_clock_and_add(t, "Computation Time");
                 if (s > 1) {
                     t = start_clock();
-                    order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);
-                    world->group_begin();
+                    world->event_record(event(3 + i % 2), HNH_STREAM_COMPUTE);
+                    if (i < s - 1) {
+                        DenseMatrix* tb = &spareB[i % 2];
+                        if (i >= 2) world->event_wait(event(3 + (i - 1) % 2), HNH_STREAM_COMM);  // kernel i-1 last read `tb`
+                        world->sendrecv(grid->col_world, curB->data(), bbytes, cdst, tb->data(), bbytes, csrc, HNH_STREAM_COMM);
+                        curB = tb;
+                    }
+                    world->event_wait(event(3 + i % 2), HNH_STREAM_COMM);  // kernel i wrote the moving accumulator
                     shiftDenseMatrix(aBuf, grid->row_world, rdst, rsrc, HNH_STREAM_COMM);
-                    shiftDenseMatrix(bBuf, grid->col_world, cdst, csrc, HNH_STREAM_COMM);
-                    world->group_end();
-                    order(HNH_STREAM_COMM, HNH_STREAM_COMPUTE, 1);
+                    world->event_record(event(1 + i % 2), HNH_STREAM_COMM);
                     stop_clock_and_add(t, "Dense Cyclic Shift Time");
                 }
             }
+            if (s > 1) world->event_wait(event(1 + (s - 1) % 2), HNH_STREAM_COMPUTE);
             auto t = start_clock();
             aBuf.sync_active();
-            bBuf.sync_active();
             stop_clock_and_add(t, "Computation Time");
         }
 
