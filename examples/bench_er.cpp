@@ -3,7 +3,7 @@
 // same algorithm names, same JSON keys appended to the output file:
 //
 //     bench_er <logM> <edgeFactor> <15d|25d|15d_fusion1|15d_fusion2|15d_sparse|25d_dense_replicate|25d_sparse_replicate>
-//              <R> <c> <outfile> [fused|unfused] [vanilla|als]
+//              <R> <c> <outfile> [fused|unfused] [vanilla|als|gat]
 //
 // One process per GPU.  Without a launcher it runs on GPU 0 (p = 1).  Multi-GPU: start N processes with
 // RANK / WORLD_SIZE / LOCAL_RANK set (torchrun, mpiexec -env, a shell loop) and HNH_ID_FILE naming a path on a
@@ -16,6 +16,7 @@
 #include <thread>
 
 #include "als_conjugate_gradients.hpp"
+#include "gat.hpp"
 #include "cannon_dense_25d.hpp"
 #include "cannon_sparse_25d.hpp"
 #include "dense_shift_15d.hpp"
@@ -65,8 +66,18 @@ static void benchmark_algorithm(SpmatLocal* spmat, string algorithm_name, string
     else hnh::fatal("Error, unknown algorithm " + algorithm_name);
 
     unique_ptr<Distributed_ALS> d_als;
-    if (app == "als") d_als.reset(new Distributed_ALS(d_ops, true));
-    else if (app != "vanilla") hnh::fatal("Error, app must be vanilla or als");
+    unique_ptr<GAT> gnn;
+    vector<GATLayer> layers;
+    if (app == "gat") {  // benchmark_dist.cpp:88-94: input features, features per head, heads
+        layers.emplace_back(256, 256, 4);
+        layers.emplace_back(1024, 256, 4);
+        layers.emplace_back(1024, 256, 6);
+        gnn.reset(new GAT(layers, d_ops));
+    } else if (app == "als") {
+        d_als.reset(new Distributed_ALS(d_ops, true));
+    } else if (app != "vanilla") {
+        hnh::fatal("Error, app must be vanilla, als or gat");
+    }
 
     DenseMatrix A = d_ops->like_A_matrix(0.001), B = d_ops->like_B_matrix(0.001);
     VectorXd S = d_ops->like_S_values(1.0), sddmm_result = d_ops->like_S_values(0.0);
@@ -89,6 +100,8 @@ static void benchmark_algorithm(SpmatLocal* spmat, string algorithm_name, string
                 d_ops->sddmmA(A, B, S, sddmm_result);
                 d_ops->spmmA(A, B, S);
             }
+        } else if (app == "gat") {
+            gnn->forwardPass();
         } else {
             d_als->application_communication_time = 0.0;
             d_als->run_cg(1);
@@ -110,12 +123,13 @@ static void benchmark_algorithm(SpmatLocal* spmat, string algorithm_name, string
              << throughput * 1e9 / 4.0 << " nnz*R/s" << endl;
     }
     d_als.reset();
+    gnn.reset();
     delete d_ops;
 }
 
 int main(int argc, char** argv) {
     if (argc < 7) {
-        cerr << "usage: bench_er logM edgeFactor algorithm R c outfile [fused|unfused] [vanilla|als]" << endl;
+        cerr << "usage: bench_er logM edgeFactor algorithm R c outfile [fused|unfused] [vanilla|als|gat]" << endl;
         return 2;
     }
     hnh::World* world = make_world();

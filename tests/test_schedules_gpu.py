@@ -132,6 +132,10 @@ def test_cpp_dropin_driver(tmp_path):
         assert r["num_trials"] == 5 and r["alg_info"]["backend"] == "hip-gfx950" and "Computation Time" in r["perf_stats"]
     r = subprocess.run([exe, "10", "8", "15d_fusion2", "16", "1", str(out), "fused", "als"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    # the GAT application of benchmark_dist.cpp:88-94,133-135 (3 layers, 14 heads, 256 features per head)
+    for alg in ("15d_fusion2", "15d_fusion1"):
+        r = subprocess.run([exe, "10", "8", alg, "256", "1", str(out), "fused", "gat"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
 
 
 def test_custom_kernel_plugin_hip():
