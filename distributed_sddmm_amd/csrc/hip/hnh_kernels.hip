@@ -317,8 +317,8 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
 }
 
 template <Op OP, int LPR, int VEC, int W, bool EXACT>
-__global__ __launch_bounds__(kBlock) void row_kernel(int64_t rows, const int32_t* __restrict__ beg_ptr,
-                                                     const int32_t* __restrict__ end_ptr,
+__global__ __launch_bounds__(kBlock) void row_kernel(int64_t rows, const int32_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ beg_ptr, const int32_t* __restrict__ end_ptr,
                                                      const int32_t* __restrict__ colidx, double* values,
                                                      const double* __restrict__ svalues,
                                                      const double* __restrict__ X, const double* __restrict__ Y,
@@ -339,12 +339,17 @@ __global__ __launch_bounds__(kBlock) void row_kernel(int64_t rows, const int32_t
         beg = __builtin_amdgcn_readfirstlane(beg);
         end = __builtin_amdgcn_readfirstlane(end);
     }
-    if (OP == Op::kSddmm && beg == end) return;
-    if ((flags & kInternalSplitLong) && end - beg > kLongRow) {
-        // left to long_row_kernel; it adds atomically, so an overwritten output row has to start from zero
-        if (OP != Op::kSddmm && (flags & HNH_FUSED_OUT_OVERWRITE)) end = beg;
-        else return;
+    if (flags & kInternalSplitLong) {
+        // hub rows (judged by the WHOLE row, also when this launch covers one column panel of it) are left to
+        // long_row_kernel; it adds atomically, so an overwritten output row has to start from zero
+        int full = rowptr[row + 1] - rowptr[row];
+        if constexpr (LPR == 64) full = __builtin_amdgcn_readfirstlane(full);
+        if (full > kLongRow) {
+            if (OP != Op::kSddmm && (flags & HNH_FUSED_OUT_OVERWRITE)) end = beg;
+            else return;
+        }
     }
+    if (OP == Op::kSddmm && beg == end) return;
     process_row<OP, LPR, VEC, W, EXACT>(row, beg, end, false, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, lig, ex);
 }
 
@@ -1000,16 +1005,16 @@ int prepare_long(hnh_ctx* ctx, hipStream_t st, int sidx, int64_t rows, const int
 template <Op OP, int LPR, int VEC, int W, bool EXACT>
 int launch_row(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, int64_t rows, const int32_t* rowptr, const int32_t* beg_ptr,
                const int32_t* end_ptr, const int32_t* colidx, double* values, const double* svalues, const double* X, const double* Y,
-               double* Out, int64_t ld, int col0, int ncols, unsigned flags, const Extras& ex) {
+               double* Out, int64_t ld, int col0, int ncols, unsigned flags, const Extras& ex, bool run_long = true) {
     constexpr int GROUPS = kBlock / LPR;
     const int64_t blocks = (rows + GROUPS - 1) / GROUPS;
     if (blocks <= 0) return HNH_OK;
     if (blocks > 0x7fffffffLL) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "too many rows for one launch");
     if (lc.enabled) flags |= kInternalSplitLong;
-    hipLaunchKernelGGL((row_kernel<OP, LPR, VEC, W, EXACT>), dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, beg_ptr, end_ptr,
+    hipLaunchKernelGGL((row_kernel<OP, LPR, VEC, W, EXACT>), dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, rowptr, beg_ptr, end_ptr,
                        colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, ex);
     if (int rc = hnh::check_hip(ctx, hipGetLastError(), "row_kernel launch")) return rc;
-    if (lc.enabled) {
+    if (lc.enabled && run_long) {  // hub rows once per pass (after the last column panel), over their whole length
         // 256 CUs x 4 resident workgroups; items are spread round-robin over all groups of the grid
         hipLaunchKernelGGL((long_row_kernel<OP, LPR, VEC, W, EXACT>), dim3(1024), dim3(kBlock), 0, st, lc.items, lc.count,
                            lc.capacity, rowptr, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, ex);
@@ -1023,10 +1028,10 @@ int launch_row(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, int64_t rows, co
 template <Op OP>
 int launch_shape(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, const Shape& s, int64_t rows, const int32_t* rowptr,
                  const int32_t* beg_ptr, const int32_t* end_ptr, const int32_t* colidx, double* values, const double* svalues,
-                 const double* X, const double* Y, double* Out, int R, unsigned flags, const Extras& ex) {
+                 const double* X, const double* Y, double* Out, int R, unsigned flags, const Extras& ex, bool run_long = true) {
 #define HNH_CASE(L, V)                                                                                                     \
     if (s.lpr == L && s.vec == V)                                                                                          \
-        return launch_row<OP, L, V, 2, true>(ctx, st, lc, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags, ex);
+        return launch_row<OP, L, V, 2, true>(ctx, st, lc, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags, ex, run_long);
     if (s.exact) {
         HNH_CASE(1, 1) HNH_CASE(2, 1) HNH_CASE(4, 1) HNH_CASE(8, 1) HNH_CASE(16, 1) HNH_CASE(32, 1) HNH_CASE(64, 1)
         HNH_CASE(64, 2) HNH_CASE(64, 3) HNH_CASE(64, 4) HNH_CASE(32, 3) HNH_CASE(32, 5) HNH_CASE(32, 7)
@@ -1037,7 +1042,7 @@ int launch_shape(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, const Shape& s
     // instance (R <= 512 even / 256 odd)
 #define HNH_NX(V, WW)                                                                                                      \
     if (s.w == WW && R <= 64 * WW * V)                                                                                     \
-        return launch_row<OP, 64, V, WW, false>(ctx, st, lc, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags, ex);
+        return launch_row<OP, 64, V, WW, false>(ctx, st, lc, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags, ex, run_long);
     HNH_NX(1, 2) HNH_NX(2, 2) HNH_NX(4, 2) HNH_NX(1, 1) HNH_NX(2, 1) HNH_NX(4, 1)
 #undef HNH_NX
     return -1;
@@ -1063,8 +1068,9 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
     if (epilogue_done != nullptr) *epilogue_done = !lc.enabled && single_pass;
     const unsigned epi = (epilogue_done != nullptr && *epilogue_done) ? kInternalEpilogue : 0u;
 
-    // Infinity-Cache panels (see panel_split_kernel): only for plain short-row blocks and single-pass widths
-    const int panels = (!lc.enabled && single_pass) ? panel_count(ctx, cols, R) : 1;
+    // Infinity-Cache panels (see panel_split_kernel): single-pass widths only; hub rows stay whole and go to the long-row
+    // pass once, after the last panel
+    const int panels = single_pass ? panel_count(ctx, cols, R) : 1;
     if (panels > 1) {
         const size_t need = (size_t)(panels - 1) * (size_t)rows * sizeof(int32_t);
         if (ctx->panel_cap[sidx] < need) {
@@ -1085,7 +1091,9 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
             unsigned f = flags;
             if (q > 0) f &= ~HNH_FUSED_OUT_OVERWRITE;  // later panels add to the rows the first one wrote
             if (q == panels - 1) f |= epi;             // the last panel completes the rows
-            if (int rc = launch_shape<OP>(ctx, st, lc, s, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, f, ex)) return rc;
+            if (int rc = launch_shape<OP>(ctx, st, lc, s, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, f, ex,
+                                          q == panels - 1))
+                return rc;
         }
         return HNH_OK;
     }
@@ -1132,7 +1140,7 @@ extern "C" {
 
 int hnh_panel_count(hnh_ctx* ctx, int64_t cols, int R, int max_row_nnz) {
     if (!ctx || R <= 0) return 1;
-    if (max_row_nnz < 0 || max_row_nnz > kLongRow) return 1;  // hub rows (or unknown): the long-row pass, no panels
+    (void)max_row_nnz;  // hub rows do not prevent panels: they stay whole and go to the long-row pass
     const Shape s = pick_shape(R, true);
     if (!(s.exact || R <= 64 * s.w * 4)) return 1;
     return panel_count(ctx, cols, R);

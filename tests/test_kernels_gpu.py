@@ -422,17 +422,27 @@ def test_fused_extras_with_hub_rows_and_many_blocks(ctx, R):
 
 @pytest.mark.parametrize("R", [8, 128, 100, 256])
 @pytest.mark.parametrize("panel_bytes", [20000, 150000])
-def test_infinity_cache_panels_do_not_change_results(monkeypatch, R, panel_bytes):
+@pytest.mark.parametrize("hubs", [False, True])
+def test_infinity_cache_panels_do_not_change_results(monkeypatch, R, panel_bytes, hubs):
     """With the `cols` hint a pass runs as one launch per column panel of the block (a contiguous piece of every CSR row);
     the panel size is shrunk here so that small blocks get 2..8 panels.  sddmm / spmm / fused (+ extras) must match."""
     monkeypatch.setenv("HNH_PANEL_BYTES", str(panel_bytes))
     from distributed_sddmm_amd import _kernels as K
     c = K.Ctx(0)
     lib = c.lib
-    rows, cols = 257, 300
-    rowptr, ridx, cidx = random_block(rows, cols, 6000, seed=R + 1)
-    nnz = len(cidx)
     rng = np.random.default_rng(R)
+    if hubs:  # rows longer than 1024 nonzeros stay whole (long-row pass, once) while the short rows are panelled
+        rows, cols = 120, 3000
+        lens = rng.integers(0, 40, rows)
+        lens[5], lens[77] = 2500, 1100
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        cidx = np.concatenate([np.sort(rng.choice(cols, n, replace=False)) for n in lens]).astype(np.int32)
+        ridx = np.repeat(np.arange(rows, dtype=np.int32), lens)
+        panel_bytes *= 10
+    else:
+        rows, cols = 257, 300
+        rowptr, ridx, cidx = random_block(rows, cols, 6000, seed=R + 1)
+    nnz = len(cidx)
     X, Y = rng.uniform(-1, 1, (rows, R)), rng.uniform(-1, 1, (cols, R))
     v0, out0 = rng.uniform(-1, 1, nnz), rng.uniform(-1, 1, (rows, R))
     d_rp, d_c, dv, dX, dY, dOut, ddot = (c.upload(a) for a in (rowptr, cidx, v0, X, Y, out0, np.zeros(rows)))
