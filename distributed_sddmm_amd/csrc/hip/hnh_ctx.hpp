@@ -16,6 +16,7 @@ struct hnh_ctx {
     void* panel_split[2] = {nullptr, nullptr};
     size_t panel_cap[2] = {0, 0};
     bool no_panels = false;  // HNH_NO_PANELS=1: A/B switch
+    bool panels_with_hubs = false;  // HNH_PANELS_WITH_HUBS=1: panel the short rows of blocks that also have hub rows
     double panel_bytes = 512.0 * 1024.0 * 1024.0;  // bytes of the gathered operand per panel (HNH_PANEL_BYTES; tests shrink it)
 };
 

@@ -1068,9 +1068,10 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
     if (epilogue_done != nullptr) *epilogue_done = !lc.enabled && single_pass;
     const unsigned epi = (epilogue_done != nullptr && *epilogue_done) ? kInternalEpilogue : 0u;
 
-    // Infinity-Cache panels (see panel_split_kernel): single-pass widths only; hub rows stay whole and go to the long-row
-    // pass once, after the last panel
-    const int panels = single_pass ? panel_count(ctx, cols, R) : 1;
+    // Infinity-Cache panels (see panel_split_kernel): single-pass widths only.  The mechanism handles hub rows (they stay
+    // whole and go to the long-row pass once, after the last panel; HNH_PANELS_WITH_HUBS=1), but on skewed graphs the hot
+    // columns are cache-resident anyway and panels cost 2.5 % (R-MAT 2^20: 6.85 -> 7.03 ms), so such blocks keep one launch.
+    const int panels = (single_pass && (!lc.enabled || ctx->panels_with_hubs)) ? panel_count(ctx, cols, R) : 1;
     if (panels > 1) {
         const size_t need = (size_t)(panels - 1) * (size_t)rows * sizeof(int32_t);
         if (ctx->panel_cap[sidx] < need) {
@@ -1140,7 +1141,7 @@ extern "C" {
 
 int hnh_panel_count(hnh_ctx* ctx, int64_t cols, int R, int max_row_nnz) {
     if (!ctx || R <= 0) return 1;
-    (void)max_row_nnz;  // hub rows do not prevent panels: they stay whole and go to the long-row pass
+    if ((max_row_nnz < 0 || max_row_nnz > kLongRow) && !ctx->panels_with_hubs) return 1;  // hub rows (or unknown): one launch
     const Shape s = pick_shape(R, true);
     if (!(s.exact || R <= 64 * s.w * 4)) return 1;
     return panel_count(ctx, cols, R);

@@ -20,6 +20,7 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
     if (!ctx) return HNH_ERR_NOMEM;
     ctx->device = device;
     ctx->no_panels = std::getenv("HNH_NO_PANELS") != nullptr;
+    ctx->panels_with_hubs = std::getenv("HNH_PANELS_WITH_HUBS") != nullptr;
     if (const char* pb = std::getenv("HNH_PANEL_BYTES")) {
         const double v = std::atof(pb);
         if (v >= 1.0) ctx->panel_bytes = v;
