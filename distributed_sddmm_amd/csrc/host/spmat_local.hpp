@@ -586,6 +586,9 @@ public:
 
     // values <-> per-block storage (SpmatLocal.hpp:571-605); device-to-device on the compute stream
     void setCSRValues(const hnh::VectorXd& values) {
+        // the reference copies without looking (SpmatLocal.hpp:571-579); a vector made by the wrong like_S*_values would
+        // read past its end, so the length is checked here
+        if (!blockStarts.empty() && (uint64_t)values.size() < blockStarts.back()) hnh::fatal("Error, sparse value vector has the wrong length!");
         for (size_t i = 0; i + 1 < blockStarts.size(); i++)
             if (csr_blocks[i] != nullptr)
                 world->copy(csr_blocks[i]->getActive()->values, values.data() + blockStarts[i],
@@ -612,6 +615,8 @@ public:
     // out[e] = svalues[e] * (block values)[e] — the Hadamard step that ends every SDDMM
     // (`SValues.cwiseProduct(choice->getCSRValues())`, 15D_dense_shift.hpp:366) without the temporary.
     void hadamardWithCSRValues(const hnh::VectorXd& svalues, hnh::VectorXd& out, int64_t out_offset = 0) {
+        if (!blockStarts.empty() && ((uint64_t)svalues.size() < out_offset + blockStarts.back() || (uint64_t)out.size() < out_offset + blockStarts.back()))
+            hnh::fatal("Error, sparse value vector has the wrong length!");
         for (size_t i = 0; i + 1 < blockStarts.size(); i++)
             if (csr_blocks[i] != nullptr && blockStarts[i + 1] > blockStarts[i])
                 world->check(world->be->hnh_hadamard_f64(world->ctx, out.data() + out_offset + blockStarts[i],

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Development aid: builds the host layer + a multi-rank harness with AddressSanitizer / UBSan and runs every schedule
+# (fusedSpMM, sddmmB, spmmB, two ALS half-steps) on p logical ranks over the oracle's CPU test double.
+set -euo pipefail
+ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)"
+H=$ROOT/distributed_sddmm_amd/csrc/host
+OUT=${TMPDIR:-/tmp}/hnh_sanitize
+mkdir -p "$OUT"
+g++ -O1 -g -std=c++17 -fopenmp -fsanitize=address,undefined -fno-omit-frame-pointer -Wno-sign-compare -I"$ROOT/include" -I"$H" \
+    "$H/world.cpp" "$H/sparse_kernels.cpp" "$H/er_generator.cpp" "$ROOT/tools/sanitize/spmd_harness.cpp" -o "$OUT/spmd_asan" -ldl -lpthread
+for cfg in "1 1 15d_fusion2" "4 1 15d_fusion2" "4 2 15d_fusion2" "8 2 15d_fusion1" "4 1 15d_sparse" "8 2 25d_dense_replicate" "8 2 25d_sparse_replicate"; do
+    ASAN_OPTIONS=detect_leaks=0 OMP_NUM_THREADS=1 "$OUT/spmd_asan" "$ROOT/oracle/liboracle_backend.so" $cfg | tail -1
+done
