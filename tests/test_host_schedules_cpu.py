@@ -155,3 +155,27 @@ def test_chunked_mesh_fetch_any_chunk_count(chunks, ring, monkeypatch):
         for matmode in (H.AMAT, H.BMAT):
             per_rank = H.run_spmd(p, lambda w: T.run_fused_out(w, "15d_fusion2", 1, case, matmode, 0.2, 0.5, True))
             T.check_fused_out(per_rank, case, matmode, 0.2, 0.5, True)
+
+
+def test_wrong_length_value_vector_is_refused():
+    """like_S_values and like_ST_values differ in length per rank; the reference copies from whichever it is given without
+    looking (SpmatLocal.hpp:571-579).  Here a too-short vector is a reported error, not an out-of-bounds read."""
+    case = T.case_inputs("rect_r16")
+
+    def body(w):
+        sp = H.SpmatLocal.from_global(w, case["M"], case["N"], case["rows"], case["cols"], case["vals"])
+        d = H.DistributedSparse(w, "15d_fusion2", sp, case["R"], 1)
+        A, B = d.like_A_matrix(0.0), d.like_B_matrix(0.0)
+        short = H.Vec.create(w, 1)
+        msgs = []
+        for call in (lambda: d.spmmA(A, B, short), lambda: d.spmmB(A, B, short)):
+            with pytest.raises(H.HnhError) as e:
+                call()
+            msgs.append(str(e.value))
+        for h in (A, B, short):
+            h.free()
+        d.free(); sp.free()
+        return msgs
+
+    for msgs in H.run_spmd(1, body):
+        assert all("wrong length" in m for m in msgs)
