@@ -334,8 +334,27 @@ public:
 
         // the moving operand is written only when it is the SpMM accumulator (approach 1)
         const bool moving_readonly = is_sddmm || fusionApproach == 2;
-        if (moving_readonly) ring_readonly(Brole, n, step);
-        else ring_readwrite(Brole, n, step);
+        if (moving_readonly && chunks > 1 && ring_mode == kMeshFetch && n > 1) {
+            // chunk-pipelined mesh fetch, as in the fused pass: local block while chunk 0 flies, then chunk q of every
+            // remote block while chunk q+1 is still on the links (same kernels on the same sub-blocks; only the order of
+            // the steps differs from the reference's block-by-block walk)
+            std::vector<DenseMatrix*> fetched = mesh_fetch_chunked(Brole, n, cw);
+            auto t = start_clock();
+            auto one = [&](int i, DenseMatrix& blk, int q) {
+                DenseMatrix part = chunk_view(blk, q, cw);
+                kernel->triple_function(mode_temp, *choice, stationary, part, block_at(i) * chunks + q, 0);
+            };
+            for (int q = 0; q < chunks; q++) one(0, *Brole, q);
+            for (int q = 0; q < chunks; q++) {
+                world->event_wait(event(8 + q), HNH_STREAM_COMPUTE);  // chunk q of every remote block has landed
+                for (int i = 1; i < n; i++) one(i, *fetched[i - 1], q);
+            }
+            stop_clock_and_add(t, "Computation Time");
+        } else if (moving_readonly) {
+            ring_readonly(Brole, n, step);
+        } else {
+            ring_readwrite(Brole, n, step);
+        }
 
         if (is_sddmm) {
             auto t = start_clock();
