@@ -69,6 +69,16 @@ def main():
     failures = []
     for item in configs.split(";"):
         alg, c = item.split(":")
+        if alg.startswith("als@"):  # ALS-CG (R-split all-reduce, hold hint) over the multi-process transport, vs the reference's golden
+            out = T.run_als(world, alg[4:], int(c), case, 1, 5)  # steps / CG iterations of tests/golden/make_golden_als.py
+            gathered = [None] * n
+            dist.all_gather_object(gathered, out)
+            if rank == 0:
+                try:
+                    T.check_als_against_golden(gathered, case)
+                except AssertionError as e:
+                    failures.append("%s c=%s: %r" % (alg, c, e))
+            continue
         out = T.run_all_ops(world, alg, int(c), case)
         gathered = [None] * n
         dist.all_gather_object(gathered, out)
