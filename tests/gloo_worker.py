@@ -79,6 +79,18 @@ def main():
                 except AssertionError as e:
                     failures.append("%s c=%s: %r" % (alg, c, e))
             continue
+        if alg.startswith("gat@"):  # GAT forward (fused head under local kernel fusion) vs the reference's golden features
+            out = T.run_gat(world, alg[4:], int(c), case)
+            gathered = [None] * n
+            dist.all_gather_object(gathered, out)
+            if rank == 0:
+                try:
+                    got = T.assemble_dense(gathered, "gat", "subA", case["M"], T.GAT_LAYERS[-1][1] * T.GAT_LAYERS[-1][2])
+                    gold = dict(np.load(os.path.join(T.GOLDEN, "gat_er8_r16.npz")))["out"]
+                    assert T.rel(got, gold) <= T.TOL
+                except AssertionError as e:
+                    failures.append("%s c=%s: %r" % (alg, c, e))
+            continue
         out = T.run_all_ops(world, alg, int(c), case)
         gathered = [None] * n
         dist.all_gather_object(gathered, out)

@@ -52,13 +52,13 @@ def test_cfg1_shape_sparse_shift_world2():
     assert "GLOO_OK" in outs[0], outs[0][-2000:]
 
 
-def test_als_over_gloo():
-    """ALS-CG over the multi-process transport against the golden factors produced by the reference's own ALS: the R-split
+def test_als_and_gat_over_gloo():
+    """ALS-CG (and, on 4 processes, the GAT forward pass) over the multi-process transport against the golden factors produced by the reference's own ALS: the R-split
     all-reduce (1.5D sparse shift, 2.5D), the fused epilogue path with the hold hint (1.5D dense, local kernel fusion) and
     the chunked mesh fetch, each on 2 or 4 processes."""
     procs, outs = launch(2, "er8_r16", "als@15d_fusion2:1;als@15d_sparse:1;als@25d_sparse_replicate:2")
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
     assert "GLOO_OK" in outs[0], outs[0][-2000:]
-    procs, outs = launch(4, "er8_r16", "als@15d_fusion2:1;als@25d_dense_replicate:1")
+    procs, outs = launch(4, "er8_r16", "als@15d_fusion2:1;als@25d_dense_replicate:1;gat@15d_fusion2:1;gat@15d_fusion1:2")
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
     assert "GLOO_OK" in outs[0], outs[0][-2000:]
