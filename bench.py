@@ -104,6 +104,7 @@ def run(args, make_world=gpu_world):
         # torch.distributed.run pins OMP_NUM_THREADS=1 per worker; the host-side setup (generator, sorts, CSR build)
         # is OpenMP code, so give every rank its share of the host cores instead (must happen before libgomp starts)
         os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // args.gpus))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL across processes)
     import torch  # first: one HIP runtime per process (see distributed_sddmm_amd/_kernels.py)
     from distributed_sddmm_amd import api as H
 
