@@ -39,14 +39,55 @@ def parse():
     ap.add_argument("--r", type=int, default=128)
     ap.add_argument("--alg", default="15d_fusion2")
     ap.add_argument("--c", type=int, default=1, help="replication factor of the 1.5D/2.5D schedule")
+    ap.add_argument("--ring-mode", choices=["mesh", "relay"], default=None,
+                    help="route of the 1.5D dense shift's moving operand: mesh = every block straight from its owner (default), "
+                         "relay = the reference's neighbour ring (sets HNH_RING_MODE)")
+    ap.add_argument("--chunks", type=int, default=None, help="column chunks of the pipelined mesh fetch (sets HNH_MESH_CHUNKS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-logm", type=int, default=18, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-logm", type=int, default=18, help="size of the CPU baseline's thread-sweep sample")
     ap.add_argument("--cpu-trials", type=int, default=2)
+    ap.add_argument("--no-cpu-full", action="store_true", help="skip the CPU baseline's run at the GPU line's full size")
+    ap.add_argument("--no-check", action="store_true", help="skip the closed-form result check (outside the timed region)")
+    ap.add_argument("--no-preflight", action="store_true", help="skip the transport self-tests of a multi-GPU run")
+    ap.add_argument("--watchdog", type=float, default=240.0, help="seconds a multi-GPU phase may take before the rank reports "
+                    "where it is stuck and exits non-zero")
     return ap.parse_args()
 
 
+class Watchdog:
+    """Per-phase watchdog of a multi-GPU run: a phase that does not finish in time prints rank + phase and ends the
+    process with a non-zero code (RCCL problems show up as hangs inside C calls; ctypes releases the GIL there)."""
+
+    def __init__(self, rank, seconds, enabled):
+        self.rank, self.seconds, self.enabled = rank, seconds, enabled
+        self.timer = None
+
+    def phase(self, name, seconds=None):
+        import threading
+        self.done()
+        if not self.enabled:
+            return
+        limit = seconds or self.seconds
+
+        def fire():
+            sys.stderr.write("[bench.py watchdog] rank %d stuck in phase '%s' for more than %.0f s - giving up\n" % (self.rank, name, limit))
+            sys.stderr.flush()
+            os._exit(3)
+
+        self.timer = threading.Timer(limit, fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def done(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
 def cpu_baseline(args):
-    """The reference timed on the host cores, bounded sample (ER 2^cpu_logm, same edge factor and R)."""
+    """The reference timed on the host cores: a thread sweep on a bounded sample (ER 2^cpu_logm, same edge factor and R), then
+    the best thread count ONCE at the GPU line's own size (1 warm-up + cpu_trials timed calls, benchmark_dist.cpp:117-149);
+    `value` is the full-size figure when that leg ran."""
     import numpy as np
     from distributed_sddmm_amd import api as H
     from oracle import refrun as RR
@@ -56,22 +97,40 @@ def cpu_baseline(args):
         rows, cols = H.generate_er(m, m, m * args.edge_factor, 12345)
         # The reference does not scale with the thread count on big hosts (measured on 2 x EPYC 9575F: 32 threads
         # beat 64/128/256, and 1 MPI rank beats 4..32, profiles/r01_cpu_baseline_sweep.log), so a few counts are
-        # tried on the same sample and the best one is reported; `cores` is the thread count of that run.
+        # tried on the sample and the best one is used; `cores` is the thread count of the reported run.
         tried, best = [], None
-        for threads in sorted({min(ncpu, 16), min(ncpu, 32), min(ncpu, 64), ncpu}):
+        for threads in sorted({min(ncpu, 16), min(ncpu, 32), min(ncpu, 64)}):
             res = RR.bench(m, m, rows, cols, args.r, "15d_fusion2", 1, 1, True, args.cpu_trials, threads=threads)
             tried.append((threads, res["nnz_R_per_s"]))
             if best is None or res["nnz_R_per_s"] > best[1]["nnz_R_per_s"]:
                 best = (threads, res)
         threads, res = best
         comp = res["perf_stats"].get("Computation Time", 0.0)
-        return {"value": res["nnz_R_per_s"], "unit": "nnz*R/s", "cores": threads, "kind": "reference",
-                "sample": "ER 2^%d, edge factor %d (%d nnz), R=%d, 15d_fusion2 fused, %d timed fusedSpMM calls after 1 warm-up, "
-                          "1 MPI rank x %d OpenMP/MKL threads (best of %s on %d hardware threads)"
-                          % (args.cpu_logm, args.edge_factor, len(rows), args.r, args.cpu_trials, threads,
-                             ", ".join("%d: %.2e" % t for t in tried), ncpu),
-                "elapsed_s": res["elapsed"],
-                "kernel_only_value": (len(rows) * args.r * args.cpu_trials / comp) if comp > 0 else None}
+        sweep = "ER 2^%d, edge factor %d (%d nnz): %s nnz*R/s at 16/32/64 threads of %d" % (
+            args.cpu_logm, args.edge_factor, len(rows), ", ".join("%d: %.2e" % t for t in tried), ncpu)
+        out = {"value": res["nnz_R_per_s"], "unit": "nnz*R/s", "cores": threads, "kind": "reference",
+               "sample": "ER 2^%d, edge factor %d (%d nnz), R=%d, 15d_fusion2 fused, %d timed fusedSpMM calls after 1 warm-up, "
+                         "1 MPI rank x %d OpenMP/MKL threads (best of the sweep)" % (args.cpu_logm, args.edge_factor, len(rows), args.r,
+                                                                                  args.cpu_trials, threads),
+               "thread_sweep": sweep, "elapsed_s": res["elapsed"],
+               "kernel_only_value": (len(rows) * args.r * args.cpu_trials / comp) if comp > 0 else None}
+        if not args.no_cpu_full and args.logm != args.cpu_logm:
+            try:
+                t0 = time.perf_counter()
+                mf = 1 << args.logm
+                rows, cols = H.generate_er(mf, mf, mf * args.edge_factor, 12345)
+                full = RR.bench(mf, mf, rows, cols, args.r, "15d_fusion2", 1, 1, True, args.cpu_trials, threads=threads, timeout=900.0)
+                compf = full["perf_stats"].get("Computation Time", 0.0)
+                out.update({"sample_value": out["value"], "sample_workload": out["sample"],
+                            "value": full["nnz_R_per_s"], "elapsed_s": full["elapsed"],
+                            "kernel_only_value": (len(rows) * args.r * args.cpu_trials / compf) if compf > 0 else None,
+                            "sample": "the GPU line's own workload: ER 2^%d, edge factor %d (%d nnz), R=%d, 15d_fusion2 fused, %d timed "
+                                      "fusedSpMM calls after 1 warm-up, 1 MPI rank x %d OpenMP/MKL threads (thread count chosen by the sweep); "
+                                      "whole leg incl. the reference's set-up %.0f s" % (args.logm, args.edge_factor, len(rows), args.r,
+                                                                                       args.cpu_trials, threads, time.perf_counter() - t0)})
+            except Exception as e:  # keep the sample figure
+                out["full_size_error"] = str(e)[:300]
+        return out
     # no compiled reference on this box: time the numpy port on a smaller sample
     from oracle import oracle as O
     m = 1 << 14
@@ -89,13 +148,18 @@ def gpu_world(H, dist, rank, n, local_rank):
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    if n > 1 and ndev < n:
+        raise SystemExit("bench.py --gpus %d: this process sees %d GPU(s); one process per GPU needs all %d visible to every rank "
+                         "(RCCL refuses two ranks on one device)" % (n, ndev, n))
+    device = local_rank % ndev
+    torch.cuda.set_device(device)
     assert H.load_backend(None) == "hip-gfx950"
     if n == 1:
-        return H.World.single(local_rank), torch.cuda.synchronize
+        return H.World.single(device), torch.cuda.synchronize
     ident = [H.rccl_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(ident, src=0)
-    return H.World.rccl(rank, n, local_rank, ident[0]), torch.cuda.synchronize
+    return H.World.rccl(rank, n, device, ident[0]), torch.cuda.synchronize
 
 
 def run(args, make_world=gpu_world):
@@ -105,6 +169,12 @@ def run(args, make_world=gpu_world):
         # is OpenMP code, so give every rank its share of the host cores instead (must happen before libgomp starts)
         os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // args.gpus))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL across processes)
+    if args.gpus > 1:
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: RCCL's bootstrap must not depend on an external interface
+    if args.ring_mode:
+        os.environ["HNH_RING_MODE"] = args.ring_mode
+    if args.chunks:
+        os.environ["HNH_MESH_CHUNKS"] = str(args.chunks)
     import torch  # first: one HIP runtime per process (see distributed_sddmm_amd/_kernels.py)
     from distributed_sddmm_amd import api as H
 
@@ -121,7 +191,32 @@ def run(args, make_world=gpu_world):
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: never depend on the container hostname resolving
         if not dist.is_initialized():
             dist.init_process_group(backend="gloo", rank=rank, world_size=n)  # bootstrap + barriers only; data moves over RCCL
+    dog = Watchdog(rank, args.watchdog, n > 1)
+    dog.phase("transport creation (RCCL communicator)")
     world, device_sync = make_world(H, dist, rank, n, local_rank)
+    dog.done()
+
+    # ---- multi-GPU preflight: every transport primitive the schedules use, on small buffers with known contents, each under
+    # the watchdog, so that a transport problem is reported as "rank r, primitive X" instead of a hang; then the order in which
+    # the ranks created their communicators is compared
+    preflight = None
+    if n > 1 and not args.no_preflight:
+        preflight = {}
+        for what, name in enumerate(H.World.PREFLIGHT):
+            dog.phase("preflight: " + name, 90.0)
+            err = world.preflight(what, 1 << 16)
+            dog.done()
+            if not err <= 1e-9:
+                sys.stderr.write("[bench.py preflight] rank %d: %s delivered wrong data (max deviation %.3e)\n" % (rank, name, err))
+                sys.stderr.flush()
+                os._exit(4)
+            preflight[name] = err
+        sig = [None] * n
+        dist.all_gather_object(sig, world.split_signature())
+        if len(set(sig)) != 1:
+            sys.stderr.write("[bench.py preflight] ranks created their communicators in different orders: %r\n" % (sig,))
+            sys.stderr.flush()
+            os._exit(4)
 
     def barrier():
         if dist is not None:
@@ -130,6 +225,7 @@ def run(args, make_world=gpu_world):
         device_sync()
 
     # ---- build: same global matrix on every rank count (strong scaling)
+    dog.phase("set-up (generator, redistribution, CSR blocks)", max(args.watchdog, 600.0))
     t_setup = time.perf_counter()
     sp = H.SpmatLocal.load_tuples(world, False, args.logm, args.edge_factor)
     info = sp.info()
@@ -144,14 +240,17 @@ def run(args, make_world=gpu_world):
     def step():
         op.fusedSpMM(A, B, S, buf, H.AMAT)
 
+    dog.phase("warm-up steps")
     for _ in range(args.warmup):
         step()
     barrier()
+    dog.phase("timed steps")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    dog.phase("roofline leg and result check", max(args.watchdog, 600.0))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -174,6 +273,46 @@ def run(args, make_world=gpu_world):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         kern_ms, launches, alg_bytes_per_call = float(t[0]) / n, int(t[1]) // n, float(t[2]) / n
     barrier()
+
+    # ---- result check at the reported size (outside the timed region): with A = B = 0.001 and S = 1 one fused call has the
+    # closed form A[i, :] = deg(i) * R * 1e-9 (every SDDMM value is R * 1e-6; row i of the SpMM adds deg(i) of them times
+    # 0.001).  deg comes from the host generator (bit-identical draws, independent of every device code path).
+    check = None
+    if not args.no_check:
+        import numpy as np
+        grows, _ = H.generate_er(m, m, m * args.edge_factor, 12345)
+        deg = np.bincount(grows, minlength=m).astype(np.float64)
+        nnz_host = int(len(grows))
+        del grows
+        A.fill(0.001)
+        B.fill(0.001)
+        step()
+        world.sync()
+        got = A.download().reshape(-1)
+        want_scale = args.r * 1e-9
+        worst, elems_checked, off = 0.0, 0, 0
+        for top, left, rc, cc in op.submatrices(H.AMAT):
+            keep = int(max(0, min(rc, m - top)))
+            blk = got[off:off + rc * cc].reshape(rc, cc)[:keep]
+            off += rc * cc
+            if keep:
+                worst = max(worst, float(np.max(np.abs(blk - deg[top:top + keep, None] * want_scale))))
+                elems_checked += keep * cc
+        ref = float(deg.max()) * want_scale
+        local_n = float(op.info()["nS"])
+        if dist is not None:
+            t = torch.tensor([worst], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            worst = float(t[0])
+            t = torch.tensor([float(elems_checked), local_n], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            elems_checked, local_n = int(t[0]), float(t[1])
+        rows_checked = elems_checked // args.r  # every rank checks the rows (and, under an R split, the columns) it owns
+        check = {"what": "one fresh fusedSpMM from A = B = 0.001, S = 1 against the closed form A[i,:] = deg(i)*R*1e-9, deg from the host generator",
+                 "rel_err": worst / ref, "tolerance": 1e-11, "rows_checked": int(rows_checked),
+                 "nnz_operator": int(nnz), "nnz_host_generator": nnz_host, "nnz_in_blocks_all_ranks": int(local_n),
+                 "ok": bool(worst / ref <= 1e-11 and nnz_host == nnz and rows_checked == m)}
+        barrier()
 
     out = None
     if rank == 0:
@@ -202,15 +341,27 @@ def run(args, make_world=gpu_world):
                                    "%s c=%d on %d x MI355X%s" % (args.logm, args.logm, args.edge_factor, nnz, args.r, args.alg, args.c, n,
                                                                 "" if n == 1 else ", RCCL ring over xGMI"),
                        "nnz": nnz, "M": m, "R": args.r, "algorithm": args.alg, "c": args.c, "transport": "none" if n == 1 else "rccl",
+                       "ring_mode": os.environ.get("HNH_RING_MODE", "mesh") if n > 1 else None,
+                       "mesh_chunks": (int(os.environ["HNH_MESH_CHUNKS"]) if "HNH_MESH_CHUNKS" in os.environ else "default") if n > 1 else None,
                        "setup_s": round(t_setup, 2)},
-            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            # `achieved` is an ALGORITHMIC rate (SURVEY 8d byte model / measured launch time), not DRAM utilisation: part of every
+            # launch's gathers is served by the 256 MiB Infinity Cache, which sits behind the counters `traffic` comes from
+            "roofline": {"bound": "hbm", "bound_detail": "hbm gather model (Infinity-Cache assisted); the binding unit is the per-CU "
+                                                          "vector-memory miss path, see DESIGN.md section 3 and profiles/r02_gather_probe.log",
+                         "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
+                         "traffic_source": "profiles/hbm_traffic.json (static: rocprofv3 FETCH_SIZE/WRITE_SIZE passes of an earlier run of "
+                                           "this command, not collected live)" if traffic is not None else None,
                          "kernel": ("row_kernel<fused> (hnh_fused_sddmm_spmm_csr), one launch per Infinity-Cache panel of B" if n == 1 else
                                     "fused_multi_kernel (hnh_fused_sddmm_spmm_csr_multi), local block + one launch per fetched chunk"),
                          "avg_launch_ms": dur * 1e3,
                          "launches_per_step": launches_per_call, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "model": "per fused call nnz*(8R+24) + 16*R*rows (SURVEY 8d), divided evenly over its launches"},
         }
+        if check is not None:
+            out["check"] = check
+        if preflight is not None:
+            out["preflight"] = {"primitives_ok": sorted(preflight), "communicator_split_order": "identical on all ranks"}
         if n == 1 and not args.no_cpu_baseline and out["backend"] == "hip-gfx950":
             try:
                 out["cpu_baseline"] = cpu_baseline(args)
@@ -219,12 +370,16 @@ def run(args, make_world=gpu_world):
                                        "sample": "FAILED: %s" % str(e)[:300]}
         print(json.dumps(out), flush=True)
 
+    dog.phase("teardown")
     for x in (A, B, S, buf):
         x.free()
     op.free()
     if dist is not None:
         dist.barrier()
     world.close()
+    dog.done()
+    if check is not None and not check["ok"]:
+        raise SystemExit("bench.py: the result check FAILED: %r" % (check,))
     return out if rank == 0 else None
 
 

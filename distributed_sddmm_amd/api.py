@@ -56,6 +56,8 @@ SIGNATURES = {
     "hnh_world_stream": (_vp, [_vp, _i32]),
     "hnh_world_ctx": (_vp, [_vp]),
     "hnh_world_grid_probe": (_i32, [_vp, _i32, _i32, _i32, _i32, _pi32, _pi32]),
+    "hnh_world_preflight": (_i32, [_vp, _i32, _i64, C.POINTER(_dbl)]),
+    "hnh_world_split_signature": (_i32, [_vp, C.POINTER(_u64), _pi32]),
     "hnh_spmat_create": (_i32, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _pvp]),
     "hnh_spmat_load_tuples": (_i32, [_vp, _i32, _i32, _i32, C.c_char_p, _pvp]),
     "hnh_spmat_info": (_i32, [_vp, _pi64]),
@@ -227,6 +229,20 @@ class World:
         out, ok = (C.c_int * 9)(), C.c_int()
         _check(lib().hnh_world_grid_probe(self.h, nr, nc, nh, adjacency, out, C.byref(ok)), "grid_probe")
         return list(out), bool(ok.value)
+
+    PREFLIGHT = ("ring sendrecv", "mesh group (n-1 pairs)", "allgather (layer)", "reduce_scatter (layer)", "allreduce (layer)",
+                 "allgatherv + reduce_scatter_v", "device alltoallv", "allgather (world, native)", "reduce_scatter (world, native)")
+
+    def preflight(self, what: int, count: int = 4096) -> float:
+        """hnh_world_preflight: one transport primitive on known data; returns the largest deviation (collective)."""
+        err = _dbl()
+        _check(lib().hnh_world_preflight(self.h, what, count, C.byref(err)), "preflight: " + self.PREFLIGHT[what])
+        return err.value
+
+    def split_signature(self):
+        sig, n = _u64(), _i32()
+        _check(lib().hnh_world_split_signature(self.h, C.byref(sig), C.byref(n)), "split_signature")
+        return int(sig.value), int(n.value)
 
     def close(self):
         if self.h:

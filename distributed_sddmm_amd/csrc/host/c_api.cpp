@@ -1,4 +1,5 @@
 // C ABI of the host layer (include/hnh_dist.h): thin handle wrappers over the C++ classes.
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -160,6 +161,172 @@ int hnh_world_grid_probe(hnh_world* w, int nr, int nc, int nh, int adjacency, in
                              g.fiber_world.size()};
         std::memcpy(out9, vals, sizeof(vals));
         *ok = g.self_test(false) ? 1 : 0;
+    });
+}
+
+int hnh_world_split_signature(hnh_world* w, uint64_t* signature, int* count) {
+    if (!w || !signature || !count) return HNH_ERR_INVALID;
+    *signature = w->w->split_signature;
+    *count = w->w->split_count;
+    return HNH_OK;
+}
+
+// Transport self-test: one communication primitive on small device buffers with known contents, verified on the host.
+// Every rank of the world calls it with the same arguments.  *max_err = largest deviation from the expected values.
+int hnh_world_preflight(hnh_world* wh, int what, int64_t count, double* max_err) {
+    return guarded(wh->w.get(), [&] {
+        hnh::World* w = wh->w.get();
+        const int p = w->size, me = w->rank;
+        if (count < 1) hnh::fatal("Error, preflight needs a positive element count!");
+        const size_t n = (size_t)count;
+        auto val = [](int rank, size_t i, int salt) { return (double)(rank + 1) * 1000.0 + (double)(i % 997) + 0.25 * salt; };
+        auto upload = [&](double* d, const std::vector<double>& h) {
+            w->copy(d, h.data(), h.size() * sizeof(double), HNH_COPY_H2D, HNH_STREAM_COMM);
+        };
+        auto download = [&](const double* d, size_t m) {
+            std::vector<double> h(m);
+            w->copy(h.data(), d, m * sizeof(double), HNH_COPY_D2H, HNH_STREAM_COMM);
+            w->sync(HNH_STREAM_COMM);
+            return h;
+        };
+        double err = 0.0;
+        auto expect = [&](double got, double want) { err = std::max(err, std::abs(got - want)); };
+        hnh::Comm world = w->world_comm();
+        // a sub-communicator like the schedules' layer communicator: pairs (c = 2) when p is even, else everybody
+        const int c = (p % 2 == 0) ? 2 : 1;
+        hnh::Comm layer = w->split(me / c, me % c);
+        hnh::Comm ring = w->split(me % c, me / c);
+        switch (what) {
+            case HNH_PREFLIGHT_RING: {  // relay step: send to ring rank +1, receive from -1 (distributed_sparse.h:351-361)
+                hnh::DeviceArray s(w, n * 8), r(w, n * 8);
+                std::vector<double> h(n);
+                for (size_t i = 0; i < n; i++) h[i] = val(me, i, 1);
+                upload((double*)s.ptr(), h);
+                const int rn = ring.size();
+                w->sendrecv(ring, s.ptr(), n * 8, (ring.me + 1) % rn, r.ptr(), n * 8, (ring.me - 1 + rn) % rn, HNH_STREAM_COMM);
+                auto got = download((double*)r.ptr(), n);
+                const int src = ring.ranks[(ring.me - 1 + rn) % rn];
+                for (size_t i = 0; i < n; i++) expect(got[i], val(src, i, 1));
+                break;
+            }
+            case HNH_PREFLIGHT_MESH: {  // all n - 1 owner -> consumer transfers as ONE group (mesh fetch)
+                const int rn = ring.size();
+                hnh::DeviceArray s(w, n * 8), r(w, n * 8 * (size_t)std::max(rn - 1, 1));
+                std::vector<double> h(n);
+                for (size_t i = 0; i < n; i++) h[i] = val(me, i, 2);
+                upload((double*)s.ptr(), h);
+                w->group_begin();
+                for (int k = 1; k < rn; k++)
+                    w->sendrecv(ring, s.ptr(), n * 8, (ring.me + k) % rn, (double*)r.ptr() + (size_t)(k - 1) * n, n * 8,
+                                (ring.me - k + rn) % rn, HNH_STREAM_COMM);
+                w->group_end();
+                auto got = download((double*)r.ptr(), n * (size_t)std::max(rn - 1, 1));
+                for (int k = 1; k < rn; k++) {
+                    const int src = ring.ranks[(ring.me - k + rn) % rn];
+                    for (size_t i = 0; i < n; i++) expect(got[(size_t)(k - 1) * n + i], val(src, i, 2));
+                }
+                break;
+            }
+            case HNH_PREFLIGHT_ALLGATHER:
+            case HNH_PREFLIGHT_ALLGATHER_WORLD: {
+                hnh::Comm& cm = (what == HNH_PREFLIGHT_ALLGATHER) ? layer : world;
+                const int m = cm.size();
+                hnh::DeviceArray s(w, n * 8), r(w, n * 8 * (size_t)m);
+                std::vector<double> h(n);
+                for (size_t i = 0; i < n; i++) h[i] = val(me, i, 3);
+                upload((double*)s.ptr(), h);
+                w->allgather(cm, s.ptr(), r.ptr(), n * 8, HNH_STREAM_COMM);
+                auto got = download((double*)r.ptr(), n * (size_t)m);
+                for (int j = 0; j < m; j++)
+                    for (size_t i = 0; i < n; i++) expect(got[(size_t)j * n + i], val(cm.ranks[j], i, 3));
+                break;
+            }
+            case HNH_PREFLIGHT_REDUCE_SCATTER:
+            case HNH_PREFLIGHT_REDUCE_SCATTER_WORLD: {
+                hnh::Comm& cm = (what == HNH_PREFLIGHT_REDUCE_SCATTER) ? layer : world;
+                const int m = cm.size();
+                hnh::DeviceArray s(w, n * 8 * (size_t)m), r(w, n * 8);
+                std::vector<double> h(n * (size_t)m);
+                for (int j = 0; j < m; j++)
+                    for (size_t i = 0; i < n; i++) h[(size_t)j * n + i] = val(me, i, 4 + j);
+                upload((double*)s.ptr(), h);
+                w->reduce_scatter_f64(cm, (const double*)s.ptr(), (double*)r.ptr(), n, HNH_STREAM_COMM);
+                auto got = download((double*)r.ptr(), n);
+                for (size_t i = 0; i < n; i++) {
+                    double want = 0.0;
+                    for (int j = 0; j < m; j++) want += val(cm.ranks[j], i, 4 + cm.me);
+                    expect(got[i], want);
+                }
+                break;
+            }
+            case HNH_PREFLIGHT_ALLREDUCE: {
+                hnh::DeviceArray b(w, n * 8);
+                std::vector<double> h(n);
+                for (size_t i = 0; i < n; i++) h[i] = val(me, i, 5);
+                upload((double*)b.ptr(), h);
+                w->allreduce_f64(layer, (double*)b.ptr(), n, HNH_STREAM_COMM);
+                auto got = download((double*)b.ptr(), n);
+                for (size_t i = 0; i < n; i++) {
+                    double want = 0.0;
+                    for (int j = 0; j < layer.size(); j++) want += val(layer.ranks[j], i, 5);
+                    expect(got[i], want);
+                }
+                break;
+            }
+            case HNH_PREFLIGHT_VARIABLE: {  // allgatherv + reduce_scatter_v with ragged counts (25D_cannon_sparse.hpp:224-233,294-300)
+                hnh::Comm& cm = ring;
+                const int m = cm.size();
+                std::vector<int> counts(m), displs(m);
+                int total = 0;
+                for (int j = 0; j < m; j++) {
+                    counts[j] = (int)std::min<size_t>(n, 1 + (size_t)(j * 37 + 11) % n);
+                    displs[j] = total;
+                    total += counts[j];
+                }
+                hnh::DeviceArray s(w, (size_t)counts[cm.me] * 8), r(w, (size_t)total * 8), r2(w, (size_t)counts[cm.me] * 8);
+                std::vector<double> h((size_t)counts[cm.me]);
+                for (size_t i = 0; i < h.size(); i++) h[i] = val(me, i, 6);
+                upload((double*)s.ptr(), h);
+                w->allgatherv_f64(cm, (const double*)s.ptr(), h.size(), (double*)r.ptr(), counts, displs, HNH_STREAM_COMM);
+                auto got = download((double*)r.ptr(), (size_t)total);
+                for (int j = 0; j < m; j++)
+                    for (int i = 0; i < counts[j]; i++) expect(got[(size_t)displs[j] + i], val(cm.ranks[j], (size_t)i, 6));
+                // every member contributes the gathered vector scaled by (its comm index + 1)
+                std::vector<double> contrib((size_t)total);
+                for (int t = 0; t < total; t++) contrib[t] = got[t] * (cm.me + 1);
+                upload((double*)r.ptr(), contrib);
+                w->reduce_scatter_v_f64(cm, (const double*)r.ptr(), (double*)r2.ptr(), counts, HNH_STREAM_COMM);
+                auto red = download((double*)r2.ptr(), (size_t)counts[cm.me]);
+                const double scale = 0.5 * m * (m + 1);
+                for (int i = 0; i < counts[cm.me]; i++) expect(red[i] / scale, val(me, (size_t)i, 6));
+                break;
+            }
+            case HNH_PREFLIGHT_ALLTOALLV: {  // the setup pipeline's device exchange (SpmatLocal.hpp:389-462)
+                std::vector<size_t> sb(p), sd(p), rb(p), rd(p);
+                size_t st = 0, rt = 0;
+                for (int j = 0; j < p; j++) {
+                    sb[j] = 8 * (1 + (size_t)(me * 7 + j * 3) % n);
+                    sd[j] = st; st += sb[j];
+                    rb[j] = 8 * (1 + (size_t)(j * 7 + me * 3) % n);
+                    rd[j] = rt; rt += rb[j];
+                }
+                hnh::DeviceArray s(w, st), r(w, rt);
+                std::vector<double> h(st / 8);
+                for (int j = 0; j < p; j++)
+                    for (size_t i = 0; i < sb[j] / 8; i++) h[sd[j] / 8 + i] = val(me, i, 7 + j);
+                upload((double*)s.ptr(), h);
+                w->sync(HNH_STREAM_COMM);
+                w->device_alltoallv(s.ptr(), sb, sd, r.ptr(), rb, rd, HNH_STREAM_COMM);
+                auto got = download((double*)r.ptr(), rt / 8);
+                for (int j = 0; j < p; j++)
+                    for (size_t i = 0; i < rb[j] / 8; i++) expect(got[rd[j] / 8 + i], val(j, i, 7 + me));
+                break;
+            }
+            default:
+                hnh::fatal("Error, unknown preflight test!");
+        }
+        w->sync_all();
+        *max_err = err;
     });
 }
 

@@ -385,6 +385,7 @@ private:
         if (n > 1) {
             for (auto& s : ring_spare) ensure(s, start->rows(), start->cols());
             order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // inputs (and earlier readers of the spares) are done
+            if (!(n == 2 && held_ptr == start->data())) held_in_ring = false;  // the spares are about to hold other blocks
         }
         const int dst = pMod(grid->rankInCol + 1, n), src = pMod(grid->rankInCol - 1, n);
         const size_t bytes = (size_t)start->size() * sizeof(double);
@@ -423,6 +424,7 @@ private:
         auto t = start_clock();
         order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // my block is final; earlier readers of the landing buffers are done
         const bool held = (held_ptr == start->data());
+        if (!held) held_in_mesh = false;  // another operand lands in the buffers: a held one has to be fetched again
         for (int q = 0; q < chunks; q++) {
             const int64_t r0 = std::min<int64_t>((int64_t)q * cw, start->rows()), r1 = std::min<int64_t>(r0 + cw, start->rows());
             const size_t off = (size_t)r0 * start->cols(), bytes = (size_t)(r1 - r0) * start->cols() * sizeof(double);
@@ -451,6 +453,7 @@ private:
         auto t = start_clock();
         order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // my block is final; earlier readers of the landing buffers are done
         const bool held = (held_ptr == start->data());
+        if (!held) held_in_mesh = false;  // another operand lands in the buffers: a held one has to be fetched again
         if (!(held && held_in_mesh)) {  // a held operand's blocks are still in the landing buffers from the previous call
             world->group_begin();
             for (int k = 1; k < n; k++)  // my block is what ring rank me+k needs at ITS step k; I need the block of me-k at mine
@@ -481,6 +484,7 @@ private:
     template <typename Step>
     void ring_readwrite(DenseMatrix* start, int n, Step&& step) {
         hnh::BufferPair bBuf(start, &ring_spare[0]);
+        if (n > 1) held_in_ring = false;  // ring_spare[0] is overwritten
         const int dst = pMod(grid->rankInCol + 1, n), src = pMod(grid->rankInCol - 1, n);
         for (int i = 0; i < n; i++) {
             step(i, *bBuf.getActive());

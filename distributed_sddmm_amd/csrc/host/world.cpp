@@ -233,10 +233,13 @@ Comm World::split(int color, int key) {
     for (int r = 0; r < size; r++)
         if (all[2 * r] == color) members.push_back({all[2 * r + 1], r});
     std::sort(members.begin(), members.end());
+    // every rank folds the WORLD-WIDE (color, key) table of this split into a running signature: ranks that created their
+    // communicators in a different order end up with different signatures (bench.py's preflight compares them)
+    for (int v : all) split_signature = (split_signature ^ (uint64_t)(uint32_t)v) * 1099511628211ULL;
+    split_count++;
     Comm c;
     c.color = color;
     c.key = key;
-    c.native_slot = std::make_shared<void*>(nullptr);
     for (size_t i = 0; i < members.size(); i++) {
         c.ranks.push_back(members[i].second);
         if (members[i].second == rank) c.me = (int)i;
@@ -244,17 +247,20 @@ Comm World::split(int color, int key) {
     return c;
 }
 
-void World::free_comm(Comm& c) { c.native_slot.reset(); }
+void World::free_comm(Comm& c) { (void)c; }
 
 // Default collectives: (n - 1) rounds of pairwise exchange; round k pairs me -> me + k, me - k -> me.
 void World::allgather(const Comm& comm, const void* sendbuf, void* recvbuf, size_t bytes, int stream) {
     const int n = comm.size(), me = comm.me;
     char* out = static_cast<char*>(recvbuf);
     if (out + (size_t)me * bytes != sendbuf) copy(out + (size_t)me * bytes, sendbuf, bytes, HNH_COPY_D2D, stream);
+    if (n == 1) return;
+    group_begin();  // RCCL: the n - 1 explicit-peer pairs of a group progress concurrently, one xGMI link each
     for (int k = 1; k < n; k++) {
         const int dst = (me + k) % n, src = (me - k + n) % n;
         sendrecv(comm, out + (size_t)me * bytes, bytes, dst, out + (size_t)src * bytes, bytes, src, stream);
     }
+    group_end();
 }
 
 void World::allgatherv_f64(const Comm& comm, const double* sendbuf, size_t sendcount, double* recvbuf,
@@ -262,11 +268,14 @@ void World::allgatherv_f64(const Comm& comm, const double* sendbuf, size_t sendc
     const int n = comm.size(), me = comm.me;
     if ((size_t)counts[me] != sendcount) fatal("Error, allgatherv: send count does not match counts[me]");
     if (recvbuf + displs[me] != sendbuf) copy(recvbuf + displs[me], sendbuf, sendcount * sizeof(double), HNH_COPY_D2D, stream);
+    if (n == 1) return;
+    group_begin();
     for (int k = 1; k < n; k++) {
         const int dst = (me + k) % n, src = (me - k + n) % n;
         sendrecv(comm, recvbuf + displs[me], sendcount * sizeof(double), dst, recvbuf + displs[src],
                  (size_t)counts[src] * sizeof(double), src, stream);
     }
+    group_end();
 }
 
 void World::reduce_scatter_v_f64(const Comm& comm, const double* sendbuf, double* recvbuf, const std::vector<int>& counts,
@@ -277,12 +286,18 @@ void World::reduce_scatter_v_f64(const Comm& comm, const double* sendbuf, double
     const size_t mycount = (size_t)counts[me];
     copy(recvbuf, sendbuf + displ[me], mycount * sizeof(double), HNH_COPY_D2D, stream);
     if (n == 1) return;
-    double* tmp = static_cast<double*>(scratch(0, std::max<size_t>(mycount, 1) * sizeof(double)));
+    // every member's contribution to my shard lands in its own buffer (one group: n - 1 links at once), then the
+    // shards are added in a fixed order, so the result does not depend on arrival order
+    double* tmp = static_cast<double*>(scratch(0, std::max<size_t>(mycount, 1) * (size_t)(n - 1) * sizeof(double)));
+    group_begin();
     for (int k = 1; k < n; k++) {
         const int dst = (me + k) % n, src = (me - k + n) % n;
-        sendrecv(comm, sendbuf + displ[dst], (size_t)counts[dst] * sizeof(double), dst, tmp, mycount * sizeof(double), src, stream);
-        if (mycount) check(be->hnh_axpy_f64(ctx, recvbuf, tmp, 1.0, (int64_t)mycount, stream), "hnh_axpy_f64");
+        sendrecv(comm, sendbuf + displ[dst], (size_t)counts[dst] * sizeof(double), dst, tmp + (size_t)(k - 1) * mycount,
+                 mycount * sizeof(double), src, stream);
     }
+    group_end();
+    for (int k = 1; k < n; k++)
+        if (mycount) check(be->hnh_axpy_f64(ctx, recvbuf, tmp + (size_t)(k - 1) * mycount, 1.0, (int64_t)mycount, stream), "hnh_axpy_f64");
 }
 
 void World::reduce_scatter_f64(const Comm& comm, const double* sendbuf, double* recvbuf, size_t count, int stream) {
@@ -529,25 +544,11 @@ RcclWorld::~RcclWorld() {
     destroy_device();
 }
 
-Comm RcclWorld::split(int color, int key) { return World::split(color, key); }
-
-// ncclCommSplit is collective over the world, and every schedule is SPMD-symmetric (when one rank runs a
-// collective on its row/fiber communicator, every rank does on its own), so the RCCL sub-communicator can be
-// created at first use.  Schedules that never run a collective (c = 1) never split at all.
-void* RcclWorld::native_for(const Comm& comm) {
-    if (comm.is_world || !comm.native_slot) return comm_;
-    if (!*comm.native_slot) check(be->hnh_comm_split(ctx, comm_, comm.color, comm.key, comm.native_slot.get()), "hnh_comm_split");
-    return *comm.native_slot;
-}
-void RcclWorld::free_comm(Comm& c) {
-    if (c.native_slot && *c.native_slot) {
-        sync_all();
-        be->hnh_comm_destroy(ctx, *c.native_slot);
-        *c.native_slot = nullptr;
-    }
-    c.native_slot.reset();
-}
-
+// Sub-communicators (rows / columns / fibers of the process grid) are NOT RCCL communicators: their collectives run as
+// one group of explicit-peer send/recv pairs on the world communicator (World::allgather etc.).  On the xGMI full mesh
+// that is the natural algorithm — every pair has its own link — and it needs no ncclCommSplit, whose preconditions
+// (no operation in flight on the parent, identical creation order on all ranks) a lazily created communicator could
+// violate (round-1 advisor finding).  Native RCCL collectives are used where the communicator IS the world.
 void RcclWorld::group_begin() { check(be->hnh_comm_group_begin(ctx), "hnh_comm_group_begin"); }
 void RcclWorld::group_end() { check(be->hnh_comm_group_end(ctx), "hnh_comm_group_end"); }
 
@@ -567,19 +568,22 @@ void RcclWorld::allgather(const Comm& comm, const void* sendbuf, void* recvbuf, 
         if (sendbuf != recvbuf) copy(recvbuf, sendbuf, bytes, HNH_COPY_D2D, stream);
         return;
     }
-    check(be->hnh_comm_allgather(ctx, native_for(comm), sendbuf, recvbuf, bytes, stream), "hnh_comm_allgather");
+    if (!comm.is_world) return World::allgather(comm, sendbuf, recvbuf, bytes, stream);
+    check(be->hnh_comm_allgather(ctx, comm_, sendbuf, recvbuf, bytes, stream), "hnh_comm_allgather");
 }
 void RcclWorld::reduce_scatter_f64(const Comm& comm, const double* sendbuf, double* recvbuf, size_t count, int stream) {
     if (comm.size() == 1) {
         copy(recvbuf, sendbuf, count * sizeof(double), HNH_COPY_D2D, stream);
         return;
     }
-    check(be->hnh_comm_reduce_scatter_f64(ctx, native_for(comm), sendbuf, recvbuf, count, stream), "hnh_comm_reduce_scatter_f64");
+    if (!comm.is_world) return World::reduce_scatter_f64(comm, sendbuf, recvbuf, count, stream);
+    check(be->hnh_comm_reduce_scatter_f64(ctx, comm_, sendbuf, recvbuf, count, stream), "hnh_comm_reduce_scatter_f64");
 }
 
 void RcclWorld::allreduce_f64(const Comm& comm, double* buf, size_t count, int stream) {
     if (comm.size() == 1 || count == 0) return;
-    check(be->hnh_comm_allreduce_f64(ctx, native_for(comm), buf, buf, count, stream), "hnh_comm_allreduce_f64");
+    if (!comm.is_world) return World::allreduce_f64(comm, buf, count, stream);
+    check(be->hnh_comm_allreduce_f64(ctx, comm_, buf, buf, count, stream), "hnh_comm_allreduce_f64");
 }
 
 void RcclWorld::barrier() {

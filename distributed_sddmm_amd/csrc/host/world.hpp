@@ -31,9 +31,6 @@ namespace hnh {
 struct Comm {
     std::vector<int> ranks;
     int me = -1;
-    // RCCL sub-communicator (RcclWorld), created on first collective use; the slot is shared by every copy of
-    // this Comm (schedules copy their grid's communicators into A_R_split_world etc.), so it is created once
-    std::shared_ptr<void*> native_slot;
     int color = 0, key = 0;  // what it was split with (MPI_Comm_split arguments)
     bool is_world = false;
     int size() const { return (int)ranks.size(); }
@@ -47,6 +44,10 @@ public:
     hnh_ctx* ctx = nullptr;
     int device = 0;
     bool timing_sync = false;  // when true perf counters synchronise the streams first (reference-like attribution)
+    // running hash over the world-wide (color, key) tables of every split() so far, and their number: identical on all
+    // ranks iff they created their communicators in the same order (checked by bench.py's multi-GPU preflight)
+    uint64_t split_signature = 1469598103934665603ULL;
+    int split_count = 0;
 
     virtual ~World();
     virtual const char* kind() const = 0;
@@ -167,8 +168,6 @@ public:
     RcclWorld(int rank, int nranks, Backend* backend, int device_ordinal, const void* unique_id);
     ~RcclWorld() override;
     const char* kind() const override { return "rccl"; }
-    Comm split(int color, int key) override;
-    void free_comm(Comm& c) override;
     void group_begin() override;
     void group_end() override;
     void sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes,
@@ -182,8 +181,7 @@ public:
                         const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl) override;
 
 private:
-    void* comm_ = nullptr;  // world communicator
-    void* native_for(const Comm& comm);
+    void* comm_ = nullptr;  // world communicator (the only RCCL communicator: see world.cpp)
 };
 
 // ---- transport supplied by the embedding program (torch.distributed / gloo in tests, MPI, ...).

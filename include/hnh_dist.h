@@ -76,6 +76,24 @@ void* hnh_world_stream(hnh_world* w, int stream);      /* raw hipStream_t */
 hnh_ctx* hnh_world_ctx(hnh_world* w);                  /* the rank's kernel-level context */
 /* FlexibleGrid(nr, nc, nh, adjacency) (FlexibleGrid.hpp:41-94): out9 = i, j, k, rankInRow, rankInCol, rankInFiber,
  * row size, col size, fiber size; *ok = result of the broadcast self test (FlexibleGrid.hpp:169-201). */
+/* Transport self-test (collective): runs ONE communication primitive on `count` doubles with known contents and reports the
+ * largest deviation from the expected values.  bench.py --gpus N runs every one of them under a watchdog before the timed
+ * region, so a transport problem shows up as "rank r, primitive X" instead of a hang (no reference counterpart). */
+enum {
+    HNH_PREFLIGHT_RING = 0,                 /* relay step: send to ring rank +1, receive from -1 */
+    HNH_PREFLIGHT_MESH = 1,                 /* n - 1 explicit-peer pairs in one group (mesh fetch) */
+    HNH_PREFLIGHT_ALLGATHER = 2,            /* over a layer sub-communicator */
+    HNH_PREFLIGHT_REDUCE_SCATTER = 3,
+    HNH_PREFLIGHT_ALLREDUCE = 4,
+    HNH_PREFLIGHT_VARIABLE = 5,             /* allgatherv + reduce_scatter_v, ragged counts */
+    HNH_PREFLIGHT_ALLTOALLV = 6,            /* device all-to-all of the set-up pipeline */
+    HNH_PREFLIGHT_ALLGATHER_WORLD = 7,      /* native RCCL collective on the world communicator */
+    HNH_PREFLIGHT_REDUCE_SCATTER_WORLD = 8,
+    HNH_PREFLIGHT_COUNT = 9
+};
+int hnh_world_preflight(hnh_world* w, int what, int64_t count, double* max_err);
+/* running hash / number of the communicator splits so far: identical on every rank iff they split in the same order */
+int hnh_world_split_signature(hnh_world* w, uint64_t* signature, int* count);
 int hnh_world_grid_probe(hnh_world* w, int nr, int nc, int nh, int adjacency, int* out9, int* ok);
 
 /* ---- sparse input (SpmatLocal.hpp:267-606) */

@@ -35,3 +35,12 @@ def test_bench_contract(nranks, alg, c):
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
     assert rf["launches_per_step"] >= 1 and rf["algorithmic_bytes_per_launch"] > 0
     assert out["backend"] == "oracle-cpu-test-double" and "cpu_baseline" not in out
+    # the closed-form result check at the run's own size, on every rank's rows
+    chk = out["check"]
+    assert chk["ok"] and chk["rel_err"] <= 1e-11 and chk["rows_checked"] == 1 << 10
+    assert chk["nnz_operator"] == chk["nnz_host_generator"] == out["config"]["nnz"]
+    if nranks > 1:  # every transport primitive ran before the timed region, and what was measured is recorded
+        assert len(out["preflight"]["primitives_ok"]) == 9
+        assert out["config"]["ring_mode"] == "mesh" and out["config"]["transport"] == "rccl"
+    else:
+        assert "preflight" not in out

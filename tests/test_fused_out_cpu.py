@@ -140,3 +140,42 @@ def test_held_operand_is_fetched_once(alg, p, ring, monkeypatch):
         assert T.rel(glob[3], want2) > 1e-3 and T.rel(glob[3], want1) > 1e-3  # own block new, remote blocks held
     elif alg == "15d_fusion2":
         assert T.rel(glob[3], want2) <= T.TOL       # relay ring of > 2 ranks: hint ignored
+
+
+@pytest.mark.parametrize("p,ring", [(4, "mesh"), (2, "relay"), (4, "relay")])
+def test_held_operand_survives_other_operands(p, ring, monkeypatch):
+    """The caller keeps the documented contract (the CONTENTS of the held matrix do not change) but moves another
+    operand between two uses of the held one: hold(B); fused(A, B); fused(A, C); fused(A, B).  The landing buffers
+    then hold C's blocks, so B has to be fetched again (round-1 advisor finding: the third call multiplied by C)."""
+    monkeypatch.setenv("HNH_RING_MODE", ring)
+    case = T.case_inputs("er8_r16")
+
+    def body(w):
+        sp = H.SpmatLocal.from_global(w, case["M"], case["N"], case["rows"], case["cols"], np.ones(len(case["rows"])))
+        d = H.DistributedSparse(w, "15d_fusion2", sp, case["R"], 1)
+        subA, subB = d.submatrices(H.AMAT), d.submatrices(H.BMAT)
+        A, B, Cm = d.like_A_matrix(0.0), d.like_B_matrix(0.0), d.like_B_matrix(0.0)
+        ones, buf = d.like_S_values(1.0), d.like_S_values(0.0)
+        a0, b0 = T.fill_local(subA, A.shape, case["A"]), T.fill_local(subB, B.shape, case["B"])
+        B.upload(b0)
+        Cm.upload(-3.0 * b0)
+        d.hold_moving_operand(B)
+        outs = []
+        for other in (B, Cm, B, B):
+            A.upload(a0)
+            d.fusedSpMM(A, other, ones, buf, H.AMAT)
+            outs.append(A.download())
+        d.hold_moving_operand(None)
+        for h in (A, B, Cm, ones, buf):
+            h.free()
+        d.free(); sp.free()
+        return dict(subA=subA, outs=outs)
+
+    per_rank = H.run_spmd(p, body)
+    glob = [T.assemble_dense([dict(subA=o["subA"], x=o["outs"][k]) for o in per_rank], "x", "subA", case["M"], case["R"]) for k in range(4)]
+    wantB, _ = T.fused_out_expected(case, H.AMAT, None, 0.0)
+    wantC, _ = T.fused_out_expected(dict(case, B=-3.0 * case["B"]), H.AMAT, None, 0.0)
+    assert T.rel(glob[0], wantB) <= T.TOL
+    assert T.rel(glob[1], wantC) <= T.TOL
+    assert T.rel(glob[2], wantB) <= T.TOL
+    assert T.rel(glob[3], wantB) <= T.TOL
