@@ -44,6 +44,23 @@ __device__ __forceinline__ void load_w(double (&dst)[W], const double* __restric
     }
 }
 
+// Load W doubles from global memory at (64-bit base address) + (32-bit byte offset).  The explicit global address space
+// keeps the access a global_load (an integer-to-generic-pointer cast would turn it into a flat_load, which also ties up
+// the LDS counter), and the base + zero-extended-offset form lets a wave-uniform base stay in scalar registers.
+typedef const __attribute__((address_space(1))) char* gbytes_t;
+template <int W>
+__device__ __forceinline__ void load_w_global(double (&dst)[W], uint64_t base, unsigned byte_off) {
+    gbytes_t p = reinterpret_cast<gbytes_t>(base) + byte_off;
+    if constexpr (W == 2) {
+        typedef double dv2 __attribute__((ext_vector_type(2)));
+        const dv2 t = *reinterpret_cast<const __attribute__((address_space(1))) dv2*>(p);
+        dst[0] = t.x;
+        dst[1] = t.y;
+    } else {
+        dst[0] = *reinterpret_cast<const __attribute__((address_space(1))) double*>(p);
+    }
+}
+
 template <int W>
 __device__ __forceinline__ void store_w(double* __restrict__ p, const double (&src)[W]) {
     if constexpr (W == 2) {
@@ -194,20 +211,34 @@ __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 
+// Gather pipeline.  HNH_PIPE = 1: a batch of U nonzeros is handled as two half batches whose gathers are issued one
+// half ahead, so that while the dot products / cross-lane reductions / axpys of one half run, the other half's loads
+// are still in flight (the wave never sits with zero outstanding loads).  Same registers as one batch of U.
+#ifndef HNH_PIPE
+#define HNH_PIPE 1
+#endif
+
+template <bool B>
+struct BoolTag { static constexpr bool value = B; };
+
 template <Op OP, int LPR, int VEC, int W, bool EXACT>
 __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool atomic_out, const int32_t* __restrict__ colidx,
                                             double* values, const double* __restrict__ svalues, const double* __restrict__ X,
                                             const double* __restrict__ Y, double* __restrict__ Out, int64_t ld, int col0,
                                             int ncols, unsigned flags, int lig, const Extras& ex) {
-    constexpr int U = Unroll<LPR, VEC>::value;
-    constexpr int SUB = LPR / U;  // lanes that end up holding the same reduced value
+    constexpr int UFULL = Unroll<LPR, VEC>::value;
+    constexpr bool PIPE = (HNH_PIPE != 0) && UFULL >= 4;
+    constexpr int U = PIPE ? UFULL / 2 : UFULL;  // nonzeros per (half) batch
+    constexpr int SUB = LPR / U;                 // lanes that end up holding the same reduced value
     bool act[VEC];
     int64_t coff[VEC];
+    unsigned lane_off[VEC];  // byte offset of this lane's chunk v inside a dense row (from column col0)
 #pragma unroll
     for (int v = 0; v < VEC; v++) {
         const int c = (v * LPR + lig) * W;
         act[v] = EXACT ? true : (c < ncols);
         coff[v] = (int64_t)col0 + c;
+        lane_off[v] = (unsigned)c * (unsigned)sizeof(double);
     }
 
     double x[VEC][W];    // SDDMM row operand X[row, :]
@@ -223,31 +254,59 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
             }
         }
     }
+    // the gathered operand: byte address of column col0 of its row 0, and its row pitch in bytes
+    const uint64_t g_base = reinterpret_cast<uint64_t>(((OP == Op::kSpmm) ? X : Y) + col0);
+    const uint64_t ld_bytes = (uint64_t)(unsigned)(ld * (int64_t)sizeof(double));
 
-    for (int e = beg; e < end; e += U) {
-        int c[U];
-        double y[U][VEC][W];
-        // issue all gathers of this batch before the first use
+    // column indices of the U nonzeros starting at e (-1 beyond `end` when the batch is not FULL).  One wave per row:
+    // e is wave-uniform and the indices come through the scalar cache; several rows per wave: ONE coalesced load per
+    // group (lane u holds index u), handed round with cross-lane moves instead of U vector loads of the same line.
+    auto load_idx = [&](auto full, int e, int (&c)[U]) {
+        constexpr bool FULL = decltype(full)::value;
+        if constexpr (LPR == 64) {
 #pragma unroll
-        for (int u = 0; u < U; u++) c[u] = (e + u < end) ? colidx[e + u] : -1;
+            for (int u = 0; u < U; u++) c[u] = (FULL || e + u < end) ? colidx[e + u] : -1;
+        } else {
+            const int my = e + (lig % U);
+            const int cv = (FULL || my < end) ? colidx[my] : -1;
+#pragma unroll
+            for (int u = 0; u < U; u++) c[u] = __shfl(cv, u, LPR);
+        }
+    };
+    auto gather = [&](auto full, const int (&c)[U], double (&y)[U][VEC][W]) {
+        constexpr bool FULL = decltype(full)::value;
 #pragma unroll
         for (int u = 0; u < U; u++) {
 #pragma unroll
             for (int v = 0; v < VEC; v++) {
 #pragma unroll
                 for (int w = 0; w < W; w++) y[u][v][w] = 0.0;
-                if (c[u] >= 0 && act[v]) {
-                    const double* src = (OP == Op::kSpmm ? X : Y) + (int64_t)c[u] * ld + coff[v];
-                    load_w<W>(y[u][v], src);
+                if ((FULL || c[u] >= 0) && act[v]) {
+                    // row base (wave-uniform when one wave owns the row: scalar registers) + a 32-bit lane offset
+                    uint64_t rowp = g_base + (uint64_t)(unsigned)c[u] * ld_bytes;
+                    if constexpr (LPR == 64) {  // keep it in scalar registers: global_load with SGPR base + VGPR offset
+                        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)rowp);
+                        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(rowp >> 32));
+                        rowp = ((uint64_t)hi << 32) | lo;
+                    }
+                    unsigned off = lane_off[v];
+                    // opaque to the optimiser: keeps the zero-extension of the offset next to the load (instruction selection
+                    // works per basic block; hoisted out of the loop it would cost a 64-bit VGPR address per gather)
+                    if constexpr (LPR == 64) asm volatile("" : "+v"(off));
+                    load_w_global<W>(y[u][v], rowp, off);
                 }
             }
         }
-
+    };
+    // dot products, value update and axpys of the U nonzeros starting at e whose dense rows are in y
+    auto compute = [&](auto full, int e, const double (&y)[U][VEC][W]) {
+        constexpr bool FULL = decltype(full)::value;
         double wgt;  // weight of nonzero (e + lig / SUB), valid in every lane of its SUB-lane subgroup
         const int mine = e + lig / SUB;
+        const bool have = FULL || mine < end;
         if constexpr (OP == Op::kSpmm) {
-            wgt = (mine < end) ? load_stream(values + mine) : 0.0;
-            if (svalues != nullptr && mine < end) wgt *= svalues[mine];
+            wgt = have ? load_stream(values + mine) : 0.0;
+            if (svalues != nullptr && have) wgt *= svalues[mine];
         } else {
             double d[U];
 #pragma unroll
@@ -260,7 +319,7 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
                 d[u] = s;
             }
             wgt = group_multi_reduce<LPR, U>(d, lig);
-            if (mine < end) {
+            if (have) {
                 const bool overwrite = (OP == Op::kFused) && (flags & HNH_FUSED_VALUES_OVERWRITE);
                 if (!overwrite) wgt += load_stream(values + mine);
                 if (OP == Op::kFused && (flags & HNH_FUSED_LEAKY_RELU)) {  // the activated weight is what gets stored
@@ -275,7 +334,6 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
                 wgt = 0.0;
             }
         }
-
         if constexpr (OP != Op::kSddmm) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -285,6 +343,88 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
 #pragma unroll
                     for (int w = 0; w < W; w++) acc[v][w] = fma(wu, y[u][v][w], acc[v][w]);
             }
+            // pin the accumulation here: left alone, the optimiser sinks the whole axpy chain to the end of the trip
+            // (its result is not needed earlier), which keeps every gather buffer alive and doubles the register count
+#pragma unroll
+            for (int v = 0; v < VEC; v++)
+#pragma unroll
+                for (int w = 0; w < W; w++) asm volatile("" : "+v"(acc[v][w]));
+        }
+    };
+    const BoolTag<true> kFull;
+    const BoolTag<false> kMasked;
+
+    int e = beg;
+    if constexpr (PIPE) {
+        // Four half batches A, B, C, D per trip through two register buffers: gathers of B fly while A is computed, C's
+        // (into A's buffer) while B is computed, D's while C is.  Every load a trip consumes is issued inside the trip —
+        // nothing but the column indices is carried round the loop — and every gather of the steady state is issued
+        // unconditionally, so the waits in front of a half's arithmetic cover exactly that half's loads.
+        double ya[U][VEC][W], yb[U][VEC][W];
+        if (e + 4 * U <= end) {
+            int c0[U], c1[U], c2[U], c3[U];
+            load_idx(kFull, e, c0);
+            load_idx(kFull, e + U, c1);
+            load_idx(kFull, e + 2 * U, c2);
+            load_idx(kFull, e + 3 * U, c3);
+            for (;;) {
+                gather(kFull, c0, ya);
+                gather(kFull, c1, yb);
+                const bool more = e + 8 * U <= end;
+                if (more) {  // the next trip's indices travel with this trip's gathers
+                    load_idx(kFull, e + 4 * U, c0);
+                    load_idx(kFull, e + 5 * U, c1);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the issue order (the scheduler would sink gathers below the waits)
+                compute(kFull, e, ya);
+                __builtin_amdgcn_sched_barrier(0);
+                gather(kFull, c2, ya);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(kFull, e + U, yb);
+                __builtin_amdgcn_sched_barrier(0);
+                gather(kFull, c3, yb);
+                if (more) {
+                    load_idx(kFull, e + 6 * U, c2);
+                    load_idx(kFull, e + 7 * U, c3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                compute(kFull, e + 2 * U, ya);
+                compute(kFull, e + 3 * U, yb);
+                e += 4 * U;
+                if (!more) break;
+            }
+        }
+        // fewer than 4U nonzeros left: masked double halves (both halves' gathers issued together), at most two trips
+        while (e < end) {
+            int c0[U], c1[U];
+            load_idx(kMasked, e, c0);
+            load_idx(kMasked, e + U, c1);
+            gather(kMasked, c0, ya);
+            gather(kMasked, c1, yb);
+            compute(kMasked, e, ya);
+            compute(kMasked, e + U, yb);  // nothing to do (all slots masked) when fewer than U nonzeros were left
+            e += 2 * U;
+        }
+    } else {
+        if (e + U <= end) {
+            int c[U];
+            load_idx(kFull, e, c);
+            for (;;) {
+                double y[U][VEC][W];
+                gather(kFull, c, y);
+                const bool more = e + 2 * U <= end;
+                if (more) load_idx(kFull, e + U, c);  // next batch's indices travel with this batch's gathers
+                compute(kFull, e, y);
+                e += U;
+                if (!more) break;
+            }
+        }
+        if (e < end) {
+            int c[U];
+            double y[U][VEC][W];
+            load_idx(kMasked, e, c);
+            gather(kMasked, c, y);
+            compute(kMasked, e, y);
         }
     }
 
@@ -316,8 +456,11 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
     }
 }
 
+#ifndef HNH_ROW_WAVES
+#define HNH_ROW_WAVES 1  // waves per SIMD the row kernels are compiled for (register budget 512 / waves)
+#endif
 template <Op OP, int LPR, int VEC, int W, bool EXACT>
-__global__ __launch_bounds__(kBlock) void row_kernel(int64_t rows, const int32_t* __restrict__ rowptr,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HNH_ROW_WAVES, 8))) void row_kernel(int64_t rows, const int32_t* __restrict__ rowptr,
                                                      const int32_t* __restrict__ beg_ptr, const int32_t* __restrict__ end_ptr,
                                                      const int32_t* __restrict__ colidx, double* values,
                                                      const double* __restrict__ svalues,

@@ -167,6 +167,32 @@ def fingerprints(rows, cols, m, n, r):
     return f1, f2, f3
 
 
+def fingerprints_closed_form(rows, cols, m, n, r, chunk: int = 1 << 24):
+    """The same three fingerprints (scratch.cpp:26-76) WITHOUT forming a dense operand, so that they can be had at any size
+    in O(nnz) time and memory — the checker of the full-size GPU tests.  Under dummy_fill (distributed_sparse.h:338-342)
+    A[i,k] = iR + k and B[j,k] = jR + k, hence with S1 = sum_k k, S2 = sum_k k^2 over k < R:
+        sddmm(i,j)  = sum_k (iR + k)(jR + k)        = R^3 ij + R S1 (i + j) + S2
+        spmmA[i,k]  = sum_{j in row i} (jR + k)      = R sj(i) + deg(i) k,     sj(i) = sum of the row's column indices
+        sum_k spmmA[i,k]^2                           = R (R sj)^2 + 2 (R sj) deg S1 + deg^2 S2      (spmmB: rows <-> columns)
+    Pinned against `fingerprints` above and the reference's own numbers in tests/test_oracle_golden.py."""
+    big_r = float(r)
+    s1 = r * (r - 1) / 2.0
+    s2 = (r - 1) * r * (2 * r - 1) / 6.0
+    f1 = 0.0
+    for s in range(0, len(rows), chunk):
+        i = rows[s:s + chunk].astype(np.float64)
+        j = cols[s:s + chunk].astype(np.float64)
+        v = big_r ** 3 * i * j + big_r * s1 * (i + j) + s2
+        f1 += float(np.sum(v * v))
+
+    def dense_side(own, other, count):
+        deg = np.bincount(own, minlength=count).astype(np.float64)
+        so = big_r * np.bincount(own, weights=other.astype(np.float64), minlength=count)
+        return float(np.sum(big_r * so * so + 2.0 * so * deg * s1 + deg * deg * s2))
+
+    return f1, dense_side(rows, cols, m), dense_side(cols, rows, n)
+
+
 # ------------------------------------------------------------------ GAT forward (gat.hpp:83-112)
 
 def gat_weight(layer: int, head: int, k: int, n: int, seed: int = 31) -> np.ndarray:

@@ -44,6 +44,8 @@ def test_numpy_oracle_matches_reference(name):
     fb2, _ = O.fused_b(rows, cols, vals, a, b, ignore_svalues=True)
     assert T.rel(fa2, g["fusedA_fusion2"]) <= T.TOL and T.rel(fb2, g["fusedB_fusion2"]) <= T.TOL
     assert T.rel(np.array(O.fingerprints(rows, cols, c["M"], c["N"], c["R"])), g["fingerprints"]) <= T.TOL
+    # the O(nnz) closed form used at full size is pinned to the same reference numbers (chunked path included)
+    assert T.rel(np.array(O.fingerprints_closed_form(rows, cols, c["M"], c["N"], c["R"], chunk=97)), g["fingerprints"]) <= T.TOL
 
 
 @pytest.mark.parametrize("name", CASES)

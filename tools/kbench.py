@@ -15,7 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--logm", type=int, default=20)
     ap.add_argument("--ef", type=int, default=96)
-    ap.add_argument("--r", type=int, default=128)
+    ap.add_argument("--r", default="128", help="embedding width, or a comma list to sweep")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--ops", default="fused,sddmm,spmm")
     ap.add_argument("--rmat", action="store_true", help="skewed R-MAT graph instead of Erdos-Renyi")
@@ -33,72 +33,73 @@ def main():
         rows_i, cols_i = H.generate_er(1 << a.logm, 1 << a.logm, (1 << a.logm) * a.ef)
     m = 1 << a.logm
     nnz = len(rows_i)
-    rowptr = np.zeros(m + 1, np.int64)
-    np.add.at(rowptr, rows_i + 1, 1)
-    rowptr = np.cumsum(rowptr).astype(np.int32)
+    rowptr = np.concatenate(([0], np.cumsum(np.bincount(rows_i, minlength=m)))).astype(np.int32)
     print("generated nnz=%d in %.1fs" % (nnz, time.time() - t0), flush=True)
     ctx = K.Ctx(0)
     lib = ctx.lib
-    R = a.r
     d_rowptr, d_c = ctx.upload(rowptr), ctx.upload(cols_i.astype(np.int32))
     del rows_i, cols_i
-    dv = K.DevArray(ctx, (nnz,), np.float64)
-    dA, dB, dOut = (K.DevArray(ctx, (m, R), np.float64) for _ in range(3))
-    lib.hnh_fill_f64(ctx.h, dA.ptr, m * R, 0.001, 0)
-    lib.hnh_fill_f64(ctx.h, dB.ptr, m * R, 0.001, 0)
-    lib.hnh_fill_f64(ctx.h, dv.ptr, nnz, 0.0, 0)
-    ev0, ev1 = C.c_void_p(), C.c_void_p()
-    lib.hnh_event_create(ctx.h, C.byref(ev0)); lib.hnh_event_create(ctx.h, C.byref(ev1))
+    for R in [int(x) for x in str(a.r).split(",")]:
+        dv = K.DevArray(ctx, (nnz,), np.float64)
+        dA, dB, dOut = (K.DevArray(ctx, (m, R), np.float64) for _ in range(3))
+        lib.hnh_fill_f64(ctx.h, dA.ptr, m * R, 0.001, 0)
+        lib.hnh_fill_f64(ctx.h, dB.ptr, m * R, 0.001, 0)
+        lib.hnh_fill_f64(ctx.h, dv.ptr, nnz, 0.0, 0)
+        ev0, ev1 = C.c_void_p(), C.c_void_p()
+        lib.hnh_event_create(ctx.h, C.byref(ev0)); lib.hnh_event_create(ctx.h, C.byref(ev1))
 
-    def timed(fn, name, bytes_alg):
-        fn(); ctx.sync()
-        ts = []
-        for _ in range(a.iters):
-            lib.hnh_event_record(ctx.h, ev0, 0)
-            fn()
-            lib.hnh_event_record(ctx.h, ev1, 0)
-            lib.hnh_event_sync(ctx.h, ev1)
-            ms = C.c_float()
-            lib.hnh_event_elapsed_ms(ctx.h, ev0, ev1, C.byref(ms))
-            ts.append(ms.value)
-        t = float(np.median(ts)) * 1e-3
-        print("%-6s R=%d  %.3f ms  %.3e nnz*R/s  alg %.2f GB -> %.2f TB/s (%.1f%% of 8 TB/s)" % (
-            name, R, t * 1e3, nnz * R / t, bytes_alg / 1e9, bytes_alg / t / 1e12, 100 * bytes_alg / t / 8e12), flush=True)
+        def timed(fn, name, bytes_alg):
+            fn(); ctx.sync()
+            ts = []
+            for _ in range(a.iters):
+                lib.hnh_event_record(ctx.h, ev0, 0)
+                fn()
+                lib.hnh_event_record(ctx.h, ev1, 0)
+                lib.hnh_event_sync(ctx.h, ev1)
+                ms = C.c_float()
+                lib.hnh_event_elapsed_ms(ctx.h, ev0, ev1, C.byref(ms))
+                ts.append(ms.value)
+            t = float(np.median(ts)) * 1e-3
+            print("%-6s R=%d  %.3f ms  %.3e nnz*R/s  alg %.2f GB -> %.2f TB/s (%.1f%% of 8 TB/s)" % (
+                name, R, t * 1e3, nnz * R / t, bytes_alg / 1e9, bytes_alg / t / 1e12, 100 * bytes_alg / t / 8e12), flush=True)
 
-    ops = a.ops.split(",")
-    if a.panels:
-        mx = C.c_int()
-        ctx.check(lib.hnh_csr_max_row_nnz(ctx.h, m, d_rowptr.ptr, C.byref(mx), 0), "max_row")
-        timed(lambda: ctx.check(lib.hnh_fused_sddmm_spmm_csr_ex(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, None, dA.ptr, dB.ptr, dOut.ptr, R, 3,
-                                                                nnz, mx.value, m, 0), "fused"), "fusedP", nnz * (8 * R + 24) + 16 * R * m)
-        timed(lambda: ctx.check(lib.hnh_sddmm_csr_ex(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, dA.ptr, dB.ptr, R, nnz, mx.value, m, 0), "sddmm"),
-              "sddmmP", nnz * (8 * R + 20) + 8 * R * m)
-        timed(lambda: ctx.check(lib.hnh_spmm_csr_ex(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, dB.ptr, dOut.ptr, R, nnz, mx.value, m, 0), "spmm"),
-              "spmmP", nnz * (8 * R + 12) + 16 * R * m)
-    if "fused" in ops:
-        timed(lambda: ctx.check(lib.hnh_fused_sddmm_spmm_csr(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, None, dA.ptr, dB.ptr,
-                                                             dOut.ptr, R, 3, 0), "fused"), "fused", nnz * (8 * R + 24) + 16 * R * m)
-    if "sddmm" in ops:
-        timed(lambda: ctx.check(lib.hnh_sddmm_csr(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, dA.ptr, dB.ptr, R, 0), "sddmm"),
-              "sddmm", nnz * (8 * R + 20) + 8 * R * m)
-    if "coo" in ops:
-        d_r = K.DevArray(ctx, (nnz,), np.int32)
-        ctx.check(lib.hnh_expand_rowptr(ctx.h, m, d_rowptr.ptr, d_r.ptr, 0), "expand")
-        timed(lambda: ctx.check(lib.hnh_sddmm_coo(ctx.h, nnz, d_r.ptr, d_c.ptr, dv.ptr, dA.ptr, dB.ptr, R, 0), "coo"),
-              "coo", nnz * (16 * R + 24))
-    if "ew" in ops:
-        n = m * R
-        timed(lambda: ctx.check(lib.hnh_fill_f64(ctx.h, dOut.ptr, n, 1.5, 0), "fill"), "fill", 8 * n)
-        timed(lambda: ctx.check(lib.hnh_hadamard_f64(ctx.h, dOut.ptr, dA.ptr, dB.ptr, n, 0), "hadamard"), "hadam", 24 * n)
-        timed(lambda: ctx.check(lib.hnh_axpy_f64(ctx.h, dOut.ptr, dA.ptr, 0.5, n, 0), "axpy"), "axpy", 24 * n)
-        dvec = K.DevArray(ctx, (m,), np.float64)
-        timed(lambda: ctx.check(lib.hnh_rowdot_f64(ctx.h, dA.ptr, dB.ptr, dvec.ptr, m, R, 0), "rowdot"), "rowdot", 16 * n)
-        timed(lambda: ctx.check(lib.hnh_row_scale_add_f64(ctx.h, dOut.ptr, None, 1.0, dA.ptr, dvec.ptr, -1.0, m, R, 0), "rsa"), "rsadd", 24 * n)
-        timed(lambda: ctx.check(lib.hnh_memcpy(ctx.h, dOut.ptr, dA.ptr, 8 * n, K.D2D, 0), "copy"), "d2dcp", 16 * n)
-        timed(lambda: ctx.check(lib.hnh_memset(ctx.h, dOut.ptr, 0, 8 * n, 0), "memset"), "mset", 8 * n)
-    if "spmm" in ops:
-        timed(lambda: ctx.check(lib.hnh_spmm_csr(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, dB.ptr, dOut.ptr, R, 0), "spmm"),
-              "spmm", nnz * (8 * R + 12) + 16 * R * m)
+        ops = a.ops.split(",")
+        if a.panels:
+            mx = C.c_int()
+            ctx.check(lib.hnh_csr_max_row_nnz(ctx.h, m, d_rowptr.ptr, C.byref(mx), 0), "max_row")
+            timed(lambda: ctx.check(lib.hnh_fused_sddmm_spmm_csr_ex(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, None, dA.ptr, dB.ptr, dOut.ptr, R, 3,
+                                                                    nnz, mx.value, m, 0), "fused"), "fusedP", nnz * (8 * R + 24) + 16 * R * m)
+            timed(lambda: ctx.check(lib.hnh_sddmm_csr_ex(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, dA.ptr, dB.ptr, R, nnz, mx.value, m, 0), "sddmm"),
+                  "sddmmP", nnz * (8 * R + 20) + 8 * R * m)
+            timed(lambda: ctx.check(lib.hnh_spmm_csr_ex(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, dB.ptr, dOut.ptr, R, nnz, mx.value, m, 0), "spmm"),
+                  "spmmP", nnz * (8 * R + 12) + 16 * R * m)
+        if "fused" in ops:
+            timed(lambda: ctx.check(lib.hnh_fused_sddmm_spmm_csr(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, None, dA.ptr, dB.ptr,
+                                                                 dOut.ptr, R, 3, 0), "fused"), "fused", nnz * (8 * R + 24) + 16 * R * m)
+        if "sddmm" in ops:
+            timed(lambda: ctx.check(lib.hnh_sddmm_csr(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, dA.ptr, dB.ptr, R, 0), "sddmm"),
+                  "sddmm", nnz * (8 * R + 20) + 8 * R * m)
+        if "coo" in ops:
+            d_r = K.DevArray(ctx, (nnz,), np.int32)
+            ctx.check(lib.hnh_expand_rowptr(ctx.h, m, d_rowptr.ptr, d_r.ptr, 0), "expand")
+            timed(lambda: ctx.check(lib.hnh_sddmm_coo(ctx.h, nnz, d_r.ptr, d_c.ptr, dv.ptr, dA.ptr, dB.ptr, R, 0), "coo"),
+                  "coo", nnz * (16 * R + 24))
+        if "ew" in ops:
+            n = m * R
+            timed(lambda: ctx.check(lib.hnh_fill_f64(ctx.h, dOut.ptr, n, 1.5, 0), "fill"), "fill", 8 * n)
+            timed(lambda: ctx.check(lib.hnh_hadamard_f64(ctx.h, dOut.ptr, dA.ptr, dB.ptr, n, 0), "hadamard"), "hadam", 24 * n)
+            timed(lambda: ctx.check(lib.hnh_axpy_f64(ctx.h, dOut.ptr, dA.ptr, 0.5, n, 0), "axpy"), "axpy", 24 * n)
+            dvec = K.DevArray(ctx, (m,), np.float64)
+            timed(lambda: ctx.check(lib.hnh_rowdot_f64(ctx.h, dA.ptr, dB.ptr, dvec.ptr, m, R, 0), "rowdot"), "rowdot", 16 * n)
+            timed(lambda: ctx.check(lib.hnh_row_scale_add_f64(ctx.h, dOut.ptr, None, 1.0, dA.ptr, dvec.ptr, -1.0, m, R, 0), "rsa"), "rsadd", 24 * n)
+            timed(lambda: ctx.check(lib.hnh_memcpy(ctx.h, dOut.ptr, dA.ptr, 8 * n, K.D2D, 0), "copy"), "d2dcp", 16 * n)
+            timed(lambda: ctx.check(lib.hnh_memset(ctx.h, dOut.ptr, 0, 8 * n, 0), "memset"), "mset", 8 * n)
+        if "spmm" in ops:
+            timed(lambda: ctx.check(lib.hnh_spmm_csr(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, dB.ptr, dOut.ptr, R, 0), "spmm"),
+                  "spmm", nnz * (8 * R + 12) + 16 * R * m)
+
+        for d in (dv, dA, dB, dOut):
+            d.free()
 
 
 if __name__ == "__main__":
