@@ -115,17 +115,17 @@ public:
 
     // Cannon skew of the moving dense operand along its grid column (:169-190) ...
     void initial_shift(DenseMatrix* localA, DenseMatrix* localB, KernelMode mode) override {
-        auto t = start_clock();
+        auto t = phase_begin("Setup Shift Time");
         DenseMatrix* m = (mode == k_sddmmA || mode == k_spmmA) ? localA : localB;
         if (m != nullptr) skew(m, -grid->rankInRow);
-        stop_clock_and_add(t, "Setup Shift Time");
+        phase_end(t);
     }
     // ... and its inverse (:192-211)
     void de_shift(DenseMatrix* localA, DenseMatrix* localB, KernelMode mode) override {
-        auto t = start_clock();
+        auto t = phase_begin("Setup Shift Time");
         DenseMatrix* m = (mode == k_sddmmA || mode == k_spmmA) ? localA : localB;
         if (m != nullptr) skew(m, +grid->rankInRow);
-        stop_clock_and_add(t, "Setup Shift Time");
+        phase_end(t);
     }
 
     VectorXd like_S_values(double value) override { return VectorXd::Constant((int64_t)ST->blockStarts[1], value); }
@@ -145,18 +145,18 @@ public:
         const bool is_sddmm = (mode == k_sddmmA || mode == k_sddmmB);
 
         {
-            auto t = start_clock();
+            auto t = phase_begin("Computation Time");
             if (is_sddmm) choice->setValuesConstant(0.0);
             else choice->setCSRValues(SValues);
-            stop_clock_and_add(t, "Computation Time");
+            phase_end(t);
         }
         if (initial_replicate && c > 1) {
-            auto t = start_clock();
+            auto t = phase_begin("Dense Fiber Communication Time");
             if (accumulation_buffer.rows() != Arole->rows() * c || accumulation_buffer.cols() != Arole->cols())
                 accumulation_buffer = DenseMatrix(Arole->rows() * c, Arole->cols());
             world->allgather(grid->fiber_world, Arole->data(), accumulation_buffer.data(), (size_t)Arole->size() * sizeof(double),
                              HNH_STREAM_COMPUTE);
-            stop_clock_and_add(t, "Dense Fiber Communication Time");
+            phase_end(t);
         }
         DenseMatrix& stationary = (c > 1) ? accumulation_buffer : *Arole;
         CSRLocal* blk = choice->csr_blocks[0];
@@ -178,12 +178,12 @@ public:
             const size_t bytes = (size_t)Brole->size() * sizeof(double);
             DenseMatrix* cur = Brole;
             for (int i = 0; i < s; i++) {
-                auto t = start_clock();
+                auto t = phase_begin("Computation Time");
                 if (i > 0) world->event_wait(event(1 + (i - 1) % 2), HNH_STREAM_COMPUTE);  // both shifts of step i-1 landed
                 kernel->triple_function(kmode, *choice, stationary, *cur, 0, localAcols * grid->j);
-                stop_clock_and_add(t, "Computation Time");
+                phase_end(t);
                 if (s > 1) {
-                    t = start_clock();
+                    t = phase_begin("Dense Cyclic Shift Time");
                     world->event_record(event(3 + i % 2), HNH_STREAM_COMPUTE);
                     if (i < s - 1) {
                         DenseMatrix* target = &dense_spare[i % 2];
@@ -191,46 +191,46 @@ public:
                         world->sendrecv(grid->col_world, cur->data(), bytes, ddst, target->data(), bytes, dsrc, HNH_STREAM_COMM);
                         cur = target;
                     }
-                    stop_clock_and_add(t, "Dense Cyclic Shift Time");
-                    t = start_clock();
+                    phase_end(t);
+                    t = phase_begin("Sparse Cyclic Shift Time");
                     world->event_wait(event(3 + i % 2), HNH_STREAM_COMM);  // kernel i wrote the travelling values
                     blk->shiftCSR(ssrc, sdst, grid->row_world, (*nnz_in_axis)[pMod(sparse_shift - i - 1, s)], 72, coo, HNH_STREAM_COMM,
                                   pMod(sparse_shift - i - 1, s));
                     choice->blockStarts[1] = blk->num_coords;
                     world->event_record(event(1 + i % 2), HNH_STREAM_COMM);
-                    stop_clock_and_add(t, "Sparse Cyclic Shift Time");
+                    phase_end(t);
                 }
             }
             if (s > 1) world->event_wait(event(1 + (s - 1) % 2), HNH_STREAM_COMPUTE);  // the sparse block is home again
         } else {
             hnh::BufferPair bBuf(Brole, &ring_spare);
             for (int i = 0; i < s; i++) {
-                auto t = start_clock();
+                auto t = phase_begin("Computation Time");
                 if (i > 0) world->event_wait(event(1 + (i - 1) % 2), HNH_STREAM_COMPUTE);
                 kernel->triple_function(kmode, *choice, stationary, *bBuf.getActive(), 0, localAcols * grid->j);
-                stop_clock_and_add(t, "Computation Time");
+                phase_end(t);
                 if (s > 1) {
-                    t = start_clock();
+                    t = phase_begin("Sparse Cyclic Shift Time");
                     world->event_record(event(3 + i % 2), HNH_STREAM_COMPUTE);
                     if (i >= 1) world->event_wait(event(3 + (i - 1) % 2), HNH_STREAM_COMM);  // kernel i-1 released the passive sparse buffer
                     blk->shiftCSR(ssrc, sdst, grid->row_world, (*nnz_in_axis)[pMod(sparse_shift - i - 1, s)], 72, csr, HNH_STREAM_COMM,
                                   pMod(sparse_shift - i - 1, s));
                     choice->blockStarts[1] = blk->num_coords;
-                    stop_clock_and_add(t, "Sparse Cyclic Shift Time");
-                    t = start_clock();
+                    phase_end(t);
+                    t = phase_begin("Dense Cyclic Shift Time");
                     world->event_wait(event(3 + i % 2), HNH_STREAM_COMM);  // kernel i wrote the moving dense operand
                     shiftDenseMatrix(bBuf, grid->col_world, ddst, dsrc, HNH_STREAM_COMM);
                     world->event_record(event(1 + i % 2), HNH_STREAM_COMM);
-                    stop_clock_and_add(t, "Dense Cyclic Shift Time");
+                    phase_end(t);
                 }
             }
             if (s > 1) world->event_wait(event(1 + (s - 1) % 2), HNH_STREAM_COMPUTE);
             bBuf.sync_active();
         }
 
-        auto t = start_clock();
+        auto t = phase_begin("Computation Time");
         if (is_sddmm) choice->hadamardWithCSRValues(SValues, *sddmm_result_ptr);
-        stop_clock_and_add(t, "Computation Time");
+        phase_end(t);
     }
 
 private:

@@ -97,7 +97,7 @@ public:
 
     // exchange with the grid-transposed rank (j, i, k); self-inverse (:157-186)
     void initial_shift(DenseMatrix* localA, DenseMatrix* localB, KernelMode mode) override {
-        auto t = start_clock();
+        auto t = phase_begin("Setup Shift Time");
         DenseMatrix* m = (mode == k_sddmmA || mode == k_spmmA) ? localB : localA;
         if (m != nullptr && sqrtpc > 1) {
             const int partner = grid->get_global_rank(grid->j, grid->i, grid->k);
@@ -106,7 +106,7 @@ public:
             shiftDenseMatrix(buf, wc, partner, partner, HNH_STREAM_COMPUTE);
             buf.sync_active();
         }
-        stop_clock_and_add(t, "Setup Shift Time");
+        phase_end(t);
     }
     void de_shift(DenseMatrix* localA, DenseMatrix* localB, KernelMode mode) override { initial_shift(localA, localB, mode); }
 
@@ -128,20 +128,20 @@ public:
 
         if (!is_sddmm) {
             if (c > 1) {
-                auto t = start_clock();
+                auto t = phase_begin("Sparse Fiber Communication Time");
                 world->allgatherv_f64(grid->fiber_world, SValues.data(), (size_t)SValues.size(), value_buffer.data(),
                                       choice->layer_coords_sizes, choice->layer_coords_start, HNH_STREAM_COMPUTE);
                 choice->setCSRValues(value_buffer);
-                stop_clock_and_add(t, "Sparse Fiber Communication Time");
+                phase_end(t);
             } else {
-                auto t = start_clock();
+                auto t = phase_begin("Computation Time");
                 choice->setCSRValues(SValues);
-                stop_clock_and_add(t, "Computation Time");
+                phase_end(t);
             }
         } else {
-            auto t = start_clock();
+            auto t = phase_begin("Computation Time");
             choice->setValuesConstant(0.0);
-            stop_clock_and_add(t, "Computation Time");
+            phase_end(t);
         }
 
         const KernelMode temp = (mode == k_sddmmB) ? k_sddmmA : (mode == k_spmmB ? k_spmmA : mode);
@@ -161,12 +161,12 @@ public:
             DenseMatrix *curA = Arole, *curB = Brole;
             const size_t abytes = (size_t)Arole->size() * sizeof(double), bbytes = (size_t)Brole->size() * sizeof(double);
             for (int i = 0; i < s; i++) {
-                auto t = start_clock();
+                auto t = phase_begin("Computation Time");
                 if (i > 0) world->event_wait(event(1 + (i - 1) % 2), HNH_STREAM_COMPUTE);
                 kernel->triple_function(temp, *choice, *curA, *curB, 0, pMod(grid->i + grid->j + i, s) * localAcols);
-                stop_clock_and_add(t, "Computation Time");
+                phase_end(t);
                 if (i < s - 1) {
-                    t = start_clock();
+                    t = phase_begin("Dense Cyclic Shift Time");
                     world->event_record(event(3 + i % 2), HNH_STREAM_COMPUTE);
                     if (i >= 2) world->event_wait(event(3 + (i - 1) % 2), HNH_STREAM_COMM);
                     DenseMatrix *ta = &spareA[i % 2], *tb = &spareB[i % 2];
@@ -177,7 +177,7 @@ public:
                     world->event_record(event(1 + i % 2), HNH_STREAM_COMM);
                     curA = ta;
                     curB = tb;
-                    stop_clock_and_add(t, "Dense Cyclic Shift Time");
+                    phase_end(t);
                 }
             }
         } else {
@@ -192,12 +192,12 @@ public:
             DenseMatrix* curB = Brole;
             const size_t bbytes = (size_t)Brole->size() * sizeof(double);
             for (int i = 0; i < s; i++) {
-                auto t = start_clock();
+                auto t = phase_begin("Computation Time");
                 if (i > 0) world->event_wait(event(1 + (i - 1) % 2), HNH_STREAM_COMPUTE);  // both shifts of step i-1 landed
                 kernel->triple_function(temp, *choice, *aBuf.getActive(), *curB, 0, pMod(grid->i + grid->j + i, s) * localAcols);
-                stop_clock_and_add(t, "Computation Time");
+                phase_end(t);
                 if (s > 1) {
-                    t = start_clock();
+                    t = phase_begin("Dense Cyclic Shift Time");
                     world->event_record(event(3 + i % 2), HNH_STREAM_COMPUTE);
                     if (i < s - 1) {
                         DenseMatrix* tb = &spareB[i % 2];
@@ -208,34 +208,34 @@ public:
                     world->event_wait(event(3 + i % 2), HNH_STREAM_COMM);  // kernel i wrote the moving accumulator
                     shiftDenseMatrix(aBuf, grid->row_world, rdst, rsrc, HNH_STREAM_COMM);
                     world->event_record(event(1 + i % 2), HNH_STREAM_COMM);
-                    stop_clock_and_add(t, "Dense Cyclic Shift Time");
+                    phase_end(t);
                 }
             }
             if (s > 1) world->event_wait(event(1 + (s - 1) % 2), HNH_STREAM_COMPUTE);
-            auto t = start_clock();
+            auto t = phase_begin("Computation Time");
             aBuf.sync_active();
-            stop_clock_and_add(t, "Computation Time");
+            phase_end(t);
         }
 
         if (is_sddmm) {
             if (c > 1) {
-                auto t = start_clock();
+                auto t = phase_begin("Sparse Fiber Communication Time");
                 CSRLocal* blk = choice->csr_blocks[0];
                 // partial dot products of all nonzeros -> this layer's shard, summed over the fiber
                 if (blk != nullptr)
                     world->reduce_scatter_v_f64(grid->fiber_world, blk->getActive()->values, sddmm_result_ptr->data(),
                                                 choice->layer_coords_sizes, HNH_STREAM_COMPUTE);
-                stop_clock_and_add(t, "Sparse Fiber Communication Time");
-                t = start_clock();
+                phase_end(t);
+                t = phase_begin("Computation Time");
                 if (SValues.size())
                     world->check(world->be->hnh_hadamard_f64(world->ctx, sddmm_result_ptr->data(), SValues.data(),
                                                              sddmm_result_ptr->data(), SValues.size(), HNH_STREAM_COMPUTE),
                                  "hnh_hadamard_f64");
-                stop_clock_and_add(t, "Computation Time");
+                phase_end(t);
             } else {
-                auto t = start_clock();
+                auto t = phase_begin("Computation Time");
                 choice->hadamardWithCSRValues(SValues, *sddmm_result_ptr);
-                stop_clock_and_add(t, "Computation Time");
+                phase_end(t);
             }
         }
     }

@@ -196,12 +196,12 @@ private:
         if (accum == &accumulation_buffer) ensure(accumulation_buffer, Arole->rows() * c, R);
         DenseMatrix* rowOperand = Arole;
         if (c > 1) {
-            auto t = start_clock();
+            auto t = phase_begin("Replication Time");
             ensure(broadcast_buffer, Arole->rows() * c, R);
             world->allgather(grid->row_world, Arole->data(), broadcast_buffer.data(), (size_t)Arole->size() * sizeof(double),
                              HNH_STREAM_COMPUTE);
             rowOperand = &broadcast_buffer;
-            stop_clock_and_add(t, "Replication Time");
+            phase_end(t);
         }
 
         const unsigned base = HNH_FUSED_VALUES_OVERWRITE | act_flag;
@@ -231,7 +231,7 @@ private:
             // the remote blocks arrive chunk by chunk over all links at once: local block while chunk 0 flies, then
             // chunk q of ALL remote blocks in one launch while chunk q+1 is still on the links
             std::vector<DenseMatrix*> fetched = mesh_fetch_chunked(Brole, n, cw);
-            auto t = start_clock();
+            auto t = phase_begin("Computation Time");
             launch({{0, Brole}}, 0, chunks, act);
             std::vector<std::pair<int, DenseMatrix*>> remote;
             for (int i = 1; i < n; i++) remote.push_back({i, fetched[i - 1]});
@@ -239,10 +239,10 @@ private:
                 world->event_wait(event(8 + q), HNH_STREAM_COMPUTE);  // chunk q of every remote block has landed
                 launch(remote, q, q + 1, q == chunks - 1 ? last : act);
             }
-            stop_clock_and_add(t, "Computation Time");
+            phase_end(t);
         } else {
             ring_readonly(Brole, n, [&](int i, DenseMatrix& cur) {
-                auto t = start_clock();
+                auto t = phase_begin("Computation Time");
                 const hnh_fused_extras* ex = (i == n - 1) ? last : act;
                 if (chunks == 1 || n == 1) {
                     // the plain row kernel, one launch per block — or, on a ring of one, per column chunk: the panel of
@@ -258,24 +258,24 @@ private:
                 } else {
                     launch({{i, &cur}}, 0, chunks, ex);
                 }
-                stop_clock_and_add(t, "Computation Time");
+                phase_end(t);
             });
         }
         if (out_fresh) accum->setZero();  // no block on this rank had a nonzero
 
         if (c > 1) {
-            auto t = start_clock();
+            auto t = phase_begin("Replication Time");
             DenseMatrix* dest = target ? target : Arole;
             world->reduce_scatter_f64(grid->row_world, accumulation_buffer.data(), dest->data(), (size_t)Arole->rows() * R, HNH_STREAM_COMPUTE);
-            stop_clock_and_add(t, "Replication Time");
-            t = start_clock();
+            phase_end(t);
+            t = phase_begin("Computation Time");
             if (epilogue) KernelImplementation::row_epilogue(world, *Arole, *dest, extras);
-            stop_clock_and_add(t, "Computation Time");
+            phase_end(t);
         } else if (target == nullptr) {
-            auto t = start_clock();
+            auto t = phase_begin("Computation Time");
             if (Arole->owns_storage()) Arole->swap(accumulation_buffer);  // `*Arole = accumulation_buffer` without the copy
             else *Arole = accumulation_buffer;
-            stop_clock_and_add(t, "Computation Time");
+            phase_end(t);
         }
     }
 
@@ -299,18 +299,18 @@ public:
         const int n = p / c;
 
         if (initial_replicate && c > 1) {
-            auto t = start_clock();
+            auto t = phase_begin("Replication Time");
             ensure(accumulation_buffer, Arole->rows() * c, R);
             world->allgather(grid->row_world, Arole->data(), accumulation_buffer.data(), (size_t)Arole->size() * sizeof(double),
                              HNH_STREAM_COMPUTE);
-            stop_clock_and_add(t, "Replication Time");
+            phase_end(t);
         }
 
         {
-            auto t = start_clock();
+            auto t = phase_begin("Computation Time");
             if (is_sddmm) choice->setValuesConstant(0.0);
             else choice->setCSRValues(SValues);
-            stop_clock_and_add(t, "Computation Time");
+            phase_end(t);
         }
 
         KernelMode mode_temp = mode;
@@ -320,7 +320,7 @@ public:
 
         const int cw = (choice == S.get()) ? chunkB : chunkA;
         auto step = [&](int i, DenseMatrix& cur) {
-            auto t = start_clock();
+            auto t = phase_begin("Computation Time");
             if (chunks == 1) {
                 kernel->triple_function(mode_temp, *choice, stationary, cur, block_at(i), 0);
             } else {  // approach 2 keeps S in column chunks of each block: same kernels on each chunk's rows of `cur`
@@ -329,7 +329,7 @@ public:
                     kernel->triple_function(mode_temp, *choice, stationary, part, block_at(i) * chunks + q, 0);
                 }
             }
-            stop_clock_and_add(t, "Computation Time");
+            phase_end(t);
         };
 
         // the moving operand is written only when it is the SpMM accumulator (approach 1)
@@ -339,7 +339,7 @@ public:
             // remote block while chunk q+1 is still on the links (same kernels on the same sub-blocks; only the order of
             // the steps differs from the reference's block-by-block walk)
             std::vector<DenseMatrix*> fetched = mesh_fetch_chunked(Brole, n, cw);
-            auto t = start_clock();
+            auto t = phase_begin("Computation Time");
             auto one = [&](int i, DenseMatrix& blk, int q) {
                 DenseMatrix part = chunk_view(blk, q, cw);
                 kernel->triple_function(mode_temp, *choice, stationary, part, block_at(i) * chunks + q, 0);
@@ -349,7 +349,7 @@ public:
                 world->event_wait(event(8 + q), HNH_STREAM_COMPUTE);  // chunk q of every remote block has landed
                 for (int i = 1; i < n; i++) one(i, *fetched[i - 1], q);
             }
-            stop_clock_and_add(t, "Computation Time");
+            phase_end(t);
         } else if (moving_readonly) {
             ring_readonly(Brole, n, step);
         } else {
@@ -357,16 +357,16 @@ public:
         }
 
         if (is_sddmm) {
-            auto t = start_clock();
+            auto t = phase_begin("Computation Time");
             choice->hadamardWithCSRValues(SValues, *sddmm_result_ptr);  // result = SValues .* block values
-            stop_clock_and_add(t, "Computation Time");
+            phase_end(t);
         }
 
         if (fusionApproach == 2 && !is_sddmm && c > 1) {
-            auto t = start_clock();
+            auto t = phase_begin("Replication Time");
             world->reduce_scatter_f64(grid->row_world, accumulation_buffer.data(), Arole->data(), (size_t)Arole->rows() * R,
                                       HNH_STREAM_COMPUTE);
-            stop_clock_and_add(t, "Replication Time");
+            phase_end(t);
         }
     }
 
@@ -394,7 +394,7 @@ private:
             if (i > 0) world->event_wait(event(1 + (i - 1) % 2), HNH_STREAM_COMPUTE);  // shift i-1 landed
             step(i, *cur);
             if (i < n - 1) {
-                auto t = start_clock();
+                auto t = phase_begin("Cyclic Shift Time");
                 world->event_record(event(3 + i % 2), HNH_STREAM_COMPUTE);                 // kernel i enqueued
                 DenseMatrix* target = &ring_spare[i % 2];
                 if (i >= 2) world->event_wait(event(3 + (i - 1) % 2), HNH_STREAM_COMM);    // kernel i-1 last read `target`
@@ -404,7 +404,7 @@ private:
                 if (held) held_in_ring = true;
                 world->event_record(event(1 + i % 2), HNH_STREAM_COMM);
                 cur = target;
-                stop_clock_and_add(t, "Cyclic Shift Time");
+                phase_end(t);
             }
         }
     }
@@ -421,7 +421,7 @@ private:
     std::vector<DenseMatrix*> mesh_fetch_chunked(DenseMatrix* start, int n, int cw) {
         if ((int)mesh_spare.size() < n - 1) mesh_spare.resize(n - 1);
         for (int k = 0; k < n - 1; k++) ensure(mesh_spare[k], start->rows(), start->cols());
-        auto t = start_clock();
+        auto t = phase_begin("Cyclic Shift Time");
         order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // my block is final; earlier readers of the landing buffers are done
         const bool held = (held_ptr == start->data());
         if (!held) held_in_mesh = false;  // another operand lands in the buffers: a held one has to be fetched again
@@ -438,7 +438,7 @@ private:
             world->event_record(event(8 + q), HNH_STREAM_COMM);
         }
         if (held) held_in_mesh = true;
-        stop_clock_and_add(t, "Cyclic Shift Time");
+        phase_end(t);
         std::vector<DenseMatrix*> out;
         for (int k = 0; k < n - 1; k++) out.push_back(&mesh_spare[k]);
         return out;
@@ -450,7 +450,7 @@ private:
         if ((int)mesh_spare.size() < n - 1) mesh_spare.resize(n - 1);
         for (int k = 0; k < n - 1; k++) ensure(mesh_spare[k], start->rows(), start->cols());
         const size_t bytes = (size_t)start->size() * sizeof(double);
-        auto t = start_clock();
+        auto t = phase_begin("Cyclic Shift Time");
         order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // my block is final; earlier readers of the landing buffers are done
         const bool held = (held_ptr == start->data());
         if (!held) held_in_mesh = false;  // another operand lands in the buffers: a held one has to be fetched again
@@ -463,7 +463,7 @@ private:
         }
         if (held) held_in_mesh = true;
         world->event_record(event(1), HNH_STREAM_COMM);
-        stop_clock_and_add(t, "Cyclic Shift Time");
+        phase_end(t);
         std::vector<DenseMatrix*> out;
         for (int k = 0; k < n - 1; k++) out.push_back(&mesh_spare[k]);
         return out;
@@ -489,15 +489,15 @@ private:
         for (int i = 0; i < n; i++) {
             step(i, *bBuf.getActive());
             if (n > 1) {
-                auto t = start_clock();
+                auto t = phase_begin("Cyclic Shift Time");
                 order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);
                 shiftDenseMatrix(bBuf, grid->col_world, dst, src, HNH_STREAM_COMM);
                 order(HNH_STREAM_COMM, HNH_STREAM_COMPUTE, 5);
-                stop_clock_and_add(t, "Cyclic Shift Time");
+                phase_end(t);
             }
         }
-        auto t = start_clock();
+        auto t = phase_begin("Computation Time");
         bBuf.sync_active();
-        stop_clock_and_add(t, "Computation Time");
+        phase_end(t);
     }
 };

@@ -86,8 +86,13 @@ public:
 
     virtual ~Distributed_Sparse() {
         if (world) {
-            world->sync_all();
-            for (void* e : events_) world->event_destroy(e);
+            world->sync_all_nothrow();  // a destructor must not throw (the C ABI runs with throw-on-error)
+            for (void* e : events_) world->be->hnh_event_destroy(world->ctx, e);
+            for (void* e : spare_events_) world->be->hnh_event_destroy(world->ctx, e);
+            for (auto& sp : spans_) {
+                world->be->hnh_event_destroy(world->ctx, sp.e0);
+                world->be->hnh_event_destroy(world->ctx, sp.e1);
+            }
         }
     }
 
@@ -132,15 +137,14 @@ public:
     DenseMatrix like_B_matrix(double value) { return DenseMatrix::Constant(localBrows, localBcols, value); }
 
     void reset_performance_timers() {
+        resolve_spans(spans_.size());
         for (auto& key : perf_counter_keys) {
             call_count[key] = 0;
             total_time[key] = 0.0;
         }
     }
 
-    // Wall-clock counters like the reference's.  GPU work is asynchronous: with world->timing_sync the
-    // streams are drained first so that the counters attribute time the way the reference does; without it
-    // they only see the host-side enqueue cost (and the bench times whole calls with events instead).
+    // The reference's wall-clock counter (distributed_sparse.h:212-223), kept for callers that time host-side work.
     void stop_clock_and_add(my_timer_t& start, const std::string& counter_name) {
         if (std::find(perf_counter_keys.begin(), perf_counter_keys.end(), counter_name) == perf_counter_keys.end())
             hnh::fatal("Error, performance counter " + counter_name + " not registered.");
@@ -149,7 +153,51 @@ public:
         total_time[counter_name] += stop_clock_get_elapsed(start);
     }
 
+    // Device-timed phases.  The schedules' work is asynchronous — a host clock around an enqueue sees microseconds — so a
+    // phase is bracketed by a pair of HIP events on the stream it runs on ("... Shift Time" of the ring loops: the
+    // communication stream; everything else, incl. the collectives of the replication phases: the compute stream).  The pairs
+    // are resolved (elapsed time added to the reference's counter of the same name) when the statistics are read, without
+    // draining a stream in the middle of a call, so the compute/communication overlap being measured is not disturbed.
+    // A span covers what the stream did between its two events, waits on the other stream included — the device-side
+    // analogue of the reference's counters, whose "Cyclic Shift Time" also contains the wait for the neighbour.
+    struct PhaseClock {
+        void* e0 = nullptr;
+        int stream = HNH_STREAM_COMPUTE;
+        int key = -1;
+        my_timer_t host;
+    };
+    static int phase_stream(const std::string& key) {
+        return (key.find("Cyclic Shift") != std::string::npos) ? HNH_STREAM_COMM : HNH_STREAM_COMPUTE;
+    }
+    PhaseClock phase_begin(const char* counter_name) {
+        PhaseClock t;
+        auto it = std::find(perf_counter_keys.begin(), perf_counter_keys.end(), counter_name);
+        if (it == perf_counter_keys.end()) hnh::fatal(std::string("Error, performance counter ") + counter_name + " not registered.");
+        t.key = (int)(it - perf_counter_keys.begin());
+        t.host = start_clock();
+        if (world->timing_sync) return t;  // reference-like attribution: wall clock around drained streams
+        t.stream = phase_stream(*it);
+        t.e0 = take_event();
+        world->event_record(t.e0, t.stream);
+        return t;
+    }
+    void phase_end(PhaseClock& t) {
+        const std::string& key = perf_counter_keys[(size_t)t.key];
+        call_count[key]++;
+        if (t.e0 == nullptr) {
+            world->sync_all();
+            total_time[key] += stop_clock_get_elapsed(t.host);
+            return;
+        }
+        void* e1 = take_event();
+        world->event_record(e1, t.stream);
+        spans_.push_back({t.e0, e1, t.key});
+        t.e0 = nullptr;
+        if (spans_.size() > 2048) resolve_spans(spans_.size() / 2);  // old spans finished long ago: no stall to speak of
+    }
+
     std::string json_perf_statistics() {  // mean over ranks, as distributed_sparse.h:245-261
+        resolve_spans(spans_.size());
         std::vector<double> vals;
         for (auto& key : perf_counter_keys) vals.push_back(total_time[key]);
         world->host_allreduce_sum(vals.data(), vals.size());
@@ -289,6 +337,33 @@ protected:
         std::vector<int> all(ring.size(), 0);
         world->host_allgather_comm(ring, &mine, all.data(), sizeof(int));
         if (blk) blk->ring_max_row_nnz = *std::max_element(all.begin(), all.end());
+    }
+
+    // device-timed phases waiting to be resolved, and recycled events
+    struct Span {
+        void* e0;
+        void* e1;
+        int key;
+    };
+    std::vector<Span> spans_;
+    std::vector<void*> spare_events_;
+    void* take_event() {
+        if (spare_events_.empty()) return world->event_create();
+        void* e = spare_events_.back();
+        spare_events_.pop_back();
+        return e;
+    }
+    void resolve_spans(size_t count) {  // the oldest `count` spans: wait for their end events, add the elapsed device time
+        count = std::min(count, spans_.size());
+        for (size_t i = 0; i < count; i++) {
+            float ms = 0.f;
+            world->check(world->be->hnh_event_sync(world->ctx, spans_[i].e1), "hnh_event_sync");
+            world->check(world->be->hnh_event_elapsed_ms(world->ctx, spans_[i].e0, spans_[i].e1, &ms), "hnh_event_elapsed_ms");
+            total_time[perf_counter_keys[(size_t)spans_[i].key]] += (double)ms * 1e-3;
+            spare_events_.push_back(spans_[i].e0);
+            spare_events_.push_back(spans_[i].e1);
+        }
+        spans_.erase(spans_.begin(), spans_.begin() + (long)count);
     }
 
     // small pool of events for compute/communication hand-offs

@@ -48,11 +48,9 @@ size_t StandardKernel::fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
     if ((flags & HNH_FUSED_LEAKY_RELU) && !extras) hnh::fatal("Error, HNH_FUSED_LEAKY_RELU needs extras!");
     CSRLocal* blk = S.csr_blocks[block];
     hnh::World* w = S.world;
-    if (blk == nullptr || blk->num_coords == 0) {  // nothing to multiply; the row epilogue still applies
-        if (wants_epilogue(extras)) {
-            if (flags & HNH_FUSED_OUT_OVERWRITE) Out.setZero();
-            row_epilogue(w, A, Out, extras);
-        }
+    if (blk == nullptr || blk->num_coords == 0) {  // nothing to multiply; the flags' contract and the row epilogue still apply
+        if (flags & HNH_FUSED_OUT_OVERWRITE) Out.setZero();  // "treat Out as zero on entry": it must not keep stale rows
+        row_epilogue(w, A, Out, extras);
         return 0;
     }
     if (blk->transpose) hnh::fatal("Error, local matrix is transposed, can't perform the fused SDDMM+SpMM");

@@ -129,7 +129,7 @@ public:
         // Replicate the dense operand that the sparse block's columns index: p/c slab-wise all-gathers over
         // the layer communicator (15D_sparse_shift.hpp:203-214).
         if (initial_replicate) {
-            auto t = start_clock();
+            auto t = phase_begin("Replication Time");
             if (c > 1) {
                 if (accumulation_buffer.rows() != Brole->rows() * c || accumulation_buffer.cols() != cols)
                     accumulation_buffer = DenseMatrix(Brole->rows() * c, cols);
@@ -138,17 +138,17 @@ public:
                     world->allgather(grid->row_world, Brole->data() + slab * i, accumulation_buffer.data() + slab * c * i,
                                      slab * sizeof(double), HNH_STREAM_COMPUTE);
             }
-            stop_clock_and_add(t, "Replication Time");
+            phase_end(t);
         }
 
         {
-            auto t = start_clock();
+            auto t = phase_begin("Computation Time");
             if (is_sddmm) choice->setValuesConstant(0.0);
             else {
                 choice->setCSRValues(SValues);
                 Arole->setZero();  // every slab is produced exactly once below (`tmp *= 0.0` in the reference)
             }
-            stop_clock_and_add(t, "Computation Time");
+            phase_end(t);
         }
 
         DenseMatrix& gathered = (c > 1) ? accumulation_buffer : *Brole;
@@ -157,15 +157,15 @@ public:
         if (n > 1) order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);
 
         for (int i = 0; i < n; i++) {
-            auto t = start_clock();
+            auto t = phase_begin("Computation Time");
             const int block_id = pMod(grid->i - i, n);
             DenseMatrix slab = DenseMatrix::view(Arole->data() + (size_t)block_id * arBwidth * Arole->cols(), arBwidth, Arole->cols());
             if (i > 0) world->event_wait(event(1 + (i - 1) % 2), HNH_STREAM_COMPUTE);  // shift i-1 landed
             kernel->triple_function(mode == k_spmmB ? k_spmmA : mode, *choice, slab, gathered, 0, 0);
-            stop_clock_and_add(t, "Computation Time");
+            phase_end(t);
 
             if (n > 1) {
-                t = start_clock();
+                t = phase_begin("Cyclic Shift Time");
                 world->event_record(event(3 + i % 2), HNH_STREAM_COMPUTE);
                 // SDDMM writes the travelling values: ship after this step's kernel.  SpMM only reads the
                 // block: ship concurrently with this step's kernel, but not before the previous kernel has
@@ -176,15 +176,15 @@ public:
                               HNH_STREAM_COMM, pMod(grid->i - i - 1, n));
                 choice->blockStarts[1] = blk->num_coords;
                 world->event_record(event(1 + i % 2), HNH_STREAM_COMM);
-                stop_clock_and_add(t, "Cyclic Shift Time");
+                phase_end(t);
             }
         }
         if (n > 1) world->event_wait(event(1 + (n - 1) % 2), HNH_STREAM_COMPUTE);  // block is home again
 
         if (is_sddmm) {
-            auto t = start_clock();
+            auto t = phase_begin("Computation Time");
             choice->hadamardWithCSRValues(SValues, *sddmm_result_ptr);
-            stop_clock_and_add(t, "Computation Time");
+            phase_end(t);
         }
     }
 };

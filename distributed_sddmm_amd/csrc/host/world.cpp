@@ -174,7 +174,7 @@ void World::dfree(void* p) {
 }
 
 void World::drain_pool() {
-    sync_all();
+    sync_all_nothrow();
     for (auto& kv : pool_) {
         be->hnh_event_destroy(ctx, kv.second.ev[0]);
         be->hnh_event_destroy(ctx, kv.second.ev[1]);
@@ -193,6 +193,14 @@ void World::sync(int stream) { check(be->hnh_stream_sync(ctx, stream), "hnh_stre
 void World::sync_all() {
     sync(HNH_STREAM_COMPUTE);
     sync(HNH_STREAM_COMM);
+}
+// Teardown variant for destructors (implicitly noexcept): a device error at this point is reported, never thrown.
+void World::sync_all_nothrow() noexcept {
+    if (!ctx) return;
+    for (int st : {HNH_STREAM_COMPUTE, HNH_STREAM_COMM}) {
+        const int rc = be->hnh_stream_sync(ctx, st);
+        if (rc != HNH_OK) std::cerr << "hnh: device error during teardown (stream " << st << ", status " << rc << "): " << be->hnh_last_error(ctx) << std::endl;
+    }
 }
 void* World::event_create() {
     void* e = nullptr;
@@ -410,6 +418,7 @@ struct ThreadGroup {
     // barrier
     int arrived = 0;
     uint64_t generation = 0;
+    uint64_t abort_epoch = 0;  // bumped when a rank fails: ranks WAITING on the group at that moment fail too instead of hanging
     // pointer publication
     std::vector<const void*> slots;
     // point-to-point mailboxes, index src * n + dst
@@ -439,6 +448,12 @@ ThreadWorld::ThreadWorld(std::shared_ptr<ThreadGroup> group, int rank_in_group, 
 }
 ThreadWorld::~ThreadWorld() { destroy_device(); }
 
+void ThreadWorld::abort_peers() noexcept {
+    std::lock_guard<std::mutex> lk(g_->mu);
+    g_->abort_epoch++;
+    g_->cv.notify_all();
+}
+
 void ThreadWorld::barrier() {
     std::unique_lock<std::mutex> lk(g_->mu);
     const uint64_t gen = g_->generation;
@@ -447,7 +462,12 @@ void ThreadWorld::barrier() {
         g_->generation++;
         g_->cv.notify_all();
     } else {
-        g_->cv.wait(lk, [&] { return g_->generation != gen; });
+        const uint64_t ep = g_->abort_epoch;
+        g_->cv.wait(lk, [&] { return g_->generation != gen || g_->abort_epoch != ep; });
+        if (g_->generation == gen) {
+            g_->arrived--;  // this rank leaves the barrier again
+            fatal("Error, a peer rank of the thread group failed");
+        }
     }
 }
 
@@ -501,7 +521,9 @@ void ThreadWorld::sendrecv(const Comm& comm, const void* sendbuf, size_t sendbyt
         {
             std::unique_lock<std::mutex> lk(g_->mu);
             auto& q = g_->box[(size_t)src * n + rank];
-            g_->cv.wait(lk, [&] { return !q.empty(); });
+            const uint64_t ep = g_->abort_epoch;
+            g_->cv.wait(lk, [&] { return !q.empty() || g_->abort_epoch != ep; });
+            if (q.empty()) fatal("Error, a peer rank of the thread group failed");
             in = q.front();
             q.pop_front();
         }
@@ -520,7 +542,9 @@ void ThreadWorld::sendrecv(const Comm& comm, const void* sendbuf, size_t sendbyt
     if (out) {
         {
             std::unique_lock<std::mutex> lk(g_->mu);
-            g_->cv.wait(lk, [&] { return out->completed; });
+            const uint64_t ep = g_->abort_epoch;
+            g_->cv.wait(lk, [&] { return out->completed || g_->abort_epoch != ep; });
+            if (!out->completed) fatal("Error, a peer rank of the thread group failed");
         }
         event_wait(out->done, stream);  // do not let later work on `stream` overwrite sendbuf before the peer's copy ran
         event_destroy(out->done);
@@ -538,7 +562,7 @@ RcclWorld::RcclWorld(int r, int nranks, Backend* backend, int device_ordinal, co
 }
 RcclWorld::~RcclWorld() {
     if (ctx) {
-        sync_all();
+        sync_all_nothrow();
         if (comm_) be->hnh_comm_destroy(ctx, comm_);
     }
     destroy_device();

@@ -51,6 +51,9 @@ public:
 
     virtual ~World();
     virtual const char* kind() const = 0;
+    // this rank failed (an error is about to be reported to its caller): wake peers that wait on it.  Only the in-process
+    // thread group can do that; process-based transports rely on their launcher.
+    virtual void abort_peers() noexcept {}
 
     // ---- communicators
     Comm world_comm();
@@ -97,6 +100,7 @@ public:
     void memset0(void* dst, size_t bytes, int stream);
     void sync(int stream);
     void sync_all();
+    void sync_all_nothrow() noexcept;  // for destructors: reports a device error instead of throwing
     void* event_create();
     void event_destroy(void* e);
     void event_record(void* e, int stream);
@@ -149,6 +153,7 @@ public:
     ThreadWorld(std::shared_ptr<ThreadGroup> group, int rank_in_group, Backend* backend, int device_ordinal);
     ~ThreadWorld() override;
     const char* kind() const override { return "thread-loopback"; }
+    void abort_peers() noexcept override;
     void sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes,
                   int src, int stream) override;
     void barrier() override;

@@ -17,8 +17,10 @@
  *   hnh_fill_f64                  : SpmatLocal::setValuesConstant, SpmatLocal.hpp:595-605
  *   hnh_hadamard_f64              : SValues.cwiseProduct(getCSRValues()), 15D_dense_shift.hpp:366
  */
+#define _POSIX_C_SOURCE 200809L /* clock_gettime */
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "hnh_kernels.h"
 
@@ -62,12 +64,18 @@ int hnh_memset(hnh_ctx* c, void* dst, int byte, size_t bytes, int stream) {
     return HNH_OK;
 }
 int hnh_stream_sync(hnh_ctx* c, int s) { (void)c; (void)s; return HNH_OK; }
-int hnh_event_create(hnh_ctx* c, void** e) { (void)c; *e = malloc(1); return HNH_OK; }
+/* the test double runs everything synchronously, so an event is just the host time at which it was recorded */
+static double now_ms(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+int hnh_event_create(hnh_ctx* c, void** e) { (void)c; *e = calloc(1, sizeof(double)); return HNH_OK; }
 int hnh_event_destroy(hnh_ctx* c, void* e) { (void)c; free(e); return HNH_OK; }
-int hnh_event_record(hnh_ctx* c, void* e, int s) { (void)c; (void)e; (void)s; return HNH_OK; }
+int hnh_event_record(hnh_ctx* c, void* e, int s) { (void)c; (void)s; *(double*)e = now_ms(); return HNH_OK; }
 int hnh_event_wait(hnh_ctx* c, void* e, int s) { (void)c; (void)e; (void)s; return HNH_OK; }
 int hnh_event_sync(hnh_ctx* c, void* e) { (void)c; (void)e; return HNH_OK; }
-int hnh_event_elapsed_ms(hnh_ctx* c, void* a, void* b, float* ms) { (void)c; (void)a; (void)b; *ms = 0.f; return HNH_OK; }
+int hnh_event_elapsed_ms(hnh_ctx* c, void* a, void* b, float* ms) { (void)c; *ms = (float)(*(double*)b - *(double*)a); return HNH_OK; }
 
 /* sparse_kernels.cpp:44-55 */
 int hnh_sddmm_coo(hnh_ctx* c, int64_t nnz, const int32_t* row_idx, const int32_t* col_idx, double* values, const double* X,

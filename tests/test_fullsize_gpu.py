@@ -1,0 +1,183 @@
+"""Parity at the sizes bench.py reports (BASELINE configs 2, 4 and 5 at full size) on the HIP path.
+
+Checkers (test infrastructure only):
+  * oracle.fingerprints_closed_form — the scratch.cpp:26-76 fingerprint trio (squared norms of SDDMM / SpMM-A / SpMM-B under
+    the dummyInitialize fill) in O(nnz), pinned to the reference's own numbers in tests/test_oracle_golden.py;
+  * oracle/_ref/ref_driver — the compiled reference itself (unmodified sources + MKL/MPICH), where it travelled with the
+    snapshot: run ONCE at config 2's full size for the fingerprints and once for an ALS step at 2^20 vertices.
+Tolerances: 1e-11 relative (fp64, only the summation order differs), 1e-9 for ALS factors (CG amplifies the summation-order
+differences; the reference's own five schedules differ by 1.2e-11 after two steps, tests/golden/als_manifest.json)."""
+import numpy as np
+import pytest
+
+import hnh_testlib as T
+from distributed_sddmm_amd import api as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, scope="module")
+def hip_backend():
+    assert H.load_backend(None) == "hip-gfx950"
+    yield
+
+
+def device_fingerprints(d):
+    """scratch.cpp:26-76 on one rank's share: sum of squares of sddmmA / spmmA / spmmB under dummyInitialize."""
+    A, B = d.like_A_matrix(0.0), d.like_B_matrix(0.0)
+    out = []
+    for mode in ("sddmm", "spmmA", "spmmB"):
+        d.dummyInitialize(A, H.AMAT)
+        d.dummyInitialize(B, H.BMAT)
+        kmode = {"sddmm": H.K_SDDMM_A, "spmmA": H.K_SPMM_A, "spmmB": H.K_SPMM_B}[mode]
+        d.initial_shift(A, B, kmode)
+        if mode == "sddmm":
+            ones, res = d.like_S_values(1.0), d.like_S_values(0.0)
+            d.sddmmA(A, B, ones, res)
+            x = res.download()
+            ones.free(); res.free()
+        elif mode == "spmmA":
+            ones = d.like_S_values(1.0)
+            d.spmmA(A, B, ones)
+            d.de_shift(A, B, kmode)
+            x = A.download()
+            ones.free()
+        else:
+            ones = d.like_ST_values(1.0)
+            d.spmmB(A, B, ones)
+            d.de_shift(A, B, kmode)
+            x = B.download()
+            ones.free()
+        out.append(float(np.sum(x.astype(np.float64) ** 2)))
+    A.free(); B.free()
+    return np.array(out)
+
+
+@pytest.fixture(scope="module")
+def config2():
+    """BASELINE config 2's matrix: ER 2^20 x 2^20, edge factor 96 (100 658 766 unique nonzeros), from the host generator."""
+    from oracle import oracle as O
+    logm, ef = 20, 96
+    m = 1 << logm
+    rows, cols = H.generate_er(m, m, m * ef, 12345)
+    assert len(rows) == 100658766
+    return dict(logm=logm, ef=ef, m=m, rows=rows, cols=cols, closed=np.array(O.fingerprints_closed_form(rows, cols, m, m, 128)))
+
+
+def test_config2_closed_form_is_the_reference(config2):
+    """The compiled reference at config 2's FULL size (1.0e8 nonzeros, R = 128; about a minute of host time) gives the
+    fingerprints the closed form predicts — so the next tests' checker is the reference's arithmetic at this very size."""
+    from oracle import refrun as RR
+    if not RR.available():
+        pytest.skip("compiled reference not available on this box")
+    ref = RR.fingerprints(config2["m"], config2["m"], config2["rows"], config2["cols"], 128, "15d_fusion2", 1, 1, timeout=1500)
+    want = np.array([ref["sddmm"], ref["spmmA"], ref["spmmB"]])
+    assert T.rel(config2["closed"], want) <= T.TOL, (config2["closed"], want)
+
+
+@pytest.mark.parametrize("alg", ["15d_fusion2", "15d_sparse"])
+def test_config2_full_size_fingerprints(config2, alg):
+    """The headline configuration itself (what bench.py times at N = 1) and one unfused schedule on the same matrix:
+    SDDMM, SpMM-A and SpMM-B through the whole operator stack on the GPU, int32 row pointers up to 1.0e8, the
+    Infinity-Cache column panels, 262 144 workgroups per launch."""
+    w = H.World.single(0)
+    sp = H.SpmatLocal.load_tuples(w, False, config2["logm"], config2["ef"])  # the device generator, as bench.py uses it
+    assert sp.info()["dist_nnz"] == len(config2["rows"])
+    d = H.DistributedSparse(w, alg, sp, 128, 1)
+    got = device_fingerprints(d)
+    assert T.rel(got, config2["closed"]) <= T.TOL, (got, config2["closed"])
+    d.free(); sp.free(); w.close()
+
+
+def test_config2_full_size_fused_elementwise(config2):
+    """fusedSpMM at config 2's size against per-row closed forms with NON-constant operands: A[i,:] = a_i, B[j,:] = b_j
+    (row-constant), S = 1  =>  sddmm(i,j) = R a_i b_j and  out[i,:] = R a_i sum_{j in row i} b_j^2  for every column."""
+    m, r = config2["m"], 128
+    rng = np.random.default_rng(7)
+    a, b = rng.uniform(0.5, 1.5, m), rng.uniform(0.5, 1.5, m)
+    w = H.World.single(0)
+    sp = H.SpmatLocal.load_tuples(w, False, config2["logm"], config2["ef"])
+    d = H.DistributedSparse(w, "15d_fusion2", sp, r, 1)
+    A, B = d.like_A_matrix(0.0), d.like_B_matrix(0.0)
+    A.upload(np.repeat(a[:, None], r, axis=1))
+    B.upload(np.repeat(b[:, None], r, axis=1))
+    S, buf = d.like_S_values(1.0), d.like_S_values(0.0)
+    d.fusedSpMM(A, B, S, buf, H.AMAT)
+    got = A.download()
+    want_row = r * a * np.bincount(config2["rows"], weights=b[config2["cols"]] ** 2, minlength=m)
+    assert np.max(np.abs(got - want_row[:, None])) <= T.TOL * np.max(np.abs(want_row))
+    for x in (A, B, S, buf):
+        x.free()
+    d.free(); sp.free(); w.close()
+
+
+def test_config4_shape_full_size_25d_dense():
+    """BASELINE config 4's shape at full size: a skewed R-MAT graph on 2^22 vertices (2.16e8 unique nonzeros, longest row
+    2.4e5 — the stand-in for com-Orkut), R = 256, 2.5D dense-replicating Cannon on p = 8, c = 2 (2 x 2 x 2) through the
+    loopback transport; fingerprints against the closed form.  Exercises travelling sparse blocks, hub-row splitting and
+    the R split at the size the configuration names."""
+    from oracle import oracle as O
+    logm, r, p, c = 22, 256, 8, 2
+    m = 1 << logm
+    rows, cols = H.generate_rmat(logm, 230_000_000)
+    want = np.array(O.fingerprints_closed_form(rows, cols, m, m, r))
+
+    def body(w):
+        sp = H.SpmatLocal.from_global(w, m, m, rows, cols, None)
+        d = H.DistributedSparse(w, "25d_dense_replicate", sp, r, c)
+        sp.free()
+        fp = device_fingerprints(d)
+        d.free()
+        return fp
+
+    per_rank = H.run_spmd(p, body)
+    got = np.sum(per_rank, axis=0)
+    assert T.rel(got, want) <= T.TOL, (got, want)
+
+
+def test_config5_als_step_at_full_size(config2):
+    """BASELINE config 5's application at 2^20 vertices, R = 128: one alternating ALS step (both half-steps, 2 CG iterations
+    each = 8 fused calls) on the GPU against the reference's own ALS code (als_conjugate_gradients.cpp) run on the host
+    cores from the same initial factors and ground truth."""
+    from oracle import oracle as O
+    from oracle import refrun as RR
+    if not RR.available():
+        pytest.skip("compiled reference not available on this box")
+    m, r, rows, cols = config2["m"], 128, config2["rows"], config2["cols"]
+    vals = O.sparse_values(rows, cols, m, 5)
+    a0, b0 = O.dense_fill(m, r, 11), O.dense_fill(m, r, 12)
+    ref = RR.als(m, m, rows, cols, vals, r, a0, b0, "15d_fusion2", 1, 1, steps=1, cg_iters=2, timeout=1800)
+    w = H.World.single(0)
+    sp = H.SpmatLocal.from_global(w, m, m, rows, cols, vals)
+    d = H.DistributedSparse(w, "15d_fusion2", sp, r, 1)
+    A, B = d.like_A_matrix(0.0), d.like_B_matrix(0.0)
+    # ground truth in the operator's value order: the coordinate probe gives key = i * N + j per value slot, and the values
+    # are a pure function of the key (oracle.sparse_values), so no lookup table is needed at 1e8 nonzeros
+    pa = np.zeros((m, r)); pa[:, 0] = np.arange(m); pa[:, 1] = 1.0
+    pb = np.zeros((m, r)); pb[:, 0] = m; pb[:, 1] = np.arange(m)
+    gts = []
+    for sddmm, like in ((d.sddmmA, d.like_S_values), (d.sddmmB, d.like_ST_values)):
+        A.upload(pa); B.upload(pb)
+        ones, res = like(1.0), like(0.0)
+        sddmm(A, B, ones, res)
+        keys = np.rint(res.download()).astype(np.uint64)
+        res.upload(O.hashed_uniform(keys, 5))
+        gts.append(res); ones.free()
+    del pa, pb
+    als = H.DistributedALS(d, False)
+    als.set_ground_truth(gts[0], gts[1])
+    A.upload(a0); B.upload(b0)
+    als.set_embeddings(A, B)
+    residuals = [als.computeResidual()]
+    als.cg_optimizer(H.AMAT, 2)
+    als.cg_optimizer(H.BMAT, 2)
+    residuals.append(als.computeResidual())
+    als.get_embeddings(A, B)
+    ga, gb = A.download(), B.download()
+    assert T.rel(ga, ref["A"]) <= T.ALS_TOL, T.rel(ga, ref["A"])
+    assert T.rel(gb, ref["B"]) <= T.ALS_TOL, T.rel(gb, ref["B"])
+    assert T.rel(np.array(residuals), ref["residuals"]) <= T.ALS_TOL
+    als.free()
+    for x in (A, B, gts[0], gts[1]):
+        x.free()
+    d.free(); sp.free(); w.close()
