@@ -44,6 +44,10 @@ SIGNATURES = {
     "hnh_spmm_csr_ex": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i64, _i32]),
     "hnh_fused_sddmm_spmm_csr_ex": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _i64, _i32, _i64, _i32]),
     "hnh_panel_count": (_i32, [_vp, _i64, _i32, _i32]),
+    "hnh_csr_window_bounds": (_i32, [_vp, _i64, _vp, _vp, _i32, _vp, _vp, _i32]),
+    "hnh_sddmm_csr_w": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _i32]),
+    "hnh_spmm_csr_w": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _i32]),
+    "hnh_fused_sddmm_spmm_csr_w": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _i64, _i32, _vp, _vp, _i32]),
     "hnh_csr_max_row_nnz": (_i32, [_vp, _i64, _vp, C.POINTER(C.c_int), _i32]),
     "hnh_fused_sddmm_spmm_csr_multi": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, C.c_uint, _i32]),
     "hnh_fused_sddmm_spmm_csr_x": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _i64, _i32, _i64, _vp, _i32]),
@@ -53,6 +57,7 @@ SIGNATURES = {
     "hnh_tuples_sort": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32]),
     "hnh_tuples_bucket_starts": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i32]),
     "hnh_tuples_transform": (_i32, [_vp, _vp, _i64, _i32, C.c_uint64, C.c_uint64, _i32]),
+    "hnh_tuples_remap_cols": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i32]),
     "hnh_generate_er_keys": (_i32, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp, C.POINTER(C.c_int64), _i32]),
     "hnh_tuples_from_keys": (_i32, [_vp, _vp, C.c_uint64, _i64, _i64, C.c_double, _vp, _i64, _i32]),
     "hnh_tuples_relabel": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32]),

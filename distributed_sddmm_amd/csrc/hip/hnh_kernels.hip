@@ -633,6 +633,44 @@ __global__ __launch_bounds__(kBlock) void panel_split_kernel(int64_t rows, const
     }
 }
 
+// Caller-defined windows (hnh_csr_window_bounds): split[b * rows + r] = first nonzero of row r with column >= bound b.
+constexpr int kMaxWindowBounds = 15;
+struct WindowBounds {
+    int32_t v[kMaxWindowBounds];
+    int n;
+};
+__global__ __launch_bounds__(kBlock) void window_bounds_kernel(int64_t rows, const int32_t* __restrict__ rowptr,
+                                                               const int32_t* __restrict__ colidx, WindowBounds wb,
+                                                               int32_t* __restrict__ split) {
+    const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= rows) return;
+    const int end = rowptr[row + 1];
+    int lo = rowptr[row];
+    for (int b = 0; b < wb.n; b++) {  // bounds are non-decreasing: continue from the previous one
+        int hi = end;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (colidx[mid] < wb.v[b]) lo = mid + 1;
+            else hi = mid;
+        }
+        split[(int64_t)b * rows + row] = lo;
+    }
+}
+
+// element-wise passes of the column-tiled fused fallback, restricted to a window: 0 = zero, 1 = LeakyReLU, 2 = *= svalues
+__global__ __launch_bounds__(kBlock) void window_values_kernel(int64_t rows, const int32_t* __restrict__ beg, const int32_t* __restrict__ end,
+                                                               double* __restrict__ values, const double* __restrict__ svalues, int mode,
+                                                               double alpha) {
+    const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 64;
+    const int lane = threadIdx.x % 64;
+    if (row >= rows) return;
+    for (int e = beg[row] + lane; e < end[row]; e += 64) {
+        if (mode == 0) values[e] = 0.0;
+        else if (mode == 1) { const double x = values[e]; values[e] = fmax(x, 0.0) + fmin(x, 0.0) * alpha; }
+        else values[e] *= svalues[e];
+    }
+}
+
 // One work item = kLongSeg consecutive nonzeros of a long row; items are listed by build_long_list_kernel.
 template <Op OP, int LPR, int VEC, int W, bool EXACT>
 __global__ __launch_bounds__(kBlock) void long_row_kernel(const int2* __restrict__ items, const int* __restrict__ item_count,
@@ -1202,10 +1240,34 @@ int panel_count(const hnh_ctx* ctx, int64_t cols, int R) {
 template <Op OP>
 int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t rows, int64_t nnz, int max_row_nnz, int64_t cols,
                  const int32_t* rowptr, const int32_t* colidx, double* values, const double* svalues, const double* X,
-                 const double* Y, double* Out, int R, unsigned flags, const Extras& ex = Extras(), bool* epilogue_done = nullptr) {
+                 const double* Y, double* Out, int R, unsigned flags, const Extras& ex = Extras(), bool* epilogue_done = nullptr,
+                 const hnh_csr_window* win = nullptr) {
     LongCtl lc;
     if (int rc = prepare_long(ctx, st, sidx, rows, rowptr, nnz, max_row_nnz, &lc)) return rc;
     const bool single_pass = s.exact || R <= 64 * s.w * 4;
+    if (win != nullptr) {
+        // a caller-defined window of every row; hub rows stay whole and go to the long-row pass with the pass's last window,
+        // which is also where a row epilogue can run inside the launch
+        const int32_t* beg_ptr = win->beg ? win->beg : rowptr;
+        const int32_t* end_ptr = win->end ? win->end : rowptr + 1;
+        const bool last = win->last != 0;
+        if (epilogue_done != nullptr) *epilogue_done = last && !lc.enabled && single_pass;
+        const unsigned f = flags | ((epilogue_done != nullptr && *epilogue_done) ? kInternalEpilogue : 0u);
+        const int rcw = launch_shape<OP>(ctx, st, lc, s, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, f, ex, last);
+        if (rcw != -1) return rcw;
+        if (OP == Op::kFused) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "fused fallback is composed by the caller");
+        const int wtile = 64 * s.w;
+        for (int col0 = 0; col0 < R; col0 += wtile) {
+            const int ncols = (R - col0 < wtile) ? (R - col0) : wtile;
+            int rc;
+            if (s.w == 2)
+                rc = launch_row<OP, 64, 1, 2, false>(ctx, st, lc, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags, ex, last);
+            else
+                rc = launch_row<OP, 64, 1, 1, false>(ctx, st, lc, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags, ex, last);
+            if (rc != HNH_OK) return rc;
+        }
+        return HNH_OK;
+    }
     // the row epilogue runs inside the launch only when every output row is completed by ONE group (no hub-row
     // segments adding atomically afterwards, no column tiles); otherwise the caller appends row_epilogue_kernel
     if (epilogue_done != nullptr) *epilogue_done = !lc.enabled && single_pass;
@@ -1354,6 +1416,10 @@ int launch_row_epilogue(hnh_ctx* ctx, hipStream_t st, double* Out, const double*
     return hnh::check_hip(ctx, hipGetLastError(), "row_epilogue_kernel launch");
 }
 
+int fused_impl(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values, const double* svalues,
+               const double* X, const double* Y, double* Out, int R, unsigned flags, int64_t nnz_in, int max_row_nnz, int64_t cols,
+               const hnh_fused_extras* extras, const hnh_csr_window* win, int stream);
+
 int check_extras(hnh_ctx* ctx, unsigned flags, const hnh_fused_extras* extras, Extras* ex, bool* want_epilogue, const char* who) {
     if (flags & ~(HNH_FUSED_VALUES_OVERWRITE | HNH_FUSED_OUT_OVERWRITE | HNH_FUSED_LEAKY_RELU))
         return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": unknown flag");
@@ -1374,6 +1440,22 @@ extern "C" {
 int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
                                const double* svalues, const double* X, const double* Y, double* Out, int R, unsigned flags,
                                int64_t nnz_in, int max_row_nnz, int64_t cols, const hnh_fused_extras* extras, int stream) {
+    return fused_impl(ctx, rows, rowptr, col_idx, values, svalues, X, Y, Out, R, flags, nnz_in, max_row_nnz, cols, extras, nullptr, stream);
+}
+
+int hnh_fused_sddmm_spmm_csr_w(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
+                               const double* svalues, const double* X, const double* Y, double* Out, int R, unsigned flags,
+                               int64_t nnz_in, int max_row_nnz, const hnh_fused_extras* extras, const hnh_csr_window* window, int stream) {
+    if (!window) return ctx ? hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr_w: null window") : HNH_ERR_INVALID;
+    return fused_impl(ctx, rows, rowptr, col_idx, values, svalues, X, Y, Out, R, flags, nnz_in, max_row_nnz, -1, extras, window, stream);
+}
+
+}  // extern "C"
+
+namespace {
+int fused_impl(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values, const double* svalues,
+               const double* X, const double* Y, double* Out, int R, unsigned flags, int64_t nnz_in, int max_row_nnz, int64_t cols,
+               const hnh_fused_extras* extras, const hnh_csr_window* win, int stream) {
     HNH_ENTER(ctx, stream);
     if (int rc = check_common(ctx, rows, R, "hnh_fused_sddmm_spmm_csr")) return rc;
     Extras ex;
@@ -1385,10 +1467,12 @@ int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr
     if (X == Out || Y == Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr: Out aliases an input");
     hipStream_t st = ctx->streams[stream];
     const Shape s = pick_shape(R, aligned16(X) && aligned16(Y) && aligned16(Out));
+    const bool closes_rows = (win == nullptr) || win->last != 0;  // the call that completes the output rows runs the epilogue
+    if (want_epilogue && !closes_rows) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr_w: a row epilogue belongs to the last window");
     if (s.exact || R <= 256 * s.w) {  // one pass: an exact instance, or a bounds-checked one wide enough for the whole row
         bool done = false;
         if (int rc = dispatch_row<Op::kFused>(ctx, st, stream, s, rows, nnz_in, max_row_nnz, cols, rowptr, col_idx, values, svalues, X, Y, Out, R,
-                                              flags, ex, want_epilogue ? &done : nullptr))
+                                              flags, ex, want_epilogue ? &done : nullptr, win))
             return rc;
         if (want_epilogue && !done) return launch_row_epilogue(ctx, st, Out, X, ex.x_scale, ex.rowdot, rows, R);
         return HNH_OK;
@@ -1402,22 +1486,81 @@ int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr
         HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
         nnz = last;
     }
-    if (flags & HNH_FUSED_VALUES_OVERWRITE) HNH_TRY_HIP(ctx, hipMemsetAsync(values, 0, sizeof(double) * (size_t)nnz, st));
+    // element-wise steps between the passes touch the window's values only (other windows hold finished or pending results)
+    const int32_t* wbeg = (win && win->beg) ? win->beg : rowptr;
+    const int32_t* wend = (win && win->end) ? win->end : rowptr + 1;
+    auto on_values = [&](int mode) {
+        if (win == nullptr) {
+            if (mode == 0) return hnh::check_hip(ctx, hipMemsetAsync(values, 0, sizeof(double) * (size_t)nnz, st), "hipMemsetAsync");
+            if (mode == 1) hipLaunchKernelGGL(leaky_relu_kernel, dim3(ew_grid(nnz)), dim3(kBlock), 0, st, values, ex.leaky_alpha, nnz);
+            else hipLaunchKernelGGL(hadamard_kernel, dim3(ew_grid(nnz)), dim3(kBlock), 0, st, values, values, svalues, nnz, false);
+        } else {
+            const int64_t blocks = (rows * 64 + kBlock - 1) / kBlock;
+            hipLaunchKernelGGL(window_values_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, wbeg, wend, values, svalues, mode, ex.leaky_alpha);
+        }
+        return hnh::check_hip(ctx, hipGetLastError(), "element-wise pass of the fused fallback");
+    };
+    if (flags & HNH_FUSED_VALUES_OVERWRITE)
+        if (int rc = on_values(0)) return rc;
     if (flags & HNH_FUSED_OUT_OVERWRITE) HNH_TRY_HIP(ctx, hipMemsetAsync(Out, 0, sizeof(double) * (size_t)rows * R, st));
-    if (int rc = dispatch_row<Op::kSddmm>(ctx, st, stream, s, rows, nnz, max_row_nnz, cols, rowptr, col_idx, values, nullptr, X, Y, nullptr, R, 0u))
+    if (int rc = dispatch_row<Op::kSddmm>(ctx, st, stream, s, rows, nnz, max_row_nnz, cols, rowptr, col_idx, values, nullptr, X, Y, nullptr, R, 0u,
+                                          Extras(), nullptr, win))
         return rc;
     if (flags & HNH_FUSED_LEAKY_RELU) {
         if (svalues) {
-            hipLaunchKernelGGL(hadamard_kernel, dim3(ew_grid(nnz)), dim3(kBlock), 0, st, values, values, svalues, nnz, false);
+            if (int rc = on_values(2)) return rc;
             svalues = nullptr;
         }
-        hipLaunchKernelGGL(leaky_relu_kernel, dim3(ew_grid(nnz)), dim3(kBlock), 0, st, values, ex.leaky_alpha, nnz);
-        if (int rc = hnh::check_hip(ctx, hipGetLastError(), "leaky_relu_kernel launch")) return rc;
+        if (int rc = on_values(1)) return rc;
     }
-    if (int rc = dispatch_row<Op::kSpmm>(ctx, st, stream, s, rows, nnz, max_row_nnz, cols, rowptr, col_idx, values, svalues, Y, nullptr, Out, R, 0u))
+    if (int rc = dispatch_row<Op::kSpmm>(ctx, st, stream, s, rows, nnz, max_row_nnz, cols, rowptr, col_idx, values, svalues, Y, nullptr, Out, R, 0u,
+                                         Extras(), nullptr, win))
         return rc;
     if (want_epilogue) return launch_row_epilogue(ctx, st, Out, X, ex.x_scale, ex.rowdot, rows, R);
     return HNH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int hnh_csr_window_bounds(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, int nbounds, const int32_t* bounds_host,
+                          int32_t* split, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (rows < 0 || nbounds < 0 || nbounds > kMaxWindowBounds) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_csr_window_bounds: bad size");
+    if (rows == 0 || nbounds == 0) return HNH_OK;
+    if (!rowptr || !col_idx || !bounds_host || !split) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_csr_window_bounds: null pointer");
+    WindowBounds wb;
+    wb.n = nbounds;
+    for (int b = 0; b < nbounds; b++) {
+        if (b > 0 && bounds_host[b] < bounds_host[b - 1]) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_csr_window_bounds: bounds must not decrease");
+        wb.v[b] = bounds_host[b];
+    }
+    hipLaunchKernelGGL(window_bounds_kernel, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->streams[stream], rows, rowptr,
+                       col_idx, wb, split);
+    return hnh::check_hip(ctx, hipGetLastError(), "window_bounds_kernel launch");
+}
+
+int hnh_sddmm_csr_w(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values, const double* X,
+                    const double* Y, int R, int64_t nnz, int max_row_nnz, const hnh_csr_window* window, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (int rc = check_common(ctx, rows, R, "hnh_sddmm_csr_w")) return rc;
+    if (rows == 0) return HNH_OK;
+    if (!rowptr || !col_idx || !values || !X || !Y || !window) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sddmm_csr_w: null pointer");
+    const Shape s = pick_shape(R, aligned16(X) && aligned16(Y));
+    return dispatch_row<Op::kSddmm>(ctx, ctx->streams[stream], stream, s, rows, nnz, max_row_nnz, -1, rowptr, col_idx, values, nullptr, X, Y,
+                                    nullptr, R, 0u, Extras(), nullptr, window);
+}
+
+int hnh_spmm_csr_w(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values, const double* X,
+                   double* Out, int R, int64_t nnz, int max_row_nnz, const hnh_csr_window* window, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (int rc = check_common(ctx, rows, R, "hnh_spmm_csr_w")) return rc;
+    if (rows == 0) return HNH_OK;
+    if (!rowptr || !col_idx || !values || !X || !Out || !window) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_spmm_csr_w: null pointer");
+    if (X == Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_spmm_csr_w: X and Out alias");
+    const Shape s = pick_shape(R, aligned16(X) && aligned16(Out));
+    return dispatch_row<Op::kSpmm>(ctx, ctx->streams[stream], stream, s, rows, nnz, max_row_nnz, -1, rowptr, col_idx,
+                                   const_cast<double*>(values), nullptr, X, nullptr, Out, R, 0u, Extras(), nullptr, window);
 }
 
 int hnh_row_epilogue_f64(hnh_ctx* ctx, double* Out, const double* X, double x_scale, double* rowdot, int64_t rows, int R, int stream) {

@@ -85,6 +85,18 @@ __global__ __launch_bounds__(kBlock) void transform_kernel(hnh_tuple* t, long lo
     }
 }
 
+__global__ __launch_bounds__(kBlock) void remap_cols_kernel(hnh_tuple* t, long long n, unsigned long long div, unsigned long long sub_div,
+                                                            unsigned long long n_sub, const long long* __restrict__ dest, long long ndest,
+                                                            int* __restrict__ bad) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const unsigned long long c = t[i].c, in = c % div;
+        const unsigned long long seg = (c / div) * n_sub + in / sub_div;
+        if ((long long)seg >= ndest || dest[seg] < 0) { *bad = 1; continue; }
+        t[i].c = (unsigned long long)dest[seg] + in % sub_div;
+    }
+}
+
 // tuples in (row, col) order -> col_idx / values; rowptr[r] = first tuple of row >= r (binary search per row);
 // max_row[0] = longest row; bad[0] = 1 when a tuple lies outside rows x cols
 __global__ __launch_bounds__(kBlock) void unzip_kernel(const hnh_tuple* __restrict__ t, long long n, long long rows, long long cols,
@@ -270,6 +282,29 @@ int hnh_tuples_transform(hnh_ctx* ctx, hnh_tuple* tuples, int64_t n, int swap_rc
     hipLaunchKernelGGL(transform_kernel, dim3(grid_for(n)), dim3(kBlock), 0, ctx->streams[stream], tuples, (long long)n, swap_rc,
                        (unsigned long long)rmod, (unsigned long long)cmod);
     return hnh::check_hip(ctx, hipGetLastError(), "transform_kernel launch");
+}
+
+int hnh_tuples_remap_cols(hnh_ctx* ctx, hnh_tuple* tuples, int64_t n, int64_t div, int64_t sub_div, int64_t n_sub, const int64_t* dest_host,
+                          int64_t ndest, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (n < 0 || div <= 0 || sub_div <= 0 || n_sub <= 0 || ndest <= 0 || !dest_host) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_remap_cols: bad argument");
+    if (n == 0) return HNH_OK;
+    if (!tuples) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_remap_cols: null pointer");
+    hipStream_t st = ctx->streams[stream];
+    Scratch s;
+    HNH_TRY_HIP(ctx, hipMalloc(&s.p, (size_t)ndest * sizeof(long long) + sizeof(int)));
+    long long* dtable = static_cast<long long*>(s.p);
+    int* bad = reinterpret_cast<int*>(dtable + ndest);
+    HNH_TRY_HIP(ctx, hipMemcpyAsync(dtable, dest_host, (size_t)ndest * sizeof(long long), hipMemcpyHostToDevice, st));
+    HNH_TRY_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(int), st));
+    hipLaunchKernelGGL(remap_cols_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, tuples, (long long)n, (unsigned long long)div,
+                       (unsigned long long)sub_div, (unsigned long long)n_sub, dtable, (long long)ndest, bad);
+    HNH_TRY_HIP(ctx, hipGetLastError());
+    int h = 0;
+    HNH_TRY_HIP(ctx, hipMemcpyAsync(&h, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
+    if (h) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_remap_cols: a tuple lies in a segment that has no destination");
+    return HNH_OK;
 }
 
 int hnh_tuples_to_csr(hnh_ctx* ctx, const hnh_tuple* sorted, int64_t n, int64_t rows, int64_t cols, int32_t* rowptr, int32_t* col_idx,

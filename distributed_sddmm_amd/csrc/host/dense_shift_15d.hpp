@@ -43,34 +43,41 @@ public:
     int fusionApproach;
     DenseMatrix accumulation_buffer;  // replicated stationary operand (approach 1) / replicated output (approach 2)
     DenseMatrix broadcast_buffer;     // approach-2 fused: replicated SDDMM row operand when c > 1
-    DenseMatrix ring_spare[2];        // persistent spare buffers of the moving operand
-    std::vector<DenseMatrix> mesh_spare;  // mesh fetch: one landing buffer per remote ring position
+    DenseMatrix ring_spare[2];        // relay ring: persistent spare buffers of the moving operand
     enum RingMode { kRelay, kMeshFetch };
     RingMode ring_mode;
-    // Column chunks (approach 2): every block column of S is cut into `chunks` column ranges = row ranges of the visiting
-    // dense block; sub-block (b, q) is csr_blocks[b * chunks + q].  Two uses:
-    //  * several ranks: the fetch is issued chunk by chunk and the kernels of chunk q run while chunk q+1 is still on the
-    //    links (default 4 chunks);
-    //  * one rank per ring (p == c, e.g. a single GPU), only when forced with HNH_MESH_CHUNKS: one launch per chunk.  This is
-    //    how the Infinity-Cache panel effect was found (16.8 -> 14.8 ms at config 2 with 2 chunks,
-    //    profiles/r01_panel_probe_same_box.log); by default a ring of one keeps whole blocks and the kernel library cuts
-    //    the same panels itself from the sorted CSR rows (hnh_kernels.h, `cols` hint), for every schedule.
-    // HNH_MESH_CHUNKS overrides the count (1 = whole blocks).
-    int chunks = 1;
-    int chunkA = 0, chunkB = 0;  // rows per chunk of a visiting A / B block
 
-    // hold_moving_operand(): the remote blocks of this matrix stay valid in mesh_spare / ring_spare[0] between calls
+    // Merged layout (approach 2 under the mesh fetch, more than one rank per ring).  The rank's S is kept as TWO blocks:
+    //   csr_blocks[0]  the block column it owns (visited at step 0, gathers from the caller's own dense block), and
+    //   csr_blocks[1]  ALL block columns visited at steps 1 .. n-1 as one CSR block whose column index is the row of the
+    //                  LANDING BUFFER the fetched dense rows arrive in.
+    // The landing buffer is chunk-major: the visiting blocks are cut into `windows` row chunks of chunkA / chunkB rows, and
+    // chunk q of the blocks of steps 1 .. n-1 lies at rows [(n-1) r0, (n-1)(r0 + w)), r0 = q * chunk, w = its height.  Fetch
+    // group q moves chunk q of every remote block (all n-1 links busy) and one WINDOWED row pass over csr_blocks[1]
+    // (hnh_csr_window: the columns of chunk q are a contiguous piece of every CSR row) runs as soon as it has landed, while
+    // chunk q+1 is still on the links.  The reference walks the same nonzeros block by block (15D_dense_shift.hpp:199-227);
+    // here a row's nonzeros of all fetched blocks are consecutive, so the gather batches of the row kernel stay full however
+    // many ranks and chunks there are.  HNH_MESH_CHUNKS sets `windows` (default 4, 1 = whole blocks).
+    bool merged = false;
+    int windows = 1;
+    int chunkA = 0, chunkB = 0;  // rows per chunk of a visiting A / B block
+    DenseMatrix landing[2];      // [0]: visiting B blocks (gathered through S), [1]: visiting A blocks (through ST)
+
+    // hold_moving_operand(): the remote blocks of this matrix stay valid in a landing buffer / ring_spare[0] between calls
     const double* held_ptr = nullptr;
-    bool held_in_mesh = false, held_in_ring = false;  // which landing buffers currently hold its remote blocks
+    int held_slot = -1;         // landing buffer that currently holds its remote blocks, or -1
+    bool held_in_ring = false;  // ... or ring_spare[0] (relay ring of two)
 
     void hold_moving_operand(const DenseMatrix* m) override {
         if (std::getenv("HNH_NO_HOLD") != nullptr) return;  // A/B switch for measurements
         held_ptr = m ? m->data() : nullptr;
-        held_in_mesh = held_in_ring = false;
+        held_slot = -1;
+        held_in_ring = false;
     }
     void release_moving_operand() override {
         held_ptr = nullptr;
-        held_in_mesh = held_in_ring = false;
+        held_slot = -1;
+        held_in_ring = false;
     }
 
     Sparse15D_Dense_Shift(SpmatLocal* S_input, int R, int c, int fusionApproach, KernelImplementation* k) : Distributed_Sparse(k) {
@@ -104,27 +111,43 @@ public:
         localBrows = divideAndRoundUp((int)this->N, p);
         setRValue(R);
 
-        if (fusionApproach == 2) {
-            if (p / c > 1) chunks = 4;  // a ring of one keeps whole blocks: the kernel library cuts its own cache panels
-            if (const char* q = std::getenv("HNH_MESH_CHUNKS")) chunks = std::atoi(q);
-            if (chunks < 1 || chunks > 8) hnh::fatal("Error, HNH_MESH_CHUNKS must be between 1 and 8!");
+        merged = (fusionApproach == 2 && ring_mode == kMeshFetch && p / c > 1);
+        windows = merged ? 4 : 1;
+        if (const char* q = std::getenv("HNH_MESH_CHUNKS")) {
+            const int v = std::atoi(q);
+            if (v < 1 || v > 8) hnh::fatal("Error, HNH_MESH_CHUNKS must be between 1 and 8!");
+            if (merged) windows = v;
         }
-        chunkA = divideAndRoundUp(localArows, chunks);
-        chunkB = divideAndRoundUp(localBrows, chunks);
+        chunkA = divideAndRoundUp(localArows, windows);
+        chunkB = divideAndRoundUp(localBrows, windows);
 
         const uint64_t arows = (uint64_t)localArows * c, brows = (uint64_t)localBrows * c;
         S->localize(arows, 0);
-        S->divideIntoBlockCols(localBrows, p, true, chunks, chunkB);
         ST->localize(brows, 0);
-        ST->divideIntoBlockCols(localArows, p, true, chunks, chunkA);
+        if (merged) {
+            lay_out_merged(S.get(), localBrows, chunkB);
+            lay_out_merged(ST.get(), localArows, chunkA);
+        } else {
+            S->divideIntoBlockCols(localBrows, p, true);
+            ST->divideIntoBlockCols(localArows, p, true);
+        }
 
         S->own_all_coordinates();
         ST->own_all_coordinates();
 
         const bool local_tpose = (fusionApproach == 1);
-        S->initializeCSRBlocks(localArows * c, chunkB, -1, local_tpose);
+        if (merged) {
+            const int n = p / c;
+            const std::vector<int64_t> wS = {localBrows, (int64_t)(n - 1) * localBrows}, wST = {localArows, (int64_t)(n - 1) * localArows};
+            S->initializeCSRBlocks(localArows * c, 0, -1, false, &wS);
+            ST->initializeCSRBlocks(localBrows * c, 0, -1, false, &wST);
+            set_chunk_windows(S.get(), localBrows, chunkB);
+            set_chunk_windows(ST.get(), localArows, chunkA);
+        } else {
+            S->initializeCSRBlocks(localArows * c, localBrows, -1, local_tpose);
+            ST->initializeCSRBlocks(localBrows * c, localArows, -1, local_tpose);
+        }
         S->release_tuples();
-        ST->initializeCSRBlocks(localBrows * c, chunkA, -1, local_tpose);
         ST->release_tuples();
         check_initialized();
     }
@@ -176,6 +199,99 @@ public:
     }
 
 private:
+    // ---- merged layout helpers
+    // visiting step of global block column b on this rank (block_at(k) == b), or -1 when the rank never visits it
+    int step_of_block(int b) const {
+        if (pMod(b - grid->rankInRow, c) != 0) return -1;
+        return pMod(grid->rankInCol - (b - grid->rankInRow) / c, p / c);
+    }
+    // first landing-buffer row of chunk q of the block fetched at step k >= 1 (br rows per block, cw rows per chunk)
+    int64_t landing_row(int k, int q, int br, int cw) const {
+        const int64_t r0 = std::min<int64_t>((int64_t)q * cw, br), w = std::min<int64_t>(cw, br - r0);
+        return (int64_t)(p / c - 1) * r0 + (int64_t)(k - 1) * w;
+    }
+    // Relabels the (row-localised, column-major) tuples' columns from global to "own block | landing-buffer row" and splits
+    // them into the two blocks of the merged layout.
+    void lay_out_merged(SpmatLocal* s, int br, int cw) {
+        const int n = p / c;
+        std::vector<int64_t> dest((size_t)p * windows, -1);
+        for (int b = 0; b < p; b++) {
+            const int k = step_of_block(b);
+            if (k < 0) continue;  // the distribution sends no nonzero of such a block column here
+            for (int q = 0; q < windows; q++) {
+                const int64_t r0 = (int64_t)q * cw;
+                if (r0 >= br) continue;  // chunk beyond the block's end
+                dest[(size_t)b * windows + q] = (k == 0) ? r0 : (int64_t)br + landing_row(k, q, br, cw);
+            }
+        }
+        s->remapColumns(br, cw, windows, dest);
+        s->sortColumnMajor((uint64_t)n * (uint64_t)br);
+        s->divideIntoLocalAndRemote(br, n);
+    }
+    void set_chunk_windows(SpmatLocal* s, int br, int cw) {
+        CSRLocal* remote = s->csr_blocks[1];
+        if (remote == nullptr || windows == 1) return;
+        std::vector<int32_t> bounds;
+        for (int q = 1; q < windows; q++) bounds.push_back((int32_t)((int64_t)(p / c - 1) * std::min<int64_t>((int64_t)q * cw, br)));
+        remote->set_windows(bounds);
+    }
+
+    // Issues the fetch of every remote block of a READ-ONLY moving operand into its landing buffer, chunk by chunk: group q
+    // moves chunk q of all n-1 blocks (explicit-peer pairs over n-1 different links) and event(8 + q) is recorded behind
+    // it.  Returns true when nothing had to move because a held operand's blocks are still there.
+    bool fetch_into_landing(DenseMatrix* start, int slot, int br, int cw) {
+        const int n = p / c;
+        ensure(landing[slot], (int64_t)(n - 1) * br, R);
+        auto t = phase_begin("Cyclic Shift Time");
+        order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // my block is final; earlier readers of the landing buffer are done
+        const bool held = (held_ptr == start->data());
+        if (!held && held_slot == slot) held_slot = -1;  // another operand lands here: a held one has to be fetched again
+        const bool resident = held && held_slot == slot;
+        for (int q = 0; q < windows; q++) {
+            const int64_t r0 = std::min<int64_t>((int64_t)q * cw, br), w = std::min<int64_t>(cw, br - r0);
+            const size_t bytes = (size_t)w * (size_t)R * sizeof(double);
+            if (bytes > 0 && !resident) {
+                world->group_begin();
+                for (int k = 1; k < n; k++)  // my block is what ring rank me+k needs at ITS step k; I need the block of me-k at mine
+                    world->sendrecv(grid->col_world, start->data() + r0 * R, bytes, pMod(grid->rankInCol + k, n),
+                                    landing[slot].data() + landing_row(k, q, br, cw) * R, bytes, pMod(grid->rankInCol - k, n), HNH_STREAM_COMM);
+                world->group_end();
+            }
+            world->event_record(event(8 + q), HNH_STREAM_COMM);
+        }
+        if (held) held_slot = slot;
+        phase_end(t);
+        return resident;
+    }
+
+    // The kernels of one pass in the merged layout: `one(block, Y, window, is_last)` is called for the own block (while the
+    // first chunk flies) and then for the fetched blocks — window by window as the chunks land, or in one piece when the
+    // data is already there or the kernel plugin does not understand windows.
+    template <typename One>
+    void walk_merged(SpmatLocal* choice, DenseMatrix* Brole, One&& one) {
+        const int slot = (choice == S.get()) ? 0 : 1;
+        const int br = slot == 0 ? localBrows : localArows, cw = slot == 0 ? chunkB : chunkA;
+        const bool resident = fetch_into_landing(Brole, slot, br, cw);
+        auto t = phase_begin("Computation Time");
+        CSRLocal* remote = choice->csr_blocks[1];
+        one(0, *Brole, -1, remote == nullptr);
+        if (remote != nullptr) {
+            const bool by_window = kernel->handles_windows() && remote->n_windows > 1 && !resident;
+            if (!by_window) {
+                world->event_wait(event(8 + windows - 1), HNH_STREAM_COMPUTE);  // every chunk has landed
+                one(1, landing[slot], -1, true);
+            } else {
+                for (int q = 0; q < windows; q++) {
+                    world->event_wait(event(8 + q), HNH_STREAM_COMPUTE);  // chunk q of every remote block has landed
+                    one(1, landing[slot], q, q == windows - 1);
+                }
+            }
+        } else {
+            world->event_wait(event(8 + windows - 1), HNH_STREAM_COMPUTE);  // keep the streams ordered for the next call
+        }
+        phase_end(t);
+    }
+
     // One pass of shifts with the fused kernel on every visiting block.  target == nullptr: the result replaces
     // Xin (the reference's in-place fusedSpMM); otherwise it is written to *target and Xin survives.
     void fused_pass(DenseMatrix& Xin, DenseMatrix& moving, SpmatLocal* choice, DenseMatrix* target, unsigned act_flag,
@@ -205,59 +321,25 @@ private:
         }
 
         const unsigned base = HNH_FUSED_VALUES_OVERWRITE | act_flag;
-        const int cw = (choice == S.get()) ? chunkB : chunkA;  // rows per chunk of the visiting blocks
         bool out_fresh = true;
-        // the fused kernel on the sub-blocks (ring step i, chunk q) of `steps` x `qs`, all in ONE launch
-        auto launch = [&](const std::vector<std::pair<int, DenseMatrix*>>& steps, int q_begin, int q_end, const hnh_fused_extras* ex) {
-            std::vector<DenseMatrix> views;
-            std::vector<DenseMatrix*> Ys;
-            std::vector<int> ids;
-            views.reserve(steps.size() * (size_t)(q_end - q_begin));
-            bool any = false;
-            for (auto& st : steps)
-                for (int q = q_begin; q < q_end; q++) {
-                    const int id = block_at(st.first) * chunks + q;
-                    views.push_back(chunk_view(*st.second, q, cw));
-                    Ys.push_back(&views.back());
-                    ids.push_back(id);
-                    any = any || choice->csr_blocks[id] != nullptr;
-                }
-            if (!any && ex == act) return;  // nothing to multiply and no epilogue to run
-            kernel->fused_multi_local(*choice, *rowOperand, Ys, *accum, ids, base | (out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u), ex);
+        // the fused kernel on one block (or one window of it); `ex` = what the call applies besides the multiplication
+        auto fused_on = [&](int block_id, DenseMatrix& Y, int window, const hnh_fused_extras* ex) {
+            CSRLocal* blk = choice->csr_blocks[block_id];
+            if (blk == nullptr && ex == act) return;  // nothing to multiply and no epilogue to run
+            if (blk != nullptr) blk->window = window;
+            kernel->fused_local(*choice, *rowOperand, Y, *accum, block_id, base | (out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u), ex);
+            if (blk != nullptr) blk->window = -1;
             out_fresh = false;
         };
 
-        if (ring_mode == kMeshFetch && n > 1) {
-            // the remote blocks arrive chunk by chunk over all links at once: local block while chunk 0 flies, then
-            // chunk q of ALL remote blocks in one launch while chunk q+1 is still on the links
-            std::vector<DenseMatrix*> fetched = mesh_fetch_chunked(Brole, n, cw);
-            auto t = phase_begin("Computation Time");
-            launch({{0, Brole}}, 0, chunks, act);
-            std::vector<std::pair<int, DenseMatrix*>> remote;
-            for (int i = 1; i < n; i++) remote.push_back({i, fetched[i - 1]});
-            for (int q = 0; q < chunks; q++) {
-                world->event_wait(event(8 + q), HNH_STREAM_COMPUTE);  // chunk q of every remote block has landed
-                launch(remote, q, q + 1, q == chunks - 1 ? last : act);
-            }
-            phase_end(t);
+        if (merged) {
+            walk_merged(choice, Brole, [&](int block_id, DenseMatrix& Y, int window, bool is_last) {
+                fused_on(block_id, Y, window, is_last ? last : act);
+            });
         } else {
             ring_readonly(Brole, n, [&](int i, DenseMatrix& cur) {
                 auto t = phase_begin("Computation Time");
-                const hnh_fused_extras* ex = (i == n - 1) ? last : act;
-                if (chunks == 1 || n == 1) {
-                    // the plain row kernel, one launch per block — or, on a ring of one, per column chunk: the panel of
-                    // `cur` that a launch gathers from then fits the Infinity Cache
-                    for (int q = 0; q < chunks; q++) {
-                        const int block_id = block_at(i) * chunks + q;
-                        const hnh_fused_extras* exq = (q == chunks - 1) ? ex : act;
-                        if (choice->csr_blocks[block_id] == nullptr && exq == act) continue;
-                        DenseMatrix part = chunk_view(cur, q, cw);
-                        kernel->fused_local(*choice, *rowOperand, part, *accum, block_id, base | (out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u), exq);
-                        out_fresh = false;
-                    }
-                } else {
-                    launch({{i, &cur}}, 0, chunks, ex);
-                }
+                fused_on(block_at(i), cur, -1, (i == n - 1) ? last : act);
                 phase_end(t);
             });
         }
@@ -318,38 +400,23 @@ public:
         if (fusionApproach == 2 && mode == k_spmmB) mode_temp = k_spmmA;
         DenseMatrix& stationary = (c > 1) ? accumulation_buffer : *Arole;
 
-        const int cw = (choice == S.get()) ? chunkB : chunkA;
-        auto step = [&](int i, DenseMatrix& cur) {
-            auto t = phase_begin("Computation Time");
-            if (chunks == 1) {
-                kernel->triple_function(mode_temp, *choice, stationary, cur, block_at(i), 0);
-            } else {  // approach 2 keeps S in column chunks of each block: same kernels on each chunk's rows of `cur`
-                for (int q = 0; q < chunks; q++) {
-                    DenseMatrix part = chunk_view(cur, q, cw);
-                    kernel->triple_function(mode_temp, *choice, stationary, part, block_at(i) * chunks + q, 0);
-                }
-            }
-            phase_end(t);
-        };
-
         // the moving operand is written only when it is the SpMM accumulator (approach 1)
         const bool moving_readonly = is_sddmm || fusionApproach == 2;
-        if (moving_readonly && chunks > 1 && ring_mode == kMeshFetch && n > 1) {
-            // chunk-pipelined mesh fetch, as in the fused pass: local block while chunk 0 flies, then chunk q of every
-            // remote block while chunk q+1 is still on the links (same kernels on the same sub-blocks; only the order of
-            // the steps differs from the reference's block-by-block walk)
-            std::vector<DenseMatrix*> fetched = mesh_fetch_chunked(Brole, n, cw);
+        auto step = [&](int i, DenseMatrix& cur) {
             auto t = phase_begin("Computation Time");
-            auto one = [&](int i, DenseMatrix& blk, int q) {
-                DenseMatrix part = chunk_view(blk, q, cw);
-                kernel->triple_function(mode_temp, *choice, stationary, part, block_at(i) * chunks + q, 0);
-            };
-            for (int q = 0; q < chunks; q++) one(0, *Brole, q);
-            for (int q = 0; q < chunks; q++) {
-                world->event_wait(event(8 + q), HNH_STREAM_COMPUTE);  // chunk q of every remote block has landed
-                for (int i = 1; i < n; i++) one(i, *fetched[i - 1], q);
-            }
+            kernel->triple_function(mode_temp, *choice, stationary, cur, block_at(i), 0);
             phase_end(t);
+        };
+        if (merged) {
+            // same kernels on the same nonzeros as the reference's block-by-block walk; the fetched blocks' share runs
+            // window by window as the chunks land
+            walk_merged(choice, Brole, [&](int block_id, DenseMatrix& Y, int window, bool) {
+                CSRLocal* blk = choice->csr_blocks[block_id];
+                if (blk == nullptr) return;
+                blk->window = window;
+                kernel->triple_function(mode_temp, *choice, stationary, Y, block_id, 0);
+                blk->window = -1;
+            });
         } else if (moving_readonly) {
             ring_readonly(Brole, n, step);
         } else {
@@ -375,13 +442,9 @@ private:
         if (m.rows() != rows || m.cols() != cols) m = DenseMatrix(rows, cols);
     }
 
-    // n kernel steps over a READ-ONLY moving operand, n-1 overlapped shifts, caller's buffer untouched.
+    // n kernel steps over a READ-ONLY moving operand on the neighbour ring: n-1 overlapped shifts, caller's buffer untouched.
     template <typename Step>
     void ring_readonly(DenseMatrix* start, int n, Step&& step) {
-        if (ring_mode == kMeshFetch && n > 2) {  // with two ranks the relay ring already is a single direct transfer
-            mesh_readonly(start, n, step);
-            return;
-        }
         if (n > 1) {
             for (auto& s : ring_spare) ensure(s, start->rows(), start->cols());
             order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // inputs (and earlier readers of the spares) are done
@@ -406,77 +469,6 @@ private:
                 cur = target;
                 phase_end(t);
             }
-        }
-    }
-
-    // rows [q * cw, (q + 1) * cw) of a visiting block (clipped; possibly empty)
-    static DenseMatrix chunk_view(DenseMatrix& block, int q, int cw) {
-        const int64_t r0 = std::min<int64_t>((int64_t)q * cw, block.rows());
-        const int64_t r1 = std::min<int64_t>(r0 + cw, block.rows());
-        return DenseMatrix::view(block.data() + r0 * block.cols(), r1 - r0, block.cols());
-    }
-
-    // mesh_fetch_all in `chunks` row ranges: group q moves rows [q*cw, (q+1)*cw) of every remote block (all n-1 links
-    // busy in every group) and event(8 + q) is recorded behind it, so consumers can start on chunk q while q+1 flies.
-    std::vector<DenseMatrix*> mesh_fetch_chunked(DenseMatrix* start, int n, int cw) {
-        if ((int)mesh_spare.size() < n - 1) mesh_spare.resize(n - 1);
-        for (int k = 0; k < n - 1; k++) ensure(mesh_spare[k], start->rows(), start->cols());
-        auto t = phase_begin("Cyclic Shift Time");
-        order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // my block is final; earlier readers of the landing buffers are done
-        const bool held = (held_ptr == start->data());
-        if (!held) held_in_mesh = false;  // another operand lands in the buffers: a held one has to be fetched again
-        for (int q = 0; q < chunks; q++) {
-            const int64_t r0 = std::min<int64_t>((int64_t)q * cw, start->rows()), r1 = std::min<int64_t>(r0 + cw, start->rows());
-            const size_t off = (size_t)r0 * start->cols(), bytes = (size_t)(r1 - r0) * start->cols() * sizeof(double);
-            if (bytes > 0 && !(held && held_in_mesh)) {  // a held operand's blocks are still in the landing buffers
-                world->group_begin();
-                for (int k = 1; k < n; k++)  // my block is what ring rank me+k needs at ITS step k; I need the block of me-k at mine
-                    world->sendrecv(grid->col_world, start->data() + off, bytes, pMod(grid->rankInCol + k, n), mesh_spare[k - 1].data() + off,
-                                    bytes, pMod(grid->rankInCol - k, n), HNH_STREAM_COMM);
-                world->group_end();
-            }
-            world->event_record(event(8 + q), HNH_STREAM_COMM);
-        }
-        if (held) held_in_mesh = true;
-        phase_end(t);
-        std::vector<DenseMatrix*> out;
-        for (int k = 0; k < n - 1; k++) out.push_back(&mesh_spare[k]);
-        return out;
-    }
-
-    // Issues all n-1 owner->consumer transfers of a read-only moving operand as one group on the communication
-    // stream and records event(1) behind them; returns the landing buffers in visiting order (step 1 .. n-1).
-    std::vector<DenseMatrix*> mesh_fetch_all(DenseMatrix* start, int n) {
-        if ((int)mesh_spare.size() < n - 1) mesh_spare.resize(n - 1);
-        for (int k = 0; k < n - 1; k++) ensure(mesh_spare[k], start->rows(), start->cols());
-        const size_t bytes = (size_t)start->size() * sizeof(double);
-        auto t = phase_begin("Cyclic Shift Time");
-        order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // my block is final; earlier readers of the landing buffers are done
-        const bool held = (held_ptr == start->data());
-        if (!held) held_in_mesh = false;  // another operand lands in the buffers: a held one has to be fetched again
-        if (!(held && held_in_mesh)) {  // a held operand's blocks are still in the landing buffers from the previous call
-            world->group_begin();
-            for (int k = 1; k < n; k++)  // my block is what ring rank me+k needs at ITS step k; I need the block of me-k at mine
-                world->sendrecv(grid->col_world, start->data(), bytes, pMod(grid->rankInCol + k, n), mesh_spare[k - 1].data(), bytes,
-                                pMod(grid->rankInCol - k, n), HNH_STREAM_COMM);
-            world->group_end();
-        }
-        if (held) held_in_mesh = true;
-        world->event_record(event(1), HNH_STREAM_COMM);
-        phase_end(t);
-        std::vector<DenseMatrix*> out;
-        for (int k = 0; k < n - 1; k++) out.push_back(&mesh_spare[k]);
-        return out;
-    }
-
-    // Same n kernel steps on the same blocks, but every block comes straight from its owner: the transfers
-    // overlap with step 0's kernel.
-    template <typename Step>
-    void mesh_readonly(DenseMatrix* start, int n, Step&& step) {
-        std::vector<DenseMatrix*> fetched = mesh_fetch_all(start, n);
-        for (int i = 0; i < n; i++) {
-            if (i == 1) world->event_wait(event(1), HNH_STREAM_COMPUTE);  // the remote blocks have landed
-            step(i, i == 0 ? *start : *fetched[i - 1]);
         }
     }
 

@@ -14,6 +14,14 @@ size_t StandardKernel::sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
     CSRHandle* active = blk->getActive();
     hnh::World* w = S.world;
     begin(w);
+    hnh_csr_window win;
+    if (blk->window_args(&win)) {  // one column range of the block (the schedule walks them as their data arrives)
+        w->check(w->be->hnh_sddmm_csr_w(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, Xptr, Yptr, (int)A.cols(),
+                                        blk->num_coords, blk->row_hint(), &win, HNH_STREAM_COMPUTE),
+                 "hnh_sddmm_csr_w");
+        end(w);
+        return processed;
+    }
     w->check(w->be->hnh_sddmm_csr_ex(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, Xptr, Yptr,
                                      (int)A.cols(), blk->num_coords, blk->row_hint(), blk->cols, HNH_STREAM_COMPUTE),
              "hnh_sddmm_csr");
@@ -34,6 +42,14 @@ size_t StandardKernel::spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B,
     const double* X = (mode == Amat) ? B.data() : A.data();
     double* Out = (mode == Amat) ? A.data() : B.data();
     begin(w);
+    hnh_csr_window win;
+    if (blk->window_args(&win)) {
+        w->check(w->be->hnh_spmm_csr_w(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, X, Out, (int)A.cols(),
+                                       blk->num_coords, blk->row_hint(), &win, HNH_STREAM_COMPUTE),
+                 "hnh_spmm_csr_w");
+        end(w);
+        return processed;
+    }
     w->check(w->be->hnh_spmm_csr_ex(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, X, Out, (int)A.cols(),
                                     blk->num_coords, blk->row_hint(), blk->cols, HNH_STREAM_COMPUTE),
              "hnh_spmm_csr");
@@ -56,6 +72,16 @@ size_t StandardKernel::fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
     if (blk->transpose) hnh::fatal("Error, local matrix is transposed, can't perform the fused SDDMM+SpMM");
     CSRHandle* active = blk->getActive();
     begin(w);
+    hnh_csr_window win;
+    if (blk->window_args(&win)) {
+        if (wants_epilogue(extras) && !win.last) hnh::fatal("Error, the row epilogue belongs to the block's last window!");
+        w->check(w->be->hnh_fused_sddmm_spmm_csr_w(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, nullptr, A.data(), B.data(),
+                                                   Out.data(), (int)A.cols(), flags, blk->num_coords, blk->row_hint(), extras, &win,
+                                                   HNH_STREAM_COMPUTE),
+                 "hnh_fused_sddmm_spmm_csr_w");
+        end(w);
+        return 0;
+    }
     w->check(w->be->hnh_fused_sddmm_spmm_csr_x(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, nullptr, A.data(),
                                                B.data(), Out.data(), (int)A.cols(), flags, blk->num_coords, blk->row_hint(), blk->cols, extras,
                                                HNH_STREAM_COMPUTE),

@@ -71,6 +71,11 @@ public:
         return n;
     }
 
+    // Row windows (CSRLocal::window): a schedule may select one column range of a block before calling the kernels, to
+    // work on data that arrives piece by piece.  An implementation that honours CSRLocal::window says so here; for the
+    // others (plugins written against the reference's two pure virtuals) the schedule waits for the whole block instead.
+    virtual bool handles_windows() const { return false; }
+
     static bool wants_epilogue(const hnh_fused_extras* extras) { return extras && (extras->x_scale != 0.0 || extras->rowdot != nullptr); }
     static void row_epilogue(hnh::World* w, DenseMatrix& X, DenseMatrix& Out, const hnh_fused_extras* extras) {
         if (!wants_epilogue(extras)) return;
@@ -97,6 +102,7 @@ public:
     double kernel_ms = 0.0;
     long kernel_launches = 0;
 
+    bool handles_windows() const override { return true; }
     size_t sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, int block, int offset) override;
     size_t spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, MatMode mode, int block) override;
     size_t fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, DenseMatrix& Out, int block, unsigned flags,

@@ -66,6 +66,32 @@ public:
     // arrays of EVERY block of its ring (config 3 sized: 8 x 6.8 MB), so a travelling block can leave its indices
     // at home: after replicate_ring_indices() each shift moves `values` only (8 B per nonzero instead of 12 B plus
     // a row pointer array) and just re-points the active handle at the resident indices of the arriving block.
+    // Row windows (hnh_csr_window of hnh_kernels.h): the block's columns are cut at `bounds` into n_windows column ranges;
+    // win_split[(q - 1) * rows + r] = first nonzero of row r in window q (device).  `window` selects the one the local
+    // kernels work on (-1 = the whole block); the 1.5D dense-shift schedule walks them as the fetched chunks arrive.
+    int32_t* win_split = nullptr;
+    int n_windows = 1;
+    int window = -1;
+    void set_windows(const std::vector<int32_t>& bounds) {
+        if (win_split) world->dfree(win_split);
+        win_split = nullptr;
+        n_windows = (int)bounds.size() + 1;
+        window = -1;
+        if (bounds.empty()) return;
+        win_split = static_cast<int32_t*>(world->dmalloc(bounds.size() * (size_t)std::max<int64_t>(rows, 1) * sizeof(int32_t)));
+        world->check(world->be->hnh_csr_window_bounds(world->ctx, rows, buffer[0].rowStart, buffer[0].col_idx, (int)bounds.size(), bounds.data(),
+                                                      win_split, HNH_STREAM_COMPUTE),
+                     "hnh_csr_window_bounds");
+    }
+    // the kernel-ABI description of the selected window; false when the whole block is selected
+    bool window_args(hnh_csr_window* w) const {
+        if (window < 0 || n_windows <= 1) return false;
+        w->beg = (window == 0) ? nullptr : win_split + (size_t)(window - 1) * (size_t)rows;
+        w->end = (window == n_windows - 1) ? nullptr : win_split + (size_t)window * (size_t)rows;
+        w->last = (window == n_windows - 1) ? 1 : 0;
+        return true;
+    }
+
     struct RingIndex {
         int32_t* col_idx = nullptr;
         int32_t* rowStart = nullptr;
@@ -185,6 +211,7 @@ public:
             world->dfree(ri.col_idx);
             world->dfree(ri.rowStart);
         }
+        world->dfree(win_split);
         delete[] buffer;
     }
 
@@ -344,12 +371,14 @@ public:
 
     // One CSRLocal per non-empty block column (max_nnz == -1; stationary), or a single padded block
     // that will travel around a ring (SpmatLocal.hpp:314-338).
-    void initializeCSRBlocks(int blockRows, int blockCols, int max_nnz, bool transpose) {
+    // `widths` (optional, max_nnz == -1 only): the column count of every block when they differ
+    void initializeCSRBlocks(int blockRows, int blockCols, int max_nnz, bool transpose, const std::vector<int64_t>* widths = nullptr) {
+        auto width = [&](size_t i) { return widths ? (*widths)[i] : (int64_t)blockCols; };
         if (resident) {
             if (max_nnz == -1) {
                 for (size_t i = 0; i + 1 < blockStarts.size(); i++) {
                     const int n = (int)(blockStarts[i + 1] - blockStarts[i]);
-                    csr_blocks.push_back(n > 0 ? new CSRLocal(CSRLocal::FromDevice(), blockRows, blockCols, n,
+                    csr_blocks.push_back(n > 0 ? new CSRLocal(CSRLocal::FromDevice(), blockRows, width(i), n,
                                                               reinterpret_cast<spcoord_t*>(dptr() + blockStarts[i]), n, transpose, false)
                                                : nullptr);
                 }
@@ -364,7 +393,7 @@ public:
         if (max_nnz == -1) {
             for (size_t i = 0; i + 1 < blockStarts.size(); i++) {
                 const int n = (int)(blockStarts[i + 1] - blockStarts[i]);
-                csr_blocks.push_back(n > 0 ? new CSRLocal(blockRows, blockCols, n, coords.data() + blockStarts[i], n, transpose, false)
+                csr_blocks.push_back(n > 0 ? new CSRLocal(blockRows, width(i), n, coords.data() + blockStarts[i], n, transpose, false)
                                            : nullptr);
             }
         } else {
@@ -575,6 +604,60 @@ public:
             if (id >= nblocks) hnh::fatal("Error, more block columns than expected!");
             while (next <= id) blockStarts[next++] = i;
             if (modIndex) coords[i].c = in % (uint64_t)chunkWidth;
+        }
+    }
+
+    // Piecewise relabelling of the column indices (hnh_tuples_remap_cols): segment seg = (c / div) * n_sub + (c % div) / sub_div
+    // moves to dest[seg], offsets inside a segment are kept; a negative dest marks a segment that must be empty.
+    void remapColumns(int64_t div, int64_t sub_div, int64_t n_sub, const std::vector<int64_t>& dest) {
+        if (resident) {
+            world->check(world->be->hnh_tuples_remap_cols(world->ctx, dptr(), (int64_t)n_resident, div, sub_div, n_sub, dest.data(),
+                                                          (int64_t)dest.size(), HNH_STREAM_COMPUTE),
+                         "hnh_tuples_remap_cols");
+            return;
+        }
+        bool bad = false;
+#pragma omp parallel for reduction(|| : bad)
+        for (size_t e = 0; e < coords.size(); e++) {
+            const uint64_t in = coords[e].c % (uint64_t)div, seg = (coords[e].c / (uint64_t)div) * (uint64_t)n_sub + in / (uint64_t)sub_div;
+            if (seg >= dest.size() || dest[seg] < 0) { bad = true; continue; }
+            coords[e].c = (uint64_t)dest[seg] + in % (uint64_t)sub_div;
+        }
+        if (bad) hnh::fatal("Error, a nonzero lies in a column segment that has no destination!");
+    }
+
+    // restores the column-major order divideIntoBlockCols() expects (after remapColumns)
+    void sortColumnMajor(uint64_t ncols) {
+        if (resident) {
+            hnh_tuple_key ckey{};
+            ckey.kind = HNH_KEY_COL_ROW;
+            int col_bits = 1;
+            while (col_bits < 32 && ((uint64_t)1 << col_bits) < ncols) col_bits++;
+            world->check(world->be->hnh_tuples_sort(world->ctx, dptr(), (int64_t)n_resident, &ckey, 32 + col_bits, HNH_STREAM_COMPUTE),
+                         "hnh_tuples_sort (column-major)");
+            return;
+        }
+        __gnu_parallel::sort(coords.begin(), coords.end(), column_major);
+    }
+
+    // Two unequal block columns: block 0 = columns [0, width0), block 1 = [width0, width0 * parts) with its column indices
+    // made block-local.  (The 1.5D dense-shift schedule under the mesh fetch: the rank's own block column, and all fetched
+    // block columns as one block whose columns index the landing buffer.)
+    void divideIntoLocalAndRemote(int64_t width0, int parts) {
+        divideIntoBlockCols((int)width0, parts, false);  // parts uniform block columns of width0 ...
+        const uint64_t cut = blockStarts[1], total = blockStarts[(size_t)parts];
+        blockStarts = {0, cut, total};                   // ... of which all but the first are merged
+        const size_t n1 = (size_t)(total - cut);
+        if (n1 == 0) return;
+        if (resident) {
+            std::vector<int64_t> dest((size_t)parts);
+            for (int b = 0; b < parts; b++) dest[(size_t)b] = (b == 0) ? -1 : (int64_t)(b - 1) * width0;
+            world->check(world->be->hnh_tuples_remap_cols(world->ctx, dptr() + cut, (int64_t)n1, width0, width0, 1, dest.data(), parts,
+                                                          HNH_STREAM_COMPUTE),
+                         "hnh_tuples_remap_cols");
+        } else {
+#pragma omp parallel for
+            for (size_t e = (size_t)cut; e < (size_t)total; e++) coords[e].c -= (uint64_t)width0;
         }
     }
 

@@ -121,6 +121,27 @@ int hnh_csr_max_row_nnz(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, int* 
 /* number of kernel launches (column panels) a row pass with these hints is run as; 1 = a single launch (profiling aid) */
 int hnh_panel_count(hnh_ctx* ctx, int64_t cols, int R, int max_row_nnz);
 
+/* Row WINDOWS.  A window restricts a row pass to a contiguous piece [beg[r], end[r]) of every CSR row (column indices are
+ * sorted within a row, so "the nonzeros whose column lies in [c0, c1)" is such a piece).  The 1.5D dense-shift schedule keeps
+ * all blocks fetched from the other ranks as ONE CSR block whose columns index the landing buffer in arrival order, and runs
+ * one windowed pass per arrived chunk, overlapping kernels with the fetch (15D_dense_shift.hpp:199-227 walks the same
+ * nonzeros block by block); the kernel library's own Infinity-Cache panels are the same mechanism with automatic bounds.
+ *   hnh_csr_window_bounds  split[b * rows + r] = first nonzero of row r with column >= bounds_host[b]  (b < nbounds <= 15)
+ *   *_w entry points       as the _ex / _x entry points, on the window only.  Hub rows (longer than 1024 nonzeros) are left
+ *                          whole: they are skipped by every window and processed — over their whole length — by the call
+ *                          whose window has `last` set, which is also the call that applies a row epilogue. */
+typedef struct hnh_csr_window {
+    const int32_t* beg; /* device, rows entries; NULL = rowptr */
+    const int32_t* end; /* device, rows entries; NULL = rowptr + 1 */
+    int last;           /* non-zero: the pass's last window */
+} hnh_csr_window;
+int hnh_csr_window_bounds(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, int nbounds,
+                          const int32_t* bounds_host, int32_t* split, int stream);
+int hnh_sddmm_csr_w(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values, const double* X,
+                    const double* Y, int R, int64_t nnz, int max_row_nnz, const hnh_csr_window* window, int stream);
+int hnh_spmm_csr_w(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values, const double* X,
+                   double* Out, int R, int64_t nnz, int max_row_nnz, const hnh_csr_window* window, int stream);
+
 /* Extras of the fused pass — what the reference's applications do immediately around their SDDMM->SpMM pair,
  * folded into the same launch while the operands are still in registers:
  *   leaky_alpha  with HNH_FUSED_LEAKY_RELU: the SpMM half uses (and values[] keeps)
@@ -138,6 +159,9 @@ typedef struct hnh_fused_extras {
 int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
                                const double* svalues, const double* X, const double* Y, double* Out, int R, unsigned flags,
                                int64_t nnz, int max_row_nnz, int64_t cols, const hnh_fused_extras* extras, int stream);
+int hnh_fused_sddmm_spmm_csr_w(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
+                               const double* svalues, const double* X, const double* Y, double* Out, int R, unsigned flags,
+                               int64_t nnz, int max_row_nnz, const hnh_fused_extras* extras, const hnh_csr_window* window, int stream);
 int hnh_row_epilogue_f64(hnh_ctx* ctx, double* Out, const double* X, double x_scale, double* rowdot, int64_t rows, int R, int stream);
 
 /* hnh_fused_sddmm_spmm_csr_multi — the fused pass over SEVERAL blocks that share their rows (the p/c blocks one rank
@@ -212,6 +236,12 @@ int hnh_tuples_sort(hnh_ctx* ctx, hnh_tuple* tuples, int64_t n, const hnh_tuple_
 int hnh_tuples_bucket_starts(hnh_ctx* ctx, const hnh_tuple* sorted, int64_t n, const hnh_tuple_key* key, int64_t nbuckets,
                              int64_t* starts_host, int stream);
 int hnh_tuples_transform(hnh_ctx* ctx, hnh_tuple* tuples, int64_t n, int swap_rc, uint64_t rmod, uint64_t cmod, int stream);
+/* hnh_tuples_remap_cols  piecewise relabelling of column indices: with seg = (c / div) * n_sub + (c % div) / sub_div,
+ *                        c <- dest_host[seg] + (c % div) % sub_div.  The 1.5D dense-shift schedule maps (block column, chunk)
+ *                        to the position of that chunk in its landing buffer with it; a negative dest marks a segment that
+ *                        must be empty (HNH_ERR_INVALID otherwise); synchronous */
+int hnh_tuples_remap_cols(hnh_ctx* ctx, hnh_tuple* tuples, int64_t n, int64_t div, int64_t sub_div, int64_t n_sub,
+                          const int64_t* dest_host, int64_t ndest, int stream);
 int hnh_tuples_to_csr(hnh_ctx* ctx, const hnh_tuple* sorted, int64_t n, int64_t rows, int64_t cols, int32_t* rowptr,
                       int32_t* col_idx, double* values, int* max_row_nnz_host, int stream);
 /* Synthetic input on the device (replaces CombBLAS GenGraph500Data with initiator {.25,.25,.25,.25}, SpmatLocal.hpp:502-505):

@@ -225,6 +225,87 @@ int hnh_fused_sddmm_spmm_csr_multi(hnh_ctx* c, int64_t rows, int nblocks, const 
     return hnh_fused_sddmm_spmm_csr_multi_x(c, rows, nblocks, blocks, X, Out, R, flags, NULL, stream);
 }
 
+/* ---- row windows (hnh_csr_window): the same loops over [beg[r], end[r]) of every row */
+int hnh_csr_window_bounds(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, int nbounds, const int32_t* bounds,
+                          int32_t* split, int stream) {
+    (void)stream;
+    if (rows < 0 || nbounds < 0 || nbounds > 15) return fail(c, HNH_ERR_INVALID, "bad size");
+    for (int b = 0; b < nbounds; b++)
+        for (int64_t r = 0; r < rows; r++) {
+            int32_t e = rowptr[r];
+            while (e < rowptr[r + 1] && col_idx[e] < bounds[b]) e++;
+            split[(int64_t)b * rows + r] = e;
+        }
+    return HNH_OK;
+}
+
+int hnh_sddmm_csr_w(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values, const double* X,
+                    const double* Y, int R, int64_t nnz, int max_row_nnz, const hnh_csr_window* w, int stream) {
+    (void)stream; (void)nnz; (void)max_row_nnz;
+    if (rows < 0 || R <= 0 || !w) return fail(c, HNH_ERR_INVALID, "bad argument");
+    for (int64_t r = 0; r < rows; r++) {
+        const int32_t b = w->beg ? w->beg[r] : rowptr[r], e = w->end ? w->end[r] : rowptr[r + 1];
+        for (int32_t i = b; i < e; i++) {
+            const double* Arow = X + (int64_t)R * r;
+            const double* Brow = Y + (int64_t)R * col_idx[i];
+            double value = 0.0;
+            for (int k = 0; k < R; k++) value += Arow[k] * Brow[k];
+            values[i] += value;
+        }
+    }
+    return HNH_OK;
+}
+
+int hnh_spmm_csr_w(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values, const double* X,
+                   double* Out, int R, int64_t nnz, int max_row_nnz, const hnh_csr_window* w, int stream) {
+    (void)stream; (void)nnz; (void)max_row_nnz;
+    if (rows < 0 || R <= 0 || !w) return fail(c, HNH_ERR_INVALID, "bad argument");
+    if (X == Out) return fail(c, HNH_ERR_INVALID, "X and Out alias");
+    for (int64_t r = 0; r < rows; r++) {
+        const int32_t b = w->beg ? w->beg[r] : rowptr[r], e = w->end ? w->end[r] : rowptr[r + 1];
+        for (int32_t i = b; i < e; i++) {
+            const double v = values[i];
+            const double* Xrow = X + (int64_t)R * col_idx[i];
+            double* Crow = Out + (int64_t)R * r;
+            for (int k = 0; k < R; k++) Crow[k] += v * Xrow[k];
+        }
+    }
+    return HNH_OK;
+}
+
+int hnh_fused_sddmm_spmm_csr_w(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
+                               const double* svalues, const double* X, const double* Y, double* Out, int R, unsigned flags,
+                               int64_t nnz, int max_row_nnz, const hnh_fused_extras* ex, const hnh_csr_window* w, int stream) {
+    if (rows < 0 || R <= 0 || !w) return fail(c, HNH_ERR_INVALID, "bad argument");
+    if ((flags & HNH_FUSED_LEAKY_RELU) && !ex) return fail(c, HNH_ERR_INVALID, "HNH_FUSED_LEAKY_RELU needs extras");
+    const int epilogue = ex && (ex->x_scale != 0.0 || ex->rowdot);
+    if (epilogue && !w->last) return fail(c, HNH_ERR_INVALID, "a row epilogue belongs to the last window");
+    if (rows == 0) return HNH_OK;
+    if (flags & HNH_FUSED_OUT_OVERWRITE) memset(Out, 0, sizeof(double) * (size_t)rows * (size_t)R);
+    for (int64_t r = 0; r < rows; r++) {
+        const int32_t b = w->beg ? w->beg[r] : rowptr[r], e = w->end ? w->end[r] : rowptr[r + 1];
+        if (flags & HNH_FUSED_VALUES_OVERWRITE)
+            for (int32_t i = b; i < e; i++) values[i] = 0.0;
+    }
+    int rc = hnh_sddmm_csr_w(c, rows, rowptr, col_idx, values, X, Y, R, nnz, max_row_nnz, w, stream);
+    if (rc != HNH_OK) return rc;
+    for (int64_t r = 0; r < rows; r++) {  /* the weights of the SpMM half: values, times svalues, activated (and kept) with LEAKY_RELU */
+        const int32_t b = w->beg ? w->beg[r] : rowptr[r], e = w->end ? w->end[r] : rowptr[r + 1];
+        for (int32_t i = b; i < e; i++) {
+            double v = values[i] * (svalues ? svalues[i] : 1.0);
+            if (flags & HNH_FUSED_LEAKY_RELU) {
+                v = v > 0.0 ? v : ex->leaky_alpha * v;
+                values[i] = v;
+            }
+            const double* Yrow = Y + (int64_t)R * col_idx[i];
+            double* Crow = Out + (int64_t)R * r;
+            for (int k = 0; k < R; k++) Crow[k] += v * Yrow[k];
+        }
+    }
+    if (epilogue) return hnh_row_epilogue_f64(c, Out, X, ex->x_scale, ex->rowdot, rows, R, stream);
+    return HNH_OK;
+}
+
 /* als_conjugate_gradients.cpp:117-127 */
 int hnh_cg_step_f64(hnh_ctx* c, double* X, double* Rm, const double* P, const double* MP, const double* alpha, double* rsnew,
                     int64_t rows, int R, int stream) {
@@ -414,6 +495,19 @@ int hnh_tuples_transform(hnh_ctx* c, hnh_tuple* t, int64_t n, int swap_rc, uint6
     }
     return HNH_OK;
 }
+int hnh_tuples_remap_cols(hnh_ctx* c, hnh_tuple* t, int64_t n, int64_t div, int64_t sub_div, int64_t n_sub, const int64_t* dest,
+                          int64_t ndest, int stream) {
+    (void)stream;
+    if (n < 0 || div <= 0 || sub_div <= 0 || n_sub <= 0 || ndest <= 0 || !dest) return fail(c, HNH_ERR_INVALID, "bad argument");
+    for (int64_t i = 0; i < n; i++) {
+        const uint64_t col = t[i].c, in = col % (uint64_t)div;
+        const uint64_t seg = (col / (uint64_t)div) * (uint64_t)n_sub + in / (uint64_t)sub_div;
+        if ((int64_t)seg >= ndest || dest[seg] < 0) return fail(c, HNH_ERR_INVALID, "a tuple lies in a segment that has no destination");
+        t[i].c = (uint64_t)dest[seg] + in % (uint64_t)sub_div;
+    }
+    return HNH_OK;
+}
+
 int hnh_tuples_to_csr(hnh_ctx* c, const hnh_tuple* t, int64_t n, int64_t rows, int64_t cols, int32_t* rowptr, int32_t* col_idx,
                       double* values, int* max_row, int stream) {
     (void)stream;
