@@ -353,7 +353,7 @@ def run(args, make_world=gpu_world):
                          "traffic_source": "profiles/hbm_traffic.json (static: rocprofv3 FETCH_SIZE/WRITE_SIZE passes of an earlier run of "
                                            "this command, not collected live)" if traffic is not None else None,
                          "kernel": ("row_kernel<fused> (hnh_fused_sddmm_spmm_csr), one launch per Infinity-Cache panel of B" if n == 1 else
-                                    "fused_multi_kernel (hnh_fused_sddmm_spmm_csr_multi), local block + one launch per fetched chunk"),
+                                    "row_kernel<fused> (hnh_fused_sddmm_spmm_csr / _w): own block, then one windowed pass over the fetched blocks per landed chunk"),
                          "avg_launch_ms": dur * 1e3,
                          "launches_per_step": launches_per_call, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "model": "per fused call nnz*(8R+24) + 16*R*rows (SURVEY 8d), divided evenly over its launches"},

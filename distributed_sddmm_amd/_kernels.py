@@ -49,9 +49,7 @@ SIGNATURES = {
     "hnh_spmm_csr_w": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _i32]),
     "hnh_fused_sddmm_spmm_csr_w": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _i64, _i32, _vp, _vp, _i32]),
     "hnh_csr_max_row_nnz": (_i32, [_vp, _i64, _vp, C.POINTER(C.c_int), _i32]),
-    "hnh_fused_sddmm_spmm_csr_multi": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, C.c_uint, _i32]),
     "hnh_fused_sddmm_spmm_csr_x": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _i64, _i32, _i64, _vp, _i32]),
-    "hnh_fused_sddmm_spmm_csr_multi_x": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, C.c_uint, _vp, _i32]),
     "hnh_row_epilogue_f64": (_i32, [_vp, _vp, _vp, C.c_double, _vp, _i64, _i32, _i32]),
     "hnh_cg_step_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "hnh_tuples_sort": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32]),
@@ -94,16 +92,16 @@ class FusedExtras(C.Structure):
 class TupleKey(C.Structure):
     """struct hnh_tuple_key"""
     _fields_ = [("kind", C.c_int), ("transpose", C.c_int), ("rows_in_block", C.c_int64), ("cols_in_block", C.c_int64),
-                ("n_col_blocks", C.c_int64), ("owner_table", C.c_void_p), ("div", C.c_int64), ("sub_div", C.c_int64), ("n_sub", C.c_int64)]
+                ("n_col_blocks", C.c_int64), ("owner_table", C.c_void_p), ("div", C.c_int64)]
 
 
-KEY_ROW_COL, KEY_COL_ROW, KEY_OWNER, KEY_COL_DIV, KEY_COL_DIV2 = 0, 1, 2, 3, 4
+KEY_ROW_COL, KEY_COL_ROW, KEY_OWNER, KEY_COL_DIV = 0, 1, 2, 3
 TUPLE_DTYPE = [("r", "<u8"), ("c", "<u8"), ("value", "<f8")]  # struct hnh_tuple
 
 
-class CsrBlock(C.Structure):
-    """struct hnh_csr_block"""
-    _fields_ = [("rowptr", _vp), ("col_idx", _vp), ("values", _vp), ("Y", _vp), ("nnz", _i64), ("max_row_nnz", _i32)]
+class CsrWindow(C.Structure):
+    """struct hnh_csr_window"""
+    _fields_ = [("beg", _vp), ("end", _vp), ("last", _i32)]
 
 
 _lib = None

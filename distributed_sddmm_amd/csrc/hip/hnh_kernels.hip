@@ -496,119 +496,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HNH_ROW_
     process_row<OP, LPR, VEC, W, EXACT>(row, beg, end, false, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, lig, ex);
 }
 
-// ---------------------------------------------------------------- fused pass over SEVERAL blocks of one block row
-// The mesh-fetch schedule has all ring blocks resident at once; walking them in ONE launch keeps the row operand
-// X[i,:] and the output accumulator in registers across blocks (a per-block launch re-reads X and read-modify-
-// writes Out for every block: 3 KiB per row per block at R = 128) and gives the gather pipeline longer rows.
-constexpr int kMaxMultiBlocks = 8;
-struct MultiBlocks {
-    const int32_t* rowptr[kMaxMultiBlocks];
-    const int32_t* colidx[kMaxMultiBlocks];
-    double* values[kMaxMultiBlocks];
-    const double* Y[kMaxMultiBlocks];
-    int n;
-};
-
-template <int LPR, int VEC, int W, bool EXACT>
-__global__ __launch_bounds__(kBlock) void fused_multi_kernel(int64_t rows, MultiBlocks mb, const double* __restrict__ X,
-                                                             double* __restrict__ Out, int64_t ld, int ncols, unsigned flags,
-                                                             Extras ex) {
-    constexpr int U = Unroll<LPR, VEC>::value;
-    constexpr int SUB = LPR / U;
-    constexpr int GROUPS = kBlock / LPR;
-    const int tid = threadIdx.x;
-    const int lig = tid % LPR;
-    int64_t row = (int64_t)blockIdx.x * GROUPS + tid / LPR;
-    if constexpr (LPR == 64) row = ((int64_t)blockIdx.x * GROUPS) + __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (row >= rows) return;
-
-    bool act[VEC];
-    int64_t coff[VEC];
-    double x[VEC][W], acc[VEC][W];
-#pragma unroll
-    for (int v = 0; v < VEC; v++) {
-        const int c = (v * LPR + lig) * W;
-        act[v] = EXACT ? true : (c < ncols);
-        coff[v] = c;
-#pragma unroll
-        for (int w = 0; w < W; w++) { x[v][w] = 0.0; acc[v][w] = 0.0; }
-        if (act[v]) {
-            load_w<W>(x[v], X + row * ld + coff[v]);
-            if (!(flags & HNH_FUSED_OUT_OVERWRITE)) load_w<W>(acc[v], Out + row * ld + coff[v]);
-        }
-    }
-
-    for (int b = 0; b < mb.n; b++) {
-        const int32_t* __restrict__ colidx = mb.colidx[b];
-        double* values = mb.values[b];
-        const double* __restrict__ Y = mb.Y[b];
-        int beg = mb.rowptr[b][row], end = mb.rowptr[b][row + 1];
-        if constexpr (LPR == 64) {
-            beg = __builtin_amdgcn_readfirstlane(beg);
-            end = __builtin_amdgcn_readfirstlane(end);
-        }
-        for (int e = beg; e < end; e += U) {
-            int c[U];
-            double y[U][VEC][W];
-#pragma unroll
-            for (int u = 0; u < U; u++) c[u] = (e + u < end) ? colidx[e + u] : -1;
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-#pragma unroll
-                for (int v = 0; v < VEC; v++) {
-#pragma unroll
-                    for (int w = 0; w < W; w++) y[u][v][w] = 0.0;
-                    if (c[u] >= 0 && act[v]) load_w<W>(y[u][v], Y + (int64_t)c[u] * ld + coff[v]);
-                }
-            }
-            double d[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                double sdot = 0.0;
-#pragma unroll
-                for (int v = 0; v < VEC; v++)
-#pragma unroll
-                    for (int w = 0; w < W; w++) sdot = fma(x[v][w], y[u][v][w], sdot);
-                d[u] = sdot;
-            }
-            double wgt = group_multi_reduce<LPR, U>(d, lig);
-            const int mine = e + lig / SUB;
-            if (mine < end) {
-                if (!(flags & HNH_FUSED_VALUES_OVERWRITE)) wgt += values[mine];
-                if (flags & HNH_FUSED_LEAKY_RELU) wgt = wgt > 0.0 ? wgt : ex.leaky_alpha * wgt;
-                if (lig % SUB == 0) values[mine] = wgt;
-            } else {
-                wgt = 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const double wu = group_bcast<LPR>(wgt, u * SUB);
-#pragma unroll
-                for (int v = 0; v < VEC; v++)
-#pragma unroll
-                    for (int w = 0; w < W; w++) acc[v][w] = fma(wu, y[u][v][w], acc[v][w]);
-            }
-        }
-    }
-    if (flags & kInternalEpilogue) {
-        double part = 0.0;
-#pragma unroll
-        for (int v = 0; v < VEC; v++)
-#pragma unroll
-            for (int w = 0; w < W; w++) {
-                acc[v][w] = fma(ex.x_scale, x[v][w], acc[v][w]);
-                part = fma(x[v][w], acc[v][w], part);
-            }
-        if (ex.rowdot != nullptr) {
-            part = group_sum<LPR>(part);
-            if (lig == 0) ex.rowdot[row] = part;
-        }
-    }
-#pragma unroll
-    for (int v = 0; v < VEC; v++)
-        if (act[v]) store_w<W>(Out + row * ld + coff[v], acc[v]);
-}
-
 // Infinity-Cache panels.  A launch that gathers from ALL rows of the dense operand revisits them at random across a
 // working set several times the 256 MiB memory-side cache; restricting a launch to the nonzeros of one column panel
 // (~512 MiB of the operand) lets about half of its gathers hit that cache (measured -12 % at config 2).  Column indices
@@ -1589,88 +1476,6 @@ int hnh_cg_step_f64(hnh_ctx* ctx, double* X, double* Rm, const double* P, const 
     if (chunks >= 64) HNH_CG(64) else if (chunks >= 16) HNH_CG(16) else if (chunks >= 4) HNH_CG(4) else HNH_CG(1)
 #undef HNH_CG
     return hnh::check_hip(ctx, hipGetLastError(), "cg_step_kernel launch");
-}
-
-int hnh_fused_sddmm_spmm_csr_multi(hnh_ctx* ctx, int64_t rows, int nblocks, const hnh_csr_block* blocks, const double* X, double* Out,
-                                   int R, unsigned flags, int stream) {
-    return hnh_fused_sddmm_spmm_csr_multi_x(ctx, rows, nblocks, blocks, X, Out, R, flags, nullptr, stream);
-}
-
-int hnh_fused_sddmm_spmm_csr_multi_x(hnh_ctx* ctx, int64_t rows, int nblocks, const hnh_csr_block* blocks, const double* X, double* Out,
-                                     int R, unsigned flags, const hnh_fused_extras* extras, int stream) {
-    HNH_ENTER(ctx, stream);
-    if (int rc = check_common(ctx, rows, R, "hnh_fused_sddmm_spmm_csr_multi")) return rc;
-    if (nblocks < 0 || (nblocks > 0 && !blocks)) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr_multi: bad block list");
-    Extras ex;
-    bool want_epilogue = false;
-    if (int rc = check_extras(ctx, flags, extras, &ex, &want_epilogue, "hnh_fused_sddmm_spmm_csr_multi")) return rc;
-    if (rows == 0) return HNH_OK;
-    if (nblocks == 0) {  // nothing to add; the epilogue still applies to the existing output rows
-        if (!want_epilogue) return HNH_OK;
-        if (!X || !Out || X == Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr_multi: bad operand");
-        if (flags & HNH_FUSED_OUT_OVERWRITE) HNH_TRY_HIP(ctx, hipMemsetAsync(Out, 0, sizeof(double) * (size_t)rows * R, ctx->streams[stream]));
-        return launch_row_epilogue(ctx, ctx->streams[stream], Out, X, ex.x_scale, ex.rowdot, rows, R);
-    }
-    if (!X || !Out || X == Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr_multi: bad operand");
-    bool vec_ok = aligned16(X) && aligned16(Out), simple = true;
-    for (int b = 0; b < nblocks; b++) {
-        if (!blocks[b].rowptr || !blocks[b].col_idx || !blocks[b].values || !blocks[b].Y || blocks[b].Y == Out)
-            return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr_multi: null pointer in block");
-        vec_ok = vec_ok && aligned16(blocks[b].Y);
-        if (blocks[b].max_row_nnz < 0 || blocks[b].max_row_nnz > kLongRow) simple = false;  // hub rows: per-block path splits them
-    }
-    const Shape s = pick_shape(R, vec_ok);
-    const bool one_pass = s.exact || R <= 256 * s.w;
-    hipStream_t st = ctx->streams[stream];
-    if (!simple || !one_pass) {  // same arithmetic, block by block
-        hnh_fused_extras act_only = {ex.leaky_alpha, 0.0, nullptr};
-        for (int b = 0; b < nblocks; b++) {
-            const unsigned f = (b == 0) ? flags : (flags & ~HNH_FUSED_OUT_OVERWRITE);
-            if (int rc = hnh_fused_sddmm_spmm_csr_x(ctx, rows, blocks[b].rowptr, blocks[b].col_idx, blocks[b].values, nullptr, X,
-                                                    blocks[b].Y, Out, R, f, blocks[b].nnz, blocks[b].max_row_nnz, -1, &act_only, stream))
-                return rc;
-        }
-        if (want_epilogue) return launch_row_epilogue(ctx, st, Out, X, ex.x_scale, ex.rowdot, rows, R);
-        return HNH_OK;
-    }
-    const bool epilogue_inside = want_epilogue && nblocks <= kMaxMultiBlocks;  // one launch completes every output row
-    for (int b0 = 0; b0 < nblocks; b0 += kMaxMultiBlocks) {
-        MultiBlocks mb;
-        mb.n = (nblocks - b0 < kMaxMultiBlocks) ? nblocks - b0 : kMaxMultiBlocks;
-        for (int b = 0; b < mb.n; b++) {
-            mb.rowptr[b] = blocks[b0 + b].rowptr; mb.colidx[b] = blocks[b0 + b].col_idx;
-            mb.values[b] = blocks[b0 + b].values; mb.Y[b] = blocks[b0 + b].Y;
-        }
-        const unsigned f = ((b0 == 0) ? flags : (flags & ~HNH_FUSED_OUT_OVERWRITE)) | (epilogue_inside ? kInternalEpilogue : 0u);
-#define HNH_MULTI(L, V, WW, EX)                                                                                     \
-    {                                                                                                               \
-        const int64_t nb = (rows + (kBlock / L) - 1) / (kBlock / L);                                                \
-        hipLaunchKernelGGL((fused_multi_kernel<L, V, WW, EX>), dim3((unsigned)nb), dim3(kBlock), 0, st, rows, mb, X, Out, (int64_t)R, R, f, ex); \
-    }
-        if (s.exact) {
-            if (s.lpr == 64 && s.vec == 1) HNH_MULTI(64, 1, 2, true)
-            else if (s.lpr == 64 && s.vec == 2) HNH_MULTI(64, 2, 2, true)
-            else if (s.lpr == 64 && s.vec == 3) HNH_MULTI(64, 3, 2, true)
-            else if (s.lpr == 64 && s.vec == 4) HNH_MULTI(64, 4, 2, true)
-            else if (s.lpr == 32 && s.vec == 1) HNH_MULTI(32, 1, 2, true)
-            else if (s.lpr == 32 && s.vec == 3) HNH_MULTI(32, 3, 2, true)
-            else if (s.lpr == 32 && s.vec == 5) HNH_MULTI(32, 5, 2, true)
-            else if (s.lpr == 32 && s.vec == 7) HNH_MULTI(32, 7, 2, true)
-            else if (s.lpr == 16) HNH_MULTI(16, 1, 2, true)
-            else if (s.lpr == 8) HNH_MULTI(8, 1, 2, true)
-            else if (s.lpr == 4) HNH_MULTI(4, 1, 2, true)
-            else if (s.lpr == 2) HNH_MULTI(2, 1, 2, true)
-            else HNH_MULTI(1, 1, 2, true)
-        } else if (s.w == 2) {
-            if (R <= 128) HNH_MULTI(64, 1, 2, false) else if (R <= 256) HNH_MULTI(64, 2, 2, false) else HNH_MULTI(64, 4, 2, false)
-        } else {
-            if (R <= 64) HNH_MULTI(64, 1, 1, false) else if (R <= 128) HNH_MULTI(64, 2, 1, false) else HNH_MULTI(64, 4, 1, false)
-        }
-#undef HNH_MULTI
-        if (int rc = hnh::check_hip(ctx, hipGetLastError(), "fused_multi_kernel launch")) return rc;
-    }
-    if (want_epilogue && !epilogue_inside) return launch_row_epilogue(ctx, st, Out, X, ex.x_scale, ex.rowdot, rows, R);
-    return HNH_OK;
 }
 
 int hnh_sddmm_coo(hnh_ctx* ctx, int64_t nnz, const int32_t* row_idx, const int32_t* col_idx, double* values,

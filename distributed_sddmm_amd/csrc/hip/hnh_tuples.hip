@@ -22,7 +22,7 @@ constexpr int kBlock = 256;
 
 struct KeyDesc {
     int kind, transpose;
-    long long rows_in_block, cols_in_block, n_col_blocks, div, sub_div, n_sub;
+    long long rows_in_block, cols_in_block, n_col_blocks, div;
     const int32_t* owner_table;
 };
 
@@ -35,8 +35,6 @@ __device__ __forceinline__ unsigned long long key_of(const hnh_tuple& t, const K
             const unsigned long long cb = (k.transpose ? t.r : t.c) / (unsigned long long)k.cols_in_block;
             return (unsigned long long)(unsigned)k.owner_table[rb * (unsigned long long)k.n_col_blocks + cb];
         }
-        case HNH_KEY_COL_DIV2:
-            return (t.c / (unsigned long long)k.div) * (unsigned long long)k.n_sub + (t.c % (unsigned long long)k.div) / (unsigned long long)k.sub_div;
         default: return t.c / (unsigned long long)k.div;  // HNH_KEY_COL_DIV
     }
 }
@@ -184,7 +182,6 @@ int desc_from(hnh_ctx* ctx, const hnh_tuple_key* key, KeyDesc* d, const char* wh
     d->kind = key->kind; d->transpose = key->transpose;
     d->rows_in_block = key->rows_in_block; d->cols_in_block = key->cols_in_block; d->n_col_blocks = key->n_col_blocks;
     d->div = key->div; d->owner_table = key->owner_table;
-    d->sub_div = key->sub_div; d->n_sub = key->n_sub;
     switch (key->kind) {
         case HNH_KEY_ROW_COL: case HNH_KEY_COL_ROW: return HNH_OK;
         case HNH_KEY_OWNER:
@@ -193,10 +190,6 @@ int desc_from(hnh_ctx* ctx, const hnh_tuple_key* key, KeyDesc* d, const char* wh
             return HNH_OK;
         case HNH_KEY_COL_DIV:
             if (key->div <= 0) return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": column divisor must be positive");
-            return HNH_OK;
-        case HNH_KEY_COL_DIV2:
-            if (key->div <= 0 || key->sub_div <= 0 || key->n_sub <= 0 || key->sub_div * key->n_sub < key->div)
-                return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": chunks must be positive and cover the block column");
             return HNH_OK;
         default: return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": unknown key kind");
     }

@@ -90,37 +90,6 @@ size_t StandardKernel::fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
     return 0;
 }
 
-// All visiting blocks of the block row in one launch (hnh_fused_sddmm_spmm_csr_multi).
-size_t StandardKernel::fused_multi_local(SpmatLocal& S, DenseMatrix& A, const std::vector<DenseMatrix*>& Bs, DenseMatrix& Out,
-                                         const std::vector<int>& blocks, unsigned flags, const hnh_fused_extras* extras) {
-    if (Bs.size() != blocks.size()) hnh::fatal("Error, fused_multi_local needs one dense operand per block!");
-    if ((flags & HNH_FUSED_LEAKY_RELU) && !extras) hnh::fatal("Error, HNH_FUSED_LEAKY_RELU needs extras!");
-    std::vector<hnh_csr_block> list;
-    int64_t rows = -1;
-    for (size_t k = 0; k < blocks.size(); k++) {
-        CSRLocal* blk = S.csr_blocks[blocks[k]];
-        if (blk == nullptr || blk->num_coords == 0) continue;
-        if (blk->transpose) hnh::fatal("Error, local matrix is transposed, can't perform the fused SDDMM+SpMM");
-        if (Bs[k]->cols() != A.cols() || Out.cols() != A.cols()) hnh::fatal("Error, fused operands must have the same number of columns!");
-        if (rows >= 0 && rows != blk->rows) hnh::fatal("Error, blocks of one fused pass must share their rows!");
-        rows = blk->rows;
-        CSRHandle* h = blk->getActive();
-        list.push_back(hnh_csr_block{h->rowStart, h->col_idx, h->values, Bs[k]->data(), blk->num_coords, blk->row_hint()});
-    }
-    hnh::World* w = S.world;
-    if (list.empty()) {
-        if (flags & HNH_FUSED_OUT_OVERWRITE) Out.setZero();
-        row_epilogue(w, A, Out, extras);
-        return 0;
-    }
-    begin(w);
-    w->check(w->be->hnh_fused_sddmm_spmm_csr_multi_x(w->ctx, rows, (int)list.size(), list.data(), A.data(), Out.data(), (int)A.cols(), flags,
-                                                     extras, HNH_STREAM_COMPUTE),
-             "hnh_fused_sddmm_spmm_csr_multi");
-    end(w);
-    return 0;
-}
-
 void StandardKernel::begin(hnh::World* w) {
     if (!profile) return;
     if (!ev0_) {

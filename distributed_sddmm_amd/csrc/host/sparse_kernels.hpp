@@ -54,23 +54,6 @@ public:
         return n;
     }
 
-    // The same fused pair over several blocks that share their rows (one per gathered operand Bs[k]), in the order
-    // given.  Default: block after block through fused_local; StandardKernel walks them in a single launch.
-    virtual size_t fused_multi_local(SpmatLocal& S, DenseMatrix& A, const std::vector<DenseMatrix*>& Bs, DenseMatrix& Out,
-                                     const std::vector<int>& blocks, unsigned flags, const hnh_fused_extras* extras = nullptr) {
-        size_t n = 0;
-        bool first = true;
-        hnh_fused_extras act_only = {extras ? extras->leaky_alpha : 0.0, 0.0, nullptr};
-        for (size_t k = 0; k < blocks.size(); k++) {
-            if (S.csr_blocks[blocks[k]] == nullptr) continue;
-            n += fused_local(S, A, *Bs[k], Out, blocks[k], first ? flags : (flags & ~HNH_FUSED_OUT_OVERWRITE), &act_only);
-            first = false;
-        }
-        if (first && (flags & HNH_FUSED_OUT_OVERWRITE)) Out.setZero();
-        row_epilogue(S.world, A, Out, extras);
-        return n;
-    }
-
     // Row windows (CSRLocal::window): a schedule may select one column range of a block before calling the kernels, to
     // work on data that arrives piece by piece.  An implementation that honours CSRLocal::window says so here; for the
     // others (plugins written against the reference's two pure virtuals) the schedule waits for the whole block instead.
@@ -107,8 +90,6 @@ public:
     size_t spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, MatMode mode, int block) override;
     size_t fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, DenseMatrix& Out, int block, unsigned flags,
                        const hnh_fused_extras* extras = nullptr) override;
-    size_t fused_multi_local(SpmatLocal& S, DenseMatrix& A, const std::vector<DenseMatrix*>& Bs, DenseMatrix& Out,
-                             const std::vector<int>& blocks, unsigned flags, const hnh_fused_extras* extras = nullptr) override;
     ~StandardKernel() override;
 
 private:

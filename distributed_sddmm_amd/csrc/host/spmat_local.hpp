@@ -572,38 +572,28 @@ public:
     void permuteVertices(uint64_t seed);
 
     // Tuples must be column-major sorted.  Splits them into block columns of `blockWidth` and (optionally)
-    // makes column indices block-local (SpmatLocal.hpp:541-563).  With chunks > 1 every block column is further cut into
-    // `chunks` column ranges of `chunkWidth` (the last may be short or empty): block column b, chunk q is block
-    // b * chunks + q, and local column indices are relative to the chunk.
-    void divideIntoBlockCols(int blockWidth, int targetDivisions, bool modIndex, int chunks = 1, int chunkWidth = 0) {
-        if (chunks < 1 || (chunks > 1 && (int64_t)chunkWidth * chunks < blockWidth)) hnh::fatal("Error, chunks do not cover the block column!");
-        if (chunks == 1) chunkWidth = blockWidth;
-        const size_t nblocks = (size_t)targetDivisions * (size_t)chunks;
-        if (resident) {  // boundaries by binary search over the column-major tuples, then the index localisation in one pass each
+    // makes column indices block-local (SpmatLocal.hpp:541-563).
+    void divideIntoBlockCols(int blockWidth, int targetDivisions, bool modIndex) {
+        const size_t nblocks = (size_t)targetDivisions;
+        if (resident) {  // boundaries by binary search over the column-major tuples, then the index localisation in one pass
             hnh_tuple_key key{};
-            key.kind = chunks > 1 ? HNH_KEY_COL_DIV2 : HNH_KEY_COL_DIV;
+            key.kind = HNH_KEY_COL_DIV;
             key.div = blockWidth;
-            key.sub_div = chunkWidth;
-            key.n_sub = chunks;
             std::vector<int64_t> starts(nblocks + 1, 0);
             world->check(world->be->hnh_tuples_bucket_starts(world->ctx, dptr(), (int64_t)n_resident, &key, (int64_t)nblocks, starts.data(),
                                                              HNH_STREAM_COMPUTE), "hnh_tuples_bucket_starts");
             if ((size_t)starts[nblocks] != n_resident) hnh::fatal("Error, more block columns than expected!");
             blockStarts.assign(starts.begin(), starts.end());
-            if (modIndex) {
-                localize(0, (uint64_t)blockWidth);
-                if (chunks > 1) localize(0, (uint64_t)chunkWidth);
-            }
+            if (modIndex) localize(0, (uint64_t)blockWidth);
             return;
         }
         blockStarts.assign(nblocks + 1, coords.size());
         size_t next = 0;  // next block whose start is still unknown
         for (uint64_t i = 0; i < coords.size(); i++) {
-            const uint64_t cb = coords[i].c / (uint64_t)blockWidth, in = coords[i].c % (uint64_t)blockWidth;
-            const uint64_t id = cb * (uint64_t)chunks + in / (uint64_t)chunkWidth;
+            const uint64_t id = coords[i].c / (uint64_t)blockWidth;
             if (id >= nblocks) hnh::fatal("Error, more block columns than expected!");
             while (next <= id) blockStarts[next++] = i;
-            if (modIndex) coords[i].c = in % (uint64_t)chunkWidth;
+            if (modIndex) coords[i].c %= (uint64_t)blockWidth;
         }
     }
 

@@ -149,7 +149,7 @@ int hnh_spmm_csr_w(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int3
  *   x_scale      != 0:  Out[i,:] += x_scale * X[i,:]                         — als_conjugate_gradients.cpp:282,295 (+ lambda * X)
  *   rowdot       != NULL: rowdot[i] = <X[i,:], Out[i,:]> of the FINAL row     — als_conjugate_gradients.cpp:93 (batch_dot_product(p, Mp))
  * The epilogue (x_scale, rowdot) runs inside the launch when one group completes the output row; with hub rows
- * (atomically combined segments), column tiles or more blocks than one launch takes it is appended as a row-wise
+ * (atomically combined segments) or column tiles it is appended as a row-wise
  * launch — same result either way.  hnh_row_epilogue_f64 is that launch on its own. */
 typedef struct hnh_fused_extras {
     double leaky_alpha;
@@ -163,24 +163,6 @@ int hnh_fused_sddmm_spmm_csr_w(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr
                                const double* svalues, const double* X, const double* Y, double* Out, int R, unsigned flags,
                                int64_t nnz, int max_row_nnz, const hnh_fused_extras* extras, const hnh_csr_window* window, int stream);
 int hnh_row_epilogue_f64(hnh_ctx* ctx, double* Out, const double* X, double x_scale, double* rowdot, int64_t rows, int R, int stream);
-
-/* hnh_fused_sddmm_spmm_csr_multi — the fused pass over SEVERAL blocks that share their rows (the p/c blocks one rank
- *   visits in 15D_dense_shift.hpp:199-227), each with its own gathered operand Y_b, in ONE launch: the row operand
- *   X[i,:] and the output accumulator stay in registers across blocks instead of being re-read / read-modify-
- *   written per block.  Same arithmetic and flags as calling hnh_fused_sddmm_spmm_csr block after block (which is
- *   what it does when a block has hub rows).  `blocks` is a HOST array of device pointers. */
-typedef struct hnh_csr_block {
-    const int32_t* rowptr;
-    const int32_t* col_idx;
-    double* values;
-    const double* Y;
-    int64_t nnz;     /* rowptr[rows], or -1 */
-    int max_row_nnz; /* longest row, or -1 */
-} hnh_csr_block;
-int hnh_fused_sddmm_spmm_csr_multi(hnh_ctx* ctx, int64_t rows, int nblocks, const hnh_csr_block* blocks, const double* X,
-                                   double* Out, int R, unsigned flags, int stream);
-int hnh_fused_sddmm_spmm_csr_multi_x(hnh_ctx* ctx, int64_t rows, int nblocks, const hnh_csr_block* blocks, const double* X,
-                                     double* Out, int R, unsigned flags, const hnh_fused_extras* extras, int stream);
 
 /* ---- element-wise helpers (K3-K5 of SURVEY §2.4) ----------------------------------------------------
  * hnh_fill_f64      — SpmatLocal::setValuesConstant (SpmatLocal.hpp:595-605), DenseMatrix::setZero
@@ -202,8 +184,6 @@ int hnh_expand_rowptr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, int32_t
  *   HNH_KEY_OWNER    owner_table[(R / rows_in_block) * n_col_blocks + (C / cols_in_block)] with (R, C) = (r, c), or (c, r)
  *                    when `transpose` — NonzeroDistribution::getOwner; owner_table is a DEVICE array
  *   HNH_KEY_COL_DIV  c / div         — block column of divideIntoBlockCols
- *   HNH_KEY_COL_DIV2 (c / div) * n_sub + (c % div) / sub_div — block column, then one of n_sub column chunks inside it
- *                    (the chunked mesh fetch of the 1.5D dense-shift schedule pipelines on these)
  * hnh_tuples_sort          stable in-place sort by key (LSD radix sort of (key, index) pairs + one gather); key_bits =
  *                          number of significant key bits (<= 0: 64), fewer bits = fewer radix passes
  * hnh_tuples_bucket_starts for tuples whose keys are non-decreasing: starts_host[b] = first index with key >= b,
@@ -220,7 +200,6 @@ typedef struct hnh_tuple {
 #define HNH_KEY_COL_ROW 1
 #define HNH_KEY_OWNER 2
 #define HNH_KEY_COL_DIV 3
-#define HNH_KEY_COL_DIV2 4
 typedef struct hnh_tuple_key {
     int kind;
     int transpose;               /* HNH_KEY_OWNER */
@@ -228,9 +207,7 @@ typedef struct hnh_tuple_key {
     int64_t cols_in_block;       /* HNH_KEY_OWNER */
     int64_t n_col_blocks;        /* HNH_KEY_OWNER */
     const int32_t* owner_table;  /* HNH_KEY_OWNER, device */
-    int64_t div;                 /* HNH_KEY_COL_DIV, HNH_KEY_COL_DIV2 */
-    int64_t sub_div;             /* HNH_KEY_COL_DIV2 */
-    int64_t n_sub;               /* HNH_KEY_COL_DIV2 */
+    int64_t div;                 /* HNH_KEY_COL_DIV */
 } hnh_tuple_key;
 int hnh_tuples_sort(hnh_ctx* ctx, hnh_tuple* tuples, int64_t n, const hnh_tuple_key* key, int key_bits, int stream);
 int hnh_tuples_bucket_starts(hnh_ctx* ctx, const hnh_tuple* sorted, int64_t n, const hnh_tuple_key* key, int64_t nbuckets,

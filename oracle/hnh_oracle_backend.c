@@ -205,31 +205,13 @@ int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* c, int64_t rows, const int32_t* rowptr, 
     return HNH_OK;
 }
 
-int hnh_fused_sddmm_spmm_csr_multi_x(hnh_ctx* c, int64_t rows, int nblocks, const hnh_csr_block* blocks, const double* X, double* Out,
-                                     int R, unsigned flags, const hnh_fused_extras* ex, int stream) {
-    if ((flags & HNH_FUSED_LEAKY_RELU) && !ex) return fail(c, HNH_ERR_INVALID, "HNH_FUSED_LEAKY_RELU needs extras");
-    hnh_fused_extras act_only = {ex ? ex->leaky_alpha : 0.0, 0.0, NULL};
-    if (nblocks == 0 && (flags & HNH_FUSED_OUT_OVERWRITE) && ex && (ex->x_scale != 0.0 || ex->rowdot))
-        memset(Out, 0, sizeof(double) * (size_t)rows * (size_t)R);
-    for (int b = 0; b < nblocks; b++) {  /* block after block: 15D_dense_shift.hpp:199-227 */
-        const unsigned f = (b == 0) ? flags : (flags & ~HNH_FUSED_OUT_OVERWRITE);
-        int rc = hnh_fused_sddmm_spmm_csr_x(c, rows, blocks[b].rowptr, blocks[b].col_idx, blocks[b].values, NULL, X, blocks[b].Y, Out, R, f,
-                                            -1, -1, -1, &act_only, stream);
-        if (rc != HNH_OK) return rc;
-    }
-    if (ex && (ex->x_scale != 0.0 || ex->rowdot)) return hnh_row_epilogue_f64(c, Out, X, ex->x_scale, ex->rowdot, rows, R, stream);
-    return HNH_OK;
-}
-int hnh_fused_sddmm_spmm_csr_multi(hnh_ctx* c, int64_t rows, int nblocks, const hnh_csr_block* blocks, const double* X, double* Out,
-                                   int R, unsigned flags, int stream) {
-    return hnh_fused_sddmm_spmm_csr_multi_x(c, rows, nblocks, blocks, X, Out, R, flags, NULL, stream);
-}
-
 /* ---- row windows (hnh_csr_window): the same loops over [beg[r], end[r]) of every row */
 int hnh_csr_window_bounds(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, int nbounds, const int32_t* bounds,
                           int32_t* split, int stream) {
     (void)stream;
     if (rows < 0 || nbounds < 0 || nbounds > 15) return fail(c, HNH_ERR_INVALID, "bad size");
+    for (int b = 1; b < nbounds; b++)
+        if (bounds[b] < bounds[b - 1]) return fail(c, HNH_ERR_INVALID, "bounds must not decrease");
     for (int b = 0; b < nbounds; b++)
         for (int64_t r = 0; r < rows; r++) {
             int32_t e = rowptr[r];
@@ -430,7 +412,6 @@ static uint64_t tuple_key(const hnh_tuple* t, const hnh_tuple_key* k) {
             const uint64_t cb = (k->transpose ? t->r : t->c) / (uint64_t)k->cols_in_block;
             return (uint64_t)(uint32_t)k->owner_table[rb * (uint64_t)k->n_col_blocks + cb];
         }
-        case HNH_KEY_COL_DIV2: return (t->c / (uint64_t)k->div) * (uint64_t)k->n_sub + (t->c % (uint64_t)k->div) / (uint64_t)k->sub_div;
         default: return t->c / (uint64_t)k->div;
     }
 }
@@ -439,9 +420,7 @@ static int key_ok(hnh_ctx* c, const hnh_tuple_key* k) {
     if (k->kind == HNH_KEY_OWNER && (k->rows_in_block <= 0 || k->cols_in_block <= 0 || k->n_col_blocks <= 0 || !k->owner_table))
         return fail(c, HNH_ERR_INVALID, "incomplete owner key");
     if (k->kind == HNH_KEY_COL_DIV && k->div <= 0) return fail(c, HNH_ERR_INVALID, "column divisor must be positive");
-    if (k->kind == HNH_KEY_COL_DIV2 && (k->div <= 0 || k->sub_div <= 0 || k->n_sub <= 0 || k->sub_div * k->n_sub < k->div))
-        return fail(c, HNH_ERR_INVALID, "chunks must be positive and cover the block column");
-    if (k->kind < HNH_KEY_ROW_COL || k->kind > HNH_KEY_COL_DIV2) return fail(c, HNH_ERR_INVALID, "unknown key kind");
+    if (k->kind < HNH_KEY_ROW_COL || k->kind > HNH_KEY_COL_DIV) return fail(c, HNH_ERR_INVALID, "unknown key kind");
     return HNH_OK;
 }
 typedef struct { uint64_t key; int64_t idx; } keyed_t;

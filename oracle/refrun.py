@@ -123,11 +123,11 @@ def dump(m, n, rows, cols, vals, r, a, b, alg: str, p: int, c: int, timeout: flo
         return res
 
 
-def fingerprints(m, n, rows, cols, r, alg: str, p: int, c: int, timeout: float = 120.0) -> dict:
+def fingerprints(m, n, rows, cols, r, alg: str, p: int, c: int, timeout: float = 120.0, threads: int | None = None) -> dict:
     with tempfile.TemporaryDirectory(prefix="hnh_ref_") as td:
         case = os.path.join(td, "case.bin")
         write_case(case, m, n, rows, cols, np.ones(len(rows)), r)
-        out = run(["fp", case, alg, c], p, alg, timeout=timeout)
+        out = run(["fp", case, alg, c], p, alg, threads=threads, timeout=timeout)
         return json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
 
 
@@ -140,14 +140,15 @@ def bench(m, n, rows, cols, r, alg: str, p: int, c: int, fused: bool, trials: in
         return json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
 
 
-def als(m, n, rows, cols, vals, r, a, b, alg: str, p: int, c: int, steps: int, cg_iters: int, timeout: float = 300.0) -> dict:
+def als(m, n, rows, cols, vals, r, a, b, alg: str, p: int, c: int, steps: int, cg_iters: int, timeout: float = 300.0,
+        threads: int | None = None) -> dict:
     """ALS-CG of the reference (als_conjugate_gradients.cpp) with ground truth = `vals`, embeddings initialised
     from (a, b): returns the global A, B after `steps` alternating steps and the residual history."""
     with tempfile.TemporaryDirectory(prefix="hnh_ref_") as td:
         case = os.path.join(td, "case.bin")
         write_case(case, m, n, rows, cols, vals, r, a, b)
         prefix = os.path.join(td, "out")
-        run(["als", case, alg, c, prefix, steps, cg_iters], p, alg, timeout=timeout)
+        run(["als", case, alg, c, prefix, steps, cg_iters], p, alg, threads=threads, timeout=timeout)
         return {"A": _assemble_dense(prefix, p, "alsA.f64", "A", m, r), "B": _assemble_dense(prefix, p, "alsB.f64", "B", n, r),
                 "residuals": np.fromfile(prefix + ".r0.residuals.f64", dtype=np.float64)}
 

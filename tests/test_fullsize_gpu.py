@@ -14,6 +14,9 @@ import hnh_testlib as T
 from distributed_sddmm_amd import api as H
 
 pytestmark = pytest.mark.gpu
+# the reference does not scale beyond ~32 OpenMP/MKL threads on a big host (profiles/r01_cpu_baseline_sweep.log); with all 256
+# hardware threads its full-size runs take three times as long
+REF_THREADS = min(32, __import__("os").cpu_count() or 1)
 
 
 @pytest.fixture(autouse=True, scope="module")
@@ -70,7 +73,8 @@ def test_config2_closed_form_is_the_reference(config2):
     from oracle import refrun as RR
     if not RR.available():
         pytest.skip("compiled reference not available on this box")
-    ref = RR.fingerprints(config2["m"], config2["m"], config2["rows"], config2["cols"], 128, "15d_fusion2", 1, 1, timeout=1500)
+    ref = RR.fingerprints(config2["m"], config2["m"], config2["rows"], config2["cols"], 128, "15d_fusion2", 1, 1, timeout=1500,
+                          threads=REF_THREADS)
     want = np.array([ref["sddmm"], ref["spmmA"], ref["spmmB"]])
     assert T.rel(config2["closed"], want) <= T.TOL, (config2["closed"], want)
 
@@ -146,7 +150,7 @@ def test_config5_als_step_at_full_size(config2):
     m, r, rows, cols = config2["m"], 128, config2["rows"], config2["cols"]
     vals = O.sparse_values(rows, cols, m, 5)
     a0, b0 = O.dense_fill(m, r, 11), O.dense_fill(m, r, 12)
-    ref = RR.als(m, m, rows, cols, vals, r, a0, b0, "15d_fusion2", 1, 1, steps=1, cg_iters=2, timeout=1800)
+    ref = RR.als(m, m, rows, cols, vals, r, a0, b0, "15d_fusion2", 1, 1, steps=1, cg_iters=2, timeout=1800, threads=REF_THREADS)
     w = H.World.single(0)
     sp = H.SpmatLocal.from_global(w, m, m, rows, cols, vals)
     d = H.DistributedSparse(w, "15d_fusion2", sp, r, 1)

@@ -291,6 +291,70 @@ def test_repeat_runs_short_rows_bitwise_hub_rows_within_tolerance(ctx):
             d.free()
 
 
+@pytest.mark.parametrize("R", [16, 128, 100, 257])
+@pytest.mark.parametrize("hubs", [False, True])
+def test_windowed_passes_equal_the_whole_block(ctx, R, hubs):
+    """hnh_*_csr_w: the block processed window by window (column ranges, as the 1.5D dense-shift schedule does while the
+    chunks of the fetched blocks land) gives what one pass over the whole block gives — SDDMM, SpMM and the fused pass with
+    activation and row epilogue on the last window; with hub rows (left whole, handled with the last window) and for widths
+    that take the column-tiled fallback."""
+    from distributed_sddmm_amd import _kernels as K
+    lib = ctx.lib
+    rng = np.random.default_rng(R + hubs)
+    rows, cols = 200, 6000
+    lens = rng.integers(0, 60, rows)
+    if hubs:
+        lens[3], lens[150] = 4000, 1300
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cidx = np.concatenate([np.sort(rng.choice(cols, int(n), replace=False)) for n in lens]).astype(np.int32)
+    ridx = np.repeat(np.arange(rows, dtype=np.int32), lens)
+    nnz = len(cidx)
+    X, Y = rng.uniform(-1, 1, (rows, R)), rng.uniform(-1, 1, (cols, R))
+    v0, out0 = rng.uniform(-1, 1, nnz), rng.uniform(-1, 1, (rows, R))
+    bounds = np.array([1500, 1500, 4100], dtype=np.int32)  # four windows, one of them empty
+    nw = len(bounds) + 1
+    d_rp, d_c, dX, dY = ctx.upload(rowptr), ctx.upload(cidx), ctx.upload(X), ctx.upload(Y)
+    d_split = ctx.upload(np.zeros((len(bounds), rows), np.int32))
+    ctx.check(lib.hnh_csr_window_bounds(ctx.h, rows, d_rp.ptr, d_c.ptr, len(bounds), bounds.ctypes.data_as(C.c_void_p), d_split.ptr, 0), "bounds")
+
+    def window(q):
+        beg = None if q == 0 else d_split.ptr + (q - 1) * rows * 4
+        end = None if q == nw - 1 else d_split.ptr + q * rows * 4
+        return K.CsrWindow(beg, end, 1 if q == nw - 1 else 0)
+
+    mx = int(lens.max())
+    # SDDMM and SpMM
+    dv = ctx.upload(v0)
+    for q in range(nw):
+        ctx.check(lib.hnh_sddmm_csr_w(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, dX.ptr, dY.ptr, R, nnz, mx, C.byref(window(q)), 0), "sddmm_w")
+    assert rel(dv.get(), O.sddmm_local(ridx, cidx, v0, X, Y)) <= TOL
+    dv.set(v0)
+    dOut = ctx.upload(out0)
+    for q in range(nw):
+        ctx.check(lib.hnh_spmm_csr_w(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, dY.ptr, dOut.ptr, R, nnz, mx, C.byref(window(q)), 0), "spmm_w")
+    assert rel(dOut.get(), O.spmm_local(rowptr, cidx, v0, Y, out0)) <= TOL
+    # fused with LeakyReLU, overwrite flags on the first window, the row epilogue on the last
+    d_dot = ctx.upload(np.zeros(rows))
+    alpha, xs = 0.2, -0.5
+    for q in range(nw):
+        ex = K.FusedExtras(alpha, xs if q == nw - 1 else 0.0, d_dot.ptr if q == nw - 1 else None)
+        flags = K.FUSED_VALUES_OVERWRITE | K.FUSED_LEAKY_RELU | (K.FUSED_OUT_OVERWRITE if q == 0 else 0)
+        ctx.check(lib.hnh_fused_sddmm_spmm_csr_w(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, None, dX.ptr, dY.ptr, dOut.ptr, R, flags, nnz, mx,
+                                                 C.byref(ex), C.byref(window(q)), 0), "fused_w")
+    dots = O.sddmm_local(ridx, cidx, np.zeros(nnz), X, Y)
+    act = np.where(dots > 0, dots, alpha * dots)
+    want = O.spmm_local(rowptr, cidx, act, Y, np.zeros((rows, R))) + xs * X
+    assert rel(dv.get(), act) <= TOL
+    assert rel(dOut.get(), want) <= TOL
+    assert rel(d_dot.get(), np.sum(X * want, axis=1)) <= TOL
+    # an epilogue on a window that is not the last one is refused
+    ex = K.FusedExtras(alpha, 1.0, None)
+    assert lib.hnh_fused_sddmm_spmm_csr_w(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, None, dX.ptr, dY.ptr, dOut.ptr, R, 0, nnz, mx, C.byref(ex),
+                                          C.byref(window(0)), 0) != 0
+    for d in (d_rp, d_c, dX, dY, d_split, dv, dOut, d_dot):
+        d.free()
+
+
 def test_fill_hashed_matches_the_oracle_hash(ctx):
     """hnh_fill_hashed_f64 = oracle.hashed_uniform keyed by the global (row, col) of a sub-block."""
     lib = ctx.lib
@@ -300,46 +364,6 @@ def test_fill_hashed_matches_the_oracle_hash(ctx):
     ii, jj = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
     keys = ((top + ii) * rg + left + jj).astype(np.uint64).reshape(-1)
     assert np.array_equal(d.get().reshape(-1), O.hashed_uniform(keys, seed) * 0.25)
-
-
-@pytest.mark.parametrize("R", [16, 128, 100, 256])
-def test_fused_multi_block_equals_block_after_block(ctx, R):
-    """hnh_fused_sddmm_spmm_csr_multi: several blocks sharing their rows, each with its own gathered operand, in ONE
-    launch == the per-block sequence of 15D_dense_shift.hpp:199-227 (incl. one block with a hub row -> per-block path)."""
-    import ctypes as C
-    from distributed_sddmm_amd import _kernels as K
-    lib = ctx.lib
-    rows, cols, nb = 203, 150, 5
-    rng = np.random.default_rng(R + 3)
-    X = rng.uniform(-1, 1, (rows, R))
-    out0 = rng.uniform(-1, 1, (rows, R))
-    dX = ctx.upload(X)
-    for hub in (False, True):
-        blocks, keep, want_out = [], [], out0.copy()
-        for b in range(nb):
-            rowptr, ridx, cidx = random_block(rows, cols, 900 + 100 * b, seed=R * 10 + b)
-            if hub and b == 2:  # one block with a long row
-                lens = np.diff(rowptr); lens[5] = 0
-                extra = np.sort(rng.choice(cols * 20, 1500, replace=False)) % cols
-                cidx = np.concatenate([cidx[:rowptr[5]], extra.astype(np.int32), cidx[rowptr[6]:]])
-                lens[5] = 1500
-                rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-                ridx = np.repeat(np.arange(rows, dtype=np.int32), lens)
-            Y = rng.uniform(-1, 1, (cols, R))
-            v0 = rng.uniform(-1, 1, len(cidx))
-            d = (ctx.upload(rowptr), ctx.upload(cidx), ctx.upload(v0), ctx.upload(Y))
-            keep.append(d)
-            vals = O.sddmm_local(ridx, cidx, v0, X, Y)
-            want_out = O.spmm_local(rowptr, cidx, vals, Y, want_out)
-            blocks.append((d, vals, int(np.diff(rowptr).max()), len(cidx)))
-        arr = (K.CsrBlock * nb)()
-        for b, (d, _, mx, nnz) in enumerate(blocks):
-            arr[b] = K.CsrBlock(d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, nnz, mx)
-        dOut = ctx.upload(out0)
-        ctx.check(lib.hnh_fused_sddmm_spmm_csr_multi(ctx.h, rows, nb, C.byref(arr), dX.ptr, dOut.ptr, R, 0, 0), "multi")
-        assert rel(dOut.get(), want_out) <= TOL
-        for d, vals, _, _ in blocks:
-            assert rel(d[2].get(), vals) <= TOL
 
 
 def _extras_expected(rowptr, ridx, cidx, v0, sv, X, Y, out0, flags, alpha, x_scale):
@@ -404,13 +428,12 @@ def test_fused_extras_activation_and_row_epilogue(ctx, R):
 
 
 @pytest.mark.parametrize("R", [16, 128, 100])
-def test_fused_extras_with_hub_rows_and_many_blocks(ctx, R):
-    """Epilogue appended as its own launch when rows are completed by several groups (hub-row segments) or several
-    launches (more blocks than one multi-block launch takes); same numbers as the in-launch epilogue."""
+def test_fused_extras_with_hub_rows(ctx, R):
+    """Epilogue appended as its own launch when rows are completed by several groups (hub-row segments); same numbers as
+    the in-launch epilogue."""
     from distributed_sddmm_amd import _kernels as K
     lib = ctx.lib
     rng = np.random.default_rng(R + 11)
-    # (1) hub rows, single block
     rows, cols = 40, 6000
     lens = rng.integers(0, 30, rows); lens[3], lens[20] = 3000, 1100
     rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
@@ -427,33 +450,6 @@ def test_fused_extras_with_hub_rows_and_many_blocks(ctx, R):
     assert rel(dv.get(), vals) <= TOL and rel(dOut.get(), out) <= TOL and rel(ddot.get(), dot) <= TOL
     for d in (d_rp, d_c, dv, dX, dY, dOut, ddot):
         d.free()
-    # (2) multi-block: 3 blocks (one launch) and 11 blocks (two launches + appended epilogue)
-    rows, cols = 150, 90
-    X = rng.uniform(-1, 1, (rows, R)); dX = ctx.upload(X)
-    for nb in (3, 11):
-        keep, want = [], np.zeros((rows, R))
-        arr = (K.CsrBlock * nb)()
-        for b in range(nb):
-            rowptr, ridx, cidx = random_block(rows, cols, 500, seed=R * 100 + b)
-            Yb, vb = rng.uniform(-1, 1, (cols, R)), rng.uniform(-1, 1, len(cidx))
-            d = [ctx.upload(a) for a in (rowptr, cidx, vb, Yb)]
-            vals = O.sddmm_local(ridx, cidx, np.zeros(len(cidx)), X, Yb)
-            vals = np.where(vals > 0, vals, 0.3 * vals)
-            want = O.spmm_local(rowptr, cidx, vals, Yb, want)
-            keep.append((d, vals))
-            arr[b].rowptr, arr[b].col_idx, arr[b].values, arr[b].Y = d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr
-            arr[b].nnz, arr[b].max_row_nnz = len(cidx), int(np.diff(rowptr).max())
-        want = want + 0.5 * X
-        dOut, ddot = ctx.upload(rng.uniform(-1, 1, (rows, R))), ctx.upload(np.zeros(rows))
-        ex = K.FusedExtras(0.3, 0.5, ddot.ptr)
-        ctx.check(lib.hnh_fused_sddmm_spmm_csr_multi_x(ctx.h, rows, nb, arr, dX.ptr, dOut.ptr, R, flags, C.byref(ex), 0), "multi_x")
-        assert rel(dOut.get(), want) <= TOL and rel(ddot.get(), np.einsum("ij,ij->i", X, want)) <= TOL
-        for d, vals in keep:
-            assert rel(d[2].get(), vals) <= TOL
-            for h in d:
-                h.free()
-        dOut.free(); ddot.free()
-    dX.free()
 
 
 @pytest.mark.parametrize("R", [8, 128, 100, 256])

@@ -23,7 +23,7 @@ def test_sort_at_scale_is_a_permutation_in_order():
     n = 10_000_000
     t = tuples_common.make_tuples(n, 1 << 20, 1 << 20, 11)
     d = ctx.upload(t)
-    key = K.TupleKey(K.KEY_COL_ROW, 0, 0, 0, 0, None, 0, 0, 0)
+    key = K.TupleKey(K.KEY_COL_ROW, 0, 0, 0, 0, None, 0)
     ctx.check(ctx.lib.hnh_tuples_sort(ctx.h, d.ptr, n, C.byref(key), 52, 0), "sort")
     got = d.get().view(K.TUPLE_DTYPE).reshape(-1)
     k = tuples_common.key_of(got, K.KEY_COL_ROW)

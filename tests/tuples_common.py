@@ -24,8 +24,6 @@ def key_of(t, kind, **kw):
     if kind == K.KEY_OWNER:
         rr, cc = (c, r) if kw["transpose"] else (r, c)
         return kw["table"][(rr // np.uint64(kw["rib"])) * np.uint64(kw["ncb"]) + cc // np.uint64(kw["cib"])].astype(np.uint64)
-    if kind == K.KEY_COL_DIV2:
-        return (c // np.uint64(kw["div"])) * np.uint64(kw["n_sub"]) + (c % np.uint64(kw["div"])) // np.uint64(kw["sub_div"])
     return c // np.uint64(kw["div"])
 
 
@@ -37,21 +35,19 @@ def run(api):
     table = np.random.default_rng(4).integers(0, 8, 10 * 7).astype(np.int32)  # 10 x 7 blocks of 100 x 111, 8 owners
     dtab = api.upload(table)
     cases = [(K.KEY_ROW_COL, {}, 64), (K.KEY_COL_ROW, {}, 32 + 10), (K.KEY_COL_DIV, dict(div=100), 4),
-             (K.KEY_COL_DIV2, dict(div=100, sub_div=34, n_sub=3), 5),
              (K.KEY_OWNER, dict(transpose=0, rib=100, cib=111, ncb=7, table=table), 3),
              (K.KEY_OWNER, dict(transpose=1, rib=111, cib=100, ncb=10, table=table), 3)]
     for kind, kw, bits in cases:
         if kind == K.KEY_OWNER and kw["transpose"]:  # 7 x 10 blocks over the transposed matrix
             kw["table"] = table[:70]
-        key = K.TupleKey(kind, kw.get("transpose", 0), kw.get("rib", 0), kw.get("cib", 0), kw.get("ncb", 0), dtab.ptr, kw.get("div", 0),
-                         kw.get("sub_div", 0), kw.get("n_sub", 0))
+        key = K.TupleKey(kind, kw.get("transpose", 0), kw.get("rib", 0), kw.get("cib", 0), kw.get("ncb", 0), dtab.ptr, kw.get("div", 0))
         d = api.upload(t0)
         api.check(lib.hnh_tuples_sort(h, d.ptr, n, C.byref(key), bits, 0), "tuples_sort")
         got = d.get().view(K.TUPLE_DTYPE).reshape(-1)
         order = np.argsort(key_of(t0, kind, **kw), kind="stable")   # the sort is stable
         assert np.array_equal(got, t0[order]), "kind %d" % kind
         # boundaries
-        nb = int(key_of(t0, kind, **kw).max()) + 1 if kind in (K.KEY_OWNER, K.KEY_COL_DIV, K.KEY_COL_DIV2) else 5
+        nb = int(key_of(t0, kind, **kw).max()) + 1 if kind in (K.KEY_OWNER, K.KEY_COL_DIV) else 5
         starts = np.zeros(nb + 1, dtype=np.int64)
         api.check(lib.hnh_tuples_bucket_starts(h, d.ptr, n, C.byref(key), nb, starts.ctypes.data_as(C.c_void_p), 0), "bucket_starts")
         want = np.searchsorted(key_of(got, kind, **kw), np.arange(nb + 1, dtype=np.uint64), side="left")
@@ -63,6 +59,21 @@ def run(api):
     got = d.get().view(K.TUPLE_DTYPE).reshape(-1)
     assert np.array_equal(got["r"], t0["c"] % 13) and np.array_equal(got["c"], t0["r"]) and np.array_equal(got["value"], t0["value"])
     d.free()
+    # remap_cols: segment (c / div) * n_sub + (c % div) / sub_div moves to dest[segment], offsets inside a segment stay
+    div, sub, nsub = 100, 34, 3
+    dest = np.random.default_rng(5).permutation(8 * nsub).astype(np.int64) * 1000   # 777 columns -> 8 blocks x 3 chunks
+    d = api.upload(t0)
+    api.check(lib.hnh_tuples_remap_cols(h, d.ptr, n, div, sub, nsub, dest.ctypes.data_as(C.c_void_p), len(dest), 0), "remap_cols")
+    got = d.get().view(K.TUPLE_DTYPE).reshape(-1)
+    c0 = t0["c"].astype(np.int64)
+    seg = (c0 // div) * nsub + (c0 % div) // sub
+    assert np.array_equal(got["c"].astype(np.int64), dest[seg] + (c0 % div) % sub) and np.array_equal(got["r"], t0["r"])
+    # a tuple in a segment without destination (negative entry, or beyond the table) is an error
+    bad = dest.copy(); bad[int(seg[0])] = -1
+    d2 = api.upload(t0)
+    assert lib.hnh_tuples_remap_cols(h, d2.ptr, n, div, sub, nsub, bad.ctypes.data_as(C.c_void_p), len(bad), 0) != 0
+    assert lib.hnh_tuples_remap_cols(h, d2.ptr, n, div, sub, nsub, dest.ctypes.data_as(C.c_void_p), 3, 0) != 0
+    d.free(); d2.free()
     # to_csr on de-duplicated (row, col)-ordered tuples, with empty rows and one hub row
     keys = np.unique(np.concatenate([key_of(t0, K.KEY_ROW_COL)[t0["r"] % 7 != 3], (np.uint64(5) << np.uint64(32)) | np.arange(cols, dtype=np.uint64)]))
     ts = np.zeros(len(keys), dtype=K.TUPLE_DTYPE)
@@ -74,16 +85,26 @@ def run(api):
     want_rp = np.searchsorted(ts["r"], np.arange(rows + 1), side="left").astype(np.int32)
     assert np.array_equal(drp.get().reshape(-1), want_rp) and np.array_equal(dci.get().reshape(-1), ts["c"].astype(np.int32))
     assert np.array_equal(dv.get().reshape(-1), ts["value"]) and mx.value == int(np.diff(want_rp).max()) == cols
+    # window bounds on that CSR block: first nonzero of every row with column >= bound
+    bounds = np.array([0, 100, 100, 500, 776, 5000], dtype=np.int32)
+    dsp = api.upload(np.zeros((len(bounds), rows), np.int32))
+    api.check(lib.hnh_csr_window_bounds(h, rows, drp.ptr, dci.ptr, len(bounds), bounds.ctypes.data_as(C.c_void_p), dsp.ptr, 0), "window_bounds")
+    ci = ts["c"].astype(np.int64)
+    for b, bound in enumerate(bounds):
+        want_split = np.array([want_rp[r] + np.searchsorted(ci[want_rp[r]:want_rp[r + 1]], bound, side="left") for r in range(rows)])
+        assert np.array_equal(dsp.get().reshape(len(bounds), rows)[b], want_split.astype(np.int32))
+    assert lib.hnh_csr_window_bounds(h, rows, drp.ptr, dci.ptr, 2, np.array([5, 3], np.int32).ctypes.data_as(C.c_void_p), dsp.ptr, 0) != 0
+    dsp.free()
     # a tuple outside the block is an error, like the reference's MKL call would be
     assert lib.hnh_tuples_to_csr(h, d.ptr, len(ts), rows, cols - 1, drp.ptr, dci.ptr, dv.ptr, C.byref(mx), 0) != 0
     # empty input
     api.check(lib.hnh_tuples_to_csr(h, None, 0, 4, 4, drp.ptr, None, None, C.byref(mx), 0), "to_csr empty")
     assert np.array_equal(drp.get().reshape(-1)[:5], np.zeros(5, np.int32)) and mx.value == 0
-    api.check(lib.hnh_tuples_sort(h, None, 0, C.byref(K.TupleKey(K.KEY_ROW_COL, 0, 0, 0, 0, None, 0, 0, 0)), 64, 0), "sort empty")
+    api.check(lib.hnh_tuples_sort(h, None, 0, C.byref(K.TupleKey(K.KEY_ROW_COL, 0, 0, 0, 0, None, 0)), 64, 0), "sort empty")
     # indices beyond 32 bits cannot be keyed
     big = t0[:10].copy(); big["r"][3] = 1 << 33
     db = api.upload(big)
-    assert lib.hnh_tuples_sort(h, db.ptr, 10, C.byref(K.TupleKey(K.KEY_ROW_COL, 0, 0, 0, 0, None, 0, 0, 0)), 64, 0) != 0
+    assert lib.hnh_tuples_sort(h, db.ptr, 10, C.byref(K.TupleKey(K.KEY_ROW_COL, 0, 0, 0, 0, None, 0)), 64, 0) != 0
     for x in (d, drp, dci, dv, dtab, db):
         x.free()
     run_generator(api)
