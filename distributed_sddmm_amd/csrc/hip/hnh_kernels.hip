@@ -544,14 +544,21 @@ __global__ __launch_bounds__(kBlock) void window_bounds_kernel(int64_t rows, con
     }
 }
 
-// element-wise passes of the column-tiled fused fallback, restricted to a window: 0 = zero, 1 = LeakyReLU, 2 = *= svalues
-__global__ __launch_bounds__(kBlock) void window_values_kernel(int64_t rows, const int32_t* __restrict__ beg, const int32_t* __restrict__ end,
-                                                               double* __restrict__ values, const double* __restrict__ svalues, int mode,
-                                                               double alpha) {
+// element-wise passes of the column-tiled fused fallback, restricted to a window: 0 = zero, 1 = LeakyReLU, 2 = *= svalues.
+// Hub rows follow the row passes' rule: untouched by every window but the last, whole with the last one.
+__global__ __launch_bounds__(kBlock) void window_values_kernel(int64_t rows, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ beg,
+                                                               const int32_t* __restrict__ end, double* __restrict__ values,
+                                                               const double* __restrict__ svalues, int mode, double alpha, bool split_long, bool last) {
     const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 64;
     const int lane = threadIdx.x % 64;
     if (row >= rows) return;
-    for (int e = beg[row] + lane; e < end[row]; e += 64) {
+    int b = beg[row], e2 = end[row];
+    if (split_long && rowptr[row + 1] - rowptr[row] > kLongRow) {
+        if (!last) return;
+        b = rowptr[row];
+        e2 = rowptr[row + 1];
+    }
+    for (int e = b + lane; e < e2; e += 64) {
         if (mode == 0) values[e] = 0.0;
         else if (mode == 1) { const double x = values[e]; values[e] = fmax(x, 0.0) + fmin(x, 0.0) * alpha; }
         else values[e] *= svalues[e];
@@ -1383,7 +1390,9 @@ int fused_impl(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t*
             else hipLaunchKernelGGL(hadamard_kernel, dim3(ew_grid(nnz)), dim3(kBlock), 0, st, values, values, svalues, nnz, false);
         } else {
             const int64_t blocks = (rows * 64 + kBlock - 1) / kBlock;
-            hipLaunchKernelGGL(window_values_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, wbeg, wend, values, svalues, mode, ex.leaky_alpha);
+            const bool split_long = !(max_row_nnz >= 0 && max_row_nnz <= kLongRow);  // as prepare_long decides for the row passes
+            hipLaunchKernelGGL(window_values_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, rowptr, wbeg, wend, values, svalues, mode,
+                               ex.leaky_alpha, split_long, win->last != 0);
         }
         return hnh::check_hip(ctx, hipGetLastError(), "element-wise pass of the fused fallback");
     };

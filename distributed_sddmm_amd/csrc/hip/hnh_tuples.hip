@@ -95,6 +95,29 @@ __global__ __launch_bounds__(kBlock) void remap_cols_kernel(hnh_tuple* t, long l
     }
 }
 
+// de-duplication with maximum (tuples sorted by (row, col)): a tuple is the head of its run when it differs from its
+// predecessor; heads are numbered by an inclusive scan; every head walks its (short) run for the maximum
+__global__ __launch_bounds__(kBlock) void head_flags_kernel(const hnh_tuple* __restrict__ t, long long n, unsigned* __restrict__ flag) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+        flag[i] = (i == 0 || t[i].r != t[i - 1].r || t[i].c != t[i - 1].c) ? 1u : 0u;
+}
+__global__ __launch_bounds__(kBlock) void compact_max_kernel(const hnh_tuple* __restrict__ t, long long n, const unsigned* __restrict__ flag,
+                                                             const unsigned* __restrict__ pos, hnh_tuple* __restrict__ out) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        if (!flag[i]) continue;
+        hnh_tuple v = t[i];
+        for (long long j = i + 1; j < n && !flag[j]; j++) v.value = fmax(v.value, t[j].value);
+        out[pos[i] - 1] = v;
+    }
+}
+__global__ __launch_bounds__(kBlock) void take_strided_kernel(const hnh_tuple* __restrict__ src, long long first, long long step,
+                                                              hnh_tuple* __restrict__ out, long long n_out) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n_out; i += stride) out[i] = src[first + i * step];
+}
+
 // tuples in (row, col) order -> col_idx / values; rowptr[r] = first tuple of row >= r (binary search per row);
 // max_row[0] = longest row; bad[0] = 1 when a tuple lies outside rows x cols
 __global__ __launch_bounds__(kBlock) void unzip_kernel(const hnh_tuple* __restrict__ t, long long n, long long rows, long long cols,
@@ -275,6 +298,49 @@ int hnh_tuples_transform(hnh_ctx* ctx, hnh_tuple* tuples, int64_t n, int swap_rc
     hipLaunchKernelGGL(transform_kernel, dim3(grid_for(n)), dim3(kBlock), 0, ctx->streams[stream], tuples, (long long)n, swap_rc,
                        (unsigned long long)rmod, (unsigned long long)cmod);
     return hnh::check_hip(ctx, hipGetLastError(), "transform_kernel launch");
+}
+
+int hnh_tuples_dedup_max(hnh_ctx* ctx, hnh_tuple* sorted, int64_t n, int64_t* n_unique_host, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (n < 0 || !n_unique_host) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_dedup_max: bad argument");
+    *n_unique_host = 0;
+    if (n == 0) return HNH_OK;
+    if (!sorted) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_dedup_max: null pointer");
+    if (n > 0xffffffffLL) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "hnh_tuples_dedup_max: more than 2^32 tuples");
+    hipStream_t st = ctx->streams[stream];
+    const size_t un = (size_t)n;
+    size_t scan_bytes = 0;
+    HNH_TRY_HIP(ctx, rocprim::inclusive_scan(nullptr, scan_bytes, (unsigned*)nullptr, (unsigned*)nullptr, un, rocprim::plus<unsigned>(), st));
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_flag = 0, o_pos = o_flag + up(un * sizeof(unsigned)), o_out = o_pos + up(un * sizeof(unsigned)),
+                 o_tmp = o_out + up(un * sizeof(hnh_tuple));
+    Scratch s;
+    HNH_TRY_HIP(ctx, hipMalloc(&s.p, o_tmp + up(scan_bytes)));
+    char* base = static_cast<char*>(s.p);
+    unsigned* flag = reinterpret_cast<unsigned*>(base + o_flag);
+    unsigned* pos = reinterpret_cast<unsigned*>(base + o_pos);
+    hnh_tuple* out = reinterpret_cast<hnh_tuple*>(base + o_out);
+    hipLaunchKernelGGL(head_flags_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, sorted, (long long)n, flag);
+    HNH_TRY_HIP(ctx, rocprim::inclusive_scan(base + o_tmp, scan_bytes, flag, pos, un, rocprim::plus<unsigned>(), st));
+    hipLaunchKernelGGL(compact_max_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, sorted, (long long)n, flag, pos, out);
+    HNH_TRY_HIP(ctx, hipGetLastError());
+    unsigned count = 0;
+    HNH_TRY_HIP(ctx, hipMemcpyAsync(&count, pos + (un - 1), sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
+    HNH_TRY_HIP(ctx, hipMemcpyAsync(sorted, out, (size_t)count * sizeof(hnh_tuple), hipMemcpyDeviceToDevice, st));
+    HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
+    *n_unique_host = (int64_t)count;
+    return HNH_OK;
+}
+
+int hnh_tuples_take_strided(hnh_ctx* ctx, const hnh_tuple* src, int64_t first, int64_t stride, hnh_tuple* out, int64_t n_out, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (n_out < 0 || first < 0 || stride <= 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_take_strided: bad argument");
+    if (n_out == 0) return HNH_OK;
+    if (!src || !out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_tuples_take_strided: null pointer");
+    hipLaunchKernelGGL(take_strided_kernel, dim3(grid_for(n_out)), dim3(kBlock), 0, ctx->streams[stream], src, (long long)first, (long long)stride,
+                       out, (long long)n_out);
+    return hnh::check_hip(ctx, hipGetLastError(), "take_strided_kernel launch");
 }
 
 int hnh_tuples_remap_cols(hnh_ctx* ctx, hnh_tuple* tuples, int64_t n, int64_t div, int64_t sub_div, int64_t n_sub, const int64_t* dest_host,

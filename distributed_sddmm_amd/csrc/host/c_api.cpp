@@ -59,15 +59,12 @@ int guarded(hnh::World* w, F&& f) {
         return HNH_OK;
     } catch (const hnh::Error& e) {
         t_error = e.what();
-        if (w) w->abort_peers();  // peers of a thread group blocked on this rank fail too instead of hanging
         return HNH_ERR_INVALID;
     } catch (const std::bad_alloc&) {
         t_error = "out of host memory";
-        if (w) w->abort_peers();
         return HNH_ERR_NOMEM;
     } catch (const std::exception& e) {
         t_error = e.what();
-        if (w) w->abort_peers();
         return HNH_ERR_DEVICE;
     }
 }

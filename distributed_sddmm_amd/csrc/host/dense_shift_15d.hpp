@@ -276,7 +276,10 @@ private:
         CSRLocal* remote = choice->csr_blocks[1];
         one(0, *Brole, -1, remote == nullptr);
         if (remote != nullptr) {
-            const bool by_window = kernel->handles_windows() && remote->n_windows > 1 && !resident;
+            // (HNH_FORCE_WINDOWS: measurement aid — walk the windows although a held operand's blocks are already there, which
+            // lets one rank's kernel sequence be timed without its peers, tools/rank_share_probe.py)
+            static const bool force_windows = std::getenv("HNH_FORCE_WINDOWS") != nullptr;
+            const bool by_window = kernel->handles_windows() && remote->n_windows > 1 && (!resident || force_windows);
             if (!by_window) {
                 world->event_wait(event(8 + windows - 1), HNH_STREAM_COMPUTE);  // every chunk has landed
                 one(1, landing[slot], -1, true);

@@ -2,7 +2,10 @@
 
 #include <parallel/algorithm>
 
+#include <omp.h>
+
 #include <algorithm>
+#include <cstdlib>
 #include <fstream>
 #include <sstream>
 
@@ -61,36 +64,100 @@ std::vector<uint64_t> vertex_permutation(uint64_t n, uint64_t seed) {
     return label;
 }
 
-void read_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std::vector<spcoord_t>& tuples) {
-    std::ifstream in(path);
+// Parses a MatrixMarket coordinate file (general / symmetric; pattern, integer or real) into 0-based tuples, mirrored
+// entries of a symmetric file included, duplicates NOT yet merged.  The body is cut at line boundaries into one piece per
+// OpenMP thread (a SuiteSparse graph like com-Orkut is ~1.7 GB of text).
+void parse_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std::vector<spcoord_t>& tuples) {
+    std::ifstream in(path, std::ios::binary | std::ios::ate);
     if (!in) fatal("Error, cannot open matrix file " + path);
-    std::string line;
-    if (!std::getline(in, line) || line.rfind("%%MatrixMarket", 0) != 0) fatal("Error, " + path + " is not a MatrixMarket file");
+    const std::streamsize fsize = in.tellg();
+    in.seekg(0);
+    std::string text((size_t)fsize, '\0');
+    if (fsize > 0 && !in.read(&text[0], fsize)) fatal("Error, cannot read matrix file " + path);
+    size_t pos = text.find('\n');
+    std::string line = text.substr(0, pos == std::string::npos ? text.size() : pos);
+    if (line.rfind("%%MatrixMarket", 0) != 0) fatal("Error, " + path + " is not a MatrixMarket file");
     std::string lower = line;
     std::transform(lower.begin(), lower.end(), lower.begin(), ::tolower);
     if (lower.find("coordinate") == std::string::npos) fatal("Error, only coordinate MatrixMarket files are supported");
     const bool pattern = lower.find("pattern") != std::string::npos;
     const bool symmetric = lower.find("symmetric") != std::string::npos;
-    while (std::getline(in, line))
-        if (!line.empty() && line[0] != '%') break;
+    // comment lines, then the size line
     uint64_t entries = 0;
-    {
+    for (;;) {
+        if (pos == std::string::npos) fatal("Error, bad MatrixMarket size line in " + path);
+        const size_t start = pos + 1;
+        pos = text.find('\n', start);
+        line = text.substr(start, (pos == std::string::npos ? text.size() : pos) - start);
+        if (line.empty() || line[0] == '%') continue;
         std::istringstream hdr(line);
         if (!(hdr >> m >> n >> entries)) fatal("Error, bad MatrixMarket size line in " + path);
+        break;
+    }
+    const char* body = text.data() + (pos == std::string::npos ? text.size() : pos + 1);
+    const char* end = text.data() + text.size();
+    const int nthreads = std::max(1, omp_get_max_threads());
+    std::vector<std::vector<spcoord_t>> part((size_t)nthreads);
+    std::vector<int> bad((size_t)nthreads, 0);
+#pragma omp parallel num_threads(nthreads)
+    {
+        const int t = omp_get_thread_num();
+        const size_t len = (size_t)(end - body);
+        const char* lo = body + len * (size_t)t / (size_t)nthreads;
+        const char* hi = body + len * (size_t)(t + 1) / (size_t)nthreads;
+        if (t > 0) {  // start at the first line that begins inside the piece
+            while (lo < end && lo[-1] != '\n') lo++;
+        }
+        while (hi < end && hi[-1] != '\n') hi++;  // ... and finish the line that straddles its end
+        std::vector<spcoord_t>& out = part[(size_t)t];
+        out.reserve((size_t)(entries / (uint64_t)nthreads + 16) * (symmetric ? 2 : 1));
+        const char* p = lo;
+        while (p < hi) {
+            while (p < hi && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n')) p++;
+            if (p >= hi) break;
+            if (*p == '%') {  // comment inside the body
+                while (p < hi && *p != '\n') p++;
+                continue;
+            }
+            char* q = nullptr;
+            const uint64_t r = std::strtoull(p, &q, 10);
+            if (q == p) { bad[(size_t)t] = 1; break; }
+            p = q;
+            const uint64_t c = std::strtoull(p, &q, 10);
+            if (q == p) { bad[(size_t)t] = 1; break; }
+            p = q;
+            double v = 1.0;
+            if (!pattern) {
+                v = std::strtod(p, &q);
+                if (q == p) { bad[(size_t)t] = 1; break; }
+                p = q;
+            }
+            while (p < hi && *p != '\n') p++;  // ignore anything else on the line (complex files are not supported anyway)
+            if (r < 1 || r > m || c < 1 || c > n) { bad[(size_t)t] = 2; break; }
+            out.push_back({r - 1, c - 1, v});
+            if (symmetric && r != c) out.push_back({c - 1, r - 1, v});
+        }
+    }
+    size_t total = 0, lines = 0;
+    for (int t = 0; t < nthreads; t++) {
+        if (bad[(size_t)t] == 1) fatal("Error, malformed line in MatrixMarket file " + path);
+        if (bad[(size_t)t] == 2) fatal("Error, MatrixMarket index out of range in " + path);
+        total += part[(size_t)t].size();
     }
     tuples.clear();
-    tuples.reserve(symmetric ? 2 * entries : entries);
-    for (uint64_t e = 0; e < entries; e++) {
-        uint64_t r, c;
-        double v = 1.0;
-        if (!(in >> r >> c)) fatal("Error, truncated MatrixMarket file " + path);
-        if (!pattern && !(in >> v)) fatal("Error, truncated MatrixMarket file " + path);
-        if (r < 1 || r > m || c < 1 || c > n) fatal("Error, MatrixMarket index out of range in " + path);
-        tuples.push_back({r - 1, c - 1, v});
-        if (symmetric && r != c) tuples.push_back({c - 1, r - 1, v});
+    tuples.reserve(total);
+    for (auto& v : part) {
+        tuples.insert(tuples.end(), v.begin(), v.end());
+        std::vector<spcoord_t>().swap(v);
     }
-    // duplicates -> maximum
-    std::sort(tuples.begin(), tuples.end(), [](const spcoord_t& a, const spcoord_t& b) { return row_major(a, b); });
+    (void)lines;
+    if (!symmetric && tuples.size() != entries) fatal("Error, truncated MatrixMarket file " + path);
+    if (symmetric && tuples.size() < entries) fatal("Error, truncated MatrixMarket file " + path);
+}
+
+// duplicates -> maximum (the reference reads with `maximum<double>()`, SpmatLocal.hpp:487); host version
+void merge_duplicates_max(std::vector<spcoord_t>& tuples) {
+    __gnu_parallel::sort(tuples.begin(), tuples.end(), [](const spcoord_t& a, const spcoord_t& b) { return row_major(a, b); });
     size_t out = 0;
     for (size_t e = 0; e < tuples.size(); e++) {
         if (out > 0 && tuples[out - 1].r == tuples[e].r && tuples[out - 1].c == tuples[e].c)
@@ -99,6 +166,11 @@ void read_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std::
             tuples[out++] = tuples[e];
     }
     tuples.resize(out);
+}
+
+void read_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std::vector<spcoord_t>& tuples) {
+    parse_matrix_market(path, m, n, tuples);
+    merge_duplicates_max(tuples);
 }
 
 }  // namespace hnh
@@ -112,6 +184,37 @@ void SpmatLocal::loadTuples(bool readFromFile, int logM, int nnz_per_row, std::s
     if (readFromFile) {
         std::vector<spcoord_t> all;
         uint64_t m = 0, n = 0;
+        if (device_setup()) {
+            // every rank parses the file (in parallel on its host cores), then the GPU orders the tuples, merges duplicate
+            // coordinates with `maximum` (SpmatLocal.hpp:487) and keeps this rank's strided slice: the tuples are
+            // device-resident from here on, like the generated ones
+            hnh::parse_matrix_market(filename, m, n, all);
+            if (m >> 32 || n >> 32) hnh::fatal("Error, matrices with more than 2^32 rows or columns are not supported!");
+            M = m;
+            N = n;
+            hnh::DeviceArray raw(world, std::max<size_t>(all.size(), 1) * sizeof(spcoord_t));
+            world->copy(raw.ptr(), all.data(), all.size() * sizeof(spcoord_t), HNH_COPY_H2D, HNH_STREAM_COMPUTE);
+            hnh_tuple* rt = static_cast<hnh_tuple*>(raw.ptr());
+            hnh_tuple_key key{};
+            key.kind = HNH_KEY_ROW_COL;
+            int row_bits = 1;
+            while (row_bits < 32 && ((uint64_t)1 << row_bits) < m) row_bits++;
+            world->check(world->be->hnh_tuples_sort(world->ctx, rt, (int64_t)all.size(), &key, 32 + row_bits, HNH_STREAM_COMPUTE), "hnh_tuples_sort");
+            int64_t unique = 0;
+            world->check(world->be->hnh_tuples_dedup_max(world->ctx, rt, (int64_t)all.size(), &unique, HNH_STREAM_COMPUTE), "hnh_tuples_dedup_max");
+            std::vector<spcoord_t>().swap(all);
+            dist_nnz = (uint64_t)unique;
+            n_resident = unique > rank ? (size_t)((unique - rank + p - 1) / p) : 0;
+            dcoords = hnh::DeviceArray(world, std::max<size_t>(n_resident, 1) * sizeof(spcoord_t));
+            world->check(world->be->hnh_tuples_take_strided(world->ctx, rt, rank, p, dptr(), (int64_t)n_resident, HNH_STREAM_COMPUTE),
+                         "hnh_tuples_take_strided");
+            world->sync(HNH_STREAM_COMPUTE);
+            resident = true;
+            if (rank == 0) std::cout << "File reader read " << dist_nnz << " nonzeros." << std::endl;
+            initialized = true;
+            if (const char* ps = std::getenv("HNH_PERMUTE_SEED")) permuteVertices(std::strtoull(ps, nullptr, 10));
+            return;
+        }
         hnh::read_matrix_market(filename, m, n, all);
         M = m;
         N = n;

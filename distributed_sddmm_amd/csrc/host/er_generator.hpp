@@ -38,5 +38,9 @@ std::vector<uint64_t> vertex_permutation(uint64_t n, uint64_t seed);
 // MatrixMarket coordinate reader (general / symmetric; pattern, integer or real); duplicates keep the
 // maximum, as the reference's `maximum<double>()` reduction does (SpmatLocal.hpp:487).  Returns all tuples.
 void read_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std::vector<spcoord_t>& tuples);
+// its two halves: the parallel parser (symmetric entries mirrored, duplicates still present) and the duplicate merge on the host
+// (the default set-up does the merge on the GPU instead: hnh_tuples_sort + hnh_tuples_dedup_max)
+void parse_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std::vector<spcoord_t>& tuples);
+void merge_duplicates_max(std::vector<spcoord_t>& tuples);
 
 }  // namespace hnh

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <chrono>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -68,7 +69,7 @@ Backend* load_backend(const char* path_c) {
     HNH_BIND(hnh_sddmm_csr_ex) HNH_BIND(hnh_spmm_csr_ex) HNH_BIND(hnh_fused_sddmm_spmm_csr_ex) HNH_BIND(hnh_csr_max_row_nnz)
     HNH_BIND(hnh_fused_sddmm_spmm_csr_x) HNH_BIND(hnh_row_epilogue_f64) HNH_BIND(hnh_cg_step_f64)
     HNH_BIND(hnh_tuples_sort) HNH_BIND(hnh_tuples_bucket_starts) HNH_BIND(hnh_tuples_transform) HNH_BIND(hnh_tuples_to_csr)
-    HNH_BIND(hnh_csr_window_bounds) HNH_BIND(hnh_sddmm_csr_w) HNH_BIND(hnh_spmm_csr_w) HNH_BIND(hnh_fused_sddmm_spmm_csr_w) HNH_BIND(hnh_tuples_remap_cols)
+    HNH_BIND(hnh_csr_window_bounds) HNH_BIND(hnh_sddmm_csr_w) HNH_BIND(hnh_spmm_csr_w) HNH_BIND(hnh_fused_sddmm_spmm_csr_w) HNH_BIND(hnh_tuples_remap_cols) HNH_BIND(hnh_tuples_dedup_max) HNH_BIND(hnh_tuples_take_strided)
     HNH_BIND(hnh_panel_count) HNH_BIND(hnh_generate_er_keys) HNH_BIND(hnh_tuples_from_keys) HNH_BIND(hnh_tuples_relabel)
     HNH_BIND(hnh_fill_f64) HNH_BIND(hnh_hadamard_f64) HNH_BIND(hnh_axpy_f64) HNH_BIND(hnh_expand_rowptr)
     HNH_BIND(hnh_rowdot_f64) HNH_BIND(hnh_row_scale_add_f64) HNH_BIND(hnh_vec_add_scalar_f64) HNH_BIND(hnh_vec_div_f64) HNH_BIND(hnh_fill_hashed_f64)
@@ -419,7 +420,17 @@ struct ThreadGroup {
     // barrier
     int arrived = 0;
     uint64_t generation = 0;
-    uint64_t abort_epoch = 0;  // bumped when a rank fails: ranks WAITING on the group at that moment fail too instead of hanging
+    // A rank that waits for a peer longer than this gives up with an error instead of hanging for ever (a peer that failed
+    // — configuration error, device error — never arrives).  HNH_THREAD_WAIT_S, default 300 s.
+    double wait_limit_s() const {
+        const char* v = std::getenv("HNH_THREAD_WAIT_S");
+        return v ? std::atof(v) : 300.0;
+    }
+    template <typename Pred>
+    void wait_or_fail(std::unique_lock<std::mutex>& lk, Pred&& done) {
+        if (!cv.wait_for(lk, std::chrono::duration<double>(wait_limit_s()), done))
+            fatal("Error, a peer rank of the thread group did not arrive (it probably failed)");
+    }
     // pointer publication
     std::vector<const void*> slots;
     // point-to-point mailboxes, index src * n + dst
@@ -449,12 +460,6 @@ ThreadWorld::ThreadWorld(std::shared_ptr<ThreadGroup> group, int rank_in_group, 
 }
 ThreadWorld::~ThreadWorld() { destroy_device(); }
 
-void ThreadWorld::abort_peers() noexcept {
-    std::lock_guard<std::mutex> lk(g_->mu);
-    g_->abort_epoch++;
-    g_->cv.notify_all();
-}
-
 void ThreadWorld::barrier() {
     std::unique_lock<std::mutex> lk(g_->mu);
     const uint64_t gen = g_->generation;
@@ -463,11 +468,9 @@ void ThreadWorld::barrier() {
         g_->generation++;
         g_->cv.notify_all();
     } else {
-        const uint64_t ep = g_->abort_epoch;
-        g_->cv.wait(lk, [&] { return g_->generation != gen || g_->abort_epoch != ep; });
-        if (g_->generation == gen) {
+        if (!g_->cv.wait_for(lk, std::chrono::duration<double>(g_->wait_limit_s()), [&] { return g_->generation != gen; })) {
             g_->arrived--;  // this rank leaves the barrier again
-            fatal("Error, a peer rank of the thread group failed");
+            fatal("Error, a peer rank of the thread group did not arrive (it probably failed)");
         }
     }
 }
@@ -522,9 +525,7 @@ void ThreadWorld::sendrecv(const Comm& comm, const void* sendbuf, size_t sendbyt
         {
             std::unique_lock<std::mutex> lk(g_->mu);
             auto& q = g_->box[(size_t)src * n + rank];
-            const uint64_t ep = g_->abort_epoch;
-            g_->cv.wait(lk, [&] { return !q.empty() || g_->abort_epoch != ep; });
-            if (q.empty()) fatal("Error, a peer rank of the thread group failed");
+            g_->wait_or_fail(lk, [&] { return !q.empty(); });
             in = q.front();
             q.pop_front();
         }
@@ -543,9 +544,7 @@ void ThreadWorld::sendrecv(const Comm& comm, const void* sendbuf, size_t sendbyt
     if (out) {
         {
             std::unique_lock<std::mutex> lk(g_->mu);
-            const uint64_t ep = g_->abort_epoch;
-            g_->cv.wait(lk, [&] { return out->completed || g_->abort_epoch != ep; });
-            if (!out->completed) fatal("Error, a peer rank of the thread group failed");
+            g_->wait_or_fail(lk, [&] { return out->completed; });
         }
         event_wait(out->done, stream);  // do not let later work on `stream` overwrite sendbuf before the peer's copy ran
         event_destroy(out->done);

@@ -51,9 +51,6 @@ public:
 
     virtual ~World();
     virtual const char* kind() const = 0;
-    // this rank failed (an error is about to be reported to its caller): wake peers that wait on it.  Only the in-process
-    // thread group can do that; process-based transports rely on their launcher.
-    virtual void abort_peers() noexcept {}
 
     // ---- communicators
     Comm world_comm();
@@ -153,7 +150,6 @@ public:
     ThreadWorld(std::shared_ptr<ThreadGroup> group, int rank_in_group, Backend* backend, int device_ordinal);
     ~ThreadWorld() override;
     const char* kind() const override { return "thread-loopback"; }
-    void abort_peers() noexcept override;
     void sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes,
                   int src, int stream) override;
     void barrier() override;

@@ -5,127 +5,8 @@
 //     bench_er <logM> <edgeFactor> <15d|25d|15d_fusion1|15d_fusion2|15d_sparse|25d_dense_replicate|25d_sparse_replicate>
 //              <R> <c> <outfile> [fused|unfused] [vanilla|als|gat]
 //
-// One process per GPU.  Without a launcher it runs on GPU 0 (p = 1).  Multi-GPU: start N processes with
-// RANK / WORLD_SIZE / LOCAL_RANK set (torchrun, mpiexec -env, a shell loop) and HNH_ID_FILE naming a path on a
-// shared filesystem; rank 0 writes the RCCL unique id there, the others read it.  (The reference uses
-// MPI_Init; MPI is not needed here.)
-#include <chrono>
-#include <cstdio>
-#include <fstream>
-#include <iostream>
-#include <thread>
-
-#include "als_conjugate_gradients.hpp"
-#include "gat.hpp"
-#include "cannon_dense_25d.hpp"
-#include "cannon_sparse_25d.hpp"
-#include "dense_shift_15d.hpp"
-#include "sparse_shift_15d.hpp"
-
-using namespace std;
-
-static int env_int(const char* k, int dflt) {
-    const char* v = getenv(k);
-    return v ? atoi(v) : dflt;
-}
-
-static hnh::World* make_world() {
-    const int rank = env_int("RANK", 0), n = env_int("WORLD_SIZE", 1), local = env_int("LOCAL_RANK", rank);
-    hnh::Backend* be = hnh::load_backend(nullptr);  // the HIP library next to libhnh_host.so; exits if missing
-    if (n == 1) return new hnh::SingleWorld(be, local);
-    const char* idfile = getenv("HNH_ID_FILE");
-    if (!idfile) hnh::fatal("Error, WORLD_SIZE > 1 needs HNH_ID_FILE (path used to hand the RCCL unique id to all ranks)");
-    char id[HNH_UNIQUE_ID_BYTES];
-    if (rank == 0) {
-        if (be->hnh_comm_unique_id(id) != HNH_OK) hnh::fatal("Error, cannot create an RCCL unique id");
-        string tmp = string(idfile) + ".tmp";
-        ofstream(tmp, ios::binary).write(id, sizeof(id));
-        rename(tmp.c_str(), idfile);
-    } else {
-        for (int tries = 0;; tries++) {
-            ifstream f(idfile, ios::binary);
-            if (f && f.read(id, sizeof(id))) break;
-            if (tries > 6000) hnh::fatal("Error, timed out waiting for the RCCL unique id file");
-            this_thread::sleep_for(chrono::milliseconds(10));
-        }
-    }
-    return new hnh::RcclWorld(rank, n, be, local, id);
-}
-
-// benchmark_dist.cpp:26-167
-static void benchmark_algorithm(SpmatLocal* spmat, string algorithm_name, string output_file, bool fused, int R, int c, string app) {
-    hnh::World* world = hnh::current_world();
-    const int rank = world->rank;
-    StandardKernel local_ops;
-    Distributed_Sparse* d_ops = nullptr;
-    if (algorithm_name == "15d_fusion1") d_ops = new Sparse15D_Dense_Shift(spmat, R, c, 1, &local_ops);
-    else if (algorithm_name == "15d_sparse") d_ops = new Sparse15D_Sparse_Shift(spmat, R, c, &local_ops);
-    else if (algorithm_name == "15d_fusion2") d_ops = new Sparse15D_Dense_Shift(spmat, R, c, 2, &local_ops);
-    else if (algorithm_name == "25d_dense_replicate") d_ops = new Sparse25D_Cannon_Dense(spmat, R, c, &local_ops);
-    else if (algorithm_name == "25d_sparse_replicate") d_ops = new Sparse25D_Cannon_Sparse(spmat, R, c, &local_ops);
-    else hnh::fatal("Error, unknown algorithm " + algorithm_name);
-
-    unique_ptr<Distributed_ALS> d_als;
-    unique_ptr<GAT> gnn;
-    vector<GATLayer> layers;
-    if (app == "gat") {  // benchmark_dist.cpp:88-94: input features, features per head, heads
-        layers.emplace_back(256, 256, 4);
-        layers.emplace_back(1024, 256, 4);
-        layers.emplace_back(1024, 256, 6);
-        gnn.reset(new GAT(layers, d_ops));
-    } else if (app == "als") {
-        d_als.reset(new Distributed_ALS(d_ops, true));
-    } else if (app != "vanilla") {
-        hnh::fatal("Error, app must be vanilla, als or gat");
-    }
-
-    DenseMatrix A = d_ops->like_A_matrix(0.001), B = d_ops->like_B_matrix(0.001);
-    VectorXd S = d_ops->like_S_values(1.0), sddmm_result = d_ops->like_S_values(0.0);
-    if (rank == 0) cout << "Starting benchmark " << app << endl;
-
-    // one untimed call: first-touch / lazily created communicators stay out of the measurement
-    if (app == "vanilla") d_ops->fusedSpMM(A, B, S, sddmm_result, Amat);
-    world->sync_all();
-    world->barrier();
-
-    d_ops->reset_performance_timers();
-    my_timer_t t = start_clock();
-    int num_trials = 0;
-    double application_communication_time = 0.0;
-    do {
-        num_trials++;
-        if (app == "vanilla") {
-            if (fused) d_ops->fusedSpMM(A, B, S, sddmm_result, Amat);
-            else {
-                d_ops->sddmmA(A, B, S, sddmm_result);
-                d_ops->spmmA(A, B, S);
-            }
-        } else if (app == "gat") {
-            gnn->forwardPass();
-        } else {
-            d_als->application_communication_time = 0.0;
-            d_als->run_cg(1);
-            application_communication_time = d_als->application_communication_time;
-        }
-    } while (num_trials < 5);
-    world->sync_all();  // GPU work is asynchronous: drain before stopping the clock
-    world->barrier();
-    const double elapsed = stop_clock_get_elapsed(t);
-    const double ops = 2.0 * (double)spmat->dist_nnz * 2.0 * R * num_trials;  // benchmark_dist.cpp:147
-    const double throughput = ops / elapsed / 1e9;
-    const string alg_info = d_ops->json_algorithm_info(), perf = d_ops->json_perf_statistics();
-    if (rank == 0) {
-        ofstream fout(output_file, ios_base::app);
-        fout << "{\"elapsed\": " << elapsed << ", \"overall_throughput\": " << throughput << ", \"fused\": " << (fused ? "true" : "false")
-             << ", \"num_trials\": " << num_trials << ", \"alg_name\": \"" << algorithm_name << "\", \"alg_info\": " << alg_info
-             << ", \"application_communication_time\": " << application_communication_time << ", \"perf_stats\": " << perf << "}," << endl;
-        cout << algorithm_name << ": " << elapsed << " s for " << num_trials << " trials, " << throughput << " GFLOP/s = "
-             << throughput * 1e9 / 4.0 << " nnz*R/s" << endl;
-    }
-    d_als.reset();
-    gnn.reset();
-    delete d_ops;
-}
+// Process bootstrap and benchmark_algorithm(): bench_common.hpp.
+#include "bench_common.hpp"
 
 int main(int argc, char** argv) {
     if (argc < 7) {

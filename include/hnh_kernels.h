@@ -221,6 +221,12 @@ int hnh_tuples_remap_cols(hnh_ctx* ctx, hnh_tuple* tuples, int64_t n, int64_t di
                           const int64_t* dest_host, int64_t ndest, int stream);
 int hnh_tuples_to_csr(hnh_ctx* ctx, const hnh_tuple* sorted, int64_t n, int64_t rows, int64_t cols, int32_t* rowptr,
                       int32_t* col_idx, double* values, int* max_row_nnz_host, int stream);
+/* File input on the device (replaces the duplicate handling of CombBLAS ParallelReadMM(..., maximum<double>()), SpmatLocal.hpp:485-498):
+ * hnh_tuples_dedup_max     tuples in HNH_KEY_ROW_COL order: every run of equal (row, col) collapses to ONE tuple carrying the
+ *                          run's MAXIMUM value; compacted in place, the new count goes to *n_unique_host; synchronous
+ * hnh_tuples_take_strided  out[i] = src[first + i * stride]: a rank's strided slice of the whole tuple list */
+int hnh_tuples_dedup_max(hnh_ctx* ctx, hnh_tuple* sorted, int64_t n, int64_t* n_unique_host, int stream);
+int hnh_tuples_take_strided(hnh_ctx* ctx, const hnh_tuple* src, int64_t first, int64_t stride, hnh_tuple* out, int64_t n_out, int stream);
 /* Synthetic input on the device (replaces CombBLAS GenGraph500Data with initiator {.25,.25,.25,.25}, SpmatLocal.hpp:502-505):
  * hnh_generate_er_keys   the counter-based Erdos-Renyi generator of er_generator.hpp / oracle.py:erdos_renyi_mn, bit for bit:
  *                        draw k -> key = (splitmix64(seed + 2kG) % m) * n + splitmix64(seed + (2k+1)G) % n; `keys` (device,

@@ -474,6 +474,28 @@ int hnh_tuples_transform(hnh_ctx* c, hnh_tuple* t, int64_t n, int swap_rc, uint6
     }
     return HNH_OK;
 }
+/* SpmatLocal.hpp:485-498: ParallelReadMM(..., maximum<double>()) keeps the largest value of duplicate coordinates */
+int hnh_tuples_dedup_max(hnh_ctx* c, hnh_tuple* t, int64_t n, int64_t* n_unique, int stream) {
+    (void)stream;
+    if (n < 0 || !n_unique) return fail(c, HNH_ERR_INVALID, "bad argument");
+    int64_t out = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (out > 0 && t[out - 1].r == t[i].r && t[out - 1].c == t[i].c) {
+            if (t[i].value > t[out - 1].value) t[out - 1].value = t[i].value;
+        } else {
+            t[out++] = t[i];
+        }
+    }
+    *n_unique = out;
+    return HNH_OK;
+}
+int hnh_tuples_take_strided(hnh_ctx* c, const hnh_tuple* src, int64_t first, int64_t stride, hnh_tuple* out, int64_t n_out, int stream) {
+    (void)stream;
+    if (n_out < 0 || first < 0 || stride <= 0) return fail(c, HNH_ERR_INVALID, "bad argument");
+    for (int64_t i = 0; i < n_out; i++) out[i] = src[first + i * stride];
+    return HNH_OK;
+}
+
 int hnh_tuples_remap_cols(hnh_ctx* c, hnh_tuple* t, int64_t n, int64_t div, int64_t sub_div, int64_t n_sub, const int64_t* dest,
                           int64_t ndest, int stream) {
     (void)stream;

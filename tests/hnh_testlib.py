@@ -89,9 +89,10 @@ def probe_local(subs: np.ndarray, shape, is_a: bool, n: int) -> np.ndarray:
     return loc
 
 
-def run_all_ops(world: H.World, alg: str, c: int, case: dict) -> dict:
-    """Executes on ONE rank; returns this rank's share of every result."""
-    sp = H.SpmatLocal.from_global(world, case["M"], case["N"], case["rows"], case["cols"], case["vals"])
+def run_all_ops(world: H.World, alg: str, c: int, case: dict, make_spmat=None) -> dict:
+    """Executes on ONE rank; returns this rank's share of every result.  make_spmat(world) may supply the input matrix (a
+    file reader, ...) instead of the case's tuples."""
+    sp = make_spmat(world) if make_spmat else H.SpmatLocal.from_global(world, case["M"], case["N"], case["rows"], case["cols"], case["vals"])
     d = H.DistributedSparse(world, alg, sp, case["R"], c)
     info = d.info()
     subA, subB = d.submatrices(H.AMAT), d.submatrices(H.BMAT)
@@ -375,3 +376,31 @@ def check_fused_out(per_rank, case, matmode, leaky_alpha, x_scale, want_rowdot):
                 if keep > 0:  # a rank whose rows are all padding (M < p * rows per rank) has nothing to compare
                     assert np.max(np.abs(o["rowdot"][off:off + keep] - want_dot[top:top + keep])) <= TOL * scale
                 off += rc
+
+
+def write_symmetric_mtx_with_duplicates(path, n, seed):
+    """A symmetric MatrixMarket file (lower triangle stored) in which about a third of the entries appear two or three
+    times with different values.  Returns the tuples a reader must produce: both triangles, duplicates merged by MAXIMUM
+    (the reference reads with maximum<double>(), SpmatLocal.hpp:485-498)."""
+    rng = np.random.default_rng(seed)
+    r, c = rng.integers(0, n, 6 * n), rng.integers(0, n, 6 * n)
+    lo = np.unique(np.maximum(r, c) * n + np.minimum(r, c))           # distinct lower-triangle coordinates
+    dup = np.concatenate([lo, lo[::3], lo[::7]])
+    rng.shuffle(dup)
+    vals = rng.uniform(-1, 1, len(dup))
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real symmetric\n% written by the test\n" + "%d %d %d\n" % (n, n, len(dup)))
+        for k, v in zip(dup.tolist(), vals.tolist()):
+            f.write("%d %d %.17g\n" % (k // n + 1, k % n + 1, v))
+    best = {}
+    for k, v in zip(dup.tolist(), vals.tolist()):
+        best[k] = max(best.get(k, -np.inf), v)
+    rows, cols, out = [], [], []
+    for k, v in best.items():
+        i, j = k // n, k % n
+        rows.append(i); cols.append(j); out.append(v)
+        if i != j:
+            rows.append(j); cols.append(i); out.append(v)
+    rows, cols, out = np.array(rows), np.array(cols), np.array(out)
+    order = np.argsort(rows * n + cols)
+    return rows[order], cols[order], out[order]

@@ -123,3 +123,29 @@ def test_config1_full_size_against_the_compiled_reference():
     ours = np.sum([o["fingerprints"] for o in per_rank], axis=0)
     want = np.array([ref["sddmm"], ref["spmmA"], ref["spmmB"]]) if isinstance(ref, dict) else np.asarray(ref)
     assert T.rel(ours, want) <= T.TOL, (ours, want)
+
+
+@pytest.mark.parametrize("host_setup", [False, True])
+def test_matrix_market_file_through_the_schedules(tmp_path, monkeypatch, host_setup):
+    """SURVEY 8(f3) on the CPU test double: symmetric .mtx with duplicates -> parsed, merged with maximum (device-style
+    pipeline: sort + hnh_tuples_dedup_max, or the host pipeline), vertex-permuted -> 2.5D dense-replicate and 1.5D fused ->
+    every operator result against the oracle on the matrix the file describes."""
+    if host_setup:
+        monkeypatch.setenv("HNH_HOST_SETUP", "1")
+    n, r, seed = 300, 16, 9
+    path = str(tmp_path / "graph.mtx")
+    rows, cols, vals = T.write_symmetric_mtx_with_duplicates(path, n, 4)
+    label = O.vertex_permutation(n, seed)
+    prow, pcol = label[rows], label[cols]
+    order = np.argsort(prow * n + pcol)
+    case = dict(name="mtx", M=n, N=n, R=r, rows=prow[order], cols=pcol[order], vals=vals[order], A=O.dense_fill(n, r, 31), B=O.dense_fill(n, r, 32))
+
+    def from_file(w):
+        sp = H.SpmatLocal.load_tuples(w, True, -1, -1, path)
+        assert sp.info()["dist_nnz"] == len(rows)
+        sp.permute(seed)
+        return sp
+
+    for alg, p, c in (("25d_dense_replicate", 8, 2), ("15d_fusion2", 4, 1)):
+        per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case, make_spmat=from_file))
+        T.check_against_oracle(T.assemble(per_rank, case), case, alg)

@@ -112,6 +112,30 @@ def test_config4_shape_skewed_graph_hip(alg, p, c):
     T.check_against_oracle(T.assemble(per_rank, case), case, alg)
 
 
+def test_matrix_market_file_to_25d_dense_on_the_gpu(tmp_path):
+    """SURVEY 8(f3), the input side end to end on the HIP path: a symmetric .mtx with duplicate entries is parsed, merged
+    (maximum, on the GPU next to the sort), vertex-permuted (random_permute.cpp:42-50) and fed to the 2.5D dense-replicating
+    schedule at R = 256 on p = 8, c = 2; every operator result against the oracle on the matrix the file describes."""
+    from oracle import oracle as O
+    n, r, seed = 600, 256, 9
+    path = str(tmp_path / "graph.mtx")
+    rows, cols, vals = T.write_symmetric_mtx_with_duplicates(path, n, 4)
+    label = O.vertex_permutation(n, seed)
+    prow, pcol = label[rows], label[cols]
+    order = np.argsort(prow * n + pcol)
+    case = dict(name="mtx", M=n, N=n, R=r, rows=prow[order], cols=pcol[order], vals=vals[order], A=O.dense_fill(n, r, 31), B=O.dense_fill(n, r, 32))
+
+    def from_file(w):
+        sp = H.SpmatLocal.load_tuples(w, True, -1, -1, path)
+        assert sp.info()["dist_nnz"] == len(rows)
+        sp.permute(seed)
+        return sp
+
+    for alg, p, c in (("25d_dense_replicate", 8, 2), ("15d_fusion2", 4, 1)):
+        per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case, make_spmat=from_file))
+        T.check_against_oracle(T.assemble(per_rank, case), case, alg)
+
+
 def test_cpp_dropin_driver(tmp_path):
     """examples/bench_er.cpp — the reference's bench_erdos_renyi.cpp + benchmark_dist.cpp re-written against our class
     headers — runs end to end and appends JSON records with the reference's keys (benchmark_dist.cpp:151-162)."""
@@ -132,6 +156,20 @@ def test_cpp_dropin_driver(tmp_path):
         assert r["num_trials"] == 5 and r["alg_info"]["backend"] == "hip-gfx950" and "Computation Time" in r["perf_stats"]
     r = subprocess.run([exe, "10", "8", "15d_fusion2", "16", "1", str(out), "fused", "als"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    # bench_file.cpp's driver: same records from a MatrixMarket file ("15d" = 15d_sparse unfused, "25d" = 25d_dense_replicate unfused)
+    exe_file = os.path.join(T.ROOT, "examples", "bench_file")
+    assert os.path.exists(exe_file), "run __graft_entry__.build()"
+    mtx = str(tmp_path / "g.mtx")
+    mrows, _, _ = T.write_symmetric_mtx_with_duplicates(mtx, 500, 3)
+    out2 = tmp_path / "file_results.json"
+    for alg in ("15d", "25d", "15d_fusion2"):
+        r = subprocess.run([exe_file, mtx, alg, "64", "1", str(out2), "vanilla"], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, HNH_PERMUTE_SEED="5"))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        assert "File reader read %d nonzeros." % len(mrows) in r.stdout
+    recs2 = json.loads("[" + out2.read_text().rstrip().rstrip(",") + "]")
+    assert [r["alg_name"] for r in recs2] == ["15d_sparse", "25d_dense_replicate", "15d_fusion2"]
+    assert all(r["alg_info"]["nnz"] == len(mrows) and r["alg_info"]["m"] == 500 and not r["fused"] for r in recs2)
     # the GAT application of benchmark_dist.cpp:88-94,133-135 (3 layers, 14 heads, 256 features per head)
     for alg in ("15d_fusion2", "15d_fusion1"):
         r = subprocess.run([exe, "10", "8", alg, "256", "1", str(out), "fused", "gat"], capture_output=True, text=True, timeout=300)

@@ -26,6 +26,7 @@ ap.add_argument("--backend", default=None, help="kernel library to load (default
 ap.add_argument("--chunks", default="", help="comma list of HNH_MESH_CHUNKS values to sweep (default: the library default)")
 a = ap.parse_args()
 
+os.environ.setdefault("HNH_FORCE_WINDOWS", "1")  # the held blocks are resident, but walk the chunk windows as a fetching call does
 from distributed_sddmm_amd import api as H  # noqa: E402
 
 name = H.load_backend(a.backend)
