@@ -394,7 +394,19 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
                 if (!more) break;
             }
         }
-        // fewer than 4U nonzeros left: masked double halves (both halves' gathers issued together), at most two trips
+        // fewer than 4U nonzeros left: one unmasked double half when at least 2U remain ...
+        if (e + 2 * U <= end) {
+            int c0[U], c1[U];
+            load_idx(kFull, e, c0);
+            load_idx(kFull, e + U, c1);
+            gather(kFull, c0, ya);
+            gather(kFull, c1, yb);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(kFull, e, ya);
+            compute(kFull, e + U, yb);
+            e += 2 * U;
+        }
+        // ... then masked double halves (both halves' gathers issued together): at most one trip
         while (e < end) {
             int c0[U], c1[U];
             load_idx(kMasked, e, c0);
