@@ -11,13 +11,14 @@ import pytest
 from test_gloo_world import ROOT, free_port
 
 
-@pytest.mark.parametrize("nranks,alg,c", [(1, "15d_fusion2", 1), (2, "15d_fusion2", 1), (4, "15d_fusion2", 1), (4, "15d_fusion2", 2), (2, "15d_fusion1", 1)])
-def test_bench_contract(nranks, alg, c):
+@pytest.mark.parametrize("nranks,alg,c,ring", [(1, "15d_fusion2", 1, None), (2, "15d_fusion2", 1, None), (4, "15d_fusion2", 1, None),
+                                                (4, "15d_fusion2", 2, None), (2, "15d_fusion1", 1, None), (4, "15d_fusion2", 1, "relay")])
+def test_bench_contract(nranks, alg, c, ring):
     port = free_port()
     procs = []
     for r in range(nranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="2", GLOO_SOCKET_IFNAME="lo")
+                   OMP_NUM_THREADS="2", GLOO_SOCKET_IFNAME="lo", BENCH_RING_MODE=ring or "")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "bench_worker.py"), alg, str(c)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=300)[0] for p in procs]
@@ -41,6 +42,6 @@ def test_bench_contract(nranks, alg, c):
     assert chk["nnz_operator"] == chk["nnz_host_generator"] == out["config"]["nnz"]
     if nranks > 1:  # every transport primitive ran before the timed region, and what was measured is recorded
         assert len(out["preflight"]["primitives_ok"]) == 9
-        assert out["config"]["ring_mode"] == "mesh" and out["config"]["transport"] == "rccl"
+        assert out["config"]["ring_mode"] == (ring or "mesh") and out["config"]["transport"] == "rccl"
     else:
         assert "preflight" not in out
