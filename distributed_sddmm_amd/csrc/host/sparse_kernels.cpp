@@ -1,5 +1,8 @@
 #include "sparse_kernels.hpp"
 
+// SDDMM of operands up to this many columns goes through the nonzero-balanced COO kernel (StandardKernel::sddmm_local)
+static constexpr int64_t kCooSddmmMaxWidth = 16;
+
 // StandardKernel::sddmm_local — sparse_kernels.cpp:13-57 of the reference:
 //   values[i] += <Arow(row_idx[i]), Brow(col_idx[i])>, with A and B swapped when the block is stored
 //   transposed (:29-37); a null block is a no-op (:25-27); always reports 0 nonzeros (:23,56).
@@ -19,6 +22,17 @@ size_t StandardKernel::sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
         w->check(w->be->hnh_sddmm_csr_w(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, Xptr, Yptr, (int)A.cols(),
                                         blk->num_coords, blk->row_hint(), &win, HNH_STREAM_COMPUTE),
                  "hnh_sddmm_csr_w");
+        end(w);
+        return processed;
+    }
+    if (A.cols() <= kCooSddmmMaxWidth) {
+        // narrow operands: several sparse rows share a wave in the row kernel, and the wave runs as long as its longest row;
+        // the COO kernel deals nonzeros out evenly instead (measured at config-2 size, R = 16: 2.06 vs 2.64 ms; R = 8: 2.03 vs
+        // 3.37 ms; at R = 128 the row kernel wins 14.4 vs 19.3 ms — profiles/r02_kbench_narrow_and_coo.log)
+        const int32_t* row_idx = blk->ensure_row_idx(HNH_STREAM_COMPUTE);
+        w->check(w->be->hnh_sddmm_coo(w->ctx, blk->num_coords, row_idx, active->col_idx, active->values, Xptr, Yptr, (int)A.cols(),
+                                      HNH_STREAM_COMPUTE),
+                 "hnh_sddmm_coo");
         end(w);
         return processed;
     }

@@ -46,6 +46,7 @@ public:
     int32_t* col_idx = nullptr;   // device
     int32_t* rowStart = nullptr;  // device, rows + 1 entries
     int32_t* row_idx = nullptr;   // device, built on demand by CSRLocal::ensure_row_idx()
+    bool row_idx_valid = false;   // row_idx describes the rowStart currently in this handle
 };
 
 class CSRLocal {
@@ -95,9 +96,11 @@ public:
     struct RingIndex {
         int32_t* col_idx = nullptr;
         int32_t* rowStart = nullptr;
+        int32_t* row_idx = nullptr;  // COO view of the same structure, built on first use (ensure_row_idx)
         int nnz = 0;
     };
     std::vector<RingIndex> ring_index;  // by ring position of the block's origin; empty = indices travel (reference behaviour)
+    int active_slot = -1;               // ring position whose block occupies the active buffer (ring-resident indices only)
 
     // Device build (the default): `dev_tuples` are this block's tuples in DEVICE memory, in any order.  One
     // radix sort into CSR order and one unzip pass; like the reference's constructor, the caller's tuples end up in CSR
@@ -210,6 +213,7 @@ public:
         for (RingIndex& ri : ring_index) {
             world->dfree(ri.col_idx);
             world->dfree(ri.rowStart);
+            world->dfree(ri.row_idx);
         }
         world->dfree(win_split);
         delete[] buffer;
@@ -244,17 +248,30 @@ public:
             buffer[t].col_idx = ring_index[me].col_idx;
             buffer[t].rowStart = ring_index[me].rowStart;
         }
+        active_slot = me;
     }
     CSRLocal(const CSRLocal&) = delete;
     CSRLocal& operator=(const CSRLocal&) = delete;
 
     CSRHandle* getActive() { return buffer + active; }
 
-    // COO row indices of the active buffer (only the COO kernel entry point needs them)
+    // COO row indices of the block in the active buffer (the nonzero-balanced SDDMM of narrow operands walks them): built
+    // once per structure — per ring position when the ring's structure is resident, again after a shift when indices travel.
     int32_t* ensure_row_idx(int stream = HNH_STREAM_COMPUTE) {
+        if (!ring_index.empty()) {
+            RingIndex& ri = ring_index[(size_t)active_slot];
+            if (!ri.row_idx) {
+                ri.row_idx = static_cast<int32_t*>(world->dmalloc((size_t)std::max(ri.nnz, 1) * sizeof(int32_t)));
+                world->check(world->be->hnh_expand_rowptr(world->ctx, rows, ri.rowStart, ri.row_idx, stream), "hnh_expand_rowptr");
+            }
+            return ri.row_idx;
+        }
         CSRHandle* h = getActive();
         if (!h->row_idx) h->row_idx = static_cast<int32_t*>(world->dmalloc((size_t)std::max(max_nnz, 1) * sizeof(int32_t)));
-        world->check(world->be->hnh_expand_rowptr(world->ctx, rows, h->rowStart, h->row_idx, stream), "hnh_expand_rowptr");
+        if (!h->row_idx_valid) {
+            world->check(world->be->hnh_expand_rowptr(world->ctx, rows, h->rowStart, h->row_idx, stream), "hnh_expand_rowptr");
+            h->row_idx_valid = true;
+        }
         return h->row_idx;
     }
 
@@ -278,6 +295,7 @@ public:
             recv->rowStart = ring_index[incoming_slot].rowStart;
             num_coords = nnz_to_receive;
             active = 1 - active;
+            active_slot = incoming_slot;
             return;
         }
         world->group_begin();  // the three arrays travel as one RCCL group
@@ -288,6 +306,7 @@ public:
         world->sendrecv(comm, send->rowStart, ((size_t)rows + 1) * sizeof(int32_t), dst, recv->rowStart,
                         ((size_t)rows + 1) * sizeof(int32_t), src, stream);
         world->group_end();
+        recv->row_idx_valid = false;  // another block's structure arrives in this handle
         num_coords = nnz_to_receive;
         active = 1 - active;
     }
