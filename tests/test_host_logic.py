@@ -128,3 +128,16 @@ def test_failing_rank_does_not_hang_its_peers(monkeypatch):
     t0 = time.time()
     assert H.run_spmd(2, body) == ["gave up", "failed as expected"]
     assert time.time() - t0 < 60
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 8])
+def test_transport_preflight_on_the_loopback_transport(p):
+    """hnh_world_preflight: every transport primitive the schedules use delivers the expected data on p logical ranks, and
+    all ranks end with the same communicator-split signature (what bench.py --gpus N checks before it times anything)."""
+    def body(w):
+        errs = [w.preflight(k, 1000) for k in range(len(H.World.PREFLIGHT))]
+        return errs, w.split_signature()
+
+    res = H.run_spmd(p, body)
+    assert all(max(errs) == 0.0 for errs, _ in res)
+    assert len({sig for _, sig in res}) == 1 and res[0][1][1] == 2 * len(H.World.PREFLIGHT)

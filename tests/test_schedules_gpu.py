@@ -80,6 +80,8 @@ def test_rccl_world_single_rank():
             T.check_against_golden(T.assemble([out], case), [out], case, alg)
         vals, ok = w.grid_probe(1, 1, 1, 3)
         assert ok and vals[:3] == [0, 0, 0]
+        # the transport self-tests bench.py --gpus N runs first (here with the one rank a 1-GPU box allows)
+        assert all(w.preflight(k, 4096) == 0.0 for k in range(len(H.World.PREFLIGHT)))
     finally:
         w.close()
 
