@@ -115,6 +115,41 @@ def test_config2_full_size_fused_elementwise(config2):
     d.free(); sp.free(); w.close()
 
 
+@pytest.mark.parametrize("c,chunks,ring", [(1, "4", "mesh"), (2, "2", "mesh"), (1, "1", "relay")])
+def test_config3_full_size_on_eight_logical_ranks(config2, monkeypatch, c, chunks, ring):
+    """BASELINE config 3 — the schedule an 8-GPU bench.py run executes (1.5D dense shift, local kernel fusion, the same 1.0e8-nonzero
+    matrix) — at FULL size on 8 logical ranks sharing the GPU: merged layout, chunked fetch into the landing buffer and windowed
+    passes (or the relay ring), with and without replication.  Checked like bench.py checks itself (closed form of one fused call
+    from constant operands, every rank's rows) and by the fingerprint trio."""
+    monkeypatch.setenv("HNH_MESH_CHUNKS", chunks)
+    monkeypatch.setenv("HNH_RING_MODE", ring)
+    m, r, p = config2["m"], 128, 8
+    deg = np.bincount(config2["rows"], minlength=m).astype(np.float64)
+
+    def body(w):
+        sp = H.SpmatLocal.load_tuples(w, False, config2["logm"], config2["ef"])
+        d = H.DistributedSparse(w, "15d_fusion2", sp, r, c)
+        sp.free()
+        A, B = d.like_A_matrix(0.001), d.like_B_matrix(0.001)
+        S, buf = d.like_S_values(1.0), d.like_S_values(0.0)
+        d.fusedSpMM(A, B, S, buf, H.AMAT)
+        got = A.download().reshape(-1)
+        worst, off = 0.0, 0
+        for top, left, rc, cc in d.submatrices(H.AMAT):
+            blk = got[off:off + rc * cc].reshape(rc, cc)
+            off += rc * cc
+            worst = max(worst, float(np.max(np.abs(blk - deg[top:top + rc, None] * (r * 1e-9)))))
+        for x in (A, B, S, buf):
+            x.free()
+        fp = device_fingerprints(d)
+        d.free()
+        return worst, fp
+
+    res = H.run_spmd(p, body)
+    assert max(x[0] for x in res) <= T.TOL * deg.max() * r * 1e-9
+    assert T.rel(np.sum([x[1] for x in res], axis=0), config2["closed"]) <= T.TOL
+
+
 def test_config4_shape_full_size_25d_dense():
     """BASELINE config 4's shape at full size: a skewed R-MAT graph on 2^22 vertices (2.16e8 unique nonzeros, longest row
     2.4e5 — the stand-in for com-Orkut), R = 256, 2.5D dense-replicating Cannon on p = 8, c = 2 (2 x 2 x 2) through the

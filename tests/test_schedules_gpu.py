@@ -144,6 +144,8 @@ def test_cpp_dropin_driver(tmp_path):
     import json
     import os
     import subprocess
+    # the class layouts live in the headers: make sure the drivers match the library they are about to load
+    subprocess.run(["make", "-C", os.path.join(T.ROOT, "examples"), "bench_er", "bench_file"], check=True, capture_output=True, timeout=600)
     exe = os.path.join(T.ROOT, "examples", "bench_er")
     assert os.path.exists(exe), "run __graft_entry__.build()"
     out = tmp_path / "results.json"
@@ -183,6 +185,7 @@ def test_custom_kernel_plugin_hip():
     drives all five schedules on the GPU and reproduces StandardKernel's results (the documented extension point)."""
     import os
     import subprocess
+    subprocess.run(["make", "-C", os.path.join(T.ROOT, "examples"), "custom_kernel"], check=True, capture_output=True, timeout=600)
     exe = os.path.join(T.ROOT, "examples", "custom_kernel")
     assert os.path.exists(exe), "run __graft_entry__.build()"
     r = subprocess.run([exe, "", "12", "8", "32"], capture_output=True, text=True, timeout=300)
