@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-full", action="store_true", help="skip the CPU baseline's run at the GPU line's full size")
     ap.add_argument("--no-check", action="store_true", help="skip the closed-form result check (outside the timed region)")
     ap.add_argument("--no-preflight", action="store_true", help="skip the transport self-tests of a multi-GPU run")
+    ap.add_argument("--no-tune", action="store_true", help="several GPUs: keep the default chunk count instead of measuring 2 / 4 / 8")
     ap.add_argument("--watchdog", type=float, default=240.0, help="seconds a multi-GPU phase may take before the rank reports "
                     "where it is stuck and exits non-zero")
     return ap.parse_args()
@@ -231,11 +232,51 @@ def run(args, make_world=gpu_world):
     info = sp.info()
     nnz, m = info["dist_nnz"], info["M"]
     op = H.DistributedSparse(world, args.alg, sp, args.r, args.c)
-    sp.free()
     A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
     S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
     barrier()
     t_setup = time.perf_counter() - t_setup
+
+    # ---- several GPUs, mesh fetch: how many chunks the fetched blocks arrive in (= windowed passes per call) trades kernel
+    # efficiency against fetch/compute overlap and depends on the xGMI bandwidth actually delivered.  Unless --chunks fixes it,
+    # the candidates are MEASURED here (1 warm-up + 3 calls each, max over ranks), outside the timed region, and the fastest
+    # one is what gets timed; the JSON line records all of them.
+    tuning = None
+    mesh = os.environ.get("HNH_RING_MODE", "mesh") == "mesh"
+    if n > 1 and mesh and args.alg == "15d_fusion2" and args.chunks is None and not args.no_tune and n // args.c > 1:
+        dog.phase("chunk-count tuning", max(args.watchdog, 600.0))
+        tuning = {}
+        default_q = int(os.environ.get("HNH_MESH_CHUNKS", "4"))
+        for q in sorted({default_q, 2, 4, 8}):
+            if q != default_q or tuning:  # the operator built above already has default_q chunks
+                for x in (A, B, S, buf):
+                    x.free()
+                op.free()
+                os.environ["HNH_MESH_CHUNKS"] = str(q)
+                op = H.DistributedSparse(world, args.alg, sp, args.r, args.c)
+                A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
+                S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
+            op.fusedSpMM(A, B, S, buf, H.AMAT)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                op.fusedSpMM(A, B, S, buf, H.AMAT)
+            barrier()
+            t = torch.tensor([(time.perf_counter() - t0) / 3], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tuning[q] = float(t.item()) * 1e3
+        best = min(tuning, key=tuning.get)
+        if int(os.environ["HNH_MESH_CHUNKS"]) != best:
+            for x in (A, B, S, buf):
+                x.free()
+            op.free()
+            os.environ["HNH_MESH_CHUNKS"] = str(best)
+            op = H.DistributedSparse(world, args.alg, sp, args.r, args.c)
+            A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
+            S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
+        A.fill(0.001)
+        barrier()
+    sp.free()
 
     def step():
         op.fusedSpMM(A, B, S, buf, H.AMAT)
@@ -362,6 +403,8 @@ def run(args, make_world=gpu_world):
             out["check"] = check
         if preflight is not None:
             out["preflight"] = {"primitives_ok": sorted(preflight), "communicator_split_order": "identical on all ranks"}
+        if tuning is not None:
+            out["config"]["mesh_chunks_tuning_ms_per_step"] = {str(k): round(v, 4) for k, v in sorted(tuning.items())}
         if n == 1 and not args.no_cpu_baseline and out["backend"] == "hip-gfx950":
             try:
                 out["cpu_baseline"] = cpu_baseline(args)

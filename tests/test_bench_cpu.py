@@ -43,5 +43,10 @@ def test_bench_contract(nranks, alg, c, ring):
     if nranks > 1:  # every transport primitive ran before the timed region, and what was measured is recorded
         assert len(out["preflight"]["primitives_ok"]) == 9
         assert out["config"]["ring_mode"] == (ring or "mesh") and out["config"]["transport"] == "rccl"
+        tuned = alg == "15d_fusion2" and ring is None and nranks // c > 1
+        assert ("mesh_chunks_tuning_ms_per_step" in out["config"]) == tuned
+        if tuned:  # the chunk count that was timed is the fastest of the measured candidates
+            t = out["config"]["mesh_chunks_tuning_ms_per_step"]
+            assert set(t) == {"2", "4", "8"} and out["config"]["mesh_chunks"] == int(min(t, key=t.get))
     else:
         assert "preflight" not in out

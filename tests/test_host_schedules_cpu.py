@@ -179,3 +179,15 @@ def test_wrong_length_value_vector_is_refused():
 
     for msgs in H.run_spmd(1, body):
         assert all("wrong length" in m for m in msgs)
+
+
+@pytest.mark.parametrize("alg", H.ALGORITHMS)
+def test_matrix_without_nonzeros(alg):
+    """A sparse matrix with NO nonzero: every operator is a (collective) no-op that leaves zeros behind, on every grid."""
+    m, n, r = 40, 24, 8
+    case = T.make_case("empty", m, n, r, np.array([], dtype=np.int64), np.array([], dtype=np.int64), seed=3)
+    for p, c in ((1, 1), (4, 1), (8, 2), (4, 4)):
+        if not T.valid_config(alg, p, c, r):
+            continue
+        per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
+        T.check_against_oracle(T.assemble(per_rank, case), case, alg)

@@ -43,6 +43,18 @@ def test_edge_cases_hip(case_name, alg):
         T.check_against_golden(T.assemble(per_rank, case), per_rank, case, alg)
 
 
+@pytest.mark.parametrize("alg", H.ALGORITHMS)
+def test_matrix_without_nonzeros_hip(alg):
+    """A sparse matrix with NO nonzero on the HIP path: every operator leaves zeros behind, on one and on several ranks."""
+    m, n, r = 40, 24, 8
+    case = T.make_case("empty", m, n, r, np.array([], dtype=np.int64), np.array([], dtype=np.int64), seed=3)
+    for p, c in ((1, 1), (4, 1), (8, 2)):
+        if not T.valid_config(alg, p, c, r):
+            continue
+        per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
+        T.check_against_oracle(T.assemble(per_rank, case), case, alg)
+
+
 @pytest.mark.parametrize("alg,p,c", [("15d_fusion2", 1, 1), ("15d_fusion2", 4, 2), ("15d_fusion1", 4, 1), ("15d_sparse", 4, 1),
                                      ("25d_dense_replicate", 4, 1), ("25d_sparse_replicate", 8, 2)])
 def test_cfg1_scale_vs_oracle(alg, p, c):
