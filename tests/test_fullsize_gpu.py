@@ -115,12 +115,15 @@ def test_config2_full_size_fused_elementwise(config2):
     d.free(); sp.free(); w.close()
 
 
-@pytest.mark.parametrize("c,chunks,ring", [(1, "4", "mesh"), (2, "2", "mesh"), (1, "1", "relay")])
-def test_config3_full_size_on_eight_logical_ranks(config2, monkeypatch, c, chunks, ring):
+@pytest.mark.parametrize("alg,c,chunks,ring", [("15d_fusion2", 1, "4", "mesh"), ("15d_fusion2", 2, "2", "mesh"), ("15d_fusion2", 1, "1", "relay"),
+                                               ("15d_fusion1", 2, "4", "mesh"), ("15d_sparse", 2, "4", "mesh"),
+                                               ("25d_dense_replicate", 2, "4", "mesh"), ("25d_sparse_replicate", 2, "4", "mesh")])
+def test_config3_full_size_on_eight_logical_ranks(config2, monkeypatch, alg, c, chunks, ring):
     """BASELINE config 3 — the schedule an 8-GPU bench.py run executes (1.5D dense shift, local kernel fusion, the same 1.0e8-nonzero
     matrix) — at FULL size on 8 logical ranks sharing the GPU: merged layout, chunked fetch into the landing buffer and windowed
-    passes (or the relay ring), with and without replication.  Checked like bench.py checks itself (closed form of one fused call
-    from constant operands, every rank's rows) and by the fingerprint trio."""
+    passes (or the relay ring), with and without replication; and the other four schedules on the same matrix and rank count.
+    Checked like bench.py checks itself (closed form of one fused call from constant operands, every rank's rows and columns) and
+    by the fingerprint trio."""
     monkeypatch.setenv("HNH_MESH_CHUNKS", chunks)
     monkeypatch.setenv("HNH_RING_MODE", ring)
     m, r, p = config2["m"], 128, 8
@@ -128,17 +131,20 @@ def test_config3_full_size_on_eight_logical_ranks(config2, monkeypatch, c, chunk
 
     def body(w):
         sp = H.SpmatLocal.load_tuples(w, False, config2["logm"], config2["ef"])
-        d = H.DistributedSparse(w, "15d_fusion2", sp, r, c)
+        d = H.DistributedSparse(w, alg, sp, r, c)
         sp.free()
         A, B = d.like_A_matrix(0.001), d.like_B_matrix(0.001)
         S, buf = d.like_S_values(1.0), d.like_S_values(0.0)
+        d.initial_shift(A, B, H.K_SDDMM_A)
         d.fusedSpMM(A, B, S, buf, H.AMAT)
+        d.de_shift(A, B, H.K_SDDMM_A)
         got = A.download().reshape(-1)
         worst, off = 0.0, 0
         for top, left, rc, cc in d.submatrices(H.AMAT):
             blk = got[off:off + rc * cc].reshape(rc, cc)
             off += rc * cc
-            worst = max(worst, float(np.max(np.abs(blk - deg[top:top + rc, None] * (r * 1e-9)))))
+            keep = max(0, min(rc, m - top))
+            worst = max(worst, float(np.max(np.abs(blk[:keep] - deg[top:top + keep, None] * (r * 1e-9)))))
         for x in (A, B, S, buf):
             x.free()
         fp = device_fingerprints(d)
