@@ -51,8 +51,10 @@ public:
     //   csr_blocks[0]  the block column it owns (visited at step 0, gathers from the caller's own dense block), and
     //   csr_blocks[1]  ALL block columns visited at steps 1 .. n-1 as one CSR block whose column index is the row of the
     //                  LANDING BUFFER the fetched dense rows arrive in.
-    // The landing buffer is chunk-major: the visiting blocks are cut into `windows` row chunks of chunkA / chunkB rows, and
-    // chunk q of the blocks of steps 1 .. n-1 lies at rows [(n-1) r0, (n-1)(r0 + w)), r0 = q * chunk, w = its height.  Fetch
+    // The landing buffer is chunk-major: the visiting blocks are cut into `windows` row chunks [cut[q], cut[q+1]) (cutA / cutB for
+    // visiting A / B blocks), and chunk q of the blocks of steps 1 .. n-1 lies at rows [(n-1) cut[q], (n-1) cut[q+1]).  The
+    // chunks are TAPERED — first and last half as high as the ones between, (1, 2, .., 2, 1) / (2Q - 2) of a block — because what
+    // cannot overlap is the wait for the first chunk and the kernel of the last one, whichever of fetch and kernels is slower.  Fetch
     // group q moves chunk q of every remote block (all n-1 links busy) and one WINDOWED row pass over csr_blocks[1]
     // (hnh_csr_window: the columns of chunk q are a contiguous piece of every CSR row) runs as soon as it has landed, while
     // chunk q+1 is still on the links.  The reference walks the same nonzeros block by block (15D_dense_shift.hpp:199-227);
@@ -60,7 +62,8 @@ public:
     // many ranks and chunks there are.  HNH_MESH_CHUNKS sets `windows` (default 4, 1 = whole blocks).
     bool merged = false;
     int windows = 1;
-    int chunkA = 0, chunkB = 0;  // rows per chunk of a visiting A / B block
+    std::vector<int64_t> cutA, cutB;  // chunk boundaries (windows + 1 entries, rows of a visiting A / B block)
+    int fineA = 0, fineB = 0;         // granularity of the boundaries: every chunk is one or two "fine" chunks of this many rows
     DenseMatrix landing[2];      // [0]: visiting B blocks (gathered through S), [1]: visiting A blocks (through ST)
 
     // hold_moving_operand(): the remote blocks of this matrix stay valid in a landing buffer / ring_spare[0] between calls
@@ -118,15 +121,15 @@ public:
             if (v < 1 || v > 8) hnh::fatal("Error, HNH_MESH_CHUNKS must be between 1 and 8!");
             if (merged) windows = v;
         }
-        chunkA = divideAndRoundUp(localArows, windows);
-        chunkB = divideAndRoundUp(localBrows, windows);
+        cutA = chunk_cuts(localArows, &fineA);
+        cutB = chunk_cuts(localBrows, &fineB);
 
         const uint64_t arows = (uint64_t)localArows * c, brows = (uint64_t)localBrows * c;
         S->localize(arows, 0);
         ST->localize(brows, 0);
         if (merged) {
-            lay_out_merged(S.get(), localBrows, chunkB);
-            lay_out_merged(ST.get(), localArows, chunkA);
+            lay_out_merged(S.get(), localBrows, cutB, fineB);
+            lay_out_merged(ST.get(), localArows, cutA, fineA);
         } else {
             S->divideIntoBlockCols(localBrows, p, true);
             ST->divideIntoBlockCols(localArows, p, true);
@@ -141,8 +144,8 @@ public:
             const std::vector<int64_t> wS = {localBrows, (int64_t)(n - 1) * localBrows}, wST = {localArows, (int64_t)(n - 1) * localArows};
             S->initializeCSRBlocks(localArows * c, 0, -1, false, &wS);
             ST->initializeCSRBlocks(localBrows * c, 0, -1, false, &wST);
-            set_chunk_windows(S.get(), localBrows, chunkB);
-            set_chunk_windows(ST.get(), localArows, chunkA);
+            set_chunk_windows(S.get(), cutB);
+            set_chunk_windows(ST.get(), cutA);
         } else {
             S->initializeCSRBlocks(localArows * c, localBrows, -1, local_tpose);
             ST->initializeCSRBlocks(localBrows * c, localArows, -1, local_tpose);
@@ -205,41 +208,55 @@ private:
         if (pMod(b - grid->rankInRow, c) != 0) return -1;
         return pMod(grid->rankInCol - (b - grid->rankInRow) / c, p / c);
     }
-    // first landing-buffer row of chunk q of the block fetched at step k >= 1 (br rows per block, cw rows per chunk)
-    int64_t landing_row(int k, int q, int br, int cw) const {
-        const int64_t r0 = std::min<int64_t>((int64_t)q * cw, br), w = std::min<int64_t>(cw, br - r0);
-        return (int64_t)(p / c - 1) * r0 + (int64_t)(k - 1) * w;
+    // Chunk boundaries of a visiting block of `br` rows: `windows` chunks built from 2 (windows - 1) fine chunks of *fine rows,
+    // first and last chunk = one fine chunk, the others = two (a single chunk when windows == 1).
+    std::vector<int64_t> chunk_cuts(int br, int* fine) const {
+        std::vector<int64_t> cut((size_t)windows + 1, br);
+        cut[0] = 0;
+        if (windows == 1) {
+            *fine = std::max(br, 1);
+            return cut;
+        }
+        *fine = std::max(1, divideAndRoundUp(br, 2 * (windows - 1)));
+        for (int q = 1; q < windows; q++) cut[(size_t)q] = std::min<int64_t>((int64_t)(2 * q - 1) * *fine, br);
+        return cut;
+    }
+    // first landing-buffer row of chunk q of the block fetched at step k >= 1
+    int64_t landing_row(int k, int q, const std::vector<int64_t>& cut) const {
+        return (int64_t)(p / c - 1) * cut[(size_t)q] + (int64_t)(k - 1) * (cut[(size_t)q + 1] - cut[(size_t)q]);
     }
     // Relabels the (row-localised, column-major) tuples' columns from global to "own block | landing-buffer row" and splits
     // them into the two blocks of the merged layout.
-    void lay_out_merged(SpmatLocal* s, int br, int cw) {
+    void lay_out_merged(SpmatLocal* s, int br, const std::vector<int64_t>& cut, int fine) {
         const int n = p / c;
-        std::vector<int64_t> dest((size_t)p * windows, -1);
+        const int nfine = divideAndRoundUp(br, fine);  // fine chunks that hold rows (<= 2 (windows - 1))
+        std::vector<int64_t> dest((size_t)p * nfine, -1);
         for (int b = 0; b < p; b++) {
             const int k = step_of_block(b);
             if (k < 0) continue;  // the distribution sends no nonzero of such a block column here
-            for (int q = 0; q < windows; q++) {
-                const int64_t r0 = (int64_t)q * cw;
-                if (r0 >= br) continue;  // chunk beyond the block's end
-                dest[(size_t)b * windows + q] = (k == 0) ? r0 : (int64_t)br + landing_row(k, q, br, cw);
+            for (int f = 0; f < nfine; f++) {
+                const int64_t r0 = (int64_t)f * fine;
+                int q = 0;
+                while (q + 1 < windows && cut[(size_t)q + 1] <= r0) q++;  // the chunk this fine chunk belongs to
+                dest[(size_t)b * nfine + f] = (k == 0) ? r0 : (int64_t)br + landing_row(k, q, cut) + (r0 - cut[(size_t)q]);
             }
         }
-        s->remapColumns(br, cw, windows, dest);
+        s->remapColumns(br, fine, nfine, dest);
         s->sortColumnMajor((uint64_t)n * (uint64_t)br);
         s->divideIntoLocalAndRemote(br, n);
     }
-    void set_chunk_windows(SpmatLocal* s, int br, int cw) {
+    void set_chunk_windows(SpmatLocal* s, const std::vector<int64_t>& cut) {
         CSRLocal* remote = s->csr_blocks[1];
         if (remote == nullptr || windows == 1) return;
         std::vector<int32_t> bounds;
-        for (int q = 1; q < windows; q++) bounds.push_back((int32_t)((int64_t)(p / c - 1) * std::min<int64_t>((int64_t)q * cw, br)));
+        for (int q = 1; q < windows; q++) bounds.push_back((int32_t)((int64_t)(p / c - 1) * cut[(size_t)q]));
         remote->set_windows(bounds);
     }
 
     // Issues the fetch of every remote block of a READ-ONLY moving operand into its landing buffer, chunk by chunk: group q
     // moves chunk q of all n-1 blocks (explicit-peer pairs over n-1 different links) and event(8 + q) is recorded behind
     // it.  Returns true when nothing had to move because a held operand's blocks are still there.
-    bool fetch_into_landing(DenseMatrix* start, int slot, int br, int cw) {
+    bool fetch_into_landing(DenseMatrix* start, int slot, int br, const std::vector<int64_t>& cut) {
         const int n = p / c;
         ensure(landing[slot], (int64_t)(n - 1) * br, R);
         auto t = phase_begin("Cyclic Shift Time");
@@ -248,13 +265,13 @@ private:
         if (!held && held_slot == slot) held_slot = -1;  // another operand lands here: a held one has to be fetched again
         const bool resident = held && held_slot == slot;
         for (int q = 0; q < windows; q++) {
-            const int64_t r0 = std::min<int64_t>((int64_t)q * cw, br), w = std::min<int64_t>(cw, br - r0);
+            const int64_t r0 = cut[(size_t)q], w = cut[(size_t)q + 1] - r0;
             const size_t bytes = (size_t)w * (size_t)R * sizeof(double);
             if (bytes > 0 && !resident) {
                 world->group_begin();
                 for (int k = 1; k < n; k++)  // my block is what ring rank me+k needs at ITS step k; I need the block of me-k at mine
                     world->sendrecv(grid->col_world, start->data() + r0 * R, bytes, pMod(grid->rankInCol + k, n),
-                                    landing[slot].data() + landing_row(k, q, br, cw) * R, bytes, pMod(grid->rankInCol - k, n), HNH_STREAM_COMM);
+                                    landing[slot].data() + landing_row(k, q, cut) * R, bytes, pMod(grid->rankInCol - k, n), HNH_STREAM_COMM);
                 world->group_end();
             }
             world->event_record(event(8 + q), HNH_STREAM_COMM);
@@ -270,8 +287,8 @@ private:
     template <typename One>
     void walk_merged(SpmatLocal* choice, DenseMatrix* Brole, One&& one) {
         const int slot = (choice == S.get()) ? 0 : 1;
-        const int br = slot == 0 ? localBrows : localArows, cw = slot == 0 ? chunkB : chunkA;
-        const bool resident = fetch_into_landing(Brole, slot, br, cw);
+        const int br = slot == 0 ? localBrows : localArows;
+        const bool resident = fetch_into_landing(Brole, slot, br, slot == 0 ? cutB : cutA);
         auto t = phase_begin("Computation Time");
         CSRLocal* remote = choice->csr_blocks[1];
         one(0, *Brole, -1, remote == nullptr);
