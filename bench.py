@@ -387,8 +387,8 @@ def run(args, make_world=gpu_world):
                        "setup_s": round(t_setup, 2)},
             # `achieved` is an ALGORITHMIC rate (SURVEY 8d byte model / measured launch time), not DRAM utilisation: part of every
             # launch's gathers is served by the 256 MiB Infinity Cache, which sits behind the counters `traffic` comes from
-            "roofline": {"bound": "hbm", "bound_detail": "hbm gather model (Infinity-Cache assisted); the binding unit is the per-CU "
-                                                          "vector-memory miss path, see DESIGN.md section 3 and profiles/r02_gather_probe.log",
+            "roofline": {"bound": "hbm", "bound_detail": "hbm gather model (Infinity-Cache assisted); the saturated resource is the memory side "
+                                                          "serving scattered dense rows, see DESIGN.md section 3 and profiles/r02_gather_probe*.log",
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "traffic_source": "profiles/hbm_traffic.json (static: rocprofv3 FETCH_SIZE/WRITE_SIZE passes of an earlier run of "

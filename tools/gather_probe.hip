@@ -30,6 +30,8 @@ __device__ __forceinline__ uint32_t mix(uint64_t x) {
 template <int LPR, int U>
 __global__ __launch_bounds__(256) void gather_kernel(const double2* __restrict__ base, uint32_t ws_rows, int per_group,
                                                      double* __restrict__ sink, uint64_t seed) {
+    extern __shared__ char occupancy_limiter[];  // dynamic LDS only limits how many workgroups a CU can hold
+    if (per_group < 0) sink[1] = occupancy_limiter[0];
     const int lig = threadIdx.x % LPR;
     const uint64_t group = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
     double2 acc = make_double2(0.0, 0.0);
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void stream_kernel(const double2* __restrict__
 }
 
 template <int LPR, int U>
-double run_gather(const double2* buf, size_t ws_bytes, double* sink, double total_gb) {
+double run_gather(const double2* buf, size_t ws_bytes, double* sink, double total_gb, int wgs_per_cu = 8) {
     const uint32_t ws_rows = (uint32_t)(ws_bytes / (LPR * 16));
     const int groups_per_block = 256 / LPR;
     const int blocks = 256 * 32;  // 32 workgroups per CU in the grid
@@ -73,7 +75,9 @@ double run_gather(const double2* buf, size_t ws_bytes, double* sink, double tota
     float best = 1e30f;
     for (int rep = 0; rep < 4; rep++) {
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL((gather_kernel<LPR, U>), dim3(blocks), dim3(256), 0, 0, buf, ws_rows, per_group, sink, 0x1234567ULL * (rep + 1));
+        // 160 KiB of LDS per CU: a workgroup that asks for 160 KiB / k of it leaves room for exactly k workgroups (k waves per SIMD)
+        const size_t lds = wgs_per_cu >= 8 ? 0 : (size_t)(160 * 1024 / wgs_per_cu) - 64;
+        hipLaunchKernelGGL((gather_kernel<LPR, U>), dim3(blocks), dim3(256), lds, 0, buf, ws_rows, per_group, sink, 0x1234567ULL * (rep + 1));
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -122,5 +126,17 @@ int main() {
     ROW(16, 16, "row  256 B (R=32),  U=16")
     ROW(8, 8, "row  128 B (R=16),  U=8")
     ROW(8, 16, "row  128 B (R=16),  U=16")
+    // how many loads in flight does it take?  waves per SIMD (via an LDS allocation that limits workgroups per CU) x loads per lane
+    printf("\nrows of 1 KiB, GB/s by waves per SIMD and gathers in flight per wave (working set 512 MiB | 1024 MiB):\n");
+    for (int k : {1, 2, 3, 4, 6, 8}) {
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_kernel<64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_kernel<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_kernel<64, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        printf("  %d waves/SIMD:  U=4 %6.0f | %6.0f    U=8 %6.0f | %6.0f    U=16 %6.0f | %6.0f\n", k,
+               run_gather<64, 4>(buf, (size_t)512 << 20, sink, 20.0, k), run_gather<64, 4>(buf, (size_t)1024 << 20, sink, 20.0, k),
+               run_gather<64, 8>(buf, (size_t)512 << 20, sink, 20.0, k), run_gather<64, 8>(buf, (size_t)1024 << 20, sink, 20.0, k),
+               run_gather<64, 16>(buf, (size_t)512 << 20, sink, 20.0, k), run_gather<64, 16>(buf, (size_t)1024 << 20, sink, 20.0, k));
+        fflush(stdout);
+    }
     return 0;
 }
