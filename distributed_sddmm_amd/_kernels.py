@@ -51,6 +51,7 @@ SIGNATURES = {
     "hnh_csr_max_row_nnz": (_i32, [_vp, _i64, _vp, C.POINTER(C.c_int), _i32]),
     "hnh_fused_sddmm_spmm_csr_x": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _i64, _i32, _i64, _vp, _i32]),
     "hnh_row_epilogue_f64": (_i32, [_vp, _vp, _vp, C.c_double, _vp, _i64, _i32, _i32]),
+    "hnh_row_epilogue_x": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "hnh_cg_step_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "hnh_tuples_sort": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32]),
     "hnh_tuples_bucket_starts": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i32]),
@@ -86,9 +87,14 @@ SIGNATURES = {
     "hnh_comm_allreduce_f64": (_i32, [_vp, _vp, _vp, _vp, _sz, _i32]),
 }
 
+class CgUpdate(C.Structure):
+    """struct hnh_cg_update"""
+    _fields_ = [("x", C.c_void_p), ("r", C.c_void_p), ("p", C.c_void_p), ("rsold", C.c_void_p), ("eps", C.c_double)]
+
+
 class FusedExtras(C.Structure):
     """struct hnh_fused_extras"""
-    _fields_ = [("leaky_alpha", C.c_double), ("x_scale", C.c_double), ("rowdot", C.c_void_p)]
+    _fields_ = [("leaky_alpha", C.c_double), ("x_scale", C.c_double), ("rowdot", C.c_void_p), ("cg", C.POINTER(CgUpdate))]
 
 
 class TupleKey(C.Structure):

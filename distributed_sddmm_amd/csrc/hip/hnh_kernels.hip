@@ -179,7 +179,10 @@ struct Unroll {
     static constexpr int value = byvec < LPR ? byvec : LPR;
 };
 
-enum class Op { kSddmm, kSpmm, kFused };
+// kFusedCg = kFused whose row epilogue also performs the CG updates of hnh_cg_update; its own instance so that the plain
+// fused kernel's register allocation (and with it its occupancy) is not touched by code it never runs
+enum class Op { kSddmm, kSpmm, kFused, kFusedCg };
+constexpr bool fused_op(Op o) { return o == Op::kFused || o == Op::kFusedCg; }
 
 // ---------------------------------------------------------------- the row kernel (sddmm / spmm / fused)
 //
@@ -202,6 +205,13 @@ struct Extras {
     double leaky_alpha = 0.0;  // HNH_FUSED_LEAKY_RELU: weight = dot > 0 ? dot : leaky_alpha * dot
     double x_scale = 0.0;      // epilogue: Out[i,:] += x_scale * X[i,:]
     double* rowdot = nullptr;  // epilogue: rowdot[i] = <X[i,:], Out[i,:]>
+    // epilogue: the rest of a batched-CG iteration on the finished row (hnh_cg_update; cg_x == nullptr: off).  cg_p is the
+    // row operand X itself, writable.
+    double* cg_x = nullptr;
+    double* cg_r = nullptr;
+    double* cg_p = nullptr;
+    double* cg_rsold = nullptr;
+    double cg_eps = 0.0;
 };
 
 template <int LPR>
@@ -320,15 +330,15 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
             }
             wgt = group_multi_reduce<LPR, U>(d, lig);
             if (have) {
-                const bool overwrite = (OP == Op::kFused) && (flags & HNH_FUSED_VALUES_OVERWRITE);
+                const bool overwrite = fused_op(OP) && (flags & HNH_FUSED_VALUES_OVERWRITE);
                 if (!overwrite) wgt += load_stream(values + mine);
-                if (OP == Op::kFused && (flags & HNH_FUSED_LEAKY_RELU)) {  // the activated weight is what gets stored
+                if (fused_op(OP) && (flags & HNH_FUSED_LEAKY_RELU)) {  // the activated weight is what gets stored
                     if (svalues != nullptr) wgt *= svalues[mine];
                     wgt = wgt > 0.0 ? wgt : ex.leaky_alpha * wgt;
                     if (lig % SUB == 0) store_stream(values + mine, wgt);
                 } else {
                     if (lig % SUB == 0) store_stream(values + mine, wgt);
-                    if (OP == Op::kFused && svalues != nullptr) wgt *= svalues[mine];
+                    if (fused_op(OP) && svalues != nullptr) wgt *= svalues[mine];
                 }
             } else {
                 wgt = 0.0;
@@ -441,7 +451,7 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
     }
 
     if constexpr (OP != Op::kSddmm) {
-        if (OP == Op::kFused && (flags & kInternalEpilogue) && !atomic_out) {  // the row is complete in this launch
+        if (fused_op(OP) && (flags & kInternalEpilogue) && !atomic_out) {  // the row is complete in this launch
             double part = 0.0;
 #pragma unroll
             for (int v = 0; v < VEC; v++)
@@ -450,9 +460,44 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
                     acc[v][w] = fma(ex.x_scale, x[v][w], acc[v][w]);
                     part = fma(x[v][w], acc[v][w], part);
                 }
-            if (ex.rowdot != nullptr) {
-                part = group_sum<LPR>(part);
-                if (lig == 0) ex.rowdot[row] = part;
+            if (ex.rowdot != nullptr || OP == Op::kFusedCg) part = group_sum<LPR>(part);
+            if (ex.rowdot != nullptr && lig == 0) ex.rowdot[row] = part;
+            if constexpr (OP == Op::kFusedCg) {
+                // x = p (search direction), acc = Mp, part = <p, Mp>: the remaining CG updates of this row, see hnh_cg_update
+                const double rs = ex.cg_rsold[row] + ex.cg_eps;
+                const double alpha = rs / (part + ex.cg_eps);
+                double rr[VEC][W];
+                double rsnew = 0.0;
+#pragma unroll
+                for (int v = 0; v < VEC; v++) {
+                    double xs[W];
+#pragma unroll
+                    for (int w = 0; w < W; w++) { xs[w] = 0.0; rr[v][w] = 0.0; }
+                    if (act[v]) {
+                        load_w_stream<W>(xs, ex.cg_x + row * ld + coff[v]);
+                        load_w_stream<W>(rr[v], ex.cg_r + row * ld + coff[v]);
+                    }
+#pragma unroll
+                    for (int w = 0; w < W; w++) {
+                        xs[w] = fma(alpha, x[v][w], xs[w]);
+                        rr[v][w] = fma(-alpha, acc[v][w], rr[v][w]);
+                        rsnew = fma(rr[v][w], rr[v][w], rsnew);
+                    }
+                    if (act[v]) {
+                        store_w_stream<W>(ex.cg_x + row * ld + coff[v], xs);
+                        store_w_stream<W>(ex.cg_r + row * ld + coff[v], rr[v]);
+                    }
+                }
+                rsnew = group_sum<LPR>(rsnew);
+                const double beta = rsnew / rs;
+#pragma unroll
+                for (int v = 0; v < VEC; v++) {
+                    double pn[W];
+#pragma unroll
+                    for (int w = 0; w < W; w++) pn[w] = fma(beta, x[v][w], rr[v][w]);
+                    if (act[v]) store_w_stream<W>(ex.cg_p + row * ld + coff[v], pn);
+                }
+                if (lig == 0) ex.cg_rsold[row] = rsnew;
             }
         }
 #pragma unroll
@@ -779,10 +824,10 @@ __global__ __launch_bounds__(kBlock) void rowdot_kernel(const double* __restrict
     if (lig == 0) out[row] = s;
 }
 
-// Out[i,:] += x_scale * X[i,:];  rowdot[i] = <X[i,:], Out[i,:]>  — the fused pass's row epilogue as its own launch
+// Out[i,:] += x_scale * X[i,:];  rowdot[i] = <X[i,:], Out[i,:]>;  optionally the CG updates of hnh_cg_update — the fused pass's
+// row epilogue as its own launch (rows completed by several launches or by atomically combined hub-row segments)
 template <int LPR, int W>
-__global__ __launch_bounds__(kBlock) void row_epilogue_kernel(double* __restrict__ Out, const double* __restrict__ X, double x_scale,
-                                                              double* __restrict__ rowdot, int64_t rows, int R) {
+__global__ __launch_bounds__(kBlock) void row_epilogue_kernel(double* __restrict__ Out, const double* X, Extras ex, int64_t rows, int R) {
     constexpr int GROUPS = kBlock / LPR;
     const int lig = threadIdx.x % LPR;
     const int64_t row = (int64_t)blockIdx.x * GROUPS + threadIdx.x / LPR;
@@ -796,13 +841,47 @@ __global__ __launch_bounds__(kBlock) void row_epilogue_kernel(double* __restrict
         load_w<W>(y, o + c);
 #pragma unroll
         for (int w = 0; w < W; w++) {
-            y[w] = fma(x_scale, x[w], y[w]);
+            y[w] = fma(ex.x_scale, x[w], y[w]);
             s = fma(x[w], y[w], s);
         }
-        if (x_scale != 0.0) store_w<W>(o + c, y);
+        if (ex.x_scale != 0.0) store_w<W>(o + c, y);
     }
     s = group_sum<LPR>(s);
-    if (lig == 0 && rowdot != nullptr) rowdot[row] = s;
+    if (lig == 0 && ex.rowdot != nullptr) ex.rowdot[row] = s;
+    if (ex.cg_x == nullptr) return;
+    // second sweep over the row (it is in L1/L2 now): x += alpha p, r -= alpha Mp, <r, r>; third: p = r + beta p
+    const double rs = ex.cg_rsold[row] + ex.cg_eps;
+    const double alpha = rs / (s + ex.cg_eps);
+    double* xs_row = ex.cg_x + row * R;
+    double* r_row = ex.cg_r + row * R;
+    double* p_row = ex.cg_p + row * R;
+    double rsnew = 0.0;
+    for (int c = lig * W; c < R; c += LPR * W) {
+        double p[W], mp[W], xs[W], r[W];
+        load_w<W>(p, p_row + c);
+        load_w<W>(mp, o + c);
+        load_w<W>(xs, xs_row + c);
+        load_w<W>(r, r_row + c);
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            xs[w] = fma(alpha, p[w], xs[w]);
+            r[w] = fma(-alpha, mp[w], r[w]);
+            rsnew = fma(r[w], r[w], rsnew);
+        }
+        store_w<W>(xs_row + c, xs);
+        store_w<W>(r_row + c, r);
+    }
+    rsnew = group_sum<LPR>(rsnew);
+    const double beta = rsnew / rs;
+    for (int c = lig * W; c < R; c += LPR * W) {
+        double p[W], r[W];
+        load_w<W>(p, p_row + c);
+        load_w<W>(r, r_row + c);  // this lane's own store above
+#pragma unroll
+        for (int w = 0; w < W; w++) p[w] = fma(beta, p[w], r[w]);
+        store_w<W>(p_row + c, p);
+    }
+    if (lig == 0) ex.cg_rsold[row] = rsnew;
 }
 
 // One CG update (als_conjugate_gradients.cpp:117-127):  X[i,:] += alpha[i] P[i,:];  Rm[i,:] -= alpha[i] MP[i,:];
@@ -1101,11 +1180,13 @@ int launch_row(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, int64_t rows, co
     hipLaunchKernelGGL((row_kernel<OP, LPR, VEC, W, EXACT>), dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, rowptr, beg_ptr, end_ptr,
                        colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, ex);
     if (int rc = hnh::check_hip(ctx, hipGetLastError(), "row_kernel launch")) return rc;
-    if (lc.enabled && run_long) {  // hub rows once per pass (after the last column panel), over their whole length
-        // 256 CUs x 4 resident workgroups; items are spread round-robin over all groups of the grid
-        hipLaunchKernelGGL((long_row_kernel<OP, LPR, VEC, W, EXACT>), dim3(1024), dim3(kBlock), 0, st, lc.items, lc.count,
-                           lc.capacity, rowptr, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, ex);
-        return hnh::check_hip(ctx, hipGetLastError(), "long_row_kernel launch");
+    if constexpr (OP != Op::kFusedCg) {  // (a pass with hub rows never runs its epilogue inside the launch)
+        if (lc.enabled && run_long) {  // hub rows once per pass (after the last column panel), over their whole length
+            // 256 CUs x 4 resident workgroups; items are spread round-robin over all groups of the grid
+            hipLaunchKernelGGL((long_row_kernel<OP, LPR, VEC, W, EXACT>), dim3(1024), dim3(kBlock), 0, st, lc.items, lc.count,
+                               lc.capacity, rowptr, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, ex);
+            return hnh::check_hip(ctx, hipGetLastError(), "long_row_kernel launch");
+        }
     }
     return HNH_OK;
 }
@@ -1125,14 +1206,30 @@ int launch_shape(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, const Shape& s
         return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "no kernel instance for this shape");
     }
 #undef HNH_CASE
+    if constexpr (OP == Op::kFusedCg) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "the CG epilogue has exact-width instances only");
     // Widths that are not a supported exact multiple: one bounds-checked pass when the row fits the widest
     // instance (R <= 512 even / 256 odd)
 #define HNH_NX(V, WW)                                                                                                      \
     if (s.w == WW && R <= 64 * WW * V)                                                                                     \
         return launch_row<OP, 64, V, WW, false>(ctx, st, lc, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags, ex, run_long);
-    HNH_NX(1, 2) HNH_NX(2, 2) HNH_NX(4, 2) HNH_NX(1, 1) HNH_NX(2, 1) HNH_NX(4, 1)
+    if constexpr (OP != Op::kFusedCg) {
+        HNH_NX(1, 2) HNH_NX(2, 2) HNH_NX(4, 2) HNH_NX(1, 1) HNH_NX(2, 1) HNH_NX(4, 1)
+    }
 #undef HNH_NX
     return -1;
+}
+
+// launch_shape for the launch that completes the output rows: with the in-launch epilogue (kInternalEpilogue in `flags`) and CG
+// updates requested, the kFusedCg instance runs instead of kFused
+template <Op OP>
+int launch_closing(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, const Shape& s, int64_t rows, const int32_t* rowptr,
+                   const int32_t* beg_ptr, const int32_t* end_ptr, const int32_t* colidx, double* values, const double* svalues,
+                   const double* X, const double* Y, double* Out, int R, unsigned flags, const Extras& ex, bool run_long = true) {
+    if constexpr (OP == Op::kFused) {
+        if ((flags & kInternalEpilogue) && ex.cg_x != nullptr)
+            return launch_shape<Op::kFusedCg>(ctx, st, lc, s, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, flags, ex, run_long);
+    }
+    return launch_shape<OP>(ctx, st, lc, s, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, flags, ex, run_long);
 }
 
 constexpr int kMaxPanels = 8;
@@ -1151,15 +1248,18 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
     LongCtl lc;
     if (int rc = prepare_long(ctx, st, sidx, rows, rowptr, nnz, max_row_nnz, &lc)) return rc;
     const bool single_pass = s.exact || R <= 64 * s.w * 4;
+    // the epilogue can ride in the launch that completes the rows when ONE group completes each row: no hub-row segments
+    // adding atomically afterwards, no column tiles (and, for the CG updates, an exact-width instance)
+    const bool epilogue_in_launch = !lc.enabled && single_pass && (ex.cg_x == nullptr || s.exact);
     if (win != nullptr) {
         // a caller-defined window of every row; hub rows stay whole and go to the long-row pass with the pass's last window,
         // which is also where a row epilogue can run inside the launch
         const int32_t* beg_ptr = win->beg ? win->beg : rowptr;
         const int32_t* end_ptr = win->end ? win->end : rowptr + 1;
         const bool last = win->last != 0;
-        if (epilogue_done != nullptr) *epilogue_done = last && !lc.enabled && single_pass;
+        if (epilogue_done != nullptr) *epilogue_done = last && epilogue_in_launch;
         const unsigned f = flags | ((epilogue_done != nullptr && *epilogue_done) ? kInternalEpilogue : 0u);
-        const int rcw = launch_shape<OP>(ctx, st, lc, s, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, f, ex, last);
+        const int rcw = launch_closing<OP>(ctx, st, lc, s, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, f, ex, last);
         if (rcw != -1) return rcw;
         if (OP == Op::kFused) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "fused fallback is composed by the caller");
         const int wtile = 64 * s.w;
@@ -1174,9 +1274,8 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
         }
         return HNH_OK;
     }
-    // the row epilogue runs inside the launch only when every output row is completed by ONE group (no hub-row
-    // segments adding atomically afterwards, no column tiles); otherwise the caller appends row_epilogue_kernel
-    if (epilogue_done != nullptr) *epilogue_done = !lc.enabled && single_pass;
+    // otherwise the caller appends row_epilogue_kernel
+    if (epilogue_done != nullptr) *epilogue_done = epilogue_in_launch;
     const unsigned epi = (epilogue_done != nullptr && *epilogue_done) ? kInternalEpilogue : 0u;
 
     // Infinity-Cache panels (see panel_split_kernel): single-pass widths only.  The mechanism handles hub rows (they stay
@@ -1203,14 +1302,14 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
             unsigned f = flags;
             if (q > 0) f &= ~HNH_FUSED_OUT_OVERWRITE;  // later panels add to the rows the first one wrote
             if (q == panels - 1) f |= epi;             // the last panel completes the rows
-            if (int rc = launch_shape<OP>(ctx, st, lc, s, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, f, ex,
-                                          q == panels - 1))
+            if (int rc = launch_closing<OP>(ctx, st, lc, s, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, f, ex,
+                                            q == panels - 1))
                 return rc;
         }
         return HNH_OK;
     }
 
-    const int rc1 = launch_shape<OP>(ctx, st, lc, s, rows, rowptr, rowptr, rowptr + 1, colidx, values, svalues, X, Y, Out, R, flags | epi, ex);
+    const int rc1 = launch_closing<OP>(ctx, st, lc, s, rows, rowptr, rowptr, rowptr + 1, colidx, values, svalues, X, Y, Out, R, flags | epi, ex);
     if (rc1 != -1) return rc1;
     // ... else column tiles; SDDMM partial dot products accumulate into `values` tile by tile
     if (OP == Op::kFused) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "fused fallback is composed by the caller");
@@ -1307,15 +1406,15 @@ int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowpt
 
 namespace {
 // the row epilogue as its own launch (hub rows / column tiles / several launches per output row)
-int launch_row_epilogue(hnh_ctx* ctx, hipStream_t st, double* Out, const double* X, double x_scale, double* rowdot, int64_t rows, int R) {
-    if (rows == 0 || (x_scale == 0.0 && rowdot == nullptr)) return HNH_OK;
-    const bool w2 = (R % 2 == 0) && aligned16(Out) && aligned16(X);
+int launch_row_epilogue(hnh_ctx* ctx, hipStream_t st, double* Out, const double* X, const Extras& ex, int64_t rows, int R) {
+    if (rows == 0 || (ex.x_scale == 0.0 && ex.rowdot == nullptr && ex.cg_x == nullptr)) return HNH_OK;
+    const bool w2 = (R % 2 == 0) && aligned16(Out) && aligned16(X) && (ex.cg_x == nullptr || (aligned16(ex.cg_x) && aligned16(ex.cg_r)));
     const int chunks = w2 ? R / 2 : R;
 #define HNH_EP(L)                                                                                                          \
     {                                                                                                                      \
         const int64_t blocks = (rows + (kBlock / L) - 1) / (kBlock / L);                                                   \
-        if (w2) hipLaunchKernelGGL((row_epilogue_kernel<L, 2>), dim3((unsigned)blocks), dim3(kBlock), 0, st, Out, X, x_scale, rowdot, rows, R); \
-        else hipLaunchKernelGGL((row_epilogue_kernel<L, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, Out, X, x_scale, rowdot, rows, R);   \
+        if (w2) hipLaunchKernelGGL((row_epilogue_kernel<L, 2>), dim3((unsigned)blocks), dim3(kBlock), 0, st, Out, X, ex, rows, R); \
+        else hipLaunchKernelGGL((row_epilogue_kernel<L, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, Out, X, ex, rows, R);   \
     }
     if (chunks >= 64) HNH_EP(64) else if (chunks >= 16) HNH_EP(16) else if (chunks >= 4) HNH_EP(4) else HNH_EP(1)
 #undef HNH_EP
@@ -1326,7 +1425,8 @@ int fused_impl(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t*
                const double* X, const double* Y, double* Out, int R, unsigned flags, int64_t nnz_in, int max_row_nnz, int64_t cols,
                const hnh_fused_extras* extras, const hnh_csr_window* win, int stream);
 
-int check_extras(hnh_ctx* ctx, unsigned flags, const hnh_fused_extras* extras, Extras* ex, bool* want_epilogue, const char* who) {
+int check_extras(hnh_ctx* ctx, unsigned flags, const hnh_fused_extras* extras, const double* X, const double* Out, Extras* ex, bool* want_epilogue,
+                 const char* who) {
     if (flags & ~(HNH_FUSED_VALUES_OVERWRITE | HNH_FUSED_OUT_OVERWRITE | HNH_FUSED_LEAKY_RELU))
         return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": unknown flag");
     if ((flags & HNH_FUSED_LEAKY_RELU) && !extras)
@@ -1335,8 +1435,19 @@ int check_extras(hnh_ctx* ctx, unsigned flags, const hnh_fused_extras* extras, E
         ex->leaky_alpha = extras->leaky_alpha;
         ex->x_scale = extras->x_scale;
         ex->rowdot = extras->rowdot;
+        if (const hnh_cg_update* cg = extras->cg) {
+            if (!cg->x || !cg->r || !cg->p || !cg->rsold) return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": hnh_cg_update with a null pointer");
+            if (X != nullptr && cg->p != X) return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": hnh_cg_update.p must be the row operand X");
+            if (cg->x == cg->r || cg->x == cg->p || cg->r == cg->p || cg->x == Out || cg->r == Out || cg->p == Out)
+                return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": hnh_cg_update operands alias");
+            ex->cg_x = cg->x;
+            ex->cg_r = cg->r;
+            ex->cg_p = cg->p;
+            ex->cg_rsold = cg->rsold;
+            ex->cg_eps = cg->eps;
+        }
     }
-    *want_epilogue = extras && (extras->x_scale != 0.0 || extras->rowdot != nullptr);
+    *want_epilogue = extras && (extras->x_scale != 0.0 || extras->rowdot != nullptr || extras->cg != nullptr);
     return HNH_OK;
 }
 }  // namespace
@@ -1366,7 +1477,7 @@ int fused_impl(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t*
     if (int rc = check_common(ctx, rows, R, "hnh_fused_sddmm_spmm_csr")) return rc;
     Extras ex;
     bool want_epilogue = false;
-    if (int rc = check_extras(ctx, flags, extras, &ex, &want_epilogue, "hnh_fused_sddmm_spmm_csr")) return rc;
+    if (int rc = check_extras(ctx, flags, extras, X, Out, &ex, &want_epilogue, "hnh_fused_sddmm_spmm_csr")) return rc;
     if (rows == 0) return HNH_OK;
     if (!rowptr || !col_idx || !values || !X || !Y || !Out)
         return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr: null pointer");
@@ -1380,7 +1491,7 @@ int fused_impl(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t*
         if (int rc = dispatch_row<Op::kFused>(ctx, st, stream, s, rows, nnz_in, max_row_nnz, cols, rowptr, col_idx, values, svalues, X, Y, Out, R,
                                               flags, ex, want_epilogue ? &done : nullptr, win))
             return rc;
-        if (want_epilogue && !done) return launch_row_epilogue(ctx, st, Out, X, ex.x_scale, ex.rowdot, rows, R);
+        if (want_epilogue && !done) return launch_row_epilogue(ctx, st, Out, X, ex, rows, R);
         return HNH_OK;
     }
     // Tiled fallback (R odd or not a supported multiple): the dot product needs the whole row before the
@@ -1424,7 +1535,7 @@ int fused_impl(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t*
     if (int rc = dispatch_row<Op::kSpmm>(ctx, st, stream, s, rows, nnz, max_row_nnz, cols, rowptr, col_idx, values, svalues, Y, nullptr, Out, R, 0u,
                                          Extras(), nullptr, win))
         return rc;
-    if (want_epilogue) return launch_row_epilogue(ctx, st, Out, X, ex.x_scale, ex.rowdot, rows, R);
+    if (want_epilogue) return launch_row_epilogue(ctx, st, Out, X, ex, rows, R);
     return HNH_OK;
 }
 }  // namespace
@@ -1476,7 +1587,22 @@ int hnh_row_epilogue_f64(hnh_ctx* ctx, double* Out, const double* X, double x_sc
     if (int rc = check_common(ctx, rows, R, "hnh_row_epilogue_f64")) return rc;
     if (rows == 0) return HNH_OK;
     if (!Out || !X || Out == X) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_row_epilogue_f64: bad operand");
-    return launch_row_epilogue(ctx, ctx->streams[stream], Out, X, x_scale, rowdot, rows, R);
+    Extras ex;
+    ex.x_scale = x_scale;
+    ex.rowdot = rowdot;
+    return launch_row_epilogue(ctx, ctx->streams[stream], Out, X, ex, rows, R);
+}
+
+int hnh_row_epilogue_x(hnh_ctx* ctx, double* Out, const double* X, const hnh_fused_extras* extras, int64_t rows, int R, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (int rc = check_common(ctx, rows, R, "hnh_row_epilogue_x")) return rc;
+    if (!extras) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_row_epilogue_x: null extras");
+    Extras ex;
+    bool want = false;
+    if (int rc = check_extras(ctx, 0u, extras, X, Out, &ex, &want, "hnh_row_epilogue_x")) return rc;
+    if (rows == 0 || !want) return HNH_OK;
+    if (!Out || !X || Out == X) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_row_epilogue_x: bad operand");
+    return launch_row_epilogue(ctx, ctx->streams[stream], Out, X, ex, rows, R);
 }
 
 int hnh_cg_step_f64(hnh_ctx* ctx, double* X, double* Rm, const double* P, const double* MP, const double* alpha, double* rsnew,

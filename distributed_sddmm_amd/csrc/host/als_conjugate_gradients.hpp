@@ -4,16 +4,20 @@
 //
 // One CG iteration = one fusedSpMM (computeQueries, .cpp:265-301) + three row-wise dot products and three
 // row-scaled updates (.cpp:82-139).  All of it stays on the GPU, and the dense passes around the fused call are
-// folded together: `+ lambda x` and <p, Mp> ride in the fused kernel's row epilogue where the schedule has a single
-// fused pass (Distributed_Sparse::fusedSpMM_out; otherwise one hnh_row_epilogue_f64 launch), and x += alpha p,
-// r -= alpha Mp, <r, r> are one launch (hnh_cg_step_f64) — 17 matrix-sized HBM passes per iteration become 9.  The
-// Allreduce of the R-split schedules (.cpp:31-36) is an RCCL all-reduce on the schedule's R-split communicator.
+// folded together.  Schedules that keep whole rows on a rank (no R split): the ENTIRE rest of the iteration — `+ lambda p`,
+// <p, Mp>, alpha, x += alpha p, r -= alpha Mp, <r, r>, p = r + beta p — runs in the fused kernel's row epilogue on the row
+// that is in registers anyway (hnh_cg_update; where the schedule has no single fused pass, as one row-wise launch after it):
+// beside the fused call an iteration reads x, r and writes x, r, p, instead of the reference's 17 matrix-sized passes.
+// R-split schedules need the reference's two Allreduces between those steps (.cpp:95-97,122-124; an RCCL all-reduce on the
+// schedule's R-split communicator): there `+ lambda p` and <p, Mp> ride in the epilogue and x += alpha p, r -= alpha Mp,
+// <r, r> are one launch (hnh_cg_step_f64) — 9 passes.
 //
 // Differences, deliberate: the reference initialises embeddings and the artificial ground truth with
 // Eigen's setRandom() on LOCAL buffers (.cpp:143-146), which makes results depend on the distribution; here
 // every random fill is a hash of the GLOBAL (row, column), so the factorisation is the same for every
 // schedule and rank count (and can be compared with the reference driven through public members).
 #pragma once
+#include <cstdlib>
 #include "distributed_sparse.hpp"
 #include "er_generator.hpp"
 
@@ -35,9 +39,21 @@ public:
         hnh::World* w = d_ops->world;
         w->check(w->be->hnh_rowdot_f64(w->ctx, x.data(), result.data(), dot.data(), x.rows(), (int)x.cols(), HNH_STREAM_COMPUTE), "hnh_rowdot_f64");
     }
+    // computeQueries plus everything else one CG iteration does to its rows (hnh_cg_update: x, r, p, rsold updated in place;
+    // cg.p is the operand being optimised in this call).  Only for schedules without an R split.
+    virtual void computeQueriesCG(DenseMatrix& A, DenseMatrix& B, MatMode matrix_to_optimize, DenseMatrix& result, const hnh_cg_update& cg) {
+        computeQueries(A, B, matrix_to_optimize, result);
+        DenseMatrix& x = (matrix_to_optimize == Amat) ? A : B;
+        hnh::World* w = d_ops->world;
+        hnh_fused_extras ex = {0.0, 0.0, nullptr, &cg};
+        w->check(w->be->hnh_row_epilogue_x(w->ctx, result.data(), x.data(), &ex, x.rows(), (int)x.cols(), HNH_STREAM_COMPUTE), "hnh_row_epilogue_x");
+    }
     virtual double computeResidual() = 0;
     virtual void initializeEmbeddings() = 0;
     virtual ~ALS_CG() {}
+
+    // false: keep the CG updates as separate launches also where they could ride in the fused call (measurement / tests)
+    bool fold_cg_updates = std::getenv("HNH_ALS_UNFOLDED") == nullptr;
 
     void allreduceVector(VectorXd& vec, const hnh::Comm& comm) {
         auto t = start_clock();
@@ -84,7 +100,14 @@ public:
         rowdot(r, r, rsold);
         if (d_ops->r_split) allreduceVector(rsold, reduction_world);
 
+        const bool folded = fold_cg_updates && !d_ops->r_split;
         for (int cg_iter = 0; cg_iter < cg_max_iter; cg_iter++) {
+            if (folded) {  // every row's dot products are complete on this rank: the whole iteration is one call
+                const hnh_cg_update cg = {X.data(), r.data(), p.data(), rsold.data(), nan_avoidance_constant};
+                if (matrix_to_optimize == Amat) computeQueriesCG(p, B, Amat, Mp, cg);
+                else computeQueriesCG(A, p, Bmat, Mp, cg);
+                continue;
+            }
             if (matrix_to_optimize == Amat) computeQueriesDot(p, B, Amat, Mp, bdot);  // Mp and bdot = <p, Mp> row-wise
             else computeQueriesDot(A, p, Bmat, Mp, bdot);
             if (d_ops->r_split) allreduceVector(bdot, reduction_world);
@@ -184,15 +207,19 @@ public:
     void computeQueriesDot(DenseMatrix& A_in, DenseMatrix& B_in, MatMode matrix_to_optimize, DenseMatrix& result, VectorXd& dot) override {
         queries(A_in, B_in, matrix_to_optimize, result, &dot);
     }
+    void computeQueriesCG(DenseMatrix& A_in, DenseMatrix& B_in, MatMode matrix_to_optimize, DenseMatrix& result, const hnh_cg_update& cg) override {
+        queries(A_in, B_in, matrix_to_optimize, result, nullptr, &cg);
+    }
 
-    void queries(DenseMatrix& A_in, DenseMatrix& B_in, MatMode matrix_to_optimize, DenseMatrix& result, VectorXd* dot) {
+    void queries(DenseMatrix& A_in, DenseMatrix& B_in, MatMode matrix_to_optimize, DenseMatrix& result, VectorXd* dot,
+                 const hnh_cg_update* cg = nullptr) {
         const double lambda = 1e-13;
         hnh::World* w = d_ops->world;
         DenseMatrix& x = (matrix_to_optimize == Amat) ? A_in : B_in;
         // Schedules with a single fused pass take the + lambda x and the row-wise <x, result> in the same launch and
         // write `result` directly (no `result = x` copy); the 1.5D dense schedule's shifts are empty (.cpp:280,284).
         if (result.rows() != x.rows() || result.cols() != x.cols()) result = DenseMatrix(x.rows(), x.cols());
-        hnh_fused_extras ex = {0.0, lambda, dot ? dot->data() : nullptr};
+        hnh_fused_extras ex = {0.0, lambda, dot ? dot->data() : nullptr, cg};
         if (d_ops->fusedSpMM_out(A_in, B_in, matrix_to_optimize, result, false, ex)) return;
 
         // the all-ones S values and the SDDMM scratch vector are the same for every call: keep them
@@ -212,8 +239,8 @@ public:
             d_ops->fusedSpMM(A_in, result, ones, sddmm_result, Bmat);
             d_ops->de_shift(&A_in, &result, k_sddmmB);
         }
-        w->check(w->be->hnh_row_epilogue_f64(w->ctx, result.data(), x.data(), lambda, dot ? dot->data() : nullptr, result.rows(),
-                                             (int)result.cols(), HNH_STREAM_COMPUTE), "hnh_row_epilogue_f64");
+        w->check(w->be->hnh_row_epilogue_x(w->ctx, result.data(), x.data(), &ex, result.rows(), (int)result.cols(), HNH_STREAM_COMPUTE),
+                 "hnh_row_epilogue_x");
     }
 
     // uniform(-1, 1) * scale keyed by the GLOBAL (row, col) through the operator's submatrix descriptors; generated

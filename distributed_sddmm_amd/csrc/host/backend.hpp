@@ -22,7 +22,7 @@ struct Backend {
     HNH_FN(hnh_event_sync) HNH_FN(hnh_event_elapsed_ms)
     HNH_FN(hnh_sddmm_coo) HNH_FN(hnh_sddmm_csr) HNH_FN(hnh_spmm_csr) HNH_FN(hnh_fused_sddmm_spmm_csr)
     HNH_FN(hnh_sddmm_csr_ex) HNH_FN(hnh_spmm_csr_ex) HNH_FN(hnh_fused_sddmm_spmm_csr_ex) HNH_FN(hnh_csr_max_row_nnz)
-    HNH_FN(hnh_fused_sddmm_spmm_csr_x) HNH_FN(hnh_row_epilogue_f64) HNH_FN(hnh_cg_step_f64)
+    HNH_FN(hnh_fused_sddmm_spmm_csr_x) HNH_FN(hnh_row_epilogue_f64) HNH_FN(hnh_row_epilogue_x) HNH_FN(hnh_cg_step_f64)
     HNH_FN(hnh_tuples_sort) HNH_FN(hnh_tuples_bucket_starts) HNH_FN(hnh_tuples_transform) HNH_FN(hnh_tuples_to_csr)
     HNH_FN(hnh_csr_window_bounds) HNH_FN(hnh_sddmm_csr_w) HNH_FN(hnh_spmm_csr_w) HNH_FN(hnh_fused_sddmm_spmm_csr_w) HNH_FN(hnh_tuples_remap_cols) HNH_FN(hnh_tuples_dedup_max) HNH_FN(hnh_tuples_take_strided)
     HNH_FN(hnh_panel_count) HNH_FN(hnh_generate_er_keys) HNH_FN(hnh_tuples_from_keys) HNH_FN(hnh_tuples_relabel)

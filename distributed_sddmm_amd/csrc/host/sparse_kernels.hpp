@@ -59,12 +59,13 @@ public:
     // others (plugins written against the reference's two pure virtuals) the schedule waits for the whole block instead.
     virtual bool handles_windows() const { return false; }
 
-    static bool wants_epilogue(const hnh_fused_extras* extras) { return extras && (extras->x_scale != 0.0 || extras->rowdot != nullptr); }
+    static bool wants_epilogue(const hnh_fused_extras* extras) {
+        return extras && (extras->x_scale != 0.0 || extras->rowdot != nullptr || extras->cg != nullptr);
+    }
     static void row_epilogue(hnh::World* w, DenseMatrix& X, DenseMatrix& Out, const hnh_fused_extras* extras) {
         if (!wants_epilogue(extras)) return;
-        w->check(w->be->hnh_row_epilogue_f64(w->ctx, Out.data(), X.data(), extras->x_scale, extras->rowdot, Out.rows(), (int)Out.cols(),
-                                             HNH_STREAM_COMPUTE),
-                 "hnh_row_epilogue_f64");
+        w->check(w->be->hnh_row_epilogue_x(w->ctx, Out.data(), X.data(), extras, Out.rows(), (int)Out.cols(), HNH_STREAM_COMPUTE),
+                 "hnh_row_epilogue_x");
     }
 
     size_t triple_function(KernelMode mode, SpmatLocal& S, DenseMatrix& localA, DenseMatrix& localB, int block, int offset) {

@@ -67,7 +67,7 @@ Backend* load_backend(const char* path_c) {
     HNH_BIND(hnh_event_sync) HNH_BIND(hnh_event_elapsed_ms)
     HNH_BIND(hnh_sddmm_coo) HNH_BIND(hnh_sddmm_csr) HNH_BIND(hnh_spmm_csr) HNH_BIND(hnh_fused_sddmm_spmm_csr)
     HNH_BIND(hnh_sddmm_csr_ex) HNH_BIND(hnh_spmm_csr_ex) HNH_BIND(hnh_fused_sddmm_spmm_csr_ex) HNH_BIND(hnh_csr_max_row_nnz)
-    HNH_BIND(hnh_fused_sddmm_spmm_csr_x) HNH_BIND(hnh_row_epilogue_f64) HNH_BIND(hnh_cg_step_f64)
+    HNH_BIND(hnh_fused_sddmm_spmm_csr_x) HNH_BIND(hnh_row_epilogue_f64) HNH_BIND(hnh_row_epilogue_x) HNH_BIND(hnh_cg_step_f64)
     HNH_BIND(hnh_tuples_sort) HNH_BIND(hnh_tuples_bucket_starts) HNH_BIND(hnh_tuples_transform) HNH_BIND(hnh_tuples_to_csr)
     HNH_BIND(hnh_csr_window_bounds) HNH_BIND(hnh_sddmm_csr_w) HNH_BIND(hnh_spmm_csr_w) HNH_BIND(hnh_fused_sddmm_spmm_csr_w) HNH_BIND(hnh_tuples_remap_cols) HNH_BIND(hnh_tuples_dedup_max) HNH_BIND(hnh_tuples_take_strided)
     HNH_BIND(hnh_panel_count) HNH_BIND(hnh_generate_er_keys) HNH_BIND(hnh_tuples_from_keys) HNH_BIND(hnh_tuples_relabel)

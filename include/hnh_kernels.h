@@ -150,11 +150,28 @@ int hnh_spmm_csr_w(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int3
  *   rowdot       != NULL: rowdot[i] = <X[i,:], Out[i,:]> of the FINAL row     — als_conjugate_gradients.cpp:93 (batch_dot_product(p, Mp))
  * The epilogue (x_scale, rowdot) runs inside the launch when one group completes the output row; with hub rows
  * (atomically combined segments) or column tiles it is appended as a row-wise
- * launch — same result either way.  hnh_row_epilogue_f64 is that launch on its own. */
+ * launch — same result either way.  hnh_row_epilogue_f64 is that launch on its own.
+ *
+ *   cg != NULL: the REST of one batched-CG iteration (als_conjugate_gradients.cpp:91-139) runs on the finished row too,
+ *   with p = the fused call's row operand X (cg->p must be that pointer, writable) and Mp = the final output row:
+ *       bdot  = <p[i,:], Mp[i,:]> + eps;      rs = rsold[i] + eps;       alpha = rs / bdot             (:91-101)
+ *       x[i,:] += alpha * p[i,:];             r[i,:] -= alpha * Mp[i,:];                                 (:112-118)
+ *       rsnew = <r[i,:], r[i,:]>;             p[i,:] = r[i,:] + (rsnew / rs) * p[i,:];   rsold[i] = rsnew   (:120-139)
+ *   Row i of p is read only by the group that owns output row i, so updating it in place is safe.  Only valid when the
+ *   whole row lives on this rank (no R split: the reference all-reduces bdot and rsnew otherwise, :95-97,122-124).
+ *   Replaces five further dense passes per CG iteration by loads/stores of rows that are already in registers. */
+typedef struct hnh_cg_update {
+    double* x;     /* the factor being optimised (rows x R) */
+    double* r;     /* residual (rows x R) */
+    double* p;     /* search direction = the fused call's X */
+    double* rsold; /* rows: <r, r> of the previous iteration in, of this one out */
+    double eps;    /* nan_avoidance_constant (:44) */
+} hnh_cg_update;
 typedef struct hnh_fused_extras {
     double leaky_alpha;
     double x_scale;
     double* rowdot;
+    const hnh_cg_update* cg;
 } hnh_fused_extras;
 int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
                                const double* svalues, const double* X, const double* Y, double* Out, int R, unsigned flags,
@@ -163,6 +180,8 @@ int hnh_fused_sddmm_spmm_csr_w(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr
                                const double* svalues, const double* X, const double* Y, double* Out, int R, unsigned flags,
                                int64_t nnz, int max_row_nnz, const hnh_fused_extras* extras, const hnh_csr_window* window, int stream);
 int hnh_row_epilogue_f64(hnh_ctx* ctx, double* Out, const double* X, double x_scale, double* rowdot, int64_t rows, int R, int stream);
+/* the same launch taking the whole extras record (x_scale, rowdot, cg; leaky_alpha is not an epilogue and is ignored) */
+int hnh_row_epilogue_x(hnh_ctx* ctx, double* Out, const double* X, const hnh_fused_extras* extras, int64_t rows, int R, int stream);
 
 /* ---- element-wise helpers (K3-K5 of SURVEY §2.4) ----------------------------------------------------
  * hnh_fill_f64      — SpmatLocal::setValuesConstant (SpmatLocal.hpp:595-605), DenseMatrix::setZero

@@ -177,6 +177,46 @@ int hnh_row_epilogue_f64(hnh_ctx* c, double* Out, const double* X, double x_scal
     return HNH_OK;
 }
 
+/* the same with the whole extras record: + the remaining updates of one batched-CG iteration, written as the reference's
+ * sequence of whole-matrix statements (als_conjugate_gradients.cpp:91-139) */
+int hnh_row_epilogue_x(hnh_ctx* c, double* Out, const double* X, const hnh_fused_extras* ex, int64_t rows, int R, int stream) {
+    if (!ex) return fail(c, HNH_ERR_INVALID, "null extras");
+    if (rows < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad size");
+    const hnh_cg_update* cg = ex->cg;
+    if (cg) {
+        if (!cg->x || !cg->r || !cg->p || !cg->rsold) return fail(c, HNH_ERR_INVALID, "hnh_cg_update with a null pointer");
+        if (cg->p != X) return fail(c, HNH_ERR_INVALID, "hnh_cg_update.p must be the row operand X");
+        if (cg->x == cg->r || cg->x == cg->p || cg->r == cg->p || cg->x == Out || cg->r == Out || cg->p == Out)
+            return fail(c, HNH_ERR_INVALID, "hnh_cg_update operands alias");
+    }
+    if (rows == 0) return HNH_OK;
+    double* bdot = cg ? (double*)malloc(sizeof(double) * (size_t)rows) : NULL;
+    if (cg && !bdot) return fail(c, HNH_ERR_NOMEM, "malloc failed");
+    int rc = HNH_OK;
+    if (ex->x_scale != 0.0 || ex->rowdot || cg) {
+        rc = hnh_row_epilogue_f64(c, Out, X, ex->x_scale, cg ? bdot : ex->rowdot, rows, R, stream);
+        if (rc == HNH_OK && cg && ex->rowdot) memcpy(ex->rowdot, bdot, sizeof(double) * (size_t)rows);
+    }
+    if (rc == HNH_OK && cg) {
+        for (int64_t i = 0; i < rows; i++) {
+            bdot[i] += cg->eps;                         /* :99  */
+            const double rs = cg->rsold[i] + cg->eps;   /* :100 */
+            const double alpha = rs / bdot[i];          /* :102 */
+            double rsnew = 0.0;
+            for (int j = 0; j < R; j++) {
+                cg->x[i * R + j] += alpha * cg->p[i * R + j];   /* :112-117 */
+                cg->r[i * R + j] -= alpha * Out[i * R + j];     /* :118 */
+                rsnew += cg->r[i * R + j] * cg->r[i * R + j];   /* :120 */
+            }
+            const double coeff = rsnew / rs;            /* :136 */
+            for (int j = 0; j < R; j++) cg->p[i * R + j] = cg->r[i * R + j] + coeff * cg->p[i * R + j]; /* :137 */
+            cg->rsold[i] = rsnew;                       /* :138 */
+        }
+    }
+    free(bdot);
+    return rc;
+}
+
 /* gat.hpp:96-99: SDDMM, LeakyReLU on the values, SpMM with them; then the row epilogue */
 int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
                                const double* svalues, const double* X, const double* Y, double* Out, int R, unsigned flags,
@@ -201,7 +241,7 @@ int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* c, int64_t rows, const int32_t* rowptr, 
         rc = hnh_fused_sddmm_spmm_csr(c, rows, rowptr, col_idx, values, svalues, X, Y, Out, R, flags, stream);
     }
     if (rc != HNH_OK) return rc;
-    if (ex && (ex->x_scale != 0.0 || ex->rowdot)) return hnh_row_epilogue_f64(c, Out, X, ex->x_scale, ex->rowdot, rows, R, stream);
+    if (ex && (ex->x_scale != 0.0 || ex->rowdot || ex->cg)) return hnh_row_epilogue_x(c, Out, X, ex, rows, R, stream);
     return HNH_OK;
 }
 
@@ -260,7 +300,7 @@ int hnh_fused_sddmm_spmm_csr_w(hnh_ctx* c, int64_t rows, const int32_t* rowptr, 
                                int64_t nnz, int max_row_nnz, const hnh_fused_extras* ex, const hnh_csr_window* w, int stream) {
     if (rows < 0 || R <= 0 || !w) return fail(c, HNH_ERR_INVALID, "bad argument");
     if ((flags & HNH_FUSED_LEAKY_RELU) && !ex) return fail(c, HNH_ERR_INVALID, "HNH_FUSED_LEAKY_RELU needs extras");
-    const int epilogue = ex && (ex->x_scale != 0.0 || ex->rowdot);
+    const int epilogue = ex && (ex->x_scale != 0.0 || ex->rowdot || ex->cg);
     if (epilogue && !w->last) return fail(c, HNH_ERR_INVALID, "a row epilogue belongs to the last window");
     if (rows == 0) return HNH_OK;
     if (flags & HNH_FUSED_OUT_OVERWRITE) memset(Out, 0, sizeof(double) * (size_t)rows * (size_t)R);
@@ -284,7 +324,7 @@ int hnh_fused_sddmm_spmm_csr_w(hnh_ctx* c, int64_t rows, const int32_t* rowptr, 
             for (int k = 0; k < R; k++) Crow[k] += v * Yrow[k];
         }
     }
-    if (epilogue) return hnh_row_epilogue_f64(c, Out, X, ex->x_scale, ex->rowdot, rows, R, stream);
+    if (epilogue) return hnh_row_epilogue_x(c, Out, X, ex, rows, R, stream);
     return HNH_OK;
 }
 

@@ -24,6 +24,16 @@ def test_als_matches_reference(case_name, alg, p, c):
     T.check_als_against_golden(per_rank, case)
 
 
+@pytest.mark.parametrize("alg,p,c", [("15d_fusion2", 1, 1), ("15d_fusion2", 4, 2), ("15d_fusion1", 4, 1), ("25d_dense_replicate", 4, 1)])
+def test_als_with_separate_cg_updates_matches_reference(monkeypatch, alg, p, c):
+    """HNH_ALS_UNFOLDED=1: schedules without an R split normally run a whole CG iteration inside the fused call (hnh_cg_update);
+    the variant with the reference's separate update steps (what R-split schedules always use) must give the same embeddings."""
+    monkeypatch.setenv("HNH_ALS_UNFOLDED", "1")
+    case = T.case_inputs("er8_r16")
+    per_rank = H.run_spmd(p, lambda w: T.run_als(w, alg, c, case, 1, 5))
+    T.check_als_against_golden(per_rank, case)
+
+
 def test_run_cg_with_artificial_ground_truth_is_distribution_independent():
     """run_cg(1) with the built-in hashed initialisation: same residual on 1 rank and on a 2 x 2 grid."""
     case = T.case_inputs("er8_r16")

@@ -427,6 +427,15 @@ def test_fused_extras_activation_and_row_epilogue(ctx, R):
         d.free()
 
 
+@pytest.mark.parametrize("R", [1, 2, 7, 16, 32, 64, 100, 128, 192, 256, 301, 512, 600])
+@pytest.mark.parametrize("variant", ["in_launch", "hub_rows", "windows", "standalone"])
+def test_folded_cg_iteration(ctx, R, variant):
+    """hnh_cg_update: the rest of a batched-CG iteration (als_conjugate_gradients.cpp:91-139) in the fused call's row epilogue,
+    for every kernel shape; with hub rows / column tiles the epilogue is its own launch, with windows it rides on the last one."""
+    import cg_common
+    cg_common.run(ctx, R, hubs=variant == "hub_rows", windows=3 if variant == "windows" else 0, standalone=variant == "standalone")
+
+
 @pytest.mark.parametrize("R", [16, 128, 100])
 def test_fused_extras_with_hub_rows(ctx, R):
     """Epilogue appended as its own launch when rows are completed by several groups (hub-row segments); same numbers as

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import hnh_testlib as T
+import cg_common
 import tuples_common
 from distributed_sddmm_amd import _kernels as K
 from distributed_sddmm_amd import api as H
@@ -42,6 +43,12 @@ class DoubleApi:
 
 def test_c_test_double_tuple_primitives():
     tuples_common.run(DoubleApi())
+
+
+@pytest.mark.parametrize("R,hubs,windows,standalone", [(16, False, 0, False), (7, False, 3, False), (32, True, 0, False), (16, False, 0, True)])
+def test_c_test_double_folded_cg_iteration(R, hubs, windows, standalone):
+    """hnh_cg_update as the test double performs it vs the reference's statement sequence in numpy (the GPU runs the same body)."""
+    cg_common.run(DoubleApi(), R, hubs=hubs, windows=windows, standalone=standalone)
 
 
 @pytest.mark.parametrize("alg,p,c", [("15d_fusion2", 4, 2), ("15d_fusion1", 4, 1), ("15d_sparse", 4, 2), ("25d_dense_replicate", 8, 2),

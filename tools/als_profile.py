@@ -9,11 +9,22 @@ alg = sys.argv[2] if len(sys.argv) > 2 else "15d_fusion2"
 sp = H.SpmatLocal.load_tuples(w, False, logm, ef)
 nnz = sp.info()["dist_nnz"]
 op = H.DistributedSparse(w, alg, sp, r, 1)
-t = time.perf_counter(); als = H.DistributedALS(op, True); w.sync(); print("ctor (artificial ground truth) %.3f s" % (time.perf_counter() - t))
-t = time.perf_counter(); als.initializeEmbeddings(); w.sync(); print("initializeEmbeddings %.3f s" % (time.perf_counter() - t))
-for it in (1, 10, 10):
-    t = time.perf_counter(); als.cg_optimizer(H.AMAT, it); w.sync(); dt = time.perf_counter() - t
-    print("cg_optimizer(Amat, %d) %.3f s -> %.2f ms per CG iteration incl. setup (fused kernel alone ~15-16 ms)" % (it, dt, dt / (it + 1) * 1e3))
+for unfolded in (False, True):
+    # HNH_ALS_UNFOLDED is read when the ALS object is made: off = the whole CG iteration rides in the fused call's row epilogue
+    # (hnh_cg_update), on = the separate dense update launches that R-split schedules need
+    if unfolded:
+        os.environ["HNH_ALS_UNFOLDED"] = "1"
+    else:
+        os.environ.pop("HNH_ALS_UNFOLDED", None)
+    label = "separate CG update launches" if unfolded else "CG updates folded into the fused call"
+    t = time.perf_counter(); als = H.DistributedALS(op, True); w.sync(); print("[%s] ctor (artificial ground truth) %.3f s" % (label, time.perf_counter() - t))
+    t = time.perf_counter(); als.initializeEmbeddings(); w.sync(); print("[%s] initializeEmbeddings %.3f s" % (label, time.perf_counter() - t))
+    took = {}
+    for it in (1, 1, 10, 10):
+        t = time.perf_counter(); als.cg_optimizer(H.AMAT, it); w.sync(); took[it] = time.perf_counter() - t
+        print("[%s] cg_optimizer(Amat, %d) %.3f s" % (label, it, took[it]))
+    print("[%s] -> %.2f ms per CG iteration ((t(10) - t(1)) / 9; the fused call alone is timed below)" % (label, (took[10] - took[1]) / 9 * 1e3))
+    als.free()
 A, B, S, buf = op.like_A_matrix(0.001), op.like_B_matrix(0.001), op.like_S_values(1.0), op.like_S_values(0.0)
 op.fusedSpMM(A, B, S, buf, H.AMAT); w.sync()
 t = time.perf_counter()
