@@ -43,7 +43,7 @@ SIGNATURES = {
     "hnh_sddmm_csr_ex": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i64, _i32]),
     "hnh_spmm_csr_ex": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i64, _i32]),
     "hnh_fused_sddmm_spmm_csr_ex": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _i64, _i32, _i64, _i32]),
-    "hnh_panel_count": (_i32, [_vp, _i64, _i32, _i32]),
+    "hnh_panel_count": (_i32, [_vp, _i64, _i64, _i64, _i32, _i32]),
     "hnh_csr_window_bounds": (_i32, [_vp, _i64, _vp, _vp, _i32, _vp, _vp, _i32]),
     "hnh_sddmm_csr_w": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _i32]),
     "hnh_spmm_csr_w": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _i32]),

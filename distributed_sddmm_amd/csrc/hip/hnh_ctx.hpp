@@ -17,6 +17,7 @@ struct hnh_ctx {
     size_t panel_cap[2] = {0, 0};
     bool no_panels = false;  // HNH_NO_PANELS=1: A/B switch
     bool panels_with_hubs = false;  // HNH_PANELS_WITH_HUBS=1: panel the short rows of blocks that also have hub rows
+    int long_row_override = 0;      // HNH_LONG_ROW=<multiple of 64, 64..1984>: fixed hub-row threshold instead of the adaptive one (measurement aid)
     double panel_bytes = 512.0 * 1024.0 * 1024.0;  // bytes of the gathered operand per panel (HNH_PANEL_BYTES; tests shrink it)
 };
 

@@ -190,13 +190,21 @@ constexpr bool fused_op(Op o) { return o == Op::kFused || o == Op::kFusedCg; }
 //
 // Long rows.  Real graphs have hub rows (an R-MAT stand-in at 2^20 vertices has rows of > 80 000 nonzeros);
 // a single group walking such a row serialises the whole launch behind it (measured: 27 % of the roofline
-// instead of 81 %).  Rows longer than kLongRow are therefore skipped by the row kernel and cut into segments
+// instead of 81 %).  Rows longer than a threshold are therefore skipped by the row kernel and cut into segments
 // of kLongSeg nonzeros that are spread over the whole chip by a second, small launch (`long_row_kernel`);
 // SDDMM segments are independent, SpMM / fused segments combine their partial output rows with hardware fp64
 // atomics (global_atomic_add_f64).  Callers that know the block's longest row (the host layer does) pass it
 // as a hint and short-row matrices never pay for any of this.
-constexpr int kLongRow = 1024;
+// The threshold adapts to the block: 3 x its mean row length, in steps of 64 within [kLongRowMin, kLongRowMax].  On a skewed
+// graph (R-MAT 2^20, mean 85) rows of 256..1024 nonzeros walked by one wave each still cost 5 % (tail and imbalance inside
+// the CUs; 1024 -> 256: 12.29 -> 11.65 ms at R = 128, 26.1 -> 24.8 ms at R = 256); on a uniform matrix whose mean is that
+// long the same 256 would push every row through the atomics path and lose the cache panels (Erdos-Renyi with 300 per row:
+// 44.0 -> 50.5 ms), hence "relative to the mean" (profiles/r02_kbench_rmat_longrow_threshold.log, r02_kbench_er_ef300_*).
+constexpr int kLongRowMin = 256;
+constexpr int kLongRowMax = 1024;
 constexpr int kLongSeg = 256;
+constexpr unsigned kLongRowShift = 16;  // flag bits 16..20 carry threshold / 64 next to kInternalSplitLong
+__host__ __device__ constexpr int long_row_of(unsigned flags) { return (int)((flags >> kLongRowShift) & 0x1fu) * 64; }
 constexpr unsigned kInternalSplitLong = 0x100u;  // flag bit, never set by callers
 constexpr unsigned kInternalEpilogue = 0x200u;   // flag bit: apply Extras::x_scale / rowdot when the output row is stored
 
@@ -544,7 +552,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HNH_ROW_
         // long_row_kernel; it adds atomically, so an overwritten output row has to start from zero
         int full = rowptr[row + 1] - rowptr[row];
         if constexpr (LPR == 64) full = __builtin_amdgcn_readfirstlane(full);
-        if (full > kLongRow) {
+        if (full > long_row_of(flags)) {
             if (OP != Op::kSddmm && (flags & HNH_FUSED_OUT_OVERWRITE)) end = beg;
             else return;
         }
@@ -605,12 +613,12 @@ __global__ __launch_bounds__(kBlock) void window_bounds_kernel(int64_t rows, con
 // Hub rows follow the row passes' rule: untouched by every window but the last, whole with the last one.
 __global__ __launch_bounds__(kBlock) void window_values_kernel(int64_t rows, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ beg,
                                                                const int32_t* __restrict__ end, double* __restrict__ values,
-                                                               const double* __restrict__ svalues, int mode, double alpha, bool split_long, bool last) {
+                                                               const double* __restrict__ svalues, int mode, double alpha, int long_row, bool last) {
     const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 64;
     const int lane = threadIdx.x % 64;
     if (row >= rows) return;
     int b = beg[row], e2 = end[row];
-    if (split_long && rowptr[row + 1] - rowptr[row] > kLongRow) {
+    if (long_row > 0 && rowptr[row + 1] - rowptr[row] > long_row) {  // long_row == 0: this pass has no hub rows
         if (!last) return;
         b = rowptr[row];
         e2 = rowptr[row + 1];
@@ -648,11 +656,11 @@ __global__ __launch_bounds__(kBlock) void long_row_kernel(const int2* __restrict
 
 __global__ __launch_bounds__(kBlock) void build_long_list_kernel(int64_t rows, const int32_t* __restrict__ rowptr,
                                                                  int2* __restrict__ items, int* __restrict__ item_count,
-                                                                 int capacity) {
+                                                                 int capacity, int long_row) {
     const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (row >= rows) return;
     const int len = rowptr[row + 1] - rowptr[row];
-    if (len <= kLongRow) return;
+    if (len <= long_row) return;
     const int nseg = (len + kLongSeg - 1) / kLongSeg;
     const int base = atomicAdd(item_count, nseg);
     for (int s2 = 0; s2 < nseg; s2++)
@@ -1134,22 +1142,32 @@ struct LongCtl {
     int2* items = nullptr;
     int* count = nullptr;
     int capacity = 0;
+    int threshold = 0;  // rows longer than this are the list's (multiple of 64)
 };
+
+// Rows longer than this go to the long-row pass (see kLongRowMin); nnz < 0 = unknown
+int long_row_threshold(const hnh_ctx* ctx, int64_t rows, int64_t nnz) {
+    if (ctx->long_row_override > 0) return ctx->long_row_override;
+    if (rows <= 0 || nnz < 0) return kLongRowMax;
+    const int64_t t = (3 * nnz / rows + 63) / 64 * 64;
+    return (int)(t < kLongRowMin ? kLongRowMin : (t > kLongRowMax ? kLongRowMax : t));
+}
 
 // Decides whether this call needs the long-row pass and, if so, builds the (row, segment) work list on the
 // device.  max_row_nnz: the caller's knowledge of the longest row (< 0 = unknown -> the list is always built);
 // nnz: number of nonzeros (< 0 = unknown -> read back from rowptr[rows], one 4-byte synchronous copy).
 int prepare_long(hnh_ctx* ctx, hipStream_t st, int sidx, int64_t rows, const int32_t* rowptr, int64_t nnz, int max_row_nnz,
                  LongCtl* lc) {
-    if (max_row_nnz >= 0 && max_row_nnz <= kLongRow) return HNH_OK;
+    if (max_row_nnz >= 0 && max_row_nnz <= (ctx->long_row_override > 0 ? ctx->long_row_override : kLongRowMin)) return HNH_OK;
     if (nnz < 0) {
         int last = 0;
         HNH_TRY_HIP(ctx, hipMemcpyAsync(&last, rowptr + rows, sizeof(int), hipMemcpyDeviceToHost, st));
         HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
         nnz = last;
     }
-    if (nnz <= kLongRow) return HNH_OK;
-    const size_t cap = (size_t)(nnz / kLongSeg + nnz / kLongRow + 16);
+    const int threshold = long_row_threshold(ctx, rows, nnz);
+    if (nnz <= threshold || (max_row_nnz >= 0 && max_row_nnz <= threshold)) return HNH_OK;
+    const size_t cap = (size_t)(nnz / kLongSeg + nnz / threshold + 16);
     if (ctx->long_cap[sidx] < cap) {
         HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
         if (ctx->long_items[sidx]) HNH_TRY_HIP(ctx, hipFree(ctx->long_items[sidx]));
@@ -1162,9 +1180,10 @@ int prepare_long(hnh_ctx* ctx, hipStream_t st, int sidx, int64_t rows, const int
     lc->count = ctx->long_count[sidx];
     lc->capacity = (int)cap;
     lc->enabled = true;
+    lc->threshold = threshold;
     HNH_TRY_HIP(ctx, hipMemsetAsync(lc->count, 0, sizeof(int), st));
     const int64_t blocks = (rows + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(build_long_list_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, rowptr, lc->items, lc->count, lc->capacity);
+    hipLaunchKernelGGL(build_long_list_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, rowptr, lc->items, lc->count, lc->capacity, threshold);
     return hnh::check_hip(ctx, hipGetLastError(), "build_long_list_kernel launch");
 }
 
@@ -1176,7 +1195,7 @@ int launch_row(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, int64_t rows, co
     const int64_t blocks = (rows + GROUPS - 1) / GROUPS;
     if (blocks <= 0) return HNH_OK;
     if (blocks > 0x7fffffffLL) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "too many rows for one launch");
-    if (lc.enabled) flags |= kInternalSplitLong;
+    if (lc.enabled) flags |= kInternalSplitLong | ((unsigned)(lc.threshold / 64) << kLongRowShift);
     hipLaunchKernelGGL((row_kernel<OP, LPR, VEC, W, EXACT>), dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, rowptr, beg_ptr, end_ptr,
                        colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, ex);
     if (int rc = hnh::check_hip(ctx, hipGetLastError(), "row_kernel launch")) return rc;
@@ -1349,9 +1368,9 @@ int check_common(hnh_ctx* ctx, int64_t n, int R, const char* who) {
 
 extern "C" {
 
-int hnh_panel_count(hnh_ctx* ctx, int64_t cols, int R, int max_row_nnz) {
+int hnh_panel_count(hnh_ctx* ctx, int64_t rows, int64_t nnz, int64_t cols, int R, int max_row_nnz) {
     if (!ctx || R <= 0) return 1;
-    if ((max_row_nnz < 0 || max_row_nnz > kLongRow) && !ctx->panels_with_hubs) return 1;  // hub rows (or unknown): one launch
+    if ((max_row_nnz < 0 || max_row_nnz > long_row_threshold(ctx, rows, nnz)) && !ctx->panels_with_hubs) return 1;  // hub rows (or unknown): one launch
     const Shape s = pick_shape(R, true);
     if (!(s.exact || R <= 64 * s.w * 4)) return 1;
     return panel_count(ctx, cols, R);
@@ -1513,7 +1532,8 @@ int fused_impl(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t*
             else hipLaunchKernelGGL(hadamard_kernel, dim3(ew_grid(nnz)), dim3(kBlock), 0, st, values, values, svalues, nnz, false);
         } else {
             const int64_t blocks = (rows * 64 + kBlock - 1) / kBlock;
-            const bool split_long = !(max_row_nnz >= 0 && max_row_nnz <= kLongRow);  // as prepare_long decides for the row passes
+            const int threshold = long_row_threshold(ctx, rows, nnz);  // as prepare_long decides for the row passes
+            const int split_long = (max_row_nnz >= 0 && max_row_nnz <= threshold) ? 0 : threshold;
             hipLaunchKernelGGL(window_values_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, rowptr, wbeg, wend, values, svalues, mode,
                                ex.leaky_alpha, split_long, win->last != 0);
         }

@@ -21,6 +21,10 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
     ctx->device = device;
     ctx->no_panels = std::getenv("HNH_NO_PANELS") != nullptr;
     ctx->panels_with_hubs = std::getenv("HNH_PANELS_WITH_HUBS") != nullptr;
+    if (const char* lr = std::getenv("HNH_LONG_ROW")) {
+        const long v = std::strtol(lr, nullptr, 10);
+        if (v >= 64 && v <= 1984) ctx->long_row_override = (int)(v / 64 * 64);
+    }
     if (const char* pb = std::getenv("HNH_PANEL_BYTES")) {
         const double v = std::atof(pb);
         if (v >= 1.0) ctx->panel_bytes = v;

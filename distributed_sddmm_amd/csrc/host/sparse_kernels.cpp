@@ -39,7 +39,7 @@ size_t StandardKernel::sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
     w->check(w->be->hnh_sddmm_csr_ex(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, Xptr, Yptr,
                                      (int)A.cols(), blk->num_coords, blk->row_hint(), blk->cols, HNH_STREAM_COMPUTE),
              "hnh_sddmm_csr");
-    end(w, profile ? w->be->hnh_panel_count(w->ctx, blk->cols, (int)A.cols(), blk->row_hint()) : 1);
+    end(w, profile ? w->be->hnh_panel_count(w->ctx, blk->rows, blk->num_coords, blk->cols, (int)A.cols(), blk->row_hint()) : 1);
     return processed;
 }
 
@@ -67,7 +67,7 @@ size_t StandardKernel::spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B,
     w->check(w->be->hnh_spmm_csr_ex(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, X, Out, (int)A.cols(),
                                     blk->num_coords, blk->row_hint(), blk->cols, HNH_STREAM_COMPUTE),
              "hnh_spmm_csr");
-    end(w, profile ? w->be->hnh_panel_count(w->ctx, blk->cols, (int)A.cols(), blk->row_hint()) : 1);
+    end(w, profile ? w->be->hnh_panel_count(w->ctx, blk->rows, blk->num_coords, blk->cols, (int)A.cols(), blk->row_hint()) : 1);
     return processed;
 }
 
@@ -100,7 +100,7 @@ size_t StandardKernel::fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
                                                B.data(), Out.data(), (int)A.cols(), flags, blk->num_coords, blk->row_hint(), blk->cols, extras,
                                                HNH_STREAM_COMPUTE),
              "hnh_fused_sddmm_spmm_csr");
-    end(w, profile ? w->be->hnh_panel_count(w->ctx, blk->cols, (int)A.cols(), blk->row_hint()) : 1);
+    end(w, profile ? w->be->hnh_panel_count(w->ctx, blk->rows, blk->num_coords, blk->cols, (int)A.cols(), blk->row_hint()) : 1);
     return 0;
 }
 

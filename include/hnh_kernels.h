@@ -101,9 +101,10 @@ int hnh_fused_sddmm_spmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, 
                              double* Out, int R, unsigned flags, int stream);
 
 /* Variants for callers that know the block: `nnz` = rowptr[rows] and `max_row_nnz` = its longest row (either may
- * be -1 = unknown).  Rows longer than 1024 nonzeros (hub vertices of real graphs) are cut into 256-nonzero
+ * be -1 = unknown).  Hub rows — rows longer than 3 x the block's mean row length, taken in steps of 64 and within
+ * [256, 1024] (1024 when nnz is unknown) — are cut into 256-nonzero
  * segments that a second small launch spreads over the whole chip (SpMM / fused segments combine with fp64
- * atomics); with max_row_nnz <= 1024 none of that machinery runs.  The plain entry points above pass -1, -1.
+ * atomics); with max_row_nnz below that threshold none of that machinery runs.  The plain entry points above pass -1, -1.
  * hnh_csr_max_row_nnz computes the hint (one device reduction + 4-byte synchronous copy).
  * cols = number of rows of the gathered dense operand (= columns of the sparse block), or -1.  When it is given and the
  * operand is larger than ~768 MiB the pass runs as several launches, one per ~512 MiB COLUMN PANEL of the block
@@ -119,7 +120,7 @@ int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowpt
                                 int R, unsigned flags, int64_t nnz, int max_row_nnz, int64_t cols, int stream);
 int hnh_csr_max_row_nnz(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, int* out_host, int stream);
 /* number of kernel launches (column panels) a row pass with these hints is run as; 1 = a single launch (profiling aid) */
-int hnh_panel_count(hnh_ctx* ctx, int64_t cols, int R, int max_row_nnz);
+int hnh_panel_count(hnh_ctx* ctx, int64_t rows, int64_t nnz, int64_t cols, int R, int max_row_nnz);
 
 /* Row WINDOWS.  A window restricts a row pass to a contiguous piece [beg[r], end[r]) of every CSR row (column indices are
  * sorted within a row, so "the nonzeros whose column lies in [c0, c1)" is such a piece).  The 1.5D dense-shift schedule keeps
@@ -127,7 +128,7 @@ int hnh_panel_count(hnh_ctx* ctx, int64_t cols, int R, int max_row_nnz);
  * one windowed pass per arrived chunk, overlapping kernels with the fetch (15D_dense_shift.hpp:199-227 walks the same
  * nonzeros block by block); the kernel library's own Infinity-Cache panels are the same mechanism with automatic bounds.
  *   hnh_csr_window_bounds  split[b * rows + r] = first nonzero of row r with column >= bounds_host[b]  (b < nbounds <= 15)
- *   *_w entry points       as the _ex / _x entry points, on the window only.  Hub rows (longer than 1024 nonzeros) are left
+ *   *_w entry points       as the _ex / _x entry points, on the window only.  Hub rows (see the _ex entry points) are left
  *                          whole: they are skipped by every window and processed — over their whole length — by the call
  *                          whose window has `last` set, which is also the call that applies a row epilogue. */
 typedef struct hnh_csr_window {

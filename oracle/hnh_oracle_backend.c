@@ -343,7 +343,10 @@ int hnh_cg_step_f64(hnh_ctx* c, double* X, double* Rm, const double* P, const do
     }
     return HNH_OK;
 }
-int hnh_panel_count(hnh_ctx* c, int64_t cols, int R, int max_row_nnz) { (void)c; (void)cols; (void)R; (void)max_row_nnz; return 1; }
+int hnh_panel_count(hnh_ctx* c, int64_t rows, int64_t nnz, int64_t cols, int R, int max_row_nnz) {
+    (void)c; (void)rows; (void)nnz; (void)cols; (void)R; (void)max_row_nnz;
+    return 1;
+}
 int hnh_csr_max_row_nnz(hnh_ctx* c, int64_t rows, const int32_t* rowptr, int* out_host, int stream) {
     (void)c; (void)stream;
     int m = 0;
