@@ -94,7 +94,8 @@ class CgUpdate(C.Structure):
 
 class FusedExtras(C.Structure):
     """struct hnh_fused_extras"""
-    _fields_ = [("leaky_alpha", C.c_double), ("x_scale", C.c_double), ("rowdot", C.c_void_p), ("cg", C.POINTER(CgUpdate))]
+    _fields_ = [("leaky_alpha", C.c_double), ("x_scale", C.c_double), ("rowdot", C.c_void_p), ("cg", C.POINTER(CgUpdate)),
+                ("relu_dst", C.c_void_p), ("relu_ld", C.c_int64)]
 
 
 class TupleKey(C.Structure):

@@ -179,8 +179,9 @@ struct Unroll {
     static constexpr int value = byvec < LPR ? byvec : LPR;
 };
 
-// kFusedCg = kFused whose row epilogue also performs the CG updates of hnh_cg_update; its own instance so that the plain
-// fused kernel's register allocation (and with it its occupancy) is not touched by code it never runs
+// kFusedCg = kFused whose row epilogue also performs the CG updates of hnh_cg_update or the ReLU delivery of
+// hnh_fused_extras::relu_dst; its own instance so that the plain fused kernel's register allocation (and with it its
+// occupancy) is not touched by code it never runs
 enum class Op { kSddmm, kSpmm, kFused, kFusedCg };
 constexpr bool fused_op(Op o) { return o == Op::kFused || o == Op::kFusedCg; }
 
@@ -220,6 +221,9 @@ struct Extras {
     double* cg_p = nullptr;
     double* cg_rsold = nullptr;
     double cg_eps = 0.0;
+    // epilogue: deliver max(row, 0) to relu_dst[row * relu_ld + column] instead of storing the row to Out (GAT head output)
+    double* relu_dst = nullptr;
+    int64_t relu_ld = 0;
 };
 
 template <int LPR>
@@ -468,9 +472,20 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
                     acc[v][w] = fma(ex.x_scale, x[v][w], acc[v][w]);
                     part = fma(x[v][w], acc[v][w], part);
                 }
-            if (ex.rowdot != nullptr || OP == Op::kFusedCg) part = group_sum<LPR>(part);
+            if (ex.rowdot != nullptr || (OP == Op::kFusedCg && ex.cg_x != nullptr)) part = group_sum<LPR>(part);
             if (ex.rowdot != nullptr && lig == 0) ex.rowdot[row] = part;
             if constexpr (OP == Op::kFusedCg) {
+              if (ex.relu_dst != nullptr) {  // the finished row leaves through a ReLU into a column block of a wider matrix
+#pragma unroll
+                for (int v = 0; v < VEC; v++) {
+                    double y[W];
+#pragma unroll
+                    for (int w = 0; w < W; w++) y[w] = fmax(acc[v][w], 0.0);
+                    if (act[v]) store_w_stream<W>(ex.relu_dst + row * ex.relu_ld + coff[v], y);
+                }
+                return;  // Out is scratch
+              }
+              if (ex.cg_x != nullptr) {
                 // x = p (search direction), acc = Mp, part = <p, Mp>: the remaining CG updates of this row, see hnh_cg_update
                 const double rs = ex.cg_rsold[row] + ex.cg_eps;
                 const double alpha = rs / (part + ex.cg_eps);
@@ -506,6 +521,7 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
                     if (act[v]) store_w_stream<W>(ex.cg_p + row * ld + coff[v], pn);
                 }
                 if (lig == 0) ex.cg_rsold[row] = rsnew;
+              }
             }
         }
 #pragma unroll
@@ -856,6 +872,17 @@ __global__ __launch_bounds__(kBlock) void row_epilogue_kernel(double* __restrict
     }
     s = group_sum<LPR>(s);
     if (lig == 0 && ex.rowdot != nullptr) ex.rowdot[row] = s;
+    if (ex.relu_dst != nullptr) {
+        double* d = ex.relu_dst + row * ex.relu_ld;
+        for (int c = lig * W; c < R; c += LPR * W) {
+            double y[W];
+            load_w<W>(y, o + c);
+#pragma unroll
+            for (int w = 0; w < W; w++) y[w] = fmax(y[w], 0.0);
+            store_w<W>(d + c, y);
+        }
+        return;
+    }
     if (ex.cg_x == nullptr) return;
     // second sweep over the row (it is in L1/L2 now): x += alpha p, r -= alpha Mp, <r, r>; third: p = r + beta p
     const double rs = ex.cg_rsold[row] + ex.cg_eps;
@@ -1245,7 +1272,7 @@ int launch_closing(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, const Shape&
                    const int32_t* beg_ptr, const int32_t* end_ptr, const int32_t* colidx, double* values, const double* svalues,
                    const double* X, const double* Y, double* Out, int R, unsigned flags, const Extras& ex, bool run_long = true) {
     if constexpr (OP == Op::kFused) {
-        if ((flags & kInternalEpilogue) && ex.cg_x != nullptr)
+        if ((flags & kInternalEpilogue) && (ex.cg_x != nullptr || ex.relu_dst != nullptr))
             return launch_shape<Op::kFusedCg>(ctx, st, lc, s, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, flags, ex, run_long);
     }
     return launch_shape<OP>(ctx, st, lc, s, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, flags, ex, run_long);
@@ -1269,7 +1296,9 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
     const bool single_pass = s.exact || R <= 64 * s.w * 4;
     // the epilogue can ride in the launch that completes the rows when ONE group completes each row: no hub-row segments
     // adding atomically afterwards, no column tiles (and, for the CG updates, an exact-width instance)
-    const bool epilogue_in_launch = !lc.enabled && single_pass && (ex.cg_x == nullptr || s.exact);
+    const bool extra_rows_ok = s.w == 1 || ((ex.cg_x == nullptr || (aligned16(ex.cg_x) && aligned16(ex.cg_r))) &&
+                                            (ex.relu_dst == nullptr || (aligned16(ex.relu_dst) && ex.relu_ld % 2 == 0)));  // 16-byte row accesses
+    const bool epilogue_in_launch = !lc.enabled && single_pass && ((ex.cg_x == nullptr && ex.relu_dst == nullptr) || (s.exact && extra_rows_ok));
     if (win != nullptr) {
         // a caller-defined window of every row; hub rows stay whole and go to the long-row pass with the pass's last window,
         // which is also where a row epilogue can run inside the launch
@@ -1426,8 +1455,9 @@ int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowpt
 namespace {
 // the row epilogue as its own launch (hub rows / column tiles / several launches per output row)
 int launch_row_epilogue(hnh_ctx* ctx, hipStream_t st, double* Out, const double* X, const Extras& ex, int64_t rows, int R) {
-    if (rows == 0 || (ex.x_scale == 0.0 && ex.rowdot == nullptr && ex.cg_x == nullptr)) return HNH_OK;
-    const bool w2 = (R % 2 == 0) && aligned16(Out) && aligned16(X) && (ex.cg_x == nullptr || (aligned16(ex.cg_x) && aligned16(ex.cg_r)));
+    if (rows == 0 || (ex.x_scale == 0.0 && ex.rowdot == nullptr && ex.cg_x == nullptr && ex.relu_dst == nullptr)) return HNH_OK;
+    const bool w2 = (R % 2 == 0) && aligned16(Out) && aligned16(X) && (ex.cg_x == nullptr || (aligned16(ex.cg_x) && aligned16(ex.cg_r))) &&
+                    (ex.relu_dst == nullptr || (aligned16(ex.relu_dst) && ex.relu_ld % 2 == 0));
     const int chunks = w2 ? R / 2 : R;
 #define HNH_EP(L)                                                                                                          \
     {                                                                                                                      \
@@ -1465,8 +1495,15 @@ int check_extras(hnh_ctx* ctx, unsigned flags, const hnh_fused_extras* extras, c
             ex->cg_rsold = cg->rsold;
             ex->cg_eps = cg->eps;
         }
+        if (extras->relu_dst != nullptr) {
+            if (extras->cg != nullptr) return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": relu_dst and cg exclude each other");
+            if (extras->relu_ld <= 0) return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": relu_dst needs its row pitch relu_ld");
+            if (extras->relu_dst == Out || extras->relu_dst == X) return hnh::fail(ctx, HNH_ERR_INVALID, std::string(who) + ": relu_dst aliases an operand");
+            ex->relu_dst = extras->relu_dst;
+            ex->relu_ld = extras->relu_ld;
+        }
     }
-    *want_epilogue = extras && (extras->x_scale != 0.0 || extras->rowdot != nullptr || extras->cg != nullptr);
+    *want_epilogue = extras && (extras->x_scale != 0.0 || extras->rowdot != nullptr || extras->cg != nullptr || extras->relu_dst != nullptr);
     return HNH_OK;
 }
 }  // namespace

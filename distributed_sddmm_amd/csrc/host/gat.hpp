@@ -60,13 +60,11 @@ public:
         // Schedules with a single fused pass (1.5D dense shift, local kernel fusion, c = 1: its shifts are empty and
         // the attention matrix is not exported) do SDDMM, LeakyReLU and SpMM in ONE gather of the neighbours' rows.
         if (d_ops->c == 1) {
+            // ... and the head's ReLU output (gat.hpp:101) leaves the same launch straight into its column block of the layer
+            // output: H only carries partial sums between the launches of a pass
             DenseMatrix H(A.rows(), A.cols());
-            hnh_fused_extras ex = {leaky_relu_alpha, 0.0, nullptr};
-            if (d_ops->fusedSpMM_out(A, A, Amat, H, true, ex)) {
-                w->check(w->be->hnh_relu_store_cols_f64(w->ctx, out.data(), out.cols(), (int64_t)j * H.cols(), H.data(), H.rows(), H.cols(),
-                                                        HNH_STREAM_COMPUTE), "hnh_relu_store_cols_f64");
-                return;
-            }
+            hnh_fused_extras ex = {leaky_relu_alpha, 0.0, nullptr, nullptr, out.data() + (int64_t)j * A.cols(), (int64_t)out.cols()};
+            if (d_ops->fusedSpMM_out(A, A, Amat, H, true, ex)) return;
         }
 
         VectorXd Svalues = d_ops->like_S_values(1.0);

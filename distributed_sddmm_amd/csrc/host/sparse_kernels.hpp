@@ -60,7 +60,7 @@ public:
     virtual bool handles_windows() const { return false; }
 
     static bool wants_epilogue(const hnh_fused_extras* extras) {
-        return extras && (extras->x_scale != 0.0 || extras->rowdot != nullptr || extras->cg != nullptr);
+        return extras && (extras->x_scale != 0.0 || extras->rowdot != nullptr || extras->cg != nullptr || extras->relu_dst != nullptr);
     }
     static void row_epilogue(hnh::World* w, DenseMatrix& X, DenseMatrix& Out, const hnh_fused_extras* extras) {
         if (!wants_epilogue(extras)) return;

@@ -173,6 +173,12 @@ typedef struct hnh_fused_extras {
     double x_scale;
     double* rowdot;
     const hnh_cg_update* cg;
+    /* relu_dst != NULL: the finished row goes, through a ReLU, into a column block of a wider matrix —
+     *   relu_dst[i * relu_ld + j] = max(Out[i, j], 0), j < R     (gat.hpp:101: `buffers[i+1].middleCols(...) = A.cwiseMax(0)`)
+     * — and Out is scratch (it holds partial sums between the launches of a pass; its final contents are undefined).
+     * relu_dst already points at the block's first column.  Not together with cg. */
+    double* relu_dst;
+    int64_t relu_ld;
 } hnh_fused_extras;
 int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
                                const double* svalues, const double* X, const double* Y, double* Out, int R, unsigned flags,

@@ -189,6 +189,11 @@ int hnh_row_epilogue_x(hnh_ctx* c, double* Out, const double* X, const hnh_fused
         if (cg->x == cg->r || cg->x == cg->p || cg->r == cg->p || cg->x == Out || cg->r == Out || cg->p == Out)
             return fail(c, HNH_ERR_INVALID, "hnh_cg_update operands alias");
     }
+    if (ex->relu_dst) {
+        if (cg) return fail(c, HNH_ERR_INVALID, "relu_dst and cg exclude each other");
+        if (ex->relu_ld <= 0) return fail(c, HNH_ERR_INVALID, "relu_dst needs its row pitch");
+        if (ex->relu_dst == Out || ex->relu_dst == X) return fail(c, HNH_ERR_INVALID, "relu_dst aliases an operand");
+    }
     if (rows == 0) return HNH_OK;
     double* bdot = cg ? (double*)malloc(sizeof(double) * (size_t)rows) : NULL;
     if (cg && !bdot) return fail(c, HNH_ERR_NOMEM, "malloc failed");
@@ -212,6 +217,10 @@ int hnh_row_epilogue_x(hnh_ctx* c, double* Out, const double* X, const hnh_fused
             for (int j = 0; j < R; j++) cg->p[i * R + j] = cg->r[i * R + j] + coeff * cg->p[i * R + j]; /* :137 */
             cg->rsold[i] = rsnew;                       /* :138 */
         }
+    }
+    if (rc == HNH_OK && ex->relu_dst) { /* gat.hpp:101 */
+        for (int64_t i = 0; i < rows; i++)
+            for (int j = 0; j < R; j++) ex->relu_dst[i * ex->relu_ld + j] = Out[i * R + j] > 0.0 ? Out[i * R + j] : 0.0;
     }
     free(bdot);
     return rc;
@@ -241,7 +250,7 @@ int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* c, int64_t rows, const int32_t* rowptr, 
         rc = hnh_fused_sddmm_spmm_csr(c, rows, rowptr, col_idx, values, svalues, X, Y, Out, R, flags, stream);
     }
     if (rc != HNH_OK) return rc;
-    if (ex && (ex->x_scale != 0.0 || ex->rowdot || ex->cg)) return hnh_row_epilogue_x(c, Out, X, ex, rows, R, stream);
+    if (ex && (ex->x_scale != 0.0 || ex->rowdot || ex->cg || ex->relu_dst)) return hnh_row_epilogue_x(c, Out, X, ex, rows, R, stream);
     return HNH_OK;
 }
 
@@ -300,7 +309,7 @@ int hnh_fused_sddmm_spmm_csr_w(hnh_ctx* c, int64_t rows, const int32_t* rowptr, 
                                int64_t nnz, int max_row_nnz, const hnh_fused_extras* ex, const hnh_csr_window* w, int stream) {
     if (rows < 0 || R <= 0 || !w) return fail(c, HNH_ERR_INVALID, "bad argument");
     if ((flags & HNH_FUSED_LEAKY_RELU) && !ex) return fail(c, HNH_ERR_INVALID, "HNH_FUSED_LEAKY_RELU needs extras");
-    const int epilogue = ex && (ex->x_scale != 0.0 || ex->rowdot || ex->cg);
+    const int epilogue = ex && (ex->x_scale != 0.0 || ex->rowdot || ex->cg || ex->relu_dst);
     if (epilogue && !w->last) return fail(c, HNH_ERR_INVALID, "a row epilogue belongs to the last window");
     if (rows == 0) return HNH_OK;
     if (flags & HNH_FUSED_OUT_OVERWRITE) memset(Out, 0, sizeof(double) * (size_t)rows * (size_t)R);

@@ -1,5 +1,6 @@
-"""Shared body of the folded-CG tests (hnh_cg_update of include/hnh_kernels.h): the fused SDDMM -> SpMM call that also
-performs the rest of one batched-CG iteration on every finished row.  The same checks run against the oracle's C test
+"""Shared body of the row-epilogue tests of the fused SDDMM -> SpMM call (include/hnh_kernels.h): hnh_cg_update — the call also
+performs the rest of one batched-CG iteration on every finished row — and relu_dst — the finished row leaves through a ReLU into
+a column block of a wider matrix (a GAT head's output, gat.hpp:96-101).  The same checks run against the oracle's C test
 double on the CPU and against the HIP library on the GPU; the expectation is the reference's sequence of whole-matrix
 statements (als_conjugate_gradients.cpp:82-139) in numpy."""
 import ctypes as C
@@ -98,4 +99,57 @@ def run(api, R, hubs=False, windows=0, standalone=False):
     exb = K.FusedExtras(0.0, lam, None, C.pointer(bad))
     assert lib.hnh_row_epilogue_x(h, dMp.ptr, dp.ptr, C.byref(exb), rows, R, 0) != 0
     for d in (d_rp, d_c, dv, dp, dY, dx, dr, drs, dMp):
+        d.free()
+
+
+def run_relu(api, R, hubs=False, windows=0, heads=3, head=1):
+    """LeakyReLU between the halves, ReLU on the way out, into column block `head` of a rows x (heads * R) matrix."""
+    lib, h = api.lib, api.h
+    rows, cols = (60, 6000) if hubs else (173, 173)
+    rowptr, ridx, cidx = block(rows, cols, R * 5 + windows + hubs, hubs)
+    nnz = len(cidx)
+    rng = np.random.default_rng(R + 200)
+    A = rng.uniform(-1, 1, (cols, R)) / np.sqrt(R)
+    X = A[:rows] if not hubs else rng.uniform(-1, 1, (rows, R)) / np.sqrt(R)
+    alpha = 0.2
+    vals = np.einsum("ij,ij->i", X[ridx], A[cidx])
+    vals = np.where(vals > 0, vals, alpha * vals)
+    Hm = np.zeros((rows, R))
+    np.add.at(Hm, ridx, vals[:, None] * A[cidx])
+    wide0 = rng.uniform(-1, 1, (rows, heads * R))
+    want = wide0.copy()
+    want[:, head * R:(head + 1) * R] = np.maximum(Hm, 0.0)
+
+    d_rp, d_c, dv, dX, dA, dH, dwide = (api.upload(a) for a in (rowptr, cidx, np.zeros(nnz), X, A, np.full((rows, R), 7.0), wide0))
+    ex = K.FusedExtras(alpha, 0.0, None, None, addr(dwide) + head * R * 8, heads * R)
+    flags = K.FUSED_VALUES_OVERWRITE | K.FUSED_LEAKY_RELU
+    maxrow = int(np.diff(rowptr).max())
+    if windows:
+        bounds = np.linspace(0, cols, windows + 1).astype(np.int32)[1:-1]
+        dsplit = api.upload(np.zeros(max(1, len(bounds)) * rows, np.int32))
+        api.check(lib.hnh_csr_window_bounds(h, rows, d_rp.ptr, d_c.ptr, len(bounds), bounds.ctypes.data_as(C.c_void_p), dsplit.ptr, 0), "bounds")
+        base = addr(dsplit)
+        act = K.FusedExtras(alpha, 0.0, None, None, None, 0)
+        for q in range(windows):
+            last = q == windows - 1
+            win = K.CsrWindow(None if q == 0 else base + (q - 1) * rows * 4, None if last else base + q * rows * 4, 1 if last else 0)
+            api.check(lib.hnh_fused_sddmm_spmm_csr_w(h, rows, d_rp.ptr, d_c.ptr, dv.ptr, None, dX.ptr, dA.ptr, dH.ptr, R,
+                                                     flags | (K.FUSED_OUT_OVERWRITE if q == 0 else 0), nnz, maxrow,
+                                                     C.byref(ex if last else act), C.byref(win), 0), "fused_w relu")
+        dsplit.free()
+    else:
+        api.check(lib.hnh_fused_sddmm_spmm_csr_x(h, rows, d_rp.ptr, d_c.ptr, dv.ptr, None, dX.ptr, dA.ptr, dH.ptr, R, flags | K.FUSED_OUT_OVERWRITE,
+                                                 nnz, maxrow, cols, C.byref(ex), 0), "fused_x relu")
+    api.check(lib.hnh_stream_sync(h, 0), "sync")
+    assert rel(np.asarray(dv.get()), vals) <= TOL
+    got = np.asarray(dwide.get()).reshape(rows, heads * R)
+    assert rel(got, want) <= TOL, (R, hubs, windows)
+    assert np.array_equal(got[:, :head * R], wide0[:, :head * R]) and np.array_equal(got[:, (head + 1) * R:], wide0[:, (head + 1) * R:])
+    # caller errors: together with cg; without a pitch
+    cg = K.CgUpdate(addr(dH), addr(dwide), addr(dX), addr(dv), 0.0)
+    bad = K.FusedExtras(alpha, 0.0, None, C.pointer(cg), addr(dwide), heads * R)
+    assert lib.hnh_fused_sddmm_spmm_csr_x(h, rows, d_rp.ptr, d_c.ptr, dv.ptr, None, dX.ptr, dA.ptr, dH.ptr, R, flags, nnz, maxrow, cols, C.byref(bad), 0) != 0
+    bad = K.FusedExtras(alpha, 0.0, None, None, addr(dwide), 0)
+    assert lib.hnh_fused_sddmm_spmm_csr_x(h, rows, d_rp.ptr, d_c.ptr, dv.ptr, None, dX.ptr, dA.ptr, dH.ptr, R, flags, nnz, maxrow, cols, C.byref(bad), 0) != 0
+    for d in (d_rp, d_c, dv, dX, dA, dH, dwide):
         d.free()

@@ -436,6 +436,15 @@ def test_folded_cg_iteration(ctx, R, variant):
     cg_common.run(ctx, R, hubs=variant == "hub_rows", windows=3 if variant == "windows" else 0, standalone=variant == "standalone")
 
 
+@pytest.mark.parametrize("R", [1, 2, 7, 16, 64, 100, 128, 256, 301, 512, 600])
+@pytest.mark.parametrize("variant", ["in_launch", "hub_rows", "windows"])
+def test_relu_delivery_into_a_column_block(ctx, R, variant):
+    """relu_dst: a GAT head's output (gat.hpp:96-101) leaves the fused launch through the ReLU into its column block of the
+    layer output; neighbouring blocks stay untouched."""
+    import cg_common
+    cg_common.run_relu(ctx, R, hubs=variant == "hub_rows", windows=3 if variant == "windows" else 0)
+
+
 @pytest.mark.parametrize("R", [16, 128, 100])
 def test_fused_extras_with_hub_rows(ctx, R):
     """Epilogue appended as its own launch when rows are completed by several groups (hub-row segments); same numbers as

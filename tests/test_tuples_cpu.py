@@ -51,6 +51,12 @@ def test_c_test_double_folded_cg_iteration(R, hubs, windows, standalone):
     cg_common.run(DoubleApi(), R, hubs=hubs, windows=windows, standalone=standalone)
 
 
+@pytest.mark.parametrize("R,hubs,windows", [(16, False, 0), (7, False, 3), (32, True, 0)])
+def test_c_test_double_relu_delivery(R, hubs, windows):
+    """relu_dst of hnh_fused_extras as the test double performs it vs numpy (the GPU runs the same body)."""
+    cg_common.run_relu(DoubleApi(), R, hubs=hubs, windows=windows)
+
+
 @pytest.mark.parametrize("alg,p,c", [("15d_fusion2", 4, 2), ("15d_fusion1", 4, 1), ("15d_sparse", 4, 2), ("25d_dense_replicate", 8, 2),
                                      ("25d_sparse_replicate", 8, 2)])
 def test_host_setup_pipeline_still_matches_the_reference(monkeypatch, alg, p, c):
