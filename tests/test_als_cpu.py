@@ -13,7 +13,7 @@ def cpu_test_double():
     yield
 
 
-@pytest.mark.parametrize("alg,p,c", [("15d_fusion1", 1, 1), ("15d_fusion2", 1, 1), ("15d_fusion2", 4, 2), ("15d_fusion1", 4, 1), ("15d_sparse", 4, 1),
+@pytest.mark.parametrize("alg,p,c", [("15d_fusion1", 1, 1), ("15d_fusion2", 1, 1), ("15d_fusion2", 4, 2), ("15d_fusion2", 4, 1), ("15d_fusion2", 8, 1), ("15d_fusion1", 4, 1), ("15d_sparse", 4, 1),
                                      ("15d_sparse", 4, 2), ("25d_dense_replicate", 4, 1), ("25d_dense_replicate", 8, 2), ("25d_sparse_replicate", 8, 2)])
 @pytest.mark.parametrize("case_name", ["er8_r16", "ragged_r8"])
 def test_als_matches_reference(case_name, alg, p, c):

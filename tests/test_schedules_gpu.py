@@ -108,8 +108,8 @@ def test_relay_ring_and_mesh_fetch_agree_with_the_reference(monkeypatch, mode, a
     T.check_against_golden(T.assemble(per_rank, case), per_rank, case, alg)
 
 
-@pytest.mark.parametrize("alg,p,c", [("15d_fusion2", 1, 1), ("15d_fusion2", 4, 2), ("15d_fusion1", 4, 1), ("15d_sparse", 4, 1),
-                                     ("25d_dense_replicate", 8, 2), ("25d_sparse_replicate", 8, 2)])
+@pytest.mark.parametrize("alg,p,c", [("15d_fusion2", 1, 1), ("15d_fusion2", 4, 2), ("15d_fusion2", 4, 1), ("15d_fusion2", 8, 1), ("15d_fusion1", 4, 1),
+                                     ("15d_sparse", 4, 1), ("25d_dense_replicate", 8, 2), ("25d_sparse_replicate", 8, 2)])
 def test_als_cg_matches_reference_hip(alg, p, c):
     """BASELINE config 5 (ALS-CG iteration around fusedSpMM) on the GPU vs the reference's own ALS code."""
     case = T.case_inputs("er8_r16")
