@@ -25,7 +25,7 @@ def block(rows, cols, seed, hubs):
     rng = np.random.default_rng(seed)
     lens = rng.integers(0, 24, rows)
     lens[rng.integers(0, rows, rows // 10)] = 0  # empty rows: Mp = lambda p there
-    if hubs:  # rows longer than 1024 nonzeros are completed by several groups: the epilogue becomes its own launch
+    if hubs:  # hub rows are completed by several groups (atomically combined segments): the epilogue becomes its own launch
         lens[1], lens[rows // 2] = 2500, 1100
     rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     cidx = np.concatenate([np.sort(rng.choice(cols, n, replace=False)) for n in lens] + [np.zeros(0, np.int64)]).astype(np.int32)

@@ -215,7 +215,8 @@ def test_gat_elementwise(ctx):
 @pytest.mark.parametrize("R", [16, 128, 100])
 @pytest.mark.parametrize("hinted", [False, True])
 def test_hub_rows_are_split_and_still_exact(ctx, R, hinted):
-    """Rows longer than 1024 nonzeros take the segmented long-row pass (SpMM / fused combine with fp64 atomics)."""
+    """Hub rows (longer than 3 x the block's mean row length, threshold within 256..1024) take the segmented long-row pass
+    (SpMM / fused combine with fp64 atomics)."""
     import ctypes as C
     from distributed_sddmm_amd import _kernels as K
     lib = ctx.lib
@@ -256,7 +257,7 @@ def test_hub_rows_are_split_and_still_exact(ctx, R, hinted):
 
 
 def test_repeat_runs_short_rows_bitwise_hub_rows_within_tolerance(ctx):
-    """Run-to-run reproducibility.  Rows of up to 1024 nonzeros are finished by ONE group in a fixed order: repeated calls
+    """Run-to-run reproducibility.  Rows below the hub-row threshold are finished by ONE group in a fixed order: repeated calls
     give bit-identical results (like the reference for a fixed thread count).  Hub rows are cut into 256-nonzero segments
     whose partial output rows combine with hardware fp64 atomics, so their summation order can change between runs: results
     agree within the parity tolerance, not necessarily bit for bit ("Long rows")."""
@@ -483,7 +484,7 @@ def test_infinity_cache_panels_do_not_change_results(monkeypatch, R, panel_bytes
     c = K.Ctx(0)
     lib = c.lib
     rng = np.random.default_rng(R)
-    if hubs:  # rows longer than 1024 nonzeros stay whole (long-row pass, once) while the short rows are panelled
+    if hubs:  # hub rows stay whole (long-row pass, once) while the short rows are panelled
         rows, cols = 120, 3000
         lens = rng.integers(0, 40, rows)
         lens[5], lens[77] = 2500, 1100
