@@ -49,7 +49,8 @@ def parse():
     ap.add_argument("--no-cpu-full", action="store_true", help="skip the CPU baseline's run at the GPU line's full size")
     ap.add_argument("--no-check", action="store_true", help="skip the closed-form result check (outside the timed region)")
     ap.add_argument("--no-preflight", action="store_true", help="skip the transport self-tests of a multi-GPU run")
-    ap.add_argument("--no-tune", action="store_true", help="several GPUs: keep the default chunk count instead of measuring 2 / 4 / 8")
+    ap.add_argument("--no-tune", action="store_true", help="several GPUs: keep the default route (mesh fetch, 4 chunks) instead of measuring "
+                    "mesh with 2 / 4 / 8 chunks and the relay ring")
     ap.add_argument("--watchdog", type=float, default=240.0, help="seconds a multi-GPU phase may take before the rank reports "
                     "where it is stuck and exits non-zero")
     return ap.parse_args()
@@ -237,25 +238,39 @@ def run(args, make_world=gpu_world):
     barrier()
     t_setup = time.perf_counter() - t_setup
 
-    # ---- several GPUs, mesh fetch: how many chunks the fetched blocks arrive in (= windowed passes per call) trades kernel
-    # efficiency against fetch/compute overlap and depends on the xGMI bandwidth actually delivered.  Unless --chunks fixes it,
-    # the candidates are MEASURED here (1 warm-up + 3 calls each, max over ranks), outside the timed region, and the fastest
-    # one is what gets timed; the JSON line records all of them.
+    # ---- several GPUs, 1.5D dense shift: how the moving operand travels.  The reference relays it round a neighbour ring
+    # (one xGMI link per direction); the default here fetches every block straight from its owner (all links at once) in chunks,
+    # with one windowed kernel pass per landed chunk — how many chunks trades kernel efficiency against fetch/compute overlap
+    # and depends on the xGMI bandwidth actually delivered.  Unless --ring-mode / --chunks fix the route, the candidates are
+    # MEASURED here (1 warm-up + 3 calls each, max over ranks), outside the timed region; the fastest one is what gets timed
+    # and the JSON line records all of them.
     tuning = None
-    mesh = os.environ.get("HNH_RING_MODE", "mesh") == "mesh"
-    if n > 1 and mesh and args.alg == "15d_fusion2" and args.chunks is None and not args.no_tune and n // args.c > 1:
-        dog.phase("chunk-count tuning", max(args.watchdog, 600.0))
-        tuning = {}
+    if n > 1 and args.alg == "15d_fusion2" and args.chunks is None and not args.no_tune and n // args.c > 1 and args.ring_mode != "relay":
+        dog.phase("route tuning (mesh chunk counts, relay ring)", max(args.watchdog, 900.0))
         default_q = int(os.environ.get("HNH_MESH_CHUNKS", "4"))
-        for q in sorted({default_q, 2, 4, 8}):
-            if q != default_q or tuning:  # the operator built above already has default_q chunks
-                for x in (A, B, S, buf):
-                    x.free()
-                op.free()
-                os.environ["HNH_MESH_CHUNKS"] = str(q)
-                op = H.DistributedSparse(world, args.alg, sp, args.r, args.c)
-                A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
-                S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
+        candidates = [("mesh", q) for q in sorted({default_q, 2, 4, 8}, key=lambda q: (q != default_q, q))]  # the built one first
+        if args.ring_mode is None:
+            candidates.append(("relay", None))
+        built = ("mesh", default_q)
+
+        def rebuild(route):
+            nonlocal op, A, B, S, buf, built
+            if route == built:
+                return
+            for x in (A, B, S, buf):
+                x.free()
+            op.free()
+            os.environ["HNH_RING_MODE"] = route[0]
+            if route[1] is not None:
+                os.environ["HNH_MESH_CHUNKS"] = str(route[1])
+            op = H.DistributedSparse(world, args.alg, sp, args.r, args.c)
+            A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
+            S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
+            built = route
+
+        tuning = {}
+        for route in candidates:
+            rebuild(route)
             op.fusedSpMM(A, B, S, buf, H.AMAT)
             barrier()
             t0 = time.perf_counter()
@@ -264,16 +279,8 @@ def run(args, make_world=gpu_world):
             barrier()
             t = torch.tensor([(time.perf_counter() - t0) / 3], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tuning[q] = float(t.item()) * 1e3
-        best = min(tuning, key=tuning.get)
-        if int(os.environ["HNH_MESH_CHUNKS"]) != best:
-            for x in (A, B, S, buf):
-                x.free()
-            op.free()
-            os.environ["HNH_MESH_CHUNKS"] = str(best)
-            op = H.DistributedSparse(world, args.alg, sp, args.r, args.c)
-            A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
-            S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
+            tuning[route] = float(t.item()) * 1e3
+        rebuild(min(tuning, key=tuning.get))  # the same choice on every rank: the times are the all-reduced maxima
         A.fill(0.001)
         barrier()
     sp.free()
@@ -380,10 +387,12 @@ def run(args, make_world=gpu_world):
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Erdos-Renyi 2^%d x 2^%d, edge factor %d (%d unique nnz), R=%d, fused SDDMM->SpMM (fusedSpMM, Amat), "
                                    "%s c=%d on %d x MI355X%s" % (args.logm, args.logm, args.edge_factor, nnz, args.r, args.alg, args.c, n,
-                                                                "" if n == 1 else ", RCCL ring over xGMI"),
+                                                                "" if n == 1 else ", RCCL over xGMI (%s)" % (
+                                                                    "neighbour relay ring" if os.environ.get("HNH_RING_MODE", "mesh") == "relay" else "chunked fetch from the owners")),
                        "nnz": nnz, "M": m, "R": args.r, "algorithm": args.alg, "c": args.c, "transport": "none" if n == 1 else "rccl",
                        "ring_mode": os.environ.get("HNH_RING_MODE", "mesh") if n > 1 else None,
-                       "mesh_chunks": (int(os.environ["HNH_MESH_CHUNKS"]) if "HNH_MESH_CHUNKS" in os.environ else "default") if n > 1 else None,
+                       "mesh_chunks": ((int(os.environ["HNH_MESH_CHUNKS"]) if "HNH_MESH_CHUNKS" in os.environ else "default")
+                                       if n > 1 and os.environ.get("HNH_RING_MODE", "mesh") == "mesh" else None),
                        "setup_s": round(t_setup, 2)},
             # `achieved` is an ALGORITHMIC rate (SURVEY 8d byte model / measured launch time), not DRAM utilisation: part of every
             # launch's gathers is served by the 256 MiB Infinity Cache, which sits behind the counters `traffic` comes from
@@ -394,6 +403,8 @@ def run(args, make_world=gpu_world):
                          "traffic_source": "profiles/hbm_traffic.json (static: rocprofv3 FETCH_SIZE/WRITE_SIZE passes of an earlier run of "
                                            "this command, not collected live)" if traffic is not None else None,
                          "kernel": ("row_kernel<fused> (hnh_fused_sddmm_spmm_csr), one launch per Infinity-Cache panel of B" if n == 1 else
+                                    "row_kernel<fused> (hnh_fused_sddmm_spmm_csr): one launch per visiting block of the relay ring"
+                                    if os.environ.get("HNH_RING_MODE", "mesh") == "relay" else
                                     "row_kernel<fused> (hnh_fused_sddmm_spmm_csr / _w): own block, then one windowed pass over the fetched blocks per landed chunk"),
                          "avg_launch_ms": dur * 1e3,
                          "launches_per_step": launches_per_call, "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -404,7 +415,8 @@ def run(args, make_world=gpu_world):
         if preflight is not None:
             out["preflight"] = {"primitives_ok": sorted(preflight), "communicator_split_order": "identical on all ranks"}
         if tuning is not None:
-            out["config"]["mesh_chunks_tuning_ms_per_step"] = {str(k): round(v, 4) for k, v in sorted(tuning.items())}
+            out["config"]["route_tuning_ms_per_step"] = {("mesh/%d chunks" % q if m == "mesh" else "relay ring"): round(v, 4)
+                                                         for (m, q), v in tuning.items()}
         if n == 1 and not args.no_cpu_baseline and out["backend"] == "hip-gfx950":
             try:
                 out["cpu_baseline"] = cpu_baseline(args)

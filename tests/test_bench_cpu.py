@@ -42,11 +42,16 @@ def test_bench_contract(nranks, alg, c, ring):
     assert chk["nnz_operator"] == chk["nnz_host_generator"] == out["config"]["nnz"]
     if nranks > 1:  # every transport primitive ran before the timed region, and what was measured is recorded
         assert len(out["preflight"]["primitives_ok"]) == 9
-        assert out["config"]["ring_mode"] == (ring or "mesh") and out["config"]["transport"] == "rccl"
         tuned = alg == "15d_fusion2" and ring is None and nranks // c > 1
-        assert ("mesh_chunks_tuning_ms_per_step" in out["config"]) == tuned
-        if tuned:  # the chunk count that was timed is the fastest of the measured candidates
-            t = out["config"]["mesh_chunks_tuning_ms_per_step"]
-            assert set(t) == {"2", "4", "8"} and out["config"]["mesh_chunks"] == int(min(t, key=t.get))
+        assert out["config"]["transport"] == "rccl"
+        assert ("route_tuning_ms_per_step" in out["config"]) == tuned
+        if tuned:  # the route that was timed is the fastest of the measured candidates (mesh fetch in 2 / 4 / 8 chunks, relay ring)
+            t = out["config"]["route_tuning_ms_per_step"]
+            assert set(t) == {"mesh/2 chunks", "mesh/4 chunks", "mesh/8 chunks", "relay ring"}
+            best = min(t, key=t.get)
+            assert out["config"]["ring_mode"] == ("relay" if best == "relay ring" else "mesh")
+            assert out["config"]["mesh_chunks"] == (None if best == "relay ring" else int(best.split("/")[1].split()[0]))
+        else:
+            assert out["config"]["ring_mode"] == (ring or "mesh")
     else:
         assert "preflight" not in out
