@@ -151,9 +151,11 @@ def gpu_world(H, dist, rank, n, local_rank):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
     ndev = torch.cuda.device_count()
-    if n > 1 and ndev < n:
-        raise SystemExit("bench.py --gpus %d: this process sees %d GPU(s); one process per GPU needs all %d visible to every rank "
-                         "(RCCL refuses two ranks on one device)" % (n, ndev, n))
+    if n > 1 and 1 < ndev < n:
+        raise SystemExit("bench.py --gpus %d: this process sees %d GPUs; one process per GPU needs either all %d visible to every rank "
+                         "(LOCAL_RANK picks one) or exactly one per rank (launcher-side isolation)" % (n, ndev, n))
+    # ndev == 1 with several ranks: the launcher gave every rank its own device; if they are in fact the same physical GPU,
+    # RCCL's communicator creation reports it (duplicate GPU) and the run ends with that error
     device = local_rank % ndev
     torch.cuda.set_device(device)
     assert H.load_backend(None) == "hip-gfx950"
