@@ -163,7 +163,11 @@ def gpu_world(H, dist, rank, n, local_rank):
         return H.World.single(device), torch.cuda.synchronize
     ident = [H.rccl_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(ident, src=0)
-    return H.World.rccl(rank, n, device, ident[0]), torch.cuda.synchronize
+    try:
+        return H.World.rccl(rank, n, device, ident[0]), torch.cuda.synchronize
+    except Exception as e:
+        raise SystemExit("bench.py --gpus %d, rank %d on device %d of %d visible: the RCCL communicator could not be created: %s\n"
+                         "(\"invalid usage\" here usually means two ranks share one physical GPU, which RCCL refuses)" % (n, rank, device, ndev, e))
 
 
 def run(args, make_world=gpu_world):
