@@ -215,6 +215,27 @@ def test_gat_forward_matches_reference_hip(alg, p, c):
     assert T.rel(out, gold) <= T.TOL
 
 
+@pytest.mark.parametrize("alg,p,c", [("15d_fusion2", 1, 1), ("15d_fusion2", 4, 1), ("15d_fusion1", 4, 2)])
+def test_gat_forward_at_benchmark_widths_against_the_compiled_reference(alg, p, c):
+    """GAT at the head widths the in-launch paths are built for (128 and 64 features per head, 256-wide layer input: exact-width
+    kernel instances, fp64 MFMA GEMM tiles, ReLU delivery into the layer output) on 2^15 vertices, against the reference's own
+    gat.hpp run on the host cores (and the numpy restatement of it)."""
+    from oracle import oracle as O
+    from oracle import refrun as RR
+    m, layers, alpha = 1 << 15, [(128, 128, 2), (256, 64, 3)], 0.2
+    rows, cols = H.generate_er(m, m, m * 16, 77)
+    x = O.dense_fill(m, 128, 41) * 4.0
+    case = dict(name="gat15", M=m, N=m, R=128, rows=rows, cols=cols, vals=np.ones(len(rows)), A=x / T.GAT_INPUT_SCALE, B=x / T.GAT_INPUT_SCALE)
+    per_rank = H.run_spmd(p, lambda w: T.run_gat(w, alg, c, case, layers=layers, alpha=alpha))
+    out = T.assemble_dense(per_rank, "gat", "subA", m, layers[-1][1] * layers[-1][2])
+    want = O.gat_forward(rows, cols, m, x, layers, alpha)
+    assert np.count_nonzero(want) > want.size // 10 and np.count_nonzero(want == 0.0) > want.size // 10  # both sides of the ReLU are hit
+    assert T.rel(out, want) <= T.TOL
+    if RR.available():
+        ref = RR.gat(m, rows, cols, 128, x, "15d_fusion1", 1, 1, alpha, layers, timeout=600)
+        assert T.rel(out, ref) <= T.TOL
+
+
 def test_operands_in_torch_memory():
     """hnh_dense_wrap: operands that live in PyTorch-owned HBM (non-owning views).  The fused schedule hands its
     result back by copying into the caller's tensor instead of swapping storage (common.h:88-92 semantics)."""
