@@ -1170,7 +1170,24 @@ struct LongCtl {
     int* count = nullptr;
     int capacity = 0;
     int threshold = 0;  // rows longer than this are the list's (multiple of 64)
+    size_t lds_pad = 0;  // unused LDS the row kernel's workgroups ask for, to cap their number per CU (row_occupancy_pad)
 };
+
+// Occupancy of the row kernels.  The memory system serves scattered rows a little FASTER when fewer waves compete for it: the
+// pure-gather probe gains 2 % going from 8 to 2-3 waves per SIMD (profiles/r02_gather_probe_occupancy.log), and the row kernels,
+// which register use would let run at 6-8 waves, gain 2-3 % at 4-5 on a uniform matrix (Erdos-Renyi, R = 32 / 128 / 256;
+// R = 64 loses 0.8 %) — but lose 9 % on a skewed one, where waves finish at very different times and more of them are needed
+// to keep the CU busy (profiles/r02_kbench_waves_cap_sweep.log).  So: blocks whose longest row is at most twice the mean, widths
+// that were measured to gain, 5 waves per SIMD.  A workgroup is one wave per SIMD, so the cap is an LDS request the kernel never
+// touches: 160 KiB / 5 per workgroup leaves room for exactly 5 of them on a CU.
+size_t row_occupancy_pad(const hnh_ctx* ctx, const Shape& s, int64_t rows, int64_t nnz, int max_row_nnz) {
+    if (ctx->row_waves_cap == 0) return 0;
+    if (ctx->row_waves_cap > 0) return (size_t)(160 * 1024 / ctx->row_waves_cap) - 64;
+    const bool measured_width = s.exact && ((s.lpr == 64 && (s.vec == 1 || s.vec == 2)) || (s.lpr == 16 && s.vec == 1));
+    if (!measured_width || rows <= 0 || nnz <= 0 || max_row_nnz < 0) return 0;
+    if ((int64_t)max_row_nnz * rows > 2 * nnz) return 0;  // not uniform
+    return (size_t)(160 * 1024 / 5) - 64;
+}
 
 // Rows longer than this go to the long-row pass (see kLongRowMin); nnz < 0 = unknown
 int long_row_threshold(const hnh_ctx* ctx, int64_t rows, int64_t nnz) {
@@ -1223,7 +1240,11 @@ int launch_row(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, int64_t rows, co
     if (blocks <= 0) return HNH_OK;
     if (blocks > 0x7fffffffLL) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "too many rows for one launch");
     if (lc.enabled) flags |= kInternalSplitLong | ((unsigned)(lc.threshold / 64) << kLongRowShift);
-    hipLaunchKernelGGL((row_kernel<OP, LPR, VEC, W, EXACT>), dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, rowptr, beg_ptr, end_ptr,
+    const size_t lds_pad = lc.lds_pad;
+    if (lds_pad > 48 * 1024)  // (only the measurement knob asks for that much)
+        HNH_TRY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&row_kernel<OP, LPR, VEC, W, EXACT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pad));
+    hipLaunchKernelGGL((row_kernel<OP, LPR, VEC, W, EXACT>), dim3((unsigned)blocks), dim3(kBlock), lds_pad, st, rows, rowptr, beg_ptr, end_ptr,
                        colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, ex);
     if (int rc = hnh::check_hip(ctx, hipGetLastError(), "row_kernel launch")) return rc;
     if constexpr (OP != Op::kFusedCg) {  // (a pass with hub rows never runs its epilogue inside the launch)
@@ -1293,6 +1314,7 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
                  const hnh_csr_window* win = nullptr) {
     LongCtl lc;
     if (int rc = prepare_long(ctx, st, sidx, rows, rowptr, nnz, max_row_nnz, &lc)) return rc;
+    if (!lc.enabled || ctx->row_waves_cap > 0) lc.lds_pad = row_occupancy_pad(ctx, s, rows, nnz, max_row_nnz);  // (hub rows = a skewed block)
     const bool single_pass = s.exact || R <= 64 * s.w * 4;
     // the epilogue can ride in the launch that completes the rows when ONE group completes each row: no hub-row segments
     // adding atomically afterwards, no column tiles (and, for the CG updates, an exact-width instance)

@@ -20,6 +20,10 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
     if (!ctx) return HNH_ERR_NOMEM;
     ctx->device = device;
     ctx->no_panels = std::getenv("HNH_NO_PANELS") != nullptr;
+    if (const char* k = std::getenv("HNH_ROW_WAVES_CAP")) {
+        const long v = std::strtol(k, nullptr, 10);
+        if (v >= 0 && v <= 7) ctx->row_waves_cap = (int)v;
+    }
     ctx->panels_with_hubs = std::getenv("HNH_PANELS_WITH_HUBS") != nullptr;
     if (const char* lr = std::getenv("HNH_LONG_ROW")) {
         const long v = std::strtol(lr, nullptr, 10);
