@@ -10,8 +10,14 @@ struct hnh_ctx {
     std::string last_error;
     // work list of the long-row pass (one per stream): items = (row, segment), count lives on the device
     void* long_items[2] = {nullptr, nullptr};
-    int* long_count[2] = {nullptr, nullptr};
+    int* long_count[2] = {nullptr, nullptr};  // two ints: number of items, number of hub rows
     size_t long_cap[2] = {0, 0};
+    // the hub rows themselves, (row, first item, segments), and the segments' partial output rows (items x row pitch doubles)
+    void* long_rows[2] = {nullptr, nullptr};
+    size_t long_rows_cap[2] = {0, 0};
+    void* long_partials[2] = {nullptr, nullptr};
+    size_t long_partials_bytes[2] = {0, 0};
+    bool hub_atomics = false;  // HNH_HUB_ATOMICS=1: combine hub-row segments with fp64 atomics (round 1's way) instead of the ordered reduction
     // per-row panel boundaries of the Infinity-Cache panels (one per stream): (panels - 1) x rows int32
     void* panel_split[2] = {nullptr, nullptr};
     size_t panel_cap[2] = {0, 0};

@@ -193,13 +193,14 @@ constexpr bool fused_op(Op o) { return o == Op::kFused || o == Op::kFusedCg; }
 // a single group walking such a row serialises the whole launch behind it (measured: 27 % of the roofline
 // instead of 81 %).  Rows longer than a threshold are therefore skipped by the row kernel and cut into segments
 // of kLongSeg nonzeros that are spread over the whole chip by a second, small launch (`long_row_kernel`);
-// SDDMM segments are independent, SpMM / fused segments combine their partial output rows with hardware fp64
-// atomics (global_atomic_add_f64).  Callers that know the block's longest row (the host layer does) pass it
-// as a hint and short-row matrices never pay for any of this.
+// SDDMM segments are independent; SpMM / fused segments write their partial output rows to scratch and a third launch
+// (`reduce_long_kernel`) adds a row's segments up in a fixed order, so results do not depend on which segment finishes
+// first (HNH_HUB_ATOMICS=1: hardware fp64 atomics instead, same speed, arrival-order sums).  Callers that know the
+// block's longest row (the host layer does) pass it as a hint and short-row matrices never pay for any of this.
 // The threshold adapts to the block: 3 x its mean row length, in steps of 64 within [kLongRowMin, kLongRowMax].  On a skewed
 // graph (R-MAT 2^20, mean 85) rows of 256..1024 nonzeros walked by one wave each still cost 5 % (tail and imbalance inside
 // the CUs; 1024 -> 256: 12.29 -> 11.65 ms at R = 128, 26.1 -> 24.8 ms at R = 256); on a uniform matrix whose mean is that
-// long the same 256 would push every row through the atomics path and lose the cache panels (Erdos-Renyi with 300 per row:
+// long the same 256 would push every row through the segment path and lose the cache panels (Erdos-Renyi with 300 per row:
 // 44.0 -> 50.5 ms), hence "relative to the mean" (profiles/r02_kbench_rmat_longrow_threshold.log, r02_kbench_er_ef300_*).
 constexpr int kLongRowMin = 256;
 constexpr int kLongRowMax = 1024;
@@ -247,7 +248,7 @@ template <Op OP, int LPR, int VEC, int W, bool EXACT>
 __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool atomic_out, const int32_t* __restrict__ colidx,
                                             double* values, const double* __restrict__ svalues, const double* __restrict__ X,
                                             const double* __restrict__ Y, double* __restrict__ Out, int64_t ld, int col0,
-                                            int ncols, unsigned flags, int lig, const Extras& ex) {
+                                            int ncols, unsigned flags, int lig, const Extras& ex, double* part_row = nullptr) {
     constexpr int UFULL = Unroll<LPR, VEC>::value;
     constexpr bool PIPE = (HNH_PIPE != 0) && UFULL >= 4;
     constexpr int U = PIPE ? UFULL / 2 : UFULL;  // nonzeros per (half) batch
@@ -528,8 +529,12 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
         for (int v = 0; v < VEC; v++) {
             if (!act[v]) continue;
             if (atomic_out) {
+                if (part_row != nullptr) {  // this segment's partial output row; reduce_long_kernel adds the segments up in order
+                    store_w_stream<W>(part_row + coff[v], acc[v]);
+                } else {
 #pragma unroll
-                for (int w = 0; w < W; w++) unsafeAtomicAdd(Out + row * ld + coff[v] + w, acc[v][w]);
+                    for (int w = 0; w < W; w++) unsafeAtomicAdd(Out + row * ld + coff[v] + w, acc[v][w]);
+                }
             } else {
                 store_w_stream<W>(Out + row * ld + coff[v], acc[v]);
             }
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HNH_ROW_
     }
     if (flags & kInternalSplitLong) {
         // hub rows (judged by the WHOLE row, also when this launch covers one column panel of it) are left to
-        // long_row_kernel; it adds atomically, so an overwritten output row has to start from zero
+        // long_row_kernel; its segments are ADDED to the output row, so an overwritten output row has to start from zero
         int full = rowptr[row + 1] - rowptr[row];
         if constexpr (LPR == 64) full = __builtin_amdgcn_readfirstlane(full);
         if (full > long_row_of(flags)) {
@@ -653,7 +658,8 @@ __global__ __launch_bounds__(kBlock) void long_row_kernel(const int2* __restrict
                                                           const int32_t* __restrict__ colidx, double* values,
                                                           const double* __restrict__ svalues, const double* __restrict__ X,
                                                           const double* __restrict__ Y, double* __restrict__ Out, int64_t ld,
-                                                          int col0, int ncols, unsigned flags, Extras ex) {
+                                                          int col0, int ncols, unsigned flags, Extras ex, double* partials,
+                                                          int partial_items) {
     constexpr int GROUPS = kBlock / LPR;
     const int tid = threadIdx.x;
     const int lig = tid % LPR;
@@ -666,21 +672,93 @@ __global__ __launch_bounds__(kBlock) void long_row_kernel(const int2* __restrict
         const int rbeg = rowptr[row], rend = rowptr[row + 1];
         const int beg = rbeg + item.y * kLongSeg;
         const int end = (beg + kLongSeg < rend) ? beg + kLongSeg : rend;
-        process_row<OP, LPR, VEC, W, EXACT>(row, beg, end, true, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, lig, ex);
+        double* part_row = (partials != nullptr && it < partial_items) ? partials + (int64_t)it * ld : nullptr;
+        process_row<OP, LPR, VEC, W, EXACT>(row, beg, end, true, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, lig, ex, part_row);
+    }
+}
+
+// Out[row, col0 .. col0 + ncols) += the sum of the row's segments' partial rows in a FIXED order: the deterministic replacement
+// of atomically combined segments.  One workgroup per hub row (a row's segments are consecutive items): wave w adds up the w-th
+// quarter of the segments front to back (8 loads in flight), then wave 0 adds the four quarter sums in wave order.
+template <int W>
+__global__ __launch_bounds__(kBlock) void reduce_long_kernel(const int4* __restrict__ hub_rows, const int* __restrict__ counts, int capacity_rows,
+                                                             const double* __restrict__ partials, int partial_items,
+                                                             double* __restrict__ Out, int64_t ld, int col0, int ncols) {
+    constexpr int WAVES = kBlock / 64;
+    __shared__ double quarter[WAVES][64][W];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int nrows = counts[1];
+    if (nrows > capacity_rows) nrows = capacity_rows;
+    for (int e = (int)blockIdx.x; e < nrows; e += (int)gridDim.x) {
+        const int4 h = hub_rows[e];  // (row, first item, segments, -)
+        int nseg = h.z;
+        if (h.y + nseg > partial_items) nseg = partial_items > h.y ? partial_items - h.y : 0;  // (the rest went the atomic way)
+        const int per = (nseg + WAVES - 1) / WAVES;
+        const int s_beg = wave * per < nseg ? wave * per : nseg;
+        const int s_end = s_beg + per < nseg ? s_beg + per : nseg;
+        double* o = Out + (int64_t)h.x * ld + col0;
+        const double* p0 = partials + (int64_t)h.y * ld + col0;
+        for (int c0 = 0; c0 < ncols; c0 += 64 * W) {
+            const int c = c0 + lane * W;
+            const bool live = c < ncols;  // ncols is a multiple of W
+            double sum[W];
+#pragma unroll
+            for (int w = 0; w < W; w++) sum[w] = 0.0;
+            int s2 = s_beg;
+            for (; s2 + 8 <= s_end; s2 += 8) {
+                double y[8][W];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+#pragma unroll
+                    for (int w = 0; w < W; w++) y[u][w] = 0.0;
+                    if (live) load_w<W>(y[u], p0 + (int64_t)(s2 + u) * ld + c);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+#pragma unroll
+                    for (int w = 0; w < W; w++) sum[w] += y[u][w];
+            }
+            for (; s2 < s_end; s2++) {
+                double y[W];
+                if (live) {
+                    load_w<W>(y, p0 + (int64_t)s2 * ld + c);
+#pragma unroll
+                    for (int w = 0; w < W; w++) sum[w] += y[w];
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < W; w++) quarter[wave][lane][w] = sum[w];
+            __syncthreads();
+            if (wave == 0 && live) {
+                double y[W];
+                load_w<W>(y, o + c);
+#pragma unroll
+                for (int w = 0; w < W; w++) {
+                    double t = quarter[0][lane][w];
+#pragma unroll
+                    for (int q = 1; q < WAVES; q++) t += quarter[q][lane][w];
+                    y[w] += t;
+                }
+                store_w<W>(o + c, y);
+            }
+            __syncthreads();
+        }
     }
 }
 
 __global__ __launch_bounds__(kBlock) void build_long_list_kernel(int64_t rows, const int32_t* __restrict__ rowptr,
                                                                  int2* __restrict__ items, int* __restrict__ item_count,
-                                                                 int capacity, int long_row) {
+                                                                 int capacity, int long_row, int4* __restrict__ hub_rows, int capacity_rows) {
     const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (row >= rows) return;
     const int len = rowptr[row + 1] - rowptr[row];
     if (len <= long_row) return;
     const int nseg = (len + kLongSeg - 1) / kLongSeg;
-    const int base = atomicAdd(item_count, nseg);
+    const int base = atomicAdd(item_count, nseg);  // item_count[0]: items, [1]: hub rows
     for (int s2 = 0; s2 < nseg; s2++)
         if (base + s2 < capacity) items[base + s2] = make_int2((int)row, s2);
+    const int slot = atomicAdd(item_count + 1, 1);
+    if (slot < capacity_rows) hub_rows[slot] = make_int4((int)row, base, nseg, 0);
 }
 
 __global__ __launch_bounds__(kBlock) void max_row_nnz_kernel(int64_t rows, const int32_t* __restrict__ rowptr, int* __restrict__ out) {
@@ -1170,6 +1248,10 @@ struct LongCtl {
     int* count = nullptr;
     int capacity = 0;
     int threshold = 0;  // rows longer than this are the list's (multiple of 64)
+    int4* hub_rows = nullptr;   // (row, first item, segments) per hub row
+    int capacity_rows = 0;
+    double* partials = nullptr;  // items x (row pitch) doubles; nullptr: segments combine with atomics
+    int partial_items = 0;
     size_t lds_pad = 0;  // unused LDS the row kernel's workgroups ask for, to cap their number per CU (row_occupancy_pad)
 };
 
@@ -1200,8 +1282,9 @@ int long_row_threshold(const hnh_ctx* ctx, int64_t rows, int64_t nnz) {
 // Decides whether this call needs the long-row pass and, if so, builds the (row, segment) work list on the
 // device.  max_row_nnz: the caller's knowledge of the longest row (< 0 = unknown -> the list is always built);
 // nnz: number of nonzeros (< 0 = unknown -> read back from rowptr[rows], one 4-byte synchronous copy).
+// out_pitch: row pitch (in doubles) of the output the segments add to, 0 for SDDMM — sizes the partial-row scratch.
 int prepare_long(hnh_ctx* ctx, hipStream_t st, int sidx, int64_t rows, const int32_t* rowptr, int64_t nnz, int max_row_nnz,
-                 LongCtl* lc) {
+                 int64_t out_pitch, LongCtl* lc) {
     if (max_row_nnz >= 0 && max_row_nnz <= (ctx->long_row_override > 0 ? ctx->long_row_override : kLongRowMin)) return HNH_OK;
     if (nnz < 0) {
         int last = 0;
@@ -1219,15 +1302,42 @@ int prepare_long(hnh_ctx* ctx, hipStream_t st, int sidx, int64_t rows, const int
         HNH_TRY_HIP(ctx, hipMalloc(&ctx->long_items[sidx], cap * sizeof(int2)));
         ctx->long_cap[sidx] = cap;
     }
-    if (!ctx->long_count[sidx]) HNH_TRY_HIP(ctx, hipMalloc((void**)&ctx->long_count[sidx], sizeof(int)));
+    if (!ctx->long_count[sidx]) HNH_TRY_HIP(ctx, hipMalloc((void**)&ctx->long_count[sidx], 2 * sizeof(int)));
+    const size_t cap_rows = (size_t)(nnz / threshold + 16);
+    if (ctx->long_rows_cap[sidx] < cap_rows) {
+        HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
+        if (ctx->long_rows[sidx]) HNH_TRY_HIP(ctx, hipFree(ctx->long_rows[sidx]));
+        ctx->long_rows[sidx] = nullptr;
+        HNH_TRY_HIP(ctx, hipMalloc(&ctx->long_rows[sidx], cap_rows * sizeof(int4)));
+        ctx->long_rows_cap[sidx] = cap_rows;
+    }
+    // Partial output rows of the segments (ordered reduction instead of atomics: results do not depend on the order in which
+    // segments finish).  `cap` bounds the number of items whatever the matrix looks like: nnz * pitch / 16 bytes at worst
+    // (8 bytes per nonzero at R = 128), allocated once per stream and kept.
+    if (out_pitch > 0 && !ctx->hub_atomics) {
+        const size_t need = cap * (size_t)out_pitch * sizeof(double);
+        if (ctx->long_partials_bytes[sidx] < need) {
+            HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
+            if (ctx->long_partials[sidx]) HNH_TRY_HIP(ctx, hipFree(ctx->long_partials[sidx]));
+            ctx->long_partials[sidx] = nullptr;
+            ctx->long_partials_bytes[sidx] = 0;
+            HNH_TRY_HIP(ctx, hipMalloc(&ctx->long_partials[sidx], need));
+            ctx->long_partials_bytes[sidx] = need;
+        }
+        lc->partials = static_cast<double*>(ctx->long_partials[sidx]);
+        lc->partial_items = (int)cap;
+    }
     lc->items = static_cast<int2*>(ctx->long_items[sidx]);
     lc->count = ctx->long_count[sidx];
     lc->capacity = (int)cap;
+    lc->hub_rows = static_cast<int4*>(ctx->long_rows[sidx]);
+    lc->capacity_rows = (int)cap_rows;
     lc->enabled = true;
     lc->threshold = threshold;
-    HNH_TRY_HIP(ctx, hipMemsetAsync(lc->count, 0, sizeof(int), st));
+    HNH_TRY_HIP(ctx, hipMemsetAsync(lc->count, 0, 2 * sizeof(int), st));
     const int64_t blocks = (rows + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(build_long_list_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, rowptr, lc->items, lc->count, lc->capacity, threshold);
+    hipLaunchKernelGGL(build_long_list_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, rowptr, lc->items, lc->count, lc->capacity, threshold,
+                       lc->hub_rows, lc->capacity_rows);
     return hnh::check_hip(ctx, hipGetLastError(), "build_long_list_kernel launch");
 }
 
@@ -1250,9 +1360,21 @@ int launch_row(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, int64_t rows, co
     if constexpr (OP != Op::kFusedCg) {  // (a pass with hub rows never runs its epilogue inside the launch)
         if (lc.enabled && run_long) {  // hub rows once per pass (after the last column panel), over their whole length
             // 256 CUs x 4 resident workgroups; items are spread round-robin over all groups of the grid
+            double* partials = (OP != Op::kSddmm) ? lc.partials : nullptr;
             hipLaunchKernelGGL((long_row_kernel<OP, LPR, VEC, W, EXACT>), dim3(1024), dim3(kBlock), 0, st, lc.items, lc.count,
-                               lc.capacity, rowptr, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, ex);
-            return hnh::check_hip(ctx, hipGetLastError(), "long_row_kernel launch");
+                               lc.capacity, rowptr, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, ex, partials, lc.partial_items);
+            if (int rc = hnh::check_hip(ctx, hipGetLastError(), "long_row_kernel launch")) return rc;
+            if (partials != nullptr) {
+                const bool pairs = (ld % 2 == 0) && (col0 % 2 == 0) && (ncols % 2 == 0) && aligned16(Out);  // 16-byte accesses
+                if (pairs)
+                    hipLaunchKernelGGL(reduce_long_kernel<2>, dim3(2048), dim3(kBlock), 0, st, lc.hub_rows, lc.count, lc.capacity_rows, partials,
+                                       lc.partial_items, Out, ld, col0, ncols);
+                else
+                    hipLaunchKernelGGL(reduce_long_kernel<1>, dim3(2048), dim3(kBlock), 0, st, lc.hub_rows, lc.count, lc.capacity_rows, partials,
+                                       lc.partial_items, Out, ld, col0, ncols);
+                return hnh::check_hip(ctx, hipGetLastError(), "reduce_long_kernel launch");
+            }
+            return HNH_OK;
         }
     }
     return HNH_OK;
@@ -1313,7 +1435,7 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
                  const double* Y, double* Out, int R, unsigned flags, const Extras& ex = Extras(), bool* epilogue_done = nullptr,
                  const hnh_csr_window* win = nullptr) {
     LongCtl lc;
-    if (int rc = prepare_long(ctx, st, sidx, rows, rowptr, nnz, max_row_nnz, &lc)) return rc;
+    if (int rc = prepare_long(ctx, st, sidx, rows, rowptr, nnz, max_row_nnz, (OP != Op::kSddmm) ? (int64_t)R : 0, &lc)) return rc;
     if (!lc.enabled || ctx->row_waves_cap > 0) lc.lds_pad = row_occupancy_pad(ctx, s, rows, nnz, max_row_nnz);  // (hub rows = a skewed block)
     const bool single_pass = s.exact || R <= 64 * s.w * 4;
     // the epilogue can ride in the launch that completes the rows when ONE group completes each row: no hub-row segments
@@ -1864,7 +1986,7 @@ int hnh_csr_max_row_nnz(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, int* 
     if (rows == 0) return HNH_OK;
     if (!rowptr) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_csr_max_row_nnz: null pointer");
     hipStream_t st = ctx->streams[stream];
-    if (!ctx->long_count[stream]) HNH_TRY_HIP(ctx, hipMalloc((void**)&ctx->long_count[stream], sizeof(int)));
+    if (!ctx->long_count[stream]) HNH_TRY_HIP(ctx, hipMalloc((void**)&ctx->long_count[stream], 2 * sizeof(int)));  // shared with prepare_long (two counters)
     HNH_TRY_HIP(ctx, hipMemsetAsync(ctx->long_count[stream], 0, sizeof(int), st));
     hipLaunchKernelGGL(max_row_nnz_kernel, dim3(ew_grid(rows)), dim3(kBlock), 0, st, rows, rowptr, ctx->long_count[stream]);
     HNH_TRY_HIP(ctx, hipGetLastError());

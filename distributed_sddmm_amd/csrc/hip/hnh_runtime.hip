@@ -20,6 +20,7 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
     if (!ctx) return HNH_ERR_NOMEM;
     ctx->device = device;
     ctx->no_panels = std::getenv("HNH_NO_PANELS") != nullptr;
+    ctx->hub_atomics = std::getenv("HNH_HUB_ATOMICS") != nullptr;
     if (const char* k = std::getenv("HNH_ROW_WAVES_CAP")) {
         const long v = std::strtol(k, nullptr, 10);
         if (v >= 0 && v <= 7) ctx->row_waves_cap = (int)v;
@@ -50,6 +51,8 @@ int hnh_ctx_destroy(hnh_ctx* ctx) {
         if (ctx->streams[s]) { (void)hipStreamSynchronize(ctx->streams[s]); (void)hipStreamDestroy(ctx->streams[s]); }
         if (ctx->long_items[s]) (void)hipFree(ctx->long_items[s]);
         if (ctx->long_count[s]) (void)hipFree(ctx->long_count[s]);
+        if (ctx->long_rows[s]) (void)hipFree(ctx->long_rows[s]);
+        if (ctx->long_partials[s]) (void)hipFree(ctx->long_partials[s]);
         if (ctx->panel_split[s]) (void)hipFree(ctx->panel_split[s]);
     }
     delete ctx;

@@ -103,8 +103,9 @@ int hnh_fused_sddmm_spmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, 
 /* Variants for callers that know the block: `nnz` = rowptr[rows] and `max_row_nnz` = its longest row (either may
  * be -1 = unknown).  Hub rows — rows longer than 3 x the block's mean row length, taken in steps of 64 and within
  * [256, 1024] (1024 when nnz is unknown) — are cut into 256-nonzero
- * segments that a second small launch spreads over the whole chip (SpMM / fused segments combine with fp64
- * atomics); with max_row_nnz below that threshold none of that machinery runs.  The plain entry points above pass -1, -1.
+ * segments that a second small launch spreads over the whole chip (SpMM / fused segments write partial output rows
+ * that a third launch adds up in a fixed order: results are bit-identical run to run); with max_row_nnz below that
+ * threshold none of that machinery runs.  The plain entry points above pass -1, -1.
  * hnh_csr_max_row_nnz computes the hint (one device reduction + 4-byte synchronous copy).
  * cols = number of rows of the gathered dense operand (= columns of the sparse block), or -1.  When it is given and the
  * operand is larger than ~768 MiB the pass runs as several launches, one per ~512 MiB COLUMN PANEL of the block
@@ -150,7 +151,7 @@ int hnh_spmm_csr_w(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int3
  *   x_scale      != 0:  Out[i,:] += x_scale * X[i,:]                         — als_conjugate_gradients.cpp:282,295 (+ lambda * X)
  *   rowdot       != NULL: rowdot[i] = <X[i,:], Out[i,:]> of the FINAL row     — als_conjugate_gradients.cpp:93 (batch_dot_product(p, Mp))
  * The epilogue (x_scale, rowdot) runs inside the launch when one group completes the output row; with hub rows
- * (atomically combined segments) or column tiles it is appended as a row-wise
+ * (segments combined after the launch) or column tiles it is appended as a row-wise
  * launch — same result either way.  hnh_row_epilogue_f64 is that launch on its own.
  *
  *   cg != NULL: the REST of one batched-CG iteration (als_conjugate_gradients.cpp:91-139) runs on the finished row too,

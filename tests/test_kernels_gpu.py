@@ -256,11 +256,17 @@ def test_hub_rows_are_split_and_still_exact(ctx, R, hinted):
     assert mx.value == 3
 
 
-def test_repeat_runs_short_rows_bitwise_hub_rows_within_tolerance(ctx):
-    """Run-to-run reproducibility.  Rows below the hub-row threshold are finished by ONE group in a fixed order: repeated calls
-    give bit-identical results (like the reference for a fixed thread count).  Hub rows are cut into 256-nonzero segments
-    whose partial output rows combine with hardware fp64 atomics, so their summation order can change between runs: results
-    agree within the parity tolerance, not necessarily bit for bit ("Long rows")."""
+@pytest.mark.parametrize("atomics", [False, True])
+def test_repeat_runs_are_bitwise_reproducible(monkeypatch, atomics):
+    """Run-to-run reproducibility.  Rows below the hub-row threshold are finished by ONE group in a fixed order.  Hub rows are cut
+    into 256-nonzero segments; each segment writes its partial output row and a second kernel adds a row's segments up in
+    segment order — so repeated calls give bit-identical results for every row (like the reference for a fixed thread count).
+    HNH_HUB_ATOMICS=1 selects round 1's way (segments combine with hardware fp64 atomics in arrival order): results then agree
+    within the parity tolerance, not necessarily bit for bit ("Long rows")."""
+    if atomics:
+        monkeypatch.setenv("HNH_HUB_ATOMICS", "1")
+    from distributed_sddmm_amd import _kernels as K
+    ctx = K.Ctx(0)
     lib, R = ctx.lib, 64
     rng = np.random.default_rng(11)
     rows, cols = 300, 9000
@@ -273,23 +279,28 @@ def test_repeat_runs_short_rows_bitwise_hub_rows_within_tolerance(ctx):
         ridx = np.repeat(np.arange(rows, dtype=np.int32), lens)
         X, Y = rng.standard_normal((rows, R)), rng.standard_normal((cols, R))
         d_rp, d_c, dX, dY = ctx.upload(rowptr), ctx.upload(cidx), ctx.upload(X), ctx.upload(Y)
-        outs, vals = [], []
+        mx = C.c_int()  # (first use of the fresh context's counters: the hint query and the hub-row pass share them)
+        ctx.check(lib.hnh_csr_max_row_nnz(ctx.h, rows, d_rp.ptr, C.byref(mx), 0), "max_row")
+        assert mx.value == int(lens.max())
+        outs, vals, spmms = [], [], []
         for _ in range(6):
-            dv, dOut = ctx.upload(np.zeros(len(cidx))), ctx.upload(np.zeros((rows, R)))
+            dv, dOut, dOut2 = ctx.upload(np.zeros(len(cidx))), ctx.upload(np.zeros((rows, R))), ctx.upload(np.zeros((rows, R)))
             ctx.check(lib.hnh_fused_sddmm_spmm_csr_ex(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, None, dX.ptr, dY.ptr, dOut.ptr, R, 3,
                                                       len(cidx), int(lens.max()), cols, 0), "fused repeat")
+            ctx.check(lib.hnh_spmm_csr_ex(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, dY.ptr, dOut2.ptr, R, len(cidx), int(lens.max()), cols, 0), "spmm repeat")
             ctx.sync()
-            outs.append(dOut.get()); vals.append(dv.get())
-            dv.free(); dOut.free()
+            outs.append(dOut.get()); vals.append(dv.get()); spmms.append(dOut2.get())
+            dv.free(); dOut.free(); dOut2.free()
         mid = O.sddmm_local(ridx, cidx, np.zeros(len(cidx)), X, Y)
         want = O.spmm_local(rowptr, cidx, mid, Y, np.zeros((rows, R)))
         for k in range(6):
             assert np.array_equal(vals[k], vals[0])  # SDDMM values: one group per nonzero batch, always bitwise
-            assert rel(outs[k], want) <= TOL
-            if not hubs:
-                assert np.array_equal(outs[k], outs[0])
+            assert rel(outs[k], want) <= TOL and rel(spmms[k], want) <= TOL
+            if not (hubs and atomics):
+                assert np.array_equal(outs[k], outs[0]) and np.array_equal(spmms[k], spmms[0])
         for d in (d_rp, d_c, dX, dY):
             d.free()
+    ctx.close()
 
 
 @pytest.mark.parametrize("R", [16, 128, 100, 257])
