@@ -40,6 +40,21 @@ def one(rng, it):
         for mm in (H.AMAT, H.BMAT):
             pr = H.run_spmd(p, lambda w: T.run_fused_out(w, alg, c, case, mm, 0.3, 0.7, True))
             T.check_fused_out(pr, case, mm, 0.3, 0.7, True)
+    if len(rows) >= m and rng.random() < 0.5:
+        # ALS: the CG iteration folded into the fused call's row epilogue (hnh_cg_update; schedules without an R split) against
+        # the variant with the reference's separate update steps — whatever the schedule, grid and route, the same factors
+        both = []
+        for unfolded in (False, True):
+            if unfolded:
+                os.environ["HNH_ALS_UNFOLDED"] = "1"
+            else:
+                os.environ.pop("HNH_ALS_UNFOLDED", None)
+            pr = H.run_spmd(p, lambda w: T.run_als(w, alg, c, case, 1, 3))
+            both.append((T.assemble_dense(pr, "alsA", "subA", m, r), T.assemble_dense(pr, "alsB", "subB", n, r), pr[0]["residuals"]))
+        os.environ.pop("HNH_ALS_UNFOLDED", None)
+        for x, y in zip(*both):
+            assert T.rel(x, y) <= T.ALS_TOL, tag
+        tag += " +als"
     return tag
 
 
