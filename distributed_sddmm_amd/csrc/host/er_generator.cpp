@@ -4,9 +4,16 @@
 
 #include <omp.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
+#include <iterator>
 #include <sstream>
 
 #include "spmat_local.hpp"
@@ -65,17 +72,66 @@ std::vector<uint64_t> vertex_permutation(uint64_t n, uint64_t seed) {
 }
 
 // Parses a MatrixMarket coordinate file (general / symmetric; pattern, integer or real) into 0-based tuples, mirrored
-// entries of a symmetric file included, duplicates NOT yet merged.  The body is cut at line boundaries into one piece per
-// OpenMP thread (a SuiteSparse graph like com-Orkut is ~1.7 GB of text).
-void parse_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std::vector<spcoord_t>& tuples) {
-    std::ifstream in(path, std::ios::binary | std::ios::ate);
-    if (!in) fatal("Error, cannot open matrix file " + path);
-    const std::streamsize fsize = in.tellg();
-    in.seekg(0);
-    std::string text((size_t)fsize, '\0');
-    if (fsize > 0 && !in.read(&text[0], fsize)) fatal("Error, cannot read matrix file " + path);
-    size_t pos = text.find('\n');
-    std::string line = text.substr(0, pos == std::string::npos ? text.size() : pos);
+// entries of a symmetric file included, duplicates NOT yet merged.  The file is memory-mapped and its body cut at line
+// boundaries into one piece per OpenMP thread, each parsed into its own vector (a SuiteSparse graph like com-Orkut is
+// ~1.7 GB of text; indices are read by a plain digit loop — strtoull spends most of its time elsewhere — and values by
+// strtod).  `parts` keeps the pieces in file order, so a caller can move them on without concatenating 24 bytes per tuple.
+namespace {
+struct MappedFile {
+    const char* data = nullptr;
+    size_t size = 0;
+    std::string fallback;  // when mmap is not available (special files)
+    int fd = -1;
+    explicit MappedFile(const std::string& path) {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) fatal("Error, cannot open matrix file " + path);
+        struct stat st;
+        if (::fstat(fd, &st) != 0) fatal("Error, cannot stat matrix file " + path);
+        size = (size_t)st.st_size;
+        if (size > 0) {
+            void* m = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                data = static_cast<const char*>(m);
+                ::madvise(m, size, MADV_SEQUENTIAL);
+                return;
+            }
+        }
+        std::ifstream in(path, std::ios::binary);
+        fallback.assign(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>());
+        data = fallback.data();
+        size = fallback.size();
+    }
+    ~MappedFile() {
+        if (data != nullptr && fallback.empty() && size > 0) ::munmap(const_cast<char*>(data), size);
+        if (fd >= 0) ::close(fd);
+    }
+    MappedFile(const MappedFile&) = delete;
+    MappedFile& operator=(const MappedFile&) = delete;
+};
+
+// decimal digits at p (after optional blanks); false when there are none
+inline bool parse_index(const char*& p, const char* hi, uint64_t& out) {
+    while (p < hi && (*p == ' ' || *p == '\t')) p++;
+    const char* q = p;
+    uint64_t v = 0;
+    while (q < hi && (unsigned)(*q - '0') <= 9u) v = v * 10 + (uint64_t)(*q++ - '0');
+    if (q == p) return false;
+    out = v;
+    p = q;
+    return true;
+}
+}  // namespace
+
+void parse_matrix_market_parts(const std::string& path, uint64_t& m, uint64_t& n, std::vector<std::vector<spcoord_t>>& parts) {
+    MappedFile file(path);
+    const char* text = file.data;
+    const char* end = text + file.size;
+    auto line_end = [&](const char* p) {
+        const void* nl = p < end ? std::memchr(p, '\n', (size_t)(end - p)) : nullptr;
+        return nl ? static_cast<const char*>(nl) : end;
+    };
+    const char* le = line_end(text);
+    std::string line(text, le);
     if (line.rfind("%%MatrixMarket", 0) != 0) fatal("Error, " + path + " is not a MatrixMarket file");
     std::string lower = line;
     std::transform(lower.begin(), lower.end(), lower.begin(), ::tolower);
@@ -85,20 +141,20 @@ void parse_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std:
     // comment lines, then the size line
     uint64_t entries = 0;
     for (;;) {
-        if (pos == std::string::npos) fatal("Error, bad MatrixMarket size line in " + path);
-        const size_t start = pos + 1;
-        pos = text.find('\n', start);
-        line = text.substr(start, (pos == std::string::npos ? text.size() : pos) - start);
-        if (line.empty() || line[0] == '%') continue;
+        if (le >= end) fatal("Error, bad MatrixMarket size line in " + path);
+        const char* start = le + 1;
+        le = line_end(start);
+        line.assign(start, le);
+        if (line.empty() || line[0] == '%' || line == "\r") continue;
         std::istringstream hdr(line);
         if (!(hdr >> m >> n >> entries)) fatal("Error, bad MatrixMarket size line in " + path);
         break;
     }
-    const char* body = text.data() + (pos == std::string::npos ? text.size() : pos + 1);
-    const char* end = text.data() + text.size();
+    const char* body = le < end ? le + 1 : end;
     const int nthreads = std::max(1, omp_get_max_threads());
-    std::vector<std::vector<spcoord_t>> part((size_t)nthreads);
+    parts.assign((size_t)nthreads, {});
     std::vector<int> bad((size_t)nthreads, 0);
+    const uint64_t mm = m, nn = n;
 #pragma omp parallel num_threads(nthreads)
     {
         const int t = omp_get_thread_num();
@@ -109,8 +165,8 @@ void parse_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std:
             while (lo < end && lo[-1] != '\n') lo++;
         }
         while (hi < end && hi[-1] != '\n') hi++;  // ... and finish the line that straddles its end
-        std::vector<spcoord_t>& out = part[(size_t)t];
-        out.reserve((size_t)(entries / (uint64_t)nthreads + 16) * (symmetric ? 2 : 1));
+        std::vector<spcoord_t>& out = parts[(size_t)t];
+        out.reserve((size_t)((double)(entries / (uint64_t)nthreads + 16) * (symmetric ? 2.0 : 1.0) * 1.05));
         const char* p = lo;
         while (p < hi) {
             while (p < hi && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n')) p++;
@@ -119,40 +175,42 @@ void parse_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std:
                 while (p < hi && *p != '\n') p++;
                 continue;
             }
-            char* q = nullptr;
-            const uint64_t r = std::strtoull(p, &q, 10);
-            if (q == p) { bad[(size_t)t] = 1; break; }
-            p = q;
-            const uint64_t c = std::strtoull(p, &q, 10);
-            if (q == p) { bad[(size_t)t] = 1; break; }
-            p = q;
+            uint64_t r = 0, c = 0;
+            if (!parse_index(p, hi, r) || !parse_index(p, hi, c)) { bad[(size_t)t] = 1; break; }
             double v = 1.0;
             if (!pattern) {
-                v = std::strtod(p, &q);
+                char* q = nullptr;
+                v = std::strtod(p, &q);  // (the mapping ends in a line feed or the file's last number: strtod stops there)
                 if (q == p) { bad[(size_t)t] = 1; break; }
                 p = q;
             }
             while (p < hi && *p != '\n') p++;  // ignore anything else on the line (complex files are not supported anyway)
-            if (r < 1 || r > m || c < 1 || c > n) { bad[(size_t)t] = 2; break; }
+            if (r < 1 || r > mm || c < 1 || c > nn) { bad[(size_t)t] = 2; break; }
             out.push_back({r - 1, c - 1, v});
             if (symmetric && r != c) out.push_back({c - 1, r - 1, v});
         }
     }
-    size_t total = 0, lines = 0;
+    size_t total = 0;
     for (int t = 0; t < nthreads; t++) {
         if (bad[(size_t)t] == 1) fatal("Error, malformed line in MatrixMarket file " + path);
         if (bad[(size_t)t] == 2) fatal("Error, MatrixMarket index out of range in " + path);
-        total += part[(size_t)t].size();
+        total += parts[(size_t)t].size();
     }
+    if (!symmetric && total != entries) fatal("Error, truncated MatrixMarket file " + path);
+    if (symmetric && total < entries) fatal("Error, truncated MatrixMarket file " + path);
+}
+
+void parse_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std::vector<spcoord_t>& tuples) {
+    std::vector<std::vector<spcoord_t>> parts;
+    parse_matrix_market_parts(path, m, n, parts);
+    size_t total = 0;
+    for (auto& v : parts) total += v.size();
     tuples.clear();
-    tuples.reserve(total);
-    for (auto& v : part) {
+    tuples.reserve(total);  // (no resize: value-initialising 24 bytes per tuple first would touch every page twice)
+    for (auto& v : parts) {
         tuples.insert(tuples.end(), v.begin(), v.end());
         std::vector<spcoord_t>().swap(v);
     }
-    (void)lines;
-    if (!symmetric && tuples.size() != entries) fatal("Error, truncated MatrixMarket file " + path);
-    if (symmetric && tuples.size() < entries) fatal("Error, truncated MatrixMarket file " + path);
 }
 
 // duplicates -> maximum (the reference reads with `maximum<double>()`, SpmatLocal.hpp:487); host version
@@ -188,21 +246,29 @@ void SpmatLocal::loadTuples(bool readFromFile, int logM, int nnz_per_row, std::s
             // every rank parses the file (in parallel on its host cores), then the GPU orders the tuples, merges duplicate
             // coordinates with `maximum` (SpmatLocal.hpp:487) and keeps this rank's strided slice: the tuples are
             // device-resident from here on, like the generated ones
-            hnh::parse_matrix_market(filename, m, n, all);
+            std::vector<std::vector<spcoord_t>> parts;  // one per parsing thread, in file order: uploaded piece by piece
+            hnh::parse_matrix_market_parts(filename, m, n, parts);
             if (m >> 32 || n >> 32) hnh::fatal("Error, matrices with more than 2^32 rows or columns are not supported!");
             M = m;
             N = n;
-            hnh::DeviceArray raw(world, std::max<size_t>(all.size(), 1) * sizeof(spcoord_t));
-            world->copy(raw.ptr(), all.data(), all.size() * sizeof(spcoord_t), HNH_COPY_H2D, HNH_STREAM_COMPUTE);
+            size_t n_raw = 0;
+            for (auto& v : parts) n_raw += v.size();
+            hnh::DeviceArray raw(world, std::max<size_t>(n_raw, 1) * sizeof(spcoord_t));
             hnh_tuple* rt = static_cast<hnh_tuple*>(raw.ptr());
+            size_t at = 0;
+            for (auto& v : parts) {
+                world->copy(rt + at, v.data(), v.size() * sizeof(spcoord_t), HNH_COPY_H2D, HNH_STREAM_COMPUTE);
+                at += v.size();
+            }
+            world->sync(HNH_STREAM_COMPUTE);  // the pieces are pageable host memory: done with them before they go
+            std::vector<std::vector<spcoord_t>>().swap(parts);
             hnh_tuple_key key{};
             key.kind = HNH_KEY_ROW_COL;
             int row_bits = 1;
             while (row_bits < 32 && ((uint64_t)1 << row_bits) < m) row_bits++;
-            world->check(world->be->hnh_tuples_sort(world->ctx, rt, (int64_t)all.size(), &key, 32 + row_bits, HNH_STREAM_COMPUTE), "hnh_tuples_sort");
+            world->check(world->be->hnh_tuples_sort(world->ctx, rt, (int64_t)n_raw, &key, 32 + row_bits, HNH_STREAM_COMPUTE), "hnh_tuples_sort");
             int64_t unique = 0;
-            world->check(world->be->hnh_tuples_dedup_max(world->ctx, rt, (int64_t)all.size(), &unique, HNH_STREAM_COMPUTE), "hnh_tuples_dedup_max");
-            std::vector<spcoord_t>().swap(all);
+            world->check(world->be->hnh_tuples_dedup_max(world->ctx, rt, (int64_t)n_raw, &unique, HNH_STREAM_COMPUTE), "hnh_tuples_dedup_max");
             dist_nnz = (uint64_t)unique;
             n_resident = unique > rank ? (size_t)((unique - rank + p - 1) / p) : 0;
             dcoords = hnh::DeviceArray(world, std::max<size_t>(n_resident, 1) * sizeof(spcoord_t));

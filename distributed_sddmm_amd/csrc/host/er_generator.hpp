@@ -41,6 +41,8 @@ void read_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std::
 // its two halves: the parallel parser (symmetric entries mirrored, duplicates still present) and the duplicate merge on the host
 // (the default set-up does the merge on the GPU instead: hnh_tuples_sort + hnh_tuples_dedup_max)
 void parse_matrix_market(const std::string& path, uint64_t& m, uint64_t& n, std::vector<spcoord_t>& tuples);
+// the same, the parsing threads' pieces kept apart (file order)
+void parse_matrix_market_parts(const std::string& path, uint64_t& m, uint64_t& n, std::vector<std::vector<spcoord_t>>& parts);
 void merge_duplicates_max(std::vector<spcoord_t>& tuples);
 
 }  // namespace hnh

@@ -149,3 +149,48 @@ def test_matrix_market_file_through_the_schedules(tmp_path, monkeypatch, host_se
     for alg, p, c in (("25d_dense_replicate", 8, 2), ("15d_fusion2", 4, 1)):
         per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case, make_spmat=from_file))
         T.check_against_oracle(T.assemble(per_rank, case), case, alg)
+
+
+@pytest.mark.parametrize("host_setup", [False, True])
+def test_matrix_market_parser_survives_untidy_files(tmp_path, monkeypatch, host_setup):
+    """The parser cuts the memory-mapped text into one piece per thread at line boundaries and reads indices with its own
+    digit loop: a general (rectangular) real file with CRLF line ends, tabs, leading blanks, exponents, comment and blank lines
+    inside the body and no line feed after the last entry must give exactly the matrix scipy reads from it."""
+    import scipy.io
+    if host_setup:
+        monkeypatch.setenv("HNH_HOST_SETUP", "1")
+    m, n, r = 70, 53, 8
+    rng = np.random.default_rng(5)
+    keys = rng.choice(m * n, 900, replace=False)
+    vals = rng.uniform(-1, 1, len(keys)) * 10.0 ** rng.integers(-3, 4, len(keys))
+    lines = []
+    for k, v in zip(keys.tolist(), vals.tolist()):
+        sep = rng.choice([" ", "\t", "   "])
+        lead = rng.choice(["", " ", "\t"])
+        num = ("%.17e" % v) if rng.random() < 0.5 else repr(v)
+        lines.append("%s%d%s%d%s%s" % (lead, k // n + 1, sep, k % n + 1, sep, num))
+        if rng.random() < 0.05:
+            lines.append("% a comment in the body")
+        if rng.random() < 0.05:
+            lines.append("")
+    text = "%%MatrixMarket matrix coordinate real general\r\n% header comment\r\n" + "%d %d %d\r\n" % (m, n, len(keys)) + "\r\n".join(lines)
+    path = str(tmp_path / "untidy.mtx")
+    with open(path, "w", newline="") as f:
+        f.write(text)  # no line end after the last entry
+    tidy = str(tmp_path / "tidy.mtx")
+    with open(tidy, "w") as f:  # what scipy is given: the same entries, conventionally formatted
+        f.write("%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (m, n, len(keys)))
+        for k, v in zip(keys.tolist(), vals.tolist()):
+            f.write("%d %d %r\n" % (k // n + 1, k % n + 1, v))
+    ref = scipy.io.mmread(tidy).tocoo()
+    order = np.argsort(ref.row.astype(np.int64) * n + ref.col)
+    case = dict(name="untidy", M=m, N=n, R=r, rows=ref.row[order].astype(np.int64), cols=ref.col[order].astype(np.int64), vals=ref.data[order],
+                A=O.dense_fill(m, r, 31), B=O.dense_fill(n, r, 32))
+
+    def from_file(w):
+        sp = H.SpmatLocal.load_tuples(w, True, -1, -1, path)
+        assert sp.info()["dist_nnz"] == len(keys) and sp.info()["M"] == m and sp.info()["N"] == n
+        return sp
+
+    per_rank = H.run_spmd(4, lambda w: T.run_all_ops(w, "15d_fusion2", 1, case, make_spmat=from_file))
+    T.check_against_oracle(T.assemble(per_rank, case), case, "15d_fusion2")
