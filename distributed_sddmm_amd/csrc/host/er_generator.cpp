@@ -178,13 +178,21 @@ void parse_matrix_market_parts(const std::string& path, uint64_t& m, uint64_t& n
             uint64_t r = 0, c = 0;
             if (!parse_index(p, hi, r) || !parse_index(p, hi, c)) { bad[(size_t)t] = 1; break; }
             double v = 1.0;
+            const void* nl = std::memchr(p, '\n', (size_t)(end - p));
             if (!pattern) {
                 char* q = nullptr;
-                v = std::strtod(p, &q);  // (the mapping ends in a line feed or the file's last number: strtod stops there)
-                if (q == p) { bad[(size_t)t] = 1; break; }
-                p = q;
+                if (nl != nullptr) {  // strtod stops at the line feed at the latest
+                    v = std::strtod(p, &q);
+                    if (q == p) { bad[(size_t)t] = 1; break; }
+                    p = q;
+                } else {  // last line of a file that does not end in a line feed: the mapping is not NUL-terminated
+                    const std::string tail(p, end);
+                    v = std::strtod(tail.c_str(), &q);
+                    if (q == tail.c_str()) { bad[(size_t)t] = 1; break; }
+                    p += q - tail.c_str();
+                }
             }
-            while (p < hi && *p != '\n') p++;  // ignore anything else on the line (complex files are not supported anyway)
+            p = nl != nullptr ? static_cast<const char*>(nl) : hi;  // ignore anything else on the line (complex files are not supported anyway)
             if (r < 1 || r > mm || c < 1 || c > nn) { bad[(size_t)t] = 2; break; }
             out.push_back({r - 1, c - 1, v});
             if (symmetric && r != c) out.push_back({c - 1, r - 1, v});

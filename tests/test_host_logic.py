@@ -67,6 +67,25 @@ def test_matrix_market_reader(tmp_path):
     assert info == {"M": 4, "N": 4, "dist_nnz": 5, "local_nnz": 5}
 
 
+def test_matrix_market_file_that_ends_on_a_page_boundary(tmp_path):
+    """The parser reads a memory mapping: a real-valued file of exactly one (two) pages whose last number is not followed by a
+    line feed must not make the value parser run past the mapping."""
+    head, body = "%%MatrixMarket matrix coordinate real general\n", "3 3 2\n1 1 2.5\n3 2 1e-3"
+    for target in (4096, 8192):
+        text = head + "%" + "x" * (target - len(head) - len(body) - 2) + "\n" + body
+        assert len(text) == target
+        path = tmp_path / ("page_%d.mtx" % target)
+        path.write_text(text)
+
+        def body_fn(w, path=path):
+            sp = H.SpmatLocal.load_tuples(w, True, -1, -1, str(path))
+            info = sp.info()
+            sp.free()
+            return info
+
+        assert H.run_spmd(1, body_fn)[0] == {"M": 3, "N": 3, "dist_nnz": 2, "local_nnz": 2}
+
+
 @pytest.mark.parametrize("dims,adjacency", [((4, 2, 1), 1), ((2, 2, 2), 3), ((2, 3, 2), 2), ((3, 2, 2), 4), ((2, 2, 3), 5), ((1, 4, 3), 6)])
 def test_flexible_grid(dims, adjacency):
     nr, nc, nh = dims
