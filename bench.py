@@ -257,7 +257,7 @@ def run(args, make_world=gpu_world):
         candidates = [("mesh", q) for q in sorted({default_q, 2, 4, 8}, key=lambda q: (q != default_q, q))]  # the built one first
         if args.ring_mode is None:
             candidates.append(("relay", None))
-        built = ("mesh", default_q)
+        built = ("mesh", default_q) if os.environ.get("HNH_RING_MODE", "mesh") == "mesh" else ("relay", None)  # what the operator above is
 
         def rebuild(route):
             nonlocal op, A, B, S, buf, built
