@@ -413,6 +413,10 @@ def run(args, make_world=gpu_world):
                                     if os.environ.get("HNH_RING_MODE", "mesh") == "relay" else
                                     "row_kernel<fused> (hnh_fused_sddmm_spmm_csr / _w): own block, then one windowed pass over the fetched blocks per landed chunk"),
                          "avg_launch_ms": dur * 1e3,
+                         # the counter-side rate (L2 <-> fabric bytes per launch / launch time; Infinity-Cache hits included)
+                         # and the compulsory floor of a call (every dense row and every nonzero touched once)
+                         "traffic_rate": (traffic / dur / 1e9) if (traffic is not None and dur > 0) else None,
+                         "compulsory_bytes_per_call": 8 * args.r * (2 * m + m) + 24 * nnz,
                          "launches_per_step": launches_per_call, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "model": "per fused call nnz*(8R+24) + 16*R*rows (SURVEY 8d), divided evenly over its launches"},
         }
