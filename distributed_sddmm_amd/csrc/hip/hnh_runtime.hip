@@ -34,12 +34,23 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
         const double v = std::atof(pb);
         if (v >= 1.0) ctx->panel_bytes = v;
     }
+    // HNH_COMM_PRIORITY=1: the communication stream gets the highest priority the device offers (its work — RCCL send/recv
+    // kernels — is small and latency-critical, while the compute stream keeps tens of thousands of workgroups queued).
+    // Opt-in: on one GPU shared by 8 logical ranks it makes no measurable difference (profiles/r02_loopback_p8_comm_priority.log)
+    // and no multi-GPU box was available to show that it helps there.
+    int least = 0, greatest = 0;
+    const bool has_priorities = std::getenv("HNH_COMM_PRIORITY") != nullptr &&
+                                hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least;
     for (int s = 0; s < 2; s++) {
-        if (hipStreamCreateWithFlags(&ctx->streams[s], hipStreamNonBlocking) != hipSuccess) {
+        hipError_t e = hipErrorUnknown;
+        if (s == HNH_STREAM_COMM && has_priorities) e = hipStreamCreateWithPriority(&ctx->streams[s], hipStreamNonBlocking, greatest);
+        if (e != hipSuccess) e = hipStreamCreateWithFlags(&ctx->streams[s], hipStreamNonBlocking);
+        if (e != hipSuccess) {
             delete ctx;
             return HNH_ERR_DEVICE;
         }
     }
+    (void)hipGetLastError();  // (a refused priority request above is not this call's error)
     *out = ctx;
     return HNH_OK;
 }
