@@ -45,7 +45,7 @@ public:
         computeQueries(A, B, matrix_to_optimize, result);
         DenseMatrix& x = (matrix_to_optimize == Amat) ? A : B;
         hnh::World* w = d_ops->world;
-        hnh_fused_extras ex = {0.0, 0.0, nullptr, &cg};
+        hnh_fused_extras ex = {0.0, 0.0, nullptr, &cg, nullptr, 0};
         w->check(w->be->hnh_row_epilogue_x(w->ctx, result.data(), x.data(), &ex, x.rows(), (int)x.cols(), HNH_STREAM_COMPUTE), "hnh_row_epilogue_x");
     }
     virtual double computeResidual() = 0;
@@ -219,7 +219,7 @@ public:
         // Schedules with a single fused pass take the + lambda x and the row-wise <x, result> in the same launch and
         // write `result` directly (no `result = x` copy); the 1.5D dense schedule's shifts are empty (.cpp:280,284).
         if (result.rows() != x.rows() || result.cols() != x.cols()) result = DenseMatrix(x.rows(), x.cols());
-        hnh_fused_extras ex = {0.0, lambda, dot ? dot->data() : nullptr, cg};
+        hnh_fused_extras ex = {0.0, lambda, dot ? dot->data() : nullptr, cg, nullptr, 0};
         if (d_ops->fusedSpMM_out(A_in, B_in, matrix_to_optimize, result, false, ex)) return;
 
         // the all-ones S values and the SDDMM scratch vector are the same for every call: keep them

@@ -577,7 +577,7 @@ int hnh_dist_hold_moving_operand(hnh_dist* d, hnh_dense* m) {
 int hnh_dist_fusedSpMM_out(hnh_dist* d, hnh_dense* A, hnh_dense* B, int matmode, hnh_dense* Out, int leaky, double leaky_alpha,
                            double x_scale, hnh_vec* rowdot, int* supported) {
     return guarded(d->w, [&] {
-        hnh_fused_extras ex = {leaky_alpha, x_scale, rowdot ? rowdot->v.data() : nullptr};
+        hnh_fused_extras ex = {leaky_alpha, x_scale, rowdot ? rowdot->v.data() : nullptr, nullptr, nullptr, 0};
         const bool ok = d->d->fusedSpMM_out(A->m, B->m, matmode == HNH_AMAT ? Amat : Bmat, Out->m, leaky != 0, ex);
         if (supported) *supported = ok ? 1 : 0;
     });

@@ -321,7 +321,7 @@ private:
         const int n = p / c;
         const bool epilogue = KernelImplementation::wants_epilogue(extras);
         if (epilogue && target == nullptr) hnh::fatal("Error, a row epilogue needs the input rows: use fusedSpMM_out!");
-        hnh_fused_extras act_only = {extras ? extras->leaky_alpha : 0.0, 0.0, nullptr};
+        hnh_fused_extras act_only = {extras ? extras->leaky_alpha : 0.0, 0.0, nullptr, nullptr, nullptr, 0};
         const hnh_fused_extras* act = act_flag ? &act_only : nullptr;
         // c == 1: every output row is finished by this rank's own launches, so the last of them also runs the
         // epilogue; c > 1: the partial outputs are reduce-scattered first
