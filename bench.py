@@ -29,7 +29,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def parse():
+def route_name(route):
+    c, mode, q = route
+    return "c=%d %s" % (c, {"mesh": "mesh/%s chunks" % q, "relay": "relay ring", "none": "replication only"}[mode])
+
+
+def keyed(idx, salt):
+    """Deterministic value in [0.5, 1.5) per global index (multiplicative hash): the operands of the result check."""
+    import numpy as np
+    h = (idx.astype(np.uint64) * np.uint64(2654435761) + np.uint64(salt) * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
+    return 0.5 + h.astype(np.float64) / 4294967296.0
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -38,7 +50,9 @@ def parse():
     ap.add_argument("--edge-factor", type=int, default=96)
     ap.add_argument("--r", type=int, default=128)
     ap.add_argument("--alg", default="15d_fusion2")
-    ap.add_argument("--c", type=int, default=1, help="replication factor of the 1.5D/2.5D schedule")
+    ap.add_argument("--c", type=int, default=None, help="replication factor of the 1.5D/2.5D schedule (the reference's command-line "
+                    "argument, bench_erdos_renyi.cpp:23-28).  Not given: 1 on one GPU; on several GPUs the candidates 1 / 2 / 4 that "
+                    "divide N are MEASURED together with the route (below) and the fastest is timed")
     ap.add_argument("--ring-mode", choices=["mesh", "relay"], default=None,
                     help="route of the 1.5D dense shift's moving operand: mesh = every block straight from its owner (default), "
                          "relay = the reference's neighbour ring (sets HNH_RING_MODE)")
@@ -53,7 +67,11 @@ def parse():
                     "mesh with 2 / 4 / 8 chunks and the relay ring")
     ap.add_argument("--watchdog", type=float, default=240.0, help="seconds a multi-GPU phase may take before the rank reports "
                     "where it is stuck and exits non-zero")
-    return ap.parse_args()
+    ap.add_argument("--nchannels", type=int, default=None, help="several GPUs: pin RCCL's channel count (NCCL_MIN/MAX_NCHANNELS); every "
+                    "channel is a workgroup that competes with the row kernel for CUs and HBM")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="self-launched run (--gpus N without WORLD_SIZE): seconds "
+                    "before the launcher ends its workers and reports the phase each one was in")
+    return ap.parse_args(argv)
 
 
 class Watchdog:
@@ -63,10 +81,25 @@ class Watchdog:
     def __init__(self, rank, seconds, enabled):
         self.rank, self.seconds, self.enabled = rank, seconds, enabled
         self.timer = None
+        self.name = "start-up"
+        # a self-launched run (launch() below) reads these files to say which phase a failed or stuck rank was in
+        d = os.environ.get("HNH_BENCH_STATUS_DIR")
+        self.status = os.path.join(d, "rank%d.phase" % rank) if d else None
+        self.note("start-up")
+
+    def note(self, name):
+        self.name = name
+        if self.status:
+            try:
+                with open(self.status, "w") as f:
+                    f.write(name)
+            except OSError:
+                pass
 
     def phase(self, name, seconds=None):
         import threading
         self.done()
+        self.note(name)
         if not self.enabled:
             return
         limit = seconds or self.seconds
@@ -183,6 +216,8 @@ def run(args, make_world=gpu_world):
         os.environ["HNH_RING_MODE"] = args.ring_mode
     if args.chunks:
         os.environ["HNH_MESH_CHUNKS"] = str(args.chunks)
+    if args.gpus > 1 and getattr(args, "nchannels", None):
+        os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"] = str(args.nchannels)
     import torch  # first: one HIP runtime per process (see distributed_sddmm_amd/_kernels.py)
     from distributed_sddmm_amd import api as H
 
@@ -190,8 +225,8 @@ def run(args, make_world=gpu_world):
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n = args.gpus
-    if world_size != n:
-        raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run); got %d" % (n, n, world_size))
+    if world_size != n:  # main() self-launches when WORLD_SIZE is absent; this is a launcher that disagrees with --gpus
+        raise SystemExit("bench.py --gpus %d was started as rank %d of WORLD_SIZE=%d: the launcher's process count and --gpus disagree" % (n, rank, world_size))
     dist = None
     if n > 1:
         import torch.distributed as dist
@@ -238,58 +273,76 @@ def run(args, make_world=gpu_world):
     sp = H.SpmatLocal.load_tuples(world, False, args.logm, args.edge_factor)
     info = sp.info()
     nnz, m = info["dist_nnz"], info["M"]
-    op = H.DistributedSparse(world, args.alg, sp, args.r, args.c)
+    c_now = args.c or 1
+    op = H.DistributedSparse(world, args.alg, sp, args.r, c_now)
     A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
     S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
     barrier()
     t_setup = time.perf_counter() - t_setup
 
-    # ---- several GPUs, 1.5D dense shift: how the moving operand travels.  The reference relays it round a neighbour ring
-    # (one xGMI link per direction); the default here fetches every block straight from its owner (all links at once) in chunks,
-    # with one windowed kernel pass per landed chunk — how many chunks trades kernel efficiency against fetch/compute overlap
-    # and depends on the xGMI bandwidth actually delivered.  Unless --ring-mode / --chunks fix the route, the candidates are
-    # MEASURED here (1 warm-up + 3 calls each, max over ranks), outside the timed region; the fastest one is what gets timed
-    # and the JSON line records all of them.
+    # ---- several GPUs, 1.5D dense shift: replication factor and route of the moving operand.  The reference takes c on the
+    # command line (bench_erdos_renyi.cpp:23-28) and relays the moving operand round a neighbour ring (one xGMI link per
+    # direction); the default here fetches every block straight from its owner (all links at once) in chunks, with one windowed
+    # kernel pass per landed chunk — how many chunks trades kernel efficiency against fetch/compute overlap, and c trades ring
+    # traffic against replication traffic; both depend on the xGMI bandwidth actually delivered.  Unless --c / --ring-mode /
+    # --chunks fix them, the candidates are MEASURED here (1 warm-up + 3 calls each, max over ranks), outside the timed region;
+    # the fastest one is what gets timed and the JSON line records all of them.
     tuning = None
-    if n > 1 and args.alg == "15d_fusion2" and args.chunks is None and not args.no_tune and n // args.c > 1 and args.ring_mode != "relay":
-        dog.phase("route tuning (mesh chunk counts, relay ring)", max(args.watchdog, 900.0))
+    if n > 1 and args.alg == "15d_fusion2" and not args.no_tune:
         default_q = int(os.environ.get("HNH_MESH_CHUNKS", "4"))
-        candidates = [("mesh", q) for q in sorted({default_q, 2, 4, 8}, key=lambda q: (q != default_q, q))]  # the built one first
-        if args.ring_mode is None:
-            candidates.append(("relay", None))
-        built = ("mesh", default_q) if os.environ.get("HNH_RING_MODE", "mesh") == "mesh" else ("relay", None)  # what the operator above is
+        fixed_mode = os.environ.get("HNH_RING_MODE") if (args.ring_mode or "HNH_RING_MODE" in os.environ) else None
+        cs = [args.c] if args.c else [c for c in (1, 2, 4) if n % c == 0]
+        candidates = []
+        for c in cs:
+            if n // c == 1:  # the whole ring is one rank: nothing shifts, the layers only replicate and reduce
+                candidates.append((c, "none", None))
+                continue
+            if fixed_mode != "relay":
+                qs = [args.chunks] if args.chunks else sorted({default_q, 2, 4} | ({8} if c == 1 else set()), key=lambda q: (q != default_q, q))
+                candidates += [(c, "mesh", q) for q in qs]
+            if fixed_mode != "mesh":
+                candidates.append((c, "relay", None))
+        mode0 = os.environ.get("HNH_RING_MODE", "mesh")
+        built = (c_now, "none", None) if n // c_now == 1 else (c_now, mode0, default_q if mode0 == "mesh" else None)  # the operator above
+        candidates.sort(key=lambda k: k != built)  # the built one first
+        if len(candidates) > 1:
+            dog.phase("route tuning (replication factor, mesh chunk counts, relay ring)", max(args.watchdog, 900.0))
 
-        def rebuild(route):
-            nonlocal op, A, B, S, buf, built
-            if route == built:
-                return
-            for x in (A, B, S, buf):
-                x.free()
-            op.free()
-            os.environ["HNH_RING_MODE"] = route[0]
-            if route[1] is not None:
-                os.environ["HNH_MESH_CHUNKS"] = str(route[1])
-            op = H.DistributedSparse(world, args.alg, sp, args.r, args.c)
-            A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
-            S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
-            built = route
+            def rebuild(route):
+                nonlocal op, A, B, S, buf, built, c_now
+                if route == built:
+                    return
+                for x in (A, B, S, buf):
+                    x.free()
+                op.free()
+                c_now = route[0]
+                if route[1] != "none":
+                    os.environ["HNH_RING_MODE"] = route[1]
+                if route[2] is not None:
+                    os.environ["HNH_MESH_CHUNKS"] = str(route[2])
+                op = H.DistributedSparse(world, args.alg, sp, args.r, c_now)
+                A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
+                S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
+                built = route
 
-        tuning = {}
-        for route in candidates:
-            rebuild(route)
-            op.fusedSpMM(A, B, S, buf, H.AMAT)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(3):
+            tuning = {}
+            for route in candidates:
+                dog.note("route tuning: c=%d %s%s" % (route[0], route[1], "" if route[2] is None else "/%d chunks" % route[2]))
+                rebuild(route)
                 op.fusedSpMM(A, B, S, buf, H.AMAT)
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    op.fusedSpMM(A, B, S, buf, H.AMAT)
+                barrier()
+                t = torch.tensor([(time.perf_counter() - t0) / 3], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                tuning[route] = float(t.item()) * 1e3
+            rebuild(min(tuning, key=tuning.get))  # the same choice on every rank: the times are the all-reduced maxima
+            A.fill(0.001)
             barrier()
-            t = torch.tensor([(time.perf_counter() - t0) / 3], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tuning[route] = float(t.item()) * 1e3
-        rebuild(min(tuning, key=tuning.get))  # the same choice on every rank: the times are the all-reduced maxima
-        A.fill(0.001)
-        barrier()
     sp.free()
+    ring_mode_now = None if (n == 1 or n // c_now == 1) else os.environ.get("HNH_RING_MODE", "mesh")
 
     def step():
         op.fusedSpMM(A, B, S, buf, H.AMAT)
@@ -321,38 +374,52 @@ def run(args, make_world=gpu_world):
     launches_per_call_local = max(1, launches // prof_calls)
     # SURVEY 8(d), per fused call of this rank: per nonzero 8R + 24 bytes, per output row 16R (row operand read + output
     # row written ONCE) — however many launches the implementation uses (it re-reads rows per launch; that is its cost)
-    alg_bytes_per_call = local_nnz * (8 * args.r + 24) + 16 * args.r * op.info()["localArows"] * args.c
+    alg_bytes_per_call = local_nnz * (8 * args.r + 24) + 16 * args.r * op.info()["localArows"] * c_now
     if dist is not None:
         t = torch.tensor([kern_ms, float(launches), float(alg_bytes_per_call)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         kern_ms, launches, alg_bytes_per_call = float(t[0]) / n, int(t[1]) // n, float(t[2]) / n
     barrier()
 
-    # ---- result check at the reported size (outside the timed region): with A = B = 0.001 and S = 1 one fused call has the
-    # closed form A[i, :] = deg(i) * R * 1e-9 (every SDDMM value is R * 1e-6; row i of the SpMM adds deg(i) of them times
-    # 0.001).  deg comes from the host generator (bit-identical draws, independent of every device code path).
+    # ---- result check at the reported size (outside the timed region), with operands keyed by GLOBAL row and column so that a
+    # block that lands in the wrong rows of a landing buffer, comes from the wrong peer or is a stale chunk changes the answer:
+    # A[i,k] = a_i u_k, B[j,k] = b_j v_k (hashes of the global indices), S = 1  =>  sddmm(i,j) = a_i b_j W with W = sum_k u_k v_k
+    # and one fused call leaves  A[i,k] = W a_i v_k sum_{j in row i} b_j^2.  The sum comes from the HOST generator's draws
+    # (bit-identical to the device generator, independent of every device code path) in O(nnz).
     check = None
     if not args.no_check:
         import numpy as np
-        grows, _ = H.generate_er(m, m, m * args.edge_factor, 12345)
-        deg = np.bincount(grows, minlength=m).astype(np.float64)
+        grows, gcols = H.generate_er(m, m, m * args.edge_factor, 12345)
         nnz_host = int(len(grows))
-        del grows
-        A.fill(0.001)
-        B.fill(0.001)
+        a_key, b_key = keyed(np.arange(m), 1), keyed(np.arange(m), 2)
+        u_key, v_key = keyed(np.arange(args.r), 3), keyed(np.arange(args.r), 4)
+        rowsum = np.bincount(grows, weights=b_key[gcols] ** 2, minlength=m)
+        del grows, gcols
+        want_row = float(np.dot(u_key, v_key)) * a_key * rowsum  # times v_k per column
+
+        def keyed_local(mat_mode, row_key, col_key):
+            parts = []
+            for top, left, rc, cc in op.submatrices(mat_mode):
+                blk = np.zeros((rc, cc))
+                keep = int(max(0, min(rc, m - top)))
+                blk[:keep] = row_key[top:top + keep, None] * col_key[None, left:left + cc]
+                parts.append(blk.reshape(-1))
+            return np.concatenate(parts)
+
+        A.upload(keyed_local(H.AMAT, a_key, u_key).reshape(A.shape))
+        B.upload(keyed_local(H.BMAT, b_key, v_key).reshape(B.shape))
         step()
         world.sync()
         got = A.download().reshape(-1)
-        want_scale = args.r * 1e-9
         worst, elems_checked, off = 0.0, 0, 0
         for top, left, rc, cc in op.submatrices(H.AMAT):
             keep = int(max(0, min(rc, m - top)))
             blk = got[off:off + rc * cc].reshape(rc, cc)[:keep]
             off += rc * cc
             if keep:
-                worst = max(worst, float(np.max(np.abs(blk - deg[top:top + keep, None] * want_scale))))
+                worst = max(worst, float(np.max(np.abs(blk - want_row[top:top + keep, None] * v_key[None, left:left + cc]))))
                 elems_checked += keep * cc
-        ref = float(deg.max()) * want_scale
+        ref = float(want_row.max() * v_key.max())
         local_n = float(op.info()["nS"])
         if dist is not None:
             t = torch.tensor([worst], dtype=torch.float64)
@@ -362,7 +429,8 @@ def run(args, make_world=gpu_world):
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             elems_checked, local_n = int(t[0]), float(t[1])
         rows_checked = elems_checked // args.r  # every rank checks the rows (and, under an R split, the columns) it owns
-        check = {"what": "one fresh fusedSpMM from A = B = 0.001, S = 1 against the closed form A[i,:] = deg(i)*R*1e-9, deg from the host generator",
+        check = {"what": "one fresh fusedSpMM from operands keyed by global row and column (A[i,k] = a_i u_k, B[j,k] = b_j v_k, S = 1) against "
+                         "the closed form A[i,k] = (u.v) a_i v_k sum_{j in row i} b_j^2, the sum taken over the host generator's nonzeros",
                  "rel_err": worst / ref, "tolerance": 1e-11, "rows_checked": int(rows_checked),
                  "nnz_operator": int(nnz), "nnz_host_generator": nnz_host, "nnz_in_blocks_all_ranks": int(local_n),
                  "ok": bool(worst / ref <= 1e-11 and nnz_host == nnz and rows_checked == m)}
@@ -392,13 +460,15 @@ def run(args, make_world=gpu_world):
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Erdos-Renyi 2^%d x 2^%d, edge factor %d (%d unique nnz), R=%d, fused SDDMM->SpMM (fusedSpMM, Amat), "
-                                   "%s c=%d on %d x MI355X%s" % (args.logm, args.logm, args.edge_factor, nnz, args.r, args.alg, args.c, n,
+                                   "%s c=%d on %d x MI355X%s" % (args.logm, args.logm, args.edge_factor, nnz, args.r, args.alg, c_now, n,
                                                                 "" if n == 1 else ", RCCL over xGMI (%s)" % (
-                                                                    "neighbour relay ring" if os.environ.get("HNH_RING_MODE", "mesh") == "relay" else "chunked fetch from the owners")),
-                       "nnz": nnz, "M": m, "R": args.r, "algorithm": args.alg, "c": args.c, "transport": "none" if n == 1 else "rccl",
-                       "ring_mode": os.environ.get("HNH_RING_MODE", "mesh") if n > 1 else None,
+                                                                    {"relay": "neighbour relay ring", "mesh": "chunked fetch from the owners",
+                                                                     None: "replication only, nothing shifts"}[ring_mode_now])),
+                       "nnz": nnz, "M": m, "R": args.r, "algorithm": args.alg, "c": c_now, "transport": "none" if n == 1 else "rccl",
+                       "ring_mode": ring_mode_now,
                        "mesh_chunks": ((int(os.environ["HNH_MESH_CHUNKS"]) if "HNH_MESH_CHUNKS" in os.environ else "default")
-                                       if n > 1 and os.environ.get("HNH_RING_MODE", "mesh") == "mesh" else None),
+                                       if ring_mode_now == "mesh" else None),
+                       "rccl_channels": (os.environ.get("NCCL_MAX_NCHANNELS", "default") if n > 1 else None),
                        "setup_s": round(t_setup, 2)},
             # `achieved` is an ALGORITHMIC rate (SURVEY 8d byte model / measured launch time), not DRAM utilisation: part of every
             # launch's gathers is served by the 256 MiB Infinity Cache, which sits behind the counters `traffic` comes from
@@ -410,7 +480,8 @@ def run(args, make_world=gpu_world):
                                            "this command, not collected live)" if traffic is not None else None,
                          "kernel": ("row_kernel<fused> (hnh_fused_sddmm_spmm_csr), one launch per Infinity-Cache panel of B" if n == 1 else
                                     "row_kernel<fused> (hnh_fused_sddmm_spmm_csr): one launch per visiting block of the relay ring"
-                                    if os.environ.get("HNH_RING_MODE", "mesh") == "relay" else
+                                    if ring_mode_now == "relay" else
+                                    "row_kernel<fused> (hnh_fused_sddmm_spmm_csr): the rank's one block (replication only)" if ring_mode_now is None else
                                     "row_kernel<fused> (hnh_fused_sddmm_spmm_csr / _w): own block, then one windowed pass over the fetched blocks per landed chunk"),
                          "avg_launch_ms": dur * 1e3,
                          # the counter-side rate (L2 <-> fabric bytes per launch / launch time; Infinity-Cache hits included)
@@ -425,8 +496,7 @@ def run(args, make_world=gpu_world):
         if preflight is not None:
             out["preflight"] = {"primitives_ok": sorted(preflight), "communicator_split_order": "identical on all ranks"}
         if tuning is not None:
-            out["config"]["route_tuning_ms_per_step"] = {("mesh/%d chunks" % q if m == "mesh" else "relay ring"): round(v, 4)
-                                                         for (m, q), v in tuning.items()}
+            out["config"]["route_tuning_ms_per_step"] = {route_name(k): round(v, 4) for k, v in tuning.items()}
         if n == 1 and not args.no_cpu_baseline and out["backend"] == "hip-gfx950":
             try:
                 out["cpu_baseline"] = cpu_baseline(args)
@@ -448,9 +518,122 @@ def run(args, make_world=gpu_world):
     return out if rank == 0 else None
 
 
+def error_line(args, message, **extra):
+    """The one JSON line of a run that failed: the contract's keys with value null, plus what went wrong and where."""
+    out = {"metric": "fused SDDMM+SpMM nnz*R/s", "value": None, "unit": "nnz*R/s", "n_gpus": args.gpus, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic", "config": {"workload": "Erdos-Renyi 2^%d, edge factor %d, R=%d, %s on %d x MI355X" % (
+               args.logm, args.edge_factor, args.r, args.alg, args.gpus)}, "error": message}
+    out.update(extra)
+    return out
+
+
+def launch(args, argv):
+    """`python bench.py --gpus N` typed as is (no WORLD_SIZE in the environment): start the N workers ourselves — one process
+    per GPU, rendezvous on 127.0.0.1 at a free port, the same environment torch.distributed.run would give them — forward
+    rank 0's JSON line, and return the worst exit code.  Whatever happens ONE JSON line is printed: a rank that fails or
+    hangs is named together with the phase it was in (the workers keep that in a status file), the others are ended."""
+    import shutil
+    import socket
+    import subprocess
+    import tempfile
+    import threading
+    n = args.gpus
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    status_dir = tempfile.mkdtemp(prefix="hnh_bench_")
+    worker = os.environ.get("HNH_BENCH_WORKER") or os.path.abspath(__file__)  # tests substitute a worker with a CPU transport
+    procs, lines, pumps = [], [], []
+
+    def pump(stream, rank):
+        for ln in stream:
+            if rank == 0 and ln.lstrip().startswith("{") and '"metric"' in ln:
+                lines.append(ln.strip())
+            else:
+                sys.stderr.write(ln if rank == 0 else "[rank %d] %s" % (rank, ln))
+                sys.stderr.flush()
+
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HNH_BENCH_STATUS_DIR=status_dir)
+        p = subprocess.Popen([sys.executable, worker] + list(argv), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        procs.append(p)
+        t = threading.Thread(target=pump, args=(p.stdout, r), daemon=True)
+        t.start()
+        pumps.append(t)
+
+    def phase_of(r):
+        try:
+            with open(os.path.join(status_dir, "rank%d.phase" % r)) as f:
+                return f.read().strip() or "start-up"
+        except OSError:
+            return "start-up (before the benchmark body)"
+
+    deadline = time.monotonic() + args.launch_timeout
+    first_bad, grace, timed_out = None, None, False
+    while any(p.poll() is None for p in procs):
+        now = time.monotonic()
+        for r, p in enumerate(procs):
+            if first_bad is None and p.poll() not in (None, 0):
+                first_bad, grace = (r, p.returncode, phase_of(r)), now + 20.0  # the others get a moment to report, then are ended
+        if (grace is not None and now > grace) or now > deadline:
+            timed_out = now > deadline and first_bad is None
+            for p in procs:  # exactly the processes started above
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    for t in pumps:
+        t.join(timeout=5)
+    codes = [p.returncode for p in procs]
+    phases = {str(r): phase_of(r) for r in range(n)}
+    if first_bad is None and not timed_out:  # everybody had ended between two polls
+        bad = [r for r, c in enumerate(codes) if c != 0]
+        if bad:
+            first_bad = (bad[0], codes[bad[0]], phases[str(bad[0])])
+    shutil.rmtree(status_dir, ignore_errors=True)
+    worst = max((abs(c) if c is not None else 1) for c in codes)
+    if timed_out:
+        print(json.dumps(error_line(args, "no result after %.0f s: the launcher ended its workers" % args.launch_timeout,
+                                    failed_rank=None, phases=phases, exit_codes=codes)), flush=True)
+        return worst or 1
+    if first_bad is None and len(lines) == 1 and worst == 0:
+        print(lines[0], flush=True)
+        return 0
+    if first_bad is not None:
+        r, code, ph = first_bad
+        msg = "rank %d exited with code %s in phase '%s'" % (r, code, ph)
+        # a failed result check still carries a measured line: keep it, marked
+        extra = {"failed_rank": r, "phase": ph, "phases": phases, "exit_codes": codes}
+        if lines:
+            try:
+                extra["line_of_rank0"] = json.loads(lines[-1])
+            except ValueError:
+                pass
+        print(json.dumps(error_line(args, msg, **extra)), flush=True)
+        return worst or 1
+    print(json.dumps(error_line(args, "the workers ended without a result line (%d lines seen)" % len(lines), failed_rank=None,
+                                phases=phases, exit_codes=codes)), flush=True)
+    return worst or 1
+
+
 def main():
-    args = parse()
-    run(args)
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch(args, argv))
+    try:
+        run(args)
+    except BaseException as e:  # one GPU, or a worker: a failure is still reported as one JSON line by whoever owns stdout
+        if int(os.environ.get("RANK", "0")) == 0 and "HNH_BENCH_STATUS_DIR" not in os.environ and not (isinstance(e, SystemExit) and e.code in (0, None)):
+            print(json.dumps(error_line(args, "%s: %s" % (type(e).__name__, str(e)[:500]), failed_rank=0)), flush=True)
+        raise
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()

@@ -23,9 +23,18 @@ def cpu_world(H, dist, rank, n, local_rank):
 
 if __name__ == "__main__":
     n = int(os.environ["WORLD_SIZE"])
-    args = argparse.Namespace(gpus=n, steps=2, warmup=1, logm=10, edge_factor=8, r=16, alg=sys.argv[1], c=int(sys.argv[2]),
+    if len(sys.argv) > 1 and sys.argv[1].startswith("--"):
+        # started by bench.py's own launcher (HNH_BENCH_WORKER points here): bench.py's command line, untouched
+        args = bench.parse(sys.argv[1:])
+        assert args.gpus == n
+        bench.run(args, make_world=cpu_world)  # rank 0 prints the JSON line itself
+        if os.environ.get("BENCH_WORKER_FAIL_RANK") == os.environ["RANK"]:  # the launcher's failure report, exercised
+            sys.exit(7)
+        sys.exit(0)
+    args = argparse.Namespace(gpus=n, steps=2, warmup=1, logm=10, edge_factor=8, r=16, alg=sys.argv[1], c=int(sys.argv[2]) or None,
                               no_cpu_baseline=True, cpu_logm=10, cpu_trials=1, ring_mode=os.environ.get("BENCH_RING_MODE") or None,
-                              chunks=None, no_cpu_full=True, no_check=False, no_preflight=False, no_tune=False, watchdog=120.0)
+                              chunks=None, no_cpu_full=True, no_check=False, no_preflight=False, no_tune=False, watchdog=120.0,
+                              nchannels=None)
     out = bench.run(args, make_world=cpu_world)
     if out is not None:
         print("BENCH_JSON " + json.dumps(out), flush=True)

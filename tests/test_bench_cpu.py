@@ -12,7 +12,8 @@ from test_gloo_world import ROOT, free_port
 
 
 @pytest.mark.parametrize("nranks,alg,c,ring", [(1, "15d_fusion2", 1, None), (2, "15d_fusion2", 1, None), (4, "15d_fusion2", 1, None),
-                                                (4, "15d_fusion2", 2, None), (2, "15d_fusion1", 1, None), (4, "15d_fusion2", 1, "relay"), (2, "15d_fusion2", 1, "mesh")])
+                                                (4, "15d_fusion2", 2, None), (2, "15d_fusion1", 1, None), (4, "15d_fusion2", 1, "relay"), (2, "15d_fusion2", 1, "mesh"),
+                                                (4, "15d_fusion2", 0, None), (2, "15d_fusion2", 0, "relay")])
 def test_bench_contract(nranks, alg, c, ring):
     port = free_port()
     procs = []
@@ -40,19 +41,79 @@ def test_bench_contract(nranks, alg, c, ring):
     chk = out["check"]
     assert chk["ok"] and chk["rel_err"] <= 1e-11 and chk["rows_checked"] == 1 << 10
     assert chk["nnz_operator"] == chk["nnz_host_generator"] == out["config"]["nnz"]
+    assert "keyed by global row and column" in chk["what"]  # a mis-routed block changes this answer (constant operands would not)
     if nranks > 1:  # every transport primitive ran before the timed region, and what was measured is recorded
         assert len(out["preflight"]["primitives_ok"]) == 9
-        tuned = alg == "15d_fusion2" and ring != "relay" and nranks // c > 1
         assert out["config"]["transport"] == "rccl"
+        cs = [c] if c else [k for k in (1, 2, 4) if nranks % k == 0]
+        want = set()
+        for k in cs:  # candidates: replication factor x (mesh fetch in 2 / 4 (/ 8) chunks, relay ring); --ring-mode fixes the route
+            if nranks // k == 1:
+                want.add("c=%d replication only" % k)
+                continue
+            if ring != "relay":
+                want |= {"c=%d mesh/%d chunks" % (k, q) for q in ((2, 4, 8) if k == 1 else (2, 4))}
+            if ring != "mesh":
+                want.add("c=%d relay ring" % k)
+        tuned = alg == "15d_fusion2" and len(want) > 1
         assert ("route_tuning_ms_per_step" in out["config"]) == tuned
-        if tuned:  # the route that was timed is the fastest of the measured candidates (mesh fetch in 2 / 4 / 8 chunks, relay ring)
+        if tuned:  # the configuration that was timed is the fastest of the measured candidates
             t = out["config"]["route_tuning_ms_per_step"]
-            # --ring-mode mesh fixes the route and leaves the chunk count to be measured
-            assert set(t) == {"mesh/2 chunks", "mesh/4 chunks", "mesh/8 chunks"} | (set() if ring == "mesh" else {"relay ring"})
+            assert set(t) == want
             best = min(t, key=t.get)
-            assert out["config"]["ring_mode"] == ("relay" if best == "relay ring" else "mesh")
-            assert out["config"]["mesh_chunks"] == (None if best == "relay ring" else int(best.split("/")[1].split()[0]))
+            bc, broute = best.split(" ", 1)
+            assert out["config"]["c"] == int(bc[2:])
+            assert out["config"]["ring_mode"] == {"relay ring": "relay", "replication only": None}.get(broute, "mesh")
+            assert out["config"]["mesh_chunks"] == (int(broute.split("/")[1].split()[0]) if broute.startswith("mesh") else None)
+            if not c and nranks == 4:
+                assert any(k.startswith("c=2") for k in t) and any(k.startswith("c=4") for k in t)
         else:
-            assert out["config"]["ring_mode"] == (ring or "mesh")
+            assert out["config"]["ring_mode"] == (None if nranks // (c or 1) == 1 else (ring or "mesh"))
     else:
         assert "preflight" not in out
+
+
+def self_launch(extra_env, nranks=2, extra_args=()):
+    env = dict(os.environ, OMP_NUM_THREADS="2", GLOO_SOCKET_IFNAME="lo", **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--steps", "2", "--warmup", "1", "--logm", "10",
+                           "--edge-factor", "8", "--r", "16", "--no-cpu-baseline", *extra_args], env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_launches_its_own_workers():
+    """`python bench.py --gpus 2` as typed (no WORLD_SIZE): bench.py starts one worker per rank itself, forwards rank 0's single
+    JSON line and exits 0.  The workers here are tests/bench_worker.py = bench.run() over gloo with the kernel test double."""
+    res = self_launch({"HNH_BENCH_WORKER": os.path.join(ROOT, "tests", "bench_worker.py")})
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["check"]["ok"] and "error" not in out
+    assert {k.split()[0] for k in out["config"]["route_tuning_ms_per_step"]} == {"c=1", "c=2"}
+
+
+def test_bench_self_launch_reports_a_failing_rank():
+    """A worker that fails: still ONE JSON line, with "error", the rank, the phase it was in and every exit code; non-zero exit."""
+    res = self_launch({"HNH_BENCH_WORKER": os.path.join(ROOT, "tests", "bench_worker.py"), "BENCH_WORKER_FAIL_RANK": "1"}, extra_args=("--no-tune",))
+    assert res.returncode == 7, (res.returncode, res.stderr[-1500:])
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["value"] is None and out["failed_rank"] == 1 and out["exit_codes"] == [0, 7] and "rank 1" in out["error"]
+    assert out["phase"] and set(out["phases"]) == {"0", "1"}
+    assert out["line_of_rank0"]["n_gpus"] == 2  # what rank 0 had measured before the failure is kept, marked as part of an error
+
+
+def test_bench_without_a_gpu_fails_loudly_with_one_line():
+    """The product path (no test worker) on a box without a GPU: no CPU fallback — one JSON line with "error", non-zero exit."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU")
+    res = self_launch({})
+    assert res.returncode != 0
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["value"] is None and "error" in out and out["failed_rank"] in (0, 1) and "transport creation" in out["phase"]
+    assert "no GPU visible" in res.stderr

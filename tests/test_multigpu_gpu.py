@@ -1,0 +1,95 @@
+"""Several GPUs, the product transport: RCCL send/recv groups across processes.  Every test here needs at least two
+visible MI355X and skips on a one-GPU box — except the last one, which checks what `bench.py --gpus 2` does THERE
+(RCCL refuses two ranks on one device: one JSON line with "error", rank and phase, within seconds, no hang)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from test_gloo_world import ROOT, free_port
+
+pytestmark = pytest.mark.gpu
+
+
+def gpus():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def launch(nranks, case, configs, timeout=600):
+    port = free_port()
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   GLOO_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py"), case, configs], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return procs, outs
+
+
+ALL_2 = ("15d_fusion1:1:mesh:4;15d_fusion2:1:mesh:4;15d_fusion2:1:mesh:2;15d_fusion2:1:relay:1;15d_fusion2:2:mesh:4;15d_sparse:1:mesh:4;"
+         "15d_sparse:2:mesh:4;25d_dense_replicate:2:mesh:4;25d_sparse_replicate:2:mesh:4;als@15d_fusion2:1:mesh:4;als@15d_sparse:1:mesh:4")
+ALL_4 = ("15d_fusion2:1:mesh:4;15d_fusion2:1:relay:1;15d_fusion2:2:mesh:2;15d_fusion1:2:mesh:4;15d_sparse:1:mesh:4;25d_dense_replicate:1:mesh:4;"
+         "25d_sparse_replicate:1:mesh:4;als@15d_fusion2:1:mesh:4;als@25d_dense_replicate:1:mesh:4")
+ALL_8 = ("15d_fusion2:1:mesh:4;15d_fusion2:1:mesh:8;15d_fusion2:1:relay:1;15d_fusion2:2:mesh:4;15d_fusion2:4:mesh:2;15d_fusion1:1:mesh:4;"
+         "15d_sparse:2:mesh:4;25d_dense_replicate:2:mesh:4;25d_sparse_replicate:2:mesh:4;als@15d_fusion2:1:mesh:4")
+
+
+@pytest.mark.parametrize("nranks,configs", [(2, ALL_2), (4, ALL_4), (8, ALL_8)])
+def test_schedules_over_rccl(nranks, configs):
+    """All five schedules (relay ring, chunked mesh fetch, replication collectives as explicit-peer groups, ALS with the held
+    operand) on `nranks` GPUs over RCCL, element-wise against the reference's golden vectors, after the transport preflight."""
+    if gpus() < nranks:
+        pytest.skip("needs %d GPUs, this box has %d" % (nranks, gpus()))
+    for case in ("er8_r16", "ragged_r8"):
+        procs, outs = launch(nranks, case, configs)
+        assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+        assert "RCCL_OK" in outs[0], outs[0][-3000:]
+
+
+def run_bench(n, *extra, timeout=900):
+    env = dict(os.environ, GLOO_SOCKET_IFNAME="lo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "HNH_BENCH_WORKER"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1", "--logm", "16",
+                           "--edge-factor", "32", "--no-cpu-baseline", *extra], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_self_launch_on_real_gpus(n):
+    """`python bench.py --gpus N` as typed: spawns its N workers, preflight, measured search over replication factor and
+    route, timed steps, and the row/column-keyed result check — which fails if any block travels to the wrong place."""
+    if gpus() < n:
+        pytest.skip("needs %d GPUs, this box has %d" % (n, gpus()))
+    res = run_bench(n)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and out["backend"] == "hip-gfx950" and out["check"]["ok"] and out["check"]["rows_checked"] == 1 << 16
+    assert len(out["preflight"]["primitives_ok"]) == 9 and out["config"]["transport"] == "rccl"
+    assert {k.split()[0] for k in out["config"]["route_tuning_ms_per_step"]} >= {"c=1", "c=2"}
+
+
+def test_bench_two_ranks_on_one_gpu_ends_with_an_error_line():
+    """One GPU, two ranks: RCCL refuses the second rank on the same device.  The run must END (no hang) with one JSON line
+    naming a rank and the phase (transport creation), and a non-zero exit code."""
+    if gpus() != 1:
+        pytest.skip("this is the one-GPU behaviour")
+    res = run_bench(2, "--watchdog", "60", "--launch-timeout", "150", timeout=240)
+    assert res.returncode != 0
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["value"] is None and "error" in out and out["n_gpus"] == 2
+    assert any("transport creation" in ph or "preflight" in ph for ph in out["phases"].values()), out
