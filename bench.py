@@ -29,6 +29,28 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """stdout carries exactly ONE line, the JSON result: everything else this process writes to file descriptor 1 (the host
+    library mirrors the reference's console messages, e.g. "R-mat generator created ... nonzeros") goes to stderr instead."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (obj if isinstance(obj, str) else json.dumps(obj)) + "\n"
+    if _JSON_FD is None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line.encode())
+
+
 def route_name(route):
     c, mode, q = route
     return "c=%d %s" % (c, {"mesh": "mesh/%s chunks" % q, "relay": "relay ring", "none": "replication only"}[mode])
@@ -67,6 +89,8 @@ def parse(argv=None):
                     "mesh with 2 / 4 / 8 chunks and the relay ring")
     ap.add_argument("--watchdog", type=float, default=240.0, help="seconds a multi-GPU phase may take before the rank reports "
                     "where it is stuck and exits non-zero")
+    ap.add_argument("--no-live-traffic", action="store_true", help="one GPU: do not run the two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE) "
+                    "behind roofline.traffic; the tracked profiles/hbm_traffic.json is quoted instead")
     ap.add_argument("--nchannels", type=int, default=None, help="several GPUs: pin RCCL's channel count (NCCL_MIN/MAX_NCHANNELS); every "
                     "channel is a workgroup that competes with the row kernel for CUs and HBM")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="self-launched run (--gpus N without WORLD_SIZE): seconds "
@@ -176,6 +200,48 @@ def cpu_baseline(args):
     dt = time.perf_counter() - t0
     return {"value": len(rows) * args.r / dt, "unit": "nnz*R/s", "cores": 1, "kind": "port",
             "sample": "numpy restatement, ER 2^14, edge factor %d (%d nnz), R=%d, one fused call" % (args.edge_factor, len(rows), args.r)}
+
+
+def live_traffic(args):
+    """roofline.traffic collected in THIS run: two short rocprofv3 passes of this very command in a child process — FETCH_SIZE
+    and WRITE_SIZE each in its own pass (they do not fit one; a counter pass is never combined with a trace domain) — read from
+    rocprofv3's rocpd database, per launch of the fused row kernel, with the micro-architecture guide's gfx950 correction
+    (FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane reads at 64 bytes: x 2; WRITE_SIZE as reported).  Runs outside
+    the timed region while this process is idle.  None when rocprofv3 is absent, this run is itself being profiled, or a pass fails."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if prof is None or "rocprofiler" in os.environ.get("LD_PRELOAD", "") or "ROCPROFILER_SDK_TOOL_LIBRARIES" in os.environ or "ROCP_TOOL_LIBRARIES" in os.environ:
+        return None
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    means, t0 = {}, time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="hnh_pmc_", dir="/tmp")
+        try:
+            cmd = [prof, "--pmc", counter, "-d", d, "-o", "pass", "--", sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "2",
+                   "--warmup", "1", "--no-cpu-baseline", "--no-check", "--no-live-traffic", "--logm", str(args.logm), "--edge-factor",
+                   str(args.edge_factor), "--r", str(args.r), "--alg", args.alg]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420, check=True)
+            vals = []
+            for db in glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True):
+                cur = sqlite3.connect(db).cursor()
+                vals += [r[0] for r in cur.execute("select value from counters_collection where kernel_name like ? and counter_name = ?",
+                                                   ("%::row_kernel<%", counter))]
+            if not vals:
+                return None
+            means[counter] = (sum(vals) / len(vals), len(vals))
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch_kb, write_kb = means["FETCH_SIZE"][0], means["WRITE_SIZE"][0]
+    return {"bytes_per_launch": 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0, "fetch_size_kb_raw": fetch_kb, "write_size_kb_raw": write_kb,
+            "launches_sampled": means["FETCH_SIZE"][1], "seconds": round(time.perf_counter() - t0, 1)}
 
 
 def gpu_world(H, dist, rank, n, local_rank):
@@ -444,16 +510,27 @@ def run(args, make_world=gpu_world):
         dur = kern_ms / max(1, launches) * 1e-3  # average launch duration, seconds
         bytes_per_launch = alg_bytes_per_call / launches_per_call
         achieved = bytes_per_launch / dur if dur > 0 else 0.0
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tf):
-            try:
-                with open(tf) as f:
-                    rec = json.load(f)
-                if rec.get("workload_key") == "er%d_ef%d_r%d_n%d" % (args.logm, args.edge_factor, args.r, n):
-                    traffic = rec.get("bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_source, live = None, None, None
+        if n == 1 and not args.no_live_traffic and H.backend_name() == "hip-gfx950":
+            live = live_traffic(args)
+        if live is not None:
+            traffic = live["bytes_per_launch"]
+            traffic_source = ("live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this command run by this process (%d launches "
+                              "sampled, %.0f s, outside the timed region); 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of the "
+                              "micro-architecture guide); raw KB: fetch %.0f, write %.0f" % (live["launches_sampled"], live["seconds"],
+                                                                                              live["fetch_size_kb_raw"], live["write_size_kb_raw"]))
+        else:
+            tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(tf):
+                try:
+                    with open(tf) as f:
+                        rec = json.load(f)
+                    if rec.get("workload_key") == "er%d_ef%d_r%d_n%d" % (args.logm, args.edge_factor, args.r, n):
+                        traffic = rec.get("bytes_per_launch")
+                        traffic_source = ("profiles/hbm_traffic.json (static: rocprofv3 FETCH_SIZE/WRITE_SIZE passes of an earlier run of "
+                                          "this command, not collected live)")
+                except Exception:
+                    traffic = None
         out = {
             "backend": H.backend_name(),
             "metric": "fused SDDMM+SpMM nnz*R/s", "value": value, "unit": "nnz*R/s", "n_gpus": n, "steps": args.steps,
@@ -476,8 +553,7 @@ def run(args, make_world=gpu_world):
                                                           "serving scattered dense rows, see DESIGN.md section 3 and profiles/r02_gather_probe*.log",
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "traffic_source": "profiles/hbm_traffic.json (static: rocprofv3 FETCH_SIZE/WRITE_SIZE passes of an earlier run of "
-                                           "this command, not collected live)" if traffic is not None else None,
+                         "traffic_source": traffic_source,
                          "kernel": ("row_kernel<fused> (hnh_fused_sddmm_spmm_csr), one launch per Infinity-Cache panel of B" if n == 1 else
                                     "row_kernel<fused> (hnh_fused_sddmm_spmm_csr): one launch per visiting block of the relay ring"
                                     if ring_mode_now == "relay" else
@@ -503,7 +579,7 @@ def run(args, make_world=gpu_world):
             except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
                 out["cpu_baseline"] = {"value": None, "unit": "nnz*R/s", "cores": os.cpu_count(), "kind": "reference",
                                        "sample": "FAILED: %s" % str(e)[:300]}
-        print(json.dumps(out), flush=True)
+        emit(out)
 
     dog.phase("teardown")
     for x in (A, B, S, buf):
@@ -600,11 +676,11 @@ def launch(args, argv):
     shutil.rmtree(status_dir, ignore_errors=True)
     worst = max((abs(c) if c is not None else 1) for c in codes)
     if timed_out:
-        print(json.dumps(error_line(args, "no result after %.0f s: the launcher ended its workers" % args.launch_timeout,
-                                    failed_rank=None, phases=phases, exit_codes=codes)), flush=True)
+        emit(error_line(args, "no result after %.0f s: the launcher ended its workers" % args.launch_timeout,
+                        failed_rank=None, phases=phases, exit_codes=codes))
         return worst or 1
     if first_bad is None and len(lines) == 1 and worst == 0:
-        print(lines[0], flush=True)
+        emit(lines[0])
         return 0
     if first_bad is not None:
         r, code, ph = first_bad
@@ -616,23 +692,24 @@ def launch(args, argv):
                 extra["line_of_rank0"] = json.loads(lines[-1])
             except ValueError:
                 pass
-        print(json.dumps(error_line(args, msg, **extra)), flush=True)
+        emit(error_line(args, msg, **extra))
         return worst or 1
-    print(json.dumps(error_line(args, "the workers ended without a result line (%d lines seen)" % len(lines), failed_rank=None,
-                                phases=phases, exit_codes=codes)), flush=True)
+    emit(error_line(args, "the workers ended without a result line (%d lines seen)" % len(lines), failed_rank=None,
+                    phases=phases, exit_codes=codes))
     return worst or 1
 
 
 def main():
     argv = sys.argv[1:]
     args = parse(argv)
+    claim_stdout()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch(args, argv))
     try:
         run(args)
     except BaseException as e:  # one GPU, or a worker: a failure is still reported as one JSON line by whoever owns stdout
         if int(os.environ.get("RANK", "0")) == 0 and "HNH_BENCH_STATUS_DIR" not in os.environ and not (isinstance(e, SystemExit) and e.code in (0, None)):
-            print(json.dumps(error_line(args, "%s: %s" % (type(e).__name__, str(e)[:500]), failed_rank=0)), flush=True)
+            emit(error_line(args, "%s: %s" % (type(e).__name__, str(e)[:500]), failed_rank=0))
         raise
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():

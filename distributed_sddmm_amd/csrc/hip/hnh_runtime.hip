@@ -5,7 +5,23 @@
 
 #include "hnh_ctx.hpp"
 
+namespace {
+// one lane spins on the constant-rate (100 MHz) clock; s_sleep keeps it off the issue ports
+__global__ void delay_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace
+
 extern "C" {
+
+int hnh_stream_delay_us(hnh_ctx* ctx, int stream, double microseconds) {
+    HNH_ENTER(ctx, stream);
+    if (!(microseconds > 0.0)) return HNH_OK;
+    if (microseconds > 5.0e6) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_stream_delay_us: more than 5 s");
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, ctx->streams[stream], (unsigned long long)(microseconds * 100.0));
+    return hnh::check_hip(ctx, hipGetLastError(), "delay_kernel");
+}
 
 const char* hnh_backend_name(void) { return "hip-gfx950"; }
 

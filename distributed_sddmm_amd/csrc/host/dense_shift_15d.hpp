@@ -264,9 +264,15 @@ private:
         const bool held = (held_ptr == start->data());
         if (!held && held_slot == slot) held_slot = -1;  // another operand lands here: a held one has to be fetched again
         const bool resident = held && held_slot == slot;
+        // HNH_PACE_LINK_GBPS=<rate>: measurement aid (tools/overlap_probe.py) — a held operand's chunks are already in the landing
+        // buffer, but the communication stream is held for as long as each chunk would take to cross ONE xGMI link at that rate
+        // (chunk q of the n-1 blocks travels over n-1 links at once), without copying anything: the event protocol is then timed
+        // against transfers of a known duration with the rank's kernels alone on the GPU.
+        const double pace_gbps = std::getenv("HNH_PACE_LINK_GBPS") ? std::atof(std::getenv("HNH_PACE_LINK_GBPS")) : 0.0;
         for (int q = 0; q < windows; q++) {
             const int64_t r0 = cut[(size_t)q], w = cut[(size_t)q + 1] - r0;
             const size_t bytes = (size_t)w * (size_t)R * sizeof(double);
+            if (bytes > 0 && resident && pace_gbps > 0.0) world->delay_us((double)bytes / (pace_gbps * 1e3), HNH_STREAM_COMM);
             if (bytes > 0 && !resident) {
                 world->group_begin();
                 for (int k = 1; k < n; k++)  // my block is what ring rank me+k needs at ITS step k; I need the block of me-k at mine

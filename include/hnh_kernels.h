@@ -70,6 +70,10 @@ int hnh_event_record(hnh_ctx* ctx, void* event, int stream);
 int hnh_event_wait(hnh_ctx* ctx, void* event, int stream); /* `stream` waits for `event` (device side) */
 int hnh_event_sync(hnh_ctx* ctx, void* event);            /* host waits for `event`                    */
 int hnh_event_elapsed_ms(hnh_ctx* ctx, void* start, void* stop, float* ms);
+/* Holds `stream` for `microseconds` (one idle-spinning wave on the constant 100 MHz clock: no memory traffic, one CU slot).
+ * Measurement aid: the paced stand-in for an xGMI transfer of known duration when a rank's fetch/compute overlap is
+ * timed on a single GPU (HNH_PACE_LINK_GBPS, tools/overlap_probe.py).  No counterpart in the reference. */
+int hnh_stream_delay_us(hnh_ctx* ctx, int stream, double microseconds);
 
 /* ---- local kernels --------------------------------------------------------------------------------
  * hnh_sddmm_coo — replaces StandardKernel::sddmm_local (sparse_kernels.cpp:13-57), COO view:
