@@ -244,7 +244,7 @@ __device__ __forceinline__ double group_sum(double v) {
 template <bool B>
 struct BoolTag { static constexpr bool value = B; };
 
-template <Op OP, int LPR, int VEC, int W, bool EXACT>
+template <Op OP, int LPR, int VEC, int W, bool EXACT, bool NARROW = false>
 __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool atomic_out, const int32_t* __restrict__ colidx,
                                             double* values, const double* __restrict__ svalues, const double* __restrict__ X,
                                             const double* __restrict__ Y, double* __restrict__ Out, int64_t ld, int col0,
@@ -377,6 +377,195 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
     const BoolTag<true> kFull;
     const BoolTag<false> kMasked;
 
+    if constexpr (NARROW) {
+        // ---- narrow rows (R = 8 / 16 / 32: 16 / 8 / 4 sparse rows share a wave), line-granular CSR streams.
+        // What bounds these widths is the number of 128-byte line requests that reach the fabric (about 55 G lines/s, counters in
+        // profiles/r03_narrow_R16_pmc_by_kernel.txt): every gathered dense row is one such request, and so is every piece of
+        // `colidx` / `values` a group touches — with 256 .. 512 groups per CU each walking its own sparse row, a stream line is
+        // long gone from L1 AND L2 (4 MiB per XCD turn over in about 5 us) when the group's next trip comes back for its second
+        // half, so the loop above fetches every stream line 2 .. 8 times (+26 % requests at R = 16).  Here a group moves through its
+        // row in trips of 16 nonzeros ALIGNED to the 128-byte lines of `values`; it reads the line of 16 values with one group-wide
+        // load (each lane 128 / LPR bytes), the 32 column indices of an aligned 128-byte block once per two trips, and writes the
+        // 16 results of a trip as one line.  Positions of the first / last trip that lie outside [beg, end) gather row 0 of the
+        // dense operand (an L1 hit, no traffic) and are zeroed, so the gathers stay unconditional.  Requires colidx / values to
+        // be 128-byte aligned (checked by the dispatcher).
+        static_assert(VEC == 1 && W == 2 && EXACT && (LPR == 4 || LPR == 8 || LPR == 16), "narrow instances");
+        constexpr int T = 16;           // nonzeros per trip = one line of `values`
+        constexpr int UQ = 4;           // nonzeros per quarter batch (reduced together by the transposed butterfly)
+        constexpr int SUBQ = LPR / UQ;  // lanes holding the same reduced dot product
+        constexpr int IPL = 32 / LPR;   // column indices per lane of a 32-index block (one line of `colidx`)
+        constexpr int VPL = T / LPR > 0 ? T / LPR : 1;  // values per lane of a trip's line (LPR = 16: one)
+        const bool vals_overwrite = fused_op(OP) && (flags & HNH_FUSED_VALUES_OVERWRITE);
+        const bool reads_values = (OP == Op::kSpmm) || !vals_overwrite;
+
+        auto load_block = [&](int b, int (&dst)[IPL]) {  // the aligned block of 32 column indices starting at nonzero b
+            const int32_t* p = colidx + b + lig * IPL;
+            if constexpr (IPL == 8) {
+                const int4 t0 = *reinterpret_cast<const int4*>(p), t1 = *reinterpret_cast<const int4*>(p + 4);
+                dst[0] = t0.x; dst[1] = t0.y; dst[2] = t0.z; dst[3] = t0.w;
+                dst[4] = t1.x; dst[5] = t1.y; dst[6] = t1.z; dst[7] = t1.w;
+            } else if constexpr (IPL == 4) {
+                const int4 t0 = *reinterpret_cast<const int4*>(p);
+                dst[0] = t0.x; dst[1] = t0.y; dst[2] = t0.z; dst[3] = t0.w;
+            } else {
+                const int2 t0 = *reinterpret_cast<const int2*>(p);
+                dst[0] = t0.x; dst[1] = t0.y;
+            }
+        };
+        auto load_line = [&](const double* base, int e0, double (&dst)[VPL]) {  // the aligned line of 16 values starting at nonzero e0
+            const double* p = base + e0 + lig * VPL;
+            if constexpr (VPL == 4) {
+                const double2 t0 = *reinterpret_cast<const double2*>(p), t1 = *reinterpret_cast<const double2*>(p + 2);
+                dst[0] = t0.x; dst[1] = t0.y; dst[2] = t1.x; dst[3] = t1.y;
+            } else if constexpr (VPL == 2) {
+                const double2 t0 = *reinterpret_cast<const double2*>(p);
+                dst[0] = t0.x; dst[1] = t0.y;
+            } else {
+                dst[0] = *p;
+            }
+        };
+        // value of nonzero k (0 .. 15) of the line held in `line`, as seen by every lane of the group (k may differ per lane)
+        auto line_value = [&](const double (&line)[VPL], int k) {
+            double r = 0.0;
+#pragma unroll
+            for (int j = 0; j < VPL; j++) {
+                const double t = __shfl(line[j], k / VPL, LPR);
+                if (k % VPL == j) r = t;
+            }
+            return r;
+        };
+
+        int e0 = beg & ~(T - 1);
+        int blk = e0 & ~31;
+        int ib[IPL], ibn[IPL];
+        double vv[VPL], vvn[VPL], sv[VPL];
+#pragma unroll
+        for (int j = 0; j < IPL; j++) { ib[j] = 0; ibn[j] = 0; }
+#pragma unroll
+        for (int j = 0; j < VPL; j++) { vv[j] = 0.0; vvn[j] = 0.0; sv[j] = 1.0; }
+        if (e0 < end) {
+            load_block(blk, ib);
+            if (blk + 32 < end) load_block(blk + 32, ibn);
+            if (reads_values) load_line(values, e0, vv);
+        }
+        for (; e0 < end; e0 += T) {
+            if (e0 == blk + 32) {  // second trip of the block done: the prefetched block becomes current, the one after it is requested
+                blk += 32;
+#pragma unroll
+                for (int j = 0; j < IPL; j++) ib[j] = ibn[j];
+                if (blk + 32 < end) load_block(blk + 32, ibn);
+            }
+            if (reads_values && e0 + T < end) load_line(values, e0 + T, vvn);  // next trip's values travel with this trip's gathers
+            if (svalues != nullptr) load_line(svalues, e0, sv);
+            const bool part = (e0 < beg) || (e0 + T > end);
+            const int half = (e0 - blk) / IPL;  // first lane holding this trip's half of the index block
+            int c[T];
+#pragma unroll
+            for (int k = 0; k < T; k++) {
+                c[k] = __shfl(ib[k % IPL], half + k / IPL, LPR);
+                if (part && !(e0 + k >= beg && e0 + k < end)) c[k] = 0;
+            }
+            double ya[UQ][1][W], yb[UQ][1][W];
+            double wq[4];  // per quarter: the value to store for nonzero 4 q + lig / SUBQ
+            auto gatherq = [&](int q, double (&y)[UQ][1][W]) {
+#pragma unroll
+                for (int u = 0; u < UQ; u++) {
+                    const uint64_t rowp = g_base + (uint64_t)(unsigned)c[4 * q + u] * ld_bytes;
+                    load_w_global<W>(y[u][0], rowp, lane_off[0]);
+                }
+            };
+            auto computeq = [&](int q, double (&y)[UQ][1][W]) {
+                if (part) {
+#pragma unroll
+                    for (int u = 0; u < UQ; u++) {
+                        const int pos = e0 + 4 * q + u;
+                        if (!(pos >= beg && pos < end)) { y[u][0][0] = 0.0; y[u][0][1] = 0.0; }
+                    }
+                }
+                const int kmine = 4 * q + lig / SUBQ;  // the nonzero whose reduced value this lane ends up holding
+                const bool have = !part || (e0 + kmine >= beg && e0 + kmine < end);
+                double wgt;
+                if constexpr (OP == Op::kSpmm) {
+                    wgt = line_value(vv, kmine);
+                    if (svalues != nullptr) wgt *= line_value(sv, kmine);
+                    if (!have) wgt = 0.0;
+                } else {
+                    double d[UQ];
+#pragma unroll
+                    for (int u = 0; u < UQ; u++) d[u] = fma(x[0][1], y[u][0][1], x[0][0] * y[u][0][0]);
+                    wgt = group_multi_reduce<LPR, UQ>(d, lig);
+                    if (!vals_overwrite) wgt += line_value(vv, kmine);
+                    if (fused_op(OP) && (flags & HNH_FUSED_LEAKY_RELU)) {  // the activated weight is what gets stored
+                        if (svalues != nullptr) wgt *= line_value(sv, kmine);
+                        wgt = wgt > 0.0 ? wgt : ex.leaky_alpha * wgt;
+                        wq[q] = wgt;
+                    } else {
+                        wq[q] = wgt;
+                        if (fused_op(OP) && svalues != nullptr) wgt *= line_value(sv, kmine);
+                    }
+                    if (!have) wgt = 0.0;
+                }
+                if constexpr (OP != Op::kSddmm) {
+#pragma unroll
+                    for (int u = 0; u < UQ; u++) {
+                        const double wu = __shfl(wgt, u * SUBQ, LPR);
+                        acc[0][0] = fma(wu, y[u][0][0], acc[0][0]);
+                        acc[0][1] = fma(wu, y[u][0][1], acc[0][1]);
+                    }
+                    asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]));
+                }
+            };
+            gatherq(0, ya);
+            gatherq(1, yb);
+            __builtin_amdgcn_sched_barrier(0);
+            computeq(0, ya);
+            __builtin_amdgcn_sched_barrier(0);
+            gatherq(2, ya);
+            __builtin_amdgcn_sched_barrier(0);
+            computeq(1, yb);
+            __builtin_amdgcn_sched_barrier(0);
+            gatherq(3, yb);
+            __builtin_amdgcn_sched_barrier(0);
+            computeq(2, ya);
+            computeq(3, yb);
+            if constexpr (OP != Op::kSpmm) {
+                // the trip's 16 results as one line: lane l stores values VPL l .. VPL l + VPL - 1; result k = 4 q + u sits in lanes
+                // [u SUBQ, (u + 1) SUBQ) of wq[q]
+                double outv[VPL];
+#pragma unroll
+                for (int j = 0; j < VPL; j++) {
+                    const int k = lig * VPL + j;
+                    outv[j] = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const double t = __shfl(wq[q], (k & 3) * SUBQ, LPR);
+                        if ((k >> 2) == q) outv[j] = t;
+                    }
+                }
+                double* vp = values + e0 + lig * VPL;
+                if (!part) {
+                    if constexpr (VPL == 4) {
+                        *reinterpret_cast<double2*>(vp) = make_double2(outv[0], outv[1]);
+                        *reinterpret_cast<double2*>(vp + 2) = make_double2(outv[2], outv[3]);
+                    } else if constexpr (VPL == 2) {
+                        *reinterpret_cast<double2*>(vp) = make_double2(outv[0], outv[1]);
+                    } else {
+                        *vp = outv[0];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VPL; j++) {
+                        const int pos = e0 + lig * VPL + j;
+                        if (pos >= beg && pos < end) vp[j] = outv[j];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < VPL; j++) vv[j] = vvn[j];
+        }
+    }
+
+    if constexpr (!NARROW) {
     int e = beg;
     if constexpr (PIPE) {
         // Four half batches A, B, C, D per trip through two register buffers: gathers of B fly while A is computed, C's
@@ -462,6 +651,7 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
             compute(kMasked, e, y);
         }
     }
+    }  // !NARROW
 
     if constexpr (OP != Op::kSddmm) {
         if (fused_op(OP) && (flags & kInternalEpilogue) && !atomic_out) {  // the row is complete in this launch
@@ -545,7 +735,7 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
 #ifndef HNH_ROW_WAVES
 #define HNH_ROW_WAVES 1  // waves per SIMD the row kernels are compiled for (register budget 512 / waves)
 #endif
-template <Op OP, int LPR, int VEC, int W, bool EXACT>
+template <Op OP, int LPR, int VEC, int W, bool EXACT, bool NARROW = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HNH_ROW_WAVES, 8))) void row_kernel(int64_t rows, const int32_t* __restrict__ rowptr,
                                                      const int32_t* __restrict__ beg_ptr, const int32_t* __restrict__ end_ptr,
                                                      const int32_t* __restrict__ colidx, double* values,
@@ -579,7 +769,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HNH_ROW_
         }
     }
     if (OP == Op::kSddmm && beg == end) return;
-    process_row<OP, LPR, VEC, W, EXACT>(row, beg, end, false, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, lig, ex);
+    process_row<OP, LPR, VEC, W, EXACT, NARROW>(row, beg, end, false, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, lig, ex);
 }
 
 // Infinity-Cache panels.  A launch that gathers from ALL rows of the dense operand revisits them at random across a
@@ -652,7 +842,7 @@ __global__ __launch_bounds__(kBlock) void window_values_kernel(int64_t rows, con
 }
 
 // One work item = kLongSeg consecutive nonzeros of a long row; items are listed by build_long_list_kernel.
-template <Op OP, int LPR, int VEC, int W, bool EXACT>
+template <Op OP, int LPR, int VEC, int W, bool EXACT, bool NARROW = false>
 __global__ __launch_bounds__(kBlock) void long_row_kernel(const int2* __restrict__ items, const int* __restrict__ item_count,
                                                           int capacity, const int32_t* __restrict__ rowptr,
                                                           const int32_t* __restrict__ colidx, double* values,
@@ -673,7 +863,7 @@ __global__ __launch_bounds__(kBlock) void long_row_kernel(const int2* __restrict
         const int beg = rbeg + item.y * kLongSeg;
         const int end = (beg + kLongSeg < rend) ? beg + kLongSeg : rend;
         double* part_row = (partials != nullptr && it < partial_items) ? partials + (int64_t)it * ld : nullptr;
-        process_row<OP, LPR, VEC, W, EXACT>(row, beg, end, true, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, lig, ex, part_row);
+        process_row<OP, LPR, VEC, W, EXACT, NARROW>(row, beg, end, true, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, lig, ex, part_row);
     }
 }
 
@@ -1226,6 +1416,7 @@ struct Shape {
 };
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+bool aligned128(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 127u) == 0; }
 
 Shape pick_shape(int R, bool vec_ok) {
     Shape s;
@@ -1341,7 +1532,7 @@ int prepare_long(hnh_ctx* ctx, hipStream_t st, int sidx, int64_t rows, const int
     return hnh::check_hip(ctx, hipGetLastError(), "build_long_list_kernel launch");
 }
 
-template <Op OP, int LPR, int VEC, int W, bool EXACT>
+template <Op OP, int LPR, int VEC, int W, bool EXACT, bool NARROW = false>
 int launch_row(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, int64_t rows, const int32_t* rowptr, const int32_t* beg_ptr,
                const int32_t* end_ptr, const int32_t* colidx, double* values, const double* svalues, const double* X, const double* Y,
                double* Out, int64_t ld, int col0, int ncols, unsigned flags, const Extras& ex, bool run_long = true) {
@@ -1352,16 +1543,16 @@ int launch_row(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, int64_t rows, co
     if (lc.enabled) flags |= kInternalSplitLong | ((unsigned)(lc.threshold / 64) << kLongRowShift);
     const size_t lds_pad = lc.lds_pad;
     if (lds_pad > 48 * 1024)  // (only the measurement knob asks for that much)
-        HNH_TRY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&row_kernel<OP, LPR, VEC, W, EXACT>),
+        HNH_TRY_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&row_kernel<OP, LPR, VEC, W, EXACT, NARROW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pad));
-    hipLaunchKernelGGL((row_kernel<OP, LPR, VEC, W, EXACT>), dim3((unsigned)blocks), dim3(kBlock), lds_pad, st, rows, rowptr, beg_ptr, end_ptr,
+    hipLaunchKernelGGL((row_kernel<OP, LPR, VEC, W, EXACT, NARROW>), dim3((unsigned)blocks), dim3(kBlock), lds_pad, st, rows, rowptr, beg_ptr, end_ptr,
                        colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, ex);
     if (int rc = hnh::check_hip(ctx, hipGetLastError(), "row_kernel launch")) return rc;
     if constexpr (OP != Op::kFusedCg) {  // (a pass with hub rows never runs its epilogue inside the launch)
         if (lc.enabled && run_long) {  // hub rows once per pass (after the last column panel), over their whole length
             // 256 CUs x 4 resident workgroups; items are spread round-robin over all groups of the grid
             double* partials = (OP != Op::kSddmm) ? lc.partials : nullptr;
-            hipLaunchKernelGGL((long_row_kernel<OP, LPR, VEC, W, EXACT>), dim3(1024), dim3(kBlock), 0, st, lc.items, lc.count,
+            hipLaunchKernelGGL((long_row_kernel<OP, LPR, VEC, W, EXACT, NARROW>), dim3(1024), dim3(kBlock), 0, st, lc.items, lc.count,
                                lc.capacity, rowptr, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, ex, partials, lc.partial_items);
             if (int rc = hnh::check_hip(ctx, hipGetLastError(), "long_row_kernel launch")) return rc;
             if (partials != nullptr) {
@@ -1390,6 +1581,15 @@ int launch_shape(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, const Shape& s
     if (s.lpr == L && s.vec == V)                                                                                          \
         return launch_row<OP, L, V, 2, true>(ctx, st, lc, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags, ex, run_long);
     if (s.exact) {
+        // narrow rows with line-aligned CSR streams: the line-granular instances (process_row, NARROW)
+        if (ctx->narrow_rows && (s.lpr == 4 || s.lpr == 8 || s.lpr == 16) && s.vec == 1 && aligned128(colidx) && aligned128(values) &&
+            (svalues == nullptr || aligned128(svalues))) {
+#define HNH_NARROW_CASE(L)                                                                                                 \
+    if (s.lpr == L)                                                                                                        \
+        return launch_row<OP, L, 1, 2, true, true>(ctx, st, lc, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, 0, R, flags, ex, run_long);
+            HNH_NARROW_CASE(4) HNH_NARROW_CASE(8) HNH_NARROW_CASE(16)
+#undef HNH_NARROW_CASE
+        }
         HNH_CASE(1, 1) HNH_CASE(2, 1) HNH_CASE(4, 1) HNH_CASE(8, 1) HNH_CASE(16, 1) HNH_CASE(32, 1) HNH_CASE(64, 1)
         HNH_CASE(64, 2) HNH_CASE(64, 3) HNH_CASE(64, 4) HNH_CASE(32, 3) HNH_CASE(32, 5) HNH_CASE(32, 7)
         return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "no kernel instance for this shape");

@@ -42,6 +42,7 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
         if (v >= 0 && v <= 7) ctx->row_waves_cap = (int)v;
     }
     ctx->panels_with_hubs = std::getenv("HNH_PANELS_WITH_HUBS") != nullptr;
+    if (const char* nr = std::getenv("HNH_NARROW_ROWS")) ctx->narrow_rows = std::atoi(nr) != 0;
     if (const char* lr = std::getenv("HNH_LONG_ROW")) {
         const long v = std::strtol(lr, nullptr, 10);
         if (v >= 64 && v <= 1984) ctx->long_row_override = (int)(v / 64 * 64);

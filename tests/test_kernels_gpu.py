@@ -527,3 +527,69 @@ def test_infinity_cache_panels_do_not_change_results(monkeypatch, R, panel_bytes
     for d in (d_rp, d_c, dv, dX, dY, dOut, ddot):
         d.free()
     c.close()
+
+
+@pytest.mark.parametrize("R", [8, 16, 32])
+@pytest.mark.parametrize("shift", [0, 1, 16])
+def test_narrow_rows_line_granular_streams(ctx, R, shift):
+    """R = 8 / 16 / 32 (16 / 8 / 4 sparse rows per wave) go through the line-granular loop of process_row when colidx / values
+    are 128-byte aligned: trips of 16 nonzeros aligned to the lines of `values`, 32-index blocks, clamped first / last trips.
+    Rows of every length class here — empty, shorter than a trip, straddling lines, several blocks long, hub rows that go to
+    the long-row pass — for SDDMM (accumulating), SpMM (beta = 1), fused (accumulate / overwrite + svalues / LeakyReLU).
+    `shift` elements in front of colidx / values: 0 = aligned (line-granular loop), 1 = only 4- / 8-byte aligned (the general
+    loop must take over), 16 = values line-aligned, colidx only 64-byte aligned (general loop again)."""
+    from distributed_sddmm_amd import _kernels as K
+    lib = ctx.lib
+    rng = np.random.default_rng(100 * R + shift)
+    rows, cols = 157, 3000
+    lens = rng.choice([0, 1, 5, 15, 16, 17, 31, 32, 33, 47, 64, 96, 100, 130, 200], rows)
+    lens[11], lens[90] = 2600, 700  # hub rows (threshold 3 x mean, within [256, 1024])
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cidx = np.concatenate([np.sort(rng.choice(cols, int(n), replace=False)) for n in lens]).astype(np.int32)
+    ridx = np.repeat(np.arange(rows, dtype=np.int32), lens)
+    nnz = len(cidx)
+    X, Y = rng.uniform(-1, 1, (rows, R)), rng.uniform(-1, 1, (cols, R))
+    v0, out0, sv = rng.uniform(-1, 1, nnz), rng.uniform(-1, 1, (rows, R)), rng.uniform(-1, 1, nnz)
+    d_rp, dX, dY = ctx.upload(rowptr), ctx.upload(X), ctx.upload(Y)
+    d_c = ctx.upload(np.concatenate([np.zeros(shift, np.int32), cidx]))
+    dv = ctx.upload(np.concatenate([np.zeros(shift), v0]))
+    dsv = ctx.upload(np.concatenate([np.zeros(shift), sv]))
+    c_ptr, v_ptr, sv_ptr = d_c.ptr + 4 * shift, dv.ptr + 8 * shift, dsv.ptr + 8 * shift
+    mx = int(lens.max())
+
+    def set_v(a):
+        dv.set(np.concatenate([np.zeros(shift), a]))
+
+    def get_v():
+        return dv.get()[shift:]
+
+    for hinted in (False, True):
+        hint = (nnz, mx, cols) if hinted else (-1, -1, -1)
+        set_v(v0)
+        ctx.check(lib.hnh_sddmm_csr_ex(ctx.h, rows, d_rp.ptr, c_ptr, v_ptr, dX.ptr, dY.ptr, R, *hint, 0), "sddmm")
+        assert rel(get_v(), O.sddmm_local(ridx, cidx, v0, X, Y)) <= TOL
+        set_v(v0)
+        dOut = ctx.upload(out0)
+        ctx.check(lib.hnh_spmm_csr_ex(ctx.h, rows, d_rp.ptr, c_ptr, v_ptr, dY.ptr, dOut.ptr, R, *hint, 0), "spmm")
+        assert rel(dOut.get(), O.spmm_local(rowptr, cidx, v0, Y, out0)) <= TOL
+        assert np.array_equal(get_v(), v0)
+        # fused, accumulate semantics
+        vals_after = O.sddmm_local(ridx, cidx, v0, X, Y)
+        dOut.set(out0)
+        ctx.check(lib.hnh_fused_sddmm_spmm_csr_ex(ctx.h, rows, d_rp.ptr, c_ptr, v_ptr, None, dX.ptr, dY.ptr, dOut.ptr, R, 0, *hint, 0), "fused")
+        assert rel(get_v(), vals_after) <= TOL
+        assert rel(dOut.get(), O.spmm_local(rowptr, cidx, vals_after, Y, out0)) <= TOL
+        # fused, overwrite + svalues + LeakyReLU (the activated, scaled weight is what is stored)
+        dots = O.sddmm_local(ridx, cidx, np.zeros(nnz), X, Y) * sv
+        act = np.where(dots > 0, dots, 0.3 * dots)
+        set_v(v0); dOut.set(out0)
+        ex = K.FusedExtras(0.3, 0.0, None)
+        ctx.check(lib.hnh_fused_sddmm_spmm_csr_x(ctx.h, rows, d_rp.ptr, c_ptr, v_ptr, sv_ptr, dX.ptr, dY.ptr, dOut.ptr, R,
+                                                 K.FUSED_VALUES_OVERWRITE | K.FUSED_OUT_OVERWRITE | K.FUSED_LEAKY_RELU, *hint, C.byref(ex), 0), "fused x")
+        assert rel(get_v(), act) <= TOL
+        assert rel(dOut.get(), O.spmm_local(rowptr, cidx, act, Y, np.zeros((rows, R)))) <= TOL
+        dOut.free()
+    # nothing in front of the arrays was touched
+    assert np.all(d_c.get()[:shift] == 0) and np.all(dv.get()[:shift] == 0)
+    for d in (d_rp, d_c, dX, dY, dv, dsv):
+        d.free()

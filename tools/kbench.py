@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--rmat", action="store_true", help="skewed R-MAT graph instead of Erdos-Renyi")
     ap.add_argument("--panels", action="store_true", help="pass the hints (nnz, longest row, cols) so that the library may "
                     "run the pass as Infinity-Cache panels")
+    ap.add_argument("--sort-rows", action="store_true", help="experiment: reorder the sparse rows by length (rows of one wave then have "
+                    "equal trip counts) — isolates the intra-wave imbalance of the narrow-row kernels")
     a = ap.parse_args()
     t0 = time.time()
     if a.rmat:
@@ -33,7 +35,17 @@ def main():
         rows_i, cols_i = H.generate_er(1 << a.logm, 1 << a.logm, (1 << a.logm) * a.ef)
     m = 1 << a.logm
     nnz = len(rows_i)
-    rowptr = np.concatenate(([0], np.cumsum(np.bincount(rows_i, minlength=m)))).astype(np.int32)
+    deg = np.bincount(rows_i, minlength=m)
+    if a.sort_rows:
+        order = np.argsort(deg, kind="stable")          # new row k = old row order[k]
+        old_ptr = np.concatenate(([0], np.cumsum(deg)))
+        deg = deg[order]
+        src = np.concatenate([np.arange(old_ptr[r], old_ptr[r + 1]) for r in order]) if m <= (1 << 12) else None
+        if src is None:  # vectorised gather of the row pieces
+            new_ptr = np.concatenate(([0], np.cumsum(deg)))
+            src = np.repeat(old_ptr[order] - new_ptr[:-1], deg) + np.arange(nnz)
+        cols_i = cols_i[src]
+    rowptr = np.concatenate(([0], np.cumsum(deg))).astype(np.int32)
     print("generated nnz=%d in %.1fs" % (nnz, time.time() - t0), flush=True)
     ctx = K.Ctx(0)
     lib = ctx.lib
