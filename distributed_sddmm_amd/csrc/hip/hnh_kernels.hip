@@ -271,7 +271,14 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
 #pragma unroll
         for (int w = 0; w < W; w++) { x[v][w] = 0.0; acc[v][w] = 0.0; }
         if (act[v]) {
-            if constexpr (OP != Op::kSpmm) load_w_stream<W>(x[v], X + row * ld + coff[v]);
+            if constexpr (OP == Op::kFusedCg) {
+                // with the CG updates the row operand IS cg_p, which the epilogue rewrites: read it through that (unrestricted)
+                // pointer, so that no access of this launch goes through the __restrict__ alias X of memory it stores to
+                const double* xsrc = (ex.cg_x != nullptr) ? ex.cg_p : X;
+                load_w_stream<W>(x[v], xsrc + row * ld + coff[v]);
+            } else if constexpr (OP != Op::kSpmm) {
+                load_w_stream<W>(x[v], X + row * ld + coff[v]);
+            }
             if constexpr (OP != Op::kSddmm) {
                 if (!atomic_out && !(flags & HNH_FUSED_OUT_OVERWRITE)) load_w_stream<W>(acc[v], Out + row * ld + coff[v]);
             }
@@ -764,7 +771,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HNH_ROW_
         int full = rowptr[row + 1] - rowptr[row];
         if constexpr (LPR == 64) full = __builtin_amdgcn_readfirstlane(full);
         if (full > long_row_of(flags)) {
-            if (OP != Op::kSddmm && (flags & HNH_FUSED_OUT_OVERWRITE)) end = beg;
+            // (the row's epilogue, if any, runs in reduce_long_kernel once its segments are added up)
+            if (OP != Op::kSddmm && (flags & HNH_FUSED_OUT_OVERWRITE)) { end = beg; flags &= ~kInternalEpilogue; }
             else return;
         }
     }
@@ -867,13 +875,19 @@ __global__ __launch_bounds__(kBlock) void long_row_kernel(const int2* __restrict
     }
 }
 
+template <int LPR, int W>
+__device__ __forceinline__ void row_epilogue_row(double* Out, const double* X, const Extras& ex, int64_t row, int R, int lig);
+
 // Out[row, col0 .. col0 + ncols) += the sum of the row's segments' partial rows in a FIXED order: the deterministic replacement
 // of atomically combined segments.  One workgroup per hub row (a row's segments are consecutive items): wave w adds up the w-th
 // quarter of the segments front to back (8 loads in flight), then wave 0 adds the four quarter sums in wave order.
 template <int W>
 __global__ __launch_bounds__(kBlock) void reduce_long_kernel(const int4* __restrict__ hub_rows, const int* __restrict__ counts, int capacity_rows,
                                                              const double* __restrict__ partials, int partial_items,
-                                                             double* __restrict__ Out, int64_t ld, int col0, int ncols) {
+                                                             double* Out, int64_t ld, int col0, int ncols, const double* X, Extras ex,
+                                                             bool epilogue) {
+    // epilogue: the fused pass's row epilogue (x_scale / rowdot / CG updates / ReLU delivery, see row_epilogue_row) on the hub row
+    // once its segments are added up — the short rows of the block got theirs inside the row kernel (whole rows: ld == R)
     constexpr int WAVES = kBlock / 64;
     __shared__ double quarter[WAVES][64][W];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -933,21 +947,43 @@ __global__ __launch_bounds__(kBlock) void reduce_long_kernel(const int4* __restr
             }
             __syncthreads();
         }
+        if (epilogue && wave == 0) row_epilogue_row<64, W>(Out, X, ex, (int64_t)h.x, (int)ld, lane);  // wave 0 reads back what it stored
     }
 }
 
 __global__ __launch_bounds__(kBlock) void build_long_list_kernel(int64_t rows, const int32_t* __restrict__ rowptr,
                                                                  int2* __restrict__ items, int* __restrict__ item_count,
                                                                  int capacity, int long_row, int4* __restrict__ hub_rows, int capacity_rows) {
+    // one thread per row; a WAVE reserves its hub rows' item and row slots with one atomic each (a skewed graph has tens of
+    // thousands of hub rows: one atomic per row on the same two counters took 0.3 ms per pass on R-MAT 2^20)
     const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (row >= rows) return;
-    const int len = rowptr[row + 1] - rowptr[row];
-    if (len <= long_row) return;
-    const int nseg = (len + kLongSeg - 1) / kLongSeg;
-    const int base = atomicAdd(item_count, nseg);  // item_count[0]: items, [1]: hub rows
+    const int lane = threadIdx.x & 63;
+    int nseg = 0;
+    if (row < rows) {
+        const int len = rowptr[row + 1] - rowptr[row];
+        if (len > long_row) nseg = (len + kLongSeg - 1) / kLongSeg;
+    }
+    const unsigned long long hubs = __ballot(nseg > 0);
+    if (hubs == 0ull) return;
+    int incl = nseg;  // inclusive prefix sum of nseg over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    const int total = __shfl(incl, 63, 64);
+    int base_items = 0, base_rows = 0;
+    if (lane == 0) {
+        base_items = atomicAdd(item_count, total);  // item_count[0]: items, [1]: hub rows
+        base_rows = atomicAdd(item_count + 1, __popcll(hubs));
+    }
+    base_items = __shfl(base_items, 0, 64);
+    base_rows = __shfl(base_rows, 0, 64);
+    if (nseg == 0) return;
+    const int base = base_items + incl - nseg;
     for (int s2 = 0; s2 < nseg; s2++)
         if (base + s2 < capacity) items[base + s2] = make_int2((int)row, s2);
-    const int slot = atomicAdd(item_count + 1, 1);
+    const int slot = base_rows + __popcll(hubs & ((1ull << lane) - 1ull));
     if (slot < capacity_rows) hub_rows[slot] = make_int4((int)row, base, nseg, 0);
 }
 
@@ -1119,11 +1155,7 @@ __global__ __launch_bounds__(kBlock) void rowdot_kernel(const double* __restrict
 // Out[i,:] += x_scale * X[i,:];  rowdot[i] = <X[i,:], Out[i,:]>;  optionally the CG updates of hnh_cg_update — the fused pass's
 // row epilogue as its own launch (rows completed by several launches or by atomically combined hub-row segments)
 template <int LPR, int W>
-__global__ __launch_bounds__(kBlock) void row_epilogue_kernel(double* __restrict__ Out, const double* X, Extras ex, int64_t rows, int R) {
-    constexpr int GROUPS = kBlock / LPR;
-    const int lig = threadIdx.x % LPR;
-    const int64_t row = (int64_t)blockIdx.x * GROUPS + threadIdx.x / LPR;
-    if (row >= rows) return;
+__device__ __forceinline__ void row_epilogue_row(double* Out, const double* X, const Extras& ex, int64_t row, int R, int lig) {
     double* o = Out + row * R;
     const double* xr = X + row * R;
     double s = 0.0;
@@ -1185,6 +1217,15 @@ __global__ __launch_bounds__(kBlock) void row_epilogue_kernel(double* __restrict
         store_w<W>(p_row + c, p);
     }
     if (lig == 0) ex.cg_rsold[row] = rsnew;
+}
+
+template <int LPR, int W>
+__global__ __launch_bounds__(kBlock) void row_epilogue_kernel(double* __restrict__ Out, const double* X, Extras ex, int64_t rows, int R) {
+    constexpr int GROUPS = kBlock / LPR;
+    const int lig = threadIdx.x % LPR;
+    const int64_t row = (int64_t)blockIdx.x * GROUPS + threadIdx.x / LPR;
+    if (row >= rows) return;
+    row_epilogue_row<LPR, W>(Out, X, ex, row, R, lig);
 }
 
 // One CG update (als_conjugate_gradients.cpp:117-127):  X[i,:] += alpha[i] P[i,:];  Rm[i,:] -= alpha[i] MP[i,:];
@@ -1474,8 +1515,9 @@ int long_row_threshold(const hnh_ctx* ctx, int64_t rows, int64_t nnz) {
 // device.  max_row_nnz: the caller's knowledge of the longest row (< 0 = unknown -> the list is always built);
 // nnz: number of nonzeros (< 0 = unknown -> read back from rowptr[rows], one 4-byte synchronous copy).
 // out_pitch: row pitch (in doubles) of the output the segments add to, 0 for SDDMM — sizes the partial-row scratch.
+// build_list = false: the launch only has to SKIP the hub rows (a window that is not the pass's last one) — threshold only.
 int prepare_long(hnh_ctx* ctx, hipStream_t st, int sidx, int64_t rows, const int32_t* rowptr, int64_t nnz, int max_row_nnz,
-                 int64_t out_pitch, LongCtl* lc) {
+                 int64_t out_pitch, LongCtl* lc, bool build_list = true) {
     if (max_row_nnz >= 0 && max_row_nnz <= (ctx->long_row_override > 0 ? ctx->long_row_override : kLongRowMin)) return HNH_OK;
     if (nnz < 0) {
         int last = 0;
@@ -1485,6 +1527,11 @@ int prepare_long(hnh_ctx* ctx, hipStream_t st, int sidx, int64_t rows, const int
     }
     const int threshold = long_row_threshold(ctx, rows, nnz);
     if (nnz <= threshold || (max_row_nnz >= 0 && max_row_nnz <= threshold)) return HNH_OK;
+    if (!build_list) {
+        lc->enabled = true;
+        lc->threshold = threshold;
+        return HNH_OK;
+    }
     const size_t cap = (size_t)(nnz / kLongSeg + nnz / threshold + 16);
     if (ctx->long_cap[sidx] < cap) {
         HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
@@ -1506,7 +1553,13 @@ int prepare_long(hnh_ctx* ctx, hipStream_t st, int sidx, int64_t rows, const int
     // segments finish).  `cap` bounds the number of items whatever the matrix looks like: nnz * pitch / 16 bytes at worst
     // (8 bytes per nonzero at R = 128), allocated once per stream and kept.
     if (out_pitch > 0 && !ctx->hub_atomics) {
-        const size_t need = cap * (size_t)out_pitch * sizeof(double);
+        // `cap` bounds the item count for ANY matrix of this size (the real count is known on the device only), which at wide rows
+        // would be more scratch than the CSR block itself: past kHubScratchBytes the remaining segments combine with atomics
+        // (exact within the parity tolerance, no longer bit-reproducible — 2 GiB hold the segments of 5e8 hub-row nonzeros at R = 128)
+        constexpr size_t kHubScratchBytes = (size_t)2 << 30;
+        size_t items = cap;
+        if (items * (size_t)out_pitch * sizeof(double) > kHubScratchBytes) items = kHubScratchBytes / ((size_t)out_pitch * sizeof(double));
+        const size_t need = items * (size_t)out_pitch * sizeof(double);
         if (ctx->long_partials_bytes[sidx] < need) {
             HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
             if (ctx->long_partials[sidx]) HNH_TRY_HIP(ctx, hipFree(ctx->long_partials[sidx]));
@@ -1516,7 +1569,7 @@ int prepare_long(hnh_ctx* ctx, hipStream_t st, int sidx, int64_t rows, const int
             ctx->long_partials_bytes[sidx] = need;
         }
         lc->partials = static_cast<double*>(ctx->long_partials[sidx]);
-        lc->partial_items = (int)cap;
+        lc->partial_items = (int)items;
     }
     lc->items = static_cast<int2*>(ctx->long_items[sidx]);
     lc->count = ctx->long_count[sidx];
@@ -1548,25 +1601,27 @@ int launch_row(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, int64_t rows, co
     hipLaunchKernelGGL((row_kernel<OP, LPR, VEC, W, EXACT, NARROW>), dim3((unsigned)blocks), dim3(kBlock), lds_pad, st, rows, rowptr, beg_ptr, end_ptr,
                        colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, ex);
     if (int rc = hnh::check_hip(ctx, hipGetLastError(), "row_kernel launch")) return rc;
-    if constexpr (OP != Op::kFusedCg) {  // (a pass with hub rows never runs its epilogue inside the launch)
-        if (lc.enabled && run_long) {  // hub rows once per pass (after the last column panel), over their whole length
-            // 256 CUs x 4 resident workgroups; items are spread round-robin over all groups of the grid
-            double* partials = (OP != Op::kSddmm) ? lc.partials : nullptr;
-            hipLaunchKernelGGL((long_row_kernel<OP, LPR, VEC, W, EXACT, NARROW>), dim3(1024), dim3(kBlock), 0, st, lc.items, lc.count,
-                               lc.capacity, rowptr, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags, ex, partials, lc.partial_items);
-            if (int rc = hnh::check_hip(ctx, hipGetLastError(), "long_row_kernel launch")) return rc;
-            if (partials != nullptr) {
-                const bool pairs = (ld % 2 == 0) && (col0 % 2 == 0) && (ncols % 2 == 0) && aligned16(Out);  // 16-byte accesses
-                if (pairs)
-                    hipLaunchKernelGGL(reduce_long_kernel<2>, dim3(2048), dim3(kBlock), 0, st, lc.hub_rows, lc.count, lc.capacity_rows, partials,
-                                       lc.partial_items, Out, ld, col0, ncols);
-                else
-                    hipLaunchKernelGGL(reduce_long_kernel<1>, dim3(2048), dim3(kBlock), 0, st, lc.hub_rows, lc.count, lc.capacity_rows, partials,
-                                       lc.partial_items, Out, ld, col0, ncols);
-                return hnh::check_hip(ctx, hipGetLastError(), "reduce_long_kernel launch");
-            }
-            return HNH_OK;
+    if (lc.enabled && run_long) {  // hub rows once per pass (after the last column panel), over their whole length
+        // (the segments are plain fused work whatever epilogue the closing launch carries: the kFused instance)
+        constexpr Op LOP = (OP == Op::kFusedCg) ? Op::kFused : OP;
+        // 256 CUs x 4 resident workgroups; items are spread round-robin over all groups of the grid
+        double* partials = (OP != Op::kSddmm) ? lc.partials : nullptr;
+        hipLaunchKernelGGL((long_row_kernel<LOP, LPR, VEC, W, EXACT, NARROW>), dim3(1024), dim3(kBlock), 0, st, lc.items, lc.count,
+                           lc.capacity, rowptr, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags & ~kInternalEpilogue, ex, partials,
+                           lc.partial_items);
+        if (int rc = hnh::check_hip(ctx, hipGetLastError(), "long_row_kernel launch")) return rc;
+        if (partials != nullptr) {
+            const bool pairs = (ld % 2 == 0) && (col0 % 2 == 0) && (ncols % 2 == 0) && aligned16(Out);  // 16-byte accesses
+            const bool epi = fused_op(OP) && (flags & kInternalEpilogue);  // (dispatch_row grants it only for whole rows, W as here)
+            if (pairs)
+                hipLaunchKernelGGL(reduce_long_kernel<2>, dim3(2048), dim3(kBlock), 0, st, lc.hub_rows, lc.count, lc.capacity_rows, partials,
+                                   lc.partial_items, Out, ld, col0, ncols, X, ex, epi);
+            else
+                hipLaunchKernelGGL(reduce_long_kernel<1>, dim3(2048), dim3(kBlock), 0, st, lc.hub_rows, lc.count, lc.capacity_rows, partials,
+                                   lc.partial_items, Out, ld, col0, ncols, X, ex, epi);
+            return hnh::check_hip(ctx, hipGetLastError(), "reduce_long_kernel launch");
         }
+        return HNH_OK;
     }
     return HNH_OK;
 }
@@ -1635,14 +1690,18 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
                  const double* Y, double* Out, int R, unsigned flags, const Extras& ex = Extras(), bool* epilogue_done = nullptr,
                  const hnh_csr_window* win = nullptr) {
     LongCtl lc;
-    if (int rc = prepare_long(ctx, st, sidx, rows, rowptr, nnz, max_row_nnz, (OP != Op::kSddmm) ? (int64_t)R : 0, &lc)) return rc;
+    if (int rc = prepare_long(ctx, st, sidx, rows, rowptr, nnz, max_row_nnz, (OP != Op::kSddmm) ? (int64_t)R : 0, &lc,
+                              win == nullptr || win->last != 0))
+        return rc;
     if (!lc.enabled || ctx->row_waves_cap > 0) lc.lds_pad = row_occupancy_pad(ctx, s, rows, nnz, max_row_nnz);  // (hub rows = a skewed block)
     const bool single_pass = s.exact || R <= 64 * s.w * 4;
-    // the epilogue can ride in the launch that completes the rows when ONE group completes each row: no hub-row segments
-    // adding atomically afterwards, no column tiles (and, for the CG updates, an exact-width instance)
+    // the epilogue can ride in the launches that complete the rows: short rows are completed by ONE group of the row kernel, hub rows
+    // by reduce_long_kernel once their segments' partial rows are added up (not when the segments combine with atomics); no
+    // column tiles (and, for the CG updates, an exact-width instance)
     const bool extra_rows_ok = s.w == 1 || ((ex.cg_x == nullptr || (aligned16(ex.cg_x) && aligned16(ex.cg_r))) &&
                                             (ex.relu_dst == nullptr || (aligned16(ex.relu_dst) && ex.relu_ld % 2 == 0)));  // 16-byte row accesses
-    const bool epilogue_in_launch = !lc.enabled && single_pass && ((ex.cg_x == nullptr && ex.relu_dst == nullptr) || (s.exact && extra_rows_ok));
+    const bool hubs_ok = !lc.enabled || (lc.partials != nullptr && lc.partial_items >= lc.capacity);
+    const bool epilogue_in_launch = hubs_ok && single_pass && ((ex.cg_x == nullptr && ex.relu_dst == nullptr) || (s.exact && extra_rows_ok));
     if (win != nullptr) {
         // a caller-defined window of every row; hub rows stay whole and go to the long-row pass with the pass's last window,
         // which is also where a row epilogue can run inside the launch

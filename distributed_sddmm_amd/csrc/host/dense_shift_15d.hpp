@@ -156,6 +156,10 @@ public:
     }
 
     void setRValue(int R) override {
+        if (R != this->R) {  // buffers of the old width are about to be replaced: nothing stays held
+            held_slot = -1;
+            held_in_ring = false;
+        }
         this->R = R;
         localAcols = R;
         localBcols = R;
@@ -258,7 +262,7 @@ private:
     // it.  Returns true when nothing had to move because a held operand's blocks are still there.
     bool fetch_into_landing(DenseMatrix* start, int slot, int br, const std::vector<int64_t>& cut) {
         const int n = p / c;
-        ensure(landing[slot], (int64_t)(n - 1) * br, R);
+        if (ensure(landing[slot], (int64_t)(n - 1) * br, R) && held_slot == slot) held_slot = -1;  // a fresh buffer holds nobody's blocks
         auto t = phase_begin("Cyclic Shift Time");
         order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // my block is final; earlier readers of the landing buffer are done
         const bool held = (held_ptr == start->data());
@@ -464,15 +468,18 @@ public:
     }
 
 private:
-    static void ensure(DenseMatrix& m, int64_t rows, int64_t cols) {
-        if (m.rows() != rows || m.cols() != cols) m = DenseMatrix(rows, cols);
+    static bool ensure(DenseMatrix& m, int64_t rows, int64_t cols) {  // true when the buffer was (re)allocated: its contents are gone
+        if (m.rows() == rows && m.cols() == cols) return false;
+        m = DenseMatrix(rows, cols);
+        return true;
     }
 
     // n kernel steps over a READ-ONLY moving operand on the neighbour ring: n-1 overlapped shifts, caller's buffer untouched.
     template <typename Step>
     void ring_readonly(DenseMatrix* start, int n, Step&& step) {
         if (n > 1) {
-            for (auto& s : ring_spare) ensure(s, start->rows(), start->cols());
+            for (auto& s : ring_spare)
+                if (ensure(s, start->rows(), start->cols())) held_in_ring = false;  // a fresh spare holds nobody's block
             order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // inputs (and earlier readers of the spares) are done
             if (!(n == 2 && held_ptr == start->data())) held_in_ring = false;  // the spares are about to hold other blocks
         }

@@ -181,6 +181,10 @@ void parse_matrix_market_parts(const std::string& path, uint64_t& m, uint64_t& n
             const void* nl = std::memchr(p, '\n', (size_t)(end - p));
             if (!pattern) {
                 char* q = nullptr;
+                // the value has to be on THIS line: strtod skips leading white space including line feeds, so a line without a
+                // value would silently take the next line's first token (and read past the mapping on a file's last line)
+                while (p < end && (*p == ' ' || *p == '\t')) p++;
+                if (p >= end || *p == '\r' || *p == '\n') { bad[(size_t)t] = 1; break; }
                 if (nl != nullptr) {  // strtod stops at the line feed at the latest
                     v = std::strtod(p, &q);
                     if (q == p) { bad[(size_t)t] = 1; break; }

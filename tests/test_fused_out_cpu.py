@@ -179,3 +179,45 @@ def test_held_operand_survives_other_operands(p, ring, monkeypatch):
     assert T.rel(glob[1], wantC) <= T.TOL
     assert T.rel(glob[2], wantB) <= T.TOL
     assert T.rel(glob[3], wantB) <= T.TOL
+
+
+@pytest.mark.parametrize("p,ring", [(4, "mesh"), (2, "relay")])
+def test_hold_does_not_survive_a_change_of_width(p, ring, monkeypatch):
+    """hold(B); fused(A, B); setRValue(R / 2) with a half-width call; setRValue(R); fused(A, B): the landing buffers (and the relay
+    ring's spares) were re-allocated twice in between — the pooled allocator may hand back the very same addresses — so B's
+    blocks have to travel again although B is still on hold (round-2 advisor finding)."""
+    monkeypatch.setenv("HNH_RING_MODE", ring)
+    case = T.case_inputs("er8_r16")
+    R = case["R"]
+
+    def body(w):
+        sp = H.SpmatLocal.from_global(w, case["M"], case["N"], case["rows"], case["cols"], np.ones(len(case["rows"])))
+        d = H.DistributedSparse(w, "15d_fusion2", sp, R, 1)
+        subA, subB = d.submatrices(H.AMAT), d.submatrices(H.BMAT)
+        A, B = d.like_A_matrix(0.0), d.like_B_matrix(0.0)
+        ones, buf = d.like_S_values(1.0), d.like_S_values(0.0)
+        a0, b0 = T.fill_local(subA, A.shape, case["A"]), T.fill_local(subB, B.shape, case["B"])
+        B.upload(b0)
+        d.hold_moving_operand(B)
+        outs = []
+        A.upload(a0)
+        d.fusedSpMM(A, B, ones, buf, H.AMAT)
+        outs.append(A.download())
+        d.setRValue(R // 2)  # narrower operands: every landing / spare buffer is replaced, and filled with other data
+        A2, B2 = d.like_A_matrix(0.5), d.like_B_matrix(-7.0)
+        d.fusedSpMM(A2, B2, ones, buf, H.AMAT)
+        d.setRValue(R)
+        A.upload(a0)
+        d.fusedSpMM(A, B, ones, buf, H.AMAT)
+        outs.append(A.download())
+        d.hold_moving_operand(None)
+        for h in (A, B, A2, B2, ones, buf):
+            h.free()
+        d.free(); sp.free()
+        return dict(subA=subA, outs=outs)
+
+    per_rank = H.run_spmd(p, body)
+    want, _ = T.fused_out_expected(case, H.AMAT, None, 0.0)
+    for k in range(2):
+        got = T.assemble_dense([dict(subA=o["subA"], x=o["outs"][k]) for o in per_rank], "x", "subA", case["M"], R)
+        assert T.rel(got, want) <= T.TOL, k

@@ -86,6 +86,21 @@ def test_matrix_market_file_that_ends_on_a_page_boundary(tmp_path):
         assert H.run_spmd(1, body_fn)[0] == {"M": 3, "N": 3, "dist_nnz": 2, "local_nnz": 2}
 
 
+@pytest.mark.parametrize("body", ["3 3 2\n1 2\n3 3 5.0\n", "3 3 2\n1 1 2.5\n3 2", "3 3 2\n1 1 2.5\n3 2   \n"])
+def test_matrix_market_line_without_a_value_is_refused(tmp_path, body):
+    """A `real` file with an entry line that has no value: the value parser must not borrow the next line's first token (the
+    entry count would still add up) nor run past the end of the mapping on the file's last line — the file is malformed."""
+    path = tmp_path / "novalue.mtx"
+    path.write_text("%%MatrixMarket matrix coordinate real general\n" + body)
+
+    def body_fn(w):
+        sp = H.SpmatLocal.load_tuples(w, True, -1, -1, str(path))
+        sp.free()
+
+    with pytest.raises(Exception, match="malformed"):
+        H.run_spmd(1, body_fn)
+
+
 @pytest.mark.parametrize("dims,adjacency", [((4, 2, 1), 1), ((2, 2, 2), 3), ((2, 3, 2), 2), ((3, 2, 2), 4), ((2, 2, 3), 5), ((1, 4, 3), 6)])
 def test_flexible_grid(dims, adjacency):
     nr, nc, nh = dims

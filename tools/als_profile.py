@@ -6,7 +6,13 @@ assert H.load_backend(None) == "hip-gfx950"
 w = H.World.single(0)
 logm, ef, r = int(sys.argv[1]) if len(sys.argv) > 1 else 20, 96, 128
 alg = sys.argv[2] if len(sys.argv) > 2 else "15d_fusion2"
-sp = H.SpmatLocal.load_tuples(w, False, logm, ef)
+RMAT = int(os.environ.get("HNH_PROFILE_RMAT_EDGES", "0"))  # > 0: a skewed R-MAT graph with this many edge draws (hub rows) instead of Erdos-Renyi
+if RMAT > 0:
+    rr, cc = H.generate_rmat(logm, RMAT)
+    print("R-MAT 2^%d vertices, %d unique nonzeros, longest row %d" % (logm, len(rr), int(__import__("numpy").bincount(rr).max())))
+    sp = H.SpmatLocal.from_global(w, 1 << logm, 1 << logm, rr, cc, None)
+else:
+    sp = H.SpmatLocal.load_tuples(w, False, logm, ef)
 nnz = sp.info()["dist_nnz"]
 op = H.DistributedSparse(w, alg, sp, r, 1)
 for unfolded in (False, True):

@@ -7,7 +7,13 @@ assert H.load_backend(None) == "hip-gfx950"
 logm = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 algs = [sys.argv[2]] if len(sys.argv) > 2 else ["15d_fusion2", "15d_fusion1"]  # fused head in one launch / the reference's call sequence
 w = H.World.single(0)
-sp = H.SpmatLocal.load_tuples(w, False, logm, 32)
+RMAT = int(os.environ.get("HNH_PROFILE_RMAT_EDGES", "0"))  # > 0: a skewed R-MAT graph with this many edge draws (hub rows) instead of Erdos-Renyi
+if RMAT > 0:
+    rr, cc = H.generate_rmat(logm, RMAT)
+    print("R-MAT 2^%d vertices, %d unique nonzeros, longest row %d" % (logm, len(rr), int(np.bincount(rr).max())))
+    sp = H.SpmatLocal.from_global(w, 1 << logm, 1 << logm, rr, cc, None)
+else:
+    sp = H.SpmatLocal.load_tuples(w, False, logm, 32)
 nnz = sp.info()["dist_nnz"]
 layers = [(256, 256, 4), (1024, 256, 4), (1024, 256, 6)]   # benchmark_dist.cpp:93-95
 for alg in algs:
