@@ -375,7 +375,7 @@ def run(args, make_world=gpu_world):
                 candidates.append((c, "none", None))
                 continue
             if fixed_mode != "relay":
-                qs = [args.chunks] if args.chunks else sorted({default_q, 2, 4} | ({8} if c == 1 else set()), key=lambda q: (q != default_q, q))
+                qs = [args.chunks] if args.chunks else sorted({default_q, 2, 4} | ({3, 8} if c == 1 else set()), key=lambda q: (q != default_q, q))
                 candidates += [(c, "mesh", q) for q in qs]
             if fixed_mode != "mesh":
                 candidates.append((c, "relay", None))
@@ -420,6 +420,7 @@ def run(args, make_world=gpu_world):
             barrier()
     sp.free()
     ring_mode_now = None if (n == 1 or n // c_now == 1) else os.environ.get("HNH_RING_MODE", "mesh")
+    transport_kind = op.json_algorithm_info().get("transport", "?")  # "rccl" in production; tests substitute other transports
 
     def step():
         op.fusedSpMM(A, B, S, buf, H.AMAT)
@@ -549,10 +550,10 @@ def run(args, make_world=gpu_world):
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Erdos-Renyi 2^%d x 2^%d, edge factor %d (%d unique nnz), R=%d, fused SDDMM->SpMM (fusedSpMM, Amat), "
                                    "%s c=%d on %d x MI355X%s" % (args.logm, args.logm, args.edge_factor, nnz, args.r, args.alg, c_now, n,
-                                                                "" if n == 1 else ", RCCL over xGMI (%s)" % (
+                                                                "" if n == 1 else ", %s (%s)" % ("RCCL over xGMI" if transport_kind == "rccl" else "transport: " + transport_kind,
                                                                     {"relay": "neighbour relay ring", "mesh": "chunked fetch from the owners",
                                                                      None: "replication only, nothing shifts"}[ring_mode_now])),
-                       "nnz": nnz, "M": m, "R": args.r, "algorithm": args.alg, "c": c_now, "transport": "none" if n == 1 else "rccl",
+                       "nnz": nnz, "M": m, "R": args.r, "algorithm": args.alg, "c": c_now, "transport": "none" if n == 1 else transport_kind,
                        "ring_mode": ring_mode_now,
                        "mesh_chunks": ((int(os.environ["HNH_MESH_CHUNKS"]) if "HNH_MESH_CHUNKS" in os.environ else "default")
                                        if ring_mode_now == "mesh" else None),

@@ -44,7 +44,7 @@ def test_bench_contract(nranks, alg, c, ring):
     assert "keyed by global row and column" in chk["what"]  # a mis-routed block changes this answer (constant operands would not)
     if nranks > 1:  # every transport primitive ran before the timed region, and what was measured is recorded
         assert len(out["preflight"]["primitives_ok"]) == 9
-        assert out["config"]["transport"] == "rccl"
+        assert out["config"]["transport"] == "callback"  # (the test transport; "rccl" on GPUs)
         cs = [c] if c else [k for k in (1, 2, 4) if nranks % k == 0]
         want = set()
         for k in cs:  # candidates: replication factor x (mesh fetch in 2 / 4 (/ 8) chunks, relay ring); --ring-mode fixes the route
@@ -52,7 +52,7 @@ def test_bench_contract(nranks, alg, c, ring):
                 want.add("c=%d replication only" % k)
                 continue
             if ring != "relay":
-                want |= {"c=%d mesh/%d chunks" % (k, q) for q in ((2, 4, 8) if k == 1 else (2, 4))}
+                want |= {"c=%d mesh/%d chunks" % (k, q) for q in ((2, 3, 4, 8) if k == 1 else (2, 4))}
             if ring != "mesh":
                 want.add("c=%d relay ring" % k)
         tuned = alg == "15d_fusion2" and len(want) > 1

@@ -81,6 +81,30 @@ def test_bench_self_launch_on_real_gpus(n):
     assert {k.split()[0] for k in out["config"]["route_tuning_ms_per_step"]} >= {"c=1", "c=2"}
 
 
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_processes_share_one_gpu(n):
+    """`python bench.py --gpus N` typed as is, N worker PROCESSES on whatever GPU is here (they share it): the HIP kernels,
+    device-resident set-up, preflight, the measured search over replication factor and route, the timed steps and the
+    row/column-keyed result check — everything of a multi-GPU run but RCCL itself (tests/bench_worker_gpu.py stages the
+    transfers through gloo)."""
+    if gpus() < 1:
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, GLOO_SOCKET_IFNAME="lo", HNH_BENCH_WORKER=os.path.join(ROOT, "tests", "bench_worker_gpu.py"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--logm", "14",
+                          "--edge-factor", "16", "--r", "32", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and out["backend"] == "hip-gfx950" and out["config"]["transport"] == "callback"  # (gloo-staged here; "rccl" on a multi-GPU node)
+    assert out["check"]["ok"] and out["check"]["rows_checked"] == 1 << 14 and out["check"]["rel_err"] <= 1e-11
+    tuned = out["config"]["route_tuning_ms_per_step"]
+    assert {k.split()[0] for k in tuned} == {"c=%d" % c for c in (1, 2, 4) if n % c == 0}
+    assert len(out["preflight"]["primitives_ok"]) == 9
+
+
 def test_bench_two_ranks_on_one_gpu_ends_with_an_error_line():
     """One GPU, two ranks: RCCL refuses the second rank on the same device.  The run must END (no hang) with one JSON line
     naming a rank and the phase (transport creation), and a non-zero exit code."""
