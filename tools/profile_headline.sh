@@ -1,6 +1,7 @@
 #!/bin/bash
 # Reproduces the headline evidence under profiles/ on a GPU box (run through gpurun from the repository root):
-#   bench line, rocprofv3 kernel-trace stats, and the two PMC passes (FETCH_SIZE, WRITE_SIZE — each in its own run,
+#   the bench line (which collects its own FETCH_SIZE / WRITE_SIZE passes live), rocprofv3 kernel-trace stats of the same
+#   command, and — as an independent cross-check of the live figure — the two PMC passes run from here (each in its own run,
 #   never combined with a trace domain).  Exports land in gpurun_out/profiles_export/ (copy them into profiles/).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -10,9 +11,9 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python "$R/bench.py" > "$OUT/${TAG}_bench_n1.json" 2> "$OUT/${TAG}_bench_n1.stderr"
 tail -c 600 "$OUT/${TAG}_bench_n1.json"
-rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_stats" -o stats -- python "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE -d "$R/gpurun_out/prof_fetch" -o fetch -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE -d "$R/gpurun_out/prof_write" -o write -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_stats" -o stats -- python "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-live-traffic --no-check > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE -d "$R/gpurun_out/prof_fetch" -o fetch -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic --no-check > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d "$R/gpurun_out/prof_write" -o write -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic --no-check > /dev/null 2>&1
 S=$(find "$R/gpurun_out/prof_stats" -name "*_results.db" | head -1)
 F=$(find "$R/gpurun_out/prof_fetch" -name "*_results.db" | head -1)
 W=$(find "$R/gpurun_out/prof_write" -name "*_results.db" | head -1)
