@@ -93,6 +93,8 @@ def parse(argv=None):
                     "behind roofline.traffic; the tracked profiles/hbm_traffic.json is quoted instead")
     ap.add_argument("--nchannels", type=int, default=None, help="several GPUs: pin RCCL's channel count (NCCL_MIN/MAX_NCHANNELS); every "
                     "channel is a workgroup that competes with the row kernel for CUs and HBM")
+    ap.add_argument("--comm-cus", type=int, default=None, help="several GPUs: set this many compute units aside for the communication stream "
+                    "(HNH_COMM_CUS: the row kernels are masked off them, RCCL's kernels run only there)")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="self-launched run (--gpus N without WORLD_SIZE): seconds "
                     "before the launcher ends its workers and reports the phase each one was in")
     return ap.parse_args(argv)
@@ -293,6 +295,8 @@ def run(args, make_world=gpu_world):
         os.environ["HNH_RING_MODE"] = args.ring_mode
     if args.chunks:
         os.environ["HNH_MESH_CHUNKS"] = str(args.chunks)
+    if args.gpus > 1 and getattr(args, "comm_cus", None):
+        os.environ["HNH_COMM_CUS"] = str(args.comm_cus)
     if args.gpus > 1 and getattr(args, "nchannels", None):
         os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"] = str(args.nchannels)
     import torch  # first: one HIP runtime per process (see distributed_sddmm_amd/_kernels.py)
@@ -558,6 +562,7 @@ def run(args, make_world=gpu_world):
                        "mesh_chunks": ((int(os.environ["HNH_MESH_CHUNKS"]) if "HNH_MESH_CHUNKS" in os.environ else "default")
                                        if ring_mode_now == "mesh" else None),
                        "rccl_channels": (os.environ.get("NCCL_MAX_NCHANNELS", "default") if n > 1 else None),
+                       "comm_cus": (int(os.environ.get("HNH_COMM_CUS", "0")) if n > 1 else None),
                        "setup_s": round(t_setup, 2)},
             # `achieved` is an ALGORITHMIC rate (SURVEY 8d byte model / measured launch time), not DRAM utilisation: part of every
             # launch's gathers is served by the 256 MiB Infinity Cache, which sits behind the counters `traffic` comes from

@@ -37,6 +37,7 @@ SIGNATURES = {
     "hnh_event_sync": (_i32, [_vp, _vp]),
     "hnh_event_elapsed_ms": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float)]),
     "hnh_stream_delay_us": (_i32, [_vp, _i32, C.c_double]),
+    "hnh_stream_paced_copy": (_i32, [_vp, _i32, _vp, _vp, C.c_size_t, _i32, C.c_double, _i32]),
     "hnh_sddmm_coo": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32]),
     "hnh_sddmm_csr": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32]),
     "hnh_spmm_csr": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32]),

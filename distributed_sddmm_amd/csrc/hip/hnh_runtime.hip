@@ -11,9 +11,47 @@ __global__ void delay_kernel(unsigned long long ticks) {
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
+// slice s = blockIdx.x / wgs copies its share of src -> dst + s * slice_bytes in tiles, never ahead of the modelled rate
+__global__ __launch_bounds__(256) void paced_copy_kernel(char* dst, const char* src, size_t slice_bytes, int wgs, unsigned long long ticks) {
+    const int slice = (int)blockIdx.x / wgs, part = (int)blockIdx.x % wgs;
+    const size_t vecs = slice_bytes / 16, per = (vecs + (size_t)wgs - 1) / (size_t)wgs;
+    const size_t lo = per * (size_t)part, hi = lo + per < vecs ? lo + per : vecs;
+    const uint4* s = reinterpret_cast<const uint4*>(src);
+    uint4* d = reinterpret_cast<uint4*>(dst + (size_t)slice * slice_bytes);
+    constexpr size_t kTile = 256 * 8;  // 32 KiB per workgroup and step
+    const size_t tiles = hi > lo ? (hi - lo + kTile - 1) / kTile : 0;
+    const unsigned long long t0 = wall_clock64();
+    for (size_t t = 0; t < tiles; t++) {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const size_t i = lo + t * kTile + (size_t)u * 256 + threadIdx.x;
+            if (i < hi) v[u] = s[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const size_t i = lo + t * kTile + (size_t)u * 256 + threadIdx.x;
+            if (i < hi) d[i] = v[u];
+        }
+        const unsigned long long due = ticks * (t + 1) / tiles;
+        while (wall_clock64() - t0 < due) __builtin_amdgcn_s_sleep(16);
+    }
+}
 }  // namespace
 
 extern "C" {
+
+int hnh_stream_paced_copy(hnh_ctx* ctx, int stream, void* dst_base, const void* src, size_t slice_bytes, int nslices, double microseconds,
+                          int wgs_per_slice) {
+    HNH_ENTER(ctx, stream);
+    if (slice_bytes == 0 || nslices <= 0) return HNH_OK;
+    if (!dst_base || !src || slice_bytes % 16 != 0 || wgs_per_slice < 1 || wgs_per_slice > 64 || nslices > 64 || !(microseconds >= 0.0) ||
+        microseconds > 5.0e6)
+        return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_stream_paced_copy: bad argument");
+    hipLaunchKernelGGL(paced_copy_kernel, dim3((unsigned)(nslices * wgs_per_slice)), dim3(256), 0, ctx->streams[stream], static_cast<char*>(dst_base),
+                       static_cast<const char*>(src), slice_bytes, wgs_per_slice, (unsigned long long)(microseconds * 100.0));
+    return hnh::check_hip(ctx, hipGetLastError(), "paced_copy_kernel");
+}
 
 int hnh_stream_delay_us(hnh_ctx* ctx, int stream, double microseconds) {
     HNH_ENTER(ctx, stream);
@@ -58,9 +96,33 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
     int least = 0, greatest = 0;
     const bool has_priorities = std::getenv("HNH_COMM_PRIORITY") != nullptr &&
                                 hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least;
+    // HNH_COMM_CUS=<n>: n compute units are set aside for the communication stream — the compute stream's kernels are masked off
+    // them (hipExtStreamCreateWithCUMask), the communication stream runs only there.  Why: a transfer workgroup that shares a CU
+    // with 20-odd row-kernel waves gets a wave's share of that CU's memory pipeline (measured with throttled copy workgroups next
+    // to the fused kernel: ~5 GB/s per workgroup, whatever the link could deliver — profiles/r03_overlap_probe_with_copies_*.log),
+    // while the row kernels, bound by the memory side and not by CUs, hardly notice a few CUs less.
+    int comm_cus = 0;
+    if (const char* cc = std::getenv("HNH_COMM_CUS")) comm_cus = std::atoi(cc);
+    hipDeviceProp_t prop;
+    uint32_t mask_compute[16] = {0}, mask_comm[16] = {0};
+    int mask_words = 0;
+    if (comm_cus > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > comm_cus &&
+        prop.multiProcessorCount <= 512) {
+        const int cus = prop.multiProcessorCount;
+        mask_words = (cus + 31) / 32;
+        for (int i = 0; i < cus; i++) {
+            if (i < comm_cus) mask_comm[i / 32] |= 1u << (i % 32);
+            else mask_compute[i / 32] |= 1u << (i % 32);
+        }
+        ctx->comm_cus = comm_cus;
+    }
     for (int s = 0; s < 2; s++) {
         hipError_t e = hipErrorUnknown;
-        if (s == HNH_STREAM_COMM && has_priorities) e = hipStreamCreateWithPriority(&ctx->streams[s], hipStreamNonBlocking, greatest);
+        if (mask_words > 0) {
+            e = hipExtStreamCreateWithCUMask(&ctx->streams[s], (uint32_t)mask_words, s == HNH_STREAM_COMM ? mask_comm : mask_compute);
+            if (e != hipSuccess) ctx->comm_cus = 0;
+        }
+        if (e != hipSuccess && s == HNH_STREAM_COMM && has_priorities) e = hipStreamCreateWithPriority(&ctx->streams[s], hipStreamNonBlocking, greatest);
         if (e != hipSuccess) e = hipStreamCreateWithFlags(&ctx->streams[s], hipStreamNonBlocking);
         if (e != hipSuccess) {
             delete ctx;

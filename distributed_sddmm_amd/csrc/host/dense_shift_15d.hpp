@@ -276,7 +276,19 @@ private:
         for (int q = 0; q < windows; q++) {
             const int64_t r0 = cut[(size_t)q], w = cut[(size_t)q + 1] - r0;
             const size_t bytes = (size_t)w * (size_t)R * sizeof(double);
-            if (bytes > 0 && resident && pace_gbps > 0.0) world->delay_us((double)bytes / (pace_gbps * 1e3), HNH_STREAM_COMM);
+            if (bytes > 0 && resident && pace_gbps > 0.0) {
+                // HNH_PACE_COPY=<workgroups per link>: the paced stand-in also moves the bytes — chunk q of the own block is read once
+                // per peer and written to each peer's place in the landing buffer (a held operand's blocks all have the caller's
+                // contents in this measurement) — so the kernels meet the HBM traffic and the workgroups of a real exchange
+                const int copy_wgs = std::getenv("HNH_PACE_COPY") ? std::atoi(std::getenv("HNH_PACE_COPY")) : 0;
+                const double us = (double)bytes / (pace_gbps * 1e3);
+                if (copy_wgs > 0)
+                    world->check(world->be->hnh_stream_paced_copy(world->ctx, HNH_STREAM_COMM, landing[slot].data() + landing_row(1, q, cut) * R,
+                                                                  start->data() + r0 * R, bytes, n - 1, us, copy_wgs),
+                                 "hnh_stream_paced_copy");
+                else
+                    world->delay_us(us, HNH_STREAM_COMM);
+            }
             if (bytes > 0 && !resident) {
                 world->group_begin();
                 for (int k = 1; k < n; k++)  // my block is what ring rank me+k needs at ITS step k; I need the block of me-k at mine

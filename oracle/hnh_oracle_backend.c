@@ -75,6 +75,11 @@ int hnh_event_destroy(hnh_ctx* c, void* e) { (void)c; free(e); return HNH_OK; }
 int hnh_event_record(hnh_ctx* c, void* e, int s) { (void)c; (void)s; *(double*)e = now_ms(); return HNH_OK; }
 int hnh_event_wait(hnh_ctx* c, void* e, int s) { (void)c; (void)e; (void)s; return HNH_OK; }
 int hnh_event_sync(hnh_ctx* c, void* e) { (void)c; (void)e; return HNH_OK; }
+int hnh_stream_paced_copy(hnh_ctx* c, int stream, void* dst, const void* src, size_t bytes, int n, double us, int wgs) {
+    (void)c; (void)stream; (void)us; (void)wgs;
+    for (int k = 0; k < n; k++) memcpy((char*)dst + (size_t)k * bytes, src, bytes);
+    return HNH_OK;
+}
 int hnh_stream_delay_us(hnh_ctx* c, int stream, double us) { (void)c; (void)stream; (void)us; return HNH_OK; }  /* synchronous double: nothing to pace */
 int hnh_event_elapsed_ms(hnh_ctx* c, void* a, void* b, float* ms) { (void)c; *ms = (float)(*(double*)b - *(double*)a); return HNH_OK; }
 

@@ -37,6 +37,9 @@ ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--backend", default=None, help="kernel library to load (default: the HIP library; tests pass the CPU test double)")
 ap.add_argument("--chunks", default="1,2,4")
 ap.add_argument("--pace", default="40,60,75", help="modelled GB/s per xGMI link and direction")
+ap.add_argument("--copy-wgs", default="0", help="comma list; > 0: the paced stand-in also MOVES the bytes (HNH_PACE_COPY: chunk q of the own block "
+                "read once per peer, written to each peer's place in the landing buffer, by this many throttled workgroups per link), so "
+                "the rank's kernels also meet the HBM traffic (896 MiB in + 896 MiB out per call) and the workgroups of a real exchange")
 a = ap.parse_args()
 
 os.environ.setdefault("HNH_FORCE_WINDOWS", "1")
@@ -98,9 +101,14 @@ def body(w):
 
 print("one rank of p=%d alone on the GPU, ER 2^%d ef %d, R=%d; link rate is a MODEL parameter (paced communication stream, no copies)" %
       (a.p, a.logm, a.ef, a.r), flush=True)
-for q in a.chunks.split(","):
+for q, wgs in [(q, w) for w in a.copy_wgs.split(",") for q in a.chunks.split(",")]:
     os.environ["HNH_MESH_CHUNKS"] = q
     Q = int(q)
+    if int(wgs) > 0:
+        os.environ["HNH_PACE_COPY"] = wgs
+        print("-- the paced transfers also move their bytes: %s throttled workgroups per link --" % wgs, flush=True)
+    else:
+        os.environ.pop("HNH_PACE_COPY", None)
     unpaced, k_all, launches, t_own, t_rem, rows, brows = H.run_spmd(a.p, body)[0]
     block_bytes = brows * a.r * 8
     print("Q=%d: unpaced call %.3f ms (%d launches, %.3f ms of kernels: own block ~%.3f, fetched blocks ~%.3f)" % (Q, unpaced, launches, k_all, t_own, t_rem), flush=True)
