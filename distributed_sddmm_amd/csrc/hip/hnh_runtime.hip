@@ -110,10 +110,18 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
         prop.multiProcessorCount <= 512) {
         const int cus = prop.multiProcessorCount;
         mask_words = (cus + 31) / 32;
-        for (int i = 0; i < cus; i++) {
-            if (i < comm_cus) mask_comm[i / 32] |= 1u << (i % 32);
-            else mask_compute[i / 32] |= 1u << (i % 32);
+        // the reserved CUs are spread over the mask with an odd stride (cus / n + 1), which lands them evenly on the XCDs whether
+        // the mask's bits enumerate the XCDs interleaved or block by block.  Measured at config 2 with 16 / 32 CUs off the compute
+        // stream (profiles/r03_kbench_cus_masked_*.log): fused and SpMM +1 %, the stand-alone SDDMM -5 % (low bits and spread alike)
+        const int stride = cus / comm_cus + 1;
+        for (int k = 0, placed = 0; placed < comm_cus && k < 4 * cus; k++) {
+            const int i = (int)(((long)k * stride) % cus);
+            if (mask_comm[i / 32] & (1u << (i % 32))) continue;
+            mask_comm[i / 32] |= 1u << (i % 32);
+            placed++;
         }
+        for (int i = 0; i < cus; i++)
+            if (!(mask_comm[i / 32] & (1u << (i % 32)))) mask_compute[i / 32] |= 1u << (i % 32);
         ctx->comm_cus = comm_cus;
     }
     for (int s = 0; s < 2; s++) {
