@@ -442,7 +442,7 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
             return r;
         };
 
-        int e0 = beg & ~(T - 1);
+        int e0 = (beg < end) ? (beg & ~(T - 1)) : end;  // (an empty row / window: no trip at all)
         int blk = e0 & ~31;
         int ib[IPL], ibn[IPL];
         double vv[VPL], vvn[VPL], sv[VPL];

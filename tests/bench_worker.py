@@ -27,6 +27,9 @@ if __name__ == "__main__":
         # started by bench.py's own launcher (HNH_BENCH_WORKER points here): bench.py's command line, untouched
         args = bench.parse(sys.argv[1:])
         assert args.gpus == n
+        if os.environ.get("BENCH_WORKER_HANG_RANK") == os.environ["RANK"]:  # a rank that never gets anywhere: the launcher's time limit, exercised
+            import time
+            time.sleep(3600)
         bench.run(args, make_world=cpu_world)  # rank 0 prints the JSON line itself
         if os.environ.get("BENCH_WORKER_FAIL_RANK") == os.environ["RANK"]:  # the launcher's failure report, exercised
             sys.exit(7)

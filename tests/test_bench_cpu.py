@@ -105,6 +105,19 @@ def test_bench_self_launch_reports_a_failing_rank():
     assert out["line_of_rank0"]["n_gpus"] == 2  # what rank 0 had measured before the failure is kept, marked as part of an error
 
 
+def test_bench_self_launch_ends_a_hung_run():
+    """A rank that hangs before it gets anywhere: at --launch-timeout the launcher ends exactly the workers it started and prints
+    ONE JSON line that says where every rank was; non-zero exit."""
+    res = self_launch({"HNH_BENCH_WORKER": os.path.join(ROOT, "tests", "bench_worker.py"), "BENCH_WORKER_HANG_RANK": "1"},
+                      extra_args=("--no-tune", "--launch-timeout", "25", "--watchdog", "15"))
+    assert res.returncode != 0
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout[-1500:]
+    out = json.loads(lines[0])
+    assert out["value"] is None and "error" in out and set(out["phases"]) == {"0", "1"}
+    assert out["phases"]["1"].startswith("start-up")  # the hung rank never reached the benchmark body
+
+
 def test_bench_without_a_gpu_fails_loudly_with_one_line():
     """The product path (no test worker) on a box without a GPU: no CPU fallback — one JSON line with "error", non-zero exit."""
     import torch
