@@ -93,8 +93,9 @@ def parse(argv=None):
                     "behind roofline.traffic; the tracked profiles/hbm_traffic.json is quoted instead")
     ap.add_argument("--nchannels", type=int, default=None, help="several GPUs: pin RCCL's channel count (NCCL_MIN/MAX_NCHANNELS); every "
                     "channel is a workgroup that competes with the row kernel for CUs and HBM")
-    ap.add_argument("--comm-cus", type=int, default=None, help="several GPUs: set this many compute units aside for the communication stream "
-                    "(HNH_COMM_CUS: the row kernels are masked off them, RCCL's kernels run only there)")
+    ap.add_argument("--comm-cus", type=int, default=None, help="compute units masked off the compute stream (HNH_COMM_CUS).  Several GPUs: they "
+                    "are set aside for the communication stream, RCCL's kernels run only there (default 0).  One GPU: not given = 0 and 16 "
+                    "are both measured and the faster is timed")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="self-launched run (--gpus N without WORLD_SIZE): seconds "
                     "before the launcher ends its workers and reports the phase each one was in")
     return ap.parse_args(argv)
@@ -348,6 +349,42 @@ def run(args, make_world=gpu_world):
         world.sync()
         device_sync()
 
+    # ---- one GPU: how many compute units the compute stream uses.  The fused pass is bound by the memory side, not by CUs, and runs
+    # ~1 % FASTER with 8 .. 24 of the 256 CUs masked off its stream (fewer requesters queueing at the fabric;
+    # profiles/r03_kbench_cus_off_x_waves_cap.log).  Measured here, not assumed: unless --comm-cus fixes it, the candidates 0 and 16
+    # are timed (1 warm-up + 3 calls each, outside the timed region) and the faster one is what gets timed; both are recorded.
+    cu_tuning = None
+    if n == 1 and make_world is gpu_world and args.comm_cus is None and not args.no_tune and "HNH_COMM_CUS" not in os.environ:
+        cu_tuning = {}
+        for off in (0, 16):
+            os.environ["HNH_COMM_CUS"] = str(off)
+            if off:
+                world.close()
+                world, device_sync = make_world(H, dist, rank, n, local_rank)
+            sp_t = H.SpmatLocal.load_tuples(world, False, args.logm, args.edge_factor)
+            op_t = H.DistributedSparse(world, args.alg, sp_t, args.r, args.c or 1)
+            sp_t.free()
+            xs = (op_t.like_A_matrix(0.001), op_t.like_B_matrix(0.001), op_t.like_S_values(1.0), op_t.like_S_values(0.0))
+            op_t.fusedSpMM(*xs, H.AMAT)
+            world.sync()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                op_t.fusedSpMM(*xs, H.AMAT)
+            world.sync()
+            cu_tuning[off] = (time.perf_counter() - t0) / 3 * 1e3
+            for x in xs:
+                x.free()
+            op_t.free()
+        best_off = min(cu_tuning, key=cu_tuning.get)
+        if best_off != 16:  # the world in hand was made with 16 CUs off
+            os.environ["HNH_COMM_CUS"] = str(best_off)
+            world.close()
+            world, device_sync = make_world(H, dist, rank, n, local_rank)
+    elif n == 1 and args.comm_cus is not None and "HNH_COMM_CUS" not in os.environ and make_world is gpu_world:
+        os.environ["HNH_COMM_CUS"] = str(args.comm_cus)
+        world.close()
+        world, device_sync = make_world(H, dist, rank, n, local_rank)
+
     # ---- build: same global matrix on every rank count (strong scaling)
     dog.phase("set-up (generator, redistribution, CSR blocks)", max(args.watchdog, 600.0))
     t_setup = time.perf_counter()
@@ -562,7 +599,8 @@ def run(args, make_world=gpu_world):
                        "mesh_chunks": ((int(os.environ["HNH_MESH_CHUNKS"]) if "HNH_MESH_CHUNKS" in os.environ else "default")
                                        if ring_mode_now == "mesh" else None),
                        "rccl_channels": (os.environ.get("NCCL_MAX_NCHANNELS", "default") if n > 1 else None),
-                       "comm_cus": (int(os.environ.get("HNH_COMM_CUS", "0")) if n > 1 else None),
+                       # compute units masked off the compute stream (several GPUs: they run the communication stream)
+                       "comm_cus": int(os.environ.get("HNH_COMM_CUS", "0")),
                        "setup_s": round(t_setup, 2)},
             # `achieved` is an ALGORITHMIC rate (SURVEY 8d byte model / measured launch time), not DRAM utilisation: part of every
             # launch's gathers is served by the 256 MiB Infinity Cache, which sits behind the counters `traffic` comes from
@@ -588,6 +626,8 @@ def run(args, make_world=gpu_world):
             out["check"] = check
         if preflight is not None:
             out["preflight"] = {"primitives_ok": sorted(preflight), "communicator_split_order": "identical on all ranks"}
+        if cu_tuning is not None:
+            out["config"]["cu_tuning_ms_per_step"] = {"%d CUs masked off the compute stream" % k: round(v, 4) for k, v in cu_tuning.items()}
         if tuning is not None:
             out["config"]["route_tuning_ms_per_step"] = {route_name(k): round(v, 4) for k, v in tuning.items()}
         if n == 1 and not args.no_cpu_baseline and out["backend"] == "hip-gfx950":
