@@ -24,6 +24,7 @@ struct hnh_ctx {
     bool no_panels = false;  // HNH_NO_PANELS=1: A/B switch
     int row_waves_cap = -1;  // HNH_ROW_WAVES_CAP=k: 1..7 = at most k waves per SIMD for every row-kernel launch, 0 = never cap; unset = the
                              // library's rule (uniform blocks of certain widths run at 5, see row_occupancy_pad in hnh_kernels.hip)
+    int long_grid = 1024;           // workgroups of the hub-row segment pass (HNH_LONG_GRID, measurement aid)
     int comm_cus = 0;               // HNH_COMM_CUS=<n>: compute units reserved for the communication stream (0 = streams share all CUs)
     bool narrow_rows = true;        // HNH_NARROW_ROWS=0: A/B switch — R = 8 / 16 / 32 through the general row loop instead of the line-granular one
     bool panels_with_hubs = false;  // HNH_PANELS_WITH_HUBS=1: panel the short rows of blocks that also have hub rows

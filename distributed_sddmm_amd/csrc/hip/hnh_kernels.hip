@@ -1606,7 +1606,7 @@ int launch_row(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, int64_t rows, co
         constexpr Op LOP = (OP == Op::kFusedCg) ? Op::kFused : OP;
         // 256 CUs x 4 resident workgroups; items are spread round-robin over all groups of the grid
         double* partials = (OP != Op::kSddmm) ? lc.partials : nullptr;
-        hipLaunchKernelGGL((long_row_kernel<LOP, LPR, VEC, W, EXACT, NARROW>), dim3(1024), dim3(kBlock), 0, st, lc.items, lc.count,
+        hipLaunchKernelGGL((long_row_kernel<LOP, LPR, VEC, W, EXACT, NARROW>), dim3((unsigned)ctx->long_grid), dim3(kBlock), 0, st, lc.items, lc.count,
                            lc.capacity, rowptr, colidx, values, svalues, X, Y, Out, ld, col0, ncols, flags & ~kInternalEpilogue, ex, partials,
                            lc.partial_items);
         if (int rc = hnh::check_hip(ctx, hipGetLastError(), "long_row_kernel launch")) return rc;

@@ -81,6 +81,10 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
     }
     ctx->panels_with_hubs = std::getenv("HNH_PANELS_WITH_HUBS") != nullptr;
     if (const char* nr = std::getenv("HNH_NARROW_ROWS")) ctx->narrow_rows = std::atoi(nr) != 0;
+    if (const char* lg = std::getenv("HNH_LONG_GRID")) {
+        const long v = std::strtol(lg, nullptr, 10);
+        if (v >= 64 && v <= 65536) ctx->long_grid = (int)v;
+    }
     if (const char* lr = std::getenv("HNH_LONG_ROW")) {
         const long v = std::strtol(lr, nullptr, 10);
         if (v >= 64 && v <= 1984) ctx->long_row_override = (int)(v / 64 * 64);
