@@ -15,6 +15,12 @@ SETS=(
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TA_TCP_STATE_READ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"
   "TA_TA_BUSY_sum TD_TD_BUSY_sum TA_BUFFER_WAVEFRONTS_sum TA_FLAT_READ_WAVEFRONTS_sum"
 )
+# PMC_SETS="1 2": only those sets (indices into SETS)
+if [ -n "${PMC_SETS:-}" ]; then
+  PICK=()
+  for k in $PMC_SETS; do PICK+=("${SETS[$k]}"); done
+  SETS=("${PICK[@]}")
+fi
 DBS=()
 i=0
 for s in "${SETS[@]}"; do
