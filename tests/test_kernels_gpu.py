@@ -593,3 +593,28 @@ def test_narrow_rows_line_granular_streams(ctx, R, shift):
     assert np.all(d_c.get()[:shift] == 0) and np.all(dv.get()[:shift] == 0)
     for d in (d_rp, d_c, dX, dY, dv, dsv):
         d.free()
+
+
+def test_stream_delay_and_paced_copy(ctx):
+    """The measurement stand-ins of the overlap probe: hnh_stream_delay_us holds a stream for the requested time (within 10 %),
+    hnh_stream_paced_copy delivers every slice bit for bit and takes at least the modelled time."""
+    import time
+    lib = ctx.lib
+    ctx.sync(1)
+    t0 = time.perf_counter()
+    ctx.check(lib.hnh_stream_delay_us(ctx.h, 1, 20000.0), "delay")
+    ctx.sync(1)
+    dt = time.perf_counter() - t0
+    assert 0.020 <= dt <= 0.030, dt
+    n = 3 * 4096 + 2  # doubles per slice: not a multiple of the copy tile
+    src = np.random.default_rng(3).uniform(-1, 1, n)
+    d_src, d_dst = ctx.upload(src), ctx.upload(np.zeros(5 * n))
+    for wgs, us in ((1, 0.0), (3, 3000.0)):
+        d_dst.set(np.zeros(5 * n))
+        t0 = time.perf_counter()
+        ctx.check(lib.hnh_stream_paced_copy(ctx.h, 1, d_dst.ptr, d_src.ptr, n * 8, 5, us, wgs), "paced copy")
+        ctx.sync(1)
+        assert time.perf_counter() - t0 >= us * 1e-6
+        assert np.array_equal(d_dst.get(), np.tile(src, 5))
+    assert lib.hnh_stream_paced_copy(ctx.h, 1, d_dst.ptr, d_src.ptr, 24, 5, 0.0, 1) != 0  # slices must be multiples of 16 bytes
+    d_src.free(); d_dst.free()

@@ -327,3 +327,13 @@ def test_fingerprints_at_scale_against_the_compiled_reference(alg):
     for h in (A, B):
         h.free()
     d.free(); sp.free(); w.close()
+
+
+@pytest.mark.parametrize("alg,p,c", [("15d_fusion2", 4, 1), ("15d_fusion2", 8, 2), ("15d_sparse", 4, 1), ("25d_dense_replicate", 8, 2)])
+def test_schedules_with_compute_units_set_aside_for_communication(alg, p, c, monkeypatch):
+    """HNH_COMM_CUS: the compute stream masked off 16 CUs, the communication stream confined to them (hipExtStreamCreateWithCUMask).
+    Same results as ever — the event protocol between a masked compute stream and a masked communication stream holds."""
+    monkeypatch.setenv("HNH_COMM_CUS", "16")
+    case = T.case_inputs("er8_r16")
+    per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
+    T.check_against_golden(T.assemble(per_rank, case), per_rank, case, alg)
