@@ -130,7 +130,10 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
     }
     for (int s = 0; s < 2; s++) {
         hipError_t e = hipErrorUnknown;
-        if (mask_words > 0) {
+        // HNH_COMM_CUS_SHARED=1: only the compute stream is masked; the communication stream may use every CU (RCCL needs all its
+        // channel workgroups resident at once — with few reserved CUs and many channels, leave its stream alone)
+        static const bool comm_shared = std::getenv("HNH_COMM_CUS_SHARED") != nullptr;
+        if (mask_words > 0 && !(s == HNH_STREAM_COMM && comm_shared)) {
             e = hipExtStreamCreateWithCUMask(&ctx->streams[s], (uint32_t)mask_words, s == HNH_STREAM_COMM ? mask_comm : mask_compute);
             if (e != hipSuccess) ctx->comm_cus = 0;
         }
