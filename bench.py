@@ -51,9 +51,27 @@ def emit(obj):
         os.write(_JSON_FD, line.encode())
 
 
+DEFAULT_CHUNKS = "1,2,2,2,1,1"  # the library's default shape of the mesh fetch (dense_shift_15d.hpp)
+
+
+def set_chunk_spec(spec):
+    """A chunk spec is a number (Q symmetric chunks, HNH_MESH_CHUNKS) or a comma list of heights (HNH_MESH_TAPER)."""
+    if "," in spec:
+        os.environ["HNH_MESH_TAPER"] = spec
+        os.environ.pop("HNH_MESH_CHUNKS", None)
+    else:
+        os.environ["HNH_MESH_CHUNKS"] = spec
+        os.environ.pop("HNH_MESH_TAPER", None)
+
+
+def current_chunk_spec():
+    return os.environ.get("HNH_MESH_TAPER") or os.environ.get("HNH_MESH_CHUNKS") or DEFAULT_CHUNKS
+
+
 def route_name(route):
     c, mode, q = route
-    return "c=%d %s" % (c, {"mesh": "mesh/%s chunks" % q, "relay": "relay ring", "none": "replication only"}[mode])
+    mesh = ("mesh/heights %s" % q) if (q and "," in str(q)) else ("mesh/%s chunks" % q)
+    return "c=%d %s" % (c, {"mesh": mesh, "relay": "relay ring", "none": "replication only"}[mode])
 
 
 def keyed(idx, salt):
@@ -78,7 +96,8 @@ def parse(argv=None):
     ap.add_argument("--ring-mode", choices=["mesh", "relay"], default=None,
                     help="route of the 1.5D dense shift's moving operand: mesh = every block straight from its owner (default), "
                          "relay = the reference's neighbour ring (sets HNH_RING_MODE)")
-    ap.add_argument("--chunks", type=int, default=None, help="column chunks of the pipelined mesh fetch (sets HNH_MESH_CHUNKS)")
+    ap.add_argument("--chunks", default=None, help="chunks of the pipelined mesh fetch: a number Q = symmetric chunks of heights "
+                    "(1, 2, .., 2, 1) (HNH_MESH_CHUNKS), or a comma list of heights, e.g. 1,2,2,2,1,1 (HNH_MESH_TAPER)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-logm", type=int, default=18, help="size of the CPU baseline's thread-sweep sample")
     ap.add_argument("--cpu-trials", type=int, default=2)
@@ -295,7 +314,7 @@ def run(args, make_world=gpu_world):
     if args.ring_mode:
         os.environ["HNH_RING_MODE"] = args.ring_mode
     if args.chunks:
-        os.environ["HNH_MESH_CHUNKS"] = str(args.chunks)
+        set_chunk_spec(str(args.chunks))
     if args.gpus > 1 and getattr(args, "comm_cus", None):
         os.environ["HNH_COMM_CUS"] = str(args.comm_cus)
     if args.gpus > 1 and getattr(args, "nchannels", None):
@@ -407,7 +426,7 @@ def run(args, make_world=gpu_world):
     # the fastest one is what gets timed and the JSON line records all of them.
     tuning = None
     if n > 1 and args.alg == "15d_fusion2" and not args.no_tune:
-        default_q = int(os.environ.get("HNH_MESH_CHUNKS", "4"))
+        default_q = current_chunk_spec()
         fixed_mode = os.environ.get("HNH_RING_MODE") if (args.ring_mode or "HNH_RING_MODE" in os.environ) else None
         cs = [args.c] if args.c else [c for c in (1, 2, 4) if n % c == 0]
         candidates = []
@@ -416,7 +435,9 @@ def run(args, make_world=gpu_world):
                 candidates.append((c, "none", None))
                 continue
             if fixed_mode != "relay":
-                qs = [args.chunks] if args.chunks else sorted({default_q, 2, 4} | ({3, 8} if c == 1 else set()), key=lambda q: (q != default_q, q))
+                # chunk shapes: the library's default, symmetric Q = 2 / 4 (/ 3 / 8), and for c = 1 a longer falling shape
+                qs = [str(args.chunks)] if args.chunks else sorted(
+                    {default_q, DEFAULT_CHUNKS, "2", "4"} | ({"3", "8", "3,4,4,3,2,1,1"} if c == 1 else set()), key=lambda q: (q != default_q, len(q), q))
                 candidates += [(c, "mesh", q) for q in qs]
             if fixed_mode != "mesh":
                 candidates.append((c, "relay", None))
@@ -437,7 +458,7 @@ def run(args, make_world=gpu_world):
                 if route[1] != "none":
                     os.environ["HNH_RING_MODE"] = route[1]
                 if route[2] is not None:
-                    os.environ["HNH_MESH_CHUNKS"] = str(route[2])
+                    set_chunk_spec(route[2])
                 op = H.DistributedSparse(world, args.alg, sp, args.r, c_now)
                 A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
                 S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
@@ -445,7 +466,7 @@ def run(args, make_world=gpu_world):
 
             tuning = {}
             for route in candidates:
-                dog.note("route tuning: c=%d %s%s" % (route[0], route[1], "" if route[2] is None else "/%d chunks" % route[2]))
+                dog.note("route tuning: " + route_name(route))
                 rebuild(route)
                 op.fusedSpMM(A, B, S, buf, H.AMAT)
                 barrier()
@@ -596,8 +617,8 @@ def run(args, make_world=gpu_world):
                                                                      None: "replication only, nothing shifts"}[ring_mode_now])),
                        "nnz": nnz, "M": m, "R": args.r, "algorithm": args.alg, "c": c_now, "transport": "none" if n == 1 else transport_kind,
                        "ring_mode": ring_mode_now,
-                       "mesh_chunks": ((int(os.environ["HNH_MESH_CHUNKS"]) if "HNH_MESH_CHUNKS" in os.environ else "default")
-                                       if ring_mode_now == "mesh" else None),
+                       # Q symmetric chunks (a number) or the chunk heights (a comma list)
+                       "mesh_chunks": (current_chunk_spec() if ring_mode_now == "mesh" else None),
                        "rccl_channels": (os.environ.get("NCCL_MAX_NCHANNELS", "default") if n > 1 else None),
                        # compute units masked off the compute stream (several GPUs: they run the communication stream)
                        "comm_cus": int(os.environ.get("HNH_COMM_CUS", "0")),

@@ -59,9 +59,11 @@ public:
     // (hnh_csr_window: the columns of chunk q are a contiguous piece of every CSR row) runs as soon as it has landed, while
     // chunk q+1 is still on the links.  The reference walks the same nonzeros block by block (15D_dense_shift.hpp:199-227);
     // here a row's nonzeros of all fetched blocks are consecutive, so the gather batches of the row kernel stay full however
-    // many ranks and chunks there are.  HNH_MESH_CHUNKS sets `windows` (default 4, 1 = whole blocks).
+    // many ranks and chunks there are.  HNH_MESH_CHUNKS = Q symmetric chunks (1 = whole blocks), HNH_MESH_TAPER = any heights;
+    // default (1, 2, 2, 2, 1, 1).
     bool merged = false;
     int windows = 1;
+    std::vector<int> taper;  // chunk heights in units of a "fine" chunk; empty = the symmetric default (1, 2, .., 2, 1)
     std::vector<int64_t> cutA, cutB;  // chunk boundaries (windows + 1 entries, rows of a visiting A / B block)
     int fineA = 0, fineB = 0;         // granularity of the boundaries: every chunk is one or two "fine" chunks of this many rows
     DenseMatrix landing[2];      // [0]: visiting B blocks (gathered through S), [1]: visiting A blocks (through ST)
@@ -115,11 +117,39 @@ public:
         setRValue(R);
 
         merged = (fusionApproach == 2 && ring_mode == kMeshFetch && p / c > 1);
-        windows = merged ? 4 : 1;
-        if (const char* q = std::getenv("HNH_MESH_CHUNKS")) {
+        // default: six chunks of heights (1, 2, 2, 2, 1, 1) / 9 — against paced transfers of 40 .. 100 GB/s per link it beats the
+        // symmetric four (1, 2, 2, 1) / 6 of round 2 by 1 .. 6 % (a smaller last chunk: a fetch-bound call ends one last-chunk kernel
+        // after the fetch) and loses 4 % to it only when the links are so fast that the kernels bind
+        windows = 1;
+        if (merged) {
+            taper = {1, 2, 2, 2, 1, 1};
+            windows = (int)taper.size();
+        }
+        if (const char* q = std::getenv("HNH_MESH_CHUNKS")) {  // Q chunks of the symmetric shape (1, 2, .., 2, 1)
             const int v = std::atoi(q);
             if (v < 1 || v > 8) hnh::fatal("Error, HNH_MESH_CHUNKS must be between 1 and 8!");
-            if (merged) windows = v;
+            if (merged) {
+                windows = v;
+                taper.clear();
+            }
+        }
+        // HNH_MESH_TAPER=w0,w1,..: chunk heights proportional to these weights instead of the symmetric default — e.g. 6,5,4,3,2,1
+        // ends on a small chunk (a fetch-bound call ends one LAST-chunk kernel after the fetch); overrides HNH_MESH_CHUNKS
+        if (const char* t = std::getenv("HNH_MESH_TAPER")) {
+            std::vector<int> w;
+            for (const char* p2 = t; *p2;) {
+                char* e2 = nullptr;
+                const long v = std::strtol(p2, &e2, 10);
+                if (e2 == p2 || v < 1 || v > 64) hnh::fatal("Error, HNH_MESH_TAPER must be a comma list of weights between 1 and 64!");
+                w.push_back((int)v);
+                p2 = (*e2 == ',') ? e2 + 1 : e2;
+                if (*e2 != ',' && *e2 != 0) hnh::fatal("Error, HNH_MESH_TAPER must be a comma list of weights between 1 and 64!");
+            }
+            if (w.empty() || w.size() > 12) hnh::fatal("Error, HNH_MESH_TAPER takes 1 to 12 weights!");
+            if (merged) {
+                taper = w;
+                windows = (int)w.size();
+            }
         }
         cutA = chunk_cuts(localArows, &fineA);
         cutB = chunk_cuts(localBrows, &fineB);
@@ -221,8 +251,20 @@ private:
             *fine = std::max(br, 1);
             return cut;
         }
-        *fine = std::max(1, divideAndRoundUp(br, 2 * (windows - 1)));
-        for (int q = 1; q < windows; q++) cut[(size_t)q] = std::min<int64_t>((int64_t)(2 * q - 1) * *fine, br);
+        // weights of the chunks in fine chunks: HNH_MESH_TAPER, or first and last = one, the others = two
+        std::vector<int> w = taper;
+        if (w.empty()) {
+            w.assign((size_t)windows, 2);
+            w.front() = w.back() = 1;
+        }
+        int total = 0;
+        for (int x : w) total += x;
+        *fine = std::max(1, divideAndRoundUp(br, total));
+        int64_t prefix = 0;
+        for (int q = 1; q < windows; q++) {
+            prefix += w[(size_t)q - 1];
+            cut[(size_t)q] = std::min<int64_t>(prefix * *fine, br);
+        }
         return cut;
     }
     // first landing-buffer row of chunk q of the block fetched at step k >= 1

@@ -53,6 +53,7 @@ def test_bench_contract(nranks, alg, c, ring):
                 continue
             if ring != "relay":
                 want |= {"c=%d mesh/%d chunks" % (k, q) for q in ((2, 3, 4, 8) if k == 1 else (2, 4))}
+                want |= {"c=%d mesh/heights %s" % (k, h) for h in (("1,2,2,2,1,1", "3,4,4,3,2,1,1") if k == 1 else ("1,2,2,2,1,1",))}
             if ring != "mesh":
                 want.add("c=%d relay ring" % k)
         tuned = alg == "15d_fusion2" and len(want) > 1
@@ -64,7 +65,7 @@ def test_bench_contract(nranks, alg, c, ring):
             bc, broute = best.split(" ", 1)
             assert out["config"]["c"] == int(bc[2:])
             assert out["config"]["ring_mode"] == {"relay ring": "relay", "replication only": None}.get(broute, "mesh")
-            assert out["config"]["mesh_chunks"] == (int(broute.split("/")[1].split()[0]) if broute.startswith("mesh") else None)
+            assert out["config"]["mesh_chunks"] == (broute.split("/")[1].split()[-1 if "heights" in broute else 0] if broute.startswith("mesh") else None)
             if not c and nranks == 4:
                 assert any(k.startswith("c=2") for k in t) and any(k.startswith("c=4") for k in t)
         else:

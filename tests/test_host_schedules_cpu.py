@@ -141,7 +141,8 @@ def test_perf_counter_keys_match_the_reference():
 @pytest.mark.parametrize("ring", ["mesh", "relay"])
 def test_chunked_mesh_fetch_any_chunk_count(chunks, ring, monkeypatch):
     """Local kernel fusion keeps S in column chunks of each block so that the fetch of the visiting dense blocks can be
-    pipelined chunk by chunk (HNH_MESH_CHUNKS; default 4 everywhere else in this suite): same results for 1 (whole
+    pipelined chunk by chunk (HNH_MESH_CHUNKS = Q symmetric chunks; the default everywhere else in this suite is six chunks of
+    heights (1, 2, 2, 2, 1, 1)): same results for 1 (whole
     blocks), a count that does not divide the block (ragged last chunk, empty chunks on tiny blocks) and the maximum."""
     monkeypatch.setenv("HNH_MESH_CHUNKS", str(chunks))
     monkeypatch.setenv("HNH_RING_MODE", ring)
@@ -155,6 +156,26 @@ def test_chunked_mesh_fetch_any_chunk_count(chunks, ring, monkeypatch):
         for matmode in (H.AMAT, H.BMAT):
             per_rank = H.run_spmd(p, lambda w: T.run_fused_out(w, "15d_fusion2", 1, case, matmode, 0.2, 0.5, True))
             T.check_fused_out(per_rank, case, matmode, 0.2, 0.5, True)
+
+
+@pytest.mark.parametrize("taper", ["6,5,4,3,2,1", "1,1", "3,4,4,3,2,1,1", "1,64,1", "5"])
+def test_chunked_mesh_fetch_any_chunk_heights(taper, monkeypatch):
+    """HNH_MESH_TAPER: the chunks of the mesh fetch with arbitrary relative heights (falling, two equal, seven, one dominating,
+    a single chunk) — same results on every golden case, including blocks smaller than the number of fine chunks."""
+    monkeypatch.setenv("HNH_MESH_TAPER", taper)
+    for name in ("er8_r16", "ragged_r8", "tiny_r8", "rect_r16"):
+        case = T.case_inputs(name)
+        for p, c in [(2, 1), (4, 2), (8, 1)]:
+            per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, "15d_fusion2", c, case))
+            T.check_against_golden(T.assemble(per_rank, case), per_rank, case, "15d_fusion2")
+
+
+def test_bad_chunk_heights_are_refused(monkeypatch):
+    case = T.case_inputs("tiny_r8")
+    for bad in ("0,1", "1,,2", "a", "1,2,x", ",".join(["1"] * 13)):
+        monkeypatch.setenv("HNH_MESH_TAPER", bad)
+        with pytest.raises(Exception, match="HNH_MESH_TAPER"):
+            H.run_spmd(2, lambda w: T.run_all_ops(w, "15d_fusion2", 1, case))
 
 
 def test_wrong_length_value_vector_is_refused():

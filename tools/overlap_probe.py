@@ -37,6 +37,7 @@ ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--backend", default=None, help="kernel library to load (default: the HIP library; tests pass the CPU test double)")
 ap.add_argument("--chunks", default="1,2,4")
 ap.add_argument("--pace", default="40,60,75", help="modelled GB/s per xGMI link and direction")
+ap.add_argument("--tapers", default="", help="semicolon list of HNH_MESH_TAPER weight lists to measure besides --chunks, e.g. \"6,5,4,3,2,1;3,4,4,3,2,1,1\"")
 ap.add_argument("--copy-wgs", default="0", help="comma list; > 0: the paced stand-in also MOVES the bytes (HNH_PACE_COPY: chunk q of the own block "
                 "read once per peer, written to each peer's place in the landing buffer, by this many throttled workgroups per link), so "
                 "the rank's kernels also meet the HBM traffic (896 MiB in + 896 MiB out per call) and the workgroups of a real exchange")
@@ -101,9 +102,17 @@ def body(w):
 
 print("one rank of p=%d alone on the GPU, ER 2^%d ef %d, R=%d; link rate is a MODEL parameter (paced communication stream, no copies)" %
       (a.p, a.logm, a.ef, a.r), flush=True)
-for q, wgs in [(q, w) for w in a.copy_wgs.split(",") for q in a.chunks.split(",")]:
-    os.environ["HNH_MESH_CHUNKS"] = q
-    Q = int(q)
+shapes = [(q, None) for q in a.chunks.split(",") if q] + [(None, t) for t in a.tapers.split(";") if t]
+for (q, taper), wgs in [(sh, w) for w in a.copy_wgs.split(",") for sh in shapes]:
+    if taper is None:
+        os.environ["HNH_MESH_CHUNKS"] = q
+        os.environ.pop("HNH_MESH_TAPER", None)
+        Q = int(q)
+        weights = [1.0] if Q == 1 else [(1.0 if i in (0, Q - 1) else 2.0) for i in range(Q)]
+    else:
+        os.environ["HNH_MESH_TAPER"] = taper
+        weights = [float(x) for x in taper.split(",")]
+        Q = len(weights)
     if int(wgs) > 0:
         os.environ["HNH_PACE_COPY"] = wgs
         print("-- the paced transfers also move their bytes: %s throttled workgroups per link --" % wgs, flush=True)
@@ -111,13 +120,14 @@ for q, wgs in [(q, w) for w in a.copy_wgs.split(",") for q in a.chunks.split(","
         os.environ.pop("HNH_PACE_COPY", None)
     unpaced, k_all, launches, t_own, t_rem, rows, brows = H.run_spmd(a.p, body)[0]
     block_bytes = brows * a.r * 8
-    print("Q=%d: unpaced call %.3f ms (%d launches, %.3f ms of kernels: own block ~%.3f, fetched blocks ~%.3f)" % (Q, unpaced, launches, k_all, t_own, t_rem), flush=True)
+    label = "Q=%d" % Q if taper is None else "taper %s" % taper
+    print("%s: unpaced call %.3f ms (%d launches, %.3f ms of kernels: own block ~%.3f, fetched blocks ~%.3f)" % (label, unpaced, launches, k_all, t_own, t_rem), flush=True)
     for g, t in rows:
         tf = block_bytes / (g * 1e9) * 1e3
         serial = tf + unpaced
         # pipeline simulation with the tapered chunk heights (1, 2, .., 2, 1) / (2Q - 2): chunk q lands at the running sum of its
         # transfer times; window q's kernel starts when chunk q has landed and the previous kernel is done
-        frac = [1.0] if Q == 1 else [(1.0 if q in (0, Q - 1) else 2.0) / (2 * Q - 2) for q in range(Q)]
+        frac = [x / sum(weights) for x in weights]
         t_comm, t_comp = 0.0, t_own
         for f in frac:
             t_comm += tf * f
