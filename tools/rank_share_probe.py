@@ -13,6 +13,10 @@ import os
 import sys
 import time
 
+# N logical ranks = 2 N streams on ONE device: HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams
+# that share a queue serialise — give every stream its own (has to be set before the HIP runtime starts)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 ap = argparse.ArgumentParser()
