@@ -309,6 +309,9 @@ def run(args, make_world=gpu_world):
         # is OpenMP code, so give every rank its share of the host cores instead (must happen before libgomp starts)
         os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // args.gpus))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL across processes)
+    # HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share one serialise: with the
+    # framework's own streams and RCCL's in the process, make sure the compute and the communication stream never have to share
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.gpus > 1:
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: RCCL's bootstrap must not depend on an external interface
     if args.ring_mode:

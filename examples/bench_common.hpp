@@ -28,6 +28,9 @@ inline int env_int(const char* k, int dflt) {
 
 inline hnh::World* make_world() {
     const int rank = env_int("RANK", 0), n = env_int("WORLD_SIZE", 1), local = env_int("LOCAL_RANK", rank);
+    // (before the HIP runtime starts) streams that share a hardware queue serialise: leave room beyond the default 4 queues so
+    // that the compute and the communication stream never have to share one with each other or with RCCL's
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     hnh::Backend* be = hnh::load_backend(nullptr);  // the HIP library next to libhnh_host.so; exits if missing
     if (n == 1) return new hnh::SingleWorld(be, local);
     const char* idfile = getenv("HNH_ID_FILE");
