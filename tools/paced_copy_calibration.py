@@ -1,5 +1,7 @@
+"""Development tool: what the throttled copy kernel behind HNH_PACE_COPY (hnh_stream_paced_copy) manages ALONE on the GPU, per
+workgroup — the calibration for reading tools/overlap_probe.py --copy-wgs (its copy loop is far weaker than an RCCL channel)."""
 import ctypes as C, sys, os, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from distributed_sddmm_amd import _kernels as K
 ctx = K.Ctx(0); lib = ctx.lib
