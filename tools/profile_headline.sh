@@ -11,9 +11,12 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python "$R/bench.py" > "$OUT/${TAG}_bench_n1.json" 2> "$OUT/${TAG}_bench_n1.stderr"
 tail -c 600 "$OUT/${TAG}_bench_n1.json"
-rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_stats" -o stats -- python "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-live-traffic --no-check > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE -d "$R/gpurun_out/prof_fetch" -o fetch -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic --no-check > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE -d "$R/gpurun_out/prof_write" -o write -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic --no-check > /dev/null 2>&1
+# the profiled runs use the CU setting the bench run measured to be faster (no second search: their kernel averages then belong
+# to exactly the configuration that was timed)
+CUS=$(python -c "import json,sys; print(json.load(open(sys.argv[1]))['config'].get('comm_cus', 0))" "$OUT/${TAG}_bench_n1.json" 2>/dev/null || echo 0)
+rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_stats" -o stats -- python "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-live-traffic --no-check --comm-cus "$CUS" > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE -d "$R/gpurun_out/prof_fetch" -o fetch -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic --no-check --comm-cus "$CUS" > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d "$R/gpurun_out/prof_write" -o write -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic --no-check --comm-cus "$CUS" > /dev/null 2>&1
 S=$(find "$R/gpurun_out/prof_stats" -name "*_results.db" | head -1)
 F=$(find "$R/gpurun_out/prof_fetch" -name "*_results.db" | head -1)
 W=$(find "$R/gpurun_out/prof_write" -name "*_results.db" | head -1)
