@@ -46,6 +46,7 @@ SIGNATURES = {
     "hnh_world_create_thread": (_i32, [_vp, _i32, _i32, _pvp]),
     "hnh_rccl_unique_id": (_i32, [_vp]),
     "hnh_world_create_rccl": (_i32, [_i32, _i32, _i32, _vp, _pvp]),
+    "hnh_world_create_ipc": (_i32, [_i32, _i32, _i32, C.c_char_p, _pvp]),
     "hnh_world_create_callback": (_i32, [_i32, _i32, _i32, C.POINTER(CommCallbacks), _pvp]),
     "hnh_world_destroy": (_i32, [_vp]),
     "hnh_world_rank": (_i32, [_vp]),
@@ -211,6 +212,14 @@ class World:
         return cls(h)
 
     @classmethod
+    def ipc(cls, rank: int, nranks: int, device: int, session: str) -> "World":
+        """One process per GPU of one node, no RCCL: receivers pull out of their peers' mapped buffers.  `session` is the same
+        string on every rank (ipc_session_id() on rank 0, handed round by the launcher)."""
+        h = _vp()
+        _check(lib().hnh_world_create_ipc(rank, nranks, device, session.encode(), C.byref(h)), "hnh_world_create_ipc")
+        return cls(h)
+
+    @classmethod
     def callback(cls, rank: int, nranks: int, device: int, callbacks: CommCallbacks) -> "World":
         h = _vp()
         _check(lib().hnh_world_create_callback(rank, nranks, device, C.byref(callbacks), C.byref(h)), "hnh_world_create_callback")
@@ -248,6 +257,13 @@ class World:
         if self.h:
             _check(lib().hnh_world_destroy(self.h), "world_destroy")
             self.h = None
+
+
+def ipc_session_id() -> str:
+    """A name no other job on this node uses (made on rank 0, given to every rank)."""
+    import os
+    import time
+    return "%d_%x" % (os.getpid(), time.time_ns())
 
 
 def rccl_unique_id() -> bytes:

@@ -30,6 +30,12 @@ struct hnh_ctx {
     bool panels_with_hubs = false;  // HNH_PANELS_WITH_HUBS=1: panel the short rows of blocks that also have hub rows
     int long_row_override = 0;      // HNH_LONG_ROW=<multiple of 64, 64..1984>: fixed hub-row threshold instead of the adaptive one (measurement aid)
     double panel_bytes = 512.0 * 1024.0 * 1024.0;  // bytes of the gathered operand per panel (HNH_PANEL_BYTES; tests shrink it)
+    // peer-to-peer pull (hnh_ipc.hip): auxiliary streams the copy-engine pulls of one group are spread over (created on first use),
+    // the fork event recorded on the issuing stream and one join event per auxiliary stream
+    static constexpr int kAuxStreams = 8;
+    hipStream_t aux[kAuxStreams] = {nullptr};
+    hipEvent_t aux_fork = nullptr, aux_join[kAuxStreams] = {nullptr};
+    int flag_kernels = -1;  // HNH_IPC_FLAGS=kernel: flag words are written / awaited by one-lane kernels instead of stream memory operations
 };
 
 namespace hnh {

@@ -160,6 +160,11 @@ int hnh_ctx_destroy(hnh_ctx* ctx) {
         if (ctx->long_partials[s]) (void)hipFree(ctx->long_partials[s]);
         if (ctx->panel_split[s]) (void)hipFree(ctx->panel_split[s]);
     }
+    for (int a = 0; a < hnh_ctx::kAuxStreams; a++) {
+        if (ctx->aux[a]) { (void)hipStreamSynchronize(ctx->aux[a]); (void)hipStreamDestroy(ctx->aux[a]); }
+        if (ctx->aux_join[a]) (void)hipEventDestroy(ctx->aux_join[a]);
+    }
+    if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
     delete ctx;
     return HNH_OK;
 }

@@ -32,6 +32,8 @@ struct Backend {
     HNH_FN(hnh_comm_unique_id) HNH_FN(hnh_comm_init) HNH_FN(hnh_comm_split) HNH_FN(hnh_comm_destroy)
     HNH_FN(hnh_comm_sendrecv) HNH_FN(hnh_comm_group_begin) HNH_FN(hnh_comm_group_end) HNH_FN(hnh_comm_allgather) HNH_FN(hnh_comm_reduce_scatter_f64)
     HNH_FN(hnh_comm_allreduce_f64)
+    HNH_FN(hnh_ipc_export) HNH_FN(hnh_ipc_open) HNH_FN(hnh_ipc_close) HNH_FN(hnh_ipc_pull) HNH_FN(hnh_ipc_flags_register) HNH_FN(hnh_ipc_flags_unregister)
+    HNH_FN(hnh_stream_write_flag) HNH_FN(hnh_stream_wait_flag)
 #undef HNH_FN
 };
 

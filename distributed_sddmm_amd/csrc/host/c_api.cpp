@@ -126,6 +126,13 @@ int hnh_world_create_rccl(int rank, int nranks, int device, const void* id, hnh_
         *out = h;
     });
 }
+int hnh_world_create_ipc(int rank, int nranks, int device, const char* session, hnh_world** out) {
+    return guarded(nullptr, [&] {
+        auto* h = new hnh_world();
+        h->w.reset(new hnh::IpcWorld(rank, nranks, hnh::default_backend(), device, session ? session : ""));
+        *out = h;
+    });
+}
 int hnh_world_create_callback(int rank, int nranks, int device, const hnh_comm_callbacks* cb, hnh_world** out) {
     return guarded(nullptr, [&] {
         auto* h = new hnh_world();

@@ -1,8 +1,13 @@
 #include "world.hpp"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <chrono>
 #include <cstring>
@@ -77,6 +82,8 @@ Backend* load_backend(const char* path_c) {
     HNH_BIND(hnh_comm_unique_id) HNH_BIND(hnh_comm_init) HNH_BIND(hnh_comm_split) HNH_BIND(hnh_comm_destroy)
     HNH_BIND(hnh_comm_sendrecv) HNH_BIND(hnh_comm_group_begin) HNH_BIND(hnh_comm_group_end) HNH_BIND(hnh_comm_allgather) HNH_BIND(hnh_comm_reduce_scatter_f64)
     HNH_BIND(hnh_comm_allreduce_f64)
+    HNH_BIND(hnh_ipc_export) HNH_BIND(hnh_ipc_open) HNH_BIND(hnh_ipc_close) HNH_BIND(hnh_ipc_pull) HNH_BIND(hnh_ipc_flags_register) HNH_BIND(hnh_ipc_flags_unregister)
+    HNH_BIND(hnh_stream_write_flag) HNH_BIND(hnh_stream_wait_flag)
 #undef HNH_BIND
     b->name = b->hnh_backend_name();
     g_backends[path] = b;
@@ -172,6 +179,7 @@ void World::dfree(void* p) {
         return;
     }
     sync_all();
+    on_device_release(p);
     check(be->hnh_free(ctx, p), "hnh_free");
 }
 
@@ -180,6 +188,7 @@ void World::drain_pool() {
     for (auto& kv : pool_) {
         be->hnh_event_destroy(ctx, kv.second.ev[0]);
         be->hnh_event_destroy(ctx, kv.second.ev[1]);
+        on_device_release(kv.second.ptr);
         be->hnh_free(ctx, kv.second.ptr);
     }
     pool_.clear();
@@ -628,6 +637,12 @@ void RcclWorld::host_allgather(const void* send, void* recv, size_t bytes) {
 
 void RcclWorld::host_alltoallv(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl,
                                void* recv, const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl) {
+    host_alltoallv_staged(send, sendbytes, senddispl, recv, recvbytes, recvdispl);
+}
+
+// Host data staged through device memory and the device transport (set-up path only).
+void World::host_alltoallv_staged(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl,
+                                  void* recv, const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl) {
     size_t stot = 0, rtot = 0;
     for (int r = 0; r < size; r++) {
         stot = std::max(stot, senddispl[r] + sendbytes[r]);
@@ -649,6 +664,280 @@ void RcclWorld::host_alltoallv(const void* send, const std::vector<size_t>& send
     sync(HNH_STREAM_COMM);
     dfree(ds);
     dfree(dr);
+}
+
+// ------------------------------------------------------------------------------------------------ IpcWorld
+namespace {
+constexpr int kIpcMaxRanks = 16;
+constexpr int kIpcSlots = 32;                   // descriptors in flight per ordered pair before the sender's HOST waits
+constexpr size_t kIpcPublishBytes = 64 * 1024;  // host all-gather staging per rank and round
+constexpr uint64_t kIpcMagic = 0x686e685f69706331ULL;
+}  // namespace
+
+struct IpcShared {
+    std::atomic<uint64_t> magic;
+    int nranks;
+    std::atomic<int> attached, detached, failed;
+    std::atomic<uint64_t> bar_arrived, bar_generation;
+    struct Msg {
+        std::atomic<uint64_t> seq;
+        uint64_t offset, bytes, alloc_bytes;
+        int32_t stream, pad;
+        unsigned char handle[HNH_IPC_HANDLE_BYTES];
+    };
+    Msg box[kIpcMaxRanks * kIpcMaxRanks][kIpcSlots];       // [from * max + to]
+    std::atomic<uint64_t> consumed[kIpcMaxRanks * kIpcMaxRanks];
+    // device-visible part (registered with the runtime): flag words, one 64-byte line each: [ready | done][stream][from * max + to]
+    alignas(4096) uint64_t flags[2][2][kIpcMaxRanks * kIpcMaxRanks][8];
+    alignas(4096) char publish[kIpcMaxRanks][kIpcPublishBytes];
+};
+
+template <typename Pred>
+void IpcWorld::wait_host(Pred&& done, const char* what) {
+    using clock = std::chrono::steady_clock;
+    const auto t0 = clock::now();
+    for (uint64_t spins = 0;; spins++) {
+        if (done()) return;
+        if (spins < 2000) continue;
+        if ((spins & 63) == 0) {
+            if (sh_->failed.load(std::memory_order_relaxed)) fatal(std::string("Error, a peer rank of the ipc world gave up while this one waited for ") + what);
+            if (std::chrono::duration<double>(clock::now() - t0).count() > wait_limit_s_) {
+                sh_->failed.store(1);
+                if (rank == 0) shm_unlink(shm_name_.c_str());  // (no-op once every rank has attached)
+                fatal(std::string("Error, ipc world: rank ") + std::to_string(rank) + " waited more than " + std::to_string((int)wait_limit_s_) +
+                      " s for " + what + " (a peer probably failed)");
+            }
+        }
+        usleep(spins < 20000 ? 1 : 50);
+    }
+}
+
+IpcWorld::IpcWorld(int r, int nranks, Backend* backend, int device_ordinal, const std::string& session) {
+    rank = r;
+    size = nranks;
+    if (nranks < 1 || nranks > kIpcMaxRanks || r < 0 || r >= nranks) fatal("Error, the ipc world takes 1 to 16 ranks of one node");
+    if (session.empty() || session.size() > 200 || session.find('/') != std::string::npos) fatal("Error, the ipc world needs a session name (no '/')");
+    if (const char* w = std::getenv("HNH_IPC_WAIT_S")) wait_limit_s_ = std::atof(w);
+    if (const char* m = std::getenv("HNH_IPC_PULL")) {
+        if (std::string(m) == "kernel") pull_mode_ = HNH_IPC_PULL_KERNEL;
+        else if (std::string(m) != "engine") fatal("Error, HNH_IPC_PULL must be engine or kernel!");
+    }
+    if (const char* w = std::getenv("HNH_IPC_PULL_WGS")) pull_wgs_ = std::max(1, std::min(256, std::atoi(w)));
+    init_device(backend, device_ordinal);
+    shm_name_ = "/hnh_ipc_" + session;
+    int fd = -1;
+    if (rank == 0) {
+        shm_unlink(shm_name_.c_str());
+        fd = shm_open(shm_name_.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)sizeof(IpcShared)) != 0) fatal("Error, ipc world: cannot create the shared-memory segment " + shm_name_);
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            fd = shm_open(shm_name_.c_str(), O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(IpcShared)) break;
+            if (fd >= 0) close(fd);
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_limit_s_)
+                fatal("Error, ipc world: rank 0 never created the shared-memory segment " + shm_name_);
+            usleep(1000);
+        }
+    }
+    void* m = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) fatal("Error, ipc world: cannot map the shared-memory segment");
+    sh_ = static_cast<IpcShared*>(m);
+    if (rank == 0) {
+        sh_->nranks = nranks;  // (a fresh segment is zero-filled)
+        sh_->magic.store(kIpcMagic, std::memory_order_release);
+    } else {
+        wait_host([&] { return sh_->magic.load(std::memory_order_acquire) == kIpcMagic; }, "rank 0 to initialise the segment");
+        if (sh_->nranks != nranks) fatal("Error, ipc world: the ranks disagree about the world size");
+    }
+    sh_->attached.fetch_add(1);
+    wait_host([&] { return sh_->attached.load() >= nranks; }, "every rank to attach");
+    if (rank == 0) shm_unlink(shm_name_.c_str());  // everybody holds a mapping: the name is no longer needed and cannot leak
+    check(be->hnh_ipc_flags_register(ctx, (void*)sh_->flags, sizeof(sh_->flags), &flags_dev_), "hnh_ipc_flags_register");
+    msg_out_.assign(nranks, 0);
+    msg_in_.assign(nranks, 0);
+    for (int s = 0; s < 2; s++) {
+        flag_out_[s].assign(nranks, 0);
+        flag_in_[s].assign(nranks, 0);
+    }
+    barrier();
+}
+
+IpcWorld::~IpcWorld() {
+    if (ctx) {
+        sync_all_nothrow();
+        if (sh_) {
+            // nobody unmaps a peer's memory while that peer may still be reading it
+            sh_->detached.fetch_add(1);
+            const auto t0 = std::chrono::steady_clock::now();
+            while (sh_->detached.load() < size && !sh_->failed.load() &&
+                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < std::min(wait_limit_s_, 60.0))
+                usleep(200);
+        }
+        for (auto& kv : opened_) be->hnh_ipc_close(ctx, kv.second);
+        opened_.clear();
+        if (sh_) be->hnh_ipc_flags_unregister(ctx, (void*)sh_->flags);
+    }
+    destroy_device();
+    if (sh_) munmap((void*)sh_, sizeof(IpcShared));
+}
+
+void IpcWorld::barrier() {
+    const uint64_t gen = sh_->bar_generation.load(std::memory_order_acquire);
+    if (sh_->bar_arrived.fetch_add(1) + 1 == (uint64_t)size) {
+        sh_->bar_arrived.store(0);
+        sh_->bar_generation.fetch_add(1, std::memory_order_release);
+    } else {
+        wait_host([&] { return sh_->bar_generation.load(std::memory_order_acquire) != gen; }, "the barrier");
+    }
+}
+
+void IpcWorld::host_allgather(const void* send, void* recv, size_t bytes) {
+    for (size_t off = 0; off < bytes || off == 0; off += kIpcPublishBytes) {
+        const size_t chunk = std::min(kIpcPublishBytes, bytes - off);
+        std::memcpy(sh_->publish[rank], static_cast<const char*>(send) + off, chunk);
+        barrier();
+        for (int r = 0; r < size; r++) std::memcpy(static_cast<char*>(recv) + (size_t)r * bytes + off, sh_->publish[r], chunk);
+        barrier();
+        if (bytes == 0) break;
+    }
+}
+
+void IpcWorld::host_alltoallv(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl,
+                              void* recv, const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl) {
+    host_alltoallv_staged(send, sendbytes, senddispl, recv, recvbytes, recvdispl);
+}
+
+void* IpcWorld::flag(int kind, int stream, int from, int to) const {
+    const size_t word = ((((size_t)kind * 2 + (size_t)stream) * (kIpcMaxRanks * kIpcMaxRanks)) + (size_t)from * kIpcMaxRanks + (size_t)to) * 8;
+    return static_cast<uint64_t*>(flags_dev_) + word;
+}
+
+void IpcWorld::on_device_release(void* p) { exported_.erase((uintptr_t)p); }
+
+const IpcWorld::Exported& IpcWorld::export_of(const void* ptr, uint64_t* offset, Exported* scratch) {
+    const uintptr_t a = (uintptr_t)ptr;
+    auto it = exported_.upper_bound(a);
+    if (it != exported_.begin()) {
+        --it;
+        if (a < it->first + it->second.bytes) {
+            *offset = (uint64_t)(a - it->first);
+            return it->second;
+        }
+    }
+    uint64_t alloc = 0;
+    check(be->hnh_ipc_export(ctx, ptr, scratch->handle, offset, &alloc), "hnh_ipc_export");
+    scratch->bytes = (size_t)alloc;
+    void* base = (void*)(a - (uintptr_t)*offset);
+    // only blocks this world allocated are remembered: it hears when they go back to the driver (on_device_release)
+    if (live_.count(base)) return exported_[(uintptr_t)base] = *scratch;
+    return *scratch;
+}
+
+void* IpcWorld::open_peer(const unsigned char* handle, uint64_t alloc_bytes) {
+    std::string key(reinterpret_cast<const char*>(handle), HNH_IPC_HANDLE_BYTES);
+    auto it = opened_.find(key);
+    if (it != opened_.end()) return it->second;
+    if (opened_.size() >= 512) {  // handles of blocks the peers have long freed pile up: drop all mappings at a quiet moment
+        sync_all();
+        for (auto& kv : opened_) check(be->hnh_ipc_close(ctx, kv.second), "hnh_ipc_close");
+        opened_.clear();
+    }
+    void* base = nullptr;
+    check(be->hnh_ipc_open(ctx, handle, alloc_bytes, &base), "hnh_ipc_open");
+    opened_[key] = base;
+    return base;
+}
+
+void IpcWorld::group_begin() { group_depth_++; }
+void IpcWorld::group_end() {
+    if (group_depth_ <= 0) fatal("Error, group_end without group_begin");
+    if (--group_depth_ == 0) flush();
+}
+
+void IpcWorld::sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes, int src,
+                        int stream) {
+    if (stream != HNH_STREAM_COMPUTE && stream != HNH_STREAM_COMM) fatal("Error, bad stream selector");
+    if (!pending_.empty() && pending_.back().stream != stream) flush();  // a group stays on one stream
+    pending_.push_back({comm.ranks[dst], comm.ranks[src], sendbuf, sendbytes, recvbuf, recvbytes, stream});
+    if (group_depth_ == 0) flush();
+}
+
+void IpcWorld::flush() {
+    if (pending_.empty()) return;
+    std::vector<Op> ops;
+    ops.swap(pending_);
+    const int stream = ops[0].stream;
+    const int M = kIpcMaxRanks;
+    // 1. sends: raise "ready" behind everything enqueued so far, then post where the bytes are
+    std::vector<uint64_t> sent(ops.size(), 0), received(ops.size(), 0);
+    for (size_t i = 0; i < ops.size(); i++) {
+        const Op& o = ops[i];
+        if ((o.dst == rank) != (o.src == rank)) fatal("Error, ipc world: a send/recv pair with exactly one end on this rank");
+        if (o.dst == rank) {
+            if (o.sendbytes != o.recvbytes) fatal("Error, self send/recv size mismatch");
+            continue;
+        }
+        if (!o.sendbytes) continue;
+        Exported scratch;
+        uint64_t offset = 0;
+        const Exported& ex = export_of(o.sendbuf, &offset, &scratch);
+        sent[i] = ++flag_out_[stream][o.dst];
+        check(be->hnh_stream_write_flag(ctx, stream, flag(0, stream, rank, o.dst), sent[i]), "hnh_stream_write_flag");
+        const uint64_t m = ++msg_out_[o.dst];
+        const size_t pair = (size_t)rank * M + o.dst;
+        if (m > kIpcSlots) wait_host([&] { return sh_->consumed[pair].load(std::memory_order_acquire) + kIpcSlots >= m; }, "a free descriptor slot");
+        IpcShared::Msg& slot = sh_->box[pair][m % kIpcSlots];
+        slot.offset = offset;
+        slot.bytes = o.sendbytes;
+        slot.alloc_bytes = ex.bytes;
+        slot.stream = stream;
+        std::memcpy(slot.handle, ex.handle, HNH_IPC_HANDLE_BYTES);
+        slot.seq.store(m, std::memory_order_release);
+    }
+    // 2. receives: learn where the peer's bytes are, wait (on the stream) until they are final
+    std::vector<void*> dsts;
+    std::vector<const void*> srcs;
+    std::vector<size_t> sizes;
+    for (size_t i = 0; i < ops.size(); i++) {
+        const Op& o = ops[i];
+        if (o.src == rank || !o.recvbytes) continue;
+        const uint64_t m = ++msg_in_[o.src];
+        const size_t pair = (size_t)o.src * M + rank;
+        IpcShared::Msg& slot = sh_->box[pair][m % kIpcSlots];
+        wait_host([&] { return slot.seq.load(std::memory_order_acquire) == m; }, "a peer's message descriptor");
+        const uint64_t offset = slot.offset, bytes = slot.bytes, alloc = slot.alloc_bytes;
+        const int peer_stream = slot.stream;
+        unsigned char handle[HNH_IPC_HANDLE_BYTES];
+        std::memcpy(handle, slot.handle, HNH_IPC_HANDLE_BYTES);
+        sh_->consumed[pair].store(m, std::memory_order_release);
+        if (bytes != o.recvbytes) fatal("Error, send/recv size mismatch between ranks");
+        if (peer_stream != stream) fatal("Error, ipc world: the two ends of a message name different streams");
+        const char* base = static_cast<const char*>(open_peer(handle, alloc));
+        received[i] = ++flag_in_[stream][o.src];
+        check(be->hnh_stream_wait_flag(ctx, stream, flag(0, stream, o.src, rank), received[i]), "hnh_stream_wait_flag");
+        dsts.push_back(o.recvbuf);
+        srcs.push_back(base + offset);
+        sizes.push_back(o.recvbytes);
+    }
+    // 3. the copies: self pairs on the stream, the peers' bytes pulled together
+    for (const Op& o : ops)
+        if (o.dst == rank && o.sendbytes && o.sendbuf != o.recvbuf) copy(o.recvbuf, o.sendbuf, o.sendbytes, HNH_COPY_D2D, stream);
+    // the copy engines take their sources from streams forked off the communication stream; on the compute stream (replication
+    // collectives) one gather-copy launch does the same without a second set of streams
+    const int mode = (stream == HNH_STREAM_COMM) ? pull_mode_ : HNH_IPC_PULL_KERNEL;
+    for (size_t lo = 0; lo < dsts.size(); lo += HNH_IPC_MAX_PULL) {
+        const int cnt = (int)std::min<size_t>(HNH_IPC_MAX_PULL, dsts.size() - lo);
+        check(be->hnh_ipc_pull(ctx, stream, cnt, dsts.data() + lo, srcs.data() + lo, sizes.data() + lo, mode, pull_wgs_), "hnh_ipc_pull");
+    }
+    // 4. tell the senders their buffers are free again; my own buffers are free once my receivers said so
+    for (size_t i = 0; i < ops.size(); i++)
+        if (received[i]) check(be->hnh_stream_write_flag(ctx, stream, flag(1, stream, ops[i].src, rank), received[i]), "hnh_stream_write_flag");
+    for (size_t i = 0; i < ops.size(); i++)
+        if (sent[i]) check(be->hnh_stream_wait_flag(ctx, stream, flag(1, stream, rank, ops[i].dst), sent[i]), "hnh_stream_wait_flag");
 }
 
 // ------------------------------------------------------------------------------------------------ CallbackWorld

@@ -107,6 +107,10 @@ public:
     void* scratch(int slot, size_t bytes);
 
 protected:
+    // a device block is about to be given back to the driver (transports that exported it forget the handle)
+    virtual void on_device_release(void* p) { (void)p; }
+    void host_alltoallv_staged(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl, void* recv,
+                               const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl);
     void init_device(Backend* backend, int device_ordinal);
     void destroy_device();
     std::vector<std::pair<void*, size_t>> scratch_;
@@ -184,6 +188,67 @@ public:
 
 private:
     void* comm_ = nullptr;  // world communicator (the only RCCL communicator: see world.cpp)
+};
+
+// ---- one process per GPU of ONE node, no RCCL: the receiver PULLS out of the sender's mapped buffer (include/hnh_kernels.h, "ipc").
+// Control plane = a POSIX shared-memory segment all ranks attach to (`session` names it; the launcher hands every rank the same
+// string): barrier, host all-gather, one mailbox per ordered pair of ranks carrying (memory handle, offset, bytes) of each
+// message, and the flag words the ranks' STREAMS order themselves with.  A send/recv pair is
+//     sender  : [write ready(me->dst) = s]  ...  [wait done(me->dst) >= s]
+//     receiver: [wait ready(src->me) >= s]  [copy peer -> local]  [write done(src->me) = s]
+// all enqueued on the stream the call names; the host only exchanges the message descriptors (posted at enqueue time, so a
+// rank waits for its peer's HOST to reach the matching call, never for its device).  A group (group_begin .. group_end) issues
+// all its ready flags first and pulls all its sources together: copy engines on forked streams, or one gather-copy kernel
+// (HNH_IPC_PULL=engine|kernel).  Works between processes that share ONE GPU as well, which is how the tests run it.
+struct IpcShared;
+class IpcWorld : public World {
+public:
+    IpcWorld(int rank, int nranks, Backend* backend, int device_ordinal, const std::string& session);
+    ~IpcWorld() override;
+    const char* kind() const override { return "ipc-pull"; }
+    void group_begin() override;
+    void group_end() override;
+    void sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes, int src,
+                  int stream) override;
+    void barrier() override;
+    void host_allgather(const void* send, void* recv, size_t bytes) override;
+    void host_alltoallv(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl, void* recv,
+                        const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl) override;
+
+protected:
+    void on_device_release(void* p) override;
+
+private:
+    struct Op {
+        int dst, src;  // world ranks
+        const void* sendbuf;
+        size_t sendbytes;
+        void* recvbuf;
+        size_t recvbytes;
+        int stream;
+    };
+    struct Exported {
+        size_t bytes;
+        unsigned char handle[HNH_IPC_HANDLE_BYTES];
+    };
+    IpcShared* sh_ = nullptr;
+    void* flags_dev_ = nullptr;
+    std::string shm_name_;
+    int group_depth_ = 0;
+    std::vector<Op> pending_;
+    std::vector<uint64_t> msg_out_, msg_in_;       // mailbox sequence per peer
+    std::vector<uint64_t> flag_out_[2], flag_in_[2];  // ready / done sequence per stream and peer
+    std::map<uintptr_t, Exported> exported_;       // by base address: allocations of this world whose handle is known
+    std::map<std::string, void*> opened_;          // by handle bytes: peers' allocations mapped into this process
+    int pull_mode_ = HNH_IPC_PULL_ENGINE, pull_wgs_ = 16;
+    double wait_limit_s_ = 300.0;
+
+    void flush();
+    void* flag(int kind, int stream, int from, int to) const;
+    const Exported& export_of(const void* ptr, uint64_t* offset, Exported* scratch);
+    void* open_peer(const unsigned char* handle, uint64_t alloc_bytes);
+    template <typename Pred>
+    void wait_host(Pred&& done, const char* what);
 };
 
 // ---- transport supplied by the embedding program (torch.distributed / gloo in tests, MPI, ...).

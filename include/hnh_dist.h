@@ -65,6 +65,9 @@ int hnh_thread_group_destroy(hnh_thread_group* g);
 int hnh_world_create_thread(hnh_thread_group* g, int rank, int device, hnh_world** out);
 int hnh_rccl_unique_id(void* id128_host);
 int hnh_world_create_rccl(int rank, int nranks, int device, const void* id128_host, hnh_world** out);
+/* One process per GPU of ONE node without RCCL: receivers pull out of their peers' mapped buffers (hnh_kernels.h, "ipc").
+ * `session` = the same string on every rank of the job (it names the node-local shared-memory rendezvous). */
+int hnh_world_create_ipc(int rank, int nranks, int device, const char* session, hnh_world** out);
 int hnh_world_create_callback(int rank, int nranks, int device, const hnh_comm_callbacks* cb, hnh_world** out);
 int hnh_world_destroy(hnh_world* w);
 int hnh_world_rank(hnh_world* w);

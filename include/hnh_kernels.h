@@ -335,6 +335,39 @@ int hnh_comm_reduce_scatter_f64(hnh_ctx* ctx, void* comm, const double* sendbuf,
 int hnh_comm_allreduce_f64(hnh_ctx* ctx, void* comm, const double* sendbuf, double* recvbuf, size_t count,
                            int stream);
 
+/* ---- peer-to-peer PULL over mapped peer memory (single node; no RCCL) -------------------------------------
+ * The second device-to-device transport behind the same schedules (host side: IpcWorld, world.hpp).  Replaces the same
+ * MPI calls as the RCCL section — MPI_Sendrecv of shiftDenseMatrix (distributed_sparse.h:351-361) and the Isend/Irecv
+ * set of CSRLocal::shiftCSR (SpmatLocal.hpp:200-259) — with the RECEIVER copying straight out of the sender's buffer:
+ *   hnh_ipc_export   the allocation that holds `ptr`, as a 64-byte handle another PROCESS of this node can open
+ *                    (hipIpcGetMemHandle of the allocation's base), plus ptr's offset in it;
+ *   hnh_ipc_open     maps a peer's allocation into this process (hipIpcOpenMemHandle; over xGMI when the peer owns
+ *                    another GPU, plainly when both processes share one); returns the base of the mapping;
+ *   hnh_ipc_pull     n copies peer -> local issued together from `stream`: mode HNH_IPC_PULL_ENGINE = one
+ *                    hipMemcpyAsync per source on auxiliary streams forked from and joined to `stream` (the copy
+ *                    engines: no compute units, every source's link busy at once), HNH_IPC_PULL_KERNEL = ONE
+ *                    gather-copy launch on `stream` (`wgs_per_copy` workgroups per source, loads over the links);
+ *   hnh_ipc_flags_*  a host shared-memory region (the processes' common mmap) made visible to the device; its
+ *                    64-bit words order the processes' STREAMS without a host round trip:
+ *   hnh_stream_write_flag / hnh_stream_wait_flag   `stream` stores `value` into a word after everything enqueued so
+ *                    far / holds `stream` until the word is >= `value` (stream memory operations of the command
+ *                    processor, or one-lane kernels with system-scope atomics: HNH_IPC_FLAGS=memop|kernel).
+ * Values only grow, so a wait never depends on WHEN the peer enqueued its write. */
+#define HNH_IPC_HANDLE_BYTES 64
+#define HNH_IPC_PULL_ENGINE 0
+#define HNH_IPC_PULL_KERNEL 1
+#define HNH_IPC_MAX_PULL 16
+int hnh_ipc_export(hnh_ctx* ctx, const void* ptr, void* handle_host /* HNH_IPC_HANDLE_BYTES */, uint64_t* offset,
+                   uint64_t* alloc_bytes);
+int hnh_ipc_open(hnh_ctx* ctx, const void* handle_host, uint64_t alloc_bytes, void** base);
+int hnh_ipc_close(hnh_ctx* ctx, void* base);
+int hnh_ipc_pull(hnh_ctx* ctx, int stream, int n, void* const* dst, const void* const* src, const size_t* bytes,
+                 int mode, int wgs_per_copy);
+int hnh_ipc_flags_register(hnh_ctx* ctx, void* host_shm, size_t bytes, void** device_view);
+int hnh_ipc_flags_unregister(hnh_ctx* ctx, void* host_shm);
+int hnh_stream_write_flag(hnh_ctx* ctx, int stream, void* flag_device, uint64_t value);
+int hnh_stream_wait_flag(hnh_ctx* ctx, int stream, void* flag_device, uint64_t value);
+
 #ifdef __cplusplus
 }
 #endif

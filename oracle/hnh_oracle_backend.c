@@ -17,10 +17,14 @@
  *   hnh_fill_f64                  : SpmatLocal::setValuesConstant, SpmatLocal.hpp:595-605
  *   hnh_hadamard_f64              : SValues.cwiseProduct(getCSRValues()), 15D_dense_shift.hpp:366
  */
-#define _POSIX_C_SOURCE 200809L /* clock_gettime */
+#define _GNU_SOURCE /* clock_gettime, process_vm_readv */
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/uio.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "hnh_kernels.h"
 
@@ -47,12 +51,34 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
 int hnh_ctx_destroy(hnh_ctx* c) { free(c); return HNH_OK; }
 const char* hnh_last_error(hnh_ctx* c) { return c ? c->err : "null context"; }
 void* hnh_ctx_stream(hnh_ctx* c, int s) { (void)c; (void)s; return NULL; }
+/* "device" blocks are remembered (base, size) so that the ipc double below can say which block a pointer lies in */
+typedef struct block { char* base; size_t bytes; struct block* next; } block;
+static block* g_blocks = NULL;
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 int hnh_malloc(hnh_ctx* c, size_t bytes, void** out) {
     if (!out) return HNH_ERR_INVALID;
     *out = malloc(bytes ? bytes : 16);
-    return *out ? HNH_OK : fail(c, HNH_ERR_NOMEM, "malloc failed");
+    if (!*out) return fail(c, HNH_ERR_NOMEM, "malloc failed");
+    block* b = (block*)malloc(sizeof(block));
+    if (b) {
+        b->base = (char*)*out;
+        b->bytes = bytes ? bytes : 16;
+        pthread_mutex_lock(&g_mu);
+        b->next = g_blocks;
+        g_blocks = b;
+        pthread_mutex_unlock(&g_mu);
+    }
+    return HNH_OK;
 }
-int hnh_free(hnh_ctx* c, void* p) { (void)c; free(p); return HNH_OK; }
+int hnh_free(hnh_ctx* c, void* p) {
+    (void)c;
+    pthread_mutex_lock(&g_mu);
+    for (block** q = &g_blocks; *q; q = &(*q)->next)
+        if ((*q)->base == (char*)p) { block* d = *q; *q = d->next; free(d); break; }
+    pthread_mutex_unlock(&g_mu);
+    free(p);
+    return HNH_OK;
+}
 int hnh_memcpy(hnh_ctx* c, void* dst, const void* src, size_t bytes, int kind, int stream) {
     (void)c; (void)kind; (void)stream;
     if (bytes) memmove(dst, src, bytes);
@@ -644,3 +670,81 @@ int hnh_comm_group_end(hnh_ctx* c) { (void)c; return HNH_OK; }
 int hnh_comm_allgather(hnh_ctx* c, void* comm, const void* s, void* r, size_t b, int st) { (void)comm; (void)s; (void)r; (void)b; (void)st; UNSUP(c); }
 int hnh_comm_reduce_scatter_f64(hnh_ctx* c, void* comm, const double* s, double* r, size_t n, int st) { (void)comm; (void)s; (void)r; (void)n; (void)st; UNSUP(c); }
 int hnh_comm_allreduce_f64(hnh_ctx* c, void* comm, const double* s, double* r, size_t n, int st) { (void)comm; (void)s; (void)r; (void)n; (void)st; UNSUP(c); }
+
+/* ---- the "ipc" section of the ABI between PROCESSES of this host: a handle is (pid, address); an opened block is a reserved,
+ * inaccessible address range standing for the peer's block; a pull reads the peer's memory with process_vm_readv; flag words
+ * live in the processes' common shared memory and, the double being synchronous, are stored / awaited on the spot. */
+typedef struct { long pid; unsigned long long base, bytes; } ipc_handle;
+typedef struct opened { char* local; size_t bytes; long pid; unsigned long long remote; struct opened* next; } opened;
+static opened* g_opened = NULL;
+int hnh_ipc_export(hnh_ctx* c, const void* ptr, void* handle_host, uint64_t* offset, uint64_t* alloc_bytes) {
+    if (!ptr || !handle_host || !offset || !alloc_bytes) return HNH_ERR_INVALID;
+    ipc_handle h = {(long)getpid(), 0, 0};
+    pthread_mutex_lock(&g_mu);
+    for (block* b = g_blocks; b; b = b->next)
+        if ((const char*)ptr >= b->base && (const char*)ptr < b->base + b->bytes) { h.base = (unsigned long long)(uintptr_t)b->base; h.bytes = b->bytes; break; }
+    pthread_mutex_unlock(&g_mu);
+    if (!h.bytes) return fail(c, HNH_ERR_INVALID, "hnh_ipc_export: not a block of hnh_malloc");
+    memset(handle_host, 0, HNH_IPC_HANDLE_BYTES);
+    memcpy(handle_host, &h, sizeof h);
+    *offset = (uint64_t)((uintptr_t)ptr - (uintptr_t)h.base);
+    *alloc_bytes = h.bytes;
+    return HNH_OK;
+}
+int hnh_ipc_open(hnh_ctx* c, const void* handle_host, uint64_t alloc_bytes, void** base) {
+    if (!handle_host || !base) return HNH_ERR_INVALID;
+    ipc_handle h;
+    memcpy(&h, handle_host, sizeof h);
+    if (h.bytes != alloc_bytes || !h.bytes) return fail(c, HNH_ERR_INVALID, "hnh_ipc_open: bad handle");
+    void* r = mmap(NULL, (size_t)h.bytes, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    opened* o = (opened*)malloc(sizeof(opened));
+    if (r == MAP_FAILED || !o) return fail(c, HNH_ERR_NOMEM, "hnh_ipc_open: cannot reserve the address range");
+    o->local = (char*)r; o->bytes = (size_t)h.bytes; o->pid = h.pid; o->remote = h.base;
+    pthread_mutex_lock(&g_mu);
+    o->next = g_opened;
+    g_opened = o;
+    pthread_mutex_unlock(&g_mu);
+    *base = r;
+    return HNH_OK;
+}
+int hnh_ipc_close(hnh_ctx* c, void* base) {
+    (void)c;
+    pthread_mutex_lock(&g_mu);
+    for (opened** q = &g_opened; *q; q = &(*q)->next)
+        if ((*q)->local == (char*)base) { opened* d = *q; *q = d->next; munmap(d->local, d->bytes); free(d); break; }
+    pthread_mutex_unlock(&g_mu);
+    return HNH_OK;
+}
+int hnh_ipc_pull(hnh_ctx* c, int stream, int n, void* const* dst, const void* const* src, const size_t* bytes, int mode, int wgs) {
+    (void)stream; (void)mode; (void)wgs;
+    for (int i = 0; i < n; i++) {
+        if (!bytes[i]) continue;
+        long pid = 0;
+        unsigned long long remote = 0;
+        pthread_mutex_lock(&g_mu);
+        for (opened* o = g_opened; o; o = o->next)
+            if ((const char*)src[i] >= o->local && (const char*)src[i] + bytes[i] <= o->local + o->bytes) { pid = o->pid; remote = o->remote + (unsigned long long)((const char*)src[i] - o->local); break; }
+        pthread_mutex_unlock(&g_mu);
+        if (!pid) return fail(c, HNH_ERR_INVALID, "hnh_ipc_pull: source is not inside an opened block");
+        size_t done = 0;
+        while (done < bytes[i]) {
+            struct iovec l = {(char*)dst[i] + done, bytes[i] - done}, r = {(void*)(uintptr_t)(remote + done), bytes[i] - done};
+            ssize_t k = process_vm_readv((pid_t)pid, &l, 1, &r, 1, 0);
+            if (k <= 0) return fail(c, HNH_ERR_DEVICE, "hnh_ipc_pull: process_vm_readv failed (ptrace permission?)");
+            done += (size_t)k;
+        }
+    }
+    return HNH_OK;
+}
+int hnh_ipc_flags_register(hnh_ctx* c, void* host_shm, size_t bytes, void** device_view) { (void)c; (void)bytes; *device_view = host_shm; return HNH_OK; }
+int hnh_ipc_flags_unregister(hnh_ctx* c, void* host_shm) { (void)c; (void)host_shm; return HNH_OK; }
+int hnh_stream_write_flag(hnh_ctx* c, int stream, void* f, uint64_t v) { (void)c; (void)stream; __atomic_store_n((uint64_t*)f, v, __ATOMIC_RELEASE); return HNH_OK; }
+int hnh_stream_wait_flag(hnh_ctx* c, int stream, void* f, uint64_t v) {
+    (void)stream;
+    const double t0 = now_ms();
+    for (unsigned spins = 0; __atomic_load_n((uint64_t*)f, __ATOMIC_ACQUIRE) < v; spins++) {
+        if (spins > 1000) { struct timespec ts = {0, 50000}; nanosleep(&ts, NULL); }
+        if ((spins & 1023) == 0 && now_ms() - t0 > 120000.0) return fail(c, HNH_ERR_DEVICE, "hnh_stream_wait_flag: the peer never raised the flag");
+    }
+    return HNH_OK;
+}

@@ -45,7 +45,7 @@ ALL_8 = ("15d_fusion2:1:mesh:4;15d_fusion2:1:mesh:8;15d_fusion2:1:relay:1;15d_fu
          "15d_sparse:2:mesh:4;25d_dense_replicate:2:mesh:4;25d_sparse_replicate:2:mesh:4;als@15d_fusion2:1:mesh:4")
 
 
-@pytest.mark.parametrize("nranks,configs", [(2, ALL_2), (4, ALL_4), (8, ALL_8)])
+@pytest.mark.parametrize("nranks,configs", [(2, ALL_2), (4, ALL_4), (8, ALL_8)], ids=["2", "4", "8"])
 def test_schedules_over_rccl(nranks, configs):
     """All five schedules (relay ring, chunked mesh fetch, replication collectives as explicit-peer groups, ALS with the held
     operand) on `nranks` GPUs over RCCL, element-wise against the reference's golden vectors, after the transport preflight."""
@@ -55,6 +55,24 @@ def test_schedules_over_rccl(nranks, configs):
         procs, outs = launch(nranks, case, configs)
         assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
         assert "RCCL_OK" in outs[0], outs[0][-3000:]
+
+
+@pytest.mark.parametrize("nranks,configs,pull,flags", [(2, ALL_2, "engine", "memop"), (2, ALL_2, "kernel", "kernel"), (4, ALL_4, "engine", "memop"),
+                                                         (4, ALL_4, "kernel", "memop"), (8, ALL_8, "engine", "memop"), (8, ALL_8, "kernel", "memop")],
+                         ids=["2-engine-memop", "2-kernel-flagkernels", "4-engine-memop", "4-kernel-memop", "8-engine-memop", "8-kernel-memop"])
+def test_schedules_over_ipc(nranks, configs, pull, flags):
+    """The ipc-pull transport ACROSS PROCESSES on whatever GPUs are here (one is enough: the processes share it): all five
+    schedules (relay ring, chunked mesh fetch, replication collectives as explicit-peer groups, ALS with the held operand) on
+    the HIP kernels, every transfer a device-to-device copy out of the peer's mapped buffer ordered by stream flag words —
+    element-wise against the reference's golden vectors, after the transport preflight.  Both ways of pulling (copy engines
+    on forked streams / one gather-copy kernel) and both ways of signalling (stream memory operations / flag kernels)."""
+    if gpus() < 1:
+        pytest.skip("needs a GPU")
+    from test_ipc_world_cpu import launch_ipc
+    for case in ("er8_r16", "ragged_r8"):
+        procs, outs = launch_ipc(nranks, case, configs, backend="hip", timeout=900, extra_env={"HNH_IPC_PULL": pull, "HNH_IPC_FLAGS": flags})
+        assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+        assert "IPC_OK" in outs[0], outs[0][-3000:]
 
 
 def run_bench(n, *extra, timeout=900):
