@@ -87,7 +87,26 @@ SIGNATURES = {
     "hnh_comm_allgather": (_i32, [_vp, _vp, _vp, _vp, _sz, _i32]),
     "hnh_comm_reduce_scatter_f64": (_i32, [_vp, _vp, _vp, _vp, _sz, _i32]),
     "hnh_comm_allreduce_f64": (_i32, [_vp, _vp, _vp, _vp, _sz, _i32]),
+    "hnh_ipc_export": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "hnh_ipc_open": (_i32, [_vp, _vp, C.c_uint64, C.POINTER(_vp)]),
+    "hnh_ipc_close": (_i32, [_vp, _vp]),
+    "hnh_ipc_pull": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32]),
+    "hnh_ipc_flags_register": (_i32, [_vp, _vp, _sz, C.POINTER(_vp)]),
+    "hnh_ipc_flags_unregister": (_i32, [_vp, _vp]),
+    "hnh_stream_write_flag": (_i32, [_vp, _i32, _vp, C.c_uint64]),
+    "hnh_stream_wait_flag": (_i32, [_vp, _i32, _vp, C.c_uint64]),
+    "hnh_csr_plan_create": (_i32, [_vp, C.POINTER(_vp)]),
+    "hnh_csr_plan_destroy": (_i32, [_vp, _vp]),
+    "hnh_sddmm_csr_p": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32]),
+    "hnh_spmm_csr_p": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32]),
+    "hnh_fused_sddmm_spmm_csr_p": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _vp, _vp, _i32]),
 }
+
+
+class CsrBlock(C.Structure):
+    """struct hnh_csr_block"""
+    _fields_ = [("rows", C.c_int64), ("nnz", C.c_int64), ("cols", C.c_int64), ("max_row_nnz", C.c_int32), ("reserved", C.c_int32),
+                ("rowptr", C.c_void_p), ("col_idx", C.c_void_p), ("plan", C.c_void_p)]
 
 class CgUpdate(C.Structure):
     """struct hnh_cg_update"""

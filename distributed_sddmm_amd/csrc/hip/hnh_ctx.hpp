@@ -17,6 +17,7 @@ struct hnh_ctx {
     size_t long_rows_cap[2] = {0, 0};
     void* long_partials[2] = {nullptr, nullptr};
     size_t long_partials_bytes[2] = {0, 0};
+    size_t hub_scratch_bytes = (size_t)2 << 30;  // HNH_HUB_SCRATCH_MB: bound of long_partials per stream; segments beyond it use atomics
     bool hub_atomics = false;  // HNH_HUB_ATOMICS=1: combine hub-row segments with fp64 atomics (round 1's way) instead of the ordered reduction
     // per-row panel boundaries of the Infinity-Cache panels (one per stream): (panels - 1) x rows int32
     void* panel_split[2] = {nullptr, nullptr};
@@ -25,7 +26,10 @@ struct hnh_ctx {
     int row_waves_cap = -1;  // HNH_ROW_WAVES_CAP=k: 1..7 = at most k waves per SIMD for every row-kernel launch, 0 = never cap; unset = the
                              // library's rule (uniform blocks of certain widths run at 5, see row_occupancy_pad in hnh_kernels.hip)
     int long_grid = 1024;           // workgroups of the hub-row segment pass (HNH_LONG_GRID, measurement aid)
-    int comm_cus = 0;               // HNH_COMM_CUS=<n>: compute units reserved for the communication stream (0 = streams share all CUs)
+    int comm_cus = 0;               // compute units masked off streams[HNH_STREAM_COMPUTE] (HNH_COMM_CUS, default 16; 0 = no mask)
+    // the unmasked twin of the compute stream for launches that want every CU (hnh::WideLaunch); null when nothing is masked
+    hipStream_t wide = nullptr;
+    hipEvent_t wide_fork = nullptr, wide_join = nullptr;
     bool narrow_rows = true;        // HNH_NARROW_ROWS=0: A/B switch — R = 8 / 16 / 32 through the general row loop instead of the line-granular one
     bool panels_with_hubs = false;  // HNH_PANELS_WITH_HUBS=1: panel the short rows of blocks that also have hub rows
     int long_row_override = 0;      // HNH_LONG_ROW=<multiple of 64, 64..1984>: fixed hub-row threshold instead of the adaptive one (measurement aid)
@@ -51,6 +55,30 @@ inline int check_hip(hnh_ctx* ctx, hipError_t e, const char* what) {
 }
 
 inline bool valid_stream(int s) { return s == HNH_STREAM_COMPUTE || s == HNH_STREAM_COMM; }
+
+// Scope of an operation that runs on ALL compute units although the compute stream is masked: the constructor makes the wide
+// stream wait for what the compute stream has enqueued so far, `stream()` is where the operation's launches go, finish()
+// makes the compute stream wait for them.  Everywhere else (no mask, or the communication stream) it is the stream itself.
+struct WideLaunch {
+    hnh_ctx* ctx;
+    hipStream_t st;
+    bool forked = false;
+    int status = HNH_OK;
+    WideLaunch(hnh_ctx* c, int sidx) : ctx(c), st(c->streams[sidx]) {
+        if (sidx != HNH_STREAM_COMPUTE || c->wide == nullptr) return;
+        status = check_hip(c, hipEventRecord(c->wide_fork, st), "hipEventRecord");
+        if (status == HNH_OK) status = check_hip(c, hipStreamWaitEvent(c->wide, c->wide_fork, 0), "hipStreamWaitEvent");
+        forked = status == HNH_OK;
+    }
+    hipStream_t stream() const { return forked ? ctx->wide : st; }
+    int finish(int rc) {
+        if (!forked) return rc;
+        forked = false;
+        int j = check_hip(ctx, hipEventRecord(ctx->wide_join, ctx->wide), "hipEventRecord");
+        if (j == HNH_OK) j = check_hip(ctx, hipStreamWaitEvent(st, ctx->wide_join, 0), "hipStreamWaitEvent");
+        return rc != HNH_OK ? rc : j;
+    }
+};
 
 }  // namespace hnh
 

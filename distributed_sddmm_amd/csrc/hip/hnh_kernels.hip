@@ -24,6 +24,7 @@
 //   * Launch: rows/(256/LPR) workgroups of 256 threads (cfg2: 262 144 workgroups >> 256 CUs); consecutive
 //     workgroups own consecutive rows, so the CSR index stream is read in order.
 #include <hip/hip_runtime.h>
+#include <new>
 #include <cstdint>
 #include "hnh_ctx.hpp"
 
@@ -1474,6 +1475,30 @@ Shape pick_shape(int R, bool vec_ok) {
     return s;
 }
 
+}  // namespace
+
+// Structure-only results of the row passes for ONE block whose index arrays keep their contents (hnh_csr_plan of hnh_kernels.h).
+struct hnh_csr_plan {
+    // whose structure this is (checked on every use: a plan handed to another block is a caller error, not a silent wrong answer)
+    const int32_t* rowptr = nullptr;
+    const int32_t* colidx = nullptr;
+    int64_t rows = -1, nnz = -1;
+    struct Split {  // per-row panel boundaries for one (panels, width)
+        int panels = 0, width = 0;
+        int32_t* split = nullptr;
+        unsigned long age = 0;
+    } splits[3];
+    unsigned long clock = 0;
+    // hub-row work list for one threshold
+    int threshold = 0;  // 0 = not built
+    int2* items = nullptr;
+    int* count = nullptr;
+    int4* hub_rows = nullptr;
+    int n_items = 0, n_hub_rows = 0;  // exact, read back once
+};
+
+namespace {
+
 struct LongCtl {
     bool enabled = false;
     int2* items = nullptr;
@@ -1516,8 +1541,10 @@ int long_row_threshold(const hnh_ctx* ctx, int64_t rows, int64_t nnz) {
 // nnz: number of nonzeros (< 0 = unknown -> read back from rowptr[rows], one 4-byte synchronous copy).
 // out_pitch: row pitch (in doubles) of the output the segments add to, 0 for SDDMM — sizes the partial-row scratch.
 // build_list = false: the launch only has to SKIP the hub rows (a window that is not the pass's last one) — threshold only.
+int partial_scratch(hnh_ctx* ctx, hipStream_t st, int sidx, size_t items_bound, int64_t out_pitch, LongCtl* lc);
+
 int prepare_long(hnh_ctx* ctx, hipStream_t st, int sidx, int64_t rows, const int32_t* rowptr, int64_t nnz, int max_row_nnz,
-                 int64_t out_pitch, LongCtl* lc, bool build_list = true) {
+                 int64_t out_pitch, LongCtl* lc, bool build_list = true, hnh_csr_plan* plan = nullptr) {
     if (max_row_nnz >= 0 && max_row_nnz <= (ctx->long_row_override > 0 ? ctx->long_row_override : kLongRowMin)) return HNH_OK;
     if (nnz < 0) {
         int last = 0;
@@ -1533,6 +1560,40 @@ int prepare_long(hnh_ctx* ctx, hipStream_t st, int sidx, int64_t rows, const int
         return HNH_OK;
     }
     const size_t cap = (size_t)(nnz / kLongSeg + nnz / threshold + 16);
+    if (plan != nullptr) {
+        // the list depends on rowptr and the threshold only: built once, its exact size read back once, then no call launches
+        // build_long_list_kernel again (it was 0.3 ms of a 6.7 ms fused call on R-MAT 2^20)
+        if (plan->threshold != threshold) {
+            HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
+            for (void* p : {(void*)plan->items, (void*)plan->count, (void*)plan->hub_rows})
+                if (p) HNH_TRY_HIP(ctx, hipFree(p));
+            plan->items = nullptr; plan->count = nullptr; plan->hub_rows = nullptr; plan->threshold = 0;
+            const size_t cap_rows = (size_t)(nnz / threshold + 16);
+            HNH_TRY_HIP(ctx, hipMalloc((void**)&plan->items, cap * sizeof(int2)));
+            HNH_TRY_HIP(ctx, hipMalloc((void**)&plan->count, 2 * sizeof(int)));
+            HNH_TRY_HIP(ctx, hipMalloc((void**)&plan->hub_rows, cap_rows * sizeof(int4)));
+            HNH_TRY_HIP(ctx, hipMemsetAsync(plan->count, 0, 2 * sizeof(int), st));
+            hipLaunchKernelGGL(build_long_list_kernel, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, rows, rowptr, plan->items,
+                               plan->count, (int)cap, threshold, plan->hub_rows, (int)cap_rows);
+            if (int rc = hnh::check_hip(ctx, hipGetLastError(), "build_long_list_kernel launch")) return rc;
+            int counts[2] = {0, 0};
+            HNH_TRY_HIP(ctx, hipMemcpyAsync(counts, plan->count, sizeof counts, hipMemcpyDeviceToHost, st));
+            HNH_TRY_HIP(ctx, hipStreamSynchronize(st));  // once per block: later calls may run on any stream
+            plan->n_items = counts[0];
+            plan->n_hub_rows = counts[1];
+            plan->threshold = threshold;
+        }
+        if (plan->n_items == 0) return HNH_OK;  // no row above the threshold after all (the hint was an upper bound)
+        lc->items = plan->items;
+        lc->count = plan->count;
+        lc->capacity = plan->n_items;
+        lc->hub_rows = plan->hub_rows;
+        lc->capacity_rows = plan->n_hub_rows;
+        lc->enabled = true;
+        lc->threshold = threshold;
+        if (out_pitch > 0 && !ctx->hub_atomics) return partial_scratch(ctx, st, sidx, (size_t)plan->n_items, out_pitch, lc);
+        return HNH_OK;
+    }
     if (ctx->long_cap[sidx] < cap) {
         HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
         if (ctx->long_items[sidx]) HNH_TRY_HIP(ctx, hipFree(ctx->long_items[sidx]));
@@ -1549,28 +1610,8 @@ int prepare_long(hnh_ctx* ctx, hipStream_t st, int sidx, int64_t rows, const int
         HNH_TRY_HIP(ctx, hipMalloc(&ctx->long_rows[sidx], cap_rows * sizeof(int4)));
         ctx->long_rows_cap[sidx] = cap_rows;
     }
-    // Partial output rows of the segments (ordered reduction instead of atomics: results do not depend on the order in which
-    // segments finish).  `cap` bounds the number of items whatever the matrix looks like: nnz * pitch / 16 bytes at worst
-    // (8 bytes per nonzero at R = 128), allocated once per stream and kept.
-    if (out_pitch > 0 && !ctx->hub_atomics) {
-        // `cap` bounds the item count for ANY matrix of this size (the real count is known on the device only), which at wide rows
-        // would be more scratch than the CSR block itself: past kHubScratchBytes the remaining segments combine with atomics
-        // (exact within the parity tolerance, no longer bit-reproducible — 2 GiB hold the segments of 5e8 hub-row nonzeros at R = 128)
-        constexpr size_t kHubScratchBytes = (size_t)2 << 30;
-        size_t items = cap;
-        if (items * (size_t)out_pitch * sizeof(double) > kHubScratchBytes) items = kHubScratchBytes / ((size_t)out_pitch * sizeof(double));
-        const size_t need = items * (size_t)out_pitch * sizeof(double);
-        if (ctx->long_partials_bytes[sidx] < need) {
-            HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
-            if (ctx->long_partials[sidx]) HNH_TRY_HIP(ctx, hipFree(ctx->long_partials[sidx]));
-            ctx->long_partials[sidx] = nullptr;
-            ctx->long_partials_bytes[sidx] = 0;
-            HNH_TRY_HIP(ctx, hipMalloc(&ctx->long_partials[sidx], need));
-            ctx->long_partials_bytes[sidx] = need;
-        }
-        lc->partials = static_cast<double*>(ctx->long_partials[sidx]);
-        lc->partial_items = (int)items;
-    }
+    if (out_pitch > 0 && !ctx->hub_atomics)
+        if (int rc = partial_scratch(ctx, st, sidx, cap, out_pitch, lc)) return rc;
     lc->items = static_cast<int2*>(ctx->long_items[sidx]);
     lc->count = ctx->long_count[sidx];
     lc->capacity = (int)cap;
@@ -1583,6 +1624,29 @@ int prepare_long(hnh_ctx* ctx, hipStream_t st, int sidx, int64_t rows, const int
     hipLaunchKernelGGL(build_long_list_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, rows, rowptr, lc->items, lc->count, lc->capacity, threshold,
                        lc->hub_rows, lc->capacity_rows);
     return hnh::check_hip(ctx, hipGetLastError(), "build_long_list_kernel launch");
+}
+
+// Partial output rows of the hub-row segments (ordered reduction instead of atomics: results do not depend on the order in which
+// segments finish): one row of `out_pitch` doubles per segment, allocated once per stream and kept.  `items_bound` is the exact
+// segment count when a plan knows it, else a bound that holds for ANY matrix of the block's size (nnz * pitch / 16 bytes at worst),
+// which at wide rows would be more scratch than the CSR block itself: past ctx->hub_scratch_bytes (HNH_HUB_SCRATCH_MB, default
+// 2 GiB = the segments of 5e8 hub-row nonzeros at R = 128) the remaining segments combine with atomics — exact within the
+// parity tolerance, no longer bit-reproducible.
+int partial_scratch(hnh_ctx* ctx, hipStream_t st, int sidx, size_t items_bound, int64_t out_pitch, LongCtl* lc) {
+    size_t items = items_bound;
+    if (items * (size_t)out_pitch * sizeof(double) > ctx->hub_scratch_bytes) items = ctx->hub_scratch_bytes / ((size_t)out_pitch * sizeof(double));
+    const size_t need = items * (size_t)out_pitch * sizeof(double);
+    if (ctx->long_partials_bytes[sidx] < need) {
+        HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
+        if (ctx->long_partials[sidx]) HNH_TRY_HIP(ctx, hipFree(ctx->long_partials[sidx]));
+        ctx->long_partials[sidx] = nullptr;
+        ctx->long_partials_bytes[sidx] = 0;
+        HNH_TRY_HIP(ctx, hipMalloc(&ctx->long_partials[sidx], need));
+        ctx->long_partials_bytes[sidx] = need;
+    }
+    lc->partials = items > 0 ? static_cast<double*>(ctx->long_partials[sidx]) : nullptr;
+    lc->partial_items = (int)items;
+    return HNH_OK;
 }
 
 template <Op OP, int LPR, int VEC, int W, bool EXACT, bool NARROW = false>
@@ -1611,8 +1675,11 @@ int launch_row(hnh_ctx* ctx, hipStream_t st, const LongCtl& lc, int64_t rows, co
                            lc.partial_items);
         if (int rc = hnh::check_hip(ctx, hipGetLastError(), "long_row_kernel launch")) return rc;
         if (partials != nullptr) {
-            const bool pairs = (ld % 2 == 0) && (col0 % 2 == 0) && (ncols % 2 == 0) && aligned16(Out);  // 16-byte accesses
-            const bool epi = fused_op(OP) && (flags & kInternalEpilogue);  // (dispatch_row grants it only for whole rows, W as here)
+            const bool epi = fused_op(OP) && (flags & kInternalEpilogue);  // (dispatch_row grants it only for whole rows)
+            // 16-byte accesses: to the output row, and with an epilogue to every row operand it reads or writes
+            const bool pairs = (ld % 2 == 0) && (col0 % 2 == 0) && (ncols % 2 == 0) && aligned16(Out) &&
+                               (!epi || (aligned16(X) && (ex.cg_x == nullptr || (aligned16(ex.cg_x) && aligned16(ex.cg_r) && aligned16(ex.cg_p))) &&
+                                         (ex.relu_dst == nullptr || (aligned16(ex.relu_dst) && ex.relu_ld % 2 == 0))));
             if (pairs)
                 hipLaunchKernelGGL(reduce_long_kernel<2>, dim3(2048), dim3(kBlock), 0, st, lc.hub_rows, lc.count, lc.capacity_rows, partials,
                                    lc.partial_items, Out, ld, col0, ncols, X, ex, epi);
@@ -1688,10 +1755,20 @@ template <Op OP>
 int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t rows, int64_t nnz, int max_row_nnz, int64_t cols,
                  const int32_t* rowptr, const int32_t* colidx, double* values, const double* svalues, const double* X,
                  const double* Y, double* Out, int R, unsigned flags, const Extras& ex = Extras(), bool* epilogue_done = nullptr,
-                 const hnh_csr_window* win = nullptr) {
+                 const hnh_csr_window* win = nullptr, hnh_csr_plan* plan = nullptr) {
+    if (plan != nullptr) {
+        if (plan->rowptr == nullptr) {  // first use: the plan is this block's from now on
+            plan->rowptr = rowptr;
+            plan->colidx = colidx;
+            plan->rows = rows;
+            plan->nnz = nnz;
+        } else if (plan->rowptr != rowptr || plan->colidx != colidx || plan->rows != rows || plan->nnz != nnz) {
+            return hnh::fail(ctx, HNH_ERR_INVALID, "the structure plan belongs to another block");
+        }
+    }
     LongCtl lc;
     if (int rc = prepare_long(ctx, st, sidx, rows, rowptr, nnz, max_row_nnz, (OP != Op::kSddmm) ? (int64_t)R : 0, &lc,
-                              win == nullptr || win->last != 0))
+                              win == nullptr || win->last != 0, plan))
         return rc;
     if (!lc.enabled || ctx->row_waves_cap > 0) lc.lds_pad = row_occupancy_pad(ctx, s, rows, nnz, max_row_nnz);  // (hub rows = a skewed block)
     const bool single_pass = s.exact || R <= 64 * s.w * 4;
@@ -1735,18 +1812,43 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
     const int panels = (single_pass && (!lc.enabled || ctx->panels_with_hubs)) ? panel_count(ctx, cols, R) : 1;
     if (panels > 1) {
         const size_t need = (size_t)(panels - 1) * (size_t)rows * sizeof(int32_t);
-        if (ctx->panel_cap[sidx] < need) {
-            HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
-            if (ctx->panel_split[sidx]) HNH_TRY_HIP(ctx, hipFree(ctx->panel_split[sidx]));
-            ctx->panel_split[sidx] = nullptr;
-            HNH_TRY_HIP(ctx, hipMalloc(&ctx->panel_split[sidx], need));
-            ctx->panel_cap[sidx] = need;
-        }
-        int32_t* split = static_cast<int32_t*>(ctx->panel_split[sidx]);
         const int width = (int)((cols + panels - 1) / panels);
-        hipLaunchKernelGGL(panel_split_kernel, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, rows, rowptr, colidx, panels,
-                           width, split);
-        if (int rc = hnh::check_hip(ctx, hipGetLastError(), "panel_split_kernel launch")) return rc;
+        int32_t* split = nullptr;
+        if (plan != nullptr) {
+            // the boundaries depend on the structure and (panels, width) only: computed once per block and width class
+            hnh_csr_plan::Split* slot = nullptr;
+            for (auto& sp : plan->splits)
+                if (sp.split != nullptr && sp.panels == panels && sp.width == width) slot = &sp;
+            if (slot == nullptr) {
+                slot = &plan->splits[0];
+                for (auto& sp : plan->splits)
+                    if (sp.split == nullptr || (slot->split != nullptr && sp.age < slot->age)) slot = &sp;
+                HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
+                if (slot->split) HNH_TRY_HIP(ctx, hipFree(slot->split));
+                slot->split = nullptr;
+                HNH_TRY_HIP(ctx, hipMalloc((void**)&slot->split, need));
+                slot->panels = panels;
+                slot->width = width;
+                hipLaunchKernelGGL(panel_split_kernel, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, rows, rowptr, colidx,
+                                   panels, width, slot->split);
+                if (int rc = hnh::check_hip(ctx, hipGetLastError(), "panel_split_kernel launch")) return rc;
+                HNH_TRY_HIP(ctx, hipStreamSynchronize(st));  // once per block and width class: later calls may run on any stream
+            }
+            slot->age = ++plan->clock;
+            split = slot->split;
+        } else {
+            if (ctx->panel_cap[sidx] < need) {
+                HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
+                if (ctx->panel_split[sidx]) HNH_TRY_HIP(ctx, hipFree(ctx->panel_split[sidx]));
+                ctx->panel_split[sidx] = nullptr;
+                HNH_TRY_HIP(ctx, hipMalloc(&ctx->panel_split[sidx], need));
+                ctx->panel_cap[sidx] = need;
+            }
+            split = static_cast<int32_t*>(ctx->panel_split[sidx]);
+            hipLaunchKernelGGL(panel_split_kernel, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, rows, rowptr, colidx, panels,
+                               width, split);
+            if (int rc = hnh::check_hip(ctx, hipGetLastError(), "panel_split_kernel launch")) return rc;
+        }
         for (int q = 0; q < panels; q++) {
             const int32_t* beg_ptr = (q == 0) ? rowptr : split + (size_t)(q - 1) * rows;
             const int32_t* end_ptr = (q == panels - 1) ? rowptr + 1 : split + (size_t)q * rows;
@@ -1815,8 +1917,10 @@ int hnh_sddmm_csr_ex(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const in
     if (rows == 0) return HNH_OK;
     if (!rowptr || !col_idx || !values || !X || !Y) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sddmm_csr: null pointer");
     const Shape s = pick_shape(R, aligned16(X) && aligned16(Y));
-    return dispatch_row<Op::kSddmm>(ctx, ctx->streams[stream], stream, s, rows, nnz, max_row_nnz, cols, rowptr, col_idx, values, nullptr, X,
-                                    Y, nullptr, R, 0u);
+    hnh::WideLaunch wide(ctx, stream);  // the stand-alone SDDMM does more arithmetic per byte than the other row passes: all CUs
+    if (wide.status != HNH_OK) return wide.status;
+    return wide.finish(dispatch_row<Op::kSddmm>(ctx, wide.stream(), stream, s, rows, nnz, max_row_nnz, cols, rowptr, col_idx, values, nullptr, X,
+                                                Y, nullptr, R, 0u));
 }
 
 int hnh_sddmm_csr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
@@ -1875,7 +1979,7 @@ int launch_row_epilogue(hnh_ctx* ctx, hipStream_t st, double* Out, const double*
 
 int fused_impl(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values, const double* svalues,
                const double* X, const double* Y, double* Out, int R, unsigned flags, int64_t nnz_in, int max_row_nnz, int64_t cols,
-               const hnh_fused_extras* extras, const hnh_csr_window* win, int stream);
+               const hnh_fused_extras* extras, const hnh_csr_window* win, int stream, hnh_csr_plan* plan = nullptr);
 
 int check_extras(hnh_ctx* ctx, unsigned flags, const hnh_fused_extras* extras, const double* X, const double* Out, Extras* ex, bool* want_epilogue,
                  const char* who) {
@@ -1931,7 +2035,7 @@ int hnh_fused_sddmm_spmm_csr_w(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr
 namespace {
 int fused_impl(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values, const double* svalues,
                const double* X, const double* Y, double* Out, int R, unsigned flags, int64_t nnz_in, int max_row_nnz, int64_t cols,
-               const hnh_fused_extras* extras, const hnh_csr_window* win, int stream) {
+               const hnh_fused_extras* extras, const hnh_csr_window* win, int stream, hnh_csr_plan* plan) {
     HNH_ENTER(ctx, stream);
     if (int rc = check_common(ctx, rows, R, "hnh_fused_sddmm_spmm_csr")) return rc;
     Extras ex;
@@ -1948,7 +2052,7 @@ int fused_impl(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t*
     if (s.exact || R <= 256 * s.w) {  // one pass: an exact instance, or a bounds-checked one wide enough for the whole row
         bool done = false;
         if (int rc = dispatch_row<Op::kFused>(ctx, st, stream, s, rows, nnz_in, max_row_nnz, cols, rowptr, col_idx, values, svalues, X, Y, Out, R,
-                                              flags, ex, want_epilogue ? &done : nullptr, win))
+                                              flags, ex, want_epilogue ? &done : nullptr, win, plan))
             return rc;
         if (want_epilogue && !done) return launch_row_epilogue(ctx, st, Out, X, ex, rows, R);
         return HNH_OK;
@@ -1983,7 +2087,7 @@ int fused_impl(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t*
         if (int rc = on_values(0)) return rc;
     if (flags & HNH_FUSED_OUT_OVERWRITE) HNH_TRY_HIP(ctx, hipMemsetAsync(Out, 0, sizeof(double) * (size_t)rows * R, st));
     if (int rc = dispatch_row<Op::kSddmm>(ctx, st, stream, s, rows, nnz, max_row_nnz, cols, rowptr, col_idx, values, nullptr, X, Y, nullptr, R, 0u,
-                                          Extras(), nullptr, win))
+                                          Extras(), nullptr, win, plan))
         return rc;
     if (flags & HNH_FUSED_LEAKY_RELU) {
         if (svalues) {
@@ -1993,7 +2097,7 @@ int fused_impl(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t*
         if (int rc = on_values(1)) return rc;
     }
     if (int rc = dispatch_row<Op::kSpmm>(ctx, st, stream, s, rows, nnz, max_row_nnz, cols, rowptr, col_idx, values, svalues, Y, nullptr, Out, R, 0u,
-                                         Extras(), nullptr, win))
+                                         Extras(), nullptr, win, plan))
         return rc;
     if (want_epilogue) return launch_row_epilogue(ctx, st, Out, X, ex, rows, R);
     return HNH_OK;
@@ -2026,8 +2130,10 @@ int hnh_sddmm_csr_w(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int
     if (rows == 0) return HNH_OK;
     if (!rowptr || !col_idx || !values || !X || !Y || !window) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sddmm_csr_w: null pointer");
     const Shape s = pick_shape(R, aligned16(X) && aligned16(Y));
-    return dispatch_row<Op::kSddmm>(ctx, ctx->streams[stream], stream, s, rows, nnz, max_row_nnz, -1, rowptr, col_idx, values, nullptr, X, Y,
-                                    nullptr, R, 0u, Extras(), nullptr, window);
+    hnh::WideLaunch wide(ctx, stream);
+    if (wide.status != HNH_OK) return wide.status;
+    return wide.finish(dispatch_row<Op::kSddmm>(ctx, wide.stream(), stream, s, rows, nnz, max_row_nnz, -1, rowptr, col_idx, values, nullptr, X, Y,
+                                                nullptr, R, 0u, Extras(), nullptr, window));
 }
 
 int hnh_spmm_csr_w(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values, const double* X,
@@ -2040,6 +2146,62 @@ int hnh_spmm_csr_w(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, const int3
     const Shape s = pick_shape(R, aligned16(X) && aligned16(Out));
     return dispatch_row<Op::kSpmm>(ctx, ctx->streams[stream], stream, s, rows, nnz, max_row_nnz, -1, rowptr, col_idx,
                                    const_cast<double*>(values), nullptr, X, nullptr, Out, R, 0u, Extras(), nullptr, window);
+}
+
+int hnh_csr_plan_create(hnh_ctx* ctx, hnh_csr_plan** out) {
+    if (!ctx || !out) return HNH_ERR_INVALID;
+    *out = new (std::nothrow) hnh_csr_plan();
+    return *out ? HNH_OK : hnh::fail(ctx, HNH_ERR_NOMEM, "hnh_csr_plan_create: out of memory");
+}
+
+int hnh_csr_plan_destroy(hnh_ctx* ctx, hnh_csr_plan* plan) {
+    if (!ctx) return HNH_ERR_INVALID;
+    if (!plan) return HNH_OK;
+    HNH_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    for (int s = 0; s < 2; s++)
+        if (ctx->streams[s]) HNH_TRY_HIP(ctx, hipStreamSynchronize(ctx->streams[s]));
+    if (ctx->wide) HNH_TRY_HIP(ctx, hipStreamSynchronize(ctx->wide));
+    for (auto& sp : plan->splits)
+        if (sp.split) (void)hipFree(sp.split);
+    for (void* p : {(void*)plan->items, (void*)plan->count, (void*)plan->hub_rows})
+        if (p) (void)hipFree(p);
+    delete plan;
+    return HNH_OK;
+}
+
+int hnh_sddmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* b, double* values, const double* X, const double* Y, int R, const hnh_csr_window* window,
+                    int stream) {
+    HNH_ENTER(ctx, stream);
+    if (!b) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sddmm_csr_p: null block");
+    if (int rc = check_common(ctx, b->rows, R, "hnh_sddmm_csr_p")) return rc;
+    if (b->rows == 0) return HNH_OK;
+    if (!b->rowptr || !b->col_idx || !values || !X || !Y) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sddmm_csr_p: null pointer");
+    const Shape s = pick_shape(R, aligned16(X) && aligned16(Y));
+    hnh::WideLaunch wide(ctx, stream);
+    if (wide.status != HNH_OK) return wide.status;
+    return wide.finish(dispatch_row<Op::kSddmm>(ctx, wide.stream(), stream, s, b->rows, b->nnz, b->max_row_nnz, window ? -1 : b->cols, b->rowptr, b->col_idx,
+                                                values, nullptr, X, Y, nullptr, R, 0u, Extras(), nullptr, window, b->plan));
+}
+
+int hnh_spmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* b, const double* values, const double* X, double* Out, int R, const hnh_csr_window* window,
+                   int stream) {
+    HNH_ENTER(ctx, stream);
+    if (!b) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_spmm_csr_p: null block");
+    if (int rc = check_common(ctx, b->rows, R, "hnh_spmm_csr_p")) return rc;
+    if (b->rows == 0) return HNH_OK;
+    if (!b->rowptr || !b->col_idx || !values || !X || !Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_spmm_csr_p: null pointer");
+    if (X == Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_spmm_csr_p: X and Out alias");
+    const Shape s = pick_shape(R, aligned16(X) && aligned16(Out));
+    return dispatch_row<Op::kSpmm>(ctx, ctx->streams[stream], stream, s, b->rows, b->nnz, b->max_row_nnz, window ? -1 : b->cols, b->rowptr, b->col_idx,
+                                   const_cast<double*>(values), nullptr, X, nullptr, Out, R, 0u, Extras(), nullptr, window, b->plan);
+}
+
+int hnh_fused_sddmm_spmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* b, double* values, const double* svalues, const double* X, const double* Y,
+                               double* Out, int R, unsigned flags, const hnh_fused_extras* extras, const hnh_csr_window* window, int stream) {
+    if (!ctx) return HNH_ERR_INVALID;
+    if (!b) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_fused_sddmm_spmm_csr_p: null block");
+    return fused_impl(ctx, b->rows, b->rowptr, b->col_idx, values, svalues, X, Y, Out, R, flags, b->nnz, b->max_row_nnz, window ? -1 : b->cols, extras,
+                      window, stream, b->plan);
 }
 
 int hnh_row_epilogue_f64(hnh_ctx* ctx, double* Out, const double* X, double x_scale, double* rowdot, int64_t rows, int R, int stream) {
@@ -2091,14 +2253,16 @@ int hnh_sddmm_coo(hnh_ctx* ctx, int64_t nnz, const int32_t* row_idx, const int32
     if (int rc = check_common(ctx, nnz, R, "hnh_sddmm_coo")) return rc;
     if (nnz == 0) return HNH_OK;
     if (!row_idx || !col_idx || !values || !X || !Y) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sddmm_coo: null pointer");
-    hipStream_t st = ctx->streams[stream];
+    hnh::WideLaunch wide(ctx, stream);
+    if (wide.status != HNH_OK) return wide.status;
+    hipStream_t st = wide.stream();
     const Shape s = pick_shape(R, aligned16(X) && aligned16(Y));
 #define HNH_CASE(L, V) \
-    if (s.lpr == L && s.vec == V) return launch_coo<L, V, 2, true>(ctx, st, nnz, row_idx, col_idx, values, X, Y, R, 0, R);
+    if (s.lpr == L && s.vec == V) return wide.finish(launch_coo<L, V, 2, true>(ctx, st, nnz, row_idx, col_idx, values, X, Y, R, 0, R));
     if (s.exact) {
         HNH_CASE(1, 1) HNH_CASE(2, 1) HNH_CASE(4, 1) HNH_CASE(8, 1) HNH_CASE(16, 1) HNH_CASE(32, 1) HNH_CASE(64, 1)
         HNH_CASE(64, 2) HNH_CASE(64, 3) HNH_CASE(64, 4) HNH_CASE(32, 3) HNH_CASE(32, 5) HNH_CASE(32, 7)
-        return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "no kernel instance for this shape");
+        return wide.finish(hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "no kernel instance for this shape"));
     }
 #undef HNH_CASE
     const int tile = 64 * s.w;
@@ -2106,9 +2270,9 @@ int hnh_sddmm_coo(hnh_ctx* ctx, int64_t nnz, const int32_t* row_idx, const int32
         const int ncols = (R - col0 < tile) ? (R - col0) : tile;
         int rc = (s.w == 2) ? launch_coo<64, 1, 2, false>(ctx, st, nnz, row_idx, col_idx, values, X, Y, R, col0, ncols)
                             : launch_coo<64, 1, 1, false>(ctx, st, nnz, row_idx, col_idx, values, X, Y, R, col0, ncols);
-        if (rc != HNH_OK) return rc;
+        if (rc != HNH_OK) return wide.finish(rc);
     }
-    return HNH_OK;
+    return wide.finish(HNH_OK);
 }
 
 int hnh_fill_f64(hnh_ctx* ctx, double* dst, int64_t n, double value, int stream) {
@@ -2213,9 +2377,11 @@ int hnh_gemm_f64(hnh_ctx* ctx, int64_t M, int64_t N, int64_t K, const double* A,
     const int64_t grid = ((row_blocks + kXcds - 1) / kXcds) * kXcds * col_blocks;  // row blocks padded to whole XCD rounds
     if (grid > 0x7fffffffLL || col_blocks > 0x7fffffffLL) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "hnh_gemm_f64: matrix too large");
     const bool vec_ok = (K % 2 == 0) && (N % 2 == 0) && aligned16(A) && aligned16(B);
-    hipLaunchKernelGGL(gemm_f64_kernel, dim3((unsigned)grid), dim3(kBlock), 0, ctx->streams[stream], M, N, K, A, B, C, row_blocks,
+    hnh::WideLaunch wide(ctx, stream);  // a dense contraction wants every matrix core
+    if (wide.status != HNH_OK) return wide.status;
+    hipLaunchKernelGGL(gemm_f64_kernel, dim3((unsigned)grid), dim3(kBlock), 0, wide.stream(), M, N, K, A, B, C, row_blocks,
                        (int)col_blocks, vec_ok);
-    return hnh::check_hip(ctx, hipGetLastError(), "gemm_f64_kernel launch");
+    return wide.finish(hnh::check_hip(ctx, hipGetLastError(), "gemm_f64_kernel launch"));
 }
 
 int hnh_leaky_relu_f64(hnh_ctx* ctx, double* v, double alpha, int64_t n, int stream) {

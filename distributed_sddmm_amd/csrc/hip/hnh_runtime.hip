@@ -75,6 +75,10 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
     ctx->device = device;
     ctx->no_panels = std::getenv("HNH_NO_PANELS") != nullptr;
     ctx->hub_atomics = std::getenv("HNH_HUB_ATOMICS") != nullptr;
+    if (const char* hs = std::getenv("HNH_HUB_SCRATCH_MB")) {
+        const double mb = std::atof(hs);
+        if (mb >= 0.0 && mb <= 262144.0) ctx->hub_scratch_bytes = (size_t)(mb * 1024.0 * 1024.0);
+    }
     if (const char* k = std::getenv("HNH_ROW_WAVES_CAP")) {
         const long v = std::strtol(k, nullptr, 10);
         if (v >= 0 && v <= 7) ctx->row_waves_cap = (int)v;
@@ -93,56 +97,78 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
         const double v = std::atof(pb);
         if (v >= 1.0) ctx->panel_bytes = v;
     }
-    // HNH_COMM_PRIORITY=1: the communication stream gets the highest priority the device offers (its work — RCCL send/recv
-    // kernels — is small and latency-critical, while the compute stream keeps tens of thousands of workgroups queued).
-    // Opt-in: on one GPU shared by 8 logical ranks it makes no measurable difference (profiles/r02_loopback_p8_comm_priority.log)
-    // and no multi-GPU box was available to show that it helps there.
+    // HNH_COMM_PRIORITY=1: the communication stream gets the highest priority the device offers.  Opt-in: on one GPU shared by 8
+    // logical ranks it makes no measurable difference (profiles/r02_loopback_p8_comm_priority.log).  A masked stream (below) is
+    // created by hipExtStreamCreateWithCUMask, which takes neither a priority nor hipStreamNonBlocking: the mask supersedes both.
     int least = 0, greatest = 0;
     const bool has_priorities = std::getenv("HNH_COMM_PRIORITY") != nullptr &&
                                 hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least;
-    // HNH_COMM_CUS=<n>: n compute units are set aside for the communication stream — the compute stream's kernels are masked off
-    // them (hipExtStreamCreateWithCUMask), the communication stream runs only there.  Why: a transfer workgroup that shares a CU
-    // with 20-odd row-kernel waves gets a wave's share of that CU's memory pipeline (measured with throttled copy workgroups next
-    // to the fused kernel: ~5 GB/s per workgroup, whatever the link could deliver — profiles/r03_overlap_probe_with_copies_*.log),
-    // while the row kernels, bound by the memory side and not by CUs, hardly notice a few CUs less.
+    // Compute units of the compute stream (HNH_COMM_CUS=<n>, default 0 = no mask).  The row kernels are bound by the memory side,
+    // not by CUs: with 16 of the 256 CUs masked off their stream the fused pass and SpMM run 0.3-2 % FASTER depending on the box
+    // (fewer requesters queueing at the fabric; profiles/r03_kbench_cus_off_x_waves_cap.log, r04_job1_bench_masked_default.json),
+    // while arithmetic-heavier launches lose — the stand-alone SDDMM 5 %, the fp64 GEMM its share of the matrix cores.  With a
+    // mask the library therefore decides per operation: streams[HNH_STREAM_COMPUTE] is masked and the entry points that want the
+    // whole chip (hnh_sddmm_*, hnh_gemm_f64) fork onto `wide`, an unmasked stream, and join back (hnh::WideLaunch) — callers keep
+    // seeing ONE compute stream.  The masked-off CUs are where a communication stream's work (RCCL channels, pull kernels) finds
+    // free slots at once; HNH_COMM_CUS_EXCLUSIVE=1 additionally confines the communication stream to them.
+    // NOT the default, for robustness: a process that had created a CU-masked stream hung in the HIP runtime's exit handler
+    // (a queue-teardown ioctl) in 4 of 80 runs when a large spinning OpenMP pool was alive at exit — 0 of 80 without the mask, with
+    // 8 OpenMP threads or with OMP_WAIT_POLICY=passive (profiles/r04_masked_stream_exit_hang.log).  One percent is not worth that.
     int comm_cus = 0;
     if (const char* cc = std::getenv("HNH_COMM_CUS")) comm_cus = std::atoi(cc);
+    static const bool comm_exclusive = std::getenv("HNH_COMM_CUS_EXCLUSIVE") != nullptr;
     hipDeviceProp_t prop;
     uint32_t mask_compute[16] = {0}, mask_comm[16] = {0};
-    int mask_words = 0;
-    if (comm_cus > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > comm_cus &&
+    int mask_words = 0, placed = 0;
+    if (comm_cus > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount >= 2 * comm_cus &&
         prop.multiProcessorCount <= 512) {
         const int cus = prop.multiProcessorCount;
         mask_words = (cus + 31) / 32;
-        // the reserved CUs are spread over the mask with an odd stride (cus / n + 1), which lands them evenly on the XCDs whether
-        // the mask's bits enumerate the XCDs interleaved or block by block.  Measured at config 2 with 16 / 32 CUs off the compute
-        // stream (profiles/r03_kbench_cus_masked_*.log): fused and SpMM +1 %, the stand-alone SDDMM -5 % (low bits and spread alike)
-        const int stride = cus / comm_cus + 1;
-        for (int k = 0, placed = 0; placed < comm_cus && k < 4 * cus; k++) {
+        // the reserved CUs are spread over the mask with a stride coprime to the CU count (so the walk visits every CU before it
+        // repeats), which lands them evenly on the XCDs whether the mask's bits enumerate the XCDs interleaved or block by block
+        auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+        int stride = cus / comm_cus + 1;
+        while (gcd(stride, cus) != 1) stride++;
+        for (int k = 0; placed < comm_cus && k < cus; k++) {
             const int i = (int)(((long)k * stride) % cus);
-            if (mask_comm[i / 32] & (1u << (i % 32))) continue;
             mask_comm[i / 32] |= 1u << (i % 32);
             placed++;
         }
         for (int i = 0; i < cus; i++)
             if (!(mask_comm[i / 32] & (1u << (i % 32)))) mask_compute[i / 32] |= 1u << (i % 32);
-        ctx->comm_cus = comm_cus;
     }
-    for (int s = 0; s < 2; s++) {
+    auto plain_stream = [&](hipStream_t* st, bool comm) {
         hipError_t e = hipErrorUnknown;
-        // HNH_COMM_CUS_SHARED=1: only the compute stream is masked; the communication stream may use every CU (RCCL needs all its
-        // channel workgroups resident at once — with few reserved CUs and many channels, leave its stream alone)
-        static const bool comm_shared = std::getenv("HNH_COMM_CUS_SHARED") != nullptr;
-        if (mask_words > 0 && !(s == HNH_STREAM_COMM && comm_shared)) {
-            e = hipExtStreamCreateWithCUMask(&ctx->streams[s], (uint32_t)mask_words, s == HNH_STREAM_COMM ? mask_comm : mask_compute);
-            if (e != hipSuccess) ctx->comm_cus = 0;
+        if (comm && has_priorities) e = hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest);
+        if (e != hipSuccess) e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+        return e;
+    };
+    bool masked = false;
+    if (mask_words > 0) {
+        masked = hipExtStreamCreateWithCUMask(&ctx->streams[HNH_STREAM_COMPUTE], (uint32_t)mask_words, mask_compute) == hipSuccess;
+        if (masked) {
+            hipError_t e = comm_exclusive ? hipExtStreamCreateWithCUMask(&ctx->streams[HNH_STREAM_COMM], (uint32_t)mask_words, mask_comm)
+                                          : plain_stream(&ctx->streams[HNH_STREAM_COMM], true);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->wide, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->wide_fork, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->wide_join, hipEventDisableTiming);
+            if (e != hipSuccess) {  // half a set-up is no set-up: start again without masks
+                for (hipStream_t* st : {&ctx->streams[0], &ctx->streams[1], &ctx->wide})
+                    if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
+                if (ctx->wide_fork) { (void)hipEventDestroy(ctx->wide_fork); ctx->wide_fork = nullptr; }
+                if (ctx->wide_join) { (void)hipEventDestroy(ctx->wide_join); ctx->wide_join = nullptr; }
+                masked = false;
+            }
         }
-        if (e != hipSuccess && s == HNH_STREAM_COMM && has_priorities) e = hipStreamCreateWithPriority(&ctx->streams[s], hipStreamNonBlocking, greatest);
-        if (e != hipSuccess) e = hipStreamCreateWithFlags(&ctx->streams[s], hipStreamNonBlocking);
-        if (e != hipSuccess) {
-            delete ctx;
-            return HNH_ERR_DEVICE;
-        }
+    }
+    if (masked) {
+        ctx->comm_cus = placed;
+    } else {
+        for (int s = 0; s < 2; s++)
+            if (plain_stream(&ctx->streams[s], s == HNH_STREAM_COMM) != hipSuccess) {
+                delete ctx;
+                return HNH_ERR_DEVICE;
+            }
     }
     (void)hipGetLastError();  // (a refused priority request above is not this call's error)
     *out = ctx;
@@ -165,6 +191,9 @@ int hnh_ctx_destroy(hnh_ctx* ctx) {
         if (ctx->aux_join[a]) (void)hipEventDestroy(ctx->aux_join[a]);
     }
     if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
+    if (ctx->wide) { (void)hipStreamSynchronize(ctx->wide); (void)hipStreamDestroy(ctx->wide); }
+    if (ctx->wide_fork) (void)hipEventDestroy(ctx->wide_fork);
+    if (ctx->wide_join) (void)hipEventDestroy(ctx->wide_join);
     delete ctx;
     return HNH_OK;
 }

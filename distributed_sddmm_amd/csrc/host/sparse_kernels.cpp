@@ -18,10 +18,9 @@ size_t StandardKernel::sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
     hnh::World* w = S.world;
     begin(w);
     hnh_csr_window win;
+    const hnh_csr_block desc = blk->block_args();
     if (blk->window_args(&win)) {  // one column range of the block (the schedule walks them as their data arrives)
-        w->check(w->be->hnh_sddmm_csr_w(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, Xptr, Yptr, (int)A.cols(),
-                                        blk->num_coords, blk->row_hint(), &win, HNH_STREAM_COMPUTE),
-                 "hnh_sddmm_csr_w");
+        w->check(w->be->hnh_sddmm_csr_p(w->ctx, &desc, active->values, Xptr, Yptr, (int)A.cols(), &win, HNH_STREAM_COMPUTE), "hnh_sddmm_csr_p");
         end(w);
         return processed;
     }
@@ -36,9 +35,7 @@ size_t StandardKernel::sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
         end(w);
         return processed;
     }
-    w->check(w->be->hnh_sddmm_csr_ex(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, Xptr, Yptr,
-                                     (int)A.cols(), blk->num_coords, blk->row_hint(), blk->cols, HNH_STREAM_COMPUTE),
-             "hnh_sddmm_csr");
+    w->check(w->be->hnh_sddmm_csr_p(w->ctx, &desc, active->values, Xptr, Yptr, (int)A.cols(), nullptr, HNH_STREAM_COMPUTE), "hnh_sddmm_csr_p");
     end(w, profile ? w->be->hnh_panel_count(w->ctx, blk->rows, blk->num_coords, blk->cols, (int)A.cols(), blk->row_hint()) : 1);
     return processed;
 }
@@ -57,16 +54,13 @@ size_t StandardKernel::spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B,
     double* Out = (mode == Amat) ? A.data() : B.data();
     begin(w);
     hnh_csr_window win;
+    const hnh_csr_block desc = blk->block_args();
     if (blk->window_args(&win)) {
-        w->check(w->be->hnh_spmm_csr_w(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, X, Out, (int)A.cols(),
-                                       blk->num_coords, blk->row_hint(), &win, HNH_STREAM_COMPUTE),
-                 "hnh_spmm_csr_w");
+        w->check(w->be->hnh_spmm_csr_p(w->ctx, &desc, active->values, X, Out, (int)A.cols(), &win, HNH_STREAM_COMPUTE), "hnh_spmm_csr_p");
         end(w);
         return processed;
     }
-    w->check(w->be->hnh_spmm_csr_ex(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, X, Out, (int)A.cols(),
-                                    blk->num_coords, blk->row_hint(), blk->cols, HNH_STREAM_COMPUTE),
-             "hnh_spmm_csr");
+    w->check(w->be->hnh_spmm_csr_p(w->ctx, &desc, active->values, X, Out, (int)A.cols(), nullptr, HNH_STREAM_COMPUTE), "hnh_spmm_csr_p");
     end(w, profile ? w->be->hnh_panel_count(w->ctx, blk->rows, blk->num_coords, blk->cols, (int)A.cols(), blk->row_hint()) : 1);
     return processed;
 }
@@ -87,19 +81,18 @@ size_t StandardKernel::fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
     CSRHandle* active = blk->getActive();
     begin(w);
     hnh_csr_window win;
+    const hnh_csr_block desc = blk->block_args();
     if (blk->window_args(&win)) {
         if (wants_epilogue(extras) && !win.last) hnh::fatal("Error, the row epilogue belongs to the block's last window!");
-        w->check(w->be->hnh_fused_sddmm_spmm_csr_w(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, nullptr, A.data(), B.data(),
-                                                   Out.data(), (int)A.cols(), flags, blk->num_coords, blk->row_hint(), extras, &win,
-                                                   HNH_STREAM_COMPUTE),
-                 "hnh_fused_sddmm_spmm_csr_w");
+        w->check(w->be->hnh_fused_sddmm_spmm_csr_p(w->ctx, &desc, active->values, nullptr, A.data(), B.data(), Out.data(), (int)A.cols(), flags, extras,
+                                                   &win, HNH_STREAM_COMPUTE),
+                 "hnh_fused_sddmm_spmm_csr_p");
         end(w);
         return 0;
     }
-    w->check(w->be->hnh_fused_sddmm_spmm_csr_x(w->ctx, blk->rows, active->rowStart, active->col_idx, active->values, nullptr, A.data(),
-                                               B.data(), Out.data(), (int)A.cols(), flags, blk->num_coords, blk->row_hint(), blk->cols, extras,
-                                               HNH_STREAM_COMPUTE),
-             "hnh_fused_sddmm_spmm_csr");
+    w->check(w->be->hnh_fused_sddmm_spmm_csr_p(w->ctx, &desc, active->values, nullptr, A.data(), B.data(), Out.data(), (int)A.cols(), flags, extras,
+                                               nullptr, HNH_STREAM_COMPUTE),
+             "hnh_fused_sddmm_spmm_csr_p");
     end(w, profile ? w->be->hnh_panel_count(w->ctx, blk->rows, blk->num_coords, blk->cols, (int)A.cols(), blk->row_hint()) : 1);
     return 0;
 }

@@ -98,6 +98,7 @@ public:
         int32_t* rowStart = nullptr;
         int32_t* row_idx = nullptr;  // COO view of the same structure, built on first use (ensure_row_idx)
         int nnz = 0;
+        hnh_csr_plan* plan = nullptr;  // structure-only work of the row passes for this ring block (block_args)
     };
     std::vector<RingIndex> ring_index;  // by ring position of the block's origin; empty = indices travel (reference behaviour)
     int active_slot = -1;               // ring position whose block occupies the active buffer (ring-resident indices only)
@@ -210,7 +211,9 @@ public:
             }
             world->dfree(buffer[t].row_idx);
         }
+        if (static_plan) world->be->hnh_csr_plan_destroy(world->ctx, static_plan);
         for (RingIndex& ri : ring_index) {
+            if (ri.plan) world->be->hnh_csr_plan_destroy(world->ctx, ri.plan);
             world->dfree(ri.col_idx);
             world->dfree(ri.rowStart);
             world->dfree(ri.row_idx);
@@ -254,6 +257,28 @@ public:
     CSRLocal& operator=(const CSRLocal&) = delete;
 
     CSRHandle* getActive() { return buffer + active; }
+
+    // The kernel-ABI description of the block in the active buffer, with the plan that caches what the row passes derive from
+    // its STRUCTURE alone (cache-panel boundaries, hub-row work list): one plan per structure that keeps its contents — the
+    // block itself when it never shifts, each ring position when the ring's structure is resident; a block that ships its
+    // indices (HNH_SHIP_INDICES=1: the arrays are overwritten by every shift) gets none.  The structure is fixed once the
+    // constructor has run (the reference's SpmatLocal.hpp:78-188), so a plan never needs invalidating.
+    hnh_csr_plan* static_plan = nullptr;
+    hnh_csr_block block_args() {
+        CSRHandle* h = getActive();
+        hnh_csr_plan** slot = !ring_index.empty() ? &ring_index[(size_t)active_slot].plan : (shifting ? nullptr : &static_plan);
+        if (slot != nullptr && *slot == nullptr) world->check(world->be->hnh_csr_plan_create(world->ctx, slot), "hnh_csr_plan_create");
+        hnh_csr_block b;
+        b.rows = rows;
+        b.nnz = num_coords;
+        b.cols = cols;
+        b.max_row_nnz = row_hint();
+        b.reserved = 0;
+        b.rowptr = h->rowStart;
+        b.col_idx = h->col_idx;
+        b.plan = slot ? *slot : nullptr;
+        return b;
+    }
 
     // COO row indices of the block in the active buffer (the nonzero-balanced SDDMM of narrow operands walks them): built
     // once per structure — per ring position when the ring's structure is resident, again after a shift when indices travel.

@@ -84,6 +84,7 @@ Backend* load_backend(const char* path_c) {
     HNH_BIND(hnh_comm_allreduce_f64)
     HNH_BIND(hnh_ipc_export) HNH_BIND(hnh_ipc_open) HNH_BIND(hnh_ipc_close) HNH_BIND(hnh_ipc_pull) HNH_BIND(hnh_ipc_flags_register) HNH_BIND(hnh_ipc_flags_unregister)
     HNH_BIND(hnh_stream_write_flag) HNH_BIND(hnh_stream_wait_flag)
+    HNH_BIND(hnh_csr_plan_create) HNH_BIND(hnh_csr_plan_destroy) HNH_BIND(hnh_sddmm_csr_p) HNH_BIND(hnh_spmm_csr_p) HNH_BIND(hnh_fused_sddmm_spmm_csr_p)
 #undef HNH_BIND
     b->name = b->hnh_backend_name();
     g_backends[path] = b;

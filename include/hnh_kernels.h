@@ -308,6 +308,38 @@ int hnh_leaky_relu_f64(hnh_ctx* ctx, double* v, double alpha, int64_t n, int str
 int hnh_relu_store_cols_f64(hnh_ctx* ctx, double* dst, int64_t ld_dst, int64_t col0, const double* src, int64_t rows,
                             int64_t cols, int stream);
 
+/* ---- block descriptors and structure plans ----------------------------------------------------------------
+ * A sparse block's STRUCTURE (rowptr / col_idx) is fixed once SpmatLocal has built it (SpmatLocal.hpp:78-188); only its
+ * values change.  Everything the row passes derive from the structure alone — the per-row boundaries of the Infinity-Cache
+ * panels, the hub-row work list (rows above the long-row threshold, cut into segments) and its exact size — is kept in an
+ * opaque plan that the owner of the block creates once and hands to every call, so steady-state calls launch row kernels
+ * only.  A plan is filled on first use (per panel count / threshold) and stays valid for as long as the two index arrays keep
+ * their contents; blocks whose indices are overwritten in place (a travelling block that ships its indices) pass plan = NULL
+ * and get the per-call behaviour of the _ex / _x / _w entry points.
+ *   hnh_csr_block   everything a call needs to know about the block: sizes, hints (as the _ex entry points), arrays, plan;
+ *   *_p             the _ex / _x / _w entry points on a block descriptor; window == NULL = the whole block (cols >= 0 then
+ *                   enables the cache panels), extras == NULL = none.
+ * HNH_HUB_SCRATCH_MB (environment, default 2048) bounds the partial-row scratch of the hub-row segments per stream; segments
+ * beyond it combine with atomics (exact within the parity tolerance, not bit-reproducible run to run). */
+typedef struct hnh_csr_plan hnh_csr_plan;
+typedef struct hnh_csr_block {
+    int64_t rows, nnz, cols;   /* nnz = rowptr[rows]; cols = rows of the gathered operand, or -1 */
+    int32_t max_row_nnz;       /* longest row, or an upper bound, or -1 = unknown */
+    int32_t reserved;
+    const int32_t* rowptr;     /* device */
+    const int32_t* col_idx;    /* device */
+    hnh_csr_plan* plan;        /* or NULL */
+} hnh_csr_block;
+int hnh_csr_plan_create(hnh_ctx* ctx, hnh_csr_plan** out);
+int hnh_csr_plan_destroy(hnh_ctx* ctx, hnh_csr_plan* plan);
+int hnh_sddmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* block, double* values, const double* X, const double* Y, int R,
+                    const hnh_csr_window* window, int stream);
+int hnh_spmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* block, const double* values, const double* X, double* Out, int R,
+                   const hnh_csr_window* window, int stream);
+int hnh_fused_sddmm_spmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* block, double* values, const double* svalues, const double* X,
+                               const double* Y, double* Out, int R, unsigned flags, const hnh_fused_extras* extras,
+                               const hnh_csr_window* window, int stream);
+
 /* ---- RCCL ring / collectives over xGMI ---------------------------------------------------------------
  * Replace the MPI calls of the shift schedules:
  *   hnh_comm_sendrecv        — MPI_Sendrecv in shiftDenseMatrix (distributed_sparse.h:351-361) and the

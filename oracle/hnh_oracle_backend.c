@@ -748,3 +748,28 @@ int hnh_stream_wait_flag(hnh_ctx* c, int stream, void* f, uint64_t v) {
     }
     return HNH_OK;
 }
+
+/* ---- block descriptors: the double has no structure-only work to cache, a plan is an empty token; the _p entry points are the
+ * _x / _w entry points on the descriptor's fields */
+struct hnh_csr_plan { int unused; };
+int hnh_csr_plan_create(hnh_ctx* c, hnh_csr_plan** out) {
+    if (!out) return HNH_ERR_INVALID;
+    *out = (hnh_csr_plan*)calloc(1, sizeof(hnh_csr_plan));
+    return *out ? HNH_OK : fail(c, HNH_ERR_NOMEM, "malloc failed");
+}
+int hnh_csr_plan_destroy(hnh_ctx* c, hnh_csr_plan* p) { (void)c; free(p); return HNH_OK; }
+static const hnh_csr_window whole_block = {NULL, NULL, 1};
+int hnh_sddmm_csr_p(hnh_ctx* c, const hnh_csr_block* b, double* values, const double* X, const double* Y, int R, const hnh_csr_window* w, int stream) {
+    if (!b) return fail(c, HNH_ERR_INVALID, "null block");
+    return hnh_sddmm_csr_w(c, b->rows, b->rowptr, b->col_idx, values, X, Y, R, b->nnz, b->max_row_nnz, w ? w : &whole_block, stream);
+}
+int hnh_spmm_csr_p(hnh_ctx* c, const hnh_csr_block* b, const double* values, const double* X, double* Out, int R, const hnh_csr_window* w, int stream) {
+    if (!b) return fail(c, HNH_ERR_INVALID, "null block");
+    return hnh_spmm_csr_w(c, b->rows, b->rowptr, b->col_idx, values, X, Out, R, b->nnz, b->max_row_nnz, w ? w : &whole_block, stream);
+}
+int hnh_fused_sddmm_spmm_csr_p(hnh_ctx* c, const hnh_csr_block* b, double* values, const double* svalues, const double* X, const double* Y,
+                               double* Out, int R, unsigned flags, const hnh_fused_extras* ex, const hnh_csr_window* w, int stream) {
+    if (!b) return fail(c, HNH_ERR_INVALID, "null block");
+    return hnh_fused_sddmm_spmm_csr_w(c, b->rows, b->rowptr, b->col_idx, values, svalues, X, Y, Out, R, flags, b->nnz, b->max_row_nnz, ex,
+                                      w ? w : &whole_block, stream);
+}

@@ -30,6 +30,15 @@ if __name__ == "__main__":
         if os.environ.get("BENCH_WORKER_HANG_RANK") == os.environ["RANK"]:  # a rank that never gets anywhere: the launcher's time limit, exercised
             import time
             time.sleep(3600)
+        poison = os.environ.get("BENCH_WORKER_POISON")
+        if poison:  # one candidate of the route search fails — on every rank, or on BENCH_WORKER_POISON_RANK only (the others then wait for it)
+            real_build = bench.Bench.build
+
+            def build(self, route):
+                if poison in bench.route_name(route) and os.environ.get("BENCH_WORKER_POISON_RANK", os.environ["RANK"]) == os.environ["RANK"]:
+                    raise RuntimeError("poisoned candidate (test)")
+                return real_build(self, route)
+            bench.Bench.build = build
         bench.run(args, make_world=cpu_world)  # rank 0 prints the JSON line itself
         if os.environ.get("BENCH_WORKER_FAIL_RANK") == os.environ["RANK"]:  # the launcher's failure report, exercised
             sys.exit(7)
@@ -37,7 +46,7 @@ if __name__ == "__main__":
     args = argparse.Namespace(gpus=n, steps=2, warmup=1, logm=10, edge_factor=8, r=16, alg=sys.argv[1], c=int(sys.argv[2]) or None,
                               no_cpu_baseline=True, cpu_logm=10, cpu_trials=1, ring_mode=os.environ.get("BENCH_RING_MODE") or None,
                               chunks=None, no_cpu_full=True, no_check=False, no_preflight=False, no_tune=False, watchdog=120.0, no_live_traffic=True,
-                              nchannels=None, comm_cus=None)
+                              nchannels=None, comm_cus=None, workload="er", app="vanilla", transport="auto", no_secondary=True, probe_timeout=60.0)
     out = bench.run(args, make_world=cpu_world)
     if out is not None:
         print("BENCH_JSON " + json.dumps(out), flush=True)

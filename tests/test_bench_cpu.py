@@ -59,7 +59,8 @@ def test_bench_contract(nranks, alg, c, ring):
         tuned = alg == "15d_fusion2" and len(want) > 1
         assert ("route_tuning_ms_per_step" in out["config"]) == tuned
         if tuned:  # the configuration that was timed is the fastest of the measured candidates
-            t = out["config"]["route_tuning_ms_per_step"]
+            t = {k.rsplit(" [", 1)[0]: v for k, v in out["config"]["route_tuning_ms_per_step"].items()}  # (names end in " [transport]")
+            assert all(k.endswith(" [default]") for k in out["config"]["route_tuning_ms_per_step"])
             assert set(t) == want
             best = min(t, key=t.get)
             bc, broute = best.split(" ", 1)
@@ -131,3 +132,77 @@ def test_bench_without_a_gpu_fails_loudly_with_one_line():
     out = json.loads(lines[0])
     assert out["value"] is None and "error" in out and out["failed_rank"] in (0, 1) and "transport creation" in out["phase"]
     assert "no GPU visible" in res.stderr
+
+
+def test_a_failing_route_candidate_is_recorded_and_the_line_survives():
+    """One candidate of the route search throws: the ranks agree to drop it (recorded as null with the reason), the transport
+    it ran on is not used again, and the run still ends with the measured line of the default route, exit code 0."""
+    res = self_launch({"HNH_BENCH_WORKER": os.path.join(ROOT, "tests", "bench_worker.py"), "BENCH_WORKER_POISON": "mesh/4 chunks"})
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["check"]["ok"] and "error" not in out
+    tuned, failed = out["config"]["route_tuning_ms_per_step"], out["config"]["route_tuning_failures"]
+    assert tuned["c=1 mesh/4 chunks [default]"] is None and "c=1 mesh/4 chunks [default]" in failed
+    assert any(v is not None for v in tuned.values())  # candidates before the failure were measured
+    assert all("skipped" in why or "poisoned" in why or "another rank" in why for why in failed.values())
+    # what was timed is a route that was measured, not the failed one
+    assert out["config"]["mesh_chunks"] != "4"
+
+
+def test_a_candidate_that_hangs_still_leaves_the_line_in_hand():
+    """A candidate fails on ONE rank only, so the other rank waits inside the transport for ever: its watchdog ends the wait, and
+    because the default route had been measured in full BEFORE the search, rank 0 prints that line, marked incomplete — the run
+    does not end without a number."""
+    res = self_launch({"HNH_BENCH_WORKER": os.path.join(ROOT, "tests", "bench_worker.py"), "BENCH_WORKER_POISON": "mesh/4 chunks",
+                       "BENCH_WORKER_POISON_RANK": "1"}, extra_args=("--watchdog", "12"))
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout[-2000:] + res.stderr[-2000:]
+    out = json.loads(lines[0])
+    assert res.returncode == 0 and out["value"] > 0 and out["check"]["ok"]
+    assert "stuck in phase 'route tuning: c=1 mesh/4 chunks [default]'" in out["incomplete"]
+    assert out["config"]["mesh_chunks"] == "1,2,2,2,1,1"  # the default route's measurement
+
+
+def run_worker_directly(n, *cli, timeout=600):
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2",
+                   GLOO_SOCKET_IFNAME="lo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "bench_worker.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0",
+                                       "--no-cpu-baseline", *cli], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-1500:] for o in outs)
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, outs[0][0][-1500:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n,cli,app", [(1, ("--workload", "rmat", "--logm", "9", "--edge-factor", "8", "--r", "16"), "vanilla"),
+                                       (2, ("--workload", "rmat", "--app", "als", "--logm", "9", "--edge-factor", "8", "--r", "16", "--no-tune"), "als"),
+                                       (1, ("--app", "gat", "--logm", "7", "--edge-factor", "4"), "gat"),
+                                       (2, ("--app", "gat", "--logm", "7", "--edge-factor", "4", "--no-tune"), "gat")])
+def test_workloads_and_applications_of_the_reference_harness(n, cli, app):
+    """--workload rmat and --app als | gat (benchmark_dist.cpp:88-141) through bench.run() on CPU ranks: the line names them and
+    carries the application's own check (ALS: the residual falls; GAT: the rank-one closed form, layer by layer)."""
+    out = run_worker_directly(n, *cli)
+    assert out["config"]["app"] == app and out["value"] > 0 and out["check"]["ok"], out.get("check")
+    if "rmat" in cli:
+        assert "R-MAT" in out["config"]["workload"]
+    if app == "als":
+        assert out["check"]["residual_after"] < out["check"]["residual_before"]
+    if app == "gat":
+        assert out["check"]["rel_err"] <= 1e-9 and "closed form" in out["check"]["what"]
+
+
+def test_matrix_market_workload(tmp_path):
+    """--workload mtx:<file> (bench_file.cpp:23-28): the file is read by the library's parallel parser on every rank, the result
+    check sums over the same file parsed independently with scipy."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hnh_testlib as T
+    mtx = str(tmp_path / "g.mtx")
+    T.write_symmetric_mtx_with_duplicates(mtx, 300, 3)
+    out = run_worker_directly(2, "--workload", "mtx:" + mtx, "--r", "16", "--no-tune")
+    assert out["data"] == "file" and "g.mtx" in out["config"]["workload"] and out["check"]["ok"] and out["check"]["rows_checked"] == out["config"]["M"]
