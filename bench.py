@@ -677,7 +677,9 @@ class Bench:
         S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
         A.upload(keyed_local(H.AMAT, a_key, u_key).reshape(A.shape))
         B.upload(keyed_local(H.BMAT, b_key, v_key).reshape(B.shape))
+        op.initial_shift(A, B, H.K_SDDMM_A)  # (Cannon's skew for the 2.5D schedules; empty for the 1.5D ones)
         op.fusedSpMM(A, B, S, buf, H.AMAT)
+        op.de_shift(A, B, H.K_SDDMM_A)
         self.world().sync()
         got = A.download().reshape(-1)
         for x in (A, B, S, buf):
@@ -1109,7 +1111,7 @@ def run(args, make_world=gpu_world):
         fallback.keep(out)
 
     # ---- one GPU: the other workloads of the reference's harness, bounded, outside the timed region
-    if n == 1 and not args.no_secondary and make_world is gpu_world:
+    if n == 1 and not args.no_secondary:
         dog.note("secondary workloads")
         sec = secondary(args, b)
         if out is not None:
@@ -1152,6 +1154,7 @@ def secondary(args, b):
     H, torch = b.H, b.torch
     world = b.world()
     out = []
+    small = os.environ.get("HNH_BENCH_SECONDARY_SMALL") is not None  # (the CPU test of this function: same code, toy sizes)
 
     def entry(name, fn):
         t0 = time.perf_counter()
@@ -1255,7 +1258,7 @@ def secondary(args, b):
 
     # (i) R-MAT with hub rows, fused at the headline width
     def rmat():
-        wl = Workload("rmat", 20, 44)
+        wl = Workload("rmat", 9 if small else 20, 8 if small else 44)
         sub = Bench(argparse.Namespace(**dict(vars(args), app="vanilla", steps=1, warmup=0, no_check=False)), H, torch, None, 0, 1, Watchdog(0, 0, False), wl)
         sub.transports = {"single": dict(b.transports["single"], sp=None)}
         try:
@@ -1271,11 +1274,11 @@ def secondary(args, b):
             sub.free_current()
             if sub.transports["single"]["sp"] is not None:
                 sub.transports["single"]["sp"].free()
-    entry("R-MAT 2^20, edge factor 44 (hub rows: long-row pass with ordered reduction), fused R=%d" % args.r, rmat)
+    entry("R-MAT 2^%d, edge factor %d (hub rows: long-row pass with ordered reduction), fused R=%d" % ((9, 8, args.r) if small else (20, 44, args.r)), rmat)
 
     # (ii) config 4's schedule and width on 8 logical ranks that share this GPU (loopback transport: device-to-device copies)
     def cfg4():
-        logm, ef, r = 18, 32, 256
+        logm, ef, r = (8, 8, 32) if small else (18, 32, 256)
         rows, cols = H.generate_rmat(logm, (1 << logm) * ef)
         m = 1 << logm
         a_key, b_key = keyed(np.arange(m), 1), keyed(np.arange(m), 2)
@@ -1309,7 +1312,9 @@ def secondary(args, b):
             A.upload(keyed_local(H.AMAT, a_key, u_key).reshape(A.shape))
             B.upload(keyed_local(H.BMAT, b_key, v_key).reshape(B.shape))
             S.fill(1.0)
+            op.initial_shift(A, B, H.K_SDDMM_A)  # Cannon's skew (25D_cannon_dense.hpp:222-248)
             op.fusedSpMM(A, B, S, buf, H.AMAT)
+            op.de_shift(A, B, H.K_SDDMM_A)
             w.sync()
             got, worst, off = A.download().reshape(-1), 0.0, 0
             for top, left, rc, cc in op.submatrices(H.AMAT):
@@ -1330,7 +1335,7 @@ def secondary(args, b):
                 "algorithmic_bytes": by, "frac": frac_of(by, ms),
                 "note": "all 8 ranks' kernels AND their device-to-device copies share this one GPU: a correctness-at-shape and cost figure, not a scaling claim",
                 "check": {"rel_err": err, "ok": bool(err <= 1e-11)}}
-    entry("config 4's shape, bounded: R-MAT 2^18, edge factor 32, R=256, 2.5D dense-replicate on 8 logical ranks", cfg4)
+    entry("config 4's shape, bounded: R-MAT 2^%d, edge factor %d, R=%d, 2.5D dense-replicate on 8 logical ranks" % ((8, 8, 32) if small else (18, 32, 256)), cfg4)
     return out
 
 

@@ -36,8 +36,6 @@ SIGNATURES = {
     "hnh_event_wait": (_i32, [_vp, _vp, _i32]),
     "hnh_event_sync": (_i32, [_vp, _vp]),
     "hnh_event_elapsed_ms": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float)]),
-    "hnh_stream_delay_us": (_i32, [_vp, _i32, C.c_double]),
-    "hnh_stream_paced_copy": (_i32, [_vp, _i32, _vp, _vp, C.c_size_t, _i32, C.c_double, _i32]),
     "hnh_sddmm_coo": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32]),
     "hnh_sddmm_csr": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32]),
     "hnh_spmm_csr": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32]),
@@ -103,6 +101,13 @@ SIGNATURES = {
 }
 
 
+# include/hnh_measurement_aids.h (tools and their tests only)
+AIDS_SIGNATURES = {
+    "hnh_stream_delay_us": (_i32, [_vp, _i32, C.c_double]),
+    "hnh_stream_paced_copy": (_i32, [_vp, _i32, _vp, _vp, C.c_size_t, _i32, C.c_double, _i32]),
+}
+
+
 class CsrBlock(C.Structure):
     """struct hnh_csr_block"""
     _fields_ = [("rows", C.c_int64), ("nnz", C.c_int64), ("cols", C.c_int64), ("max_row_nnz", C.c_int32), ("reserved", C.c_int32),
@@ -155,7 +160,7 @@ def load(path: str | None = None) -> C.CDLL:
         except ImportError:
             pass
     lib = C.CDLL(p)  # RTLD_LOCAL: the oracle test double exports the same symbol names
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(AIDS_SIGNATURES.items()):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
     if path is None:

@@ -18,7 +18,9 @@ import numpy as np
 from . import _kernels
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-HOST_LIB = os.path.join(HERE, "lib", "libhnh_host.so")
+# HNH_HOST_LIB_DEV: the measurement tools load libhnh_host_aids.so (the same library + the paced stand-ins, see
+# include/hnh_measurement_aids.h); nothing else sets it
+HOST_LIB = os.environ.get("HNH_HOST_LIB_DEV") or os.path.join(HERE, "lib", "libhnh_host.so")
 
 K_SDDMM_A, K_SPMM_A, K_SPMM_B, K_SDDMM_B = 0, 1, 2, 3
 AMAT, BMAT = 0, 1

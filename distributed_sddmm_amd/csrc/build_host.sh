@@ -5,7 +5,14 @@ set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
 mkdir -p "$HERE/../lib"
-g++ -O2 -g -std=c++17 -fopenmp -fPIC -shared -Wall -Wno-sign-compare -Wno-unused-variable \
-    -I"$ROOT/include" -I"$HERE/host" \
-    "$HERE/host/world.cpp" "$HERE/host/sparse_kernels.cpp" "$HERE/host/er_generator.cpp" "$HERE/host/c_api.cpp" \
-    -o "$HERE/../lib/libhnh_host.so" -ldl -lpthread -Wl,-Bsymbolic
+build() {  # $1 = output name, rest = extra flags
+    out="$1"; shift
+    g++ -O2 -g -std=c++17 -fopenmp -fPIC -shared -Wall -Wno-sign-compare -Wno-unused-variable "$@" \
+        -I"$ROOT/include" -I"$HERE/host" \
+        "$HERE/host/world.cpp" "$HERE/host/sparse_kernels.cpp" "$HERE/host/er_generator.cpp" "$HERE/host/c_api.cpp" \
+        -o "$HERE/../lib/$out" -ldl -lpthread -lrt -Wl,-Bsymbolic
+}
+build libhnh_host.so &
+# the same library plus the paced stand-ins of the overlap measurements (tools/ only; see include/hnh_measurement_aids.h)
+build libhnh_host_aids.so -DHNH_MEASUREMENT_AIDS &
+wait

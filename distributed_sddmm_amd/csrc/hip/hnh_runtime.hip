@@ -4,6 +4,7 @@
 #include <cstdlib>
 
 #include "hnh_ctx.hpp"
+#include "hnh_measurement_aids.h"
 
 namespace {
 // one lane spins on the constant-rate (100 MHz) clock; s_sleep keeps it off the issue ports

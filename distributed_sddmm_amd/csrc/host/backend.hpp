@@ -7,6 +7,9 @@
 #include <cstdint>
 #include <string>
 #include "hnh_kernels.h"
+#ifdef HNH_MEASUREMENT_AIDS
+#include "hnh_measurement_aids.h"
+#endif
 
 namespace hnh {
 
@@ -19,7 +22,7 @@ struct Backend {
     HNH_FN(hnh_ctx_create) HNH_FN(hnh_ctx_destroy) HNH_FN(hnh_last_error) HNH_FN(hnh_ctx_stream)
     HNH_FN(hnh_malloc) HNH_FN(hnh_free) HNH_FN(hnh_memcpy) HNH_FN(hnh_memset) HNH_FN(hnh_stream_sync)
     HNH_FN(hnh_event_create) HNH_FN(hnh_event_destroy) HNH_FN(hnh_event_record) HNH_FN(hnh_event_wait)
-    HNH_FN(hnh_event_sync) HNH_FN(hnh_event_elapsed_ms) HNH_FN(hnh_stream_delay_us) HNH_FN(hnh_stream_paced_copy)
+    HNH_FN(hnh_event_sync) HNH_FN(hnh_event_elapsed_ms)
     HNH_FN(hnh_sddmm_coo) HNH_FN(hnh_sddmm_csr) HNH_FN(hnh_spmm_csr) HNH_FN(hnh_fused_sddmm_spmm_csr)
     HNH_FN(hnh_sddmm_csr_ex) HNH_FN(hnh_spmm_csr_ex) HNH_FN(hnh_fused_sddmm_spmm_csr_ex) HNH_FN(hnh_csr_max_row_nnz)
     HNH_FN(hnh_fused_sddmm_spmm_csr_x) HNH_FN(hnh_row_epilogue_f64) HNH_FN(hnh_row_epilogue_x) HNH_FN(hnh_cg_step_f64)
@@ -35,6 +38,9 @@ struct Backend {
     HNH_FN(hnh_ipc_export) HNH_FN(hnh_ipc_open) HNH_FN(hnh_ipc_close) HNH_FN(hnh_ipc_pull) HNH_FN(hnh_ipc_flags_register) HNH_FN(hnh_ipc_flags_unregister)
     HNH_FN(hnh_stream_write_flag) HNH_FN(hnh_stream_wait_flag)
     HNH_FN(hnh_csr_plan_create) HNH_FN(hnh_csr_plan_destroy) HNH_FN(hnh_sddmm_csr_p) HNH_FN(hnh_spmm_csr_p) HNH_FN(hnh_fused_sddmm_spmm_csr_p)
+#ifdef HNH_MEASUREMENT_AIDS
+    HNH_FN(hnh_stream_delay_us) HNH_FN(hnh_stream_paced_copy)
+#endif
 #undef HNH_FN
 };
 

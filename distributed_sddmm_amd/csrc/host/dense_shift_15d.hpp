@@ -65,7 +65,7 @@ public:
     int windows = 1;
     std::vector<int> taper;  // chunk heights in units of a "fine" chunk; empty = the symmetric default (1, 2, .., 2, 1)
     std::vector<int64_t> cutA, cutB;  // chunk boundaries (windows + 1 entries, rows of a visiting A / B block)
-    int fineA = 0, fineB = 0;         // granularity of the boundaries: every chunk is one or two "fine" chunks of this many rows
+    int fineA = 0, fineB = 0;         // granularity of the boundaries: a chunk is w_q "fine" chunks of this many rows (w_q = its weight, 1 .. 64)
     DenseMatrix landing[2];      // [0]: visiting B blocks (gathered through S), [1]: visiting A blocks (through ST)
 
     // hold_moving_operand(): the remote blocks of this matrix stay valid in a landing buffer / ring_spare[0] between calls
@@ -242,8 +242,8 @@ private:
         if (pMod(b - grid->rankInRow, c) != 0) return -1;
         return pMod(grid->rankInCol - (b - grid->rankInRow) / c, p / c);
     }
-    // Chunk boundaries of a visiting block of `br` rows: `windows` chunks built from 2 (windows - 1) fine chunks of *fine rows,
-    // first and last chunk = one fine chunk, the others = two (a single chunk when windows == 1).
+    // Chunk boundaries of a visiting block of `br` rows: chunk q is w_q fine chunks of *fine rows, w = the taper weights
+    // (HNH_MESH_TAPER: 1 .. 64 each, up to 12 of them) or the symmetric default (1, 2, .., 2, 1); a single chunk when windows == 1.
     std::vector<int64_t> chunk_cuts(int br, int* fine) const {
         std::vector<int64_t> cut((size_t)windows + 1, br);
         cut[0] = 0;
@@ -275,7 +275,7 @@ private:
     // them into the two blocks of the merged layout.
     void lay_out_merged(SpmatLocal* s, int br, const std::vector<int64_t>& cut, int fine) {
         const int n = p / c;
-        const int nfine = divideAndRoundUp(br, fine);  // fine chunks that hold rows (<= 2 (windows - 1))
+        const int nfine = divideAndRoundUp(br, fine);  // fine chunks that hold rows (<= the sum of the weights, at most 12 x 64)
         std::vector<int64_t> dest((size_t)p * nfine, -1);
         for (int b = 0; b < p; b++) {
             const int k = step_of_block(b);
@@ -310,19 +310,23 @@ private:
         const bool held = (held_ptr == start->data());
         if (!held && held_slot == slot) held_slot = -1;  // another operand lands here: a held one has to be fetched again
         const bool resident = held && held_slot == slot;
-        // HNH_PACE_LINK_GBPS=<rate>: measurement aid (tools/overlap_probe.py) — a held operand's chunks are already in the landing
-        // buffer, but the communication stream is held for as long as each chunk would take to cross ONE xGMI link at that rate
-        // (chunk q of the n-1 blocks travels over n-1 links at once), without copying anything: the event protocol is then timed
-        // against transfers of a known duration with the rank's kernels alone on the GPU.
+#ifdef HNH_MEASUREMENT_AIDS
+        // (libhnh_host_aids.so only, tools/overlap_probe.py) HNH_PACE_LINK_GBPS=<rate>: a held operand's chunks are already in the
+        // landing buffer, but the communication stream is held for as long as each chunk would take to cross ONE xGMI link at that
+        // rate (chunk q of the n-1 blocks travels over n-1 links at once), without copying anything: the event protocol is then
+        // timed against transfers of a known duration with the rank's kernels alone on the GPU.  HNH_PACE_COPY=<workgroups per
+        // link>: the stand-in also moves the bytes (chunk q of the OWN block into every peer's place in the landing buffer — only
+        // meaningful when all blocks hold the same contents, i.e. on the single-process transports).
         const double pace_gbps = std::getenv("HNH_PACE_LINK_GBPS") ? std::atof(std::getenv("HNH_PACE_LINK_GBPS")) : 0.0;
+        const int copy_wgs = std::getenv("HNH_PACE_COPY") ? std::atoi(std::getenv("HNH_PACE_COPY")) : 0;
+        if (copy_wgs > 0 && std::string(world->kind()) != "thread-loopback" && std::string(world->kind()) != "single")
+            hnh::fatal("Error, HNH_PACE_COPY is a single-process measurement aid!");
+#endif
         for (int q = 0; q < windows; q++) {
             const int64_t r0 = cut[(size_t)q], w = cut[(size_t)q + 1] - r0;
             const size_t bytes = (size_t)w * (size_t)R * sizeof(double);
+#ifdef HNH_MEASUREMENT_AIDS
             if (bytes > 0 && resident && pace_gbps > 0.0) {
-                // HNH_PACE_COPY=<workgroups per link>: the paced stand-in also moves the bytes — chunk q of the own block is read once
-                // per peer and written to each peer's place in the landing buffer (a held operand's blocks all have the caller's
-                // contents in this measurement) — so the kernels meet the HBM traffic and the workgroups of a real exchange
-                const int copy_wgs = std::getenv("HNH_PACE_COPY") ? std::atoi(std::getenv("HNH_PACE_COPY")) : 0;
                 const double us = (double)bytes / (pace_gbps * 1e3);
                 if (copy_wgs > 0)
                     world->check(world->be->hnh_stream_paced_copy(world->ctx, HNH_STREAM_COMM, landing[slot].data() + landing_row(1, q, cut) * R,
@@ -331,6 +335,7 @@ private:
                 else
                     world->delay_us(us, HNH_STREAM_COMM);
             }
+#endif
             if (bytes > 0 && !resident) {
                 world->group_begin();
                 for (int k = 1; k < n; k++)  // my block is what ring rank me+k needs at ITS step k; I need the block of me-k at mine
@@ -357,9 +362,13 @@ private:
         CSRLocal* remote = choice->csr_blocks[1];
         one(0, *Brole, -1, remote == nullptr);
         if (remote != nullptr) {
-            // (HNH_FORCE_WINDOWS: measurement aid — walk the windows although a held operand's blocks are already there, which
-            // lets one rank's kernel sequence be timed without its peers, tools/rank_share_probe.py)
+#ifdef HNH_MEASUREMENT_AIDS
+            // (libhnh_host_aids.so only) HNH_FORCE_WINDOWS: walk the windows although a held operand's blocks are already there,
+            // which lets one rank's kernel sequence be timed without its peers (tools/rank_share_probe.py)
             static const bool force_windows = std::getenv("HNH_FORCE_WINDOWS") != nullptr;
+#else
+            constexpr bool force_windows = false;
+#endif
             const bool by_window = kernel->handles_windows() && remote->n_windows > 1 && (!resident || force_windows);
             if (!by_window) {
                 world->event_wait(event(8 + windows - 1), HNH_STREAM_COMPUTE);  // every chunk has landed

@@ -69,7 +69,7 @@ Backend* load_backend(const char* path_c) {
     HNH_BIND(hnh_ctx_create) HNH_BIND(hnh_ctx_destroy) HNH_BIND(hnh_last_error) HNH_BIND(hnh_ctx_stream)
     HNH_BIND(hnh_malloc) HNH_BIND(hnh_free) HNH_BIND(hnh_memcpy) HNH_BIND(hnh_memset) HNH_BIND(hnh_stream_sync)
     HNH_BIND(hnh_event_create) HNH_BIND(hnh_event_destroy) HNH_BIND(hnh_event_record) HNH_BIND(hnh_event_wait)
-    HNH_BIND(hnh_event_sync) HNH_BIND(hnh_event_elapsed_ms) HNH_BIND(hnh_stream_delay_us) HNH_BIND(hnh_stream_paced_copy)
+    HNH_BIND(hnh_event_sync) HNH_BIND(hnh_event_elapsed_ms)
     HNH_BIND(hnh_sddmm_coo) HNH_BIND(hnh_sddmm_csr) HNH_BIND(hnh_spmm_csr) HNH_BIND(hnh_fused_sddmm_spmm_csr)
     HNH_BIND(hnh_sddmm_csr_ex) HNH_BIND(hnh_spmm_csr_ex) HNH_BIND(hnh_fused_sddmm_spmm_csr_ex) HNH_BIND(hnh_csr_max_row_nnz)
     HNH_BIND(hnh_fused_sddmm_spmm_csr_x) HNH_BIND(hnh_row_epilogue_f64) HNH_BIND(hnh_row_epilogue_x) HNH_BIND(hnh_cg_step_f64)
@@ -85,6 +85,9 @@ Backend* load_backend(const char* path_c) {
     HNH_BIND(hnh_ipc_export) HNH_BIND(hnh_ipc_open) HNH_BIND(hnh_ipc_close) HNH_BIND(hnh_ipc_pull) HNH_BIND(hnh_ipc_flags_register) HNH_BIND(hnh_ipc_flags_unregister)
     HNH_BIND(hnh_stream_write_flag) HNH_BIND(hnh_stream_wait_flag)
     HNH_BIND(hnh_csr_plan_create) HNH_BIND(hnh_csr_plan_destroy) HNH_BIND(hnh_sddmm_csr_p) HNH_BIND(hnh_spmm_csr_p) HNH_BIND(hnh_fused_sddmm_spmm_csr_p)
+#ifdef HNH_MEASUREMENT_AIDS
+    HNH_BIND(hnh_stream_delay_us) HNH_BIND(hnh_stream_paced_copy)
+#endif
 #undef HNH_BIND
     b->name = b->hnh_backend_name();
     g_backends[path] = b;
@@ -224,7 +227,9 @@ void World::event_destroy(void* e) {
 }
 void World::event_record(void* e, int stream) { check(be->hnh_event_record(ctx, e, stream), "hnh_event_record"); }
 void World::event_wait(void* e, int stream) { check(be->hnh_event_wait(ctx, e, stream), "hnh_event_wait"); }
+#ifdef HNH_MEASUREMENT_AIDS
 void World::delay_us(double us, int stream) { check(be->hnh_stream_delay_us(ctx, stream, us), "hnh_stream_delay_us"); }
+#endif
 
 void* World::scratch(int slot, size_t bytes) {
     if ((int)scratch_.size() <= slot) scratch_.resize(slot + 1, {nullptr, 0});

@@ -102,7 +102,9 @@ public:
     void event_destroy(void* e);
     void event_record(void* e, int stream);
     void event_wait(void* e, int stream);
-    void delay_us(double us, int stream);  // holds the stream without memory traffic (paced stand-in of a transfer; measurement aid)
+#ifdef HNH_MEASUREMENT_AIDS
+    void delay_us(double us, int stream);  // holds the stream without memory traffic (paced stand-in of a transfer)
+#endif
     // scratch that persists across calls (grown on demand), one per slot
     void* scratch(int slot, size_t bytes);
 

@@ -70,17 +70,6 @@ int hnh_event_record(hnh_ctx* ctx, void* event, int stream);
 int hnh_event_wait(hnh_ctx* ctx, void* event, int stream); /* `stream` waits for `event` (device side) */
 int hnh_event_sync(hnh_ctx* ctx, void* event);            /* host waits for `event`                    */
 int hnh_event_elapsed_ms(hnh_ctx* ctx, void* start, void* stop, float* ms);
-/* Holds `stream` for `microseconds` (one idle-spinning wave on the constant 100 MHz clock: no memory traffic, one CU slot).
- * Measurement aid: the paced stand-in for an xGMI transfer of known duration when a rank's fetch/compute overlap is
- * timed on a single GPU (HNH_PACE_LINK_GBPS, tools/overlap_probe.py).  No counterpart in the reference. */
-int hnh_stream_delay_us(hnh_ctx* ctx, int stream, double microseconds);
-/* The same stand-in WITH the memory traffic and the compute units a transfer costs its receiver and sender: `nslices` slices of
- * `slice_bytes` are copied src -> dst_base + k * slice_bytes (k = 0 .. nslices-1; every slice reads the same source, as a rank's
- * block goes to all its peers) by `wgs_per_slice` workgroups each, throttled so that a slice takes `microseconds` (the modelled
- * link time).  HNH_PACE_COPY in the overlap measurement.  No counterpart in the reference. */
-int hnh_stream_paced_copy(hnh_ctx* ctx, int stream, void* dst_base, const void* src, size_t slice_bytes, int nslices,
-                          double microseconds, int wgs_per_slice);
-
 /* ---- local kernels --------------------------------------------------------------------------------
  * hnh_sddmm_coo — replaces StandardKernel::sddmm_local (sparse_kernels.cpp:13-57), COO view:
  *     for e in [0, nnz):  values[e] += < X[row_idx[e], :], Y[col_idx[e], :] >

@@ -27,6 +27,7 @@
 #include <unistd.h>
 
 #include "hnh_kernels.h"
+#include "hnh_measurement_aids.h"
 
 struct hnh_ctx {
     int device;

@@ -206,3 +206,25 @@ def test_matrix_market_workload(tmp_path):
     T.write_symmetric_mtx_with_duplicates(mtx, 300, 3)
     out = run_worker_directly(2, "--workload", "mtx:" + mtx, "--r", "16", "--no-tune")
     assert out["data"] == "file" and "g.mtx" in out["config"]["workload"] and out["check"]["ok"] and out["check"]["rows_checked"] == out["config"]["M"]
+
+
+def test_secondary_workloads_are_listed_with_their_checks():
+    """N = 1: the other workloads of the reference's harness ride in the same JSON line under "secondary", each with its byte
+    model, a fraction and a check of its own (toy sizes here; the code is the GPU run's)."""
+    port = free_port()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2",
+               HNH_BENCH_SECONDARY_SMALL="1")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_worker.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                          "--logm", "9", "--edge-factor", "8", "--r", "16"], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    sec = out["secondary"]
+    assert len(sec) == 7 and not [e for e in sec if "error" in e], [e.get("error") for e in sec]
+    by_name = {e["workload"]: e for e in sec}
+    for r in (8, 16, 256):
+        e = next(v for k, v in by_name.items() if "R=%d:" % r in k)
+        assert e["check"]["ok"] and all(e[op]["ms"] > 0 and e[op]["algorithmic_bytes"] > 0 for op in ("fused", "sddmm", "spmm"))
+    assert next(v for k, v in by_name.items() if "ALS" in k)["check"]["ok"]
+    assert next(v for k, v in by_name.items() if k.startswith("GAT"))["check"]["rel_err"] <= 1e-9
+    assert next(v for k, v in by_name.items() if k.startswith("R-MAT"))["check"]["ok"]
+    assert next(v for k, v in by_name.items() if "config 4" in k)["check"]["ok"]

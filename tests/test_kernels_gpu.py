@@ -596,7 +596,7 @@ def test_narrow_rows_line_granular_streams(ctx, R, shift):
 
 
 def test_stream_delay_and_paced_copy(ctx):
-    """The measurement stand-ins of the overlap probe: hnh_stream_delay_us holds a stream for the requested time (within 10 %),
+    """The measurement stand-ins of the overlap probe: hnh_stream_delay_us holds a stream for at least the requested time (and not for many times as long),
     hnh_stream_paced_copy delivers every slice bit for bit and takes at least the modelled time."""
     import time
     lib = ctx.lib
@@ -605,7 +605,7 @@ def test_stream_delay_and_paced_copy(ctx):
     ctx.check(lib.hnh_stream_delay_us(ctx.h, 1, 20000.0), "delay")
     ctx.sync(1)
     dt = time.perf_counter() - t0
-    assert 0.020 <= dt <= 0.030, dt
+    assert 0.020 <= dt <= 0.200, dt  # (the upper bound only catches a clock-rate mistake: a loaded box may add scheduling time)
     n = 3 * 4096 + 2  # doubles per slice: not a multiple of the copy tile
     src = np.random.default_rng(3).uniform(-1, 1, n)
     d_src, d_dst = ctx.upload(src), ctx.upload(np.zeros(5 * n))

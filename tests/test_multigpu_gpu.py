@@ -1,6 +1,6 @@
-"""Several GPUs, the product transport: RCCL send/recv groups across processes.  Every test here needs at least two
-visible MI355X and skips on a one-GPU box — except the last one, which checks what `bench.py --gpus 2` does THERE
-(RCCL refuses two ranks on one device: one JSON line with "error", rank and phase, within seconds, no hang)."""
+"""Several ranks as several PROCESSES.  The RCCL tests need at least two visible MI355X and skip on a one-GPU box; the
+ipc-pull transport (receivers copy out of their peers' mapped buffers) also works between processes that SHARE one GPU, so
+its schedule tests and the `bench.py --gpus N` runs below exercise the cross-process device-to-device path on any box."""
 import json
 import os
 import subprocess
@@ -85,8 +85,9 @@ def run_bench(n, *extra, timeout=900):
 
 @pytest.mark.parametrize("n", [2, 8])
 def test_bench_self_launch_on_real_gpus(n):
-    """`python bench.py --gpus N` as typed: spawns its N workers, preflight, measured search over replication factor and
-    route, timed steps, and the row/column-keyed result check — which fails if any block travels to the wrong place."""
+    """`python bench.py --gpus N` as typed: spawns its N workers, tries RCCL and the ipc-pull transport in child processes, runs
+    the preflight, the measured search over transport, replication factor and route, the timed steps, and the row/column-keyed
+    result check — which fails if any block travels to the wrong place."""
     if gpus() < n:
         pytest.skip("needs %d GPUs, this box has %d" % (n, gpus()))
     res = run_bench(n)
@@ -95,43 +96,50 @@ def test_bench_self_launch_on_real_gpus(n):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == n and out["backend"] == "hip-gfx950" and out["check"]["ok"] and out["check"]["rows_checked"] == 1 << 16
-    assert len(out["preflight"]["primitives_ok"]) == 9 and out["config"]["transport"] == "rccl"
-    assert {k.split()[0] for k in out["config"]["route_tuning_ms_per_step"]} >= {"c=1", "c=2"}
+    assert len(out["preflight"]["primitives_ok"]) == 9 and out["config"]["transport"] in ("rccl", "ipc-pull")
+    assert all(v.startswith("ok") for v in out["config"]["transport_trials"].values()), out["config"]["transport_trials"]
+    tuned = out["config"]["route_tuning_ms_per_step"]
+    assert {k.split()[0] for k in tuned} >= {"c=1", "c=2"} and {k.rsplit("[", 1)[1] for k in tuned} >= {"rccl]", "ipc]", "ipc-kernel]"}
 
 
 @pytest.mark.parametrize("n", [2, 4])
 def test_bench_processes_share_one_gpu(n):
-    """`python bench.py --gpus N` typed as is, N worker PROCESSES on whatever GPU is here (they share it): the HIP kernels,
-    device-resident set-up, preflight, the measured search over replication factor and route, the timed steps and the
-    row/column-keyed result check — everything of a multi-GPU run but RCCL itself (tests/bench_worker_gpu.py stages the
-    transfers through gloo)."""
-    if gpus() < 1:
-        pytest.skip("needs a GPU")
-    env = dict(os.environ, GLOO_SOCKET_IFNAME="lo", HNH_BENCH_WORKER=os.path.join(ROOT, "tests", "bench_worker_gpu.py"))
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+    """`python bench.py --gpus N` typed as is on a box with ONE GPU: the N worker processes share it.  RCCL refuses that (its
+    child-process trial says so and the run goes on without it); the ipc-pull transport moves every block device to device
+    between the processes — both of its variants are measured — and the run ends with a checked line: HIP kernels,
+    device-resident set-up, preflight, the search over transport variant, replication factor and route, timed steps, the
+    row/column-keyed result check."""
+    if gpus() != 1:
+        pytest.skip("this is the one-GPU behaviour")
+    env = dict(os.environ, GLOO_SOCKET_IFNAME="lo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "HNH_BENCH_WORKER"):
         env.pop(k, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--logm", "14",
-                          "--edge-factor", "16", "--r", "32", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                          "--edge-factor", "16", "--r", "32", "--no-cpu-baseline", "--probe-timeout", "240"], env=env, capture_output=True, text=True, timeout=1500)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == n and out["backend"] == "hip-gfx950" and out["config"]["transport"] == "callback"  # (gloo-staged here; "rccl" on a multi-GPU node)
+    assert out["n_gpus"] == n and out["backend"] == "hip-gfx950" and out["config"]["transport"] == "ipc-pull" and "incomplete" not in out
     assert out["check"]["ok"] and out["check"]["rows_checked"] == 1 << 14 and out["check"]["rel_err"] <= 1e-11
+    trials = out["config"]["transport_trials"]
+    assert trials["ipc"].startswith("ok") and not trials["rccl"].startswith("ok")
     tuned = out["config"]["route_tuning_ms_per_step"]
     assert {k.split()[0] for k in tuned} == {"c=%d" % c for c in (1, 2, 4) if n % c == 0}
-    assert len(out["preflight"]["primitives_ok"]) == 9
+    assert {k.rsplit("[", 1)[1] for k in tuned} == {"ipc]", "ipc-kernel]"} and all(v is not None for v in tuned.values())
+    assert len(out["preflight"]["primitives_ok"]) == 9 and out["preflight"]["transports"] == ["ipc", "ipc-kernel"]
 
 
-def test_bench_two_ranks_on_one_gpu_ends_with_an_error_line():
-    """One GPU, two ranks: RCCL refuses the second rank on the same device.  The run must END (no hang) with one JSON line
-    naming a rank and the phase (transport creation), and a non-zero exit code."""
+def test_bench_rccl_only_on_one_gpu_ends_with_an_error_line():
+    """One GPU, two ranks, --transport rccl: RCCL refuses the second rank on the same device.  The run must END (no hang) with
+    one JSON line that says no transport is usable and why, and a non-zero exit code."""
     if gpus() != 1:
         pytest.skip("this is the one-GPU behaviour")
-    res = run_bench(2, "--watchdog", "60", "--launch-timeout", "150", timeout=240)
+    res = run_bench(2, "--transport", "rccl", "--watchdog", "60", "--launch-timeout", "400", "--probe-timeout", "120", timeout=600)
     assert res.returncode != 0
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["value"] is None and "error" in out and out["n_gpus"] == 2
-    assert any("transport creation" in ph or "preflight" in ph for ph in out["phases"].values()), out
+    assert any("transport" in ph for ph in out["phases"].values()), out
+    assert "no usable device-to-device transport" in res.stderr

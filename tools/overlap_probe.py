@@ -31,6 +31,8 @@ import time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the paced stand-ins and HNH_FORCE_WINDOWS live in the measurement build of the host library only
+os.environ.setdefault("HNH_HOST_LIB_DEV", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "distributed_sddmm_amd", "lib", "libhnh_host_aids.so"))
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--p", type=int, default=8)
