@@ -455,7 +455,7 @@ int hnh_dist_set_r(hnh_dist* d, int R) {
 }
 int hnh_dist_json(hnh_dist* d, int which, char* buf, size_t capacity) {
     return guarded(d->w, [&] {
-        std::string s = which == 0 ? d->d->json_algorithm_info() : d->d->json_perf_statistics();
+        std::string s = (which == 0 ? d->d->json_algorithm_info() : d->d->json_perf_statistics()).dump();
         if (s.size() + 1 > capacity) hnh::fatal("Error, JSON buffer too small");
         std::memcpy(buf, s.c_str(), s.size() + 1);
     });

@@ -17,6 +17,7 @@
 //     temporaries) is allocated once and reused;
 //   * JSON is produced as text (same keys as the reference's nlohmann objects).
 #pragma once
+#include "json.hpp"
 #include <algorithm>
 #include <cassert>
 #include <iomanip>
@@ -109,26 +110,39 @@ public:
     }
 
     // ---- reporting (distributed_sparse.h:131-179, 245-261)
-    std::string json_algorithm_info() {
+    hnh::json json_algorithm_info() {
         std::vector<uint64_t> mine = {(uint64_t)(S->owned_coords_end - S->owned_coords_start),
                                       (uint64_t)(ST->owned_coords_end - ST->owned_coords_start)};
         std::vector<uint64_t> all(2 * (size_t)p);
         world->host_allgather(mine.data(), all.data(), 2 * sizeof(uint64_t));
-        std::ostringstream o;
-        o << "{\"alg_name\": \"" << algorithm_name << "\", \"m\": " << M << ", \"n\": " << N << ", \"nnz\": " << S->dist_nnz
-          << ", \"r\": " << R << ", \"adjacency_mode\": " << grid->adjacency << ", \"p\": " << p << ", \"c\": " << c
-          << ", \"dim_interpretations\": [";
-        for (size_t i = 0; i < proc_grid_names.size(); i++) o << (i ? ", " : "") << "\"" << proc_grid_names[i] << "\"";
-        o << "], \"dim_values\": [";
-        for (size_t i = 0; i < proc_grid_names.size(); i++) o << (i ? ", " : "") << grid->dim_list[i];
-        o << "], \"nnz_procs\": [";
-        for (int r = 0; r < p; r++) o << (r ? ", " : "") << all[2 * r];
-        o << "], \"nnz_tpose_procs\": [";
-        for (int r = 0; r < p; r++) o << (r ? ", " : "") << all[2 * r + 1];
-        o << "], \"transport\": \"" << world->kind() << "\", \"backend\": \"" << world->be->name << "\"}";
-        return o.str();
+        hnh::json jobj;  // the reference's keys, in its order (distributed_sparse.h:132-141)
+        jobj["alg_name"] = algorithm_name;
+        jobj["m"] = (uint64_t)M;
+        jobj["n"] = (uint64_t)N;
+        jobj["nnz"] = (uint64_t)S->dist_nnz;
+        jobj["r"] = R;
+        jobj["adjacency_mode"] = grid->adjacency;
+        jobj["p"] = p;
+        jobj["c"] = c;
+        hnh::json dim_interpretations = hnh::json::array(), dim_values = hnh::json::array();
+        for (size_t i = 0; i < proc_grid_names.size(); i++) {
+            dim_interpretations.push_back(proc_grid_names[i]);
+            dim_values.push_back(grid->dim_list[i]);
+        }
+        jobj["dim_interpretations"] = dim_interpretations;
+        jobj["dim_values"] = dim_values;
+        hnh::json nnz = hnh::json::array(), nnz_tpose = hnh::json::array();
+        for (int r = 0; r < p; r++) {
+            nnz.push_back(all[2 * (size_t)r]);
+            nnz_tpose.push_back(all[2 * (size_t)r + 1]);
+        }
+        jobj["nnz_procs"] = nnz;
+        jobj["nnz_tpose_procs"] = nnz_tpose;
+        jobj["transport"] = world->kind();  // (two keys the reference does not have)
+        jobj["backend"] = world->be->name;
+        return jobj;
     }
-    void print_algorithm_info() { std::cout << json_algorithm_info() << std::endl; }
+    void print_algorithm_info() { std::cout << json_algorithm_info().dump(4) << std::endl; }
     void setVerbose(bool value) { verbose = value; }
 
     virtual VectorXd like_S_values(double value) { return VectorXd::Constant(S->owned_coords_end - S->owned_coords_start, value); }
@@ -196,17 +210,14 @@ public:
         if (spans_.size() > 2048) resolve_spans(spans_.size() / 2);  // old spans finished long ago: no stall to speak of
     }
 
-    std::string json_perf_statistics() {  // mean over ranks, as distributed_sparse.h:245-261
+    hnh::json json_perf_statistics() {  // mean over ranks, as distributed_sparse.h:245-261
         resolve_spans(spans_.size());
         std::vector<double> vals;
         for (auto& key : perf_counter_keys) vals.push_back(total_time[key]);
         world->host_allreduce_sum(vals.data(), vals.size());
-        std::ostringstream o;
-        o << std::setprecision(17) << "{";
-        for (size_t i = 0; i < perf_counter_keys.size(); i++)
-            o << (i ? ", " : "") << "\"" << perf_counter_keys[i] << "\": " << vals[i] / p;
-        o << "}";
-        return o.str();
+        hnh::json j_obj = hnh::json::object();
+        for (size_t i = 0; i < perf_counter_keys.size(); i++) j_obj[perf_counter_keys[i]] = vals[i] / p;
+        return j_obj;
     }
 
     void print_performance_statistics() {
@@ -214,8 +225,8 @@ public:
             std::cout << std::endl << "================================" << std::endl << "==== Performance Statistics ====" << std::endl
                       << "================================" << std::endl;
         }
-        std::string info = json_algorithm_info(), stats = json_perf_statistics();
-        if (proc_rank == 0) std::cout << info << std::endl << stats << std::endl << "=================================" << std::endl;
+        hnh::json info = json_algorithm_info(), stats = json_perf_statistics();
+        if (proc_rank == 0) std::cout << info.dump(4) << std::endl << stats.dump(4) << std::endl << "=================================" << std::endl;
     }
 
     // If the input buffers need to be shifted / transposed

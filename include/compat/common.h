@@ -6,3 +6,4 @@
 using hnh::BufferPair;
 using hnh::DenseMatrix;
 using hnh::VectorXd;
+using namespace std;  // the reference's headers say so at global scope, and code written against them relies on it

@@ -175,3 +175,50 @@ def test_transport_preflight_on_the_loopback_transport(p):
     res = H.run_spmd(p, body)
     assert all(max(errs) == 0.0 for errs, _ in res)
     assert len({sig for _, sig in res}) == 1 and res[0][1][1] == 2 * len(H.World.PREFLIGHT)
+
+
+def test_the_references_own_harness_compiles_against_the_class_headers(tmp_path):
+    """The reference's benchmark_dist.cpp, UNCHANGED (copied from /root/reference at test time, never into the repository),
+    compiled against include/compat — its includes (`distributed_sparse.h`, `json.hpp`, `mpi.h` ...), `using json =
+    nlohmann::json`, `j_obj["alg_info"] = d_ops->json_algorithm_info()` and `.dump(4)` all resolve — and run on the kernel test
+    double: three records with the reference's keys."""
+    import json
+    import shutil
+    import subprocess
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "benchmark_dist.cpp")):
+        pytest.skip("the reference's sources are not on this box")
+    for f in ("benchmark_dist.cpp", "benchmark_dist.hpp"):
+        shutil.copy(os.path.join(ref, f), tmp_path / f)
+    (tmp_path / "main.cpp").write_text('''
+#include "benchmark_dist.hpp"
+#include "world.hpp"
+int main(int argc, char** argv) {
+    hnh::load_backend(argv[1]);
+    hnh::SingleWorld world(hnh::default_backend(), 0);
+    hnh::set_current_world(&world);
+    {
+        SpmatLocal S;
+        S.loadTuples(false, 8, 8, "");
+        benchmark_algorithm(&S, "15d_fusion2", argv[2], true, 16, 1, "vanilla");
+        benchmark_algorithm(&S, "15d_sparse", argv[2], false, 16, 1, "vanilla");
+        benchmark_algorithm(&S, "25d_dense_replicate", argv[2], true, 16, 1, "als");
+    }
+    world.sync_all();
+    hnh::set_current_world(nullptr);
+    return 0;
+}
+''')
+    lib = os.path.join(T.ROOT, "distributed_sddmm_amd", "lib")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-fopenmp", "-w", "-I" + os.path.join(T.ROOT, "include", "compat"),
+                    "-I" + os.path.join(T.ROOT, "distributed_sddmm_amd", "csrc", "host"), "-I" + os.path.join(T.ROOT, "include"),
+                    "benchmark_dist.cpp", "main.cpp", "-o", "refbench", "-L" + lib, "-lhnh_host", "-ldl", "-lpthread", "-Wl,-rpath," + lib],
+                   cwd=tmp_path, check=True, capture_output=True, timeout=600)
+    out = tmp_path / "out.json"
+    res = subprocess.run([str(tmp_path / "refbench"), T.ORACLE_BACKEND, str(out)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    recs = json.loads("[" + out.read_text().rstrip().rstrip(",") + "]")
+    assert [r["alg_name"] for r in recs] == ["15d_fusion2", "15d_sparse", "25d_dense_replicate"]
+    for r in recs:
+        assert set(r) == {"elapsed", "overall_throughput", "fused", "num_trials", "alg_name", "alg_info", "application_communication_time", "perf_stats"}
+        assert r["num_trials"] == 5 and r["alg_info"]["m"] == 256 and r["alg_info"]["p"] == 1 and "Computation Time" in r["perf_stats"]

@@ -303,6 +303,80 @@ def test_repeat_runs_are_bitwise_reproducible(monkeypatch, atomics):
     ctx.close()
 
 
+@pytest.mark.parametrize("budget_mb", ["0.01", "0"])
+def test_hub_scratch_budget_mixes_ordered_and_atomic_segments(monkeypatch, budget_mb):
+    """HNH_HUB_SCRATCH_MB bounds the partial-row scratch of the hub-row segments: with room for only SOME of a block's segments
+    (0.01 MB = 20 of the 43 here) the first ones are reduced in order and the rest combine with atomics in the same launch; with
+    no room at all every segment uses atomics.  Either way the results agree with the oracle, through the per-call entry points
+    and through a block descriptor with a structure plan (whose exact segment count sizes the scratch), and a row epilogue that
+    cannot ride in the launch runs as its own kernel."""
+    monkeypatch.setenv("HNH_HUB_SCRATCH_MB", budget_mb)
+    from distributed_sddmm_amd import _kernels as K
+    ctx = K.Ctx(0)
+    lib, R = ctx.lib, 64
+    rng = np.random.default_rng(21)
+    rows, cols = 300, 9000
+    lens = rng.integers(0, 40, rows)
+    lens[5], lens[77], lens[200] = 6000, 1500, 3100
+    rowptr = np.zeros(rows + 1, np.int32); rowptr[1:] = np.cumsum(lens)
+    cidx = np.concatenate([np.sort(rng.choice(cols, int(n), replace=False)) for n in lens]).astype(np.int32)
+    ridx = np.repeat(np.arange(rows, dtype=np.int32), lens)
+    X, Y = rng.standard_normal((rows, R)), rng.standard_normal((cols, R))
+    d_rp, d_c, dX, dY = ctx.upload(rowptr), ctx.upload(cidx), ctx.upload(X), ctx.upload(Y)
+    mid = O.sddmm_local(ridx, cidx, np.zeros(len(cidx)), X, Y)
+    want = O.spmm_local(rowptr, cidx, mid, Y, np.zeros((rows, R)))
+    plan = C.c_void_p()
+    ctx.check(lib.hnh_csr_plan_create(ctx.h, C.byref(plan)), "plan")
+    blk = K.CsrBlock(rows, len(cidx), cols, int(lens.max()), 0, d_rp.ptr, d_c.ptr, plan)
+    for use_plan in (False, True, True):  # (the second planned call reuses the cached hub list)
+        dv, dOut, dDot = ctx.upload(np.zeros(len(cidx))), ctx.upload(np.full((rows, R), 7.0)), ctx.upload(np.zeros(rows))
+        ex = K.FusedExtras(0.0, 0.5, dDot.ptr, None, None, 0)
+        if use_plan:
+            ctx.check(lib.hnh_fused_sddmm_spmm_csr_p(ctx.h, C.byref(blk), dv.ptr, None, dX.ptr, dY.ptr, dOut.ptr, R, 3, C.byref(ex), None, 0), "fused_p")
+        else:
+            ctx.check(lib.hnh_fused_sddmm_spmm_csr_x(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, None, dX.ptr, dY.ptr, dOut.ptr, R, 3, len(cidx),
+                                                     int(lens.max()), cols, C.byref(ex), 0), "fused_x")
+        ctx.sync()
+        out = want + 0.5 * X  # Out += x_scale * X, rowdot = <X, Out>
+        assert rel(dv.get(), mid) <= TOL and rel(dOut.get(), out) <= TOL
+        assert rel(dDot.get(), np.sum(X * out, axis=1)) <= TOL
+        dOut2 = ctx.upload(np.zeros((rows, R)))
+        if use_plan:
+            ctx.check(lib.hnh_spmm_csr_p(ctx.h, C.byref(blk), dv.ptr, dY.ptr, dOut2.ptr, R, None, 0), "spmm_p")
+        else:
+            ctx.check(lib.hnh_spmm_csr_ex(ctx.h, rows, d_rp.ptr, d_c.ptr, dv.ptr, dY.ptr, dOut2.ptr, R, len(cidx), int(lens.max()), cols, 0), "spmm")
+        ctx.sync()
+        assert rel(dOut2.get(), want) <= TOL
+        for d in (dv, dOut, dDot, dOut2):
+            d.free()
+    ctx.check(lib.hnh_csr_plan_destroy(ctx.h, plan), "plan destroy")
+    for d in (d_rp, d_c, dX, dY):
+        d.free()
+
+
+def test_a_plan_refuses_another_blocks_arrays(ctx):
+    """A structure plan belongs to the block it was first used with: handing it to other index arrays is an error, not a silently
+    wrong answer."""
+    from distributed_sddmm_amd import _kernels as K
+    lib, R = ctx.lib, 16
+    rowptr = np.arange(0, 41, 4, dtype=np.int32)
+    cidx = np.tile(np.arange(4, dtype=np.int32), 10)
+    d_rp, d_c, d_c2 = ctx.upload(rowptr), ctx.upload(cidx), ctx.upload(cidx)
+    dv, dX, dY = ctx.upload(np.zeros(40)), ctx.upload(np.ones((10, R))), ctx.upload(np.ones((4, R)))
+    plan = C.c_void_p()
+    ctx.check(lib.hnh_csr_plan_create(ctx.h, C.byref(plan)), "plan")
+    blk = K.CsrBlock(10, 40, 4, 4, 0, d_rp.ptr, d_c.ptr, plan)
+    ctx.check(lib.hnh_sddmm_csr_p(ctx.h, C.byref(blk), dv.ptr, dX.ptr, dY.ptr, R, None, 0), "sddmm_p")
+    other = K.CsrBlock(10, 40, 4, 4, 0, d_rp.ptr, d_c2.ptr, plan)
+    assert lib.hnh_sddmm_csr_p(ctx.h, C.byref(other), dv.ptr, dX.ptr, dY.ptr, R, None, 0) != 0
+    assert b"another block" in lib.hnh_last_error(ctx.h)
+    ctx.sync()
+    assert np.allclose(dv.get(), R)
+    ctx.check(lib.hnh_csr_plan_destroy(ctx.h, plan), "plan destroy")
+    for d in (d_rp, d_c, d_c2, dv, dX, dY):
+        d.free()
+
+
 @pytest.mark.parametrize("R", [16, 128, 100, 257])
 @pytest.mark.parametrize("hubs", [False, True])
 def test_windowed_passes_equal_the_whole_block(ctx, R, hubs):
