@@ -351,7 +351,7 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
             }
             wgt = group_multi_reduce<LPR, U>(d, lig);
             if (have) {
-                const bool overwrite = fused_op(OP) && (flags & HNH_FUSED_VALUES_OVERWRITE);
+                const bool overwrite = (OP != Op::kSpmm) && (flags & HNH_FUSED_VALUES_OVERWRITE);
                 if (!overwrite) wgt += load_stream(values + mine);
                 if (fused_op(OP) && (flags & HNH_FUSED_LEAKY_RELU)) {  // the activated weight is what gets stored
                     if (svalues != nullptr) wgt *= svalues[mine];
@@ -403,7 +403,7 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
         constexpr int SUBQ = LPR / UQ;  // lanes holding the same reduced dot product
         constexpr int IPL = 32 / LPR;   // column indices per lane of a 32-index block (one line of `colidx`)
         constexpr int VPL = T / LPR > 0 ? T / LPR : 1;  // values per lane of a trip's line (LPR = 16: one)
-        const bool vals_overwrite = fused_op(OP) && (flags & HNH_FUSED_VALUES_OVERWRITE);
+        const bool vals_overwrite = (OP != Op::kSpmm) && (flags & HNH_FUSED_VALUES_OVERWRITE);
         const bool reads_values = (OP == Op::kSpmm) || !vals_overwrite;
 
         auto load_block = [&](int b, int (&dst)[IPL]) {  // the aligned block of 32 column indices starting at nonzero b
@@ -1794,10 +1794,11 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
         for (int col0 = 0; col0 < R; col0 += wtile) {
             const int ncols = (R - col0 < wtile) ? (R - col0) : wtile;
             int rc;
+            const unsigned ft = (col0 == 0) ? flags : (flags & ~HNH_FUSED_VALUES_OVERWRITE);  // later tiles add their partial dot products
             if (s.w == 2)
-                rc = launch_row<OP, 64, 1, 2, false>(ctx, st, lc, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags, ex, last);
+                rc = launch_row<OP, 64, 1, 2, false>(ctx, st, lc, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, col0, ncols, ft, ex, last);
             else
-                rc = launch_row<OP, 64, 1, 1, false>(ctx, st, lc, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags, ex, last);
+                rc = launch_row<OP, 64, 1, 1, false>(ctx, st, lc, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, col0, ncols, ft, ex, last);
             if (rc != HNH_OK) return rc;
         }
         return HNH_OK;
@@ -1870,10 +1871,11 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
     for (int col0 = 0; col0 < R; col0 += tile) {
         const int ncols = (R - col0 < tile) ? (R - col0) : tile;
         int rc;
+        const unsigned ft = (col0 == 0) ? flags : (flags & ~HNH_FUSED_VALUES_OVERWRITE);  // later tiles add their partial dot products
         if (s.w == 2)
-            rc = launch_row<OP, 64, 1, 2, false>(ctx, st, lc, rows, rowptr, rowptr, rowptr + 1, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags, ex);
+            rc = launch_row<OP, 64, 1, 2, false>(ctx, st, lc, rows, rowptr, rowptr, rowptr + 1, colidx, values, svalues, X, Y, Out, R, col0, ncols, ft, ex);
         else
-            rc = launch_row<OP, 64, 1, 1, false>(ctx, st, lc, rows, rowptr, rowptr, rowptr + 1, colidx, values, svalues, X, Y, Out, R, col0, ncols, flags, ex);
+            rc = launch_row<OP, 64, 1, 1, false>(ctx, st, lc, rows, rowptr, rowptr, rowptr + 1, colidx, values, svalues, X, Y, Out, R, col0, ncols, ft, ex);
         if (rc != HNH_OK) return rc;
     }
     return HNH_OK;
@@ -2169,10 +2171,11 @@ int hnh_csr_plan_destroy(hnh_ctx* ctx, hnh_csr_plan* plan) {
     return HNH_OK;
 }
 
-int hnh_sddmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* b, double* values, const double* X, const double* Y, int R, const hnh_csr_window* window,
-                    int stream) {
+int hnh_sddmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* b, double* values, const double* X, const double* Y, int R, unsigned flags,
+                    const hnh_csr_window* window, int stream) {
     HNH_ENTER(ctx, stream);
     if (!b) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sddmm_csr_p: null block");
+    if (flags & ~HNH_FUSED_VALUES_OVERWRITE) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sddmm_csr_p: unknown flag");
     if (int rc = check_common(ctx, b->rows, R, "hnh_sddmm_csr_p")) return rc;
     if (b->rows == 0) return HNH_OK;
     if (!b->rowptr || !b->col_idx || !values || !X || !Y) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sddmm_csr_p: null pointer");
@@ -2180,7 +2183,7 @@ int hnh_sddmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* b, double* values, const 
     hnh::WideLaunch wide(ctx, stream);
     if (wide.status != HNH_OK) return wide.status;
     return wide.finish(dispatch_row<Op::kSddmm>(ctx, wide.stream(), stream, s, b->rows, b->nnz, b->max_row_nnz, window ? -1 : b->cols, b->rowptr, b->col_idx,
-                                                values, nullptr, X, Y, nullptr, R, 0u, Extras(), nullptr, window, b->plan));
+                                                values, nullptr, X, Y, nullptr, R, flags, Extras(), nullptr, window, b->plan));
 }
 
 int hnh_spmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* b, const double* values, const double* X, double* Out, int R, const hnh_csr_window* window,

@@ -144,10 +144,12 @@ public:
         if ((uint64_t)SValues.size() != choice->blockStarts[1]) hnh::fatal("Error, sparse value vector has the wrong length!");
         const bool is_sddmm = (mode == k_sddmmA || mode == k_sddmmB);
 
+        // (SDDMM: the travelling block's first visit — step 0, at home — may store instead of add, see CSRLocal::values_fresh)
+        const bool fresh = is_sddmm && kernel->overwrites_fresh_values();
         {
             auto t = phase_begin("Computation Time");
-            if (is_sddmm) choice->setValuesConstant(0.0);
-            else choice->setCSRValues(SValues);
+            if (is_sddmm && !fresh) choice->setValuesConstant(0.0);
+            else if (!is_sddmm) choice->setCSRValues(SValues);
             phase_end(t);
         }
         if (initial_replicate && c > 1) {
@@ -180,7 +182,9 @@ public:
             for (int i = 0; i < s; i++) {
                 auto t = phase_begin("Computation Time");
                 if (i > 0) world->event_wait(event(1 + (i - 1) % 2), HNH_STREAM_COMPUTE);  // both shifts of step i-1 landed
+                if (choice->csr_blocks[0] != nullptr) choice->csr_blocks[0]->values_fresh = fresh && i == 0;
                 kernel->triple_function(kmode, *choice, stationary, *cur, 0, localAcols * grid->j);
+                if (choice->csr_blocks[0] != nullptr) choice->csr_blocks[0]->values_fresh = false;
                 phase_end(t);
                 if (s > 1) {
                     t = phase_begin("Dense Cyclic Shift Time");

@@ -138,7 +138,7 @@ public:
                 choice->setCSRValues(SValues);
                 phase_end(t);
             }
-        } else {
+        } else if (!kernel->overwrites_fresh_values()) {  // (otherwise the stationary block's first visit stores instead of adding)
             auto t = phase_begin("Computation Time");
             choice->setValuesConstant(0.0);
             phase_end(t);
@@ -163,7 +163,9 @@ public:
             for (int i = 0; i < s; i++) {
                 auto t = phase_begin("Computation Time");
                 if (i > 0) world->event_wait(event(1 + (i - 1) % 2), HNH_STREAM_COMPUTE);
+                if (choice->csr_blocks[0] != nullptr) choice->csr_blocks[0]->values_fresh = kernel->overwrites_fresh_values() && i == 0;
                 kernel->triple_function(temp, *choice, *curA, *curB, 0, pMod(grid->i + grid->j + i, s) * localAcols);
+                if (choice->csr_blocks[0] != nullptr) choice->csr_blocks[0]->values_fresh = false;
                 phase_end(t);
                 if (i < s - 1) {
                     t = phase_begin("Dense Cyclic Shift Time");

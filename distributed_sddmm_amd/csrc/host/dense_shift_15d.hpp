@@ -46,6 +46,9 @@ public:
     DenseMatrix ring_spare[2];        // relay ring: persistent spare buffers of the moving operand
     enum RingMode { kRelay, kMeshFetch };
     RingMode ring_mode;
+    // the read-WRITE ring (SpMM accumulator of replication reuse) in two row halves, one half's shift under the other half's kernel
+    // (ring_readwrite_halves); HNH_ACC_HALVES=0: the reference's kernel -> shift sequence
+    bool acc_halves = true;
 
     // Merged layout (approach 2 under the mesh fetch, more than one rank per ring).  The rank's S is kept as TWO blocks:
     //   csr_blocks[0]  the block column it owns (visited at step 0, gathers from the caller's own dense block), and
@@ -93,6 +96,7 @@ public:
             if (std::string(m) == "relay") ring_mode = kRelay;
             else if (std::string(m) != "mesh") hnh::fatal("Error, HNH_RING_MODE must be relay or mesh!");
         }
+        if (const char* h = std::getenv("HNH_ACC_HALVES")) acc_halves = std::atoi(h) != 0;
         if (c < 1 || p % c != 0) hnh::fatal("Error, for 1.5D algorithm, must have c divide num_procs!");
         if (fusionApproach != 1 && fusionApproach != 2) hnh::fatal("Error, fusion approach must be 1 or 2!");
 
@@ -481,10 +485,13 @@ public:
             phase_end(t);
         }
 
+        // SDDMM: every block (window) is visited exactly once per call, so a kernel that honours CSRLocal::values_fresh stores its
+        // results and the zero fill of the reference (distributed_sparse.h:280) is not needed; other plugins get zeroed values
+        const bool fresh = is_sddmm && kernel->overwrites_fresh_values();
         {
             auto t = phase_begin("Computation Time");
-            if (is_sddmm) choice->setValuesConstant(0.0);
-            else choice->setCSRValues(SValues);
+            if (is_sddmm && !fresh) choice->setValuesConstant(0.0);
+            else if (!is_sddmm) choice->setCSRValues(SValues);
             phase_end(t);
         }
 
@@ -497,7 +504,10 @@ public:
         const bool moving_readonly = is_sddmm || fusionApproach == 2;
         auto step = [&](int i, DenseMatrix& cur) {
             auto t = phase_begin("Computation Time");
+            CSRLocal* blk = choice->csr_blocks[block_at(i)];
+            if (blk != nullptr) blk->values_fresh = fresh;
             kernel->triple_function(mode_temp, *choice, stationary, cur, block_at(i), 0);
+            if (blk != nullptr) blk->values_fresh = false;
             phase_end(t);
         };
         if (merged) {
@@ -507,11 +517,15 @@ public:
                 CSRLocal* blk = choice->csr_blocks[block_id];
                 if (blk == nullptr) return;
                 blk->window = window;
+                blk->values_fresh = fresh;
                 kernel->triple_function(mode_temp, *choice, stationary, Y, block_id, 0);
+                blk->values_fresh = false;
                 blk->window = -1;
             });
         } else if (moving_readonly) {
             ring_readonly(Brole, n, step);
+        } else if (n > 1 && acc_halves && kernel->handles_row_parts()) {
+            ring_readwrite_halves(Brole, n, choice, step);
         } else {
             ring_readwrite(Brole, n, step);
         }
@@ -566,6 +580,48 @@ private:
                 phase_end(t);
             }
         }
+    }
+
+    // The same ring with the accumulator cut into two row halves H0, H1 (CSRLocal::row_part: the visiting block's SpMM runs per half):
+    //     compute:  K(i,H0)  K(i,H1)            K(i+1,H0)  K(i+1,H1) ...
+    //     comm:              S(i,H0)  S(i,H1)              S(i+1,H0) ...
+    // S(i,H0) waits for K(i,H0) only and runs under K(i,H1); K(i+1,H0) waits for S(i,H0) only and runs under S(i,H1): per step
+    // max(kernel, shift) instead of their sum (the reference's kernel -> MPI_Sendrecv -> barrier, 15D_dense_shift.hpp:343-356).
+    // Same rows, same arithmetic per row, same n shifts; a half is sent only after its kernel and overwritten only after its send.
+    template <typename Step>
+    void ring_readwrite_halves(DenseMatrix* start, int n, SpmatLocal* choice, Step&& step) {
+        hnh::BufferPair bBuf(start, &ring_spare[0]);
+        held_in_ring = false;  // ring_spare[0] is overwritten
+        const int dst = pMod(grid->rankInCol + 1, n), src = pMod(grid->rankInCol - 1, n);
+        const int64_t h = start->rows() / 2, cols = start->cols();
+        const size_t bytes0 = (size_t)h * (size_t)cols * sizeof(double), bytes1 = (size_t)(start->rows() - h) * (size_t)cols * sizeof(double);
+        order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // earlier users of the spare are done
+        for (int i = 0; i < n; i++) {
+            CSRLocal* blk = choice->csr_blocks[block_at(i)];
+            DenseMatrix* act = bBuf.getActive();
+            DenseMatrix* pas = bBuf.getPassive();
+            for (int part = 0; part < 2; part++) {
+                if (i > 0) world->event_wait(event(12 + part), HNH_STREAM_COMPUTE);  // this half of the arriving accumulator has landed
+                if (blk != nullptr) blk->select_row_part(part);
+                step(i, *act);
+                if (blk != nullptr) blk->select_row_part(-1);
+                world->event_record(event(10 + part), HNH_STREAM_COMPUTE);
+            }
+            auto t = phase_begin("Cyclic Shift Time");
+            for (int part = 0; part < 2; part++) {
+                world->event_wait(event(10 + part), HNH_STREAM_COMM);
+                const size_t off = part == 0 ? 0 : (size_t)h * (size_t)cols, bytes = part == 0 ? bytes0 : bytes1;
+                world->sendrecv(grid->col_world, act->data() + off, bytes, dst, pas->data() + off, bytes, src, HNH_STREAM_COMM);
+                world->event_record(event(12 + part), HNH_STREAM_COMM);
+            }
+            bBuf.swapActive();
+            phase_end(t);
+        }
+        world->event_wait(event(12), HNH_STREAM_COMPUTE);
+        world->event_wait(event(13), HNH_STREAM_COMPUTE);
+        auto t = phase_begin("Computation Time");
+        bBuf.sync_active();
+        phase_end(t);
     }
 
     // n kernel steps that WRITE the moving operand, n shifts, result handed back to the caller's matrix.

@@ -59,6 +59,14 @@ public:
     // others (plugins written against the reference's two pure virtuals) the schedule waits for the whole block instead.
     virtual bool handles_windows() const { return false; }
 
+    // Row parts (CSRLocal::row_part): the SpMM of the selected half of a block's rows.  An implementation that honours it says so
+    // here; for the others the schedule keeps the whole-block step (kernel, then shift).
+    virtual bool handles_row_parts() const { return false; }
+
+    // An implementation that honours CSRLocal::values_fresh says so here: the schedules then skip zeroing the block values before
+    // an SDDMM (distributed_sparse.h:280's setValuesConstant) and mark every first visit instead.
+    virtual bool overwrites_fresh_values() const { return false; }
+
     static bool wants_epilogue(const hnh_fused_extras* extras) {
         return extras && (extras->x_scale != 0.0 || extras->rowdot != nullptr || extras->cg != nullptr || extras->relu_dst != nullptr);
     }
@@ -87,6 +95,8 @@ public:
     long kernel_launches = 0;
 
     bool handles_windows() const override { return true; }
+    bool overwrites_fresh_values() const override { return true; }
+    bool handles_row_parts() const override { return true; }
     size_t sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, int block, int offset) override;
     size_t spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, MatMode mode, int block) override;
     size_t fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, DenseMatrix& Out, int block, unsigned flags,

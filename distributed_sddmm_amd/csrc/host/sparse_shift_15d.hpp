@@ -141,10 +141,13 @@ public:
             phase_end(t);
         }
 
+        // SDDMM: the travelling block accumulates partial dot products (R is split over the ring); its FIRST visit — step 0, at home —
+        // may store instead of add when the kernel honours CSRLocal::values_fresh, and then nobody has to zero the values first
+        const bool fresh = is_sddmm && kernel->overwrites_fresh_values();
         {
             auto t = phase_begin("Computation Time");
-            if (is_sddmm) choice->setValuesConstant(0.0);
-            else {
+            if (is_sddmm && !fresh) choice->setValuesConstant(0.0);
+            else if (!is_sddmm) {
                 choice->setCSRValues(SValues);
                 Arole->setZero();  // every slab is produced exactly once below (`tmp *= 0.0` in the reference)
             }
@@ -161,7 +164,9 @@ public:
             const int block_id = pMod(grid->i - i, n);
             DenseMatrix slab = DenseMatrix::view(Arole->data() + (size_t)block_id * arBwidth * Arole->cols(), arBwidth, Arole->cols());
             if (i > 0) world->event_wait(event(1 + (i - 1) % 2), HNH_STREAM_COMPUTE);  // shift i-1 landed
+            blk->values_fresh = fresh && i == 0;
             kernel->triple_function(mode == k_spmmB ? k_spmmA : mode, *choice, slab, gathered, 0, 0);
+            blk->values_fresh = false;
             phase_end(t);
 
             if (n > 1) {

@@ -73,6 +73,10 @@ public:
     int32_t* win_split = nullptr;
     int n_windows = 1;
     int window = -1;
+    // Set by a schedule around an SDDMM call: the values of the selected window are known to be zero (nobody has written them
+    // since the operation began), so a kernel that says overwrites_fresh_values() may store its results instead of adding to them
+    // — and the schedule has skipped the zero fill.  Kernels that do not know the hint are never given unfilled values.
+    bool values_fresh = false;
     void set_windows(const std::vector<int32_t>& bounds) {
         if (win_split) world->dfree(win_split);
         win_split = nullptr;
@@ -212,6 +216,8 @@ public:
             world->dfree(buffer[t].row_idx);
         }
         if (static_plan) world->be->hnh_csr_plan_destroy(world->ctx, static_plan);
+        for (hnh_csr_plan* pp : part_plan)
+            if (pp) world->be->hnh_csr_plan_destroy(world->ctx, pp);
         for (RingIndex& ri : ring_index) {
             if (ri.plan) world->be->hnh_csr_plan_destroy(world->ctx, ri.plan);
             world->dfree(ri.col_idx);
@@ -264,10 +270,33 @@ public:
     // indices (HNH_SHIP_INDICES=1: the arrays are overwritten by every shift) gets none.  The structure is fixed once the
     // constructor has run (the reference's SpmatLocal.hpp:78-188), so a plan never needs invalidating.
     hnh_csr_plan* static_plan = nullptr;
+
+    // Row parts.  When a block's OUTPUT is a buffer that travels (the SpMM accumulator of 1.5D replication reuse), the schedule runs
+    // the block's rows in two halves so that one half's shift overlaps the other half's kernel: `row_part` selects rows
+    // [0, part_rows0) or [part_rows0, rows) for the next SpMM (-1 = all rows).  A part is a CSR view of its own (row pointers from
+    // rowStart + first row, the same col_idx / values arrays), with its own structure plan.  Blocks that never shift only.
+    int row_part = -1;
+    int64_t part_rows0 = 0;
+    int part_nnz0 = -1;  // nonzeros of part 0 (read back once, when the parts are first used)
+    hnh_csr_plan* part_plan[2] = {nullptr, nullptr};
+    int64_t part_first_row() const { return row_part == 1 ? part_rows0 : 0; }
+    void select_row_part(int part) {
+        if (part >= 0) {
+            if (shifting) hnh::fatal("Error, row parts are for blocks that never shift!");
+            part_rows0 = rows / 2;
+            if (part_nnz0 < 0) {
+                int32_t v = 0;
+                world->copy(&v, buffer[0].rowStart + part_rows0, sizeof(int32_t), HNH_COPY_D2H, HNH_STREAM_COMPUTE);
+                world->sync(HNH_STREAM_COMPUTE);
+                part_nnz0 = v;
+            }
+        }
+        row_part = part;
+    }
+
     hnh_csr_block block_args() {
         CSRHandle* h = getActive();
         hnh_csr_plan** slot = !ring_index.empty() ? &ring_index[(size_t)active_slot].plan : (shifting ? nullptr : &static_plan);
-        if (slot != nullptr && *slot == nullptr) world->check(world->be->hnh_csr_plan_create(world->ctx, slot), "hnh_csr_plan_create");
         hnh_csr_block b;
         b.rows = rows;
         b.nnz = num_coords;
@@ -276,6 +305,13 @@ public:
         b.reserved = 0;
         b.rowptr = h->rowStart;
         b.col_idx = h->col_idx;
+        if (row_part >= 0) {
+            slot = &part_plan[row_part];
+            b.rows = row_part == 0 ? part_rows0 : rows - part_rows0;
+            b.nnz = row_part == 0 ? part_nnz0 : num_coords - part_nnz0;
+            b.rowptr = h->rowStart + part_first_row();  // (row pointers are offsets into the block's col_idx / values: still valid)
+        }
+        if (slot != nullptr && *slot == nullptr) world->check(world->be->hnh_csr_plan_create(world->ctx, slot), "hnh_csr_plan_create");
         b.plan = slot ? *slot : nullptr;
         return b;
     }

@@ -321,8 +321,11 @@ typedef struct hnh_csr_block {
 } hnh_csr_block;
 int hnh_csr_plan_create(hnh_ctx* ctx, hnh_csr_plan** out);
 int hnh_csr_plan_destroy(hnh_ctx* ctx, hnh_csr_plan* plan);
+/* flags of hnh_sddmm_csr_p: HNH_FUSED_VALUES_OVERWRITE = the (window's) values are known to be zero — the reference zeroes them
+ * before its SDDMM loop accumulates (distributed_sparse.h:280 -> sparse_kernels.cpp:54) — so values[e] = dot may be STORED instead
+ * of read, added to and stored: the caller skips its zero fill, the kernel the read (whole lines written, none fetched). */
 int hnh_sddmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* block, double* values, const double* X, const double* Y, int R,
-                    const hnh_csr_window* window, int stream);
+                    unsigned flags, const hnh_csr_window* window, int stream);
 int hnh_spmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* block, const double* values, const double* X, double* Out, int R,
                    const hnh_csr_window* window, int stream);
 int hnh_fused_sddmm_spmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* block, double* values, const double* svalues, const double* X,

@@ -760,8 +760,16 @@ int hnh_csr_plan_create(hnh_ctx* c, hnh_csr_plan** out) {
 }
 int hnh_csr_plan_destroy(hnh_ctx* c, hnh_csr_plan* p) { (void)c; free(p); return HNH_OK; }
 static const hnh_csr_window whole_block = {NULL, NULL, 1};
-int hnh_sddmm_csr_p(hnh_ctx* c, const hnh_csr_block* b, double* values, const double* X, const double* Y, int R, const hnh_csr_window* w, int stream) {
+int hnh_sddmm_csr_p(hnh_ctx* c, const hnh_csr_block* b, double* values, const double* X, const double* Y, int R, unsigned flags,
+                    const hnh_csr_window* w, int stream) {
     if (!b) return fail(c, HNH_ERR_INVALID, "null block");
+    if (flags & HNH_FUSED_VALUES_OVERWRITE) { /* "known to be zero": the double does not rely on it */
+        const hnh_csr_window* ww = w ? w : &whole_block;
+        for (int64_t r = 0; r < b->rows; r++) {
+            const int32_t lo = ww->beg ? ww->beg[r] : b->rowptr[r], hi = ww->end ? ww->end[r] : b->rowptr[r + 1];
+            for (int32_t i = lo; i < hi; i++) values[i] = 0.0;
+        }
+    }
     return hnh_sddmm_csr_w(c, b->rows, b->rowptr, b->col_idx, values, X, Y, R, b->nnz, b->max_row_nnz, w ? w : &whole_block, stream);
 }
 int hnh_spmm_csr_p(hnh_ctx* c, const hnh_csr_block* b, const double* values, const double* X, double* Out, int R, const hnh_csr_window* w, int stream) {

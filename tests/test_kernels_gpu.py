@@ -366,9 +366,9 @@ def test_a_plan_refuses_another_blocks_arrays(ctx):
     plan = C.c_void_p()
     ctx.check(lib.hnh_csr_plan_create(ctx.h, C.byref(plan)), "plan")
     blk = K.CsrBlock(10, 40, 4, 4, 0, d_rp.ptr, d_c.ptr, plan)
-    ctx.check(lib.hnh_sddmm_csr_p(ctx.h, C.byref(blk), dv.ptr, dX.ptr, dY.ptr, R, None, 0), "sddmm_p")
+    ctx.check(lib.hnh_sddmm_csr_p(ctx.h, C.byref(blk), dv.ptr, dX.ptr, dY.ptr, R, 0, None, 0), "sddmm_p")
     other = K.CsrBlock(10, 40, 4, 4, 0, d_rp.ptr, d_c2.ptr, plan)
-    assert lib.hnh_sddmm_csr_p(ctx.h, C.byref(other), dv.ptr, dX.ptr, dY.ptr, R, None, 0) != 0
+    assert lib.hnh_sddmm_csr_p(ctx.h, C.byref(other), dv.ptr, dX.ptr, dY.ptr, R, 0, None, 0) != 0
     assert b"another block" in lib.hnh_last_error(ctx.h)
     ctx.sync()
     assert np.allclose(dv.get(), R)

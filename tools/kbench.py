@@ -76,7 +76,7 @@ def main():
             # a model that charges memory for bytes a cache serves (the COO kernel's row-operand gathers; any operand that fits the
             # 256 MiB Infinity Cache) can exceed the HBM peak: such a line is a rate of the MODEL, not of HBM
             note = "  [cache-assisted: the byte model counts gathers that L1/L2/Infinity Cache serve]" if frac > 1.0 else ""
-            print("%-6s R=%d  %.3f ms  %.3e nnz*R/s  alg %.2f GB -> %.2f TB/s (%.1f%% of 8 TB/s)%s" % (
+            print("%-16s R=%d  %.3f ms  %.3e nnz*R/s  alg %.2f GB -> %.2f TB/s (%.1f%% of 8 TB/s)%s" % (
                 name, R, t * 1e3, nnz * R / t, bytes_alg / 1e9, bytes_alg / t / 1e12, 100 * frac, note), flush=True)
 
         ops = a.ops.split(",")
@@ -89,6 +89,21 @@ def main():
                   "sddmmP", nnz * (8 * R + 20) + 8 * R * m)
             timed(lambda: ctx.check(lib.hnh_spmm_csr_ex(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, dB.ptr, dOut.ptr, R, nnz, mx.value, m, 0), "spmm"),
                   "spmmP", nnz * (8 * R + 12) + 16 * R * m)
+        if "plan" in ops:  # the host layer's way: block descriptor + structure plan (steady state: row kernels only), SDDMM storing
+            mx = C.c_int()
+            ctx.check(lib.hnh_csr_max_row_nnz(ctx.h, m, d_rowptr.ptr, C.byref(mx), 0), "max_row")
+            plan = C.c_void_p()
+            ctx.check(lib.hnh_csr_plan_create(ctx.h, C.byref(plan)), "plan")
+            blk = K.CsrBlock(m, nnz, m, mx.value, 0, d_rowptr.ptr, d_c.ptr, plan)
+            timed(lambda: ctx.check(lib.hnh_fused_sddmm_spmm_csr_p(ctx.h, C.byref(blk), dv.ptr, None, dA.ptr, dB.ptr, dOut.ptr, R, 3, None, None, 0), "fused_p"),
+                  "fused/plan", nnz * (8 * R + 24) + 16 * R * m)
+            timed(lambda: ctx.check(lib.hnh_sddmm_csr_p(ctx.h, C.byref(blk), dv.ptr, dA.ptr, dB.ptr, R, 0, None, 0), "sddmm_p"),
+                  "sddmm/plan", nnz * (8 * R + 20) + 8 * R * m)
+            timed(lambda: ctx.check(lib.hnh_sddmm_csr_p(ctx.h, C.byref(blk), dv.ptr, dA.ptr, dB.ptr, R, 1, None, 0), "sddmm_p"),
+                  "sddmm/plan,store", nnz * (8 * R + 20) + 8 * R * m)
+            timed(lambda: ctx.check(lib.hnh_spmm_csr_p(ctx.h, C.byref(blk), dv.ptr, dB.ptr, dOut.ptr, R, None, 0), "spmm_p"),
+                  "spmm/plan", nnz * (8 * R + 12) + 16 * R * m)
+            ctx.check(lib.hnh_csr_plan_destroy(ctx.h, plan), "plan destroy")
         if "fused" in ops:
             timed(lambda: ctx.check(lib.hnh_fused_sddmm_spmm_csr(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, None, dA.ptr, dB.ptr,
                                                                  dOut.ptr, R, 3, 0), "fused"), "fused", nnz * (8 * R + 24) + 16 * R * m)
