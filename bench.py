@@ -81,7 +81,8 @@ def route_name(route):
     """route = (transport, c, mode, chunk spec)"""
     tr, c, mode, q = route
     mesh = ("mesh/heights %s" % q) if (q and "," in str(q)) else ("mesh/%s chunks" % q)
-    return "c=%d %s [%s]" % (c, {"mesh": mesh, "relay": "relay ring", "none": "replication only"}[mode], tr)
+    return "c=%d %s [%s]" % (c, {"mesh": mesh, "relay": "relay ring", "none": "replication only",
+                                 "fusion1": "15d_fusion1 (replication reuse: SDDMM + SpMM, accumulator ring in two halves)"}[mode], tr)
 
 
 def keyed(idx, salt):
@@ -581,7 +582,7 @@ class Bench:
         H, args = self.H, self.args
         tr, c, mode, q = route
         t = self.transports[tr]
-        if mode != "none":
+        if mode in ("mesh", "relay"):
             os.environ["HNH_RING_MODE"] = mode
         if q is not None:
             set_chunk_spec(q)
@@ -591,7 +592,7 @@ class Bench:
             info = t["sp"].info()
             self.nnz, self.m = info["dist_nnz"], info["M"]
         r0 = GAT_LAYERS[0][0] if args.app == "gat" else args.r
-        self.op = H.DistributedSparse(t["world"], args.alg, t["sp"], r0, c)
+        self.op = H.DistributedSparse(t["world"], "15d_fusion1" if mode == "fusion1" else args.alg, t["sp"], r0, c)
         self.route = route
         if args.app == "als":
             self.als = H.DistributedALS(self.op, True)
@@ -829,19 +830,20 @@ def compose_line(args, b, res, extra):
     dur = res["kern_ms"] / max(1, res["launches"]) * 1e-3  # average launch duration, seconds
     bytes_per_launch = res["alg_bytes_per_step"] / launches_per_step
     achieved = bytes_per_launch / dur if dur > 0 else 0.0
-    ring_mode_now = None if (n == 1 or mode == "none") else mode
+    ring_mode_now = None if (n == 1 or mode == "none") else ("accumulator ring (two halves)" if mode == "fusion1" else mode)
+    alg_now = "15d_fusion1" if mode == "fusion1" else args.alg
     step_is = {"vanilla": "fused SDDMM->SpMM (fusedSpMM, Amat)", "als": "one alternating ALS step by batched CG (run_cg(1): 24 fused calls)",
                "gat": "one GAT forward pass (3 layers, 14 heads, benchmark_dist.cpp:88-94)"}[args.app]
     how = "" if n == 1 else ", %s (%s)" % (
         {"rccl": "RCCL over xGMI", "ipc": "ipc-pull over mapped peer memory, copy engines", "ipc-kernel": "ipc-pull over mapped peer memory, pull kernel"}.get(tr, "transport: " + tr),
-        {"relay": "neighbour relay ring", "mesh": "chunked fetch from the owners", None: "replication only, nothing shifts"}[ring_mode_now])
+        {"relay": "neighbour relay ring", "mesh": "chunked fetch from the owners", None: "replication only, nothing shifts"}.get(ring_mode_now, ring_mode_now))
     out = {
         "backend": H.backend_name(),
         "metric": "fused SDDMM+SpMM nnz*R/s", "value": value, "unit": "nnz*R/s", "n_gpus": n, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic" if b.wl.kind != "mtx" else "file",
-        "config": {"workload": "%s, R=%d, %s, %s c=%d on %d x MI355X%s" % (b.wl.describe(b.nnz), args.r, step_is, args.alg, c_now, n, how),
-                   "nnz": b.nnz, "M": b.m, "R": args.r, "algorithm": args.alg, "app": args.app, "c": c_now,
+        "config": {"workload": "%s, R=%d, %s, %s c=%d on %d x MI355X%s" % (b.wl.describe(b.nnz), args.r, step_is, alg_now, c_now, n, how),
+                   "nnz": b.nnz, "M": b.m, "R": args.r, "algorithm": alg_now, "app": args.app, "c": c_now,
                    "transport": "none" if n == 1 else res["transport_kind"],
                    "transport_variant": None if n == 1 else tr, "ring_mode": ring_mode_now,
                    # Q symmetric chunks (a number) or the chunk heights (a comma list)
@@ -860,6 +862,8 @@ def compose_line(args, b, res, extra):
                                 "row_kernel<fused> (hnh_fused_sddmm_spmm_csr_p): one launch per visiting block of the relay ring"
                                 if ring_mode_now == "relay" else
                                 "row_kernel<fused> (hnh_fused_sddmm_spmm_csr_p): the rank's one block (replication only)" if ring_mode_now is None else
+                                "row_kernel<sddmm> + row_kernel<spmm> per visiting block (15d_fusion1 runs the pair, not the fused pass; the byte model stays the fused one)"
+                                if mode == "fusion1" else
                                 "row_kernel<fused> (hnh_fused_sddmm_spmm_csr_p): own block, then one windowed pass over the fetched blocks per landed chunk"),
                      # device time of a kernel CALL (HIP events around it on the compute stream) divided by the row-kernel launches it made
                      "avg_launch_ms": dur * 1e3,
@@ -1037,6 +1041,10 @@ def run(args, make_world=gpu_world):
                     cand += [(tr, c, "mesh", q) for q in qs]
                 if fixed_mode != "mesh":
                     cand.append((tr, c, "relay", None))
+                if fixed_mode is None and args.app == "vanilla":
+                    # the other fusion strategy of the same schedule (replication reuse): twice the gathers, but its moving operand is
+                    # replicated once for both kernels and its accumulator travels in two halves under the kernels
+                    cand.append((tr, c, "fusion1", None))
             return cand
 
         stage1 = [(tr, c0, mode0, default_q if mode0 == "mesh" else None) for tr in b.usable()]

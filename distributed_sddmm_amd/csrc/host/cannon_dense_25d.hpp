@@ -36,9 +36,11 @@ public:
     DenseMatrix accumulation_buffer;
     DenseMatrix ring_spare;
     DenseMatrix dense_spare[2];  // landing buffers of the read-only (SDDMM) dense ring
+    bool acc_halves = true;      // SpMM: the accumulator's shift in two row halves, each under the other half's kernel (HNH_ACC_HALVES=0: off)
 
     Sparse25D_Cannon_Dense(SpmatLocal* S_input, int R, int c, KernelImplementation* k) : Distributed_Sparse(k) {
         this->c = c;
+        if (const char* h = std::getenv("HNH_ACC_HALVES")) acc_halves = std::atoi(h) != 0;
         if (c < 1 || p % c != 0) hnh::fatal("Error, for 2.5D algorithm, p / c must be a perfect square!");
         sqrtpc = (int)std::lround(std::sqrt((double)(p / c)));
         if (sqrtpc * sqrtpc * c != p) hnh::fatal("Error, for 2.5D algorithm, p / c must be a perfect square!");
@@ -206,6 +208,50 @@ public:
                 }
             }
             if (s > 1) world->event_wait(event(1 + (s - 1) % 2), HNH_STREAM_COMPUTE);  // the sparse block is home again
+        } else if (s > 1 && acc_halves && kernel->handles_row_parts() && blk != nullptr && blk->supports_row_parts()) {
+            // SpMM: the moving dense operand is the ACCUMULATOR, so its shift has to follow the kernel that wrote it
+            // (25D_cannon_dense.hpp:274-302: kernel -> two shifts -> barrier).  In two row halves (CSRLocal::row_part) one half travels
+            // under the other half's kernel:
+            //     compute:  K(i,H0)  K(i,H1)            K(i+1,H0) ...        comm:  sparse(i)  D(i,H0)  D(i,H1)  sparse(i+1) ...
+            // The sparse block is only read: its shift starts as soon as kernel i-1 has released the passive buffer, as before.
+            hnh::BufferPair bBuf(Brole, &ring_spare);
+            const int64_t h = Brole->rows() / 2, cols = Brole->cols();
+            const size_t bytes0 = (size_t)h * (size_t)cols * sizeof(double), bytes1 = (size_t)(Brole->rows() - h) * (size_t)cols * sizeof(double);
+            order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);  // earlier users of the spare are done
+            for (int i = 0; i < s; i++) {
+                DenseMatrix* act = bBuf.getActive();
+                DenseMatrix* pas = bBuf.getPassive();
+                auto t = phase_begin("Computation Time");
+                if (i > 0) world->event_wait(event(1 + (i - 1) % 2), HNH_STREAM_COMPUTE);  // the sparse block of step i has landed
+                for (int part = 0; part < 2; part++) {
+                    if (i > 0) world->event_wait(event(14 + part), HNH_STREAM_COMPUTE);    // this half of the accumulator has landed
+                    blk->select_row_part(part);
+                    kernel->triple_function(kmode, *choice, stationary, *act, 0, localAcols * grid->j);
+                    blk->select_row_part(-1);
+                    world->event_record(event(10 + 2 * (i % 2) + part), HNH_STREAM_COMPUTE);
+                }
+                phase_end(t);
+                t = phase_begin("Sparse Cyclic Shift Time");
+                if (i >= 1) world->event_wait(event(10 + 2 * ((i - 1) % 2) + 1), HNH_STREAM_COMM);  // kernel i-1 released the passive sparse buffer
+                blk->shiftCSR(ssrc, sdst, grid->row_world, (*nnz_in_axis)[pMod(sparse_shift - i - 1, s)], 72, csr, HNH_STREAM_COMM,
+                              pMod(sparse_shift - i - 1, s));
+                choice->blockStarts[1] = blk->num_coords;
+                world->event_record(event(1 + i % 2), HNH_STREAM_COMM);
+                phase_end(t);
+                t = phase_begin("Dense Cyclic Shift Time");
+                for (int part = 0; part < 2; part++) {
+                    world->event_wait(event(10 + 2 * (i % 2) + part), HNH_STREAM_COMM);  // kernel (i, part) wrote this half
+                    const size_t off = part == 0 ? 0 : (size_t)h * (size_t)cols, bytes = part == 0 ? bytes0 : bytes1;
+                    world->sendrecv(grid->col_world, act->data() + off, bytes, ddst, pas->data() + off, bytes, dsrc, HNH_STREAM_COMM);
+                    world->event_record(event(14 + part), HNH_STREAM_COMM);
+                }
+                bBuf.swapActive();
+                phase_end(t);
+            }
+            world->event_wait(event(1 + (s - 1) % 2), HNH_STREAM_COMPUTE);
+            world->event_wait(event(14), HNH_STREAM_COMPUTE);
+            world->event_wait(event(15), HNH_STREAM_COMPUTE);
+            bBuf.sync_active();
         } else {
             hnh::BufferPair bBuf(Brole, &ring_spare);
             for (int i = 0; i < s; i++) {

@@ -103,6 +103,8 @@ public:
         int32_t* row_idx = nullptr;  // COO view of the same structure, built on first use (ensure_row_idx)
         int nnz = 0;
         hnh_csr_plan* plan = nullptr;  // structure-only work of the row passes for this ring block (block_args)
+        int part_nnz0 = -1;            // row parts of this ring block (select_row_part)
+        hnh_csr_plan* part_plan[2] = {nullptr, nullptr};
     };
     std::vector<RingIndex> ring_index;  // by ring position of the block's origin; empty = indices travel (reference behaviour)
     int active_slot = -1;               // ring position whose block occupies the active buffer (ring-resident indices only)
@@ -220,6 +222,8 @@ public:
             if (pp) world->be->hnh_csr_plan_destroy(world->ctx, pp);
         for (RingIndex& ri : ring_index) {
             if (ri.plan) world->be->hnh_csr_plan_destroy(world->ctx, ri.plan);
+            for (hnh_csr_plan* pp : ri.part_plan)
+                if (pp) world->be->hnh_csr_plan_destroy(world->ctx, pp);
             world->dfree(ri.col_idx);
             world->dfree(ri.rowStart);
             world->dfree(ri.row_idx);
@@ -280,15 +284,18 @@ public:
     int part_nnz0 = -1;  // nonzeros of part 0 (read back once, when the parts are first used)
     hnh_csr_plan* part_plan[2] = {nullptr, nullptr};
     int64_t part_first_row() const { return row_part == 1 ? part_rows0 : 0; }
+    // whether this block can be run in row parts: its structure must keep its contents (never shifts, or ring-resident indices)
+    bool supports_row_parts() const { return !shifting || !ring_index.empty(); }
     void select_row_part(int part) {
         if (part >= 0) {
-            if (shifting) hnh::fatal("Error, row parts are for blocks that never shift!");
+            if (!supports_row_parts()) hnh::fatal("Error, row parts need a block whose index arrays keep their contents!");
             part_rows0 = rows / 2;
-            if (part_nnz0 < 0) {
+            int* known = ring_index.empty() ? &part_nnz0 : &ring_index[(size_t)active_slot].part_nnz0;
+            if (*known < 0) {
                 int32_t v = 0;
-                world->copy(&v, buffer[0].rowStart + part_rows0, sizeof(int32_t), HNH_COPY_D2H, HNH_STREAM_COMPUTE);
+                world->copy(&v, getActive()->rowStart + part_rows0, sizeof(int32_t), HNH_COPY_D2H, HNH_STREAM_COMPUTE);
                 world->sync(HNH_STREAM_COMPUTE);
-                part_nnz0 = v;
+                *known = v;
             }
         }
         row_part = part;
@@ -306,9 +313,11 @@ public:
         b.rowptr = h->rowStart;
         b.col_idx = h->col_idx;
         if (row_part >= 0) {
-            slot = &part_plan[row_part];
+            const bool ring = !ring_index.empty();
+            slot = ring ? &ring_index[(size_t)active_slot].part_plan[row_part] : &part_plan[row_part];
+            const int nnz0 = ring ? ring_index[(size_t)active_slot].part_nnz0 : part_nnz0;
             b.rows = row_part == 0 ? part_rows0 : rows - part_rows0;
-            b.nnz = row_part == 0 ? part_nnz0 : num_coords - part_nnz0;
+            b.nnz = row_part == 0 ? nnz0 : num_coords - nnz0;
             b.rowptr = h->rowStart + part_first_row();  // (row pointers are offsets into the block's col_idx / values: still valid)
         }
         if (slot != nullptr && *slot == nullptr) world->check(world->be->hnh_csr_plan_create(world->ctx, slot), "hnh_csr_plan_create");

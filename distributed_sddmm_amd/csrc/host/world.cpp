@@ -548,6 +548,15 @@ void ThreadWorld::sendrecv(const Comm& comm, const void* sendbuf, size_t sendbyt
         if (in->bytes != recvbytes) fatal("Error, send/recv size mismatch between ranks");
         event_wait(in->ready, stream);
         copy(recvbuf, in->ptr, recvbytes, HNH_COPY_D2D, stream);
+#ifdef HNH_MEASUREMENT_AIDS
+        // (libhnh_host_aids.so only) HNH_PACE_LINK_GBPS=<rate>: the loopback copy is followed by a hold of the stream for as long as
+        // the message would take to cross ONE xGMI link at that rate — a transfer of known duration for overlap measurements
+        // on a single GPU (tools/overlap_probe_accumulator.py)
+        if (const char* pace = std::getenv("HNH_PACE_LINK_GBPS")) {
+            const double gbps = std::atof(pace);
+            if (gbps > 0.0) delay_us((double)recvbytes / (gbps * 1e3), stream);
+        }
+#endif
         void* done = event_create();
         event_record(done, stream);
         {

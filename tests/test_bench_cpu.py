@@ -56,17 +56,30 @@ def test_bench_contract(nranks, alg, c, ring):
                 want |= {"c=%d mesh/heights %s" % (k, h) for h in (("1,2,2,2,1,1", "3,4,4,3,2,1,1") if k == 1 else ("1,2,2,2,1,1",))}
             if ring != "mesh":
                 want.add("c=%d relay ring" % k)
+            if ring is None:  # the schedule's other fusion strategy joins the search when nothing fixes the route
+                want.add("c=%d 15d_fusion1 (replication reuse: SDDMM + SpMM, accumulator ring in two halves)" % k)
         tuned = alg == "15d_fusion2" and len(want) > 1
         assert ("route_tuning_ms_per_step" in out["config"]) == tuned
-        if tuned:  # the configuration that was timed is the fastest of the measured candidates
+        if tuned:
+            # what is reported is a COMPLETE measurement (timed steps + check) of either the fastest candidate of the search or the
+            # default route measured before it — whichever full measurement was faster
             t = {k.rsplit(" [", 1)[0]: v for k, v in out["config"]["route_tuning_ms_per_step"].items()}  # (names end in " [transport]")
             assert all(k.endswith(" [default]") for k in out["config"]["route_tuning_ms_per_step"])
             assert set(t) == want
-            best = min(t, key=t.get)
-            bc, broute = best.split(" ", 1)
-            assert out["config"]["c"] == int(bc[2:])
-            assert out["config"]["ring_mode"] == {"relay ring": "relay", "replication only": None}.get(broute, "mesh")
-            assert out["config"]["mesh_chunks"] == (broute.split("/")[1].split()[-1 if "heights" in broute else 0] if broute.startswith("mesh") else None)
+
+            def matches(name):
+                bc, broute = name.split(" ", 1)
+                if out["config"]["c"] != int(bc[2:]):
+                    return False
+                if broute.startswith("15d_fusion1"):
+                    return out["config"]["algorithm"] == "15d_fusion1" and out["config"]["ring_mode"].startswith("accumulator ring")
+                return (out["config"]["algorithm"] == "15d_fusion2" and
+                        out["config"]["ring_mode"] == {"relay ring": "relay", "replication only": None}.get(broute, "mesh") and
+                        out["config"]["mesh_chunks"] == (broute.split("/")[1].split()[-1 if "heights" in broute else 0] if broute.startswith("mesh") else None))
+
+            c0 = c or 1
+            default = ("c=%d replication only" % c0) if nranks // c0 == 1 else (("c=%d relay ring" % c0) if ring == "relay" else "c=%d mesh/heights 1,2,2,2,1,1" % c0)
+            assert matches(min(t, key=t.get)) or matches(default)
             if not c and nranks == 4:
                 assert any(k.startswith("c=2") for k in t) and any(k.startswith("c=4") for k in t)
         else:
@@ -172,7 +185,7 @@ def run_worker_directly(n, *cli, timeout=600):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2",
                    GLOO_SOCKET_IFNAME="lo")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "bench_worker.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0",
-                                       "--no-cpu-baseline", *cli], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+                                       "--no-cpu-baseline", "--no-secondary", *cli], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=timeout) for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-1500:] for o in outs)
     lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]

@@ -92,6 +92,20 @@ def test_configuration_errors_are_reported():
     assert "unknown algorithm" in errs[3]
 
 
+@pytest.mark.parametrize("env", [{"HNH_ACC_HALVES": "0"}, {"HNH_SHIP_INDICES": "1"}, {"HNH_ACC_HALVES": "0", "HNH_SHIP_INDICES": "1"}])
+@pytest.mark.parametrize("alg,p,c", [("15d_fusion1", 4, 1), ("15d_fusion1", 8, 2), ("25d_dense_replicate", 4, 1), ("25d_dense_replicate", 8, 2),
+                                     ("15d_sparse", 4, 1)])
+def test_whole_accumulator_shifts_and_travelling_indices_agree_with_the_reference(monkeypatch, env, alg, p, c):
+    """The defaults pipeline a moving ACCUMULATOR in two row halves (one half's shift under the other half's kernel) and keep the
+    ring's sparsity structure resident; HNH_ACC_HALVES=0 is the reference's kernel -> shift sequence, HNH_SHIP_INDICES=1 its
+    payload (indices travel with the block, which also rules the row halves out for travelling blocks) — same results."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    case = T.case_inputs("ragged_r8")
+    per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
+    T.check_against_golden(T.assemble(per_rank, case), per_rank, case, alg)
+
+
 @pytest.mark.parametrize("mode", ["relay", "mesh"])
 @pytest.mark.parametrize("alg,p,c", [("15d_fusion2", 4, 1), ("15d_fusion2", 8, 1), ("15d_fusion2", 8, 2), ("15d_fusion1", 8, 1), ("15d_fusion1", 4, 1)])
 def test_relay_ring_and_mesh_fetch_agree_with_the_reference(monkeypatch, mode, alg, p, c):

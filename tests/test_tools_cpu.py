@@ -31,3 +31,8 @@ def test_overlap_probe_runs_on_the_test_double():
     assert "taper 3,2,1:" in out and "taper 1,2,2,2,1,1:" in out and "Q=2:" in out
     assert out.count("GB/s/link:") == 6  # one rate per shape and variant
     assert out.count("the paced transfers also move their bytes: 2 throttled workgroups per link") == 3
+
+
+def test_accumulator_overlap_probe_runs_on_the_test_double():
+    out = run_tool("overlap_probe_accumulator.py", "--gbps", "0,60")
+    assert "15d_fusion1 spmmA" in out and "loopback copies only" in out and out.count(" ms") >= 4
