@@ -105,6 +105,8 @@ SIGNATURES = {
 AIDS_SIGNATURES = {
     "hnh_stream_delay_us": (_i32, [_vp, _i32, C.c_double]),
     "hnh_stream_paced_copy": (_i32, [_vp, _i32, _vp, _vp, C.c_size_t, _i32, C.c_double, _i32]),
+    "hnh_stream_pace_begin": (_i32, [_vp, _i32]),
+    "hnh_stream_pace_end": (_i32, [_vp, _i32, C.c_double]),
 }
 
 

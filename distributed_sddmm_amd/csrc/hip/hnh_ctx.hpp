@@ -39,6 +39,7 @@ struct hnh_ctx {
     static constexpr int kAuxStreams = 8;
     hipStream_t aux[kAuxStreams] = {nullptr};
     hipEvent_t aux_fork = nullptr, aux_join[kAuxStreams] = {nullptr};
+    unsigned long long* pace_stamp[2] = {nullptr, nullptr};  // measurement aid (hnh_stream_pace_begin / _end): the clock at the begin mark
     int flag_kernels = -1;  // HNH_IPC_FLAGS=kernel: flag words are written / awaited by one-lane kernels instead of stream memory operations
 };
 

@@ -12,6 +12,13 @@ __global__ void delay_kernel(unsigned long long ticks) {
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
+// a transfer of modelled duration that INCLUDES whatever real work sits between the two marks: stamp the clock, ..., hold until
+// `ticks` have passed since the stamp
+__global__ void stamp_kernel(unsigned long long* t) { *t = wall_clock64(); }
+__global__ void hold_until_kernel(const unsigned long long* t, unsigned long long ticks) {
+    const unsigned long long t0 = *t;
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
 // slice s = blockIdx.x / wgs copies its share of src -> dst + s * slice_bytes in tiles, never ahead of the modelled rate
 __global__ __launch_bounds__(256) void paced_copy_kernel(char* dst, const char* src, size_t slice_bytes, int wgs, unsigned long long ticks) {
     const int slice = (int)blockIdx.x / wgs, part = (int)blockIdx.x % wgs;
@@ -52,6 +59,22 @@ int hnh_stream_paced_copy(hnh_ctx* ctx, int stream, void* dst_base, const void* 
     hipLaunchKernelGGL(paced_copy_kernel, dim3((unsigned)(nslices * wgs_per_slice)), dim3(256), 0, ctx->streams[stream], static_cast<char*>(dst_base),
                        static_cast<const char*>(src), slice_bytes, wgs_per_slice, (unsigned long long)(microseconds * 100.0));
     return hnh::check_hip(ctx, hipGetLastError(), "paced_copy_kernel");
+}
+
+int hnh_stream_pace_begin(hnh_ctx* ctx, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (!ctx->pace_stamp[stream]) HNH_TRY_HIP(ctx, hipMalloc((void**)&ctx->pace_stamp[stream], sizeof(unsigned long long)));
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, ctx->streams[stream], ctx->pace_stamp[stream]);
+    return hnh::check_hip(ctx, hipGetLastError(), "stamp_kernel");
+}
+
+int hnh_stream_pace_end(hnh_ctx* ctx, int stream, double microseconds) {
+    HNH_ENTER(ctx, stream);
+    if (!ctx->pace_stamp[stream]) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_stream_pace_end without hnh_stream_pace_begin");
+    if (!(microseconds > 0.0)) return HNH_OK;
+    if (microseconds > 5.0e6) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_stream_pace_end: more than 5 s");
+    hipLaunchKernelGGL(hold_until_kernel, dim3(1), dim3(1), 0, ctx->streams[stream], ctx->pace_stamp[stream], (unsigned long long)(microseconds * 100.0));
+    return hnh::check_hip(ctx, hipGetLastError(), "hold_until_kernel");
 }
 
 int hnh_stream_delay_us(hnh_ctx* ctx, int stream, double microseconds) {
@@ -186,6 +209,7 @@ int hnh_ctx_destroy(hnh_ctx* ctx) {
         if (ctx->long_rows[s]) (void)hipFree(ctx->long_rows[s]);
         if (ctx->long_partials[s]) (void)hipFree(ctx->long_partials[s]);
         if (ctx->panel_split[s]) (void)hipFree(ctx->panel_split[s]);
+        if (ctx->pace_stamp[s]) (void)hipFree(ctx->pace_stamp[s]);
     }
     for (int a = 0; a < hnh_ctx::kAuxStreams; a++) {
         if (ctx->aux[a]) { (void)hipStreamSynchronize(ctx->aux[a]); (void)hipStreamDestroy(ctx->aux[a]); }

@@ -86,7 +86,7 @@ Backend* load_backend(const char* path_c) {
     HNH_BIND(hnh_stream_write_flag) HNH_BIND(hnh_stream_wait_flag)
     HNH_BIND(hnh_csr_plan_create) HNH_BIND(hnh_csr_plan_destroy) HNH_BIND(hnh_sddmm_csr_p) HNH_BIND(hnh_spmm_csr_p) HNH_BIND(hnh_fused_sddmm_spmm_csr_p)
 #ifdef HNH_MEASUREMENT_AIDS
-    HNH_BIND(hnh_stream_delay_us) HNH_BIND(hnh_stream_paced_copy)
+    HNH_BIND(hnh_stream_delay_us) HNH_BIND(hnh_stream_paced_copy) HNH_BIND(hnh_stream_pace_begin) HNH_BIND(hnh_stream_pace_end)
 #endif
 #undef HNH_BIND
     b->name = b->hnh_backend_name();
@@ -547,15 +547,21 @@ void ThreadWorld::sendrecv(const Comm& comm, const void* sendbuf, size_t sendbyt
         }
         if (in->bytes != recvbytes) fatal("Error, send/recv size mismatch between ranks");
         event_wait(in->ready, stream);
-        copy(recvbuf, in->ptr, recvbytes, HNH_COPY_D2D, stream);
 #ifdef HNH_MEASUREMENT_AIDS
-        // (libhnh_host_aids.so only) HNH_PACE_LINK_GBPS=<rate>: the loopback copy is followed by a hold of the stream for as long as
-        // the message would take to cross ONE xGMI link at that rate — a transfer of known duration for overlap measurements
-        // on a single GPU (tools/overlap_probe_accumulator.py)
+        // (libhnh_host_aids.so only) HNH_PACE_LINK_GBPS=<rate>: the message takes at least as long as it would need to cross ONE
+        // xGMI link at that rate — the loopback copy included (stamp the clock, copy, hold the stream until the modelled time has
+        // passed since the stamp): a transfer of known duration for overlap measurements on a single GPU
+        // (tools/overlap_probe_accumulator.py)
+        double pace_us = 0.0;
         if (const char* pace = std::getenv("HNH_PACE_LINK_GBPS")) {
             const double gbps = std::atof(pace);
-            if (gbps > 0.0) delay_us((double)recvbytes / (gbps * 1e3), stream);
+            if (gbps > 0.0) pace_us = (double)recvbytes / (gbps * 1e3);
         }
+        if (pace_us > 0.0) check(be->hnh_stream_pace_begin(ctx, stream), "hnh_stream_pace_begin");
+#endif
+        copy(recvbuf, in->ptr, recvbytes, HNH_COPY_D2D, stream);
+#ifdef HNH_MEASUREMENT_AIDS
+        if (pace_us > 0.0) check(be->hnh_stream_pace_end(ctx, stream, pace_us), "hnh_stream_pace_end");
 #endif
         void* done = event_create();
         event_record(done, stream);

@@ -22,6 +22,12 @@ int hnh_stream_delay_us(hnh_ctx* ctx, int stream, double microseconds);
 int hnh_stream_paced_copy(hnh_ctx* ctx, int stream, void* dst_base, const void* src, size_t slice_bytes, int nslices,
                           double microseconds, int wgs_per_slice);
 
+/* A transfer of modelled duration that INCLUDES the real work enqueued between the two marks (the loopback transport's copy):
+ * begin stamps the device clock on `stream`, end holds the stream until `microseconds` have passed since that stamp — the
+ * transfer takes max(real work, modelled time), as a link that is slower than the local copy would. */
+int hnh_stream_pace_begin(hnh_ctx* ctx, int stream);
+int hnh_stream_pace_end(hnh_ctx* ctx, int stream, double microseconds);
+
 #ifdef __cplusplus
 }
 #endif

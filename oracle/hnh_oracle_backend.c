@@ -107,6 +107,8 @@ int hnh_stream_paced_copy(hnh_ctx* c, int stream, void* dst, const void* src, si
     for (int k = 0; k < n; k++) memcpy((char*)dst + (size_t)k * bytes, src, bytes);
     return HNH_OK;
 }
+int hnh_stream_pace_begin(hnh_ctx* c, int stream) { (void)c; (void)stream; return HNH_OK; }
+int hnh_stream_pace_end(hnh_ctx* c, int stream, double us) { (void)c; (void)stream; (void)us; return HNH_OK; }
 int hnh_stream_delay_us(hnh_ctx* c, int stream, double us) { (void)c; (void)stream; (void)us; return HNH_OK; }  /* synchronous double: nothing to pace */
 int hnh_event_elapsed_ms(hnh_ctx* c, void* a, void* b, float* ms) { (void)c; *ms = (float)(*(double*)b - *(double*)a); return HNH_OK; }
 
