@@ -495,6 +495,10 @@ def probe_transports(args, dist, rank, n, names):
         dist.broadcast_object_list(port, src=0)
         env = dict(os.environ, MASTER_PORT=str(port[0]), MASTER_ADDR="127.0.0.1")
         env.pop("HNH_BENCH_STATUS_DIR", None)
+        # under torch.distributed.run the workers are told to use the AGENT's store (TORCHELASTIC_USE_AGENT_STORE): the children
+        # rendezvous on a port of their own, where rank 0's child has to host the store itself
+        for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+            env.pop(k)
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--probe-transport", name]
         if args.nchannels:
             cmd += ["--nchannels", str(args.nchannels)]
@@ -617,16 +621,21 @@ class Bench:
         else:
             self.op.fusedSpMM(self.A, self.B, self.S, self.buf, self.H.AMAT)
 
-    def quick_time(self, calls=3):
+    def quick_time(self, calls=5):
+        """one warm-up call, then `calls` calls timed one by one (barrier + device synchronise around each, max over ranks): the
+        MEDIAN — candidates a per cent apart are within the noise of a mean of three"""
         self.step()
         self.barrier()
-        t0 = time.perf_counter()
+        times = []
         for _ in range(calls):
+            t0 = time.perf_counter()
             self.step()
-        self.barrier()
-        return self.max_over_ranks((time.perf_counter() - t0) / calls) * 1e3
+            self.barrier()
+            times.append(self.max_over_ranks(time.perf_counter() - t0))
+        times.sort()
+        return times[len(times) // 2] * 1e3
 
-    def try_route(self, route, calls=3):
+    def try_route(self, route, calls=5):
         """quick_time(route) with failure isolation: (ms, None) or (None, reason); a transport on which a candidate failed is
         not used again (its streams may hold half a call)."""
         tr = route[0]
@@ -938,6 +947,11 @@ def run(args, make_world=gpu_world):
         dog.phase("transport trials in child processes (%s)" % ", ".join(wanted), args.probe_timeout * len(wanted) + 120.0)
         probe = probe_transports(args, dist, rank, n, [w for w in wanted if w != "ipc-kernel"])  # (the two ipc variants share every primitive but the copy)
         dog.done()
+        if not any(v.startswith("ok") for v in probe.values()):
+            # nothing passed its trial: the trial machinery itself (child start-up, rendezvous) may be what failed — try the transports
+            # here after all, under the watchdog, rather than give up without a number
+            sys.stderr.write("[bench.py] rank %d: no transport passed its child-process trial (%r); trying them in this process\n" % (rank, probe))
+            probe = {k: "ok (trial failed: %s; created in the benchmark process)" % v[:120] for k, v in probe.items()}
         for name in wanted:
             if not probe[name if name != "ipc-kernel" else "ipc"].startswith("ok"):
                 continue
@@ -1021,8 +1035,8 @@ def run(args, make_world=gpu_world):
     # the default here fetches every block straight from its owner (all links at once) in chunks, with one windowed kernel pass per
     # landed chunk — how many chunks trades kernel efficiency against fetch/compute overlap, c trades ring traffic against
     # replication traffic, and the transports differ in who moves the bytes (RCCL channels, copy engines, a pull kernel); all of it
-    # depends on the xGMI bandwidth actually delivered.  Unless flags fix them, the candidates are MEASURED (1 warm-up + 3 calls each,
-    # max over ranks): first the default route on every transport, then replication factors and chunk shapes on the fastest one.
+    # depends on the xGMI bandwidth actually delivered.  Unless flags fix them, the candidates are MEASURED (1 warm-up + 5 calls each, the
+    # median, max over ranks): first the default route on every transport, then replication factors and chunk shapes on the fastest one.
     # A candidate that fails is recorded as null with its reason and the search goes on without its transport.
     tuning = None
     if n > 1 and args.alg == "15d_fusion2" and not args.no_tune:
@@ -1244,7 +1258,7 @@ def secondary(args, b):
                 sub.transports["single"]["sp"] = None
             try:
                 sub.build(("single", 1, "none", None))
-                ms = sub.quick_time(1 if app == "gat" else 1)
+                ms = sub.quick_time(1)
                 chk = sub.check_app()
                 info = sub.op.info()
                 if app == "als":

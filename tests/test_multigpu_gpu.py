@@ -130,6 +130,28 @@ def test_bench_processes_share_one_gpu(n):
     assert len(out["preflight"]["primitives_ok"]) == 9 and out["preflight"]["transports"] == ["ipc", "ipc-kernel"]
 
 
+def test_bench_under_torch_distributed_run_on_one_gpu():
+    """The driver's way of starting a multi-GPU run — `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` — with two
+    workers on a one-GPU box: the elastic agent's environment must not leak into the transport trials' own rendezvous, and rank 0
+    prints the one JSON line (over ipc-pull here)."""
+    if gpus() != 1:
+        pytest.skip("this is the one-GPU behaviour")
+    env = dict(os.environ, GLOO_SOCKET_IFNAME="lo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "HNH_BENCH_WORKER"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--logm", "14",
+                          "--edge-factor", "16", "--no-cpu-baseline", "--probe-timeout", "240", "--chunks", "2"], env=env,  # (no "--r": the launcher's own
+                         # option parser takes it for an abbreviation of its --rdzv-* / --role / --run-path options)
+                         capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["transport"] == "ipc-pull" and out["check"]["ok"] and "incomplete" not in out
+    assert out["config"]["transport_trials"]["ipc"].startswith("ok (") and "trial failed" not in out["config"]["transport_trials"]["ipc"]
+
+
 def test_bench_rccl_only_on_one_gpu_ends_with_an_error_line():
     """One GPU, two ranks, --transport rccl: RCCL refuses the second rank on the same device.  The run must END (no hang) with
     one JSON line that says no transport is usable and why, and a non-zero exit code."""
