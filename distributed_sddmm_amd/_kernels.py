@@ -96,6 +96,7 @@ SIGNATURES = {
     "hnh_csr_plan_create": (_i32, [_vp, C.POINTER(_vp)]),
     "hnh_csr_plan_destroy": (_i32, [_vp, _vp]),
     "hnh_sddmm_csr_p": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _vp, _i32]),
+    "hnh_sddmm_csr_ps": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _vp, _i32]),
     "hnh_spmm_csr_p": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32]),
     "hnh_fused_sddmm_spmm_csr_p": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _vp, _vp, _i32]),
 }

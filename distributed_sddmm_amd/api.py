@@ -77,6 +77,7 @@ SIGNATURES = {
     "hnh_dist_json": (_i32, [_vp, _i32, C.c_char_p, _sz]),
     "hnh_dist_reset_timers": (_i32, [_vp]),
     "hnh_dist_kernel_profile": (_i32, [_vp, _i32, _pdbl, _pi64]),
+    "hnh_dist_borrow_stats": (_i32, [_vp, _pi64]),
     "hnh_dense_create": (_i32, [_vp, _i64, _i64, _dbl, _pvp]),
     "hnh_dense_wrap": (_i32, [_vp, _vp, _i64, _i64, _pvp]),
     "hnh_dense_like": (_i32, [_vp, _i32, _dbl, _pvp]),
@@ -546,6 +547,12 @@ class DistributedSparse:
         ms, n = C.c_double(), C.c_int64()
         _check(lib().hnh_dist_kernel_profile(self.h, enable, C.byref(ms), C.byref(n)), "kernel_profile")
         return ms.value, n.value
+
+    def borrow_stats(self):
+        """(SpMM arrays lent, SpMM arrays copied, SDDMM results written in place, SDDMM results by a Hadamard pass) — block counts."""
+        out = (C.c_int64 * 4)()
+        _check(lib().hnh_dist_borrow_stats(self.h, out), "borrow_stats")
+        return tuple(out)
 
     def free(self):
         if self.h:

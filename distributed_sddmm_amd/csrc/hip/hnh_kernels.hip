@@ -352,6 +352,9 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
             wgt = group_multi_reduce<LPR, U>(d, lig);
             if (have) {
                 const bool overwrite = (OP != Op::kSpmm) && (flags & HNH_FUSED_VALUES_OVERWRITE);
+                if constexpr (OP == Op::kSddmm) {  // stand-alone SDDMM with its closing Hadamard folded in: the result is scale .* dots
+                    if (svalues != nullptr) wgt *= svalues[mine];
+                }
                 if (!overwrite) wgt += load_stream(values + mine);
                 if (fused_op(OP) && (flags & HNH_FUSED_LEAKY_RELU)) {  // the activated weight is what gets stored
                     if (svalues != nullptr) wgt *= svalues[mine];
@@ -502,6 +505,9 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
 #pragma unroll
                     for (int u = 0; u < UQ; u++) d[u] = fma(x[0][1], y[u][0][1], x[0][0] * y[u][0][0]);
                     wgt = group_multi_reduce<LPR, UQ>(d, lig);
+                    if constexpr (OP == Op::kSddmm) {  // (the folded Hadamard of the stand-alone SDDMM, as in the general loop)
+                        if (svalues != nullptr) wgt *= line_value(sv, kmine);
+                    }
                     if (!vals_overwrite) wgt += line_value(vv, kmine);
                     if (fused_op(OP) && (flags & HNH_FUSED_LEAKY_RELU)) {  // the activated weight is what gets stored
                         if (svalues != nullptr) wgt *= line_value(sv, kmine);
@@ -2173,17 +2179,23 @@ int hnh_csr_plan_destroy(hnh_ctx* ctx, hnh_csr_plan* plan) {
 
 int hnh_sddmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* b, double* values, const double* X, const double* Y, int R, unsigned flags,
                     const hnh_csr_window* window, int stream) {
+    return hnh_sddmm_csr_ps(ctx, b, values, nullptr, X, Y, R, flags, window, stream);
+}
+
+int hnh_sddmm_csr_ps(hnh_ctx* ctx, const hnh_csr_block* b, double* values, const double* scale, const double* X, const double* Y, int R,
+                     unsigned flags, const hnh_csr_window* window, int stream) {
     HNH_ENTER(ctx, stream);
     if (!b) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sddmm_csr_p: null block");
     if (flags & ~HNH_FUSED_VALUES_OVERWRITE) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sddmm_csr_p: unknown flag");
     if (int rc = check_common(ctx, b->rows, R, "hnh_sddmm_csr_p")) return rc;
     if (b->rows == 0) return HNH_OK;
     if (!b->rowptr || !b->col_idx || !values || !X || !Y) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sddmm_csr_p: null pointer");
+    if (scale == values) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sddmm_csr_ps: scale aliases values");
     const Shape s = pick_shape(R, aligned16(X) && aligned16(Y));
     hnh::WideLaunch wide(ctx, stream);
     if (wide.status != HNH_OK) return wide.status;
     return wide.finish(dispatch_row<Op::kSddmm>(ctx, wide.stream(), stream, s, b->rows, b->nnz, b->max_row_nnz, window ? -1 : b->cols, b->rowptr, b->col_idx,
-                                                values, nullptr, X, Y, nullptr, R, flags, Extras(), nullptr, window, b->plan));
+                                                values, scale, X, Y, nullptr, R, flags, Extras(), nullptr, window, b->plan));
 }
 
 int hnh_spmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* b, const double* values, const double* X, double* Out, int R, const hnh_csr_window* window,

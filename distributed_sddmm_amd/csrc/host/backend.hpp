@@ -37,7 +37,7 @@ struct Backend {
     HNH_FN(hnh_comm_allreduce_f64)
     HNH_FN(hnh_ipc_export) HNH_FN(hnh_ipc_open) HNH_FN(hnh_ipc_close) HNH_FN(hnh_ipc_pull) HNH_FN(hnh_ipc_flags_register) HNH_FN(hnh_ipc_flags_unregister)
     HNH_FN(hnh_stream_write_flag) HNH_FN(hnh_stream_wait_flag)
-    HNH_FN(hnh_csr_plan_create) HNH_FN(hnh_csr_plan_destroy) HNH_FN(hnh_sddmm_csr_p) HNH_FN(hnh_spmm_csr_p) HNH_FN(hnh_fused_sddmm_spmm_csr_p)
+    HNH_FN(hnh_csr_plan_create) HNH_FN(hnh_csr_plan_destroy) HNH_FN(hnh_sddmm_csr_p) HNH_FN(hnh_sddmm_csr_ps) HNH_FN(hnh_spmm_csr_p) HNH_FN(hnh_fused_sddmm_spmm_csr_p)
 #ifdef HNH_MEASUREMENT_AIDS
     HNH_FN(hnh_stream_delay_us) HNH_FN(hnh_stream_paced_copy) HNH_FN(hnh_stream_pace_begin) HNH_FN(hnh_stream_pace_end)
 #endif

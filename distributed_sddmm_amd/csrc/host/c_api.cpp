@@ -474,6 +474,12 @@ int hnh_dist_kernel_profile(hnh_dist* d, int enable, double* total_ms, int64_t* 
     return HNH_OK;
 }
 
+int hnh_dist_borrow_stats(hnh_dist* d, int64_t out4[4]) {
+    if (!d || !out4) return HNH_ERR_INVALID;
+    for (int k = 0; k < 4; k++) out4[k] = d->d->S->borrow_stats[k] + d->d->ST->borrow_stats[k];
+    return HNH_OK;
+}
+
 // ------------------------------------------------------------------ dense / vectors
 int hnh_dense_create(hnh_world* w, int64_t rows, int64_t cols, double fill, hnh_dense** out) {
     return guarded(w->w.get(), [&] {

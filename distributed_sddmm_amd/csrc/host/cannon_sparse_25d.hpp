@@ -131,11 +131,13 @@ public:
                 auto t = phase_begin("Sparse Fiber Communication Time");
                 world->allgatherv_f64(grid->fiber_world, SValues.data(), (size_t)SValues.size(), value_buffer.data(),
                                       choice->layer_coords_sizes, choice->layer_coords_start, HNH_STREAM_COMPUTE);
-                choice->setCSRValues(value_buffer);
+                if (kernel->borrows_value_arrays()) choice->lendCSRValues(value_buffer, Arole->cols(), borrow_mode);  // (the stationary block reads it in place)
+                else choice->setCSRValues(value_buffer);
                 phase_end(t);
             } else {
                 auto t = phase_begin("Computation Time");
-                choice->setCSRValues(SValues);
+                if (kernel->borrows_value_arrays()) choice->lendCSRValues(SValues, Arole->cols(), borrow_mode);
+                else choice->setCSRValues(SValues);
                 phase_end(t);
             }
         } else if (!kernel->overwrites_fresh_values()) {  // (otherwise the stationary block's first visit stores instead of adding)
@@ -240,6 +242,7 @@ public:
                 phase_end(t);
             }
         }
+        choice->reclaimValueArrays();
     }
 
 private:

@@ -488,9 +488,14 @@ public:
         // SDDMM: every block (window) is visited exactly once per call, so a kernel that honours CSRLocal::values_fresh stores its
         // results and the zero fill of the reference (distributed_sparse.h:280) is not needed; other plugins get zeroed values
         const bool fresh = is_sddmm && kernel->overwrites_fresh_values();
+        // ... and a kernel that borrows_value_arrays() reads SValues in place (SpMM: no setCSRValues copy) and writes SValues .* dots
+        // straight into the result (SDDMM: no closing Hadamard pass): the blocks of this schedule never move
+        const bool borrow = kernel->borrows_value_arrays();
         {
             auto t = phase_begin("Computation Time");
             if (is_sddmm && !fresh) choice->setValuesConstant(0.0);
+            else if (is_sddmm && borrow) choice->lendSddmmTargets(SValues, *sddmm_result_ptr, Arole->cols(), borrow_mode);
+            else if (!is_sddmm && borrow) choice->lendCSRValues(SValues, Arole->cols(), borrow_mode);
             else if (!is_sddmm) choice->setCSRValues(SValues);
             phase_end(t);
         }
@@ -532,9 +537,10 @@ public:
 
         if (is_sddmm) {
             auto t = phase_begin("Computation Time");
-            choice->hadamardWithCSRValues(SValues, *sddmm_result_ptr);  // result = SValues .* block values
+            choice->hadamardWithCSRValues(SValues, *sddmm_result_ptr);  // result = SValues .* block values (blocks that did not borrow)
             phase_end(t);
         }
+        choice->reclaimValueArrays();
 
         if (fusionApproach == 2 && !is_sddmm && c > 1) {
             auto t = phase_begin("Replication Time");

@@ -70,8 +70,12 @@ public:
     bool verbose;
     std::string debug_msg;
     hnh::World* world;
+    // Borrowed value arrays (SpmatLocal::lendCSRValues / lendSddmmTargets) for stationary blocks, read at construction from
+    // HNH_BORROW: unset = where it pays (SpmatLocal::lendable), "off" = the reference's copy / Hadamard passes, "force" = always
+    int borrow_mode = 0;
 
     Distributed_Sparse(KernelImplementation* k) {
+        if (const char* b = std::getenv("HNH_BORROW")) borrow_mode = std::string(b) == "off" ? -1 : (std::string(b) == "force" ? 1 : 0);
         world = hnh::current_world();
         proc_rank = world->rank;
         p = world->size;

@@ -20,12 +20,15 @@ size_t StandardKernel::sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
     hnh_csr_window win;
     const hnh_csr_block desc = blk->block_args();
     const unsigned fresh = blk->values_fresh ? HNH_FUSED_VALUES_OVERWRITE : 0u;  // first visit: store instead of read-add-store
+    // (a lent destination: the products scale .* dots go straight into the caller's result vector, CSRLocal::sddmm_dst)
+    double* dst = blk->sddmm_dst ? blk->sddmm_dst : active->values;
+    const double* scale = blk->sddmm_dst ? blk->sddmm_scale : nullptr;
     if (blk->window_args(&win)) {  // one column range of the block (the schedule walks them as their data arrives)
-        w->check(w->be->hnh_sddmm_csr_p(w->ctx, &desc, active->values, Xptr, Yptr, (int)A.cols(), fresh, &win, HNH_STREAM_COMPUTE), "hnh_sddmm_csr_p");
+        w->check(w->be->hnh_sddmm_csr_ps(w->ctx, &desc, dst, scale, Xptr, Yptr, (int)A.cols(), fresh, &win, HNH_STREAM_COMPUTE), "hnh_sddmm_csr_ps");
         end(w);
         return processed;
     }
-    if (A.cols() <= kCooSddmmMaxWidth && !fresh) {  // (the COO kernel accumulates: first visits take the storing CSR pass)
+    if (A.cols() <= kCooSddmmMaxWidth && !fresh && scale == nullptr) {  // (the COO kernel accumulates: first visits take the storing CSR pass)
         // narrow operands: several sparse rows share a wave in the row kernel, and the wave runs as long as its longest row;
         // the COO kernel deals nonzeros out evenly instead (measured at config-2 size, R = 16: 2.06 vs 2.64 ms; R = 8: 2.03 vs
         // 3.37 ms; at R = 128 the row kernel wins 14.4 vs 19.3 ms — profiles/r02_kbench_narrow_and_coo.log)
@@ -36,7 +39,7 @@ size_t StandardKernel::sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
         end(w);
         return processed;
     }
-    w->check(w->be->hnh_sddmm_csr_p(w->ctx, &desc, active->values, Xptr, Yptr, (int)A.cols(), fresh, nullptr, HNH_STREAM_COMPUTE), "hnh_sddmm_csr_p");
+    w->check(w->be->hnh_sddmm_csr_ps(w->ctx, &desc, dst, scale, Xptr, Yptr, (int)A.cols(), fresh, nullptr, HNH_STREAM_COMPUTE), "hnh_sddmm_csr_ps");
     end(w, profile ? w->be->hnh_panel_count(w->ctx, blk->rows, blk->num_coords, blk->cols, (int)A.cols(), blk->row_hint()) : 1);
     return processed;
 }
@@ -53,15 +56,16 @@ size_t StandardKernel::spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B,
     hnh::World* w = S.world;
     const double* X = (mode == Amat) ? B.data() : A.data();
     double* Out = ((mode == Amat) ? A.data() : B.data()) + blk->part_first_row() * A.cols();  // (a row part writes its own rows of the output)
+    const double* vals = blk->spmm_values ? blk->spmm_values : active->values;  // (lent: the caller's SValues slice, read in place)
     begin(w);
     hnh_csr_window win;
     const hnh_csr_block desc = blk->block_args();
     if (blk->window_args(&win)) {
-        w->check(w->be->hnh_spmm_csr_p(w->ctx, &desc, active->values, X, Out, (int)A.cols(), &win, HNH_STREAM_COMPUTE), "hnh_spmm_csr_p");
+        w->check(w->be->hnh_spmm_csr_p(w->ctx, &desc, vals, X, Out, (int)A.cols(), &win, HNH_STREAM_COMPUTE), "hnh_spmm_csr_p");
         end(w);
         return processed;
     }
-    w->check(w->be->hnh_spmm_csr_p(w->ctx, &desc, active->values, X, Out, (int)A.cols(), nullptr, HNH_STREAM_COMPUTE), "hnh_spmm_csr_p");
+    w->check(w->be->hnh_spmm_csr_p(w->ctx, &desc, vals, X, Out, (int)A.cols(), nullptr, HNH_STREAM_COMPUTE), "hnh_spmm_csr_p");
     end(w, profile ? w->be->hnh_panel_count(w->ctx, blk->rows, blk->num_coords, blk->cols, (int)A.cols(), blk->row_hint()) : 1);
     return processed;
 }

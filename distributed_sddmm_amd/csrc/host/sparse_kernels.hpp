@@ -67,6 +67,11 @@ public:
     // an SDDMM (distributed_sparse.h:280's setValuesConstant) and mark every first visit instead.
     virtual bool overwrites_fresh_values() const { return false; }
 
+    // An implementation that honours CSRLocal::spmm_values and CSRLocal::sddmm_dst / sddmm_scale says so here: the schedules then
+    // let stationary blocks read SValues in place (no setCSRValues copy) and write `SValues .* dots` straight into the result of an
+    // SDDMM (no closing Hadamard pass).  Requires overwrites_fresh_values().
+    virtual bool borrows_value_arrays() const { return false; }
+
     static bool wants_epilogue(const hnh_fused_extras* extras) {
         return extras && (extras->x_scale != 0.0 || extras->rowdot != nullptr || extras->cg != nullptr || extras->relu_dst != nullptr);
     }
@@ -97,6 +102,7 @@ public:
     bool handles_windows() const override { return true; }
     bool overwrites_fresh_values() const override { return true; }
     bool handles_row_parts() const override { return true; }
+    bool borrows_value_arrays() const override { return true; }
     size_t sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, int block, int offset) override;
     size_t spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, MatMode mode, int block) override;
     size_t fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, DenseMatrix& Out, int block, unsigned flags,

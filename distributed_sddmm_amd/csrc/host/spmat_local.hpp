@@ -77,6 +77,15 @@ public:
     // since the operation began), so a kernel that says overwrites_fresh_values() may store its results instead of adding to them
     // — and the schedule has skipped the zero fill.  Kernels that do not know the hint are never given unfilled values.
     bool values_fresh = false;
+    // Borrowed value arrays.  A schedule whose kernel says borrows_value_arrays() may, for ONE operation on a block that never
+    // shifts, point the kernels at slices of the CALLER's vectors instead of the block's own value array:
+    //   spmm_values               the SpMM reads its nonzero values here — the copy of setCSRValues (SpmatLocal.hpp:571-579) is skipped;
+    //   sddmm_dst / sddmm_scale   the SDDMM stores scale[e] * dot[e] into dst[e] (result and SValues slices) — the block's own values
+    //                             and the closing Hadamard pass (15D_dense_shift.hpp:366) are not touched.
+    // Set through SpmatLocal::lendCSRValues / lendSddmmTargets, cleared by reclaimValueArrays() before the operation returns.
+    const double* spmm_values = nullptr;
+    double* sddmm_dst = nullptr;
+    const double* sddmm_scale = nullptr;
     void set_windows(const std::vector<int32_t>& bounds) {
         if (win_split) world->dfree(win_split);
         win_split = nullptr;
@@ -774,17 +783,73 @@ public:
                              "hnh_fill_f64");
     }
 
+    // ---- borrowed value arrays (CSRLocal::spmm_values / sddmm_dst): the slice of a caller's vector that belongs to block i stands in
+    // for the block's value array.  The narrow row kernels (R = 8 / 16 / 32) walk 128-byte lines of the value arrays, so at those
+    // widths a slice is lent only when it starts on a line; blocks that cannot borrow fall back to the copy / the Hadamard pass.
+    // block-level counts since construction: SpMM value arrays lent / copied, SDDMM results written in place / by a Hadamard pass
+    int64_t borrow_stats[4] = {0, 0, 0, 0};
+    // mode: Distributed_Sparse::borrow_mode (-1 never, 1 always, 0 by this rule)
+    static bool lendable(const void* p, int64_t R, int mode) { return mode != 0 ? mode > 0 : (R > 32 || reinterpret_cast<uintptr_t>(p) % 128 == 0); }
+
+    // setCSRValues for an SpMM whose kernel borrows_value_arrays(): stationary blocks read `values` in place
+    void lendCSRValues(const hnh::VectorXd& values, int64_t R, int mode = 0) {
+        if (!blockStarts.empty() && (uint64_t)values.size() < blockStarts.back()) hnh::fatal("Error, sparse value vector has the wrong length!");
+        for (size_t i = 0; i + 1 < blockStarts.size(); i++) {
+            CSRLocal* blk = csr_blocks[i];
+            if (blk == nullptr) continue;
+            const double* src = values.data() + blockStarts[i];
+            if (!blk->shifting && lendable(src, R, mode)) {
+                blk->spmm_values = src;
+                borrow_stats[0]++;
+                continue;
+            }
+            borrow_stats[1]++;
+            world->copy(blk->getActive()->values, src, sizeof(double) * (blockStarts[i + 1] - blockStarts[i]), HNH_COPY_D2D, HNH_STREAM_COMPUTE);
+        }
+    }
+
+    // for an SDDMM that visits every nonzero once (first visits store): stationary blocks write svalues .* dots straight into `out`;
+    // hadamardWithCSRValues() then skips them
+    void lendSddmmTargets(const hnh::VectorXd& svalues, hnh::VectorXd& out, int64_t R, int mode = 0) {
+        if (!blockStarts.empty() && ((uint64_t)svalues.size() < blockStarts.back() || (uint64_t)out.size() < blockStarts.back()))
+            hnh::fatal("Error, sparse value vector has the wrong length!");
+        if (svalues.data() == out.data()) return;  // in-place call: the kernel's scale operand must not alias its destination
+        for (size_t i = 0; i + 1 < blockStarts.size(); i++) {
+            CSRLocal* blk = csr_blocks[i];
+            if (blk == nullptr || blk->shifting) continue;
+            double* dst = out.data() + blockStarts[i];
+            const double* scale = svalues.data() + blockStarts[i];
+            if (lendable(dst, R, mode) && lendable(scale, R, mode)) {
+                blk->sddmm_dst = dst;
+                blk->sddmm_scale = scale;
+                borrow_stats[2]++;
+            }
+        }
+    }
+
+    void reclaimValueArrays() {
+        for (CSRLocal* blk : csr_blocks)
+            if (blk != nullptr) {
+                blk->spmm_values = nullptr;
+                blk->sddmm_dst = nullptr;
+                blk->sddmm_scale = nullptr;
+            }
+    }
+
     // out[e] = svalues[e] * (block values)[e] — the Hadamard step that ends every SDDMM
-    // (`SValues.cwiseProduct(choice->getCSRValues())`, 15D_dense_shift.hpp:366) without the temporary.
+    // (`SValues.cwiseProduct(choice->getCSRValues())`, 15D_dense_shift.hpp:366) without the temporary.  Blocks whose SDDMM already
+    // wrote the product (lendSddmmTargets) are skipped.
     void hadamardWithCSRValues(const hnh::VectorXd& svalues, hnh::VectorXd& out, int64_t out_offset = 0) {
         if (!blockStarts.empty() && ((uint64_t)svalues.size() < out_offset + blockStarts.back() || (uint64_t)out.size() < out_offset + blockStarts.back()))
             hnh::fatal("Error, sparse value vector has the wrong length!");
         for (size_t i = 0; i + 1 < blockStarts.size(); i++)
-            if (csr_blocks[i] != nullptr && blockStarts[i + 1] > blockStarts[i])
+            if (csr_blocks[i] != nullptr && csr_blocks[i]->sddmm_dst == nullptr && blockStarts[i + 1] > blockStarts[i]) {
+                borrow_stats[3]++;
                 world->check(world->be->hnh_hadamard_f64(world->ctx, out.data() + out_offset + blockStarts[i],
                                                          svalues.data() + out_offset + blockStarts[i],
                                                          csr_blocks[i]->getActive()->values,
                                                          (int64_t)(blockStarts[i + 1] - blockStarts[i]), HNH_STREAM_COMPUTE),
                              "hnh_hadamard_f64");
+            }
     }
 };

@@ -84,7 +84,7 @@ Backend* load_backend(const char* path_c) {
     HNH_BIND(hnh_comm_allreduce_f64)
     HNH_BIND(hnh_ipc_export) HNH_BIND(hnh_ipc_open) HNH_BIND(hnh_ipc_close) HNH_BIND(hnh_ipc_pull) HNH_BIND(hnh_ipc_flags_register) HNH_BIND(hnh_ipc_flags_unregister)
     HNH_BIND(hnh_stream_write_flag) HNH_BIND(hnh_stream_wait_flag)
-    HNH_BIND(hnh_csr_plan_create) HNH_BIND(hnh_csr_plan_destroy) HNH_BIND(hnh_sddmm_csr_p) HNH_BIND(hnh_spmm_csr_p) HNH_BIND(hnh_fused_sddmm_spmm_csr_p)
+    HNH_BIND(hnh_csr_plan_create) HNH_BIND(hnh_csr_plan_destroy) HNH_BIND(hnh_sddmm_csr_p) HNH_BIND(hnh_sddmm_csr_ps) HNH_BIND(hnh_spmm_csr_p) HNH_BIND(hnh_fused_sddmm_spmm_csr_p)
 #ifdef HNH_MEASUREMENT_AIDS
     HNH_BIND(hnh_stream_delay_us) HNH_BIND(hnh_stream_paced_copy) HNH_BIND(hnh_stream_pace_begin) HNH_BIND(hnh_stream_pace_end)
 #endif

@@ -132,6 +132,11 @@ int hnh_dist_json(hnh_dist* d, int which, char* buf, size_t capacity);
 int hnh_dist_reset_timers(hnh_dist* d); /* reset_performance_timers */
 /* HIP-event time of the local kernels launched by the operator's StandardKernel since enabling */
 int hnh_dist_kernel_profile(hnh_dist* d, int enable, double* total_ms, int64_t* launches);
+/* Borrowed value arrays of stationary blocks (an addition; HNH_BORROW=off|force, default = where it pays): block-level counts since
+ * construction, S and ST together: [0] SpMM value arrays read in place from the caller's vector, [1] copied as setCSRValues does
+ * (SpmatLocal.hpp:571-579), [2] SDDMM results written as SValues .* dots by the kernel, [3] by the closing Hadamard pass
+ * (15D_dense_shift.hpp:366) */
+int hnh_dist_borrow_stats(hnh_dist* d, int64_t out4[4]);
 
 /* ---- dense operands / value vectors (device resident) */
 int hnh_dense_create(hnh_world* w, int64_t rows, int64_t cols, double fill, hnh_dense** out);

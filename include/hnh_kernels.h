@@ -326,6 +326,13 @@ int hnh_csr_plan_destroy(hnh_ctx* ctx, hnh_csr_plan* plan);
  * of read, added to and stored: the caller skips its zero fill, the kernel the read (whole lines written, none fetched). */
 int hnh_sddmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* block, double* values, const double* X, const double* Y, int R,
                     unsigned flags, const hnh_csr_window* window, int stream);
+/* hnh_sddmm_csr_ps: the SDDMM with the Hadamard product that ends every sddmmA / sddmmB of the reference folded in
+ * (`SValues.cwiseProduct(choice->getCSRValues())`, 15D_dense_shift.hpp:366): dst[e] (+)= scale[e] * dot[e], so a caller whose
+ * nonzeros are each visited once per operation points dst at its slice of the RESULT vector and scale at the same slice of
+ * SValues, and neither the block's own values nor a closing element-wise pass are touched (24 B per nonzero saved; 8 added).
+ * scale == NULL: hnh_sddmm_csr_p.  scale must not alias dst. */
+int hnh_sddmm_csr_ps(hnh_ctx* ctx, const hnh_csr_block* block, double* dst, const double* scale, const double* X, const double* Y,
+                     int R, unsigned flags, const hnh_csr_window* window, int stream);
 int hnh_spmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* block, const double* values, const double* X, double* Out, int R,
                    const hnh_csr_window* window, int stream);
 int hnh_fused_sddmm_spmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* block, double* values, const double* svalues, const double* X,

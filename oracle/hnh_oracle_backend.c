@@ -58,8 +58,8 @@ static block* g_blocks = NULL;
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 int hnh_malloc(hnh_ctx* c, size_t bytes, void** out) {
     if (!out) return HNH_ERR_INVALID;
-    *out = malloc(bytes ? bytes : 16);
-    if (!*out) return fail(c, HNH_ERR_NOMEM, "malloc failed");
+    *out = NULL;  /* 256-byte aligned like hipMalloc: the host layer's alignment rules (SpmatLocal::lendable) then decide as on the device */
+    if (posix_memalign(out, 256, bytes ? bytes : 16) != 0 || !*out) return fail(c, HNH_ERR_NOMEM, "malloc failed");
     block* b = (block*)malloc(sizeof(block));
     if (b) {
         b->base = (char*)*out;
@@ -773,6 +773,30 @@ int hnh_sddmm_csr_p(hnh_ctx* c, const hnh_csr_block* b, double* values, const do
         }
     }
     return hnh_sddmm_csr_w(c, b->rows, b->rowptr, b->col_idx, values, X, Y, R, b->nnz, b->max_row_nnz, w ? w : &whole_block, stream);
+}
+/* dst[e] (+)= scale[e] * <X[i_e,:], Y[j_e,:]>: the SDDMM with its closing Hadamard folded in (sparse_kernels.cpp:44-55 followed by
+ * 15D_dense_shift.hpp:366).  With HNH_FUSED_VALUES_OVERWRITE the destination is written without being read. */
+int hnh_sddmm_csr_ps(hnh_ctx* c, const hnh_csr_block* b, double* dst, const double* scale, const double* X, const double* Y, int R,
+                     unsigned flags, const hnh_csr_window* w, int stream) {
+    (void)stream;
+    if (!scale) return hnh_sddmm_csr_p(c, b, dst, X, Y, R, flags, w, stream);
+    if (!b) return fail(c, HNH_ERR_INVALID, "null block");
+    if (flags & ~HNH_FUSED_VALUES_OVERWRITE) return fail(c, HNH_ERR_INVALID, "unknown flag");
+    if (b->rows < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad argument");
+    if (scale == dst) return fail(c, HNH_ERR_INVALID, "scale aliases dst");
+    const hnh_csr_window* ww = w ? w : &whole_block;
+    for (int64_t r = 0; r < b->rows; r++) {
+        const int32_t lo = ww->beg ? ww->beg[r] : b->rowptr[r], hi = ww->end ? ww->end[r] : b->rowptr[r + 1];
+        for (int32_t i = lo; i < hi; i++) {
+            const double* Arow = X + (int64_t)R * r;
+            const double* Brow = Y + (int64_t)R * b->col_idx[i];
+            double value = 0.0;
+            for (int k = 0; k < R; k++) value += Arow[k] * Brow[k];
+            if (flags & HNH_FUSED_VALUES_OVERWRITE) dst[i] = scale[i] * value;
+            else dst[i] += scale[i] * value;
+        }
+    }
+    return HNH_OK;
 }
 int hnh_spmm_csr_p(hnh_ctx* c, const hnh_csr_block* b, const double* values, const double* X, double* Out, int R, const hnh_csr_window* w, int stream) {
     if (!b) return fail(c, HNH_ERR_INVALID, "null block");

@@ -156,6 +156,7 @@ def run_all_ops(world: H.World, alg: str, c: int, case: dict, make_spmat=None) -
     out["fingerprints"] = np.array(fps)
     out["alg_info"] = d.json_algorithm_info()
     out["perf"] = d.json_perf_statistics()
+    out["borrow"] = d.borrow_stats()
     for x in (A, B, S, ST):
         x.free()
     d.free(); sp.free()

@@ -226,3 +226,53 @@ def test_matrix_without_nonzeros(alg):
             continue
         per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
         T.check_against_oracle(T.assemble(per_rank, case), case, alg)
+
+
+@pytest.mark.parametrize("mode", ["force", "off"])
+@pytest.mark.parametrize("alg,p,c", [("15d_fusion1", 4, 1), ("15d_fusion2", 4, 2), ("15d_fusion2", 1, 1), ("25d_sparse_replicate", 8, 2),
+                                     ("15d_sparse", 4, 1)])
+def test_borrowed_value_arrays(monkeypatch, mode, alg, p, c):
+    """Stationary blocks may read SValues in place (no setCSRValues copy, SpmatLocal.hpp:571-579) and take the SDDMM's result as
+    SValues .* dots straight from the kernel (no closing Hadamard, 15D_dense_shift.hpp:366).  HNH_BORROW=force lends whatever the
+    alignment, off never does: both give the reference's golden vectors, and the block counts say which path ran.  Travelling
+    blocks (sparse shift) never borrow."""
+    monkeypatch.setenv("HNH_BORROW", mode)
+    case = T.case_inputs("er8_r16")
+    per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
+    T.check_against_golden(T.assemble(per_rank, case), per_rank, case, alg)
+    lent_spmm, copied, lent_sddmm, hadamard = (sum(r["borrow"][k] for r in per_rank) for k in range(4))
+    if mode == "off" or alg == "15d_sparse":
+        assert lent_spmm == 0 and lent_sddmm == 0 and (hadamard > 0 or alg == "25d_sparse_replicate")
+        assert copied > 0 or alg == "15d_sparse"  # (the sparse shift copies through setCSRValues, which is not counted)
+    elif alg == "25d_sparse_replicate":  # its SDDMM visits the block sqrt(p/c) times: only the SpMM side borrows
+        assert lent_spmm > 0 and copied == 0 and lent_sddmm == 0
+    else:
+        assert lent_spmm > 0 and copied == 0 and lent_sddmm > 0 and hadamard == 0
+
+
+def test_in_place_sddmm_does_not_borrow(monkeypatch):
+    """sddmmA(A, B, S, S): result and SValues are the same vector — the kernel's scale operand must not alias its destination, so
+    the call takes the block-values + Hadamard route and still returns S .* dots."""
+    monkeypatch.setenv("HNH_BORROW", "force")
+    case = T.case_inputs("er8_r16")
+
+    def body(w):
+        sp = H.SpmatLocal.from_global(w, case["M"], case["N"], case["rows"], case["cols"], case["vals"])
+        d = H.DistributedSparse(w, "15d_fusion2", sp, case["R"], 1)
+        A, B = d.like_A_matrix(0.0), d.like_B_matrix(0.0)
+        subA, subB = d.submatrices(H.AMAT), d.submatrices(H.BMAT)
+        A.upload(T.fill_local(subA, A.shape, case["A"])); B.upload(T.fill_local(subB, B.shape, case["B"]))
+        S, res = d.like_S_values(0.5), d.like_S_values(0.0)
+        d.sddmmA(A, B, S, res)
+        before = d.borrow_stats()
+        d.sddmmA(A, B, S, S)
+        after = d.borrow_stats()
+        out = (res.download(), S.download(), before, after)
+        for x in (A, B, S, res):
+            x.free()
+        d.free(); sp.free()
+        return out
+
+    for res, inplace, before, after in H.run_spmd(2, body):
+        assert np.array_equal(res, inplace)
+        assert before[2] > 0 and after[2] == before[2] and after[3] > before[3]

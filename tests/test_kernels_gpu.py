@@ -669,6 +669,65 @@ def test_narrow_rows_line_granular_streams(ctx, R, shift):
         d.free()
 
 
+@pytest.mark.parametrize("R", [8, 16, 32, 64, 100, 128, 256, 257, 600])
+@pytest.mark.parametrize("shift", [0, 3])
+def test_sddmm_with_the_hadamard_folded_in(ctx, R, shift):
+    """hnh_sddmm_csr_ps: dst[e] (+)= scale[e] * <X[i_e,:], Y[j_e,:]> — storing into garbage (first visits) and accumulating, over the
+    whole block and window by window, with hub rows, a structure plan, line-aligned arrays (narrow instances at R = 8 / 16 / 32)
+    and arrays that start 3 elements into a line (`shift`; the general loop), widths that take the column-tiled fallback
+    (257, 600: every tile scales its partial dot product).  scale = NULL is hnh_sddmm_csr_p; scale aliasing dst is refused."""
+    from distributed_sddmm_amd import _kernels as K
+    lib = ctx.lib
+    rng = np.random.default_rng(7 * R + shift)
+    rows, cols = 211, 5000
+    lens = rng.choice([0, 1, 7, 16, 17, 33, 64, 90, 130], rows)
+    lens[4], lens[120] = 3000, 800  # hub rows
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cidx = np.concatenate([np.sort(rng.choice(cols, int(n), replace=False)) for n in lens]).astype(np.int32)
+    ridx = np.repeat(np.arange(rows, dtype=np.int32), lens)
+    nnz = len(cidx)
+    X, Y = rng.uniform(-1, 1, (rows, R)), rng.uniform(-1, 1, (cols, R))
+    sv, v0 = rng.uniform(-1, 1, nnz), rng.uniform(-1, 1, nnz)
+    dots = O.sddmm_local(ridx, cidx, np.zeros(nnz), X, Y)
+    d_rp, d_c, dX, dY = ctx.upload(rowptr), ctx.upload(cidx), ctx.upload(X), ctx.upload(Y)
+    pad = np.zeros(shift)
+    d_dst, d_sv = ctx.upload(np.concatenate([pad, np.full(nnz, 1e300)])), ctx.upload(np.concatenate([pad, sv]))
+    dst_ptr, sv_ptr = d_dst.ptr + 8 * shift, d_sv.ptr + 8 * shift
+    plan = C.c_void_p()
+    ctx.check(lib.hnh_csr_plan_create(ctx.h, C.byref(plan)), "plan")
+    blk = K.CsrBlock(rows, nnz, cols, int(lens.max()), 0, d_rp.ptr, d_c.ptr, plan)
+    # first visit: stored over garbage
+    ctx.check(lib.hnh_sddmm_csr_ps(ctx.h, C.byref(blk), dst_ptr, sv_ptr, dX.ptr, dY.ptr, R, K.FUSED_VALUES_OVERWRITE, None, 0), "sddmm_ps")
+    assert rel(d_dst.get()[shift:], sv * dots) <= TOL
+    # a later visit adds
+    d_dst.set(np.concatenate([pad, v0]))
+    ctx.check(lib.hnh_sddmm_csr_ps(ctx.h, C.byref(blk), dst_ptr, sv_ptr, dX.ptr, dY.ptr, R, 0, None, 0), "sddmm_ps")
+    assert rel(d_dst.get()[shift:], v0 + sv * dots) <= TOL
+    # window by window, each window's first visit storing
+    bounds = np.array([1200, 1200, 3700], dtype=np.int32)
+    nw = len(bounds) + 1
+    d_split = ctx.upload(np.zeros((len(bounds), rows), np.int32))
+    ctx.check(lib.hnh_csr_window_bounds(ctx.h, rows, d_rp.ptr, d_c.ptr, len(bounds), bounds.ctypes.data_as(C.c_void_p), d_split.ptr, 0), "bounds")
+    d_dst.set(np.concatenate([pad, np.full(nnz, -1e300)]))
+    noplan = K.CsrBlock(rows, nnz, cols, int(lens.max()), 0, d_rp.ptr, d_c.ptr, None)
+    for q in range(nw):
+        beg = None if q == 0 else d_split.ptr + (q - 1) * rows * 4
+        end = None if q == nw - 1 else d_split.ptr + q * rows * 4
+        win = K.CsrWindow(beg, end, 1 if q == nw - 1 else 0)
+        ctx.check(lib.hnh_sddmm_csr_ps(ctx.h, C.byref(noplan), dst_ptr, sv_ptr, dX.ptr, dY.ptr, R, K.FUSED_VALUES_OVERWRITE, C.byref(win), 0), "sddmm_ps w")
+    assert rel(d_dst.get()[shift:], sv * dots) <= TOL
+    # no scale: the plain SDDMM; an aliased scale: refused
+    d_dst.set(np.concatenate([pad, v0]))
+    ctx.check(lib.hnh_sddmm_csr_ps(ctx.h, C.byref(blk), dst_ptr, None, dX.ptr, dY.ptr, R, 0, None, 0), "sddmm_ps")
+    assert rel(d_dst.get()[shift:], v0 + dots) <= TOL
+    assert lib.hnh_sddmm_csr_ps(ctx.h, C.byref(blk), dst_ptr, dst_ptr, dX.ptr, dY.ptr, R, 0, None, 0) != 0
+    # nothing in front of the arrays was touched, the scale array is unchanged
+    assert np.all(d_dst.get()[:shift] == 0) and np.array_equal(d_sv.get()[shift:], sv)
+    ctx.check(lib.hnh_csr_plan_destroy(ctx.h, plan), "plan destroy")
+    for d in (d_rp, d_c, dX, dY, d_dst, d_sv, d_split):
+        d.free()
+
+
 def test_stream_delay_and_paced_copy(ctx):
     """The measurement stand-ins of the overlap probe: hnh_stream_delay_us holds a stream for at least the requested time (and not for many times as long),
     hnh_stream_paced_copy delivers every slice bit for bit and takes at least the modelled time."""

@@ -78,4 +78,13 @@ def test_c_restatement_matches_reference(name):
     vals[:] = 3.0
     assert lib.hnh_fused_sddmm_spmm_csr(ctx, C.c_int64(m), p(rowptr), p(cols), p(vals), None, p(a), p(b), p(out), r, 3, 0) == 0
     assert T.rel(out, g["fusedA_fusion2"]) <= T.TOL
+    # the SDDMM with its closing Hadamard folded in (hnh_sddmm_csr_ps) IS the reference's sddmmA: storing into garbage, and adding
+    from distributed_sddmm_amd import _kernels as K
+    blk = K.CsrBlock(m, len(rows), n, -1, 0, p(rowptr), p(cols), None)
+    dst = np.full(len(rows), 1e300)
+    assert lib.hnh_sddmm_csr_ps(ctx, C.byref(blk), p(dst), p(sv), p(a), p(b), r, K.FUSED_VALUES_OVERWRITE, None, 0) == 0
+    assert T.rel(dst, g["sddmmA"]) <= T.TOL
+    assert lib.hnh_sddmm_csr_ps(ctx, C.byref(blk), p(dst), p(sv), p(a), p(b), r, 0, None, 0) == 0
+    assert T.rel(dst, 2 * g["sddmmA"]) <= T.TOL
+    assert lib.hnh_sddmm_csr_ps(ctx, C.byref(blk), p(sv), p(sv), p(a), p(b), r, 0, None, 0) != 0  # scale must not alias the destination
     lib.hnh_ctx_destroy(ctx)

@@ -337,3 +337,40 @@ def test_schedules_with_compute_units_set_aside_for_communication(alg, p, c, mon
     case = T.case_inputs("er8_r16")
     per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
     T.check_against_golden(T.assemble(per_rank, case), per_rank, case, alg)
+
+
+@pytest.mark.parametrize("mode", [None, "force", "off"])
+@pytest.mark.parametrize("alg,p,c", [("15d_fusion2", 1, 1), ("15d_fusion2", 4, 2), ("15d_fusion1", 4, 1), ("25d_sparse_replicate", 8, 2)])
+def test_borrowed_value_arrays_hip(monkeypatch, mode, alg, p, c):
+    """Stationary blocks on the HIP kernels: the SpMM reads the caller's SValues slice in place, the SDDMM writes SValues .* dots
+    straight into the caller's result (hnh_sddmm_csr_ps).  Golden vectors at R = 16 — by default a slice is lent there only when it
+    starts on a 128-byte line (the narrow row kernels), `force` sends unaligned slices through the general loop — and a wider
+    operand (R = 64, hub rows included) against the oracle, where every slice is lent by default."""
+    if mode is None:
+        monkeypatch.delenv("HNH_BORROW", raising=False)
+    else:
+        monkeypatch.setenv("HNH_BORROW", mode)
+    case = T.case_inputs("er8_r16")
+    per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
+    T.check_against_golden(T.assemble(per_rank, case), per_rank, case, alg)
+    stats = [sum(r["borrow"][k] for r in per_rank) for k in range(4)]
+    if mode == "off":
+        assert stats[0] == 0 and stats[2] == 0
+    elif mode == "force":
+        assert stats[0] > 0 and stats[1] == 0 and (stats[2] > 0) == (alg != "25d_sparse_replicate")
+    if not T.valid_config(alg, p, c, 64):
+        return
+    rng = np.random.default_rng(5)
+    m = 640
+    lens = rng.integers(0, 30, m)
+    lens[7], lens[300] = 600, 450  # hub rows
+    rows = np.repeat(np.arange(m, dtype=np.int64), lens)
+    cols = np.concatenate([np.sort(rng.choice(m, int(k), replace=False)) for k in lens]).astype(np.int64)
+    wide = T.make_case("wide_r64", m, m, 64, rows, cols, seed=9)
+    per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, wide))
+    T.check_against_oracle(T.assemble(per_rank, wide), wide, alg)
+    stats = [sum(r["borrow"][k] for r in per_rank) for k in range(4)]
+    if mode != "off":
+        assert stats[0] > 0 and stats[1] == 0
+        if alg != "25d_sparse_replicate":
+            assert stats[2] > 0 and stats[3] == 0

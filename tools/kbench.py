@@ -104,6 +104,25 @@ def main():
             timed(lambda: ctx.check(lib.hnh_spmm_csr_p(ctx.h, C.byref(blk), dv.ptr, dB.ptr, dOut.ptr, R, None, 0), "spmm_p"),
                   "spmm/plan", nnz * (8 * R + 12) + 16 * R * m)
             ctx.check(lib.hnh_csr_plan_destroy(ctx.h, plan), "plan destroy")
+        if "fold" in ops:  # a whole sddmmA: storing SDDMM + the closing Hadamard pass, against the SDDMM with the Hadamard folded in
+            mx = C.c_int()
+            ctx.check(lib.hnh_csr_max_row_nnz(ctx.h, m, d_rowptr.ptr, C.byref(mx), 0), "max_row")
+            plan = C.c_void_p()
+            ctx.check(lib.hnh_csr_plan_create(ctx.h, C.byref(plan)), "plan")
+            blk = K.CsrBlock(m, nnz, m, mx.value, 0, d_rowptr.ptr, d_c.ptr, plan)
+            d_sv, d_res = K.DevArray(ctx, (nnz,), np.float64), K.DevArray(ctx, (nnz,), np.float64)
+            ctx.check(lib.hnh_fill_f64(ctx.h, d_sv.ptr, nnz, 0.5, 0), "fill")
+            model = nnz * (8 * R + 20) + 8 * R * m  # (the same SDDMM model for both: what a caller gets per sddmmA)
+
+            def two_pass():
+                ctx.check(lib.hnh_sddmm_csr_p(ctx.h, C.byref(blk), dv.ptr, dA.ptr, dB.ptr, R, 1, None, 0), "sddmm_p")
+                ctx.check(lib.hnh_hadamard_f64(ctx.h, d_res.ptr, d_sv.ptr, dv.ptr, nnz, 0), "hadamard")
+
+            timed(two_pass, "sddmm+hadamard", model)
+            timed(lambda: ctx.check(lib.hnh_sddmm_csr_ps(ctx.h, C.byref(blk), d_res.ptr, d_sv.ptr, dA.ptr, dB.ptr, R, 1, None, 0), "sddmm_ps"),
+                  "sddmm folded", model)
+            ctx.check(lib.hnh_csr_plan_destroy(ctx.h, plan), "plan destroy")
+            d_sv.free(); d_res.free()
         if "fused" in ops:
             timed(lambda: ctx.check(lib.hnh_fused_sddmm_spmm_csr(ctx.h, m, d_rowptr.ptr, d_c.ptr, dv.ptr, None, dA.ptr, dB.ptr,
                                                                  dOut.ptr, R, 3, 0), "fused"), "fused", nnz * (8 * R + 24) + 16 * R * m)
