@@ -1199,6 +1199,17 @@ def secondary(args, b):
         ms, launches = op.kernel_profile(0)
         return ms / calls, max(1, launches // calls)
 
+    def call_time(fn, calls):
+        """wall time per WHOLE operator call (ms), device drained on both sides: the local kernels plus whatever the operation does around
+        them (value copies, zero fills, the closing Hadamard of an SDDMM)"""
+        fn()
+        world.sync()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            fn()
+        world.sync()
+        return (time.perf_counter() - t0) * 1e3 / calls
+
     def frac_of(bytes_alg, ms):
         return bytes_alg / (ms * 1e-3) / HBM_PEAK
 
@@ -1206,7 +1217,7 @@ def secondary(args, b):
     if args.app == "vanilla" and b.op is not None:
         op, m, nnz = b.op, b.m, b.nnz
         host = b.wl.host_nonzeros(H)
-        for r in (8, 16, 256):
+        for r in (8, 16, 128, 256):
             def widths(r=r):
                 op.setRValue(r)
                 A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
@@ -1217,10 +1228,11 @@ def secondary(args, b):
                     res["fused"] = {"ms": ms, "algorithmic_bytes": fused_bytes(nnz, r, m), "frac": frac_of(fused_bytes(nnz, r, m), ms)}
                     ms, _ = kernel_time(op, lambda: op.sddmmA(A, B, S, buf), 3)
                     by = nnz * (8 * r + 20) + 8 * r * m
-                    res["sddmm"] = {"ms": ms, "algorithmic_bytes": by, "frac": frac_of(by, ms)}
+                    res["sddmm"] = {"ms": ms, "algorithmic_bytes": by, "frac": frac_of(by, ms), "call_ms": call_time(lambda: op.sddmmA(A, B, S, buf), 3)}
                     ms, _ = kernel_time(op, lambda: op.spmmA(A, B, S), 3)
                     by = nnz * (8 * r + 12) + 16 * r * m
-                    res["spmm"] = {"ms": ms, "algorithmic_bytes": by, "frac": frac_of(by, ms)}
+                    res["spmm"] = {"ms": ms, "algorithmic_bytes": by, "frac": frac_of(by, ms), "call_ms": call_time(lambda: op.spmmA(A, B, S), 3)}
+                    res["borrowed_value_arrays"] = dict(zip(("spmm_lent", "spmm_copied", "sddmm_in_place", "sddmm_hadamard"), op.borrow_stats()))
                     if host is not None:  # closed forms with the keyed operands: sddmm(i,j) = a_i b_j (u.v); spmm[i,k] = v_k sum_j b_j
                         grows, gcols = host
                         a_key, b_key = keyed(np.arange(m), 1), keyed(np.arange(m), 2)
@@ -1242,7 +1254,8 @@ def secondary(args, b):
                     for x in (A, B, S, buf):
                         x.free()
                 return res
-            entry("the headline matrix at R=%d: fused / SDDMM / SpMM kernels through the operator (device time of the local kernels)" % r, widths)
+            entry("the headline matrix at R=%d: fused / SDDMM / SpMM kernels through the operator (ms = device time of the local kernels, "
+                  "call_ms = the whole sddmmA / spmmA call)" % r, widths)
         b.op.setRValue(args.r)
 
     # (iii) one ALS step, (iv) the GAT forward pass — on the headline's matrix and transport, a fresh operator each

@@ -232,11 +232,14 @@ def test_secondary_workloads_are_listed_with_their_checks():
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
     sec = out["secondary"]
-    assert len(sec) == 7 and not [e for e in sec if "error" in e], [e.get("error") for e in sec]
+    assert len(sec) == 8 and not [e for e in sec if "error" in e], [e.get("error") for e in sec]
     by_name = {e["workload"]: e for e in sec}
-    for r in (8, 16, 256):
+    for r in (8, 16, 128, 256):
         e = next(v for k, v in by_name.items() if "R=%d:" % r in k)
         assert e["check"]["ok"] and all(e[op]["ms"] > 0 and e[op]["algorithmic_bytes"] > 0 for op in ("fused", "sddmm", "spmm"))
+        assert e["sddmm"]["call_ms"] > 0 and e["spmm"]["call_ms"] > 0  # whole sddmmA / spmmA calls
+        b = e["borrowed_value_arrays"]  # one stationary block at offset 0: SValues read in place, results written in place
+        assert b["spmm_lent"] > 0 and b["sddmm_in_place"] > 0 and b["spmm_copied"] == 0 and b["sddmm_hadamard"] == 0
     assert next(v for k, v in by_name.items() if "ALS" in k)["check"]["ok"]
     assert next(v for k, v in by_name.items() if k.startswith("GAT"))["check"]["rel_err"] <= 1e-9
     assert next(v for k, v in by_name.items() if k.startswith("R-MAT"))["check"]["ok"]
