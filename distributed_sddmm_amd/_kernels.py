@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HNH_KERNEL_LIB_DEV") or os.path.join(HERE, "lib", "libhnh_kernels.so")  # override: kernel tuning experiments only
 
 OK = 0
-STREAM_COMPUTE, STREAM_COMM = 0, 1
+STREAM_COMPUTE, STREAM_COMM, STREAM_AUX = 0, 1, 2
 H2D, D2H, D2D = 0, 1, 2
 FUSED_VALUES_OVERWRITE, FUSED_OUT_OVERWRITE, FUSED_LEAKY_RELU = 1, 2, 4
 UNIQUE_ID_BYTES = 128

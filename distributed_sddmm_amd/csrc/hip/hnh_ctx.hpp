@@ -6,22 +6,22 @@
 
 struct hnh_ctx {
     int device = 0;
-    hipStream_t streams[2] = {nullptr, nullptr};  // [HNH_STREAM_COMPUTE], [HNH_STREAM_COMM]
+    hipStream_t streams[HNH_STREAMS] = {nullptr};  // [HNH_STREAM_COMPUTE], [HNH_STREAM_COMM], [HNH_STREAM_AUX]
     std::string last_error;
     // work list of the long-row pass (one per stream): items = (row, segment), count lives on the device
-    void* long_items[2] = {nullptr, nullptr};
-    int* long_count[2] = {nullptr, nullptr};  // two ints: number of items, number of hub rows
-    size_t long_cap[2] = {0, 0};
+    void* long_items[HNH_STREAMS] = {nullptr};
+    int* long_count[HNH_STREAMS] = {nullptr};  // two ints: number of items, number of hub rows
+    size_t long_cap[HNH_STREAMS] = {0};
     // the hub rows themselves, (row, first item, segments), and the segments' partial output rows (items x row pitch doubles)
-    void* long_rows[2] = {nullptr, nullptr};
-    size_t long_rows_cap[2] = {0, 0};
-    void* long_partials[2] = {nullptr, nullptr};
-    size_t long_partials_bytes[2] = {0, 0};
+    void* long_rows[HNH_STREAMS] = {nullptr};
+    size_t long_rows_cap[HNH_STREAMS] = {0};
+    void* long_partials[HNH_STREAMS] = {nullptr};
+    size_t long_partials_bytes[HNH_STREAMS] = {0};
     size_t hub_scratch_bytes = (size_t)2 << 30;  // HNH_HUB_SCRATCH_MB: bound of long_partials per stream; segments beyond it use atomics
     bool hub_atomics = false;  // HNH_HUB_ATOMICS=1: combine hub-row segments with fp64 atomics (round 1's way) instead of the ordered reduction
     // per-row panel boundaries of the Infinity-Cache panels (one per stream): (panels - 1) x rows int32
-    void* panel_split[2] = {nullptr, nullptr};
-    size_t panel_cap[2] = {0, 0};
+    void* panel_split[HNH_STREAMS] = {nullptr};
+    size_t panel_cap[HNH_STREAMS] = {0};
     bool no_panels = false;  // HNH_NO_PANELS=1: A/B switch
     int row_waves_cap = -1;  // HNH_ROW_WAVES_CAP=k: 1..7 = at most k waves per SIMD for every row-kernel launch, 0 = never cap; unset = the
                              // library's rule (uniform blocks of certain widths run at 5, see row_occupancy_pad in hnh_kernels.hip)
@@ -39,7 +39,7 @@ struct hnh_ctx {
     static constexpr int kAuxStreams = 8;
     hipStream_t aux[kAuxStreams] = {nullptr};
     hipEvent_t aux_fork = nullptr, aux_join[kAuxStreams] = {nullptr};
-    unsigned long long* pace_stamp[2] = {nullptr, nullptr};  // measurement aid (hnh_stream_pace_begin / _end): the clock at the begin mark
+    unsigned long long* pace_stamp[HNH_STREAMS] = {nullptr};  // measurement aid (hnh_stream_pace_begin / _end): the clock at the begin mark
     int flag_kernels = -1;  // HNH_IPC_FLAGS=kernel: flag words are written / awaited by one-lane kernels instead of stream memory operations
 };
 
@@ -55,7 +55,7 @@ inline int check_hip(hnh_ctx* ctx, hipError_t e, const char* what) {
     return fail(ctx, HNH_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
 }
 
-inline bool valid_stream(int s) { return s == HNH_STREAM_COMPUTE || s == HNH_STREAM_COMM; }
+inline bool valid_stream(int s) { return s >= 0 && s < HNH_STREAMS; }
 
 // Scope of an operation that runs on ALL compute units although the compute stream is masked: the constructor makes the wide
 // stream wait for what the compute stream has enqueued so far, `stream()` is where the operation's launches go, finish()

@@ -2166,7 +2166,7 @@ int hnh_csr_plan_destroy(hnh_ctx* ctx, hnh_csr_plan* plan) {
     if (!ctx) return HNH_ERR_INVALID;
     if (!plan) return HNH_OK;
     HNH_TRY_HIP(ctx, hipSetDevice(ctx->device));
-    for (int s = 0; s < 2; s++)
+    for (int s = 0; s < HNH_STREAMS; s++)
         if (ctx->streams[s]) HNH_TRY_HIP(ctx, hipStreamSynchronize(ctx->streams[s]));
     if (ctx->wide) HNH_TRY_HIP(ctx, hipStreamSynchronize(ctx->wide));
     for (auto& sp : plan->splits)

@@ -161,9 +161,21 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
         for (int i = 0; i < cus; i++)
             if (!(mask_comm[i / 32] & (1u << (i % 32)))) mask_compute[i / 32] |= 1u << (i % 32);
     }
+    // HNH_AUX_PRIORITY=high|low: priority of HNH_STREAM_AUX (the GAT pipeline's dense products beside the attention passes of the
+    // compute stream); default: the same priority as the compute stream
+    int aux_priority = 0;
+    bool aux_has_priority = false;
+    if (const char* ap = std::getenv("HNH_AUX_PRIORITY")) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
+            aux_has_priority = true;
+            aux_priority = (ap[0] == 'h') ? hi : lo;
+        }
+    }
     auto plain_stream = [&](hipStream_t* st, bool comm) {
         hipError_t e = hipErrorUnknown;
         if (comm && has_priorities) e = hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest);
+        if (!comm && aux_has_priority && st == &ctx->streams[HNH_STREAM_AUX]) e = hipStreamCreateWithPriority(st, hipStreamNonBlocking, aux_priority);
         if (e != hipSuccess) e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
         return e;
     };
@@ -173,11 +185,12 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
         if (masked) {
             hipError_t e = comm_exclusive ? hipExtStreamCreateWithCUMask(&ctx->streams[HNH_STREAM_COMM], (uint32_t)mask_words, mask_comm)
                                           : plain_stream(&ctx->streams[HNH_STREAM_COMM], true);
+            if (e == hipSuccess) e = plain_stream(&ctx->streams[HNH_STREAM_AUX], false);
             if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->wide, hipStreamNonBlocking);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->wide_fork, hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->wide_join, hipEventDisableTiming);
             if (e != hipSuccess) {  // half a set-up is no set-up: start again without masks
-                for (hipStream_t* st : {&ctx->streams[0], &ctx->streams[1], &ctx->wide})
+                for (hipStream_t* st : {&ctx->streams[0], &ctx->streams[1], &ctx->streams[2], &ctx->wide})
                     if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
                 if (ctx->wide_fork) { (void)hipEventDestroy(ctx->wide_fork); ctx->wide_fork = nullptr; }
                 if (ctx->wide_join) { (void)hipEventDestroy(ctx->wide_join); ctx->wide_join = nullptr; }
@@ -188,7 +201,7 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
     if (masked) {
         ctx->comm_cus = placed;
     } else {
-        for (int s = 0; s < 2; s++)
+        for (int s = 0; s < HNH_STREAMS; s++)
             if (plain_stream(&ctx->streams[s], s == HNH_STREAM_COMM) != hipSuccess) {
                 delete ctx;
                 return HNH_ERR_DEVICE;
@@ -202,7 +215,7 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
 int hnh_ctx_destroy(hnh_ctx* ctx) {
     if (!ctx) return HNH_ERR_INVALID;
     (void)hipSetDevice(ctx->device);
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < HNH_STREAMS; s++) {
         if (ctx->streams[s]) { (void)hipStreamSynchronize(ctx->streams[s]); (void)hipStreamDestroy(ctx->streams[s]); }
         if (ctx->long_items[s]) (void)hipFree(ctx->long_items[s]);
         if (ctx->long_count[s]) (void)hipFree(ctx->long_count[s]);

@@ -12,6 +12,7 @@
 // do not split R (1.5D dense shift), which is what the parity tests use.
 #pragma once
 #include "distributed_sparse.hpp"
+#include <cstdlib>
 
 class GATLayer {
 public:
@@ -46,15 +47,86 @@ public:
         }
     }
 
+    ~GAT() {
+        if (d_ops == nullptr || d_ops->world == nullptr) return;
+        hnh::World* w = d_ops->world;
+        w->sync_all_nothrow();  // the events below may still be waited on
+        for (void* e : {ev_input, ev_gemm[0], ev_gemm[1], ev_head[0], ev_head[1]})
+            if (e) w->event_destroy(e);
+    }
+    GAT(const GAT&) = delete;
+    GAT& operator=(const GAT&) = delete;
+
     // Computes the j'th self-attention head of the i'th layer (gat.hpp:83-104)
     void computeSelfAttentionHead(int i, int j) {
+        DenseMatrix A;
+        head_product(i, j, A, HNH_STREAM_COMPUTE);
+        head_attention(i, j, A);
+    }
+
+    // The reference runs the heads one after the other (gat.hpp:106-112).  Here a layer is a two-stage pipeline: the product
+    // X * W of head j + 1 (MFMA bound, HNH_STREAM_AUX) runs beside the attention pass of head j (HBM bound, the compute stream),
+    // between two product buffers; the layers' outputs are the reference's, bit for bit (same kernels, same operands).
+    // HNH_GAT_SERIAL=1: the reference's order on one stream (A/B measurements).
+    void forwardPass() {
+        if (std::getenv("HNH_GAT_SERIAL") != nullptr) {
+            for (size_t i = 0; i < layers.size(); i++)
+                for (int j = 0; j < layers[i].num_heads; j++) computeSelfAttentionHead((int)i, j);
+            return;
+        }
         hnh::World* w = d_ops->world;
-        d_ops->setRValue(layers[i].features_per_head);
+        if (!ev_input)
+            for (void** e : {&ev_input, &ev_gemm[0], &ev_gemm[1], &ev_head[0], &ev_head[1]}) *e = w->event_create();
+        for (size_t i = 0; i < layers.size(); i++) {
+            const int H = layers[i].num_heads;
+            // (allocated before the mark below: the allocator orders a recycled block behind its last use on the compute and
+            // communication streams, and the auxiliary stream inherits that through the mark)
+            for (int b = 0; b < (H > 1 ? 2 : 1); b++) shape_product((int)i, product[b]);
+            // the layer's input is complete, and both product buffers are free, once the compute stream gets here
+            w->event_record(ev_input, HNH_STREAM_COMPUTE);
+            w->event_wait(ev_input, HNH_STREAM_AUX);
+            head_product((int)i, 0, product[0], HNH_STREAM_AUX);
+            w->event_record(ev_gemm[0], HNH_STREAM_AUX);
+            for (int j = 0; j < H; j++) {
+                w->event_wait(ev_gemm[j % 2], HNH_STREAM_COMPUTE);
+                if (j + 1 < H) {
+                    // product[(j + 1) % 2] was last read by head j - 1, which the compute stream has been given already
+                    if (j >= 1) w->event_wait(ev_head[(j - 1) % 2], HNH_STREAM_AUX);
+                    head_product((int)i, j + 1, product[(j + 1) % 2], HNH_STREAM_AUX);
+                    w->event_record(ev_gemm[(j + 1) % 2], HNH_STREAM_AUX);
+                }
+                head_attention((int)i, j, product[j % 2]);
+                w->event_record(ev_head[j % 2], HNH_STREAM_COMPUTE);
+            }
+        }
+        // every product was awaited by the compute stream: nothing is left on the auxiliary stream
+    }
+
+private:
+    DenseMatrix product[2];  // X * W_j of the head in flight and of the next one
+    void* ev_input = nullptr;
+    void* ev_gemm[2] = {nullptr, nullptr};
+    void* ev_head[2] = {nullptr, nullptr};
+
+    void shape_product(int i, DenseMatrix& A) {
+        const int64_t rows = buffers[i].rows(), cols = layers[i].wMats[0].cols();
+        if (A.rows() != rows || A.cols() != cols) A = DenseMatrix(rows, cols);
+    }
+
+    // A = buffers[i] * W_j (gat.hpp:88) on `stream`
+    void head_product(int i, int j, DenseMatrix& A, int stream) {
+        hnh::World* w = d_ops->world;
         DenseMatrix& X = buffers[i];
         DenseMatrix& W = layers[i].wMats[j];
         if (X.cols() != W.rows()) hnh::fatal("Error, GAT weight shape does not match the layer input!");
-        DenseMatrix A(X.rows(), W.cols());
-        w->check(w->be->hnh_gemm_f64(w->ctx, X.rows(), W.cols(), X.cols(), X.data(), W.data(), A.data(), HNH_STREAM_COMPUTE), "hnh_gemm_f64");
+        shape_product(i, A);
+        w->check(w->be->hnh_gemm_f64(w->ctx, X.rows(), W.cols(), X.cols(), X.data(), W.data(), A.data(), stream), "hnh_gemm_f64");
+    }
+
+    // the rest of the head (gat.hpp:89-101) from its product A, on the compute stream; A is consumed (the unfused route zeroes it)
+    void head_attention(int i, int j, DenseMatrix& A) {
+        hnh::World* w = d_ops->world;
+        d_ops->setRValue(layers[i].features_per_head);
         DenseMatrix& out = buffers[i + 1];
 
         // Schedules with a single fused pass (1.5D dense shift, local kernel fusion, c = 1: its shifts are empty and
@@ -80,10 +152,5 @@ public:
         w->check(w->be->hnh_relu_store_cols_f64(w->ctx, out.data(), out.cols(), (int64_t)j * A.cols(), A.data(), A.rows(), A.cols(),
                                                 HNH_STREAM_COMPUTE),
                  "hnh_relu_store_cols_f64");
-    }
-
-    void forwardPass() {
-        for (size_t i = 0; i < layers.size(); i++)
-            for (int j = 0; j < layers[i].num_heads; j++) computeSelfAttentionHead((int)i, j);
     }
 };

@@ -208,11 +208,12 @@ void World::sync(int stream) { check(be->hnh_stream_sync(ctx, stream), "hnh_stre
 void World::sync_all() {
     sync(HNH_STREAM_COMPUTE);
     sync(HNH_STREAM_COMM);
+    sync(HNH_STREAM_AUX);
 }
 // Teardown variant for destructors (implicitly noexcept): a device error at this point is reported, never thrown.
 void World::sync_all_nothrow() noexcept {
     if (!ctx) return;
-    for (int st : {HNH_STREAM_COMPUTE, HNH_STREAM_COMM}) {
+    for (int st : {HNH_STREAM_COMPUTE, HNH_STREAM_COMM, HNH_STREAM_AUX}) {
         const int rc = be->hnh_stream_sync(ctx, st);
         if (rc != HNH_OK) std::cerr << "hnh: device error during teardown (stream " << st << ", status " << rc << "): " << be->hnh_last_error(ctx) << std::endl;
     }

@@ -16,7 +16,10 @@
  *   - SDDMM ACCUMULATES into `values` (sparse_kernels.cpp:54) and SpMM uses alpha = 1, beta = 1
  *     (sparse_kernels.cpp:97,104): callers zero the destination first, exactly as in the reference.
  *
- * `stream` arguments select one of the context's HIP streams: HNH_STREAM_COMPUTE or HNH_STREAM_COMM.
+ * `stream` arguments select one of the context's HIP streams: HNH_STREAM_COMPUTE, HNH_STREAM_COMM or
+ * HNH_STREAM_AUX (a second compute stream for work that may run BESIDE the compute stream's: the GAT
+ * forward pass puts the next head's MFMA-bound GEMM there while the HBM-bound fused pass of the current
+ * head runs; ordered against the others with events like any stream).
  * All kernels and copies are asynchronous with respect to the host.
  */
 #ifndef HNH_KERNELS_H
@@ -37,6 +40,8 @@ extern "C" {
 
 #define HNH_STREAM_COMPUTE 0
 #define HNH_STREAM_COMM 1
+#define HNH_STREAM_AUX 2
+#define HNH_STREAMS 3
 
 #define HNH_COPY_H2D 0
 #define HNH_COPY_D2H 1

@@ -44,3 +44,25 @@ def test_gat_reproduces_the_reference_even_where_it_is_wrong():
     per_rank = H.run_spmd(4, lambda w: T.run_gat(w, "15d_fusion2", 2, case))
     out = T.assemble_dense(per_rank, "gat", "subA", case["M"], T.GAT_LAYERS[-1][1] * T.GAT_LAYERS[-1][2])
     assert T.rel(out, gold()["quirk_fusion2_p4_c2"]) <= T.TOL
+
+
+def test_pipelined_forward_is_the_serial_forward(monkeypatch):
+    """forwardPass pipelines the heads of a layer over two product buffers (product of head j + 1 on the auxiliary stream);
+    HNH_GAT_SERIAL=1 is the reference's head-after-head order (gat.hpp:106-112).  Same result bit for bit, with layers of
+    different widths (the product buffers are re-shaped between layers) and a one-head layer."""
+    m, layers = 1 << 9, [(16, 8, 3), (24, 4, 1), (4, 6, 2)]
+    rows, cols = H.generate_er(m, m, m * 6, 3)
+    x = O.dense_fill(m, 16, 2) * 4.0
+    case = dict(name="gatpipe", M=m, N=m, R=16, rows=rows, cols=cols, vals=np.ones(len(rows)), A=x / T.GAT_INPUT_SCALE, B=x / T.GAT_INPUT_SCALE)
+
+    def forward(p, c, alg):
+        per_rank = H.run_spmd(p, lambda w: T.run_gat(w, alg, c, case, layers=layers))
+        return T.assemble_dense(per_rank, "gat", "subA", m, layers[-1][1] * layers[-1][2])
+
+    for alg, p, c in [("15d_fusion2", 1, 1), ("15d_fusion1", 2, 2)]:
+        monkeypatch.setenv("HNH_GAT_SERIAL", "1")
+        serial = forward(p, c, alg)
+        monkeypatch.delenv("HNH_GAT_SERIAL")
+        assert np.count_nonzero(serial) > serial.size // 10
+        assert np.array_equal(forward(p, c, alg), serial)
+        assert T.rel(serial, O.gat_forward(rows, cols, m, x, layers, T.GAT_ALPHA)) <= T.TOL

@@ -236,6 +236,30 @@ def test_gat_forward_at_benchmark_widths_against_the_compiled_reference(alg, p, 
         assert T.rel(out, ref) <= T.TOL
 
 
+@pytest.mark.parametrize("alg,p,c", [("15d_fusion2", 1, 1), ("15d_fusion2", 2, 1), ("15d_fusion1", 2, 2)])
+def test_gat_pipelined_forward_is_the_serial_forward(alg, p, c, monkeypatch):
+    """forwardPass runs the product X * W of head j + 1 on HNH_STREAM_AUX beside the attention pass of head j (two product
+    buffers, events): the same kernels on the same operands as the reference's head-after-head order (gat.hpp:106-112,
+    HNH_GAT_SERIAL=1), so the layer outputs must agree BIT FOR BIT, run after run (a missing event shows up as a difference).
+    Three layers of different widths, so the product buffers are re-shaped between layers."""
+    from oracle import oracle as O
+    m, layers, alpha = 1 << 14, [(128, 128, 3), (384, 64, 4), (256, 32, 2)], 0.2
+    rows, cols = H.generate_er(m, m, m * 24, 5)
+    x = O.dense_fill(m, 128, 9) * 4.0
+    case = dict(name="gatpipe", M=m, N=m, R=128, rows=rows, cols=cols, vals=np.ones(len(rows)), A=x / T.GAT_INPUT_SCALE, B=x / T.GAT_INPUT_SCALE)
+
+    def forward():
+        per_rank = H.run_spmd(p, lambda w: T.run_gat(w, alg, c, case, layers=layers, alpha=alpha))
+        return T.assemble_dense(per_rank, "gat", "subA", m, layers[-1][1] * layers[-1][2])
+
+    monkeypatch.setenv("HNH_GAT_SERIAL", "1")
+    serial = forward()
+    monkeypatch.delenv("HNH_GAT_SERIAL")
+    assert np.count_nonzero(serial) > serial.size // 10
+    for _ in range(3):
+        assert np.array_equal(forward(), serial)
+
+
 def test_operands_in_torch_memory():
     """hnh_dense_wrap: operands that live in PyTorch-owned HBM (non-owning views).  The fused schedule hands its
     result back by copying into the caller's tensor instead of swapping storage (common.h:88-92 semantics)."""

@@ -32,6 +32,7 @@ for alg in algs:
     heads_total = sum(l[2] for l in layers)
     print("GAT forward [%s] (2^%d vertices, %d nnz, %d heads): %.1f ms, %.2f ms per head" % (alg, logm, nnz, heads_total, dt * 1e3, dt * 1e3 / heads_total))
     gnn.free(); x.free(); op.free()
+if os.environ.get("HNH_PROFILE_NO_GEMM"): sys.exit(0)
 # GEMM alone: M x 1024 times 1024 x 256
 ctx = K.Ctx(0); lib = ctx.lib
 M, Kd, N = 1 << logm, 1024, 256
