@@ -57,10 +57,18 @@ def test_schedules_over_rccl(nranks, configs):
         assert "RCCL_OK" in outs[0], outs[0][-3000:]
 
 
-@pytest.mark.parametrize("nranks,configs,pull,flags", [(2, ALL_2, "engine", "memop"), (2, ALL_2, "kernel", "kernel"), (4, ALL_4, "engine", "memop"),
-                                                         (4, ALL_4, "kernel", "memop"), (8, ALL_8, "engine", "memop"), (8, ALL_8, "kernel", "memop")],
+# Copy-engine pulls between 8 (4) processes that share ONE GPU cost ~100 ms per cross-process dependency (the hardware scheduler
+# time-slices the processes): that variant runs one configuration per schedule family on one case at 8 ranks, every configuration on
+# one case at 4; the pull-kernel variant and the 2-rank runs cover every configuration on both cases.
+ENGINE_8 = "15d_fusion2:1:mesh:4;15d_fusion2:2:mesh:4;15d_fusion1:1:mesh:4;15d_sparse:2:mesh:4;25d_dense_replicate:2:mesh:4;25d_sparse_replicate:2:mesh:4"
+
+
+@pytest.mark.parametrize("nranks,configs,pull,flags,cases",
+                         [(2, ALL_2, "engine", "memop", ("er8_r16", "ragged_r8")), (2, ALL_2, "kernel", "kernel", ("er8_r16", "ragged_r8")),
+                          (4, ALL_4, "engine", "memop", ("er8_r16",)), (4, ALL_4, "kernel", "memop", ("er8_r16", "ragged_r8")),
+                          (8, ENGINE_8, "engine", "memop", ("ragged_r8",)), (8, ALL_8, "kernel", "memop", ("er8_r16", "ragged_r8"))],
                          ids=["2-engine-memop", "2-kernel-flagkernels", "4-engine-memop", "4-kernel-memop", "8-engine-memop", "8-kernel-memop"])
-def test_schedules_over_ipc(nranks, configs, pull, flags):
+def test_schedules_over_ipc(nranks, configs, pull, flags, cases):
     """The ipc-pull transport ACROSS PROCESSES on whatever GPUs are here (one is enough: the processes share it): all five
     schedules (relay ring, chunked mesh fetch, replication collectives as explicit-peer groups, ALS with the held operand) on
     the HIP kernels, every transfer a device-to-device copy out of the peer's mapped buffer ordered by stream flag words —
@@ -69,7 +77,7 @@ def test_schedules_over_ipc(nranks, configs, pull, flags):
     if gpus() < 1:
         pytest.skip("needs a GPU")
     from test_ipc_world_cpu import launch_ipc
-    for case in ("er8_r16", "ragged_r8"):
+    for case in cases:
         procs, outs = launch_ipc(nranks, case, configs, backend="hip", timeout=900, extra_env={"HNH_IPC_PULL": pull, "HNH_IPC_FLAGS": flags})
         assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
         assert "IPC_OK" in outs[0], outs[0][-3000:]
