@@ -157,7 +157,7 @@ def test_cpp_dropin_driver(tmp_path):
     import os
     import subprocess
     # the class layouts live in the headers: make sure the drivers match the library they are about to load
-    subprocess.run(["make", "-C", os.path.join(T.ROOT, "examples"), "bench_er", "bench_file"], check=True, capture_output=True, timeout=600)
+    subprocess.run(["make", "-C", os.path.join(T.ROOT, "examples"), "bench_er", "bench_file", "bench_heatmap"], check=True, capture_output=True, timeout=600)
     exe = os.path.join(T.ROOT, "examples", "bench_er")
     assert os.path.exists(exe), "run __graft_entry__.build()"
     out = tmp_path / "results.json"
@@ -186,6 +186,15 @@ def test_cpp_dropin_driver(tmp_path):
     recs2 = json.loads("[" + out2.read_text().rstrip().rstrip(",") + "]")
     assert [r["alg_name"] for r in recs2] == ["15d_sparse", "25d_dense_replicate", "15d_fusion2"]
     assert all(r["alg_info"]["nnz"] == len(mrows) and r["alg_info"]["m"] == 500 and not r["fused"] for r in recs2)
+    # bench_heatmap.cpp's driver: the width sweep of one family on one matrix (a short width list here)
+    out3 = tmp_path / "heatmap.json"
+    for family, algs in (("15d", ["15d_fusion1", "15d_fusion2", "15d_sparse"]), ("25d", ["25d_sparse_replicate", "25d_dense_replicate"])):
+        r = subprocess.run([os.path.join(T.ROOT, "examples", "bench_heatmap"), "11", "8", family, "1", str(out3), "64,192"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    recs3 = json.loads("[" + out3.read_text().rstrip().rstrip(",") + "]")
+    assert [(r["alg_name"], r["alg_info"]["r"]) for r in recs3] == [(a, w) for fam in (["15d_fusion1", "15d_fusion2", "15d_sparse"], ["25d_sparse_replicate", "25d_dense_replicate"])
+                                                                   for w in (64, 192) for a in fam]
+    assert all(r["fused"] == (r["alg_name"] != "25d_sparse_replicate") for r in recs3)
     # the GAT application of benchmark_dist.cpp:88-94,133-135 (3 layers, 14 heads, 256 features per head)
     for alg in ("15d_fusion2", "15d_fusion1"):
         r = subprocess.run([exe, "10", "8", alg, "256", "1", str(out), "fused", "gat"], capture_output=True, text=True, timeout=300)

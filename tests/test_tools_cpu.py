@@ -36,3 +36,47 @@ def test_overlap_probe_runs_on_the_test_double():
 def test_accumulator_overlap_probe_runs_on_the_test_double():
     out = run_tool("overlap_probe_accumulator.py", "--gbps", "0,60")
     assert "15d_fusion1 spmmA" in out and "loopback copies only" in out and out.count(" ms") >= 4
+
+
+def test_cpp_drivers_run_on_the_test_double(tmp_path):
+    """examples/bench_er, bench_file, bench_heatmap (the reference's three `main()`s, bench_erdos_renyi.cpp / bench_file.cpp /
+    bench_heatmap.cpp, against this repository's class headers) compile and run end to end on CPU: the drivers load the kernel
+    library that sits next to libhnh_host.so, so a directory holding a copy of the host library and the C test double under the
+    kernel library's name stands in for a GPU box.  (Their GPU twin is tests/test_schedules_gpu.py::test_cpp_dropin_driver.)"""
+    import json
+    import shutil
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples"), "bench_er", "bench_file", "bench_heatmap"], check=True, capture_output=True, timeout=600)
+    libdir = tmp_path / "lib"
+    libdir.mkdir()
+    shutil.copy(os.path.join(ROOT, "distributed_sddmm_amd", "lib", "libhnh_host.so"), libdir / "libhnh_host.so")
+    shutil.copy(T.ORACLE_BACKEND, libdir / "libhnh_kernels.so")
+    env = dict(os.environ, LD_LIBRARY_PATH=str(libdir), OMP_NUM_THREADS="2", HNH_HOST_SETUP="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+
+    def run(exe, *args):
+        r = subprocess.run([os.path.join(ROOT, "examples", exe), *args], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        return r.stdout
+
+    def records(path):
+        return json.loads("[" + path.read_text().rstrip().rstrip(",") + "]")
+
+    out = tmp_path / "er.json"
+    run("bench_er", "9", "8", "15d", "16", "1", str(out), "fused")
+    run("bench_er", "9", "8", "15d_sparse", "16", "1", str(out), "unfused")
+    run("bench_er", "8", "8", "15d_fusion2", "16", "1", str(out), "fused", "als")
+    recs = records(out)
+    assert [(r["alg_name"], r["fused"]) for r in recs] == [("15d_fusion1", True), ("15d_fusion2", True), ("15d_sparse", False), ("15d_fusion2", True)]
+    assert all(r["alg_info"]["backend"] == "oracle-cpu-test-double" and r["num_trials"] == 5 and "Computation Time" in r["perf_stats"] for r in recs)
+    heat = tmp_path / "heat.json"
+    run("bench_heatmap", "9", "8", "15d", "1", str(heat), "16,24")
+    run("bench_heatmap", "9", "8", "25d", "1", str(heat), "16")
+    assert [(r["alg_name"], r["alg_info"]["r"], r["fused"]) for r in records(heat)] == [
+        ("15d_fusion1", 16, True), ("15d_fusion2", 16, True), ("15d_sparse", 16, True), ("15d_fusion1", 24, True), ("15d_fusion2", 24, True),
+        ("15d_sparse", 24, True), ("25d_sparse_replicate", 16, False), ("25d_dense_replicate", 16, True)]
+    mtx = str(tmp_path / "g.mtx")
+    mrows, _, _ = T.write_symmetric_mtx_with_duplicates(mtx, 300, 3)
+    fout = tmp_path / "file.json"
+    assert "File reader read %d nonzeros." % len(mrows) in run("bench_file", mtx, "15d_fusion2", "16", "1", str(fout), "vanilla")
+    assert records(fout)[0]["alg_info"]["nnz"] == len(mrows)
