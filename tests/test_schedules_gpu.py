@@ -195,6 +195,16 @@ def test_cpp_dropin_driver(tmp_path):
     assert [(r["alg_name"], r["alg_info"]["r"]) for r in recs3] == [(a, w) for fam in (["15d_fusion1", "15d_fusion2", "15d_sparse"], ["25d_sparse_replicate", "25d_dense_replicate"])
                                                                    for w in (64, 192) for a in fam]
     assert all(r["fused"] == (r["alg_name"] != "25d_sparse_replicate") for r in recs3)
+    # examples/verify = scratch.cpp:26-76 verify_operation: the fingerprint trio of every algorithm on the file's matrix, against the
+    # oracle's numbers (the compiled reference prints the same ones, tests/test_tools_cpu.py)
+    from oracle import oracle as O
+    subprocess.run(["make", "-C", os.path.join(T.ROOT, "examples"), "verify"], check=True, capture_output=True, timeout=600)
+    r = subprocess.run([os.path.join(T.ROOT, "examples", "verify"), mtx, "all", "32", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    got = np.array([float(ln.split(":")[1]) for ln in r.stdout.splitlines() if "Fingerprint:" in ln]).reshape(5, 3)
+    mr, mc, _ = T.write_symmetric_mtx_with_duplicates(str(tmp_path / "again.mtx"), 500, 3)
+    want = np.array(O.fingerprints(mr, mc, 500, 500, 32))
+    assert np.max(np.abs(got - want) / want) <= 1e-11
     # the GAT application of benchmark_dist.cpp:88-94,133-135 (3 layers, 14 heads, 256 features per head)
     for alg in ("15d_fusion2", "15d_fusion1"):
         r = subprocess.run([exe, "10", "8", alg, "256", "1", str(out), "fused", "gat"], capture_output=True, text=True, timeout=300)

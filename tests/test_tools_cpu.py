@@ -45,7 +45,7 @@ def test_cpp_drivers_run_on_the_test_double(tmp_path):
     kernel library's name stands in for a GPU box.  (Their GPU twin is tests/test_schedules_gpu.py::test_cpp_dropin_driver.)"""
     import json
     import shutil
-    subprocess.run(["make", "-C", os.path.join(ROOT, "examples"), "bench_er", "bench_file", "bench_heatmap"], check=True, capture_output=True, timeout=600)
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples"), "bench_er", "bench_file", "bench_heatmap", "verify"], check=True, capture_output=True, timeout=600)
     libdir = tmp_path / "lib"
     libdir.mkdir()
     shutil.copy(os.path.join(ROOT, "distributed_sddmm_amd", "lib", "libhnh_host.so"), libdir / "libhnh_host.so")
@@ -80,3 +80,17 @@ def test_cpp_drivers_run_on_the_test_double(tmp_path):
     fout = tmp_path / "file.json"
     assert "File reader read %d nonzeros." % len(mrows) in run("bench_file", mtx, "15d_fusion2", "16", "1", str(fout), "vanilla")
     assert records(fout)[0]["alg_info"]["nnz"] == len(mrows)
+    # examples/verify = the reference's own check (scratch.cpp:26-76 verify_operation): three fingerprints that must not depend on
+    # the algorithm, and must be the numbers the reference prints for the same matrix
+    import numpy as np
+    from oracle import oracle as O
+    from oracle import refrun as RR
+    mrows, mcols, _ = T.write_symmetric_mtx_with_duplicates(mtx, 300, 3)
+    want = np.array(O.fingerprints(mrows, mcols, 300, 300, 16))
+    text = run("verify", mtx, "all", "16", "1")
+    got = np.array([float(ln.split(":")[1]) for ln in text.splitlines() if "Fingerprint:" in ln]).reshape(5, 3)
+    assert sorted(ln.split()[1] for ln in text.splitlines() if ln.startswith("==")) == sorted(T.H.ALGORITHMS)
+    assert np.max(np.abs(got - want) / want) <= 1e-11
+    if RR.available():
+        ref = RR.fingerprints(300, 300, mrows, mcols, 16, "15d_sparse", 1, 1)
+        assert np.max(np.abs(got - np.array([ref["sddmm"], ref["spmmA"], ref["spmmB"]])) / want) <= 1e-11
