@@ -2,9 +2,12 @@
 // benchmark_algorithm() (benchmark_dist.cpp:26-167) re-written against THIS repository's class headers.
 //
 // One process per GPU.  Without a launcher a driver runs on GPU 0 (p = 1).  Multi-GPU: start N processes with
-// RANK / WORLD_SIZE / LOCAL_RANK set (torchrun, mpiexec -env, a shell loop) and HNH_ID_FILE naming a path on a
-// shared filesystem; rank 0 writes the RCCL unique id there, the others read it.  (The reference uses MPI_Init;
-// MPI is not needed here.)
+// RANK / WORLD_SIZE / LOCAL_RANK set (torchrun, mpiexec -env, a shell loop) and either
+//   HNH_ID_FILE=<path on a shared filesystem>          RCCL: rank 0 writes the unique id there, the others read it, or
+//   HNH_TRANSPORT=ipc HNH_IPC_SESSION=<name>           the ipc-pull transport of one node (receivers copy out of their peers'
+//                                                      mapped buffers; the ranks meet in a shared-memory session of that name);
+//                                                      HNH_DEVICE=<ordinal> overrides LOCAL_RANK as the device (processes may share one).
+// (The reference uses MPI_Init; MPI is not needed here.)
 #pragma once
 #include <chrono>
 #include <cstdio>
@@ -33,7 +36,14 @@ inline hnh::World* make_world() {
     // that the compute and the communication stream never have to share one with each other or with RCCL's
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
     hnh::Backend* be = hnh::load_backend(nullptr);  // the HIP library next to libhnh_host.so; exits if missing
-    if (n == 1) return new hnh::SingleWorld(be, local);
+    if (n == 1) return new hnh::SingleWorld(be, env_int("HNH_DEVICE", local));
+    const char* transport = getenv("HNH_TRANSPORT");
+    if (transport && string(transport) == "ipc") {
+        const char* session = getenv("HNH_IPC_SESSION");
+        if (!session || !*session) hnh::fatal("Error, HNH_TRANSPORT=ipc needs HNH_IPC_SESSION (a name shared by all ranks of the run)");
+        return new hnh::IpcWorld(rank, n, be, env_int("HNH_DEVICE", local), session);
+    }
+    if (transport && string(transport) != "rccl") hnh::fatal(string("Error, unknown HNH_TRANSPORT ") + transport + " (rccl or ipc)");
     const char* idfile = getenv("HNH_ID_FILE");
     if (!idfile) hnh::fatal("Error, WORLD_SIZE > 1 needs HNH_ID_FILE (path used to hand the RCCL unique id to all ranks)");
     char id[HNH_UNIQUE_ID_BYTES];
@@ -50,7 +60,7 @@ inline hnh::World* make_world() {
             this_thread::sleep_for(chrono::milliseconds(10));
         }
     }
-    return new hnh::RcclWorld(rank, n, be, local, id);
+    return new hnh::RcclWorld(rank, n, be, env_int("HNH_DEVICE", local), id);
 }
 
 // benchmark_dist.cpp:26-167

@@ -173,3 +173,38 @@ def test_bench_rccl_only_on_one_gpu_ends_with_an_error_line():
     assert out["value"] is None and "error" in out and out["n_gpus"] == 2
     assert any("transport" in ph for ph in out["phases"].values()), out
     assert "no usable device-to-device transport" in res.stderr
+
+
+def test_cpp_verify_across_processes_share_one_gpu(tmp_path):
+    """examples/verify (the reference's scratch.cpp check against the class headers) as 2 and 4 PROCESSES over the ipc-pull transport
+    on the HIP library, all on device 0 (HNH_TRANSPORT=ipc: the C++ drivers' way of running several ranks without RCCL): same
+    fingerprints as the oracle's for every schedule family."""
+    import time
+    import numpy as np
+    import hnh_testlib as T
+    from oracle import oracle as O
+    if gpus() < 1:
+        pytest.skip("needs a GPU")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples"), "verify"], check=True, capture_output=True, timeout=600)
+    mtx = str(tmp_path / "g.mtx")
+    mrows, mcols, _ = T.write_symmetric_mtx_with_duplicates(mtx, 512, 4)
+    want = np.array(O.fingerprints(mrows, mcols, 512, 512, 32))
+    for n, c, alg in ((2, 1, "15d_fusion2"), (4, 2, "15d_sparse"), (4, 1, "25d_dense_replicate")):
+        session = "g%d_%x" % (os.getpid(), time.time_ns())
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(n), LOCAL_RANK=str(r), HNH_DEVICE="0", HNH_TRANSPORT="ipc", HNH_IPC_SESSION=session,
+                       HNH_IPC_WAIT_S="120", HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="16", OMP_NUM_THREADS="4")
+            procs.append(subprocess.Popen([os.path.join(ROOT, "examples", "verify"), mtx, alg, "32", str(c)], env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.STDOUT, text=True))
+        outs = []
+        try:
+            for p in procs:
+                outs.append(p.communicate(timeout=300)[0])
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        assert all(p.returncode == 0 for p in procs), "\n".join(o[-1000:] for o in outs)
+        got = np.array([float(ln.split(":")[1]) for ln in outs[0].splitlines() if "Fingerprint:" in ln])
+        assert got.shape == (3,) and np.max(np.abs(got - want) / want) <= 1e-11, (alg, n, c, got, want)

@@ -94,3 +94,44 @@ def test_cpp_drivers_run_on_the_test_double(tmp_path):
     if RR.available():
         ref = RR.fingerprints(300, 300, mrows, mcols, 16, "15d_sparse", 1, 1)
         assert np.max(np.abs(got - np.array([ref["sddmm"], ref["spmmA"], ref["spmmB"]])) / want) <= 1e-11
+
+
+def test_cpp_verify_across_processes_over_ipc(tmp_path):
+    """examples/verify as 2 and 4 PROCESSES over the ipc-pull transport (HNH_TRANSPORT=ipc, the C++ drivers' second way of meeting
+    besides RCCL), on the test double: the fingerprints of every algorithm that fits the grid equal the one-process numbers."""
+    import shutil
+    import time
+    import numpy as np
+    from oracle import oracle as O
+    from test_ipc_world_cpu import can_read_peer_memory
+    if not can_read_peer_memory():
+        import pytest
+        pytest.skip("process_vm_readv between own processes is not permitted here")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples"), "verify"], check=True, capture_output=True, timeout=600)
+    libdir = tmp_path / "lib"
+    libdir.mkdir()
+    shutil.copy(os.path.join(ROOT, "distributed_sddmm_amd", "lib", "libhnh_host.so"), libdir / "libhnh_host.so")
+    shutil.copy(T.ORACLE_BACKEND, libdir / "libhnh_kernels.so")
+    mtx = str(tmp_path / "g.mtx")
+    mrows, mcols, _ = T.write_symmetric_mtx_with_duplicates(mtx, 256, 4)
+    want = np.array(O.fingerprints(mrows, mcols, 256, 256, 16))
+    for n, c, algs in ((2, 1, ["15d_fusion2", "15d_sparse"]), (4, 2, ["15d_fusion1", "15d_fusion2", "15d_sparse"]), (4, 1, ["25d_dense_replicate", "25d_sparse_replicate"])):
+        for alg in algs:
+            session = "v%d_%x" % (os.getpid(), time.time_ns())
+            procs = []
+            for r in range(n):
+                env = dict(os.environ, LD_LIBRARY_PATH=str(libdir), OMP_NUM_THREADS="2", HNH_HOST_SETUP="1", RANK=str(r), WORLD_SIZE=str(n),
+                           LOCAL_RANK=str(r), HNH_DEVICE="0", HNH_TRANSPORT="ipc", HNH_IPC_SESSION=session, HNH_IPC_WAIT_S="120")
+                procs.append(subprocess.Popen([os.path.join(ROOT, "examples", "verify"), mtx, alg, "16", str(c)], env=env, stdout=subprocess.PIPE,
+                                              stderr=subprocess.STDOUT, text=True))
+            outs = []
+            try:
+                for p in procs:
+                    outs.append(p.communicate(timeout=300)[0])
+            finally:
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+            assert all(p.returncode == 0 for p in procs), "\n".join(o[-1000:] for o in outs)
+            got = np.array([float(ln.split(":")[1]) for ln in outs[0].splitlines() if "Fingerprint:" in ln])
+            assert got.shape == (3,) and np.max(np.abs(got - want) / want) <= 1e-11, (alg, n, c, got, want)
