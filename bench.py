@@ -1279,7 +1279,7 @@ def secondary(args, b):
                     what = "24 fused calls (2 half-steps x (2 + 10 CG iterations)) with the CG updates in the row epilogue"
                 else:
                     by = sum(h * fused_bytes(sub.nnz, f, sub.m) for _, f, h in GAT_LAYERS)
-                    what = "14 fused heads (SDDMM -> LeakyReLU -> SpMM -> ReLU delivery) + 14 fp64 MFMA GEMMs"
+                    what = "14 fused heads (SDDMM -> LeakyReLU -> SpMM -> ReLU delivery) + 14 fp64 MFMA GEMMs, the product of head j + 1 on a second compute stream beside the attention pass of head j"
                 return {"ms": ms, "what": what, "nnz": sub.nnz, "M": sub.m, "R": info["R"], "algorithmic_bytes_fused_calls": by,
                         "frac_whole_step": frac_of(by, ms), "check": chk}
             finally:
