@@ -40,6 +40,7 @@ struct hnh_ctx {
     hipStream_t aux[kAuxStreams] = {nullptr};
     hipEvent_t aux_fork = nullptr, aux_join[kAuxStreams] = {nullptr};
     unsigned long long* pace_stamp[HNH_STREAMS] = {nullptr};  // measurement aid (hnh_stream_pace_begin / _end): the clock at the begin mark
+    int gemm_waves = 4;     // HNH_GEMM_WAVES=8: hnh_gemm_f64 with 256 x 128 tiles of 8 waves instead of 128 x 128 tiles of 4
     int flag_kernels = -1;  // HNH_IPC_FLAGS=kernel: flag words are written / awaited by one-lane kernels instead of stream memory operations
 };
 

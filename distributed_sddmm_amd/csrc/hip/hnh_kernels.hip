@@ -1342,10 +1342,17 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 16, kGemmLd = 128 + 4;
 constexpr int kXcds = 8;
 
-__global__ __launch_bounds__(kBlock) void gemm_f64_kernel(int64_t M, int64_t N, int64_t K, const double* __restrict__ A,
-                                                          const double* __restrict__ B, double* __restrict__ C, int64_t row_blocks,
-                                                          int col_blocks, bool vec_ok) {
-    __shared__ double As[2][kGemmBK][kGemmLd];
+// WM = wave rows of the workgroup: 2 = the 128 x 128 tile of 4 waves described above (two workgroups of it share a CU);
+// 4 = a 256 x 128 tile of 8 waves (HNH_GEMM_WAVES=8): two waves per SIMD come from ONE workgroup, so the kernel keeps its latency
+// hiding when it shares the CUs with another stream's kernel (the GAT pipeline) — and reads each B tile for twice the rows.
+template <int WM>
+__global__ __launch_bounds__(128 * WM) void gemm_f64_kernel(int64_t M, int64_t N, int64_t K, const double* __restrict__ A,
+                                                            const double* __restrict__ B, double* __restrict__ C, int64_t row_blocks,
+                                                            int col_blocks, bool vec_ok) {
+    constexpr int BM = 64 * WM, LDA = BM + 4, T = 128 * WM;
+    constexpr int BPT = kGemmBK * kGemmBN / T;  // doubles of the B tile per thread (8 or 4)
+    constexpr int BLANES = kGemmBN / BPT;       // threads per B tile row
+    __shared__ double As[2][kGemmBK][LDA];
     __shared__ double Bs[2][kGemmBK][kGemmLd];
     // XCD-aware tile assignment
     const int64_t id = blockIdx.x;
@@ -1353,7 +1360,7 @@ __global__ __launch_bounds__(kBlock) void gemm_f64_kernel(int64_t M, int64_t N, 
     const int64_t rb = (slot / col_blocks) * kXcds + xcd;
     const int cb = (int)(slot % col_blocks);
     if (rb >= row_blocks) return;
-    const int64_t row0 = rb * kGemmBM, col0 = (int64_t)cb * kGemmBN;
+    const int64_t row0 = rb * BM, col0 = (int64_t)cb * kGemmBN;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -1363,11 +1370,11 @@ __global__ __launch_bounds__(kBlock) void gemm_f64_kernel(int64_t M, int64_t N, 
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
-    // global -> register staging: A: row am, 8 consecutive k;  B: row bk, 8 consecutive n
-    const int am = tid & 127, ak = (tid >> 7) * 8;
-    const int bk = tid >> 4, bn = (tid & 15) * 8;
-    const bool interior = vec_ok && row0 + kGemmBM <= M && col0 + kGemmBN <= N;
-    double ra[8], rbv[8];
+    // global -> register staging: A: row am, 8 consecutive k;  B: row bk, BPT consecutive n
+    const int am = tid % BM, ak = (tid / BM) * 8;
+    const int bk = tid / BLANES, bn = (tid % BLANES) * BPT;
+    const bool interior = vec_ok && row0 + BM <= M && col0 + kGemmBN <= N;
+    double ra[8], rbv[BPT];
     auto fetch = [&](int64_t k0) {
         if (interior && k0 + kGemmBK <= K) {
             const double* ap = A + (row0 + am) * K + k0 + ak;
@@ -1375,8 +1382,11 @@ __global__ __launch_bounds__(kBlock) void gemm_f64_kernel(int64_t M, int64_t N, 
 #pragma unroll
             for (int q = 0; q < 8; q += 2) {
                 const double2 va = *reinterpret_cast<const double2*>(ap + q);
-                const double2 vb = *reinterpret_cast<const double2*>(bp + q);
                 ra[q] = va.x; ra[q + 1] = va.y;
+            }
+#pragma unroll
+            for (int q = 0; q < BPT; q += 2) {
+                const double2 vb = *reinterpret_cast<const double2*>(bp + q);
                 rbv[q] = vb.x; rbv[q + 1] = vb.y;
             }
         } else {
@@ -1384,6 +1394,9 @@ __global__ __launch_bounds__(kBlock) void gemm_f64_kernel(int64_t M, int64_t N, 
             for (int q = 0; q < 8; q++) {
                 const int64_t gr = row0 + am, gk = k0 + ak + q;
                 ra[q] = (gr < M && gk < K) ? A[gr * K + gk] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < BPT; q++) {
                 const int64_t hk = k0 + bk, hc = col0 + bn + q;
                 rbv[q] = (hk < K && hc < N) ? B[hk * N + hc] : 0.0;
             }
@@ -1393,7 +1406,7 @@ __global__ __launch_bounds__(kBlock) void gemm_f64_kernel(int64_t M, int64_t N, 
 #pragma unroll
         for (int q = 0; q < 8; q++) As[buf][ak + q][am] = ra[q];
 #pragma unroll
-        for (int q = 0; q < 8; q += 2) *reinterpret_cast<double2*>(&Bs[buf][bk][bn + q]) = make_double2(rbv[q], rbv[q + 1]);
+        for (int q = 0; q < BPT; q += 2) *reinterpret_cast<double2*>(&Bs[buf][bk][bn + q]) = make_double2(rbv[q], rbv[q + 1]);
     };
 
     const int64_t ktiles = (K + kGemmBK - 1) / kGemmBK;
@@ -2388,14 +2401,18 @@ int hnh_gemm_f64(hnh_ctx* ctx, int64_t M, int64_t N, int64_t K, const double* A,
     if (M < 0 || N < 0 || K < 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_gemm_f64: negative size");
     if (M == 0 || N == 0) return HNH_OK;
     if (!C || (K > 0 && (!A || !B))) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_gemm_f64: null pointer");
-    const int64_t row_blocks = (M + kGemmBM - 1) / kGemmBM, col_blocks = (N + kGemmBN - 1) / kGemmBN;
+    const bool tall = ctx->gemm_waves == 8;
+    const int64_t bm = tall ? 2 * kGemmBM : kGemmBM;
+    const int64_t row_blocks = (M + bm - 1) / bm, col_blocks = (N + kGemmBN - 1) / kGemmBN;
     const int64_t grid = ((row_blocks + kXcds - 1) / kXcds) * kXcds * col_blocks;  // row blocks padded to whole XCD rounds
     if (grid > 0x7fffffffLL || col_blocks > 0x7fffffffLL) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "hnh_gemm_f64: matrix too large");
     const bool vec_ok = (K % 2 == 0) && (N % 2 == 0) && aligned16(A) && aligned16(B);
     hnh::WideLaunch wide(ctx, stream);  // a dense contraction wants every matrix core
     if (wide.status != HNH_OK) return wide.status;
-    hipLaunchKernelGGL(gemm_f64_kernel, dim3((unsigned)grid), dim3(kBlock), 0, wide.stream(), M, N, K, A, B, C, row_blocks,
-                       (int)col_blocks, vec_ok);
+    if (tall)
+        hipLaunchKernelGGL(gemm_f64_kernel<4>, dim3((unsigned)grid), dim3(512), 0, wide.stream(), M, N, K, A, B, C, row_blocks, (int)col_blocks, vec_ok);
+    else
+        hipLaunchKernelGGL(gemm_f64_kernel<2>, dim3((unsigned)grid), dim3(256), 0, wide.stream(), M, N, K, A, B, C, row_blocks, (int)col_blocks, vec_ok);
     return wide.finish(hnh::check_hip(ctx, hipGetLastError(), "gemm_f64_kernel launch"));
 }
 

@@ -197,6 +197,23 @@ def test_gemm_f64_mfma(ctx, M, N, K):
     assert rel(dC.get(), A @ B) <= 1e-13
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (100, 37, 29), (513, 130, 70), (1000, 256, 256), (5, 3, 1), (2100, 300, 72), (4096, 256, 1024), (257, 129, 17), (256, 128, 64)])
+def test_gemm_f64_mfma_tall_workgroups(M, N, K, monkeypatch):
+    """HNH_GEMM_WAVES=8: the same contraction through 256 x 128 tiles of 8 waves (two waves per SIMD from one workgroup)."""
+    from distributed_sddmm_amd import _kernels as K_
+    monkeypatch.setenv("HNH_GEMM_WAVES", "8")
+    c = K_.Ctx(0)
+    try:
+        rng = np.random.default_rng(M * 11 + N)
+        A, B = rng.uniform(-1, 1, (M, K)), rng.uniform(-1, 1, (K, N))
+        B[0, :] += np.arange(N)
+        dA, dB, dC = c.upload(A), c.upload(B), c.upload(np.full((M, N), 7.0))
+        c.check(c.lib.hnh_gemm_f64(c.h, M, N, K, dA.ptr, dB.ptr, dC.ptr, 0), "gemm")
+        assert rel(dC.get(), A @ B) <= 1e-13
+    finally:
+        c.close()
+
+
 def test_gat_elementwise(ctx):
     lib = ctx.lib
     rng = np.random.default_rng(1)
