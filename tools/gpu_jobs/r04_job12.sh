@@ -12,8 +12,8 @@ run HNH_GEMM_WAVES=8
 run HNH_GEMM_WAVES=8 HNH_GAT_SERIAL=1
 run HNH_GEMM_WAVES=4 HNH_GAT_SERIAL=1
 cat "$OUT/gat_gemm_waves.log"
-( timeout 1100 python -m pytest tests/ -x -q -m gpu --durations=12 > "$OUT/gputests_all.log" 2>&1; echo rc=$? >> "$OUT/gputests_all.log" )
+( timeout 640 python -m pytest tests/ -x -q -m gpu --durations=12 > "$OUT/gputests_all.log" 2>&1; echo rc=$? >> "$OUT/gputests_all.log" )
 tail -n 18 "$OUT/gputests_all.log"
 cd /tmp && export TMPDIR=/tmp
-timeout 400 python "$R/bench.py" > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.stderr"
+timeout 200 python "$R/bench.py" > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.stderr"
 tail -c 600 "$OUT/bench_n1.json"
