@@ -70,10 +70,17 @@ int hnh_comm_sendrecv(hnh_ctx* ctx, void* comm, const void* sendbuf, size_t send
     if (!comm) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_comm_sendrecv: null communicator");
     hipStream_t st = ctx->streams[stream];
     HNH_TRY_NCCL(ctx, ncclGroupStart());
-    if (sendbytes) HNH_TRY_NCCL(ctx, ncclSend(sendbuf, sendbytes, ncclInt8, dst, (ncclComm_t)comm, st));
-    if (recvbytes) HNH_TRY_NCCL(ctx, ncclRecv(recvbuf, recvbytes, ncclInt8, src, (ncclComm_t)comm, st));
-    HNH_TRY_NCCL(ctx, ncclGroupEnd());
-    return HNH_OK;
+    // a call that fails inside the group still closes it: an open group would swallow every later call on this thread
+    ncclResult_t r = ncclSuccess;
+    const char* what = "ncclSend";
+    if (sendbytes) r = ncclSend(sendbuf, sendbytes, ncclInt8, dst, (ncclComm_t)comm, st);
+    if (r == ncclSuccess && recvbytes) {
+        what = "ncclRecv";
+        r = ncclRecv(recvbuf, recvbytes, ncclInt8, src, (ncclComm_t)comm, st);
+    }
+    const ncclResult_t rend = ncclGroupEnd();
+    if (r != ncclSuccess) return check_nccl(ctx, r, what);
+    return check_nccl(ctx, rend, "ncclGroupEnd");
 }
 
 int hnh_comm_group_begin(hnh_ctx* ctx) {

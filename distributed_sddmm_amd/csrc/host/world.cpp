@@ -10,10 +10,13 @@
 #include <atomic>
 #include <condition_variable>
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <deque>
+#include <fstream>
 #include <map>
 #include <mutex>
+#include <thread>
 
 namespace hnh {
 
@@ -407,6 +410,73 @@ void World::host_allreduce_sum(double* v, size_t n) {
         for (int r = 0; r < size; r++) s += all[(size_t)r * n + j];
         v[j] = s;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ bootstrap from the environment
+namespace {
+int env_int(const char* k, int dflt) {
+    const char* v = std::getenv(k);
+    return (v && *v) ? std::atoi(v) : dflt;
+}
+}  // namespace
+
+World* world_from_environment() {
+    const int rank = env_int("RANK", 0), n = env_int("WORLD_SIZE", 1), local = env_int("LOCAL_RANK", rank);
+    if (n < 1 || rank < 0 || rank >= n) fatal("Error, RANK / WORLD_SIZE of this process do not describe a rank of a world");
+    // (before the HIP runtime starts) streams that share a hardware queue serialise: leave room beyond the default 4 queues so
+    // that the compute and the communication stream never have to share one with each other or with RCCL's
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);  // hosts that only support dmabuf IPC (RCCL and mapped peer memory across processes)
+    Backend* be = load_backend(nullptr);  // the kernel library next to this one; exits if missing
+    const int device = env_int("HNH_DEVICE", local);
+    if (n == 1) return new SingleWorld(be, device);
+    const char* transport = std::getenv("HNH_TRANSPORT");
+    if (transport && std::string(transport) == "ipc") {
+        const char* session = std::getenv("HNH_IPC_SESSION");
+        if (!session || !*session) fatal("Error, HNH_TRANSPORT=ipc needs HNH_IPC_SESSION (a name shared by all ranks of the run)");
+        return new IpcWorld(rank, n, be, device, session);
+    }
+    if (transport && *transport && std::string(transport) != "rccl") fatal(std::string("Error, unknown HNH_TRANSPORT ") + transport + " (rccl or ipc)");
+    const char* idfile = std::getenv("HNH_ID_FILE");
+    if (!idfile || !*idfile) fatal("Error, WORLD_SIZE > 1 needs HNH_ID_FILE (path used to hand the RCCL unique id to all ranks) or HNH_TRANSPORT=ipc");
+    char id[HNH_UNIQUE_ID_BYTES];
+    if (rank == 0) {
+        if (be->hnh_comm_unique_id(id) != HNH_OK) fatal("Error, cannot create an RCCL unique id");
+        const std::string tmp = std::string(idfile) + ".tmp";
+        std::ofstream(tmp, std::ios::binary).write(id, sizeof(id));
+        if (std::rename(tmp.c_str(), idfile) != 0) fatal(std::string("Error, cannot write the RCCL unique id file ") + idfile);
+    } else {
+        for (int tries = 0;; tries++) {
+            std::ifstream f(idfile, std::ios::binary);
+            if (f && f.read(id, sizeof(id))) break;
+            if (tries > 6000) fatal("Error, timed out waiting for the RCCL unique id file");
+            std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        }
+    }
+    return new RcclWorld(rank, n, be, device, id);
+}
+
+namespace {
+World* g_process_world = nullptr;
+void destroy_process_world() {
+    World* w = g_process_world;
+    g_process_world = nullptr;
+    if (w == nullptr) return;
+    w->sync_all_nothrow();
+    if (current_world_or_null() == w) set_current_world(nullptr);
+    delete w;
+}
+}  // namespace
+
+World* process_world() {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (g_process_world == nullptr) {
+        g_process_world = world_from_environment();
+        std::atexit(destroy_process_world);  // registered after the kernel library (and with it the HIP runtime) was loaded: runs before their handlers
+    }
+    set_current_world(g_process_world);
+    return g_process_world;
 }
 
 // ------------------------------------------------------------------------------------------------ SingleWorld

@@ -135,6 +135,20 @@ World* current_world();
 World* current_world_or_null();
 void set_current_world(World* w);
 
+// Process bootstrap of a stand-alone driver — what MPI_Init is to the reference's mains (bench_erdos_renyi.cpp:20, bench_file.cpp:20,
+// scratch.cpp:79).  One process per GPU; the launcher (torchrun, mpiexec -env, a shell loop) sets RANK / WORLD_SIZE / LOCAL_RANK:
+//   no WORLD_SIZE, or 1                                  SingleWorld on device HNH_DEVICE (default LOCAL_RANK, default 0)
+//   HNH_ID_FILE=<path every rank can read>               RcclWorld: rank 0 writes the RCCL unique id there, the others read it
+//   HNH_TRANSPORT=ipc HNH_IPC_SESSION=<name>             IpcWorld (ipc-pull): the ranks of one node meet in a shared-memory session of that name;
+//                                                        HNH_DEVICE=<ordinal> overrides LOCAL_RANK as the device (processes may share one)
+// Loads the kernel library that sits next to this one (exits loudly if it or the GPU is missing).  The caller owns the world.
+World* world_from_environment();
+// The same, once per process and owned by the library: created on the first call, made the calling thread's current world, and torn
+// down by an exit handler — after main() has returned, because the reference's mains destroy their SpmatLocal and operators AFTER
+// MPI_Finalize (bench_erdos_renyi.cpp:119-120, scratch.cpp:148) and those objects hand their device memory back through the world.
+// include/compat/mpi.h maps MPI_Init onto this.
+World* process_world();
+
 // ---- p = 1
 class SingleWorld : public World {
 public:

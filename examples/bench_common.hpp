@@ -7,7 +7,8 @@
 //   HNH_TRANSPORT=ipc HNH_IPC_SESSION=<name>           the ipc-pull transport of one node (receivers copy out of their peers'
 //                                                      mapped buffers; the ranks meet in a shared-memory session of that name);
 //                                                      HNH_DEVICE=<ordinal> overrides LOCAL_RANK as the device (processes may share one).
-// (The reference uses MPI_Init; MPI is not needed here.)
+// (hnh::world_from_environment(), world.hpp.  The reference uses MPI_Init; MPI is not needed here — and the reference's own mains
+// compile unchanged against include/compat, whose MPI_Init is this bootstrap: tests/test_reference_mains_cpu.py.)
 #pragma once
 #include <chrono>
 #include <cstdio>
@@ -25,43 +26,8 @@
 using namespace std;
 using json = hnh::json;  // (the reference: `using json = nlohmann::json;`, benchmark_dist.cpp:22)
 
-inline int env_int(const char* k, int dflt) {
-    const char* v = getenv(k);
-    return v ? atoi(v) : dflt;
-}
-
-inline hnh::World* make_world() {
-    const int rank = env_int("RANK", 0), n = env_int("WORLD_SIZE", 1), local = env_int("LOCAL_RANK", rank);
-    // (before the HIP runtime starts) streams that share a hardware queue serialise: leave room beyond the default 4 queues so
-    // that the compute and the communication stream never have to share one with each other or with RCCL's
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
-    hnh::Backend* be = hnh::load_backend(nullptr);  // the HIP library next to libhnh_host.so; exits if missing
-    if (n == 1) return new hnh::SingleWorld(be, env_int("HNH_DEVICE", local));
-    const char* transport = getenv("HNH_TRANSPORT");
-    if (transport && string(transport) == "ipc") {
-        const char* session = getenv("HNH_IPC_SESSION");
-        if (!session || !*session) hnh::fatal("Error, HNH_TRANSPORT=ipc needs HNH_IPC_SESSION (a name shared by all ranks of the run)");
-        return new hnh::IpcWorld(rank, n, be, env_int("HNH_DEVICE", local), session);
-    }
-    if (transport && string(transport) != "rccl") hnh::fatal(string("Error, unknown HNH_TRANSPORT ") + transport + " (rccl or ipc)");
-    const char* idfile = getenv("HNH_ID_FILE");
-    if (!idfile) hnh::fatal("Error, WORLD_SIZE > 1 needs HNH_ID_FILE (path used to hand the RCCL unique id to all ranks)");
-    char id[HNH_UNIQUE_ID_BYTES];
-    if (rank == 0) {
-        if (be->hnh_comm_unique_id(id) != HNH_OK) hnh::fatal("Error, cannot create an RCCL unique id");
-        string tmp = string(idfile) + ".tmp";
-        ofstream(tmp, ios::binary).write(id, sizeof(id));
-        rename(tmp.c_str(), idfile);
-    } else {
-        for (int tries = 0;; tries++) {
-            ifstream f(idfile, ios::binary);
-            if (f && f.read(id, sizeof(id))) break;
-            if (tries > 6000) hnh::fatal("Error, timed out waiting for the RCCL unique id file");
-            this_thread::sleep_for(chrono::milliseconds(10));
-        }
-    }
-    return new hnh::RcclWorld(rank, n, be, env_int("HNH_DEVICE", local), id);
-}
+// the process bootstrap lives in the host library (world.hpp); the reference's own mains reach it through MPI_Init of include/compat/mpi.h
+inline hnh::World* make_world() { return hnh::world_from_environment(); }
 
 // benchmark_dist.cpp:26-167
 inline void benchmark_algorithm(SpmatLocal* spmat, string algorithm_name, string output_file, bool fused, int R, int c, string app) {

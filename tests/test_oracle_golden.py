@@ -88,3 +88,19 @@ def test_c_restatement_matches_reference(name):
     assert T.rel(dst, 2 * g["sddmmA"]) <= T.TOL
     assert lib.hnh_sddmm_csr_ps(ctx, C.byref(blk), p(sv), p(sv), p(a), p(b), r, 0, None, 0) != 0  # scale must not alias the destination
     lib.hnh_ctx_destroy(ctx)
+
+
+def test_closed_form_is_the_reference_at_config2_full_size():
+    """The O(nnz) closed form that checks the full-size GPU runs, against the compiled reference's own fingerprints at BASELINE
+    config 2's FULL size (ER 2^20, 100 658 766 nonzeros, R = 128; tests/golden/fullsize_reference.json, written by
+    tests/golden/make_golden_fullsize.py from oracle/_ref/ref_driver: 195 s on 8 host cores) — about 20 s and 3 GB here."""
+    import json
+    from distributed_sddmm_amd import api as H
+    path = os.path.join(T.GOLDEN, "fullsize_reference.json")
+    rec = json.load(open(path)).get("config2_fingerprints")
+    assert rec is not None, "tests/golden/fullsize_reference.json has no config2_fingerprints (run tests/golden/make_golden_fullsize.py config2)"
+    m = 1 << rec["logm"]
+    rows, cols = H.generate_er(m, m, m * rec["edge_factor"], rec["seed"])
+    assert len(rows) == rec["nnz"] == 100658766
+    closed = np.array(O.fingerprints_closed_form(rows, cols, m, m, rec["R"]))
+    assert T.rel(closed, np.array(rec["values"])) <= T.TOL, (closed, rec["values"])

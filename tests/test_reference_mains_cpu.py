@@ -1,0 +1,137 @@
+"""The reference's own `main()`s, UNCHANGED, against this repository's class headers.
+
+bench_erdos_renyi.cpp, bench_file.cpp, bench_heatmap.cpp (+ benchmark_dist.cpp, the harness they call) and scratch.cpp (the
+reference's only correctness check, `verify_operation`, plus a GAT forward pass) are copied from /root/reference at test time —
+never into the repository — and compiled with nothing but `-I include/compat`: their includes (`benchmark_dist.hpp`,
+`15D_dense_shift.hpp` ... `json.hpp`, and through them `<mpi.h>` and `common.h`), `MPI_Init` / `initialize_mpi_datatypes` /
+`MPI_Allreduce(MPI_IN_PLACE, ...)` / `MPI_Finalize`, `using json = nlohmann::json`, the `NonzeroDistribution` subclass of scratch.cpp
+all resolve.  They then RUN on the kernel test double (a directory holding the host library and the C test double under the kernel
+library's name stands in for a GPU box, as in tests/test_tools_cpu.py): one process, and — the launcher's environment
+(RANK / WORLD_SIZE, HNH_TRANSPORT=ipc) being what MPI's launcher is to the reference — two and four processes over the ipc-pull
+transport.  The fingerprints scratch.cpp prints are the oracle's (= the compiled reference's) for the same file."""
+import json
+import os
+import shutil
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+import hnh_testlib as T
+from test_ipc_world_cpu import can_read_peer_memory
+
+REF = "/root/reference"
+MAINS = ("bench_erdos_renyi", "bench_file", "bench_heatmap", "scratch")
+
+
+@pytest.fixture(scope="module")
+def mains(tmp_path_factory):
+    if not os.path.exists(os.path.join(REF, "scratch.cpp")):
+        pytest.skip("the reference's sources are not on this box")
+    d = tmp_path_factory.mktemp("refmains")
+    for f in ("benchmark_dist.cpp", "benchmark_dist.hpp") + tuple(m + ".cpp" for m in MAINS):
+        shutil.copy(os.path.join(REF, f), d / f)
+    lib = os.path.join(T.ROOT, "distributed_sddmm_amd", "lib")
+    flags = ["g++", "-O1", "-std=c++17", "-fopenmp", "-w", "-I" + os.path.join(T.ROOT, "include", "compat"),
+             "-I" + os.path.join(T.ROOT, "distributed_sddmm_amd", "csrc", "host"), "-I" + os.path.join(T.ROOT, "include")]
+    link = ["-L" + lib, "-lhnh_host", "-ldl", "-lpthread", "-Wl,-rpath," + lib]
+    subprocess.run(flags + ["-c", "benchmark_dist.cpp", "-o", "benchmark_dist.o"], cwd=d, check=True, capture_output=True, timeout=600)
+    procs = [subprocess.Popen(flags + ([] if m == "scratch" else ["benchmark_dist.o"]) + [m + ".cpp", "-o", m] + link, cwd=d,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for m in MAINS]
+    for m, p in zip(MAINS, procs):
+        out = p.communicate(timeout=600)[0]
+        assert p.returncode == 0, "%s.cpp does not compile unchanged against include/compat:\n%s" % (m, out[-3000:])
+    libdir = d / "lib"
+    libdir.mkdir()
+    shutil.copy(os.path.join(lib, "libhnh_host.so"), libdir / "libhnh_host.so")
+    shutil.copy(T.ORACLE_BACKEND, libdir / "libhnh_kernels.so")
+    env = dict(os.environ, LD_LIBRARY_PATH=str(libdir), OMP_NUM_THREADS="2", HNH_HOST_SETUP="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HNH_TRANSPORT", "HNH_ID_FILE"):
+        env.pop(k, None)
+    mtx = str(d / "g.mtx")
+    rows, cols, _ = T.write_symmetric_mtx_with_duplicates(mtx, 256, 4)
+    return dict(dir=d, env=env, mtx=mtx, rows=rows, cols=cols)
+
+
+def records(path):
+    return json.loads("[" + open(path).read().rstrip().rstrip(",") + "]")
+
+
+def run(mains, exe, *args):
+    r = subprocess.run([str(mains["dir"] / exe), *args], env=mains["env"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    return r.stdout
+
+
+def run_ranks(mains, n, exe, *args):
+    """`exe` as n processes over the ipc-pull transport (what `mpiexec -n` is to the reference); returns rank 0's output."""
+    session = "m%d_%x" % (os.getpid(), time.time_ns())
+    procs = []
+    for r in range(n):
+        env = dict(mains["env"], RANK=str(r), WORLD_SIZE=str(n), LOCAL_RANK=str(r), HNH_DEVICE="0", HNH_TRANSPORT="ipc", HNH_IPC_SESSION=session,
+                   HNH_IPC_WAIT_S="120")
+        procs.append(subprocess.Popen([str(mains["dir"] / exe), *args], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=600)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1000:] for o in outs)
+    assert not [f for f in os.listdir("/dev/shm") if session in f], "the exit handler of the process world left its shared-memory session behind"
+    return outs[0]
+
+
+def test_the_three_benchmark_mains_run_unchanged(mains):
+    d = mains["dir"]
+    # bench_erdos_renyi.cpp:19-120: logM edgeFactor 15d|25d R c outfile
+    run(mains, "bench_erdos_renyi", "9", "8", "15d", "16", "1", str(d / "er.json"))
+    run(mains, "bench_erdos_renyi", "8", "8", "25d", "16", "1", str(d / "er.json"))
+    recs = records(d / "er.json")
+    assert [(r["alg_name"], r["fused"]) for r in recs] == [("15d_fusion1", True), ("15d_fusion2", True), ("25d_sparse_replicate", False), ("25d_dense_replicate", True)]
+    for r in recs:
+        assert set(r) == {"elapsed", "overall_throughput", "fused", "num_trials", "alg_name", "alg_info", "application_communication_time", "perf_stats"}
+        assert r["num_trials"] == 5 and r["alg_info"]["backend"] == "oracle-cpu-test-double" and r["alg_info"]["p"] == 1 and "Computation Time" in r["perf_stats"]
+    assert recs[0]["alg_info"]["m"] == 512 and recs[2]["alg_info"]["m"] == 256
+    # bench_file.cpp:19-103: file 15d|25d R c outfile app
+    assert "File reader read %d nonzeros." % len(mains["rows"]) in run(mains, "bench_file", mains["mtx"], "15d", "16", "1", str(d / "file.json"), "vanilla")
+    run(mains, "bench_file", mains["mtx"], "25d", "16", "1", str(d / "file.json"), "als")
+    recs = records(d / "file.json")
+    assert [(r["alg_name"], r["alg_info"]["nnz"]) for r in recs] == [("15d_sparse", len(mains["rows"])), ("25d_dense_replicate", len(mains["rows"]))]
+    # bench_heatmap.cpp:17-109: logM edgeFactor 15d|25d c outfile; R = 64 ... 448
+    run(mains, "bench_heatmap", "7", "4", "15d", "1", str(d / "heat.json"))
+    recs = records(d / "heat.json")
+    assert [(r["alg_name"], r["alg_info"]["r"]) for r in recs] == [(a, r) for r in (64, 128, 192, 256, 320, 384, 448) for a in ("15d_fusion1", "15d_fusion2", "15d_sparse")]
+
+
+def fingerprints(text):
+    got = [float(ln.split(":")[1]) for ln in text.splitlines() if "Fingerprint:" in ln]
+    assert len(got) == 3, text[-1500:]
+    return np.array(got)
+
+
+def test_scratch_cpp_prints_the_references_fingerprints(mains):
+    """scratch.cpp:78-148: file R c — 1.5D sparse shift, verify_operation, then the GAT forward pass of the benchmark's three layers.
+    The stream prints six significant digits."""
+    from oracle import oracle as O
+    want = np.array(O.fingerprints(mains["rows"], mains["cols"], 256, 256, 16))
+    assert np.max(np.abs(fingerprints(run(mains, "scratch", mains["mtx"], "16", "1")) - want) / want) <= 1e-5
+
+
+@pytest.mark.parametrize("n,c", [(2, 1), (4, 2)])
+def test_the_mains_across_processes_over_ipc(mains, n, c):
+    """The same binaries as n processes: MPI_Init picks the transport from the launcher's environment, the exit handler of the process
+    world ends the session.  Same records (p = n), same fingerprints."""
+    if not can_read_peer_memory():
+        pytest.skip("process_vm_readv between own processes is not permitted here")
+    from oracle import oracle as O
+    d = mains["dir"]
+    out = d / ("er_%d.json" % n)
+    run_ranks(mains, n, "bench_erdos_renyi", "9", "8", "15d", "16", str(c), str(out))
+    recs = records(out)
+    assert [(r["alg_name"], r["alg_info"]["p"], r["alg_info"]["c"]) for r in recs] == [("15d_fusion1", n, c), ("15d_fusion2", n, c)]
+    want = np.array(O.fingerprints(mains["rows"], mains["cols"], 256, 256, 16))
+    assert np.max(np.abs(fingerprints(run_ranks(mains, n, "scratch", mains["mtx"], "16", str(c))) - want) / want) <= 1e-5

@@ -1,6 +1,9 @@
 #!/bin/bash
 # Development aid: builds the host layer + a multi-rank harness with AddressSanitizer / UBSan and runs every schedule
-# (fusedSpMM, sddmmB, spmmB, two ALS half-steps) on p logical ranks over the oracle's CPU test double.
+# (fusedSpMM both ways, sddmmA/B, spmmA/B, the GAT forward pass twice where R is not split, two ALS half-steps) on p logical ranks
+# over the oracle's CPU test double — first with the defaults, then under every switch that selects another host code path.
+# (ThreadSanitizer is not part of this: gcc 11's libtsan does not intercept pthread_cond_clockwait, so every
+# condition_variable::wait_for of the loopback transport is reported as a double lock + races on the data it guards.)
 set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)"
 H=$ROOT/distributed_sddmm_amd/csrc/host
@@ -10,4 +13,11 @@ g++ -O1 -g -std=c++17 -fopenmp -fsanitize=address,undefined -fno-omit-frame-poin
     "$H/world.cpp" "$H/sparse_kernels.cpp" "$H/er_generator.cpp" "$ROOT/tools/sanitize/spmd_harness.cpp" -o "$OUT/spmd_asan" -ldl -lpthread
 for cfg in "1 1 15d_fusion2" "4 1 15d_fusion2" "4 2 15d_fusion2" "8 2 15d_fusion1" "4 1 15d_sparse" "8 2 25d_dense_replicate" "8 2 25d_sparse_replicate"; do
     ASAN_OPTIONS=detect_leaks=0 OMP_NUM_THREADS=1 "$OUT/spmd_asan" "$ROOT/oracle/liboracle_backend.so" $cfg | tail -1
+done
+for envs in HNH_RING_MODE=relay HNH_ACC_HALVES=0 HNH_SHIP_INDICES=1 HNH_BORROW=off HNH_BORROW=force HNH_MESH_CHUNKS=4 HNH_MESH_TAPER=3,4,4,3,2,1,1 \
+            HNH_HOST_SETUP=1 HNH_GAT_SERIAL=1; do
+    for cfg in "4 1 15d_fusion2" "4 2 15d_fusion1" "8 2 25d_dense_replicate" "4 1 15d_sparse"; do
+        echo -n "$envs: "
+        env "$envs" ASAN_OPTIONS=detect_leaks=0 OMP_NUM_THREADS=1 "$OUT/spmd_asan" "$ROOT/oracle/liboracle_backend.so" $cfg | tail -1
+    done
 done

@@ -8,6 +8,7 @@
 #include "dense_shift_15d.hpp"
 #include "sparse_shift_15d.hpp"
 #include "als_conjugate_gradients.hpp"
+#include "gat.hpp"
 using namespace std;
 static Distributed_Sparse* make(const string& alg, SpmatLocal* S, int R, int c, KernelImplementation* k) {
     if (alg == "15d_fusion1") return new Sparse15D_Dense_Shift(S, R, c, 1, k);
@@ -39,6 +40,22 @@ int main(int argc, char** argv) {
                     d->initial_shift(&A, &B, k_sddmmA); d->fusedSpMM(A, B, Sv, res, Amat); d->de_shift(&A, &B, k_sddmmA);
                     d->initial_shift(&A, &B, k_sddmmB); d->sddmmB(A, B, STv, resT); d->de_shift(&A, &B, k_sddmmB);
                     d->initial_shift(&A, &B, k_spmmB); d->spmmB(A, B, STv); d->de_shift(&A, &B, k_spmmB);
+                }
+                for (int it = 0; it < 2; it++) {
+                    d->initial_shift(&A, &B, k_sddmmA); d->sddmmA(A, B, Sv, res); d->de_shift(&A, &B, k_sddmmA);
+                    d->initial_shift(&A, &B, k_spmmA); d->spmmA(A, B, Sv); d->de_shift(&A, &B, k_spmmA);
+                    d->initial_shift(&A, &B, k_sddmmB); d->fusedSpMM(A, B, STv, resT, Bmat); d->de_shift(&A, &B, k_sddmmB);
+                }
+                if (alg == "15d_fusion1" || alg == "15d_fusion2") {  // (the schedules that do not split R: gat.hpp's precondition)
+                    vector<GATLayer> layers = {GATLayer(16, 8, 2), GATLayer(16, 8, 3)};
+                    GAT gat(layers, d.get());
+                    for (auto& l : gat.layers)
+                        for (auto& W : l.wMats) W = DenseMatrix::Constant(W.rows(), W.cols(), 0.01);
+                    gat.buffers[0] = DenseMatrix::Constant(gat.buffers[0].rows(), gat.buffers[0].cols(), 0.5);
+                    gat.forwardPass();
+                    gat.forwardPass();
+                    w.sync_all();
+                    d->setRValue(16);
                 }
                 Distributed_ALS als(d.get(), true);
                 als.initializeEmbeddings();
