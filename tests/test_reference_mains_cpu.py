@@ -1,8 +1,8 @@
 """The reference's own `main()`s, UNCHANGED, against this repository's class headers.
 
 bench_erdos_renyi.cpp, bench_file.cpp, bench_heatmap.cpp (+ benchmark_dist.cpp, the harness they call) and scratch.cpp (the
-reference's only correctness check, `verify_operation`, plus a GAT forward pass) are copied from /root/reference at test time —
-never into the repository — and compiled with nothing but `-I include/compat`: their includes (`benchmark_dist.hpp`,
+reference's only correctness check, `verify_operation`, plus a GAT forward pass) are copied from /root/reference into a temp dir at
+test time — never into the repository — and compiled with nothing but `-I include/compat` (oracle/build_ref_mains.sh): their includes (`benchmark_dist.hpp`,
 `15D_dense_shift.hpp` ... `json.hpp`, and through them `<mpi.h>` and `common.h`), `MPI_Init` / `initialize_mpi_datatypes` /
 `MPI_Allreduce(MPI_IN_PLACE, ...)` / `MPI_Finalize`, `using json = nlohmann::json`, the `NonzeroDistribution` subclass of scratch.cpp
 all resolve.  They then RUN on the kernel test double (a directory holding the host library and the C test double under the kernel
@@ -29,29 +29,21 @@ MAINS = ("bench_erdos_renyi", "bench_file", "bench_heatmap", "scratch")
 def mains(tmp_path_factory):
     if not os.path.exists(os.path.join(REF, "scratch.cpp")):
         pytest.skip("the reference's sources are not on this box")
+    # oracle/build_ref_mains.sh: the six reference files copied to a temp dir, compiled with -I include/compat and nothing else changed,
+    # linked with lib/libhnh_host.so -> oracle/_ref/mains/ (the same binaries run on the HIP library in tests/test_zz_reference_mains_gpu.py)
+    r = subprocess.run(["bash", os.path.join(T.ROOT, "oracle", "build_ref_mains.sh")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, "the reference's mains do not compile unchanged against include/compat:\n" + (r.stdout + r.stderr)[-4000:]
     d = tmp_path_factory.mktemp("refmains")
-    for f in ("benchmark_dist.cpp", "benchmark_dist.hpp") + tuple(m + ".cpp" for m in MAINS):
-        shutil.copy(os.path.join(REF, f), d / f)
-    lib = os.path.join(T.ROOT, "distributed_sddmm_amd", "lib")
-    flags = ["g++", "-O1", "-std=c++17", "-fopenmp", "-w", "-I" + os.path.join(T.ROOT, "include", "compat"),
-             "-I" + os.path.join(T.ROOT, "distributed_sddmm_amd", "csrc", "host"), "-I" + os.path.join(T.ROOT, "include")]
-    link = ["-L" + lib, "-lhnh_host", "-ldl", "-lpthread", "-Wl,-rpath," + lib]
-    subprocess.run(flags + ["-c", "benchmark_dist.cpp", "-o", "benchmark_dist.o"], cwd=d, check=True, capture_output=True, timeout=600)
-    procs = [subprocess.Popen(flags + ([] if m == "scratch" else ["benchmark_dist.o"]) + [m + ".cpp", "-o", m] + link, cwd=d,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for m in MAINS]
-    for m, p in zip(MAINS, procs):
-        out = p.communicate(timeout=600)[0]
-        assert p.returncode == 0, "%s.cpp does not compile unchanged against include/compat:\n%s" % (m, out[-3000:])
     libdir = d / "lib"
     libdir.mkdir()
-    shutil.copy(os.path.join(lib, "libhnh_host.so"), libdir / "libhnh_host.so")
+    shutil.copy(os.path.join(T.ROOT, "distributed_sddmm_amd", "lib", "libhnh_host.so"), libdir / "libhnh_host.so")
     shutil.copy(T.ORACLE_BACKEND, libdir / "libhnh_kernels.so")
-    env = dict(os.environ, LD_LIBRARY_PATH=str(libdir), OMP_NUM_THREADS="2", HNH_HOST_SETUP="1")
+    env = dict(os.environ, LD_LIBRARY_PATH=str(libdir), OMP_NUM_THREADS="2", HNH_HOST_SETUP="1")  # (LD_LIBRARY_PATH goes before the binaries' RUNPATH)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HNH_TRANSPORT", "HNH_ID_FILE"):
         env.pop(k, None)
     mtx = str(d / "g.mtx")
     rows, cols, _ = T.write_symmetric_mtx_with_duplicates(mtx, 256, 4)
-    return dict(dir=d, env=env, mtx=mtx, rows=rows, cols=cols)
+    return dict(dir=d, bin=os.path.join(T.ROOT, "oracle", "_ref", "mains"), env=env, mtx=mtx, rows=rows, cols=cols)
 
 
 def records(path):
@@ -59,7 +51,7 @@ def records(path):
 
 
 def run(mains, exe, *args):
-    r = subprocess.run([str(mains["dir"] / exe), *args], env=mains["env"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([os.path.join(mains["bin"], exe), *args], env=mains["env"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     return r.stdout
 
@@ -71,7 +63,7 @@ def run_ranks(mains, n, exe, *args):
     for r in range(n):
         env = dict(mains["env"], RANK=str(r), WORLD_SIZE=str(n), LOCAL_RANK=str(r), HNH_DEVICE="0", HNH_TRANSPORT="ipc", HNH_IPC_SESSION=session,
                    HNH_IPC_WAIT_S="120")
-        procs.append(subprocess.Popen([str(mains["dir"] / exe), *args], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        procs.append(subprocess.Popen([os.path.join(mains["bin"], exe), *args], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     try:
         for p in procs:
