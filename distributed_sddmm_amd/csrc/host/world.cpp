@@ -28,6 +28,7 @@ void set_throw_on_error(bool on) { g_throw = on; }
 
 void fatal(const std::string& msg) {
     std::cout << msg << std::endl;  // the reference reports configuration errors on cout
+    if (World* w = current_world_or_null()) w->note_failure();  // peers that wait for this rank learn now, not at their time limit
     if (g_throw) throw Error(msg);
     std::exit(1);
 }
@@ -875,6 +876,10 @@ IpcWorld::~IpcWorld() {
     }
     destroy_device();
     if (sh_) munmap((void*)sh_, sizeof(IpcShared));
+}
+
+void IpcWorld::note_failure() noexcept {
+    if (sh_) sh_->failed.store(1);
 }
 
 void IpcWorld::barrier() {

@@ -51,6 +51,9 @@ public:
 
     virtual ~World();
     virtual const char* kind() const = 0;
+    // Called by hnh::fatal() on the failing thread's current world before it exits or throws: a transport whose peers would
+    // otherwise wait for this rank until their time limit tells them now (IpcWorld: the session's `failed` word).
+    virtual void note_failure() noexcept {}
 
     // ---- communicators
     Comm world_comm();
@@ -222,6 +225,7 @@ public:
     IpcWorld(int rank, int nranks, Backend* backend, int device_ordinal, const std::string& session);
     ~IpcWorld() override;
     const char* kind() const override { return "ipc-pull"; }
+    void note_failure() noexcept override;
     void group_begin() override;
     void group_end() override;
     void sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes, int src,

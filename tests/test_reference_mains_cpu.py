@@ -127,3 +127,25 @@ def test_the_mains_across_processes_over_ipc(mains, n, c):
     assert [(r["alg_name"], r["alg_info"]["p"], r["alg_info"]["c"]) for r in recs] == [("15d_fusion1", n, c), ("15d_fusion2", n, c)]
     want = np.array(O.fingerprints(mains["rows"], mains["cols"], 256, 256, 16))
     assert np.max(np.abs(fingerprints(run_ranks(mains, n, "scratch", mains["mtx"], "16", str(c))) - want) / want) <= 1e-5
+
+
+def test_a_rank_that_fails_ends_its_peers_at_once(mains):
+    """One rank of two cannot open its input and exits through hnh::fatal (the reference's print-and-exit(1) convention): the other, waiting
+    for it inside the collective read, is told through the session's `failed` word and ends with a message within seconds — not at the
+    transport's time limit (set to ten minutes here) — and the exit handlers leave no shared-memory session behind."""
+    if not can_read_peer_memory():
+        pytest.skip("process_vm_readv between own processes is not permitted here")
+    session = "f%d_%x" % (os.getpid(), time.time_ns())
+    procs, t0 = [], time.time()
+    for r, path in ((0, mains["mtx"]), (1, str(mains["dir"] / "missing.mtx"))):
+        env = dict(mains["env"], RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), HNH_DEVICE="0", HNH_TRANSPORT="ipc", HNH_IPC_SESSION=session, HNH_IPC_WAIT_S="600")
+        procs.append(subprocess.Popen([os.path.join(mains["bin"], "scratch"), path, "16", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    try:
+        outs = [p.communicate(timeout=120)[0] for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert [p.returncode for p in procs] == [1, 1] and time.time() - t0 < 60
+    assert "cannot open matrix file" in outs[1] and "a peer rank of the ipc world gave up" in outs[0], outs
+    assert not [f for f in os.listdir("/dev/shm") if session in f]
