@@ -23,7 +23,8 @@ One JSON line is printed by rank 0.  Extra objects:
   cpu_baseline — the reference itself (oracle/_ref/ref_driver = unmodified reference sources + MKL/MPICH)
                  timed on this box's host cores on a bounded sample of the same workload (N = 1 only).
   secondary    — N = 1: R-MAT (hub rows), config 4's schedule on 8 logical ranks, one ALS-CG step, the GAT forward pass,
-                 narrow and wide operands; each with its own byte model, fraction of 8 TB/s and a closed-form check.
+                 narrow and wide operands, the one point the reference's tree prints a time for; each with its
+                 own byte model, fraction of 8 TB/s and a closed-form check.
 """
 import argparse
 import json
@@ -1371,6 +1372,43 @@ def secondary(args, b):
                 "note": "all 8 ranks' kernels AND their device-to-device copies share this one GPU: a correctness-at-shape and cost figure, not a scaling claim",
                 "check": {"rel_err": err, "ok": bool(err <= 1e-11)}}
     entry("config 4's shape, bounded: R-MAT 2^%d, edge factor %d, R=%d, 2.5D dense-replicate on 8 logical ranks" % ((8, 8, 32) if small else (18, 32, 256)), cfg4)
+
+    # (vi) the one throughput the reference's own tree prints for this path: the p = 1 point of its weak-scaling
+    # experiment 1 — `15d_sparse`, fused, 5 FusedMM calls in 0.8375 s on one Cori KNL node (ipdps_chart_generator.ipynb:564), at the size
+    # its own throughput line implies (:573,589: 2^16 rows, 32 nonzeros per row, R = 256) — timed the reference's way (benchmark_dist.cpp:
+    # 117-149: wall time of 5 calls) on this GPU.  Other hardware, a printed cell output, not a controlled comparison: context only.
+    def knl_point():
+        logm, ef, r = (8, 8, 32) if small else (16, 32, 256)
+        wl = Workload("er", logm, ef)
+        sub = Bench(argparse.Namespace(**dict(vars(args), app="vanilla", alg="15d_sparse", r=r, steps=5, warmup=0, no_check=False)), H, torch, None, 0, 1,
+                    Watchdog(0, 0, False), wl)
+        sub.transports = {"single": dict(b.transports["single"], sp=None)}
+        try:
+            sub.build(("single", 1, "none", None))
+            sub.step()
+            world.sync()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                sub.step()
+            world.sync()
+            s5 = time.perf_counter() - t0
+            chk = sub.check()
+            by = sub.nnz * (16 * r + 44) + 16 * r * sub.m  # this schedule runs the SDDMM + SpMM pair (SURVEY 8d B_unfused)
+            ref_s, ref_rate = 0.8375, (2 ** 16) * 32 * 256 * 5 / 0.8375
+            res = {"seconds_for_5_fusedmm": s5, "ms": s5 / 5 * 1e3, "nnz": sub.nnz, "M": sub.m, "R": r, "schedule": "15d_sparse, fused, p = 1, c = 1",
+                   "nnzR_per_s": sub.nnz * r * 5 / s5, "algorithmic_bytes": by, "frac": frac_of(by, s5 / 5 * 1e3),
+                   "check": {k: chk[k] for k in ("rel_err", "rows_checked", "ok")}}
+            if not small:
+                res["reference_printed"] = {"seconds_for_5_fusedmm": ref_s, "nnzR_per_s": ref_rate, "hardware": "one Cori KNL node, 1 MPI rank",
+                                            "source": "ipdps_chart_generator.ipynb:564 (time), :573,589 (the size its throughput line implies)",
+                                            "speedup": ref_s / s5}
+            return res
+        finally:
+            sub.free_current()
+            if sub.transports["single"]["sp"] is not None:
+                sub.transports["single"]["sp"].free()
+    entry("the reference's printed weak-scaling point at p = 1: ER 2^%d, %d nonzeros per row, R=%d, 15d_sparse fused, 5 FusedMM timed the reference's way"
+          % ((8, 8, 32) if small else (16, 32, 256)), knl_point)
     return out
 
 

@@ -232,7 +232,7 @@ def test_secondary_workloads_are_listed_with_their_checks():
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
     sec = out["secondary"]
-    assert len(sec) == 8 and not [e for e in sec if "error" in e], [e.get("error") for e in sec]
+    assert len(sec) == 9 and not [e for e in sec if "error" in e], [e.get("error") for e in sec]
     by_name = {e["workload"]: e for e in sec}
     for r in (8, 16, 128, 256):
         e = next(v for k, v in by_name.items() if "R=%d:" % r in k)
@@ -244,3 +244,5 @@ def test_secondary_workloads_are_listed_with_their_checks():
     assert next(v for k, v in by_name.items() if k.startswith("GAT"))["check"]["rel_err"] <= 1e-9
     assert next(v for k, v in by_name.items() if k.startswith("R-MAT"))["check"]["ok"]
     assert next(v for k, v in by_name.items() if "config 4" in k)["check"]["ok"]
+    knl = next(v for k, v in by_name.items() if "printed weak-scaling point" in k)  # (the comparison itself is only made at the printed size)
+    assert knl["check"]["ok"] and knl["seconds_for_5_fusedmm"] > 0 and knl["schedule"].startswith("15d_sparse") and "reference_printed" not in knl
