@@ -209,6 +209,11 @@ def test_cpp_dropin_driver(tmp_path):
     for alg in ("15d_fusion2", "15d_fusion1"):
         r = subprocess.run([exe, "10", "8", alg, "256", "1", str(out), "fused", "gat"], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    # examples/c_operator.c: the operator C ABI from plain C11 with its own closed-form check in C (exit status 0 = matches to 1e-11)
+    subprocess.run(["make", "-C", os.path.join(T.ROOT, "examples"), "c_operator"], check=True, capture_output=True, timeout=600)
+    for alg in ("15d_fusion2", "25d_dense_replicate"):
+        r = subprocess.run([os.path.join(T.ROOT, "examples", "c_operator"), "14", "16", alg, "128"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and alg + " on hip-gfx950: 16384 x 16384" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
 def test_custom_kernel_plugin_hip():

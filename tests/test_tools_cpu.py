@@ -94,6 +94,12 @@ def test_cpp_drivers_run_on_the_test_double(tmp_path):
     if RR.available():
         ref = RR.fingerprints(300, 300, mrows, mcols, 16, "15d_sparse", 1, 1)
         assert np.max(np.abs(got - np.array([ref["sddmm"], ref["spmmA"], ref["spmmB"]])) / want) <= 1e-11
+    # examples/c_operator.c: the operator C ABI (include/hnh_dist.h) from plain C11 — gcc -std=c11 -pedantic, no C++ on the caller's
+    # side — with its own closed-form check of fusedSpMM in C (exit status 0 = matches to 1e-11), every algorithm
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples"), "c_operator"], check=True, capture_output=True, timeout=600)
+    for alg in T.H.ALGORITHMS:
+        text = run("c_operator", "9", "8", alg, "16")
+        assert alg + " on oracle-cpu-test-double: 512 x 512, 4050 nonzeros" in text and "checked on 8192 elements" in text
 
 
 def test_cpp_verify_across_processes_over_ipc(tmp_path):
