@@ -419,11 +419,41 @@ int env_int(const char* k, int dflt) {
     const char* v = std::getenv(k);
     return (v && *v) ? std::atoi(v) : dflt;
 }
+
+// Who am I, says the launcher: torchrun / a shell loop (RANK, WORLD_SIZE, LOCAL_RANK), MPICH's mpiexec (PMI_RANK, PMI_SIZE,
+// MPI_LOCALRANKID) or Open MPI's (OMPI_COMM_WORLD_*) — the launchers are only used to START the processes, no MPI library is linked.
+// `token` is a name all ranks of THIS launch share and other launches do not: HNH_JOB_TOKEN, or the launcher's process id (every
+// rank of a one-node launch is a child of the same agent / proxy / shell) plus the rendezvous port when there is one.
+struct Launch {
+    int rank = 0, size = 1, local = 0;
+    std::string token;
+};
+Launch launch_from_environment() {
+    static const char* const kinds[][3] = {{"RANK", "WORLD_SIZE", "LOCAL_RANK"},
+                                           {"PMI_RANK", "PMI_SIZE", "MPI_LOCALRANKID"},
+                                           {"OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_RANK"}};
+    Launch l;
+    for (const auto& k : kinds) {
+        const char* n = std::getenv(k[1]);
+        if (n == nullptr || !*n) continue;
+        l.size = std::atoi(n);
+        l.rank = env_int(k[0], 0);
+        l.local = env_int(k[2], l.rank);
+        break;
+    }
+    if (const char* t = std::getenv("HNH_JOB_TOKEN")) l.token = t;
+    if (l.token.empty()) {
+        l.token = "p" + std::to_string((long)getppid());
+        if (const char* port = std::getenv("MASTER_PORT")) l.token += std::string("_") + port;
+    }
+    return l;
+}
 }  // namespace
 
 World* world_from_environment() {
-    const int rank = env_int("RANK", 0), n = env_int("WORLD_SIZE", 1), local = env_int("LOCAL_RANK", rank);
-    if (n < 1 || rank < 0 || rank >= n) fatal("Error, RANK / WORLD_SIZE of this process do not describe a rank of a world");
+    const Launch l = launch_from_environment();
+    const int rank = l.rank, n = l.size, local = l.local;
+    if (n < 1 || rank < 0 || rank >= n) fatal("Error, the launcher's environment (RANK / WORLD_SIZE, PMI_RANK / PMI_SIZE, ...) does not describe a rank of a world");
     // (before the HIP runtime starts) streams that share a hardware queue serialise: leave room beyond the default 4 queues so
     // that the compute and the communication stream never have to share one with each other or with RCCL's
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
@@ -434,27 +464,31 @@ World* world_from_environment() {
     const char* transport = std::getenv("HNH_TRANSPORT");
     if (transport && std::string(transport) == "ipc") {
         const char* session = std::getenv("HNH_IPC_SESSION");
-        if (!session || !*session) fatal("Error, HNH_TRANSPORT=ipc needs HNH_IPC_SESSION (a name shared by all ranks of the run)");
-        return new IpcWorld(rank, n, be, device, session);
+        return new IpcWorld(rank, n, be, device, (session && *session) ? std::string(session) : "auto_" + l.token);
     }
     if (transport && *transport && std::string(transport) != "rccl") fatal(std::string("Error, unknown HNH_TRANSPORT ") + transport + " (rccl or ipc)");
-    const char* idfile = std::getenv("HNH_ID_FILE");
-    if (!idfile || !*idfile) fatal("Error, WORLD_SIZE > 1 needs HNH_ID_FILE (path used to hand the RCCL unique id to all ranks) or HNH_TRANSPORT=ipc");
+    // RCCL: rank 0 hands the unique id to the others through a file — HNH_ID_FILE (any path all ranks see), or one in /dev/shm named
+    // after the launch, which rank 0 removes once the communicator exists (creating it is collective: by then every rank has read it)
+    const char* idfile_env = std::getenv("HNH_ID_FILE");
+    const bool own_file = (idfile_env == nullptr || !*idfile_env);
+    const std::string idfile = own_file ? "/dev/shm/hnh_rccl_id_" + l.token : std::string(idfile_env);
     char id[HNH_UNIQUE_ID_BYTES];
     if (rank == 0) {
-        if (be->hnh_comm_unique_id(id) != HNH_OK) fatal("Error, cannot create an RCCL unique id");
-        const std::string tmp = std::string(idfile) + ".tmp";
+        if (be->hnh_comm_unique_id(id) != HNH_OK) fatal("Error, cannot create an RCCL unique id (HNH_TRANSPORT=ipc selects the ipc-pull transport)");
+        const std::string tmp = idfile + ".tmp";
         std::ofstream(tmp, std::ios::binary).write(id, sizeof(id));
-        if (std::rename(tmp.c_str(), idfile) != 0) fatal(std::string("Error, cannot write the RCCL unique id file ") + idfile);
+        if (std::rename(tmp.c_str(), idfile.c_str()) != 0) fatal("Error, cannot write the RCCL unique id file " + idfile);
     } else {
         for (int tries = 0;; tries++) {
             std::ifstream f(idfile, std::ios::binary);
             if (f && f.read(id, sizeof(id))) break;
-            if (tries > 6000) fatal("Error, timed out waiting for the RCCL unique id file");
+            if (tries > 6000) fatal("Error, timed out waiting for the RCCL unique id file " + idfile);
             std::this_thread::sleep_for(std::chrono::milliseconds(10));
         }
     }
-    return new RcclWorld(rank, n, be, device, id);
+    World* w = new RcclWorld(rank, n, be, device, id);
+    if (rank == 0 && own_file) std::remove(idfile.c_str());
+    return w;
 }
 
 namespace {

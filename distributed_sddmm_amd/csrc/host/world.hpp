@@ -139,12 +139,19 @@ World* current_world_or_null();
 void set_current_world(World* w);
 
 // Process bootstrap of a stand-alone driver — what MPI_Init is to the reference's mains (bench_erdos_renyi.cpp:20, bench_file.cpp:20,
-// scratch.cpp:79).  One process per GPU; the launcher (torchrun, mpiexec -env, a shell loop) sets RANK / WORLD_SIZE / LOCAL_RANK:
-//   no WORLD_SIZE, or 1                                  SingleWorld on device HNH_DEVICE (default LOCAL_RANK, default 0)
-//   HNH_ID_FILE=<path every rank can read>               RcclWorld: rank 0 writes the RCCL unique id there, the others read it
-//   HNH_TRANSPORT=ipc HNH_IPC_SESSION=<name>             IpcWorld (ipc-pull): the ranks of one node meet in a shared-memory session of that name;
-//                                                        HNH_DEVICE=<ordinal> overrides LOCAL_RANK as the device (processes may share one)
-// Loads the kernel library that sits next to this one (exits loudly if it or the GPU is missing).  The caller owns the world.
+// scratch.cpp:79).  One process per GPU.  Rank, world size and local rank come from whichever launcher started the processes:
+// RANK / WORLD_SIZE / LOCAL_RANK (torchrun, a shell loop), PMI_RANK / PMI_SIZE / MPI_LOCALRANKID (MPICH's mpiexec — the reference's own
+// launch line `mpiexec -n 8 ./bench_erdos_renyi ...` works as typed; the launcher only starts processes, no MPI library is linked) or
+// OMPI_COMM_WORLD_* (Open MPI's).
+//   one rank                                             SingleWorld on device HNH_DEVICE (default: the local rank)
+//   several, default or HNH_TRANSPORT=rccl               RcclWorld: rank 0 hands the RCCL unique id to the others through HNH_ID_FILE (a path
+//                                                        every rank sees) or, without it, a file in /dev/shm named after the launch
+//   several, HNH_TRANSPORT=ipc                           IpcWorld (ipc-pull): the ranks of one node meet in a shared-memory session —
+//                                                        HNH_IPC_SESSION, or a name derived from the launch
+//   HNH_DEVICE=<ordinal>                                 overrides the local rank as the device (processes may share one)
+// "Named after the launch" = HNH_JOB_TOKEN, or the parent process id (the launcher's agent / proxy / shell, common to the ranks of a
+// one-node launch) plus MASTER_PORT when set.  Loads the kernel library that sits next to this one (exits loudly if it or the GPU is
+// missing).  The caller owns the world.
 World* world_from_environment();
 // The same, once per process and owned by the library: created on the first call, made the calling thread's current world, and torn
 // down by an exit handler — after main() has returned, because the reference's mains destroy their SpmatLocal and operators AFTER

@@ -149,3 +149,21 @@ def test_a_rank_that_fails_ends_its_peers_at_once(mains):
     assert [p.returncode for p in procs] == [1, 1] and time.time() - t0 < 60
     assert "cannot open matrix file" in outs[1] and "a peer rank of the ipc world gave up" in outs[0], outs
     assert not [f for f in os.listdir("/dev/shm") if session in f]
+
+
+def test_the_references_launch_line_with_mpiexec(mains):
+    """`mpiexec -n 4 ./bench_erdos_renyi 9 8 15d 16 2 out.json` — the reference's launch line, MPICH's launcher, the reference's unmodified
+    main — over this engine: MPI_Init reads PMI_RANK / PMI_SIZE / MPI_LOCALRANKID (the launcher only starts the processes; no MPI library
+    is linked) and the ranks meet in a session named after the launch (no HNH_IPC_SESSION)."""
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not os.path.exists(mpiexec):
+        pytest.skip("no mpiexec on this box")
+    if not can_read_peer_memory():
+        pytest.skip("process_vm_readv between own processes is not permitted here")
+    out = mains["dir"] / "er_mpiexec.json"
+    env = dict(mains["env"], HNH_TRANSPORT="ipc", HNH_DEVICE="0", HNH_IPC_WAIT_S="120")
+    r = subprocess.run([mpiexec, "-n", "4", os.path.join(mains["bin"], "bench_erdos_renyi"), "9", "8", "15d", "16", "2", str(out)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert [(x["alg_name"], x["alg_info"]["p"], x["alg_info"]["c"], x["alg_info"]["transport"]) for x in records(out)] == [
+        ("15d_fusion1", 4, 2, "ipc-pull"), ("15d_fusion2", 4, 2, "ipc-pull")]
