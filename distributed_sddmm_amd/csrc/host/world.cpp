@@ -16,6 +16,7 @@
 #include <fstream>
 #include <map>
 #include <mutex>
+#include <set>
 #include <thread>
 
 namespace hnh {
@@ -26,9 +27,19 @@ bool g_throw = false;
 }
 void set_throw_on_error(bool on) { g_throw = on; }
 
+namespace {
+// worlds that exist: a thread's current-world pointer may outlive its world (destroyed on another thread, or a stack object gone out
+// of scope), and fatal() must not call into one that is gone
+std::mutex g_live_mu;
+std::set<const World*> g_live_worlds;
+}  // namespace
+
 void fatal(const std::string& msg) {
     std::cout << msg << std::endl;  // the reference reports configuration errors on cout
-    if (World* w = current_world_or_null()) w->note_failure();  // peers that wait for this rank learn now, not at their time limit
+    if (World* w = current_world_or_null()) {  // peers that wait for this rank learn now, not at their time limit
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        if (g_live_worlds.count(w)) w->note_failure();
+    }
     if (g_throw) throw Error(msg);
     std::exit(1);
 }
@@ -118,7 +129,17 @@ World* current_world() {
 World* current_world_or_null() { return t_world; }
 void set_current_world(World* w) { t_world = w; }
 
-World::~World() {}
+World::World() {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live_worlds.insert(this);
+}
+World::~World() {
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live_worlds.erase(this);
+    }
+    if (t_world == this) t_world = nullptr;
+}
 
 void World::init_device(Backend* backend, int device_ordinal) {
     be = backend ? backend : default_backend();

@@ -49,7 +49,10 @@ public:
     uint64_t split_signature = 1469598103934665603ULL;
     int split_count = 0;
 
+    World();
     virtual ~World();
+    World(const World&) = delete;
+    World& operator=(const World&) = delete;
     virtual const char* kind() const = 0;
     // Called by hnh::fatal() on the failing thread's current world before it exits or throws: a transport whose peers would
     // otherwise wait for this rank until their time limit tells them now (IpcWorld: the session's `failed` word).

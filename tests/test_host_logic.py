@@ -222,3 +222,26 @@ int main(int argc, char** argv) {
     for r in recs:
         assert set(r) == {"elapsed", "overall_throughput", "fused", "num_trials", "alg_name", "alg_info", "application_communication_time", "perf_stats"}
         assert r["num_trials"] == 5 and r["alg_info"]["m"] == 256 and r["alg_info"]["p"] == 1 and "Computation Time" in r["perf_stats"]
+
+
+def test_an_error_after_a_world_was_destroyed_is_still_an_error():
+    """hnh::fatal tells the failing thread's CURRENT world (World::note_failure: an ipc session's peers stop waiting at once); the
+    thread's current-world pointer may outlive its world — closed here, or made current on another thread — and must then be left
+    alone: the next failing call still comes back as an error."""
+    import threading
+    w = H.World.single(0)
+    w.barrier()
+    w.close()
+    with pytest.raises(H.HnhError):
+        H.World.rccl(0, 2, 0, bytes(128))  # (the test double has no RCCL)
+    box = {}
+
+    def other_thread():
+        box["w"] = H.World.single(0)
+        box["w"].barrier()
+    t = threading.Thread(target=other_thread)
+    t.start()
+    t.join()
+    box["w"].close()
+    with pytest.raises(H.HnhError):
+        H.World.rccl(0, 2, 0, bytes(128))
