@@ -21,3 +21,20 @@ for envs in HNH_RING_MODE=relay HNH_ACC_HALVES=0 HNH_SHIP_INDICES=1 HNH_BORROW=o
         env "$envs" ASAN_OPTIONS=detect_leaks=0 OMP_NUM_THREADS=1 "$OUT/spmd_asan" "$ROOT/oracle/liboracle_backend.so" $cfg | tail -1
     done
 done
+
+# Second stage: the ipc-pull transport's host side (IpcWorld: shared-memory control plane, mailboxes, flag words, handle caches) across
+# PROCESSES — examples/verify built with the same sanitizers, as 4 / 8 ranks over the test double's process_vm_readv pull.
+g++ -O1 -g -std=c++17 -fopenmp -fsanitize=address,undefined -fno-omit-frame-pointer -Wno-sign-compare -I"$ROOT/include" -I"$H" \
+    "$H/world.cpp" "$H/sparse_kernels.cpp" "$H/er_generator.cpp" "$ROOT/examples/verify.cpp" -o "$OUT/verify_asan" -ldl -lpthread -lrt
+cp "$ROOT/oracle/liboracle_backend.so" "$OUT/libhnh_kernels.so"   # (the drivers load the kernel library next to the host code: here, the binary)
+for cfg in "4 2 15d_fusion1" "4 1 15d_fusion2" "4 1 15d_sparse" "4 1 25d_dense_replicate" "8 2 25d_sparse_replicate"; do
+    set -- $cfg
+    pids=()
+    for r in $(seq 0 $(($1 - 1))); do
+        RANK=$r WORLD_SIZE=$1 LOCAL_RANK=$r HNH_DEVICE=0 HNH_TRANSPORT=ipc HNH_IPC_SESSION="asan_$$_$3" HNH_IPC_WAIT_S=120 HNH_HOST_SETUP=1 \
+            ASAN_OPTIONS=detect_leaks=0 OMP_NUM_THREADS=1 "$OUT/verify_asan" er:8:6 "$3" 16 "$2" > "$OUT/ipc_rank$r.log" 2>&1 &
+        pids+=($!)
+    done
+    for p in "${pids[@]}"; do wait "$p"; done
+    echo "ipc $cfg: $(grep -h Fingerprint "$OUT/ipc_rank0.log" | tr '\n' ' ')"
+done
