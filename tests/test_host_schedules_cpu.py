@@ -1,5 +1,5 @@
 """Host logic on CPU: every schedule class (1.5D dense shift approach 1/2, 1.5D sparse shift, 2.5D Cannon
-dense / sparse), every (p, c) up to 8 ranks, through the in-process loopback transport — with the kernel
+dense / sparse), every (p, c) up to 8 ranks and a selection up to 18 (odd counts, 3 x 3 / 4 x 4 faces), through the in-process loopback transport — with the kernel
 ABI served by the oracle's C test double (explicitly loaded here; the product never does that).  Results
 are compared element-wise, by global coordinate, with the golden vectors produced by the reference.
 
@@ -43,6 +43,22 @@ def test_edge_cases(case_name, alg):
             continue
         per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
         T.check_against_golden(T.assemble(per_rank, case), per_rank, case, alg)
+
+
+@pytest.mark.parametrize("case_name", ["er8_r16", "ragged_r8", "rect_r16"])
+def test_grids_beyond_eight_and_not_powers_of_two(case_name):
+    """p = 3 ... 18, odd counts, 3 x 3 and 4 x 4 faces, three layers: the owner functions, ring lengths and R splits of every schedule
+    where the reference's arithmetic has remainders (the reference's outputs do not depend on the grid, so the golden vectors apply)."""
+    case = T.case_inputs(case_name)
+    ran = 0
+    for alg in H.ALGORITHMS:
+        for p, c in [(3, 1), (3, 3), (5, 1), (6, 2), (6, 3), (9, 1), (9, 3), (12, 2), (12, 3), (16, 1), (16, 4), (18, 2)]:
+            if not T.valid_config(alg, p, c, case["R"]):
+                continue
+            per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
+            T.check_against_golden(T.assemble(per_rank, case), per_rank, case, alg)
+            ran += 1
+    assert ran >= 20
 
 
 def test_value_vector_lengths_follow_the_reference():
