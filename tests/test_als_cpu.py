@@ -14,7 +14,10 @@ def cpu_test_double():
 
 
 @pytest.mark.parametrize("alg,p,c", [("15d_fusion1", 1, 1), ("15d_fusion2", 1, 1), ("15d_fusion2", 4, 2), ("15d_fusion2", 4, 1), ("15d_fusion2", 8, 1), ("15d_fusion1", 4, 1), ("15d_sparse", 4, 1),
-                                     ("15d_sparse", 4, 2), ("25d_dense_replicate", 4, 1), ("25d_dense_replicate", 8, 2), ("25d_sparse_replicate", 8, 2)])
+                                     ("15d_sparse", 4, 2), ("25d_dense_replicate", 4, 1), ("25d_dense_replicate", 8, 2), ("25d_sparse_replicate", 8, 2),
+                                     # grids with remainders: odd counts, three layers, 2 x 2 x 4
+                                     ("15d_fusion2", 5, 1), ("15d_fusion2", 6, 2), ("15d_fusion1", 9, 3), ("15d_sparse", 12, 3), ("25d_dense_replicate", 16, 4),
+                                     ("25d_sparse_replicate", 16, 4)])
 @pytest.mark.parametrize("case_name", ["er8_r16", "ragged_r8"])
 def test_als_matches_reference(case_name, alg, p, c):
     case = T.case_inputs(case_name)
