@@ -77,7 +77,8 @@ def test_bench_erdos_renyi_as_two_processes_sharing_the_gpu(env, tmp_path):
     session = "z%d_%x" % (os.getpid(), time.time_ns())
     procs = []
     for r in range(2):
-        e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), HNH_DEVICE="0", HNH_TRANSPORT="ipc", HNH_IPC_SESSION=session, HNH_IPC_WAIT_S="120")
+        e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), HNH_DEVICE="0", HNH_TRANSPORT="ipc", HNH_IPC_SESSION=session, HNH_IPC_WAIT_S="120",
+                 HNH_IPC_PULL="kernel")  # (copy-engine pulls between processes that share ONE GPU cost ~0.1 s per dependency: tests/test_multigpu_gpu.py)
         procs.append(subprocess.Popen([os.path.join(BIN, "bench_erdos_renyi"), "10", "8", "15d", "32", "1", str(out)], env=e, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
