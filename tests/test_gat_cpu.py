@@ -29,7 +29,8 @@ def test_numpy_restatement_matches_reference():
 
 
 @pytest.mark.parametrize("alg,p,c", [("15d_fusion1", 1, 1), ("15d_fusion1", 4, 1), ("15d_fusion1", 4, 2), ("15d_fusion1", 8, 2),
-                                     ("15d_fusion2", 1, 1), ("15d_fusion2", 4, 1)])
+                                     ("15d_fusion2", 1, 1), ("15d_fusion2", 4, 1),
+                                     ("15d_fusion1", 6, 2), ("15d_fusion1", 9, 3), ("15d_fusion2", 5, 1)])  # (grids with remainders)
 def test_gat_matches_reference(alg, p, c):
     case = T.case_inputs("er8_r16")
     per_rank = H.run_spmd(p, lambda w: T.run_gat(w, alg, c, case))
