@@ -4,7 +4,9 @@
  *   (1) compare it with the golden vectors produced by the reference itself (tests/test_oracle_golden.py)
  *   (2) stand in for the GPU when the HOST logic (redistribution, block layout, shift schedules,
  *       transports) is exercised on a machine without one (pytest -m "not gpu").
- * "Device" pointers are host pointers here; streams and events are no-ops (everything is synchronous).
+ * "Device" pointers are host pointers here and every call runs on the spot (streams and events do not schedule anything) — but what
+ * the host layer ENQUEUES is watched: hnh_stream_order.h keeps a vector clock per stream and the bytes every call reads and writes,
+ * and reports conflicting accesses that no event / synchronisation orders (HNH_ORDER_CHECK=1; on for every test process).
  * The product never loads this library: hnh_backend_load() is given its path explicitly by tests only,
  * and bench.py / smoke() assert that the active backend is "hip-gfx950".
  *
@@ -29,9 +31,12 @@
 #include "hnh_kernels.h"
 #include "hnh_measurement_aids.h"
 
+#include "hnh_stream_order.h" /* the happens-before checker of the stream protocol (HNH_ORDER_CHECK=1); does not touch the arithmetic */
+
 struct hnh_ctx {
     int device;
     char err[256];
+    int hb_slot; /* timelines of this context in the checker, or -1 */
 };
 
 static int fail(hnh_ctx* c, int code, const char* msg) {
@@ -41,21 +46,91 @@ static int fail(hnh_ctx* c, int code, const char* msg) {
 
 const char* hnh_backend_name(void) { return "oracle-cpu-test-double"; }
 
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 int hnh_ctx_create(int device, hnh_ctx** out) {
     if (!out) return HNH_ERR_INVALID;
     hnh_ctx* c = (hnh_ctx*)calloc(1, sizeof(hnh_ctx));
     if (!c) return HNH_ERR_NOMEM;
     c->device = device;
+    c->hb_slot = -1;
+    if (hb_enabled()) {
+        pthread_mutex_lock(&g_mu);
+        c->hb_slot = hb_slot_take();
+        pthread_mutex_unlock(&g_mu);
+    }
     *out = c;
     return HNH_OK;
 }
-int hnh_ctx_destroy(hnh_ctx* c) { free(c); return HNH_OK; }
+int hnh_ctx_destroy(hnh_ctx* c) {
+    if (c && c->hb_slot >= 0) {  /* (the slot's clock components keep counting for its next owner: old records stay "earlier") */
+        pthread_mutex_lock(&g_mu);
+        hb_slot_used[c->hb_slot] = 0;
+        pthread_mutex_unlock(&g_mu);
+    }
+    free(c);
+    return HNH_OK;
+}
 const char* hnh_last_error(hnh_ctx* c) { return c ? c->err : "null context"; }
 void* hnh_ctx_stream(hnh_ctx* c, int s) { (void)c; (void)s; return NULL; }
 /* "device" blocks are remembered (base, size) so that the ipc double below can say which block a pointer lies in */
-typedef struct block { char* base; size_t bytes; struct block* next; } block;
+typedef struct block { char* base; size_t bytes; struct block* next; hb_rec* recs; int nrec, cap; } block;
 static block* g_blocks = NULL;
-static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+
+/* ---- the checker's hooks (hnh_stream_order.h): HB_OP opens a call on a stream, HB_R / HB_W declare the bytes it reads / writes */
+static int hb_op_begin(hnh_ctx* c, int stream, const char* name) {
+    if (!hb_enabled() || !c || c->hb_slot < 0 || stream < 0 || stream >= HB_HOST) return 0;
+    if (hb_cur.depth++ > 0) return 1;  /* a call made by another call of the ABI belongs to the outer one */
+    pthread_mutex_lock(&g_mu);
+    hb_cur.t = hb_tick(c->hb_slot, stream);
+    pthread_mutex_unlock(&g_mu);
+    hb_cur.name = name;
+    return 1;
+}
+static void hb_op_end(int* opened) {
+    if (*opened) hb_cur.depth--;
+}
+#define HB_OP(c, stream, name) int hb_scope_ __attribute__((cleanup(hb_op_end))) = hb_op_begin((c), (stream), (name)); (void)hb_scope_
+static void hb_access(const void* p, size_t bytes, int write) {
+    if (hb_cur.depth <= 0 || !p || !bytes) return;
+    pthread_mutex_lock(&g_mu);
+    for (block* b = g_blocks; b; b = b->next)
+        if ((const char*)p >= b->base && (const char*)p < b->base + b->bytes) {
+            uint64_t lo = (uint64_t)((const char*)p - b->base), hi = lo + bytes;
+            if (hi > b->bytes) hi = b->bytes;
+            hb_touch(&b->recs, &b->nrec, &b->cap, b->base, lo, hi, write, hb_cur.t, hb_cur.name);
+            break;
+        }  /* (memory that is not a "device" block — host arrays of a copy — is not tracked) */
+    pthread_mutex_unlock(&g_mu);
+}
+#define HB_R(p, bytes) hb_access((p), (size_t)(bytes), 0)
+#define HB_W(p, bytes) hb_access((p), (size_t)(bytes), 1)
+/* the accesses of a row pass over [beg[r], end[r]) of every row (NULL = the whole rows): index streams, the nonzeros' values
+ * (`values_write`: -1 = not touched), and the rows of the gathered operand the column indices in range address */
+static void hb_row_pass(int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const int32_t* beg, const int32_t* end, const double* values,
+                        int values_write, const double* svalues, const double* gathered, int R) {
+    if (hb_cur.depth <= 0 || rows <= 0) return;
+    int64_t lo = -1, hi = -1;
+    int32_t cmin = 0, cmax = 0;
+    for (int64_t r = 0; r < rows; r++) {
+        const int32_t b = beg ? beg[r] : rowptr[r], e = end ? end[r] : rowptr[r + 1];
+        if (b >= e) continue;
+        if (lo < 0) { lo = b; cmin = cmax = col_idx[b]; }
+        if (b < lo) lo = b;
+        if (e > hi) hi = e;
+        for (int32_t i = b; i < e; i++) {
+            if (col_idx[i] < cmin) cmin = col_idx[i];
+            if (col_idx[i] > cmax) cmax = col_idx[i];
+        }
+    }
+    HB_R(rowptr, (size_t)(rows + 1) * sizeof(int32_t));
+    if (beg) HB_R(beg, (size_t)rows * sizeof(int32_t));
+    if (end) HB_R(end, (size_t)rows * sizeof(int32_t));
+    if (lo < 0) return;
+    HB_R(col_idx + lo, (size_t)(hi - lo) * sizeof(int32_t));
+    if (values && values_write >= 0) hb_access(values + lo, (size_t)(hi - lo) * sizeof(double), values_write);
+    if (svalues) HB_R(svalues + lo, (size_t)(hi - lo) * sizeof(double));
+    if (gathered) HB_R(gathered + (int64_t)cmin * R, (size_t)(cmax - cmin + 1) * (size_t)R * sizeof(double));
+}
 int hnh_malloc(hnh_ctx* c, size_t bytes, void** out) {
     if (!out) return HNH_ERR_INVALID;
     *out = NULL;  /* 256-byte aligned like hipMalloc: the host layer's alignment rules (SpmatLocal::lendable) then decide as on the device */
@@ -64,6 +139,8 @@ int hnh_malloc(hnh_ctx* c, size_t bytes, void** out) {
     if (b) {
         b->base = (char*)*out;
         b->bytes = bytes ? bytes : 16;
+        b->recs = NULL;
+        b->nrec = b->cap = 0;
         pthread_mutex_lock(&g_mu);
         b->next = g_blocks;
         g_blocks = b;
@@ -72,51 +149,141 @@ int hnh_malloc(hnh_ctx* c, size_t bytes, void** out) {
     return HNH_OK;
 }
 int hnh_free(hnh_ctx* c, void* p) {
-    (void)c;
     pthread_mutex_lock(&g_mu);
+    if (c && c->hb_slot >= 0)  /* hipFree synchronises the device: the host thread is behind every stream of every context */
+        for (int t = 0; t < HB_T; t++) hb_join(hb_vc[c->hb_slot * HB_LANES + HB_HOST], hb_vc[t]);
     for (block** q = &g_blocks; *q; q = &(*q)->next)
-        if ((*q)->base == (char*)p) { block* d = *q; *q = d->next; free(d); break; }
+        if ((*q)->base == (char*)p) { block* d = *q; *q = d->next; free(d->recs); free(d); break; }
     pthread_mutex_unlock(&g_mu);
     free(p);
     return HNH_OK;
 }
 int hnh_memcpy(hnh_ctx* c, void* dst, const void* src, size_t bytes, int kind, int stream) {
-    (void)c; (void)kind; (void)stream;
+    (void)kind;
+    HB_OP(c, stream, "hnh_memcpy");
+    HB_R(src, bytes);
+    HB_W(dst, bytes);
     if (bytes) memmove(dst, src, bytes);
     return HNH_OK;
 }
 int hnh_memset(hnh_ctx* c, void* dst, int byte, size_t bytes, int stream) {
-    (void)c; (void)stream;
+    HB_OP(c, stream, "hnh_memset");
+    HB_W(dst, bytes);
     if (bytes) memset(dst, byte, bytes);
     return HNH_OK;
 }
-int hnh_stream_sync(hnh_ctx* c, int s) { (void)c; (void)s; return HNH_OK; }
+int hnh_stream_sync(hnh_ctx* c, int s) {
+    if (c && c->hb_slot >= 0 && s >= 0 && s < HB_HOST) {  /* the host thread is behind everything the stream was given */
+        pthread_mutex_lock(&g_mu);
+        hb_join(hb_vc[c->hb_slot * HB_LANES + HB_HOST], hb_vc[c->hb_slot * HB_LANES + s]);
+        pthread_mutex_unlock(&g_mu);
+    }
+    return HNH_OK;
+}
 /* the test double runs everything synchronously, so an event is just the host time at which it was recorded */
 static double now_ms(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
-int hnh_event_create(hnh_ctx* c, void** e) { (void)c; *e = calloc(1, sizeof(double)); return HNH_OK; }
-int hnh_event_destroy(hnh_ctx* c, void* e) { (void)c; free(e); return HNH_OK; }
-int hnh_event_record(hnh_ctx* c, void* e, int s) { (void)c; (void)s; *(double*)e = now_ms(); return HNH_OK; }
-int hnh_event_wait(hnh_ctx* c, void* e, int s) { (void)c; (void)e; (void)s; return HNH_OK; }
-int hnh_event_sync(hnh_ctx* c, void* e) { (void)c; (void)e; return HNH_OK; }
+int hnh_event_create(hnh_ctx* c, void** e) { (void)c; *e = calloc(1, sizeof(hb_event)); return *e ? HNH_OK : HNH_ERR_NOMEM; }
+int hnh_event_destroy(hnh_ctx* c, void* e) {
+    (void)c;
+    if (e) free(((hb_event*)e)->clk);
+    free(e);
+    return HNH_OK;
+}
+int hnh_event_record(hnh_ctx* c, void* e, int s) {
+    hb_event* ev = (hb_event*)e;
+    ev->ms = now_ms();
+    if (c && c->hb_slot >= 0 && s >= 0 && s < HB_HOST) {  /* the event stands for everything the stream was given so far */
+        pthread_mutex_lock(&g_mu);
+        const int t = hb_tick(c->hb_slot, s);
+        if (!ev->clk) ev->clk = (uint32_t*)malloc(sizeof(uint32_t) * HB_T);
+        if (ev->clk) memcpy(ev->clk, hb_vc[t], sizeof(uint32_t) * HB_T);
+        pthread_mutex_unlock(&g_mu);
+    }
+    return HNH_OK;
+}
+int hnh_event_wait(hnh_ctx* c, void* e, int s) {
+    hb_event* ev = (hb_event*)e;
+    /* (HNH_ORDER_CHECK_DROP_WAITS: the checker's own test — with the waits ignored the protocol must be reported as racy) */
+    if (c && c->hb_slot >= 0 && s >= 0 && s < HB_HOST && ev && ev->clk && !getenv("HNH_ORDER_CHECK_DROP_WAITS")) {  /* what the stream is given from now on runs behind the event */
+        pthread_mutex_lock(&g_mu);
+        hb_join(hb_vc[hb_tick(c->hb_slot, s)], ev->clk);
+        pthread_mutex_unlock(&g_mu);
+    }
+    return HNH_OK;
+}
+int hnh_event_sync(hnh_ctx* c, void* e) {
+    hb_event* ev = (hb_event*)e;
+    if (c && c->hb_slot >= 0 && ev && ev->clk) {
+        pthread_mutex_lock(&g_mu);
+        hb_join(hb_vc[c->hb_slot * HB_LANES + HB_HOST], ev->clk);
+        pthread_mutex_unlock(&g_mu);
+    }
+    return HNH_OK;
+}
+
+/* ---- the checker's own entry points (tests only) */
+void hnh_oracle_order_enable(int on) {
+    pthread_mutex_lock(&g_mu);
+    if (on && hb_on <= 0) {
+        static int registered = 0;
+        if (!registered && (registered = 1)) atexit(hb_at_exit);
+    }
+    hb_on = on ? 1 : 0;
+    pthread_mutex_unlock(&g_mu);
+}
+long hnh_oracle_order_races(void) { return hb_races; }
+long hnh_oracle_order_accesses(void) { return hb_checked; }
+/* copies the reports so far (NUL terminated) and forgets them and the count */
+long hnh_oracle_order_report(char* buf, size_t capacity) {
+    pthread_mutex_lock(&g_mu);
+    const long n = hb_races;
+    if (buf && capacity) {
+        const size_t k = hb_report_len < capacity - 1 ? hb_report_len : capacity - 1;
+        memcpy(buf, hb_report, k);
+        buf[k] = 0;
+    }
+    hb_races = 0;
+    hb_report_len = 0;
+    hb_report[0] = 0;
+    pthread_mutex_unlock(&g_mu);
+    return n;
+}
 int hnh_stream_paced_copy(hnh_ctx* c, int stream, void* dst, const void* src, size_t bytes, int n, double us, int wgs) {
-    (void)c; (void)stream; (void)us; (void)wgs;
+    (void)us; (void)wgs;
+    HB_OP(c, stream, "hnh_stream_paced_copy");
+    HB_R(src, bytes);
+    HB_W(dst, (size_t)n * bytes);
     for (int k = 0; k < n; k++) memcpy((char*)dst + (size_t)k * bytes, src, bytes);
     return HNH_OK;
 }
 int hnh_stream_pace_begin(hnh_ctx* c, int stream) { (void)c; (void)stream; return HNH_OK; }
 int hnh_stream_pace_end(hnh_ctx* c, int stream, double us) { (void)c; (void)stream; (void)us; return HNH_OK; }
 int hnh_stream_delay_us(hnh_ctx* c, int stream, double us) { (void)c; (void)stream; (void)us; return HNH_OK; }  /* synchronous double: nothing to pace */
-int hnh_event_elapsed_ms(hnh_ctx* c, void* a, void* b, float* ms) { (void)c; *ms = (float)(*(double*)b - *(double*)a); return HNH_OK; }
+int hnh_event_elapsed_ms(hnh_ctx* c, void* a, void* b, float* ms) { (void)c; *ms = (float)(((hb_event*)b)->ms - ((hb_event*)a)->ms); return HNH_OK; }
 
 /* sparse_kernels.cpp:44-55 */
 int hnh_sddmm_coo(hnh_ctx* c, int64_t nnz, const int32_t* row_idx, const int32_t* col_idx, double* values, const double* X,
                   const double* Y, int R, int stream) {
-    (void)stream;
     if (nnz < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad size");
+    HB_OP(c, stream, "hnh_sddmm_coo");
+    if (hb_cur.depth > 0 && nnz > 0) {
+        int32_t rmin = row_idx[0], rmax = row_idx[0], cmin = col_idx[0], cmax = col_idx[0];
+        for (int64_t i = 1; i < nnz; i++) {
+            if (row_idx[i] < rmin) rmin = row_idx[i];
+            if (row_idx[i] > rmax) rmax = row_idx[i];
+            if (col_idx[i] < cmin) cmin = col_idx[i];
+            if (col_idx[i] > cmax) cmax = col_idx[i];
+        }
+        HB_R(row_idx, nnz * sizeof(int32_t));
+        HB_R(col_idx, nnz * sizeof(int32_t));
+        HB_W(values, nnz * sizeof(double));
+        HB_R(X + (int64_t)rmin * R, (size_t)(rmax - rmin + 1) * R * sizeof(double));
+        HB_R(Y + (int64_t)cmin * R, (size_t)(cmax - cmin + 1) * R * sizeof(double));
+    }
     for (int64_t i = 0; i < nnz; i++) {
         const double* Arow = X + (int64_t)R * row_idx[i];
         const double* Brow = Y + (int64_t)R * col_idx[i];
@@ -129,8 +296,10 @@ int hnh_sddmm_coo(hnh_ctx* c, int64_t nnz, const int32_t* row_idx, const int32_t
 
 int hnh_sddmm_csr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values, const double* X,
                   const double* Y, int R, int stream) {
-    (void)stream;
     if (rows < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad size");
+    HB_OP(c, stream, "hnh_sddmm_csr");
+    hb_row_pass(rows, rowptr, col_idx, NULL, NULL, values, 1, NULL, Y, R);
+    HB_R(X, (size_t)rows * R * sizeof(double));
     for (int64_t r = 0; r < rows; r++)
         for (int32_t i = rowptr[r]; i < rowptr[r + 1]; i++) {
             const double* Arow = X + (int64_t)R * r;
@@ -151,9 +320,11 @@ int hnh_sddmm_csr_ex(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int3
 /* C = 1.0 * S * X + 1.0 * C, row-major, ld = R (sparse_kernels.cpp:95-107) */
 int hnh_spmm_csr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values, const double* X,
                  double* Out, int R, int stream) {
-    (void)stream;
     if (rows < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad size");
     if (X == Out) return fail(c, HNH_ERR_INVALID, "X and Out alias");
+    HB_OP(c, stream, "hnh_spmm_csr");
+    hb_row_pass(rows, rowptr, col_idx, NULL, NULL, values, 0, NULL, X, R);
+    HB_W(Out, (size_t)rows * R * sizeof(double));
     for (int64_t r = 0; r < rows; r++)
         for (int32_t i = rowptr[r]; i < rowptr[r + 1]; i++) {
             const double v = values[i];
@@ -176,6 +347,8 @@ int hnh_fused_sddmm_spmm_csr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, co
                              int stream) {
     if (rows < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad size");
     if (rows == 0) return HNH_OK;
+    HB_OP(c, stream, "hnh_fused_sddmm_spmm_csr");
+    if (svalues) HB_R(svalues, (size_t)rowptr[rows] * sizeof(double));
     const int32_t nnz = rowptr[rows];
     if (flags & HNH_FUSED_VALUES_OVERWRITE) memset(values, 0, sizeof(double) * (size_t)nnz);
     if (flags & HNH_FUSED_OUT_OVERWRITE) memset(Out, 0, sizeof(double) * (size_t)rows * (size_t)R);
@@ -199,8 +372,11 @@ int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* c, int64_t rows, const int32_t* rowptr,
 
 /* als_conjugate_gradients.cpp:282,295 (+ lambda * X) and :93 (batch_dot_product(p, Mp)) on a finished output */
 int hnh_row_epilogue_f64(hnh_ctx* c, double* Out, const double* X, double x_scale, double* rowdot, int64_t rows, int R, int stream) {
-    (void)stream;
     if (rows < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad size");
+    HB_OP(c, stream, "hnh_row_epilogue_f64");
+    HB_W(Out, (size_t)rows * R * sizeof(double));
+    HB_R(X, (size_t)rows * R * sizeof(double));
+    if (rowdot) HB_W(rowdot, (size_t)rows * sizeof(double));
     for (int64_t i = 0; i < rows; i++) {
         double s = 0.0;
         for (int j = 0; j < R; j++) {
@@ -230,6 +406,18 @@ int hnh_row_epilogue_x(hnh_ctx* c, double* Out, const double* X, const hnh_fused
         if (ex->relu_dst == Out || ex->relu_dst == X) return fail(c, HNH_ERR_INVALID, "relu_dst aliases an operand");
     }
     if (rows == 0) return HNH_OK;
+    HB_OP(c, stream, "hnh_row_epilogue_x");
+    HB_W(Out, (size_t)rows * R * sizeof(double));
+    HB_R(X, (size_t)rows * R * sizeof(double));
+    if (ex->rowdot) HB_W(ex->rowdot, (size_t)rows * sizeof(double));
+    if (cg) {
+        HB_W(cg->x, (size_t)rows * R * sizeof(double));
+        HB_W(cg->r, (size_t)rows * R * sizeof(double));
+        HB_W(cg->p, (size_t)rows * R * sizeof(double));
+        HB_W(cg->rsold, (size_t)rows * sizeof(double));
+    }
+    if (ex->relu_dst)
+        for (int64_t i = 0; i < rows && hb_cur.depth > 0; i++) HB_W(ex->relu_dst + i * ex->relu_ld, (size_t)R * sizeof(double));
     double* bdot = cg ? (double*)malloc(sizeof(double) * (size_t)rows) : NULL;
     if (cg && !bdot) return fail(c, HNH_ERR_NOMEM, "malloc failed");
     int rc = HNH_OK;
@@ -269,6 +457,8 @@ int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* c, int64_t rows, const int32_t* rowptr, 
     if (rows < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad size");
     if ((flags & HNH_FUSED_LEAKY_RELU) && !ex) return fail(c, HNH_ERR_INVALID, "HNH_FUSED_LEAKY_RELU needs extras");
     if (rows == 0) return HNH_OK;
+    HB_OP(c, stream, "hnh_fused_sddmm_spmm_csr_x");
+    if (svalues) HB_R(svalues, (size_t)rowptr[rows] * sizeof(double));
     int rc;
     if (flags & HNH_FUSED_LEAKY_RELU) {
         const int32_t nnz = rowptr[rows];
@@ -292,8 +482,10 @@ int hnh_fused_sddmm_spmm_csr_x(hnh_ctx* c, int64_t rows, const int32_t* rowptr, 
 /* ---- row windows (hnh_csr_window): the same loops over [beg[r], end[r]) of every row */
 int hnh_csr_window_bounds(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, int nbounds, const int32_t* bounds,
                           int32_t* split, int stream) {
-    (void)stream;
     if (rows < 0 || nbounds < 0 || nbounds > 15) return fail(c, HNH_ERR_INVALID, "bad size");
+    HB_OP(c, stream, "hnh_csr_window_bounds");
+    hb_row_pass(rows, rowptr, col_idx, NULL, NULL, NULL, -1, NULL, NULL, 0);
+    HB_W(split, (size_t)nbounds * (size_t)rows * sizeof(int32_t));
     for (int b = 1; b < nbounds; b++)
         if (bounds[b] < bounds[b - 1]) return fail(c, HNH_ERR_INVALID, "bounds must not decrease");
     for (int b = 0; b < nbounds; b++)
@@ -307,8 +499,11 @@ int hnh_csr_window_bounds(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const
 
 int hnh_sddmm_csr_w(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values, const double* X,
                     const double* Y, int R, int64_t nnz, int max_row_nnz, const hnh_csr_window* w, int stream) {
-    (void)stream; (void)nnz; (void)max_row_nnz;
+    (void)nnz; (void)max_row_nnz;
     if (rows < 0 || R <= 0 || !w) return fail(c, HNH_ERR_INVALID, "bad argument");
+    HB_OP(c, stream, "hnh_sddmm_csr_w");
+    hb_row_pass(rows, rowptr, col_idx, w->beg, w->end, values, 1, NULL, Y, R);
+    HB_R(X, (size_t)rows * R * sizeof(double));
     for (int64_t r = 0; r < rows; r++) {
         const int32_t b = w->beg ? w->beg[r] : rowptr[r], e = w->end ? w->end[r] : rowptr[r + 1];
         for (int32_t i = b; i < e; i++) {
@@ -324,9 +519,12 @@ int hnh_sddmm_csr_w(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32
 
 int hnh_spmm_csr_w(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values, const double* X,
                    double* Out, int R, int64_t nnz, int max_row_nnz, const hnh_csr_window* w, int stream) {
-    (void)stream; (void)nnz; (void)max_row_nnz;
+    (void)nnz; (void)max_row_nnz;
     if (rows < 0 || R <= 0 || !w) return fail(c, HNH_ERR_INVALID, "bad argument");
     if (X == Out) return fail(c, HNH_ERR_INVALID, "X and Out alias");
+    HB_OP(c, stream, "hnh_spmm_csr_w");
+    hb_row_pass(rows, rowptr, col_idx, w->beg, w->end, values, 0, NULL, X, R);
+    HB_W(Out, (size_t)rows * R * sizeof(double));
     for (int64_t r = 0; r < rows; r++) {
         const int32_t b = w->beg ? w->beg[r] : rowptr[r], e = w->end ? w->end[r] : rowptr[r + 1];
         for (int32_t i = b; i < e; i++) {
@@ -347,6 +545,10 @@ int hnh_fused_sddmm_spmm_csr_w(hnh_ctx* c, int64_t rows, const int32_t* rowptr, 
     const int epilogue = ex && (ex->x_scale != 0.0 || ex->rowdot || ex->cg || ex->relu_dst);
     if (epilogue && !w->last) return fail(c, HNH_ERR_INVALID, "a row epilogue belongs to the last window");
     if (rows == 0) return HNH_OK;
+    HB_OP(c, stream, "hnh_fused_sddmm_spmm_csr_w");
+    hb_row_pass(rows, rowptr, col_idx, w->beg, w->end, values, 1, svalues, Y, R);
+    HB_R(X, (size_t)rows * R * sizeof(double));
+    HB_W(Out, (size_t)rows * R * sizeof(double));
     if (flags & HNH_FUSED_OUT_OVERWRITE) memset(Out, 0, sizeof(double) * (size_t)rows * (size_t)R);
     for (int64_t r = 0; r < rows; r++) {
         const int32_t b = w->beg ? w->beg[r] : rowptr[r], e = w->end ? w->end[r] : rowptr[r + 1];
@@ -375,7 +577,13 @@ int hnh_fused_sddmm_spmm_csr_w(hnh_ctx* c, int64_t rows, const int32_t* rowptr, 
 /* als_conjugate_gradients.cpp:117-127 */
 int hnh_cg_step_f64(hnh_ctx* c, double* X, double* Rm, const double* P, const double* MP, const double* alpha, double* rsnew,
                     int64_t rows, int R, int stream) {
-    (void)c; (void)stream;
+    HB_OP(c, stream, "hnh_cg_step_f64");
+    HB_W(X, (size_t)rows * R * sizeof(double));
+    HB_W(Rm, (size_t)rows * R * sizeof(double));
+    HB_R(P, (size_t)rows * R * sizeof(double));
+    HB_R(MP, (size_t)rows * R * sizeof(double));
+    HB_R(alpha, (size_t)rows * sizeof(double));
+    HB_W(rsnew, (size_t)rows * sizeof(double));
     for (int64_t i = 0; i < rows; i++) {
         double s = 0.0;
         for (int j = 0; j < R; j++) {
@@ -392,7 +600,8 @@ int hnh_panel_count(hnh_ctx* c, int64_t rows, int64_t nnz, int64_t cols, int R, 
     return 1;
 }
 int hnh_csr_max_row_nnz(hnh_ctx* c, int64_t rows, const int32_t* rowptr, int* out_host, int stream) {
-    (void)c; (void)stream;
+    HB_OP(c, stream, "hnh_csr_max_row_nnz");
+    HB_R(rowptr, (size_t)(rows + 1) * sizeof(int32_t));
     int m = 0;
     for (int64_t r = 0; r < rows; r++) if (rowptr[r + 1] - rowptr[r] > m) m = rowptr[r + 1] - rowptr[r];
     *out_host = m;
@@ -400,22 +609,30 @@ int hnh_csr_max_row_nnz(hnh_ctx* c, int64_t rows, const int32_t* rowptr, int* ou
 }
 
 int hnh_fill_f64(hnh_ctx* c, double* dst, int64_t n, double v, int stream) {
-    (void)c; (void)stream;
+    HB_OP(c, stream, "hnh_fill_f64");
+    HB_W(dst, (size_t)n * sizeof(double));
     for (int64_t i = 0; i < n; i++) dst[i] = v;
     return HNH_OK;
 }
 int hnh_hadamard_f64(hnh_ctx* c, double* out, const double* a, const double* b, int64_t n, int stream) {
-    (void)c; (void)stream;
+    HB_OP(c, stream, "hnh_hadamard_f64");
+    HB_R(a, (size_t)n * sizeof(double));
+    HB_R(b, (size_t)n * sizeof(double));
+    HB_W(out, (size_t)n * sizeof(double));
     for (int64_t i = 0; i < n; i++) out[i] = a[i] * b[i];
     return HNH_OK;
 }
 int hnh_axpy_f64(hnh_ctx* c, double* y, const double* x, double alpha, int64_t n, int stream) {
-    (void)c; (void)stream;
+    HB_OP(c, stream, "hnh_axpy_f64");
+    HB_R(x, (size_t)n * sizeof(double));
+    HB_W(y, (size_t)n * sizeof(double));
     for (int64_t i = 0; i < n; i++) y[i] += alpha * x[i];
     return HNH_OK;
 }
 int hnh_expand_rowptr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, int32_t* row_idx, int stream) {
-    (void)c; (void)stream;
+    HB_OP(c, stream, "hnh_expand_rowptr");
+    HB_R(rowptr, (size_t)(rows + 1) * sizeof(int32_t));
+    if (rows > 0) HB_W(row_idx + rowptr[0], (size_t)(rowptr[rows] - rowptr[0]) * sizeof(int32_t));
     for (int64_t r = 0; r < rows; r++)
         for (int32_t i = rowptr[r]; i < rowptr[r + 1]; i++) row_idx[i] = (int32_t)r;
     return HNH_OK;
@@ -423,7 +640,10 @@ int hnh_expand_rowptr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, int32_t* 
 
 /* als_conjugate_gradients.cpp:9-11 */
 int hnh_rowdot_f64(hnh_ctx* c, const double* A, const double* B, double* out, int64_t rows, int R, int stream) {
-    (void)c; (void)stream;
+    HB_OP(c, stream, "hnh_rowdot_f64");
+    HB_R(A, (size_t)rows * R * sizeof(double));
+    HB_R(B, (size_t)rows * R * sizeof(double));
+    HB_W(out, (size_t)rows * sizeof(double));
     for (int64_t i = 0; i < rows; i++) {
         double s = 0.0;
         for (int j = 0; j < R; j++) s += A[i * R + j] * B[i * R + j];
@@ -434,7 +654,11 @@ int hnh_rowdot_f64(hnh_ctx* c, const double* A, const double* B, double* out, in
 /* scale_matrix_rows + add (als_conjugate_gradients.cpp:13-29,117-123,137) */
 int hnh_row_scale_add_f64(hnh_ctx* c, double* Y, const double* yv, double ya, const double* X, const double* xv, double xa,
                           int64_t rows, int R, int stream) {
-    (void)c; (void)stream;
+    HB_OP(c, stream, "hnh_row_scale_add_f64");
+    HB_W(Y, (size_t)rows * R * sizeof(double));
+    HB_R(X, (size_t)rows * R * sizeof(double));
+    if (yv) HB_R(yv, (size_t)rows * sizeof(double));
+    if (xv) HB_R(xv, (size_t)rows * sizeof(double));
     for (int64_t i = 0; i < rows; i++) {
         const double fy = ya * (yv ? yv[i] : 1.0), fx = xa * (xv ? xv[i] : 1.0);
         for (int j = 0; j < R; j++) Y[i * R + j] = fy * Y[i * R + j] + fx * X[i * R + j];
@@ -442,13 +666,15 @@ int hnh_row_scale_add_f64(hnh_ctx* c, double* Y, const double* yv, double ya, co
     return HNH_OK;
 }
 int hnh_vec_add_scalar_f64(hnh_ctx* c, double* v, double s, int64_t n, int stream) {
-    (void)c; (void)stream;
+    HB_OP(c, stream, "hnh_vec_add_scalar_f64");
+    HB_W(v, (size_t)n * sizeof(double));
     for (int64_t i = 0; i < n; i++) v[i] += s;
     return HNH_OK;
 }
 int hnh_fill_hashed_f64(hnh_ctx* c, double* dst, int64_t rows, int64_t cols, int64_t top_row, int64_t left_col, int64_t rg,
                         uint64_t seed, double scale, int stream) {
-    (void)c; (void)stream;
+    HB_OP(c, stream, "hnh_fill_hashed_f64");
+    HB_W(dst, (size_t)rows * (size_t)cols * sizeof(double));
     for (int64_t i = 0; i < rows; i++)
         for (int64_t j = 0; j < cols; j++) {
             uint64_t z = seed * 0xD1342543DE82EF95ull + (uint64_t)((top_row + i) * rg + left_col + j) * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
@@ -460,14 +686,20 @@ int hnh_fill_hashed_f64(hnh_ctx* c, double* dst, int64_t rows, int64_t cols, int
     return HNH_OK;
 }
 int hnh_vec_div_f64(hnh_ctx* c, double* out, const double* num, const double* den, int64_t n, int stream) {
-    (void)c; (void)stream;
+    HB_OP(c, stream, "hnh_vec_div_f64");
+    HB_R(num, (size_t)n * sizeof(double));
+    HB_R(den, (size_t)n * sizeof(double));
+    HB_W(out, (size_t)n * sizeof(double));
     for (int64_t i = 0; i < n; i++) out[i] = num[i] / den[i];
     return HNH_OK;
 }
 
 /* gat.hpp:88 (Eigen dense product), :96-97, :103 */
 int hnh_gemm_f64(hnh_ctx* c, int64_t M, int64_t N, int64_t K, const double* A, const double* B, double* C, int stream) {
-    (void)c; (void)stream;
+    HB_OP(c, stream, "hnh_gemm_f64");
+    HB_R(A, (size_t)M * K * sizeof(double));
+    HB_R(B, (size_t)K * N * sizeof(double));
+    HB_W(C, (size_t)M * N * sizeof(double));
     for (int64_t i = 0; i < M; i++) {
         for (int64_t j = 0; j < N; j++) C[i * N + j] = 0.0;
         for (int64_t k = 0; k < K; k++) {
@@ -478,12 +710,15 @@ int hnh_gemm_f64(hnh_ctx* c, int64_t M, int64_t N, int64_t K, const double* A, c
     return HNH_OK;
 }
 int hnh_leaky_relu_f64(hnh_ctx* c, double* v, double alpha, int64_t n, int stream) {
-    (void)c; (void)stream;
+    HB_OP(c, stream, "hnh_leaky_relu_f64");
+    HB_W(v, (size_t)n * sizeof(double));
     for (int64_t i = 0; i < n; i++) v[i] = (v[i] > 0.0 ? v[i] : 0.0) + (v[i] < 0.0 ? v[i] : 0.0) * alpha;
     return HNH_OK;
 }
 int hnh_relu_store_cols_f64(hnh_ctx* c, double* dst, int64_t ld, int64_t col0, const double* src, int64_t rows, int64_t cols, int stream) {
-    (void)c; (void)stream;
+    HB_OP(c, stream, "hnh_relu_store_cols_f64");
+    HB_R(src, (size_t)rows * (size_t)cols * sizeof(double));
+    for (int64_t i = 0; i < rows && hb_cur.depth > 0; i++) HB_W(dst + i * ld + col0, (size_t)cols * sizeof(double));
     for (int64_t i = 0; i < rows; i++)
         for (int64_t j = 0; j < cols; j++) dst[i * ld + col0 + j] = src[i * cols + j] > 0.0 ? src[i * cols + j] : 0.0;
     return HNH_OK;
@@ -517,8 +752,10 @@ static int keyed_cmp(const void* a, const void* b) {
     return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0); /* stable */
 }
 int hnh_tuples_sort(hnh_ctx* c, hnh_tuple* t, int64_t n, const hnh_tuple_key* k, int key_bits, int stream) {
-    (void)stream; (void)key_bits;
+    (void)key_bits;
     if (n < 0) return fail(c, HNH_ERR_INVALID, "negative size");
+    HB_OP(c, stream, "hnh_tuples_sort");
+    HB_W(t, (size_t)n * sizeof(hnh_tuple));
     int rc = key_ok(c, k);
     if (rc != HNH_OK) return rc;
     if (n <= 1) return HNH_OK;
@@ -541,8 +778,10 @@ int hnh_tuples_sort(hnh_ctx* c, hnh_tuple* t, int64_t n, const hnh_tuple_key* k,
 }
 int hnh_tuples_bucket_starts(hnh_ctx* c, const hnh_tuple* t, int64_t n, const hnh_tuple_key* k, int64_t nbuckets, int64_t* starts,
                              int stream) {
-    (void)stream;
     if (n < 0 || nbuckets < 0 || !starts) return fail(c, HNH_ERR_INVALID, "bad argument");
+    HB_OP(c, stream, "hnh_tuples_bucket_starts");
+    HB_R(t, (size_t)n * sizeof(hnh_tuple));
+    HB_W(starts, (size_t)(nbuckets + 1) * sizeof(int64_t));
     int rc = key_ok(c, k);
     if (rc != HNH_OK) return rc;
     int64_t i = 0;
@@ -553,7 +792,8 @@ int hnh_tuples_bucket_starts(hnh_ctx* c, const hnh_tuple* t, int64_t n, const hn
     return HNH_OK;
 }
 int hnh_tuples_transform(hnh_ctx* c, hnh_tuple* t, int64_t n, int swap_rc, uint64_t rmod, uint64_t cmod, int stream) {
-    (void)c; (void)stream;
+    HB_OP(c, stream, "hnh_tuples_transform");
+    HB_W(t, (size_t)n * sizeof(hnh_tuple));
     for (int64_t i = 0; i < n; i++) {
         if (swap_rc) { const uint64_t x = t[i].r; t[i].r = t[i].c; t[i].c = x; }
         if (rmod) t[i].r %= rmod;
@@ -563,8 +803,9 @@ int hnh_tuples_transform(hnh_ctx* c, hnh_tuple* t, int64_t n, int swap_rc, uint6
 }
 /* SpmatLocal.hpp:485-498: ParallelReadMM(..., maximum<double>()) keeps the largest value of duplicate coordinates */
 int hnh_tuples_dedup_max(hnh_ctx* c, hnh_tuple* t, int64_t n, int64_t* n_unique, int stream) {
-    (void)stream;
     if (n < 0 || !n_unique) return fail(c, HNH_ERR_INVALID, "bad argument");
+    HB_OP(c, stream, "hnh_tuples_dedup_max");
+    HB_W(t, (size_t)n * sizeof(hnh_tuple));
     int64_t out = 0;
     for (int64_t i = 0; i < n; i++) {
         if (out > 0 && t[out - 1].r == t[i].r && t[out - 1].c == t[i].c) {
@@ -577,16 +818,19 @@ int hnh_tuples_dedup_max(hnh_ctx* c, hnh_tuple* t, int64_t n, int64_t* n_unique,
     return HNH_OK;
 }
 int hnh_tuples_take_strided(hnh_ctx* c, const hnh_tuple* src, int64_t first, int64_t stride, hnh_tuple* out, int64_t n_out, int stream) {
-    (void)stream;
     if (n_out < 0 || first < 0 || stride <= 0) return fail(c, HNH_ERR_INVALID, "bad argument");
+    HB_OP(c, stream, "hnh_tuples_take_strided");
+    if (n_out > 0) HB_R(src + first, (size_t)((n_out - 1) * stride + 1) * sizeof(hnh_tuple));
+    HB_W(out, (size_t)n_out * sizeof(hnh_tuple));
     for (int64_t i = 0; i < n_out; i++) out[i] = src[first + i * stride];
     return HNH_OK;
 }
 
 int hnh_tuples_remap_cols(hnh_ctx* c, hnh_tuple* t, int64_t n, int64_t div, int64_t sub_div, int64_t n_sub, const int64_t* dest,
                           int64_t ndest, int stream) {
-    (void)stream;
     if (n < 0 || div <= 0 || sub_div <= 0 || n_sub <= 0 || ndest <= 0 || !dest) return fail(c, HNH_ERR_INVALID, "bad argument");
+    HB_OP(c, stream, "hnh_tuples_remap_cols");
+    HB_W(t, (size_t)n * sizeof(hnh_tuple));
     for (int64_t i = 0; i < n; i++) {
         const uint64_t col = t[i].c, in = col % (uint64_t)div;
         const uint64_t seg = (col / (uint64_t)div) * (uint64_t)n_sub + in / (uint64_t)sub_div;
@@ -598,8 +842,12 @@ int hnh_tuples_remap_cols(hnh_ctx* c, hnh_tuple* t, int64_t n, int64_t div, int6
 
 int hnh_tuples_to_csr(hnh_ctx* c, const hnh_tuple* t, int64_t n, int64_t rows, int64_t cols, int32_t* rowptr, int32_t* col_idx,
                       double* values, int* max_row, int stream) {
-    (void)stream;
     if (n < 0 || rows < 0 || cols < 0 || !rowptr) return fail(c, HNH_ERR_INVALID, "bad argument");
+    HB_OP(c, stream, "hnh_tuples_to_csr");
+    HB_R(t, (size_t)n * sizeof(hnh_tuple));
+    HB_W(rowptr, (size_t)(rows + 1) * sizeof(int32_t));
+    HB_W(col_idx, (size_t)n * sizeof(int32_t));
+    HB_W(values, (size_t)n * sizeof(double));
     for (int64_t r = 0; r <= rows; r++) rowptr[r] = 0;
     for (int64_t i = 0; i < n; i++) {
         if ((int64_t)t[i].r >= rows || (int64_t)t[i].c >= cols) return fail(c, HNH_ERR_INVALID, "nonzero outside its block");
@@ -629,8 +877,9 @@ static int u64_cmp(const void* a, const void* b) {
     return x < y ? -1 : (x > y ? 1 : 0);
 }
 int hnh_generate_er_keys(hnh_ctx* c, uint64_t m, uint64_t n, uint64_t draws, uint64_t seed, uint64_t* keys, int64_t* n_unique, int stream) {
-    (void)stream;
     if (!n_unique || m == 0 || n == 0) return fail(c, HNH_ERR_INVALID, "bad argument");
+    HB_OP(c, stream, "hnh_generate_er_keys");
+    HB_W(keys, (size_t)draws * sizeof(uint64_t));
     const uint64_t G = 0x9E3779B97F4A7C15ull;
     for (uint64_t k = 0; k < draws; k++) {
         const uint64_t base = seed + (2 * k) * G;
@@ -645,8 +894,10 @@ int hnh_generate_er_keys(hnh_ctx* c, uint64_t m, uint64_t n, uint64_t draws, uin
 }
 int hnh_tuples_from_keys(hnh_ctx* c, const uint64_t* keys, uint64_t ncols, int64_t first, int64_t stride, double value, hnh_tuple* out,
                          int64_t n_out, int stream) {
-    (void)stream;
     if (n_out < 0 || first < 0 || stride <= 0 || ncols == 0) return fail(c, HNH_ERR_INVALID, "bad argument");
+    HB_OP(c, stream, "hnh_tuples_from_keys");
+    if (n_out > 0) HB_R(keys + first, (size_t)((n_out - 1) * stride + 1) * sizeof(uint64_t));
+    HB_W(out, (size_t)n_out * sizeof(hnh_tuple));
     for (int64_t i = 0; i < n_out; i++) {
         const uint64_t key = keys[first + i * stride];
         out[i].r = key / ncols; out[i].c = key % ncols; out[i].value = value;
@@ -654,7 +905,8 @@ int hnh_tuples_from_keys(hnh_ctx* c, const uint64_t* keys, uint64_t ncols, int64
     return HNH_OK;
 }
 int hnh_tuples_relabel(hnh_ctx* c, hnh_tuple* t, int64_t n, const uint64_t* row_label, const uint64_t* col_label, int stream) {
-    (void)c; (void)stream;
+    HB_OP(c, stream, "hnh_tuples_relabel");
+    HB_W(t, (size_t)n * sizeof(hnh_tuple));
     for (int64_t i = 0; i < n; i++) { t[i].r = row_label[t[i].r]; t[i].c = col_label[t[i].c]; }
     return HNH_OK;
 }
@@ -719,9 +971,11 @@ int hnh_ipc_close(hnh_ctx* c, void* base) {
     return HNH_OK;
 }
 int hnh_ipc_pull(hnh_ctx* c, int stream, int n, void* const* dst, const void* const* src, const size_t* bytes, int mode, int wgs) {
-    (void)stream; (void)mode; (void)wgs;
+    (void)mode; (void)wgs;
+    HB_OP(c, stream, "hnh_ipc_pull");  /* (the sources live in other processes: only this side of the transfer is seen) */
     for (int i = 0; i < n; i++) {
         if (!bytes[i]) continue;
+        HB_W(dst[i], bytes[i]);
         long pid = 0;
         unsigned long long remote = 0;
         pthread_mutex_lock(&g_mu);
@@ -765,6 +1019,7 @@ static const hnh_csr_window whole_block = {NULL, NULL, 1};
 int hnh_sddmm_csr_p(hnh_ctx* c, const hnh_csr_block* b, double* values, const double* X, const double* Y, int R, unsigned flags,
                     const hnh_csr_window* w, int stream) {
     if (!b) return fail(c, HNH_ERR_INVALID, "null block");
+    HB_OP(c, stream, "hnh_sddmm_csr_p");
     if (flags & HNH_FUSED_VALUES_OVERWRITE) { /* "known to be zero": the double does not rely on it */
         const hnh_csr_window* ww = w ? w : &whole_block;
         for (int64_t r = 0; r < b->rows; r++) {
@@ -778,13 +1033,15 @@ int hnh_sddmm_csr_p(hnh_ctx* c, const hnh_csr_block* b, double* values, const do
  * 15D_dense_shift.hpp:366).  With HNH_FUSED_VALUES_OVERWRITE the destination is written without being read. */
 int hnh_sddmm_csr_ps(hnh_ctx* c, const hnh_csr_block* b, double* dst, const double* scale, const double* X, const double* Y, int R,
                      unsigned flags, const hnh_csr_window* w, int stream) {
-    (void)stream;
     if (!scale) return hnh_sddmm_csr_p(c, b, dst, X, Y, R, flags, w, stream);
     if (!b) return fail(c, HNH_ERR_INVALID, "null block");
     if (flags & ~HNH_FUSED_VALUES_OVERWRITE) return fail(c, HNH_ERR_INVALID, "unknown flag");
     if (b->rows < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad argument");
     if (scale == dst) return fail(c, HNH_ERR_INVALID, "scale aliases dst");
     const hnh_csr_window* ww = w ? w : &whole_block;
+    HB_OP(c, stream, "hnh_sddmm_csr_ps");
+    hb_row_pass(b->rows, b->rowptr, b->col_idx, ww->beg, ww->end, dst, 1, scale, Y, R);
+    HB_R(X, (size_t)b->rows * R * sizeof(double));
     for (int64_t r = 0; r < b->rows; r++) {
         const int32_t lo = ww->beg ? ww->beg[r] : b->rowptr[r], hi = ww->end ? ww->end[r] : b->rowptr[r + 1];
         for (int32_t i = lo; i < hi; i++) {

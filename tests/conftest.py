@@ -8,6 +8,11 @@ import pytest
 # in the HIP runtime's exit handler in 4 of 80 runs while a large spinning pool was alive, never with a passive one
 # (profiles/r04_masked_stream_exit_hang.log) — the test process should not be the 81st.
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+# The kernel test double checks the host layer's STREAM PROTOCOL while it computes (oracle/hnh_stream_order.h): two calls that touch the same
+# bytes of "device" memory from different streams, at least one writing, with no event / synchronisation path between them, are a race —
+# which a synchronous CPU run could never show as a wrong number.  On by default for every test process (and the processes they start, which
+# exit with status 86 and the report if they saw one); this process reports at the end of the session (below).  HNH_ORDER_CHECK=0 turns it off.
+os.environ.setdefault("HNH_ORDER_CHECK", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -16,3 +21,23 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """The test double's happens-before checker of the stream protocol (oracle/hnh_stream_order.h) ran beside every test of this
+    process: every race it saw is printed and fails the session."""
+    if os.environ.get("HNH_ORDER_CHECK", "0") in ("", "0"):
+        return
+    import ctypes
+    path = os.path.join(ROOT, "oracle", "liboracle_backend.so")
+    if not os.path.exists(path):
+        return
+    lib = ctypes.CDLL(path)
+    lib.hnh_oracle_order_report.restype = ctypes.c_long
+    lib.hnh_oracle_order_accesses.restype = ctypes.c_long
+    buf = ctypes.create_string_buffer(16384)
+    races = lib.hnh_oracle_order_report(buf, 16384)
+    print("\n[stream-order checker] %d accesses checked in this process, %d races" % (lib.hnh_oracle_order_accesses(), races))
+    if races:
+        print(buf.value.decode())
+        session.exitstatus = 1

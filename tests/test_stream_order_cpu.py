@@ -1,0 +1,165 @@
+"""The host layer's STREAM PROTOCOL under a happens-before checker (oracle/hnh_stream_order.h, built into the kernel test double).
+
+On a GPU the compute, communication and auxiliary streams of a rank — and the streams of different ranks — run concurrently, and
+the only things that order them are the events the host layer records and waits for.  The CPU test double executes every call on the
+spot, so a missing wait can never show up there as a wrong number; and on one GPU a race only shows when the timing happens to
+expose it.  The double therefore also tracks, per call, the bytes of "device" memory it reads and writes and a vector clock per
+stream with exactly HIP's ordering edges (stream order, enqueue order, event record / wait / synchronise, stream synchronise,
+free); two conflicting accesses with no path between them are reported as a race.
+
+tests/conftest.py turns the checker on for EVERY test process, so the whole CPU suite (all schedules, every (p, c), grids with
+remainders, ALS, the GAT pipeline, the fuzz test with every host switch, bench.py's workers) runs under it and the session fails
+on any race.  This file holds what is specific to the checker: that it sees a deliberately unordered pair, that it accepts the
+same pair once an event orders it, that it is sensitive to the real protocol (ignoring the event waits of a schedule must produce
+races), and that the paths with the most stream traffic are clean."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import hnh_testlib as T
+from distributed_sddmm_amd import _kernels as K
+from distributed_sddmm_amd import api as H
+
+
+@pytest.fixture(scope="module")
+def checker():
+    assert H.load_backend(T.ORACLE_BACKEND) == "oracle-cpu-test-double"
+    lib = ctypes.CDLL(T.ORACLE_BACKEND)
+    lib.hnh_oracle_order_report.restype = ctypes.c_long
+    lib.hnh_oracle_order_accesses.restype = ctypes.c_long
+    lib.hnh_oracle_order_enable(1)
+
+    class Checker:
+        def drain(self):
+            """(races since the last drain, their text)"""
+            buf = ctypes.create_string_buffer(16384)
+            n = lib.hnh_oracle_order_report(buf, 16384)
+            return n, buf.value.decode()
+
+        def accesses(self):
+            return lib.hnh_oracle_order_accesses()
+    c = Checker()
+    before, text = c.drain()
+    assert before == 0, "races left behind by earlier tests of this process:\n" + text
+    yield c
+
+
+def test_an_unordered_pair_is_a_race_and_an_event_orders_it(checker):
+    """Kernel ABI, two streams of one context: fill a buffer on the compute stream, read it on the communication stream."""
+    lib = K.load(T.ORACLE_BACKEND)  # (the test double through the same ctypes signatures as the HIP library)
+    ctx, x, y, ev = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+
+    def ok(rc):
+        assert rc == 0, lib.hnh_last_error(ctx)
+    ok(lib.hnh_ctx_create(0, ctypes.byref(ctx)))
+    ok(lib.hnh_malloc(ctx, 8192, ctypes.byref(x)))
+    ok(lib.hnh_malloc(ctx, 8192, ctypes.byref(y)))
+    ok(lib.hnh_event_create(ctx, ctypes.byref(ev)))
+    ok(lib.hnh_fill_f64(ctx, y, 1024, 1.0, K.STREAM_COMPUTE))
+    ok(lib.hnh_stream_sync(ctx, K.STREAM_COMPUTE))
+    assert checker.drain()[0] == 0
+    ok(lib.hnh_fill_f64(ctx, x, 1024, 2.0, K.STREAM_COMPUTE))
+    ok(lib.hnh_axpy_f64(ctx, y, x, 1.0, 1024, K.STREAM_COMM))   # reads x with nothing between the streams
+    n, text = checker.drain()
+    assert n == 1 and "hnh_axpy_f64 (read" in text and "hnh_fill_f64 (write" in text and "comm" in text and "compute" in text, text
+    ok(lib.hnh_fill_f64(ctx, x, 1024, 3.0, K.STREAM_COMPUTE))  # (a write after that unordered read: the same missing edge, the other way round)
+    assert checker.drain()[0] == 1
+    # the same pair with an event between the streams
+    ok(lib.hnh_event_record(ctx, ev, K.STREAM_COMPUTE))
+    ok(lib.hnh_event_wait(ctx, ev, K.STREAM_COMM))
+    ok(lib.hnh_axpy_f64(ctx, y, x, 1.0, 1024, K.STREAM_COMM))
+    assert checker.drain() == (0, "")
+    # a host synchronisation orders like an event (what the host enqueues afterwards runs behind everything the streams were given);
+    # disjoint halves of one block on two streams are not a conflict
+    ok(lib.hnh_stream_sync(ctx, K.STREAM_COMPUTE))
+    ok(lib.hnh_stream_sync(ctx, K.STREAM_COMM))
+    ok(lib.hnh_fill_f64(ctx, x.value + 0, 512, 4.0, K.STREAM_COMM))
+    ok(lib.hnh_fill_f64(ctx, x.value + 512 * 8, 512, 5.0, K.STREAM_AUX))
+    assert checker.drain()[0] == 0
+    ok(lib.hnh_stream_sync(ctx, K.STREAM_COMM))
+    ok(lib.hnh_stream_sync(ctx, K.STREAM_AUX))
+    ok(lib.hnh_fill_f64(ctx, x, 1024, 6.0, K.STREAM_COMPUTE))
+    assert checker.drain()[0] == 0
+    ok(lib.hnh_event_destroy(ctx, ev))
+    ok(lib.hnh_free(ctx, x))
+    ok(lib.hnh_free(ctx, y))
+    ok(lib.hnh_ctx_destroy(ctx))
+
+
+STREAM_HEAVY = [("15d_fusion2", 4, 1, {}), ("15d_fusion2", 8, 2, {"HNH_MESH_TAPER": "3,4,4,3,2,1,1"}), ("15d_fusion2", 4, 1, {"HNH_RING_MODE": "relay"}),
+                ("15d_fusion1", 4, 1, {}), ("15d_fusion1", 6, 2, {"HNH_ACC_HALVES": "0"}), ("15d_sparse", 4, 1, {"HNH_SHIP_INDICES": "1"}),
+                ("25d_dense_replicate", 8, 2, {}), ("25d_sparse_replicate", 8, 2, {"HNH_BORROW": "force"}), ("25d_dense_replicate", 16, 4, {})]
+
+
+@pytest.mark.parametrize("alg,p,c,env", STREAM_HEAVY)
+def test_schedules_are_race_free(checker, monkeypatch, alg, p, c, env):
+    """Every operation of a schedule on p logical ranks (mesh fetch into windows of the landing buffer, relay ring, accumulator rings in
+    halves and whole, travelling sparse blocks, Cannon's two rings): results as ever, and no two conflicting accesses without a path."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    case = T.case_inputs("ragged_r8" if p == 16 else "er8_r16")
+    if not T.valid_config(alg, p, c, case["R"]):
+        pytest.skip("R not divisible for this grid")
+    before = checker.accesses()
+    per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
+    T.check_against_golden(T.assemble(per_rank, case), per_rank, case, alg)
+    n, text = checker.drain()
+    assert n == 0, text
+    assert checker.accesses() - before > 500  # (the run was actually watched)
+
+
+def test_als_and_the_gat_pipeline_are_race_free(checker):
+    """ALS-CG (the CG updates in the fused call's row epilogue; held moving operand) and the GAT forward pass (products of head j + 1 on
+    the auxiliary stream beside the attention pass of head j, two product buffers, the caching allocator's recycling)."""
+    case = T.case_inputs("er8_r16")
+    for alg, p, c in (("15d_fusion2", 4, 1), ("15d_fusion1", 4, 2), ("25d_dense_replicate", 4, 1)):
+        per_rank = H.run_spmd(p, lambda w: T.run_als(w, alg, c, case, 1, 5))
+        T.check_als_against_golden(per_rank, case)
+    for alg, p, c in (("15d_fusion2", 1, 1), ("15d_fusion2", 4, 1), ("15d_fusion1", 4, 2)):
+        H.run_spmd(p, lambda w: T.run_gat(w, alg, c, case))
+    n, text = checker.drain()
+    assert n == 0, text
+
+
+def test_the_checker_sees_the_protocol(checker, monkeypatch):
+    """Sensitivity: the same schedules with every hnh_event_wait ignored BY THE CHECKER (the double computes as ever) are reported as
+    racy — kernels against the transfers that fill and drain their operands, transfers against transfers — so silence above means the
+    events are really there."""
+    monkeypatch.setenv("HNH_ORDER_CHECK_DROP_WAITS", "1")
+    case = T.case_inputs("er8_r16")
+    seen = {}
+    for alg, p, c in (("15d_fusion2", 4, 1), ("15d_fusion1", 4, 1), ("15d_sparse", 4, 1), ("25d_dense_replicate", 4, 1)):
+        per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, alg, c, case))
+        T.check_against_golden(T.assemble(per_rank, case), per_rank, case, alg)   # (the arithmetic does not depend on the checker)
+        n, text = checker.drain()
+        seen[alg] = (n, text)
+    monkeypatch.delenv("HNH_ORDER_CHECK_DROP_WAITS")
+    assert all(n > 50 for n, _ in seen.values()), {k: v[0] for k, v in seen.items()}
+    assert "context" in seen["15d_fusion2"][1] and ("_p (read" in seen["15d_fusion2"][1] or "_p (write" in seen["15d_fusion2"][1]), seen["15d_fusion2"][1][:2000]
+    assert checker.drain()[0] == 0
+
+
+def test_a_process_that_ends_with_an_unreported_race_fails(tmp_path):
+    """The processes tests start (bench workers, C++ drivers on the test double) inherit the checker; one that saw a race exits with
+    status 86 and the report on stderr whatever its own exit status would have been."""
+    import subprocess
+    import sys
+    script = tmp_path / "racy.py"
+    script.write_text('''
+import ctypes, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import hnh_testlib as T
+from distributed_sddmm_amd import _kernels as K
+lib = K.load(T.ORACLE_BACKEND)
+ctx, x = ctypes.c_void_p(), ctypes.c_void_p()
+assert lib.hnh_ctx_create(0, ctypes.byref(ctx)) == 0 and lib.hnh_malloc(ctx, 4096, ctypes.byref(x)) == 0
+assert lib.hnh_fill_f64(ctx, x, 512, 1.0, K.STREAM_COMPUTE) == 0
+assert lib.hnh_fill_f64(ctx, x, 512, 2.0, K.STREAM_COMM) == 0   # two writers, no edge
+print("done")
+''' % (T.ROOT, os.path.join(T.ROOT, "tests")))
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, HNH_ORDER_CHECK="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 86 and "done" in r.stdout and "RACE hnh_fill_f64 (write" in r.stderr, (r.returncode, r.stderr[-1000:])
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, HNH_ORDER_CHECK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0
