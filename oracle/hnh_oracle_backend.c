@@ -207,8 +207,10 @@ int hnh_event_record(hnh_ctx* c, void* e, int s) {
 }
 int hnh_event_wait(hnh_ctx* c, void* e, int s) {
     hb_event* ev = (hb_event*)e;
-    /* (HNH_ORDER_CHECK_DROP_WAITS: the checker's own test — with the waits ignored the protocol must be reported as racy) */
-    if (c && c->hb_slot >= 0 && s >= 0 && s < HB_HOST && ev && ev->clk && !getenv("HNH_ORDER_CHECK_DROP_WAITS")) {  /* what the stream is given from now on runs behind the event */
+    /* (the checker's own tests: HNH_ORDER_CHECK_DROP_WAITS ignores every wait — the protocol must then be reported as racy —
+     * and hnh_oracle_order_drop_wait(k) ignores the k-th wait from now: single-fault injection, which waits are load-bearing) */
+    if (c && c->hb_slot >= 0 && s >= 0 && s < HB_HOST && ev && ev->clk && !getenv("HNH_ORDER_CHECK_DROP_WAITS") &&
+        __atomic_add_fetch(&hb_wait_count, 1, __ATOMIC_RELAXED) != hb_wait_drop) {  /* what the stream is given from now on runs behind the event */
         pthread_mutex_lock(&g_mu);
         hb_join(hb_vc[hb_tick(c->hb_slot, s)], ev->clk);
         pthread_mutex_unlock(&g_mu);
@@ -236,6 +238,13 @@ void hnh_oracle_order_enable(int on) {
     pthread_mutex_unlock(&g_mu);
 }
 long hnh_oracle_order_races(void) { return hb_races; }
+/* restarts the count of event waits and ignores the k-th one from now on (k <= 0: none); returns the waits counted before */
+long hnh_oracle_order_drop_wait(long k) {
+    const long seen = hb_wait_count;
+    hb_wait_count = 0;
+    hb_wait_drop = k > 0 ? k : -1;
+    return seen;
+}
 long hnh_oracle_order_accesses(void) { return hb_checked; }
 /* copies the reports so far (NUL terminated) and forgets them and the count */
 long hnh_oracle_order_report(char* buf, size_t capacity) {

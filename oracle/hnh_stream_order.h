@@ -49,6 +49,7 @@ static int hb_on = -1;                    /* -1 = read HNH_ORDER_CHECK at first 
 static uint32_t hb_vc[HB_T][HB_T];
 static unsigned char hb_slot_used[HB_CTX_SLOTS];
 static long hb_races = 0, hb_checked = 0;
+static long hb_wait_count = 0, hb_wait_drop = -1;   /* single-fault injection of the checker's own tests */
 static char hb_report[HB_REPORT_BYTES];
 static size_t hb_report_len = 0;
 static __thread struct { int depth, t; const char* name; } hb_cur;
