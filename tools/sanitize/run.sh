@@ -11,8 +11,12 @@ OUT=${TMPDIR:-/tmp}/hnh_sanitize
 mkdir -p "$OUT"
 g++ -O1 -g -std=c++17 -fopenmp -fsanitize=address,undefined -fno-omit-frame-pointer -Wno-sign-compare -I"$ROOT/include" -I"$H" \
     "$H/world.cpp" "$H/sparse_kernels.cpp" "$H/er_generator.cpp" "$ROOT/tools/sanitize/spmd_harness.cpp" -o "$OUT/spmd_asan" -ldl -lpthread
+# the test double itself under the same sanitizers, with its stream-order checker on (oracle/hnh_stream_order.h: the checker's own code is checked too;
+# a run that saw a race of the stream protocol exits with status 86 and the report)
+gcc -O1 -g -std=c11 -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -Wall -I"$ROOT/include" "$ROOT/oracle/hnh_oracle_backend.c" -o "$OUT/liboracle_asan.so"
 for cfg in "1 1 15d_fusion2" "4 1 15d_fusion2" "4 2 15d_fusion2" "8 2 15d_fusion1" "4 1 15d_sparse" "8 2 25d_dense_replicate" "8 2 25d_sparse_replicate"; do
     ASAN_OPTIONS=detect_leaks=0 OMP_NUM_THREADS=1 "$OUT/spmd_asan" "$ROOT/oracle/liboracle_backend.so" $cfg | tail -1
+    HNH_ORDER_CHECK=1 ASAN_OPTIONS=detect_leaks=0 OMP_NUM_THREADS=1 "$OUT/spmd_asan" "$OUT/liboracle_asan.so" $cfg | tail -1
 done
 for envs in HNH_RING_MODE=relay HNH_ACC_HALVES=0 HNH_SHIP_INDICES=1 HNH_BORROW=off HNH_BORROW=force HNH_MESH_CHUNKS=4 HNH_MESH_TAPER=3,4,4,3,2,1,1 \
             HNH_HOST_SETUP=1 HNH_GAT_SERIAL=1; do
