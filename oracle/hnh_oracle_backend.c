@@ -135,6 +135,9 @@ int hnh_malloc(hnh_ctx* c, size_t bytes, void** out) {
     if (!out) return HNH_ERR_INVALID;
     *out = NULL;  /* 256-byte aligned like hipMalloc: the host layer's alignment rules (SpmatLocal::lendable) then decide as on the device */
     if (posix_memalign(out, 256, bytes ? bytes : 16) != 0 || !*out) return fail(c, HNH_ERR_NOMEM, "malloc failed");
+    /* hipMalloc does not clear memory: neither does the double — fresh blocks are filled with 0xFF (NaN as doubles, -1 as indices), so host
+     * code that relies on a zeroed allocation fails here as it would, eventually, on the device (HNH_ORACLE_NO_POISON=1 turns it off) */
+    if (!getenv("HNH_ORACLE_NO_POISON")) memset(*out, 0xFF, bytes ? bytes : 16);
     block* b = (block*)malloc(sizeof(block));
     if (b) {
         b->base = (char*)*out;
@@ -153,7 +156,14 @@ int hnh_free(hnh_ctx* c, void* p) {
     if (c && c->hb_slot >= 0)  /* hipFree synchronises the device: the host thread is behind every stream of every context */
         for (int t = 0; t < HB_T; t++) hb_join(hb_vc[c->hb_slot * HB_LANES + HB_HOST], hb_vc[t]);
     for (block** q = &g_blocks; *q; q = &(*q)->next)
-        if ((*q)->base == (char*)p) { block* d = *q; *q = d->next; free(d->recs); free(d); break; }
+        if ((*q)->base == (char*)p) {
+            block* d = *q;
+            *q = d->next;
+            if (!getenv("HNH_ORACLE_NO_POISON")) memset(d->base, 0xFF, d->bytes);  /* whoever still reads this block reads NaNs / -1 */
+            free(d->recs);
+            free(d);
+            break;
+        }
     pthread_mutex_unlock(&g_mu);
     free(p);
     return HNH_OK;
