@@ -104,6 +104,27 @@ static void hb_access(const void* p, size_t bytes, int write) {
 }
 #define HB_R(p, bytes) hb_access((p), (size_t)(bytes), 0)
 #define HB_W(p, bytes) hb_access((p), (size_t)(bytes), 1)
+/* Device-to-host copies are asynchronous on the GPU (hipMemcpyAsync): the host may read the destination only behind a synchronisation
+ * that covers the copy.  Under the checker the double holds the bytes back — the destination is filled with 0xFF at once and gets the
+ * data when the host thread of some context synchronises past the copy (stream / event synchronise, free) — so host code that reads a
+ * result too early reads NaNs here instead of, by luck of timing, the right numbers. */
+typedef struct hb_pending { void* dst; void* snap; size_t bytes; int t; uint32_t clk; struct hb_pending* next; } hb_pending;
+static hb_pending *hb_pend_head = NULL, **hb_pend_tail = &hb_pend_head;
+static void hb_deliver(int host_t) {  /* under g_mu: everything the host timeline is now behind */
+    for (hb_pending** q = &hb_pend_head; *q;) {
+        hb_pending* e = *q;
+        if (hb_vc[host_t][e->t] >= e->clk) {
+            memcpy(e->dst, e->snap, e->bytes);
+            *q = e->next;
+            free(e->snap);
+            free(e);
+        } else {
+            q = &e->next;
+        }
+    }
+    hb_pend_tail = &hb_pend_head;
+    while (*hb_pend_tail) hb_pend_tail = &(*hb_pend_tail)->next;
+}
 /* the accesses of a row pass over [beg[r], end[r]) of every row (NULL = the whole rows): index streams, the nonzeros' values
  * (`values_write`: -1 = not touched), and the rows of the gathered operand the column indices in range address */
 static void hb_row_pass(int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const int32_t* beg, const int32_t* end, const double* values,
@@ -154,7 +175,10 @@ int hnh_malloc(hnh_ctx* c, size_t bytes, void** out) {
 int hnh_free(hnh_ctx* c, void* p) {
     pthread_mutex_lock(&g_mu);
     if (c && c->hb_slot >= 0)  /* hipFree synchronises the device: the host thread is behind every stream of every context */
+    {
         for (int t = 0; t < HB_T; t++) hb_join(hb_vc[c->hb_slot * HB_LANES + HB_HOST], hb_vc[t]);
+        hb_deliver(c->hb_slot * HB_LANES + HB_HOST);
+    }
     for (block** q = &g_blocks; *q; q = &(*q)->next)
         if ((*q)->base == (char*)p) {
             block* d = *q;
@@ -169,10 +193,25 @@ int hnh_free(hnh_ctx* c, void* p) {
     return HNH_OK;
 }
 int hnh_memcpy(hnh_ctx* c, void* dst, const void* src, size_t bytes, int kind, int stream) {
-    (void)kind;
     HB_OP(c, stream, "hnh_memcpy");
     HB_R(src, bytes);
     HB_W(dst, bytes);
+    if (bytes && kind == HNH_COPY_D2H && hb_cur.depth == 1) {  /* held back until the host synchronises past this copy (above) */
+        hb_pending* e = (hb_pending*)malloc(sizeof(hb_pending));
+        void* snap = malloc(bytes);
+        if (e && snap) {
+            memcpy(snap, src, bytes);
+            memset(dst, 0xFF, bytes);
+            pthread_mutex_lock(&g_mu);
+            *e = (hb_pending){dst, snap, bytes, hb_cur.t, hb_vc[hb_cur.t][hb_cur.t], NULL};
+            *hb_pend_tail = e;
+            hb_pend_tail = &e->next;
+            pthread_mutex_unlock(&g_mu);
+            return HNH_OK;
+        }
+        free(e);
+        free(snap);
+    }
     if (bytes) memmove(dst, src, bytes);
     return HNH_OK;
 }
@@ -186,6 +225,7 @@ int hnh_stream_sync(hnh_ctx* c, int s) {
     if (c && c->hb_slot >= 0 && s >= 0 && s < HB_HOST) {  /* the host thread is behind everything the stream was given */
         pthread_mutex_lock(&g_mu);
         hb_join(hb_vc[c->hb_slot * HB_LANES + HB_HOST], hb_vc[c->hb_slot * HB_LANES + s]);
+        hb_deliver(c->hb_slot * HB_LANES + HB_HOST);
         pthread_mutex_unlock(&g_mu);
     }
     return HNH_OK;
@@ -232,6 +272,7 @@ int hnh_event_sync(hnh_ctx* c, void* e) {
     if (c && c->hb_slot >= 0 && ev && ev->clk) {
         pthread_mutex_lock(&g_mu);
         hb_join(hb_vc[c->hb_slot * HB_LANES + HB_HOST], ev->clk);
+        hb_deliver(c->hb_slot * HB_LANES + HB_HOST);
         pthread_mutex_unlock(&g_mu);
     }
     return HNH_OK;

@@ -15,7 +15,8 @@
  * RACE of the stream protocol — what would be a data race on a GPU, where the streams really run concurrently — and are
  * reported with both calls' names (hnh_oracle_order_report).  The shift schedules, the mesh fetch with its landing-buffer
  * windows, the two-half accumulator rings, the GAT pipeline on the auxiliary stream and the caching allocator's recycling
- * are all checked this way in tests/test_stream_order_cpu.py.  Nothing here changes what the double computes.
+ * are all checked this way in tests/test_stream_order_cpu.py.  Nothing here changes what the double computes.  With the same clocks the
+ * double also delivers device-to-host copies only when the host synchronises past them (hb_deliver in hnh_oracle_backend.c).
  */
 #ifndef HNH_STREAM_ORDER_H
 #define HNH_STREAM_ORDER_H

@@ -192,3 +192,29 @@ def test_single_missing_waits_are_detected(checker):
     finally:
         lib.hnh_oracle_order_drop_wait(0)
     assert tried >= 20 and detected * 5 >= tried, (detected, tried)
+
+
+def test_device_to_host_copies_arrive_at_the_synchronisation(checker):
+    """hipMemcpyAsync semantics for results the host reads: under the checker the double fills the host destination with 0xFF and delivers
+    the bytes when the host synchronises past the copy — a stream synchronise, or an event recorded behind it — never before."""
+    lib = K.load(T.ORACLE_BACKEND)
+    ctx, x, ev = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.hnh_ctx_create(0, ctypes.byref(ctx)) == 0 and lib.hnh_malloc(ctx, 800, ctypes.byref(x)) == 0
+    assert lib.hnh_event_create(ctx, ctypes.byref(ev)) == 0
+    assert lib.hnh_fill_f64(ctx, x, 100, 7.0, K.STREAM_COMPUTE) == 0
+    host = np.zeros(100)
+    assert lib.hnh_memcpy(ctx, host.ctypes.data, x, 800, K.D2H, K.STREAM_COMPUTE) == 0
+    assert np.isnan(host).all()                                   # not there yet
+    assert lib.hnh_stream_sync(ctx, K.STREAM_COMM) == 0           # (another stream's synchronisation does not cover it)
+    assert np.isnan(host).all()
+    assert lib.hnh_stream_sync(ctx, K.STREAM_COMPUTE) == 0
+    assert (host == 7.0).all()
+    assert lib.hnh_fill_f64(ctx, x, 100, 8.0, K.STREAM_COMPUTE) == 0
+    assert lib.hnh_memcpy(ctx, host.ctypes.data, x, 800, K.D2H, K.STREAM_COMPUTE) == 0
+    assert lib.hnh_fill_f64(ctx, x, 100, 9.0, K.STREAM_COMPUTE) == 0  # (later work on the stream does not change what was copied)
+    assert lib.hnh_event_record(ctx, ev, K.STREAM_COMPUTE) == 0
+    assert np.isnan(host).all()
+    assert lib.hnh_event_sync(ctx, ev) == 0
+    assert (host == 8.0).all()
+    assert lib.hnh_event_destroy(ctx, ev) == 0 and lib.hnh_free(ctx, x) == 0 and lib.hnh_ctx_destroy(ctx) == 0
+    assert checker.drain()[0] == 0
