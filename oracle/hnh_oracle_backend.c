@@ -37,6 +37,8 @@ struct hnh_ctx {
     int device;
     char err[256];
     int hb_slot; /* timelines of this context in the checker, or -1 */
+    long hb_blocks; /* blocks this context has allocated: a context that never allocates (a test that hands host arrays to the kernels
+                       directly) is not held to "operands are device memory" */
 };
 
 static int fail(hnh_ctx* c, int code, const char* msg) {
@@ -84,26 +86,37 @@ static int hb_op_begin(hnh_ctx* c, int stream, const char* name) {
     hb_cur.t = hb_tick(c->hb_slot, stream);
     pthread_mutex_unlock(&g_mu);
     hb_cur.name = name;
+    hb_cur.strict = c->hb_blocks > 0;
     return 1;
 }
 static void hb_op_end(int* opened) {
     if (*opened) hb_cur.depth--;
 }
 #define HB_OP(c, stream, name) int hb_scope_ __attribute__((cleanup(hb_op_end))) = hb_op_begin((c), (stream), (name)); (void)hb_scope_
-static void hb_access(const void* p, size_t bytes, int write) {
+/* `where`: 1 = an operand that must be device memory, 0 = the host side of a copy (must NOT be device memory) */
+static void hb_access_at(const void* p, size_t bytes, int write, int where) {
     if (hb_cur.depth <= 0 || !p || !bytes) return;
     pthread_mutex_lock(&g_mu);
-    for (block* b = g_blocks; b; b = b->next)
-        if ((const char*)p >= b->base && (const char*)p < b->base + b->bytes) {
-            uint64_t lo = (uint64_t)((const char*)p - b->base), hi = lo + bytes;
-            if (hi > b->bytes) hi = b->bytes;
-            hb_touch(&b->recs, &b->nrec, &b->cap, b->base, lo, hi, write, hb_cur.t, hb_cur.name);
-            break;
-        }  /* (memory that is not a "device" block — host arrays of a copy — is not tracked) */
+    block* b = g_blocks;
+    for (; b; b = b->next)
+        if ((const char*)p >= b->base && (const char*)p < b->base + b->bytes) break;
+    if (b && where) {
+        uint64_t lo = (uint64_t)((const char*)p - b->base), hi = lo + bytes;
+        if (hi > b->bytes) {  /* the ranges are exact (index streams are scanned): this call runs past the end of its operand */
+            hb_note_misuse(hb_cur.name, write, "runs past the end of its block", p, bytes);
+            hi = b->bytes;
+        }
+        hb_touch(&b->recs, &b->nrec, &b->cap, b->base, lo, hi, write, hb_cur.t, hb_cur.name);
+    } else if (b && !where) {
+        hb_note_misuse(hb_cur.name, write, "takes device memory where the copy kind says host memory", p, bytes);
+    } else if (!b && where && hb_cur.strict) {  /* a host pointer works here and faults on the GPU */
+        hb_note_misuse(hb_cur.name, write, "is given a pointer that is not device memory (no block of hnh_malloc holds it)", p, bytes);
+    }
     pthread_mutex_unlock(&g_mu);
 }
-#define HB_R(p, bytes) hb_access((p), (size_t)(bytes), 0)
-#define HB_W(p, bytes) hb_access((p), (size_t)(bytes), 1)
+#define HB_R(p, bytes) hb_access_at((p), (size_t)(bytes), 0, 1)
+#define HB_W(p, bytes) hb_access_at((p), (size_t)(bytes), 1, 1)
+#define HB_HOST_SIDE(p, bytes) hb_access_at((p), (size_t)(bytes), 0, 0)
 /* Device-to-host copies are asynchronous on the GPU (hipMemcpyAsync): the host may read the destination only behind a synchronisation
  * that covers the copy.  Under the checker the double holds the bytes back — the destination is filled with 0xFF at once and gets the
  * data when the host thread of some context synchronises past the copy (stream / event synchronise, free) — so host code that reads a
@@ -148,7 +161,7 @@ static void hb_row_pass(int64_t rows, const int32_t* rowptr, const int32_t* col_
     if (end) HB_R(end, (size_t)rows * sizeof(int32_t));
     if (lo < 0) return;
     HB_R(col_idx + lo, (size_t)(hi - lo) * sizeof(int32_t));
-    if (values && values_write >= 0) hb_access(values + lo, (size_t)(hi - lo) * sizeof(double), values_write);
+    if (values && values_write >= 0) hb_access_at(values + lo, (size_t)(hi - lo) * sizeof(double), values_write, 1);
     if (svalues) HB_R(svalues + lo, (size_t)(hi - lo) * sizeof(double));
     if (gathered) HB_R(gathered + (int64_t)cmin * R, (size_t)(cmax - cmin + 1) * (size_t)R * sizeof(double));
 }
@@ -165,6 +178,7 @@ int hnh_malloc(hnh_ctx* c, size_t bytes, void** out) {
         b->bytes = bytes ? bytes : 16;
         b->recs = NULL;
         b->nrec = b->cap = 0;
+        if (c) c->hb_blocks++;
         pthread_mutex_lock(&g_mu);
         b->next = g_blocks;
         g_blocks = b;
@@ -194,8 +208,8 @@ int hnh_free(hnh_ctx* c, void* p) {
 }
 int hnh_memcpy(hnh_ctx* c, void* dst, const void* src, size_t bytes, int kind, int stream) {
     HB_OP(c, stream, "hnh_memcpy");
-    HB_R(src, bytes);
-    HB_W(dst, bytes);
+    if (kind == HNH_COPY_H2D) HB_HOST_SIDE(src, bytes); else HB_R(src, bytes);
+    if (kind == HNH_COPY_D2H) HB_HOST_SIDE(dst, bytes); else HB_W(dst, bytes);
     if (bytes && kind == HNH_COPY_D2H && hb_cur.depth == 1) {  /* held back until the host synchronises past this copy (above) */
         hb_pending* e = (hb_pending*)malloc(sizeof(hb_pending));
         void* snap = malloc(bytes);
@@ -378,13 +392,7 @@ int hnh_sddmm_csr_ex(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int3
 }
 
 /* C = 1.0 * S * X + 1.0 * C, row-major, ld = R (sparse_kernels.cpp:95-107) */
-int hnh_spmm_csr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values, const double* X,
-                 double* Out, int R, int stream) {
-    if (rows < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad size");
-    if (X == Out) return fail(c, HNH_ERR_INVALID, "X and Out alias");
-    HB_OP(c, stream, "hnh_spmm_csr");
-    hb_row_pass(rows, rowptr, col_idx, NULL, NULL, values, 0, NULL, X, R);
-    HB_W(Out, (size_t)rows * R * sizeof(double));
+static void spmm_csr_loop(int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values, const double* X, double* Out, int R) {
     for (int64_t r = 0; r < rows; r++)
         for (int32_t i = rowptr[r]; i < rowptr[r + 1]; i++) {
             const double v = values[i];
@@ -392,6 +400,15 @@ int hnh_spmm_csr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t*
             double* Crow = Out + (int64_t)R * r;
             for (int k = 0; k < R; k++) Crow[k] += v * Xrow[k];
         }
+}
+int hnh_spmm_csr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, const double* values, const double* X,
+                 double* Out, int R, int stream) {
+    if (rows < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad size");
+    if (X == Out) return fail(c, HNH_ERR_INVALID, "X and Out alias");
+    HB_OP(c, stream, "hnh_spmm_csr");
+    hb_row_pass(rows, rowptr, col_idx, NULL, NULL, values, 0, NULL, X, R);
+    HB_W(Out, (size_t)rows * R * sizeof(double));
+    spmm_csr_loop(rows, rowptr, col_idx, values, X, Out, R);
     return HNH_OK;
 }
 
@@ -418,9 +435,11 @@ int hnh_fused_sddmm_spmm_csr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, co
     double* w = (double*)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
     if (!w) return fail(c, HNH_ERR_NOMEM, "malloc failed");
     for (int32_t i = 0; i < nnz; i++) w[i] = values[i] * svalues[i];
-    rc = hnh_spmm_csr(c, rows, rowptr, col_idx, w, Y, Out, R, stream);
+    if (Y == Out) { free(w); return fail(c, HNH_ERR_INVALID, "X and Out alias"); }
+    HB_W(Out, (size_t)rows * R * sizeof(double));  /* (the SDDMM half above declared the index streams, the values and the rows of Y) */
+    spmm_csr_loop(rows, rowptr, col_idx, w, Y, Out, R);  /* w is the double's own scratch, not an operand */
     free(w);
-    return rc;
+    return HNH_OK;
 }
 
 int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* c, int64_t rows, const int32_t* rowptr, const int32_t* col_idx, double* values,
@@ -431,12 +450,7 @@ int hnh_fused_sddmm_spmm_csr_ex(hnh_ctx* c, int64_t rows, const int32_t* rowptr,
 }
 
 /* als_conjugate_gradients.cpp:282,295 (+ lambda * X) and :93 (batch_dot_product(p, Mp)) on a finished output */
-int hnh_row_epilogue_f64(hnh_ctx* c, double* Out, const double* X, double x_scale, double* rowdot, int64_t rows, int R, int stream) {
-    if (rows < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad size");
-    HB_OP(c, stream, "hnh_row_epilogue_f64");
-    HB_W(Out, (size_t)rows * R * sizeof(double));
-    HB_R(X, (size_t)rows * R * sizeof(double));
-    if (rowdot) HB_W(rowdot, (size_t)rows * sizeof(double));
+static void row_epilogue_loop(double* Out, const double* X, double x_scale, double* rowdot, int64_t rows, int R) {
     for (int64_t i = 0; i < rows; i++) {
         double s = 0.0;
         for (int j = 0; j < R; j++) {
@@ -445,6 +459,14 @@ int hnh_row_epilogue_f64(hnh_ctx* c, double* Out, const double* X, double x_scal
         }
         if (rowdot) rowdot[i] = s;
     }
+}
+int hnh_row_epilogue_f64(hnh_ctx* c, double* Out, const double* X, double x_scale, double* rowdot, int64_t rows, int R, int stream) {
+    if (rows < 0 || R <= 0) return fail(c, HNH_ERR_INVALID, "bad size");
+    HB_OP(c, stream, "hnh_row_epilogue_f64");
+    HB_W(Out, (size_t)rows * R * sizeof(double));
+    HB_R(X, (size_t)rows * R * sizeof(double));
+    if (rowdot) HB_W(rowdot, (size_t)rows * sizeof(double));
+    row_epilogue_loop(Out, X, x_scale, rowdot, rows, R);
     return HNH_OK;
 }
 
@@ -482,8 +504,8 @@ int hnh_row_epilogue_x(hnh_ctx* c, double* Out, const double* X, const hnh_fused
     if (cg && !bdot) return fail(c, HNH_ERR_NOMEM, "malloc failed");
     int rc = HNH_OK;
     if (ex->x_scale != 0.0 || ex->rowdot || cg) {
-        rc = hnh_row_epilogue_f64(c, Out, X, ex->x_scale, cg ? bdot : ex->rowdot, rows, R, stream);
-        if (rc == HNH_OK && cg && ex->rowdot) memcpy(ex->rowdot, bdot, sizeof(double) * (size_t)rows);
+        row_epilogue_loop(Out, X, ex->x_scale, cg ? bdot : ex->rowdot, rows, R);  /* (bdot is the double's own scratch; the operands are declared above) */
+        if (cg && ex->rowdot) memcpy(ex->rowdot, bdot, sizeof(double) * (size_t)rows);
     }
     if (rc == HNH_OK && cg) {
         for (int64_t i = 0; i < rows; i++) {
@@ -840,8 +862,7 @@ int hnh_tuples_bucket_starts(hnh_ctx* c, const hnh_tuple* t, int64_t n, const hn
                              int stream) {
     if (n < 0 || nbuckets < 0 || !starts) return fail(c, HNH_ERR_INVALID, "bad argument");
     HB_OP(c, stream, "hnh_tuples_bucket_starts");
-    HB_R(t, (size_t)n * sizeof(hnh_tuple));
-    HB_W(starts, (size_t)(nbuckets + 1) * sizeof(int64_t));
+    HB_R(t, (size_t)n * sizeof(hnh_tuple));  /* (`starts` is host memory by contract: starts_host) */
     int rc = key_ok(c, k);
     if (rc != HNH_OK) return rc;
     int64_t i = 0;

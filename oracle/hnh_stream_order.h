@@ -53,7 +53,7 @@ static long hb_races = 0, hb_checked = 0;
 static long hb_wait_count = 0, hb_wait_drop = -1;   /* single-fault injection of the checker's own tests */
 static char hb_report[HB_REPORT_BYTES];
 static size_t hb_report_len = 0;
-static __thread struct { int depth, t; const char* name; } hb_cur;
+static __thread struct { int depth, t, strict; const char* name; } hb_cur;
 
 /* a process that ends with unreported races says so and fails (a pytest session drains the report first: tests/conftest.py) */
 static void hb_at_exit(void) {
@@ -96,6 +96,14 @@ static void hb_note_race(const hb_rec* r, int t, int write, const char* op, cons
                                           op, write ? "write" : "read", t / HB_LANES, (const char*[]){"compute", "comm", "aux", "host"}[t % HB_LANES],
                                           r->op, r->write ? "write" : "read", r->t / HB_LANES, (const char*[]){"compute", "comm", "aux", "host"}[r->t % HB_LANES],
                                           base, (unsigned long long)lo, (unsigned long long)hi, (unsigned long long)r->lo, (unsigned long long)r->hi);
+    if (getenv("HNH_ORDER_CHECK_ABORT")) { fputs(hb_report, stderr); abort(); }
+}
+/* a call that misuses memory in a way the CPU forgives and the GPU does not (counted with the races) */
+static void hb_note_misuse(const char* op, int write, const char* what, const void* p, size_t bytes) {
+    hb_races++;
+    if (hb_report_len + 300 < HB_REPORT_BYTES)
+        hb_report_len += (size_t)snprintf(hb_report + hb_report_len, HB_REPORT_BYTES - hb_report_len, "MISUSE %s (%s of %zu bytes at %p) %s\n", op,
+                                          write ? "write" : "read", bytes, p, what);
     if (getenv("HNH_ORDER_CHECK_ABORT")) { fputs(hb_report, stderr); abort(); }
 }
 /* one access of the current call to bytes [lo, hi) of a block whose records are (*recs)[0 .. *n) */

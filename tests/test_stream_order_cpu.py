@@ -218,3 +218,28 @@ def test_device_to_host_copies_arrive_at_the_synchronisation(checker):
     assert (host == 8.0).all()
     assert lib.hnh_event_destroy(ctx, ev) == 0 and lib.hnh_free(ctx, x) == 0 and lib.hnh_ctx_destroy(ctx) == 0
     assert checker.drain()[0] == 0
+
+
+def test_memory_misuse_the_cpu_forgives_is_reported(checker):
+    """Three things that work on host pointers and fault (or corrupt) on the GPU: a host array handed to a kernel as an operand, a call
+    that runs past the end of its device block, a copy whose kind says "host" for what is device memory."""
+    lib = K.load(T.ORACLE_BACKEND)
+    ctx, x = ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.hnh_ctx_create(0, ctypes.byref(ctx)) == 0 and lib.hnh_malloc(ctx, 800, ctypes.byref(x)) == 0
+    host = np.zeros(100)
+    assert lib.hnh_fill_f64(ctx, host.ctypes.data, 100, 1.0, K.STREAM_COMPUTE) == 0          # the double happily fills the numpy array
+    n, text = checker.drain()
+    assert n == 1 and "MISUSE hnh_fill_f64" in text and "not device memory" in text, text
+    big, out = ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.hnh_malloc(ctx, 1600, ctypes.byref(big)) == 0 and lib.hnh_malloc(ctx, 1600, ctypes.byref(out)) == 0
+    assert lib.hnh_fill_f64(ctx, x, 100, 1.0, K.STREAM_COMPUTE) == 0 and lib.hnh_fill_f64(ctx, big, 200, 1.0, K.STREAM_COMPUTE) == 0
+    assert lib.hnh_rowdot_f64(ctx, x, big, out, 101, 1, K.STREAM_COMPUTE) == 0                # reads 808 bytes of a block of 800
+    n, text = checker.drain()
+    assert n == 1 and "MISUSE hnh_rowdot_f64 (read of 808 bytes" in text and "runs past the end of its block" in text, text
+    assert lib.hnh_free(ctx, big) == 0 and lib.hnh_free(ctx, out) == 0
+    assert lib.hnh_memcpy(ctx, x, host.ctypes.data, 800, K.D2H, K.STREAM_COMPUTE) == 0        # "device to host" with a device destination
+    n, text = checker.drain()
+    assert n >= 1 and "where the copy kind says host memory" in text, text
+    assert lib.hnh_stream_sync(ctx, K.STREAM_COMPUTE) == 0
+    assert lib.hnh_free(ctx, x) == 0 and lib.hnh_ctx_destroy(ctx) == 0
+    assert checker.drain()[0] == 0
