@@ -235,6 +235,16 @@ int hnh_memset(hnh_ctx* c, void* dst, int byte, size_t bytes, int stream) {
     if (bytes) memset(dst, byte, bytes);
     return HNH_OK;
 }
+/* calls the ABI documents as synchronous (they hand a count or a bound back to the host) end with this */
+static int hb_synchronous(hnh_ctx* c, int s) {
+    if (c && c->hb_slot >= 0 && s >= 0 && s < HB_HOST) {
+        pthread_mutex_lock(&g_mu);
+        hb_join(hb_vc[c->hb_slot * HB_LANES + HB_HOST], hb_vc[c->hb_slot * HB_LANES + s]);
+        hb_deliver(c->hb_slot * HB_LANES + HB_HOST);
+        pthread_mutex_unlock(&g_mu);
+    }
+    return HNH_OK;
+}
 int hnh_stream_sync(hnh_ctx* c, int s) {
     if (c && c->hb_slot >= 0 && s >= 0 && s < HB_HOST) {  /* the host thread is behind everything the stream was given */
         pthread_mutex_lock(&g_mu);
@@ -687,7 +697,7 @@ int hnh_csr_max_row_nnz(hnh_ctx* c, int64_t rows, const int32_t* rowptr, int* ou
     int m = 0;
     for (int64_t r = 0; r < rows; r++) if (rowptr[r + 1] - rowptr[r] > m) m = rowptr[r + 1] - rowptr[r];
     *out_host = m;
-    return HNH_OK;
+    return hb_synchronous(c, stream);
 }
 
 int hnh_fill_f64(hnh_ctx* c, double* dst, int64_t n, double v, int stream) {
@@ -870,7 +880,7 @@ int hnh_tuples_bucket_starts(hnh_ctx* c, const hnh_tuple* t, int64_t n, const hn
         while (i < n && tuple_key(&t[i], k) < (uint64_t)b) i++;
         starts[b] = i;
     }
-    return HNH_OK;
+    return hb_synchronous(c, stream);
 }
 int hnh_tuples_transform(hnh_ctx* c, hnh_tuple* t, int64_t n, int swap_rc, uint64_t rmod, uint64_t cmod, int stream) {
     HB_OP(c, stream, "hnh_tuples_transform");
@@ -896,7 +906,7 @@ int hnh_tuples_dedup_max(hnh_ctx* c, hnh_tuple* t, int64_t n, int64_t* n_unique,
         }
     }
     *n_unique = out;
-    return HNH_OK;
+    return hb_synchronous(c, stream);
 }
 int hnh_tuples_take_strided(hnh_ctx* c, const hnh_tuple* src, int64_t first, int64_t stride, hnh_tuple* out, int64_t n_out, int stream) {
     if (n_out < 0 || first < 0 || stride <= 0) return fail(c, HNH_ERR_INVALID, "bad argument");
@@ -918,7 +928,7 @@ int hnh_tuples_remap_cols(hnh_ctx* c, hnh_tuple* t, int64_t n, int64_t div, int6
         if ((int64_t)seg >= ndest || dest[seg] < 0) return fail(c, HNH_ERR_INVALID, "a tuple lies in a segment that has no destination");
         t[i].c = (uint64_t)dest[seg] + in % (uint64_t)sub_div;
     }
-    return HNH_OK;
+    return hb_synchronous(c, stream);
 }
 
 int hnh_tuples_to_csr(hnh_ctx* c, const hnh_tuple* t, int64_t n, int64_t rows, int64_t cols, int32_t* rowptr, int32_t* col_idx,
@@ -944,7 +954,7 @@ int hnh_tuples_to_csr(hnh_ctx* c, const hnh_tuple* t, int64_t n, int64_t rows, i
         rowptr[r + 1] += rowptr[r];
     }
     if (max_row) *max_row = m;
-    return HNH_OK;
+    return hb_synchronous(c, stream);
 }
 
 static uint64_t splitmix64_c(uint64_t x) {
@@ -971,7 +981,7 @@ int hnh_generate_er_keys(hnh_ctx* c, uint64_t m, uint64_t n, uint64_t draws, uin
     for (uint64_t k = 0; k < draws; k++)
         if (out == 0 || keys[out - 1] != keys[k]) keys[out++] = keys[k];
     *n_unique = (int64_t)out;
-    return HNH_OK;
+    return hb_synchronous(c, stream);
 }
 int hnh_tuples_from_keys(hnh_ctx* c, const uint64_t* keys, uint64_t ncols, int64_t first, int64_t stride, double value, hnh_tuple* out,
                          int64_t n_out, int stream) {
