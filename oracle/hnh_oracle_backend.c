@@ -37,6 +37,7 @@ struct hnh_ctx {
     int device;
     char err[256];
     int hb_slot; /* timelines of this context in the checker, or -1 */
+    char* flags_base; size_t flags_bytes; /* hnh_ipc_flags_register: this rank's mapping of the session's flag words */
     long hb_blocks; /* blocks this context has allocated: a context that never allocates (a test that hands host arrays to the kernels
                        directly) is not held to "operands are device memory" */
 };
@@ -1074,6 +1075,7 @@ int hnh_ipc_pull(hnh_ctx* c, int stream, int n, void* const* dst, const void* co
             if ((const char*)src[i] >= o->local && (const char*)src[i] + bytes[i] <= o->local + o->bytes) { pid = o->pid; remote = o->remote + (unsigned long long)((const char*)src[i] - o->local); break; }
         pthread_mutex_unlock(&g_mu);
         if (!pid) return fail(c, HNH_ERR_INVALID, "hnh_ipc_pull: source is not inside an opened block");
+        if (pid == (long)getpid()) HB_R((const void*)(uintptr_t)remote, bytes[i]);  /* ranks that are threads of this process: the checker sees both ends */
         size_t done = 0;
         while (done < bytes[i]) {
             struct iovec l = {(char*)dst[i] + done, bytes[i] - done}, r = {(void*)(uintptr_t)(remote + done), bytes[i] - done};
@@ -1084,15 +1086,57 @@ int hnh_ipc_pull(hnh_ctx* c, int stream, int n, void* const* dst, const void* co
     }
     return HNH_OK;
 }
-int hnh_ipc_flags_register(hnh_ctx* c, void* host_shm, size_t bytes, void** device_view) { (void)c; (void)bytes; *device_view = host_shm; return HNH_OK; }
+int hnh_ipc_flags_register(hnh_ctx* c, void* host_shm, size_t bytes, void** device_view) {
+    if (c) { c->flags_base = (char*)host_shm; c->flags_bytes = bytes; }
+    *device_view = host_shm;
+    return HNH_OK;
+}
 int hnh_ipc_flags_unregister(hnh_ctx* c, void* host_shm) { (void)c; (void)host_shm; return HNH_OK; }
-int hnh_stream_write_flag(hnh_ctx* c, int stream, void* f, uint64_t v) { (void)c; (void)stream; __atomic_store_n((uint64_t*)f, v, __ATOMIC_RELEASE); return HNH_OK; }
+/* Flag words order streams of different ranks like events do: a wait for value v runs behind the write that raised the word to v (values
+ * only grow).  The checker keeps the clocks of the recent writes of THIS process, so ranks that are threads of one process (the ipc-pull
+ * transport run that way by tests/test_stream_order_cpu.py) have their whole protocol checked; writes of other processes leave no edge. */
+typedef struct hb_flag_write { void* f; uint64_t v; unsigned long seq; uint32_t clk[HB_T]; } hb_flag_write;
+#define HB_FLAG_WRITES 1024
+static hb_flag_write* hb_flag_ring = NULL;
+static unsigned long hb_flag_next = 0;
+/* every rank maps the session's segment at its own address: a flag word is named by its offset in the registered region */
+static void* hb_flag_name(hnh_ctx* c, void* f) {
+    if (c && c->flags_base && (char*)f >= c->flags_base && (char*)f < c->flags_base + c->flags_bytes) return (void*)(uintptr_t)((char*)f - c->flags_base + 1);
+    return f;
+}
+int hnh_stream_write_flag(hnh_ctx* c, int stream, void* f, uint64_t v) {
+    if (c && c->hb_slot >= 0 && stream >= 0 && stream < HB_HOST) {
+        pthread_mutex_lock(&g_mu);
+        if (!hb_flag_ring) hb_flag_ring = (hb_flag_write*)calloc(HB_FLAG_WRITES, sizeof(hb_flag_write));
+        if (hb_flag_ring) {
+            hb_flag_write* w = &hb_flag_ring[hb_flag_next % HB_FLAG_WRITES];
+            w->f = hb_flag_name(c, f);
+            w->v = v;
+            w->seq = ++hb_flag_next;
+            memcpy(w->clk, hb_vc[hb_tick(c->hb_slot, stream)], sizeof(w->clk));
+        }
+        pthread_mutex_unlock(&g_mu);
+    }
+    __atomic_store_n((uint64_t*)f, v, __ATOMIC_RELEASE);
+    return HNH_OK;
+}
 int hnh_stream_wait_flag(hnh_ctx* c, int stream, void* f, uint64_t v) {
-    (void)stream;
     const double t0 = now_ms();
     for (unsigned spins = 0; __atomic_load_n((uint64_t*)f, __ATOMIC_ACQUIRE) < v; spins++) {
         if (spins > 1000) { struct timespec ts = {0, 50000}; nanosleep(&ts, NULL); }
         if ((spins & 1023) == 0 && now_ms() - t0 > 120000.0) return fail(c, HNH_ERR_DEVICE, "hnh_stream_wait_flag: the peer never raised the flag");
+    }
+    if (c && c->hb_slot >= 0 && stream >= 0 && stream < HB_HOST && !getenv("HNH_ORDER_CHECK_DROP_WAITS")) {
+        pthread_mutex_lock(&g_mu);
+        const hb_flag_write* best = NULL;  /* the write that raised the word to (at least) v: the smallest recorded value >= v */
+        void* name = hb_flag_name(c, f);
+        for (int i = 0; hb_flag_ring && i < HB_FLAG_WRITES; i++)
+            if (hb_flag_ring[i].f == name && hb_flag_ring[i].v >= v &&
+                (!best || hb_flag_ring[i].v < best->v || (hb_flag_ring[i].v == best->v && hb_flag_ring[i].seq > best->seq)))
+                best = &hb_flag_ring[i];
+        const int t = hb_tick(c->hb_slot, stream);
+        if (best) hb_join(hb_vc[t], best->clk);
+        pthread_mutex_unlock(&g_mu);
     }
     return HNH_OK;
 }
