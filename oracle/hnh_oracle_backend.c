@@ -1003,20 +1003,293 @@ int hnh_tuples_relabel(hnh_ctx* c, hnh_tuple* t, int64_t n, const uint64_t* row_
     return HNH_OK;
 }
 
-/* no RCCL on the CPU: host-logic tests use the thread-loopback or callback transports */
-#define UNSUP(c) return fail((c), HNH_ERR_UNSUPPORTED, "RCCL transport is not available in the CPU test double")
-int hnh_comm_unique_id(void* id) { (void)id; return HNH_ERR_UNSUPPORTED; }
-int hnh_comm_init(hnh_ctx* c, int n, int r, const void* id, void** comm) { (void)n; (void)r; (void)id; (void)comm; UNSUP(c); }
-int hnh_comm_split(hnh_ctx* c, void* comm, int color, int key, void** nc) { (void)comm; (void)color; (void)key; (void)nc; UNSUP(c); }
-int hnh_comm_destroy(hnh_ctx* c, void* comm) { (void)comm; UNSUP(c); }
-int hnh_comm_sendrecv(hnh_ctx* c, void* comm, const void* s, size_t sb, int dst, void* r, size_t rb, int src, int st) {
-    (void)comm; (void)s; (void)sb; (void)dst; (void)r; (void)rb; (void)src; (void)st; UNSUP(c);
+/* ---- the RCCL section of the ABI, EMULATED between ranks that are threads of this process (tests/test_rccl_emulation_cpu.py).
+ * What is emulated is the calling contract the product's default transport (RcclWorld) depends on, as NCCL / RCCL document it:
+ *   - a communicator is formed by all n ranks calling init with the same unique id (collective);
+ *   - point-to-point operations of one ncclGroupStart/End are issued together; a send and a receive match in the ORDER they were issued
+ *     for their (source, destination) pair on the communicator, and their sizes must agree;
+ *   - collectives are called by every rank of the communicator in the same order;
+ *   - an operation that never finds its partner hangs on the GPU — here it fails after HNH_ORACLE_COMM_WAIT_S (default 120 s).
+ * Data moves with memcpy; the stream-order checker sees a send as a read of its buffer on the sender's stream, a receive as a write on
+ * the receiver's stream that runs behind the matching send, a collective as running behind every rank's contribution. */
+typedef struct emu_msg { const void* src; size_t bytes; int taken; uint32_t clk[HB_T]; struct emu_msg* next; } emu_msg;
+typedef struct emu_group {
+    unsigned char id[HNH_UNIQUE_ID_BYTES];
+    int n, joined, refs;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    emu_msg** q;          /* n * n FIFOs, q[src * n + dst] */
+    int arrived, leaving; /* collectives: two-phase meeting */
+    unsigned long gen;
+    const void** contrib; /* n send buffers of the collective in flight */
+    uint32_t* contrib_clk;
+    struct emu_group* next;
+} emu_group;
+typedef struct emu_comm { emu_group* g; int rank; } emu_comm;
+typedef struct emu_op { emu_comm* comm; hnh_ctx* ctx; int is_send, peer, stream; void* buf; size_t bytes; emu_msg* msg; } emu_op;
+static emu_group* g_emu_groups = NULL;
+static unsigned char (*g_emu_ids)[HNH_UNIQUE_ID_BYTES] = NULL;
+static int g_emu_nids = 0;
+static pthread_mutex_t g_emu_mu = PTHREAD_MUTEX_INITIALIZER;
+static __thread int emu_depth = 0, emu_nops = 0;
+static __thread emu_op emu_ops[1024];
+
+static double emu_wait_limit_ms(void) {
+    const char* v = getenv("HNH_ORACLE_COMM_WAIT_S");
+    return (v && *v ? atof(v) : 120.0) * 1e3;
 }
-int hnh_comm_group_begin(hnh_ctx* c) { (void)c; return HNH_OK; }
-int hnh_comm_group_end(hnh_ctx* c) { (void)c; return HNH_OK; }
-int hnh_comm_allgather(hnh_ctx* c, void* comm, const void* s, void* r, size_t b, int st) { (void)comm; (void)s; (void)r; (void)b; (void)st; UNSUP(c); }
-int hnh_comm_reduce_scatter_f64(hnh_ctx* c, void* comm, const double* s, double* r, size_t n, int st) { (void)comm; (void)s; (void)r; (void)n; (void)st; UNSUP(c); }
-int hnh_comm_allreduce_f64(hnh_ctx* c, void* comm, const double* s, double* r, size_t n, int st) { (void)comm; (void)s; (void)r; (void)n; (void)st; UNSUP(c); }
+/* waits on g->cv (g->mu held) until *cond; 0 = timed out */
+#define EMU_WAIT(g, cond)                                                                     \
+    ({                                                                                        \
+        const double t0_ = now_ms(), lim_ = emu_wait_limit_ms();                              \
+        int ok_ = 1;                                                                          \
+        while (!(cond)) {                                                                     \
+            struct timespec ts_;                                                              \
+            clock_gettime(CLOCK_REALTIME, &ts_);                                              \
+            ts_.tv_nsec += 50 * 1000 * 1000;                                                  \
+            if (ts_.tv_nsec >= 1000000000L) { ts_.tv_sec++; ts_.tv_nsec -= 1000000000L; }     \
+            pthread_cond_timedwait(&(g)->cv, &(g)->mu, &ts_);                                 \
+            if (now_ms() - t0_ > lim_) { ok_ = (cond) ? 1 : 0; break; }                       \
+        }                                                                                     \
+        ok_;                                                                                  \
+    })
+
+int hnh_comm_unique_id(void* id) {
+    if (!id) return HNH_ERR_INVALID;
+    static unsigned long counter = 0;
+    unsigned char* b = (unsigned char*)id;
+    memset(b, 0, HNH_UNIQUE_ID_BYTES);
+    pthread_mutex_lock(&g_emu_mu);
+    const unsigned long long stamp[3] = {0x686e68656d75ULL /* "hnhemu" */, (unsigned long long)getpid(), ++counter};
+    memcpy(b, stamp, sizeof stamp);
+    const double t = now_ms();
+    memcpy(b + sizeof stamp, &t, sizeof t);
+    void* grown = realloc(g_emu_ids, (size_t)(g_emu_nids + 1) * HNH_UNIQUE_ID_BYTES);
+    if (grown) { g_emu_ids = grown; memcpy(g_emu_ids[g_emu_nids++], b, HNH_UNIQUE_ID_BYTES); }
+    pthread_mutex_unlock(&g_emu_mu);
+    return grown ? HNH_OK : HNH_ERR_NOMEM;
+}
+int hnh_comm_init(hnh_ctx* c, int n, int r, const void* id, void** comm) {
+    if (!id || !comm || n <= 0 || r < 0 || r >= n) return fail(c, HNH_ERR_INVALID, "hnh_comm_init: bad argument");
+    pthread_mutex_lock(&g_emu_mu);
+    int known = 0;
+    for (int i = 0; i < g_emu_nids; i++) known |= memcmp(g_emu_ids[i], id, HNH_UNIQUE_ID_BYTES) == 0;
+    if (!known) {
+        pthread_mutex_unlock(&g_emu_mu);
+        return fail(c, HNH_ERR_UNSUPPORTED, "RCCL transport is not available in the CPU test double (the emulation joins ranks of THIS process by an id from hnh_comm_unique_id)");
+    }
+    emu_group* g = g_emu_groups;
+    for (; g; g = g->next)
+        if (memcmp(g->id, id, HNH_UNIQUE_ID_BYTES) == 0) break;
+    if (!g) {
+        g = (emu_group*)calloc(1, sizeof(emu_group));
+        if (g) {
+            memcpy(g->id, id, HNH_UNIQUE_ID_BYTES);
+            g->n = n;
+            pthread_mutex_init(&g->mu, NULL);
+            pthread_cond_init(&g->cv, NULL);
+            g->q = (emu_msg**)calloc((size_t)n * n, sizeof(emu_msg*));
+            g->contrib = (const void**)calloc((size_t)n, sizeof(void*));
+            g->contrib_clk = (uint32_t*)calloc((size_t)n * HB_T, sizeof(uint32_t));
+            g->next = g_emu_groups;
+            g_emu_groups = g;
+        }
+    }
+    pthread_mutex_unlock(&g_emu_mu);
+    if (!g || !g->q || !g->contrib || !g->contrib_clk) return fail(c, HNH_ERR_NOMEM, "hnh_comm_init: malloc failed");
+    if (g->n != n) return fail(c, HNH_ERR_INVALID, "hnh_comm_init: the ranks disagree about the communicator's size");
+    emu_comm* ec = (emu_comm*)calloc(1, sizeof(emu_comm));
+    if (!ec) return fail(c, HNH_ERR_NOMEM, "hnh_comm_init: malloc failed");
+    ec->g = g;
+    ec->rank = r;
+    pthread_mutex_lock(&g->mu);
+    g->joined++;
+    g->refs++;
+    pthread_cond_broadcast(&g->cv);
+    const int ok = EMU_WAIT(g, g->joined >= n);  /* ncclCommInitRank is collective */
+    pthread_mutex_unlock(&g->mu);
+    if (!ok) { free(ec); return fail(c, HNH_ERR_DEVICE, "hnh_comm_init: the other ranks never joined the communicator"); }
+    *comm = ec;
+    return HNH_OK;
+}
+int hnh_comm_split(hnh_ctx* c, void* comm, int color, int key, void** nc) {
+    (void)comm; (void)color; (void)key; (void)nc;
+    return fail(c, HNH_ERR_UNSUPPORTED, "hnh_comm_split is not emulated (the product does not split RCCL communicators)");
+}
+int hnh_comm_destroy(hnh_ctx* c, void* comm) {
+    (void)c;
+    emu_comm* ec = (emu_comm*)comm;
+    if (!ec) return HNH_OK;
+    pthread_mutex_lock(&ec->g->mu);
+    ec->g->refs--;
+    pthread_mutex_unlock(&ec->g->mu);  /* (the group record stays: ids are never reused) */
+    free(ec);
+    return HNH_OK;
+}
+static void emu_declare_send(emu_op* o) {
+    HB_OP(o->ctx, o->stream, "ncclSend");
+    HB_R(o->buf, o->bytes);
+    if (hb_cur.depth > 0) {
+        pthread_mutex_lock(&g_mu);
+        memcpy(o->msg->clk, hb_vc[hb_cur.t], sizeof(o->msg->clk));
+        pthread_mutex_unlock(&g_mu);
+    }
+}
+static void emu_declare_recv(emu_op* o, const emu_msg* m) {
+    HB_OP(o->ctx, o->stream, "ncclRecv");
+    if (hb_cur.depth > 0) {
+        pthread_mutex_lock(&g_mu);
+        hb_join(hb_vc[hb_cur.t], m->clk);  /* behind the matching send */
+        pthread_mutex_unlock(&g_mu);
+    }
+    HB_W(o->buf, o->bytes);
+}
+/* issues the operations collected since the outermost group began */
+static int emu_issue(hnh_ctx* c) {
+    int rc = HNH_OK;
+    const int nops = emu_nops;
+    emu_nops = 0;
+    for (int i = 0; i < nops && rc == HNH_OK; i++) {  /* 1. every send is posted */
+        emu_op* o = &emu_ops[i];
+        if (!o->is_send) continue;
+        emu_group* g = o->comm->g;
+        o->msg = (emu_msg*)calloc(1, sizeof(emu_msg));
+        if (!o->msg) { rc = fail(c, HNH_ERR_NOMEM, "malloc failed"); break; }
+        o->msg->src = o->buf;
+        o->msg->bytes = o->bytes;
+        emu_declare_send(o);
+        pthread_mutex_lock(&g->mu);
+        emu_msg** tail = &g->q[(size_t)o->comm->rank * g->n + o->peer];
+        while (*tail) tail = &(*tail)->next;
+        *tail = o->msg;
+        pthread_cond_broadcast(&g->cv);
+        pthread_mutex_unlock(&g->mu);
+    }
+    for (int i = 0; i < nops && rc == HNH_OK; i++) {  /* 2. every receive takes the oldest send of its pair */
+        emu_op* o = &emu_ops[i];
+        if (o->is_send) continue;
+        emu_group* g = o->comm->g;
+        emu_msg** head = &g->q[(size_t)o->peer * g->n + o->comm->rank];
+        pthread_mutex_lock(&g->mu);
+        emu_msg* m = NULL;
+        const int ok = EMU_WAIT(g, ({ m = *head; while (m && m->taken) m = m->next; m != NULL; }));
+        if (ok) m->taken = 1;  /* claimed: the bytes are copied outside the lock */
+        pthread_mutex_unlock(&g->mu);
+        if (!ok) { rc = fail(c, HNH_ERR_DEVICE, "ncclRecv: the peer never issued the matching ncclSend (this hangs on the GPU)"); break; }
+        if (m->bytes != o->bytes) { rc = fail(c, HNH_ERR_INVALID, "ncclSend / ncclRecv sizes of a matching pair differ (undefined on the GPU)"); }
+        else {
+            emu_declare_recv(o, m);
+            memcpy(o->buf, m->src, o->bytes);
+        }
+        pthread_mutex_lock(&g->mu);
+        m->taken = 2;  /* consumed: the sender may go on */
+        pthread_cond_broadcast(&g->cv);
+        pthread_mutex_unlock(&g->mu);
+    }
+    for (int i = 0; i < nops; i++) {  /* 3. a send is complete when its bytes were taken */
+        emu_op* o = &emu_ops[i];
+        if (!o->is_send || !o->msg) continue;
+        emu_group* g = o->comm->g;
+        pthread_mutex_lock(&g->mu);
+        const int ok = (rc == HNH_OK) ? EMU_WAIT(g, o->msg->taken == 2) : (o->msg->taken == 2);
+        if (ok) {  /* unlink and free my message */
+            for (emu_msg** q = &g->q[(size_t)o->comm->rank * g->n + o->peer]; *q; q = &(*q)->next)
+                if (*q == o->msg) { *q = o->msg->next; break; }
+            free(o->msg);
+        } else if (rc == HNH_OK) {
+            rc = fail(c, HNH_ERR_DEVICE, "ncclSend: the peer never issued the matching ncclRecv (this hangs on the GPU)");
+        }
+        pthread_mutex_unlock(&g->mu);
+    }
+    return rc;
+}
+int hnh_comm_sendrecv(hnh_ctx* c, void* comm, const void* s, size_t sb, int dst, void* r, size_t rb, int src, int st) {
+    emu_comm* ec = (emu_comm*)comm;
+    if (!ec) return fail(c, HNH_ERR_INVALID, "hnh_comm_sendrecv: null communicator");
+    if (dst < 0 || dst >= ec->g->n || src < 0 || src >= ec->g->n) return fail(c, HNH_ERR_INVALID, "hnh_comm_sendrecv: peer out of range");
+    if (emu_nops + 2 > (int)(sizeof emu_ops / sizeof emu_ops[0])) return fail(c, HNH_ERR_UNSUPPORTED, "too many operations in one group for the emulation");
+    if (sb) emu_ops[emu_nops++] = (emu_op){ec, c, 1, dst, st, (void*)s, sb, NULL};
+    if (rb) emu_ops[emu_nops++] = (emu_op){ec, c, 0, src, st, r, rb, NULL};
+    return emu_depth > 0 ? HNH_OK : emu_issue(c);
+}
+int hnh_comm_group_begin(hnh_ctx* c) { (void)c; emu_depth++; return HNH_OK; }
+int hnh_comm_group_end(hnh_ctx* c) {
+    if (emu_depth <= 0) return fail(c, HNH_ERR_INVALID, "ncclGroupEnd without ncclGroupStart");
+    return --emu_depth > 0 ? HNH_OK : emu_issue(c);
+}
+/* collectives: everybody contributes, everybody reads everybody's contribution, nobody leaves before everybody has read */
+static int emu_collective(hnh_ctx* c, emu_comm* ec, const void* send, size_t send_bytes, void* recv, size_t recv_bytes, int stream, const char* name,
+                          void (*combine)(const emu_group*, int, void*, size_t), size_t unit) {
+    emu_group* g = ec->g;
+    if (emu_depth > 0) return fail(c, HNH_ERR_UNSUPPORTED, "collectives inside a group are not emulated");
+    uint32_t mine[HB_T];
+    memset(mine, 0, sizeof mine);
+    {
+        HB_OP(c, stream, name);
+        HB_R(send, send_bytes);
+        if (hb_cur.depth > 0) { pthread_mutex_lock(&g_mu); memcpy(mine, hb_vc[hb_cur.t], sizeof mine); pthread_mutex_unlock(&g_mu); }
+    }
+    pthread_mutex_lock(&g->mu);
+    int ok = EMU_WAIT(g, g->leaving == 0);  /* the previous collective has emptied */
+    const unsigned long gen = g->gen;
+    g->contrib[ec->rank] = send;
+    memcpy(g->contrib_clk + (size_t)ec->rank * HB_T, mine, sizeof mine);
+    if (ok && ++g->arrived == g->n) { g->arrived = 0; g->leaving = g->n; g->gen++; pthread_cond_broadcast(&g->cv); }
+    ok = ok && EMU_WAIT(g, g->gen != gen);
+    pthread_mutex_unlock(&g->mu);
+    if (!ok) return fail(c, HNH_ERR_DEVICE, "a collective was not called by every rank of the communicator (this hangs on the GPU)");
+    void* tmp = malloc(recv_bytes ? recv_bytes : 1);  /* (in-place calls: nothing is written before everybody has read) */
+    if (!tmp) return fail(c, HNH_ERR_NOMEM, "malloc failed");
+    combine(g, ec->rank, tmp, unit);
+    {
+        HB_OP(c, stream, name);
+        if (hb_cur.depth > 0) {
+            pthread_mutex_lock(&g_mu);
+            for (int r = 0; r < g->n; r++) hb_join(hb_vc[hb_cur.t], g->contrib_clk + (size_t)r * HB_T);
+            pthread_mutex_unlock(&g_mu);
+        }
+        HB_W(recv, recv_bytes);
+    }
+    pthread_mutex_lock(&g->mu);
+    if (--g->leaving == 0) pthread_cond_broadcast(&g->cv);
+    ok = EMU_WAIT(g, g->leaving == 0 || g->gen != gen + 1);
+    pthread_mutex_unlock(&g->mu);
+    memcpy(recv, tmp, recv_bytes);
+    free(tmp);
+    return ok ? HNH_OK : fail(c, HNH_ERR_DEVICE, "a collective did not complete on every rank");
+}
+static void emu_allgather(const emu_group* g, int me, void* out, size_t unit) {
+    (void)me;
+    for (int r = 0; r < g->n; r++) memcpy((char*)out + (size_t)r * unit, g->contrib[r], unit);
+}
+static void emu_reduce_scatter(const emu_group* g, int me, void* out, size_t unit) {  /* unit = doubles per rank; rank order: deterministic */
+    double* o = (double*)out;
+    for (size_t i = 0; i < unit; i++) o[i] = 0.0;
+    for (int r = 0; r < g->n; r++)
+        for (size_t i = 0; i < unit; i++) o[i] += ((const double*)g->contrib[r])[(size_t)me * unit + i];
+}
+static void emu_allreduce(const emu_group* g, int me, void* out, size_t unit) {
+    (void)me;
+    double* o = (double*)out;
+    for (size_t i = 0; i < unit; i++) o[i] = 0.0;
+    for (int r = 0; r < g->n; r++)
+        for (size_t i = 0; i < unit; i++) o[i] += ((const double*)g->contrib[r])[i];
+}
+int hnh_comm_allgather(hnh_ctx* c, void* comm, const void* s, void* r, size_t b, int st) {
+    emu_comm* ec = (emu_comm*)comm;
+    if (!ec) return fail(c, HNH_ERR_INVALID, "hnh_comm_allgather: null communicator");
+    return emu_collective(c, ec, s, b, r, b * (size_t)ec->g->n, st, "ncclAllGather", emu_allgather, b);
+}
+int hnh_comm_reduce_scatter_f64(hnh_ctx* c, void* comm, const double* s, double* r, size_t n, int st) {
+    emu_comm* ec = (emu_comm*)comm;
+    if (!ec) return fail(c, HNH_ERR_INVALID, "hnh_comm_reduce_scatter_f64: null communicator");
+    return emu_collective(c, ec, s, n * (size_t)ec->g->n * sizeof(double), r, n * sizeof(double), st, "ncclReduceScatter", emu_reduce_scatter, n);
+}
+int hnh_comm_allreduce_f64(hnh_ctx* c, void* comm, const double* s, double* r, size_t n, int st) {
+    emu_comm* ec = (emu_comm*)comm;
+    if (!ec) return fail(c, HNH_ERR_INVALID, "hnh_comm_allreduce_f64: null communicator");
+    return emu_collective(c, ec, s, n * sizeof(double), r, n * sizeof(double), st, "ncclAllReduce", emu_allreduce, n);
+}
 
 /* ---- the "ipc" section of the ABI between PROCESSES of this host: a handle is (pid, address); an opened block is a reserved,
  * inaccessible address range standing for the peer's block; a pull reads the peer's memory with process_vm_readv; flag words
