@@ -222,3 +222,26 @@ def test_a_kernel_that_touches_a_buffer_in_flight_is_a_race(checker):
     n, text = checker()
     # (two reports: against the send, and against the fill on the communication stream that the send was ordered behind)
     assert n == 2 and "RACE hnh_fill_f64 (write, context" in text and "vs ncclSend (read" in text and "ncclRecv" not in text, text
+
+
+def test_random_configurations_over_the_rccl_emulation(checker, monkeypatch):
+    """The fuzz generator of tests/test_fuzz_cpu.py (schedule x grid incl. remainders x sizes incl. M < p x every host switch, ALS twice)
+    with its ranks on RcclWorld: a fixed sample here; a one-off exploration of 4 x 500 draws (1 408 valid configurations) was clean."""
+    import random
+    import test_fuzz_cpu as F
+    monkeypatch.setenv("HNH_ORACLE_COMM_WAIT_S", "60")
+    monkeypatch.setattr(H, "run_spmd", over_rccl)
+    saved = {k: os.environ.get(k) for k in F.KNOBS}
+    rng, done = random.Random(21), 0
+    try:
+        for it in range(14):
+            done += 1 if F.one(rng, it) else 0
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert done >= 6
+    n, text = checker()
+    assert n == 0, text
