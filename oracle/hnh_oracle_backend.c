@@ -1003,112 +1003,138 @@ int hnh_tuples_relabel(hnh_ctx* c, hnh_tuple* t, int64_t n, const uint64_t* row_
     return HNH_OK;
 }
 
-/* ---- the RCCL section of the ABI, EMULATED between ranks that are threads of this process (tests/test_rccl_emulation_cpu.py).
- * What is emulated is the calling contract the product's default transport (RcclWorld) depends on, as NCCL / RCCL document it:
+/* ---- the RCCL section of the ABI, EMULATED between ranks that are threads of this process or processes of this host
+ * (tests/test_rccl_emulation_cpu.py).  What is emulated is the calling contract the product's default transport (RcclWorld) depends
+ * on, as NCCL / RCCL document it:
  *   - a communicator is formed by all n ranks calling init with the same unique id (collective);
  *   - point-to-point operations of one ncclGroupStart/End are issued together; a send and a receive match in the ORDER they were issued
  *     for their (source, destination) pair on the communicator, and their sizes must agree;
  *   - collectives are called by every rank of the communicator in the same order;
  *   - an operation that never finds its partner hangs on the GPU — here it fails after HNH_ORACLE_COMM_WAIT_S (default 120 s).
- * Data moves with memcpy; the stream-order checker sees a send as a read of its buffer on the sender's stream, a receive as a write on
- * the receiver's stream that runs behind the matching send, a collective as running behind every rank's contribution. */
-typedef struct emu_msg { const void* src; size_t bytes; int taken; uint32_t clk[HB_T]; struct emu_msg* next; } emu_msg;
-typedef struct emu_group {
-    unsigned char id[HNH_UNIQUE_ID_BYTES];
-    int n, joined, refs;
-    pthread_mutex_t mu;
-    pthread_cond_t cv;
-    emu_msg** q;          /* n * n FIFOs, q[src * n + dst] */
-    int arrived, leaving; /* collectives: two-phase meeting */
-    unsigned long gen;
-    const void** contrib; /* n send buffers of the collective in flight */
-    uint32_t* contrib_clk;
-    struct emu_group* next;
-} emu_group;
-typedef struct emu_comm { emu_group* g; int rank; } emu_comm;
-typedef struct emu_op { emu_comm* comm; hnh_ctx* ctx; int is_send, peer, stream; void* buf; size_t bytes; emu_msg* msg; } emu_op;
-static emu_group* g_emu_groups = NULL;
-static unsigned char (*g_emu_ids)[HNH_UNIQUE_ID_BYTES] = NULL;
-static int g_emu_nids = 0;
-static pthread_mutex_t g_emu_mu = PTHREAD_MUTEX_INITIALIZER;
+ * The communicator's state lives in a shared-memory segment named after the unique id (descriptor rings per ordered pair, one meeting
+ * point for collectives); bytes move with memcpy inside a process and process_vm_readv between processes.  Inside one process the
+ * stream-order checker sees a send as a read of its buffer on the sender's stream, a receive as a write on the receiver's stream that
+ * runs behind the matching send, a collective as running behind every rank's contribution. */
+#include <fcntl.h>
+#include <stdatomic.h>
+#include <sys/stat.h>
+#define EMU_MAX_RANKS 32
+#define EMU_RING 64
+#define EMU_MAGIC 0x686e68656d7532ULL /* "hnhemu2" */
+typedef struct emu_desc { _Atomic unsigned state; /* 0 free, 1 posted, 2 claimed, 3 consumed */ long pid; unsigned long long addr, bytes; unsigned long token; } emu_desc;
+typedef struct emu_pair { _Atomic unsigned long posted, claimed; emu_desc ring[EMU_RING]; } emu_pair;
+typedef struct emu_coll {
+    _Atomic unsigned long gen;
+    _Atomic int arrived, leaving;
+    long pid[EMU_MAX_RANKS];
+    unsigned long long addr[EMU_MAX_RANKS];
+    unsigned long token[EMU_MAX_RANKS];
+} emu_coll;
+typedef struct emu_shared {
+    _Atomic unsigned long long magic;
+    _Atomic int n, joined;
+    emu_coll coll;
+    emu_pair pair[EMU_MAX_RANKS * EMU_MAX_RANKS];
+} emu_shared;
+typedef struct emu_comm { emu_shared* g; int rank, n; } emu_comm;
+typedef struct emu_op { emu_comm* comm; hnh_ctx* ctx; int is_send, peer, stream; void* buf; size_t bytes; emu_desc* desc; } emu_op;
 static __thread int emu_depth = 0, emu_nops = 0;
 static __thread emu_op emu_ops[1024];
+/* clocks of this process's sends / contributions, by token (the checker's edges exist inside one process only) */
+#define EMU_TOKENS 4096
+static uint32_t (*emu_clk)[HB_T] = NULL;
+static unsigned long emu_next_token = 0;
 
 static double emu_wait_limit_ms(void) {
     const char* v = getenv("HNH_ORACLE_COMM_WAIT_S");
     return (v && *v ? atof(v) : 120.0) * 1e3;
 }
-/* waits on g->cv (g->mu held) until *cond; 0 = timed out */
-#define EMU_WAIT(g, cond)                                                                     \
-    ({                                                                                        \
-        const double t0_ = now_ms(), lim_ = emu_wait_limit_ms();                              \
-        int ok_ = 1;                                                                          \
-        while (!(cond)) {                                                                     \
-            struct timespec ts_;                                                              \
-            clock_gettime(CLOCK_REALTIME, &ts_);                                              \
-            ts_.tv_nsec += 50 * 1000 * 1000;                                                  \
-            if (ts_.tv_nsec >= 1000000000L) { ts_.tv_sec++; ts_.tv_nsec -= 1000000000L; }     \
-            pthread_cond_timedwait(&(g)->cv, &(g)->mu, &ts_);                                 \
-            if (now_ms() - t0_ > lim_) { ok_ = (cond) ? 1 : 0; break; }                       \
-        }                                                                                     \
-        ok_;                                                                                  \
+/* polls until cond; evaluates to 0 when the time limit passed first */
+#define EMU_POLL(cond)                                                       \
+    ({                                                                       \
+        const double t0_ = now_ms(), lim_ = emu_wait_limit_ms();             \
+        int ok_ = 1;                                                         \
+        for (unsigned spins_ = 0; !(cond); spins_++) {                       \
+            if (spins_ > 200) { struct timespec ts_ = {0, 20000}; nanosleep(&ts_, NULL); } \
+            if ((spins_ & 255) == 255 && now_ms() - t0_ > lim_) { ok_ = (cond) ? 1 : 0; break; } \
+        }                                                                    \
+        ok_;                                                                 \
     })
+static unsigned long emu_store_clock(void) {  /* the current call's clock, kept for receivers of this process */
+    if (hb_cur.depth <= 0) return 0;
+    pthread_mutex_lock(&g_mu);
+    if (!emu_clk) emu_clk = calloc(EMU_TOKENS, sizeof *emu_clk);
+    const unsigned long token = ++emu_next_token;
+    if (emu_clk) memcpy(emu_clk[token % EMU_TOKENS], hb_vc[hb_cur.t], sizeof emu_clk[0]);
+    pthread_mutex_unlock(&g_mu);
+    return token;
+}
+static void emu_join_clock(long pid, unsigned long token) {
+    if (hb_cur.depth <= 0 || !token || pid != (long)getpid() || !emu_clk) return;
+    pthread_mutex_lock(&g_mu);
+    hb_join(hb_vc[hb_cur.t], emu_clk[token % EMU_TOKENS]);
+    pthread_mutex_unlock(&g_mu);
+}
+static int emu_fetch(void* dst, long pid, unsigned long long addr, size_t bytes) {  /* a peer's bytes */
+    if (pid == (long)getpid()) { memcpy(dst, (const void*)(uintptr_t)addr, bytes); return 1; }
+    for (size_t done = 0; done < bytes;) {
+        struct iovec l = {(char*)dst + done, bytes - done}, r = {(void*)(uintptr_t)(addr + done), bytes - done};
+        const ssize_t k = process_vm_readv((pid_t)pid, &l, 1, &r, 1, 0);
+        if (k <= 0) return 0;
+        done += (size_t)k;
+    }
+    return 1;
+}
 
 int hnh_comm_unique_id(void* id) {
     if (!id) return HNH_ERR_INVALID;
-    static unsigned long counter = 0;
+    static _Atomic unsigned long counter = 0;
     unsigned char* b = (unsigned char*)id;
     memset(b, 0, HNH_UNIQUE_ID_BYTES);
-    pthread_mutex_lock(&g_emu_mu);
-    const unsigned long long stamp[3] = {0x686e68656d75ULL /* "hnhemu" */, (unsigned long long)getpid(), ++counter};
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    const unsigned long long stamp[4] = {EMU_MAGIC, (unsigned long long)getpid(), ++counter, (unsigned long long)ts.tv_sec * 1000000000ULL + (unsigned long long)ts.tv_nsec};
     memcpy(b, stamp, sizeof stamp);
-    const double t = now_ms();
-    memcpy(b + sizeof stamp, &t, sizeof t);
-    void* grown = realloc(g_emu_ids, (size_t)(g_emu_nids + 1) * HNH_UNIQUE_ID_BYTES);
-    if (grown) { g_emu_ids = grown; memcpy(g_emu_ids[g_emu_nids++], b, HNH_UNIQUE_ID_BYTES); }
-    pthread_mutex_unlock(&g_emu_mu);
-    return grown ? HNH_OK : HNH_ERR_NOMEM;
+    return HNH_OK;
 }
 int hnh_comm_init(hnh_ctx* c, int n, int r, const void* id, void** comm) {
     if (!id || !comm || n <= 0 || r < 0 || r >= n) return fail(c, HNH_ERR_INVALID, "hnh_comm_init: bad argument");
-    pthread_mutex_lock(&g_emu_mu);
-    int known = 0;
-    for (int i = 0; i < g_emu_nids; i++) known |= memcmp(g_emu_ids[i], id, HNH_UNIQUE_ID_BYTES) == 0;
-    if (!known) {
-        pthread_mutex_unlock(&g_emu_mu);
-        return fail(c, HNH_ERR_UNSUPPORTED, "RCCL transport is not available in the CPU test double (the emulation joins ranks of THIS process by an id from hnh_comm_unique_id)");
+    unsigned long long stamp[4];
+    memcpy(stamp, id, sizeof stamp);
+    if (stamp[0] != EMU_MAGIC)
+        return fail(c, HNH_ERR_UNSUPPORTED, "RCCL transport is not available in the CPU test double (its emulation joins ranks of this host by an id from hnh_comm_unique_id)");
+    if (n > EMU_MAX_RANKS) return fail(c, HNH_ERR_UNSUPPORTED, "the RCCL emulation takes up to 32 ranks");
+    char name[96];
+    snprintf(name, sizeof name, "/hnh_emu_%llx_%llx_%llx", stamp[1], stamp[2], stamp[3]);
+    int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    const int creator = fd >= 0;
+    if (creator) {
+        if (ftruncate(fd, (off_t)sizeof(emu_shared)) != 0) { close(fd); shm_unlink(name); return fail(c, HNH_ERR_NOMEM, "hnh_comm_init: cannot size the communicator's segment"); }
+    } else {
+        struct stat st;
+        const int ok = EMU_POLL(({ fd = shm_open(name, O_RDWR, 0600); int good = fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(emu_shared); if (!good && fd >= 0) { close(fd); fd = -1; } good; }));
+        if (!ok) return fail(c, HNH_ERR_DEVICE, "hnh_comm_init: the communicator's segment never appeared");
     }
-    emu_group* g = g_emu_groups;
-    for (; g; g = g->next)
-        if (memcmp(g->id, id, HNH_UNIQUE_ID_BYTES) == 0) break;
-    if (!g) {
-        g = (emu_group*)calloc(1, sizeof(emu_group));
-        if (g) {
-            memcpy(g->id, id, HNH_UNIQUE_ID_BYTES);
-            g->n = n;
-            pthread_mutex_init(&g->mu, NULL);
-            pthread_cond_init(&g->cv, NULL);
-            g->q = (emu_msg**)calloc((size_t)n * n, sizeof(emu_msg*));
-            g->contrib = (const void**)calloc((size_t)n, sizeof(void*));
-            g->contrib_clk = (uint32_t*)calloc((size_t)n * HB_T, sizeof(uint32_t));
-            g->next = g_emu_groups;
-            g_emu_groups = g;
-        }
+    emu_shared* g = (emu_shared*)mmap(NULL, sizeof(emu_shared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (g == MAP_FAILED) return fail(c, HNH_ERR_NOMEM, "hnh_comm_init: cannot map the communicator's segment");
+    if (creator) {  /* (a fresh segment is zero-filled: every ring empty) */
+        atomic_store(&g->n, n);
+        atomic_store(&g->magic, EMU_MAGIC);
+    } else if (!EMU_POLL(atomic_load(&g->magic) == EMU_MAGIC)) {
+        munmap(g, sizeof(emu_shared));
+        return fail(c, HNH_ERR_DEVICE, "hnh_comm_init: the communicator's segment was never initialised");
     }
-    pthread_mutex_unlock(&g_emu_mu);
-    if (!g || !g->q || !g->contrib || !g->contrib_clk) return fail(c, HNH_ERR_NOMEM, "hnh_comm_init: malloc failed");
-    if (g->n != n) return fail(c, HNH_ERR_INVALID, "hnh_comm_init: the ranks disagree about the communicator's size");
+    if (atomic_load(&g->n) != n) { munmap(g, sizeof(emu_shared)); return fail(c, HNH_ERR_INVALID, "hnh_comm_init: the ranks disagree about the communicator's size"); }
+    atomic_fetch_add(&g->joined, 1);
+    const int all = EMU_POLL(atomic_load(&g->joined) >= n);  /* ncclCommInitRank is collective */
+    if (creator) shm_unlink(name);  /* everybody who will ever join has it open (or never will) */
+    if (!all) { munmap(g, sizeof(emu_shared)); return fail(c, HNH_ERR_DEVICE, "hnh_comm_init: the other ranks never joined the communicator"); }
     emu_comm* ec = (emu_comm*)calloc(1, sizeof(emu_comm));
-    if (!ec) return fail(c, HNH_ERR_NOMEM, "hnh_comm_init: malloc failed");
+    if (!ec) { munmap(g, sizeof(emu_shared)); return fail(c, HNH_ERR_NOMEM, "hnh_comm_init: malloc failed"); }
     ec->g = g;
     ec->rank = r;
-    pthread_mutex_lock(&g->mu);
-    g->joined++;
-    g->refs++;
-    pthread_cond_broadcast(&g->cv);
-    const int ok = EMU_WAIT(g, g->joined >= n);  /* ncclCommInitRank is collective */
-    pthread_mutex_unlock(&g->mu);
-    if (!ok) { free(ec); return fail(c, HNH_ERR_DEVICE, "hnh_comm_init: the other ranks never joined the communicator"); }
+    ec->n = n;
     *comm = ec;
     return HNH_OK;
 }
@@ -1120,28 +1146,18 @@ int hnh_comm_destroy(hnh_ctx* c, void* comm) {
     (void)c;
     emu_comm* ec = (emu_comm*)comm;
     if (!ec) return HNH_OK;
-    pthread_mutex_lock(&ec->g->mu);
-    ec->g->refs--;
-    pthread_mutex_unlock(&ec->g->mu);  /* (the group record stays: ids are never reused) */
+    munmap(ec->g, sizeof(emu_shared));
     free(ec);
     return HNH_OK;
 }
 static void emu_declare_send(emu_op* o) {
     HB_OP(o->ctx, o->stream, "ncclSend");
     HB_R(o->buf, o->bytes);
-    if (hb_cur.depth > 0) {
-        pthread_mutex_lock(&g_mu);
-        memcpy(o->msg->clk, hb_vc[hb_cur.t], sizeof(o->msg->clk));
-        pthread_mutex_unlock(&g_mu);
-    }
+    o->desc->token = emu_store_clock();
 }
-static void emu_declare_recv(emu_op* o, const emu_msg* m) {
+static void emu_declare_recv(emu_op* o, const emu_desc* d) {
     HB_OP(o->ctx, o->stream, "ncclRecv");
-    if (hb_cur.depth > 0) {
-        pthread_mutex_lock(&g_mu);
-        hb_join(hb_vc[hb_cur.t], m->clk);  /* behind the matching send */
-        pthread_mutex_unlock(&g_mu);
-    }
+    emu_join_clock(d->pid, d->token);  /* behind the matching send */
     HB_W(o->buf, o->bytes);
 }
 /* issues the operations collected since the outermost group began */
@@ -1149,64 +1165,52 @@ static int emu_issue(hnh_ctx* c) {
     int rc = HNH_OK;
     const int nops = emu_nops;
     emu_nops = 0;
-    for (int i = 0; i < nops && rc == HNH_OK; i++) {  /* 1. every send is posted */
+    for (int i = 0; i < nops && rc == HNH_OK; i++) {  /* 1. every send is posted: the next descriptor of its pair's ring */
         emu_op* o = &emu_ops[i];
         if (!o->is_send) continue;
-        emu_group* g = o->comm->g;
-        o->msg = (emu_msg*)calloc(1, sizeof(emu_msg));
-        if (!o->msg) { rc = fail(c, HNH_ERR_NOMEM, "malloc failed"); break; }
-        o->msg->src = o->buf;
-        o->msg->bytes = o->bytes;
+        emu_pair* pr = &o->comm->g->pair[o->comm->rank * EMU_MAX_RANKS + o->peer];
+        emu_desc* d = &pr->ring[atomic_load(&pr->posted) % EMU_RING];
+        if (!EMU_POLL(atomic_load(&d->state) == 0)) { rc = fail(c, HNH_ERR_DEVICE, "ncclSend: too many sends of this pair were never received (this hangs on the GPU)"); break; }
+        o->desc = d;
+        d->pid = (long)getpid();
+        d->addr = (unsigned long long)(uintptr_t)o->buf;
+        d->bytes = o->bytes;
         emu_declare_send(o);
-        pthread_mutex_lock(&g->mu);
-        emu_msg** tail = &g->q[(size_t)o->comm->rank * g->n + o->peer];
-        while (*tail) tail = &(*tail)->next;
-        *tail = o->msg;
-        pthread_cond_broadcast(&g->cv);
-        pthread_mutex_unlock(&g->mu);
+        atomic_store(&d->state, 1);
+        atomic_fetch_add(&pr->posted, 1);
     }
-    for (int i = 0; i < nops && rc == HNH_OK; i++) {  /* 2. every receive takes the oldest send of its pair */
+    for (int i = 0; i < nops && rc == HNH_OK; i++) {  /* 2. every receive takes the oldest unclaimed send of its pair */
         emu_op* o = &emu_ops[i];
         if (o->is_send) continue;
-        emu_group* g = o->comm->g;
-        emu_msg** head = &g->q[(size_t)o->peer * g->n + o->comm->rank];
-        pthread_mutex_lock(&g->mu);
-        emu_msg* m = NULL;
-        const int ok = EMU_WAIT(g, ({ m = *head; while (m && m->taken) m = m->next; m != NULL; }));
-        if (ok) m->taken = 1;  /* claimed: the bytes are copied outside the lock */
-        pthread_mutex_unlock(&g->mu);
-        if (!ok) { rc = fail(c, HNH_ERR_DEVICE, "ncclRecv: the peer never issued the matching ncclSend (this hangs on the GPU)"); break; }
-        if (m->bytes != o->bytes) { rc = fail(c, HNH_ERR_INVALID, "ncclSend / ncclRecv sizes of a matching pair differ (undefined on the GPU)"); }
+        emu_pair* pr = &o->comm->g->pair[o->peer * EMU_MAX_RANKS + o->comm->rank];
+        const unsigned long idx = atomic_load(&pr->claimed);
+        emu_desc* d = &pr->ring[idx % EMU_RING];
+        if (!EMU_POLL(atomic_load(&pr->posted) > idx && atomic_load(&d->state) == 1)) {
+            rc = fail(c, HNH_ERR_DEVICE, "ncclRecv: the peer never issued the matching ncclSend (this hangs on the GPU)");
+            break;
+        }
+        atomic_store(&d->state, 2);
+        atomic_fetch_add(&pr->claimed, 1);
+        if (d->bytes != o->bytes) rc = fail(c, HNH_ERR_INVALID, "ncclSend / ncclRecv sizes of a matching pair differ (undefined on the GPU)");
         else {
-            emu_declare_recv(o, m);
-            memcpy(o->buf, m->src, o->bytes);
+            emu_declare_recv(o, d);
+            if (!emu_fetch(o->buf, d->pid, d->addr, o->bytes)) rc = fail(c, HNH_ERR_DEVICE, "ncclRecv: cannot read the peer's memory (process_vm_readv: ptrace permission?)");
         }
-        pthread_mutex_lock(&g->mu);
-        m->taken = 2;  /* consumed: the sender may go on */
-        pthread_cond_broadcast(&g->cv);
-        pthread_mutex_unlock(&g->mu);
+        atomic_store(&d->state, 3);  /* consumed: the sender may go on */
     }
-    for (int i = 0; i < nops; i++) {  /* 3. a send is complete when its bytes were taken */
+    for (int i = 0; i < nops; i++) {  /* 3. a send is complete when its bytes were taken; its descriptor is free again */
         emu_op* o = &emu_ops[i];
-        if (!o->is_send || !o->msg) continue;
-        emu_group* g = o->comm->g;
-        pthread_mutex_lock(&g->mu);
-        const int ok = (rc == HNH_OK) ? EMU_WAIT(g, o->msg->taken == 2) : (o->msg->taken == 2);
-        if (ok) {  /* unlink and free my message */
-            for (emu_msg** q = &g->q[(size_t)o->comm->rank * g->n + o->peer]; *q; q = &(*q)->next)
-                if (*q == o->msg) { *q = o->msg->next; break; }
-            free(o->msg);
-        } else if (rc == HNH_OK) {
+        if (!o->is_send || !o->desc) continue;
+        if (rc == HNH_OK && !EMU_POLL(atomic_load(&o->desc->state) == 3))
             rc = fail(c, HNH_ERR_DEVICE, "ncclSend: the peer never issued the matching ncclRecv (this hangs on the GPU)");
-        }
-        pthread_mutex_unlock(&g->mu);
+        if (atomic_load(&o->desc->state) == 3) atomic_store(&o->desc->state, 0);
     }
     return rc;
 }
 int hnh_comm_sendrecv(hnh_ctx* c, void* comm, const void* s, size_t sb, int dst, void* r, size_t rb, int src, int st) {
     emu_comm* ec = (emu_comm*)comm;
     if (!ec) return fail(c, HNH_ERR_INVALID, "hnh_comm_sendrecv: null communicator");
-    if (dst < 0 || dst >= ec->g->n || src < 0 || src >= ec->g->n) return fail(c, HNH_ERR_INVALID, "hnh_comm_sendrecv: peer out of range");
+    if (dst < 0 || dst >= ec->n || src < 0 || src >= ec->n) return fail(c, HNH_ERR_INVALID, "hnh_comm_sendrecv: peer out of range");
     if (emu_nops + 2 > (int)(sizeof emu_ops / sizeof emu_ops[0])) return fail(c, HNH_ERR_UNSUPPORTED, "too many operations in one group for the emulation");
     if (sb) emu_ops[emu_nops++] = (emu_op){ec, c, 1, dst, st, (void*)s, sb, NULL};
     if (rb) emu_ops[emu_nops++] = (emu_op){ec, c, 0, src, st, r, rb, NULL};
@@ -1219,71 +1223,74 @@ int hnh_comm_group_end(hnh_ctx* c) {
 }
 /* collectives: everybody contributes, everybody reads everybody's contribution, nobody leaves before everybody has read */
 static int emu_collective(hnh_ctx* c, emu_comm* ec, const void* send, size_t send_bytes, void* recv, size_t recv_bytes, int stream, const char* name,
-                          void (*combine)(const emu_group*, int, void*, size_t), size_t unit) {
-    emu_group* g = ec->g;
+                          void (*combine)(int n, int me, void* const* contrib, void* out, size_t unit), size_t unit) {
+    emu_coll* k = &ec->g->coll;
+    const int n = ec->n;
     if (emu_depth > 0) return fail(c, HNH_ERR_UNSUPPORTED, "collectives inside a group are not emulated");
-    uint32_t mine[HB_T];
-    memset(mine, 0, sizeof mine);
+    if (!EMU_POLL(atomic_load(&k->leaving) == 0)) return fail(c, HNH_ERR_DEVICE, "a previous collective never completed");
+    const unsigned long gen = atomic_load(&k->gen);
     {
         HB_OP(c, stream, name);
         HB_R(send, send_bytes);
-        if (hb_cur.depth > 0) { pthread_mutex_lock(&g_mu); memcpy(mine, hb_vc[hb_cur.t], sizeof mine); pthread_mutex_unlock(&g_mu); }
+        k->token[ec->rank] = emu_store_clock();
     }
-    pthread_mutex_lock(&g->mu);
-    int ok = EMU_WAIT(g, g->leaving == 0);  /* the previous collective has emptied */
-    const unsigned long gen = g->gen;
-    g->contrib[ec->rank] = send;
-    memcpy(g->contrib_clk + (size_t)ec->rank * HB_T, mine, sizeof mine);
-    if (ok && ++g->arrived == g->n) { g->arrived = 0; g->leaving = g->n; g->gen++; pthread_cond_broadcast(&g->cv); }
-    ok = ok && EMU_WAIT(g, g->gen != gen);
-    pthread_mutex_unlock(&g->mu);
-    if (!ok) return fail(c, HNH_ERR_DEVICE, "a collective was not called by every rank of the communicator (this hangs on the GPU)");
-    void* tmp = malloc(recv_bytes ? recv_bytes : 1);  /* (in-place calls: nothing is written before everybody has read) */
-    if (!tmp) return fail(c, HNH_ERR_NOMEM, "malloc failed");
-    combine(g, ec->rank, tmp, unit);
+    k->pid[ec->rank] = (long)getpid();
+    k->addr[ec->rank] = (unsigned long long)(uintptr_t)send;
+    if (atomic_fetch_add(&k->arrived, 1) + 1 == n) {
+        atomic_store(&k->arrived, 0);
+        atomic_store(&k->leaving, n);
+        atomic_fetch_add(&k->gen, 1);
+    }
+    if (!EMU_POLL(atomic_load(&k->gen) != gen)) return fail(c, HNH_ERR_DEVICE, "a collective was not called by every rank of the communicator (this hangs on the GPU)");
+    /* everybody's contribution, fetched whole (peers in other processes: a copy); nothing is written before everybody has read */
+    int rc = HNH_OK;
+    void* contrib[EMU_MAX_RANKS];
+    for (int r = 0; r < n; r++) {
+        contrib[r] = malloc(send_bytes ? send_bytes : 1);
+        if (!contrib[r] || !emu_fetch(contrib[r], k->pid[r], k->addr[r], send_bytes)) rc = fail(c, HNH_ERR_DEVICE, "a collective cannot read a peer's contribution");
+    }
+    void* tmp = malloc(recv_bytes ? recv_bytes : 1);
+    if (!tmp) rc = fail(c, HNH_ERR_NOMEM, "malloc failed");
+    if (rc == HNH_OK) combine(n, ec->rank, contrib, tmp, unit);
     {
         HB_OP(c, stream, name);
-        if (hb_cur.depth > 0) {
-            pthread_mutex_lock(&g_mu);
-            for (int r = 0; r < g->n; r++) hb_join(hb_vc[hb_cur.t], g->contrib_clk + (size_t)r * HB_T);
-            pthread_mutex_unlock(&g_mu);
-        }
+        for (int r = 0; r < n; r++) emu_join_clock(k->pid[r], k->token[r]);
         HB_W(recv, recv_bytes);
     }
-    pthread_mutex_lock(&g->mu);
-    if (--g->leaving == 0) pthread_cond_broadcast(&g->cv);
-    ok = EMU_WAIT(g, g->leaving == 0 || g->gen != gen + 1);
-    pthread_mutex_unlock(&g->mu);
-    memcpy(recv, tmp, recv_bytes);
+    for (int r = 0; r < n; r++) free(contrib[r]);
+    atomic_fetch_sub(&k->leaving, 1);
+    const int ok = EMU_POLL(atomic_load(&k->leaving) == 0 || atomic_load(&k->gen) != gen + 1);
+    if (rc == HNH_OK && tmp) memcpy(recv, tmp, recv_bytes);
     free(tmp);
+    if (rc != HNH_OK) return rc;
     return ok ? HNH_OK : fail(c, HNH_ERR_DEVICE, "a collective did not complete on every rank");
 }
-static void emu_allgather(const emu_group* g, int me, void* out, size_t unit) {
+static void emu_allgather(int n, int me, void* const* contrib, void* out, size_t unit) {
     (void)me;
-    for (int r = 0; r < g->n; r++) memcpy((char*)out + (size_t)r * unit, g->contrib[r], unit);
+    for (int r = 0; r < n; r++) memcpy((char*)out + (size_t)r * unit, contrib[r], unit);
 }
-static void emu_reduce_scatter(const emu_group* g, int me, void* out, size_t unit) {  /* unit = doubles per rank; rank order: deterministic */
+static void emu_reduce_scatter(int n, int me, void* const* contrib, void* out, size_t unit) {  /* unit = doubles per rank; rank order: deterministic */
     double* o = (double*)out;
     for (size_t i = 0; i < unit; i++) o[i] = 0.0;
-    for (int r = 0; r < g->n; r++)
-        for (size_t i = 0; i < unit; i++) o[i] += ((const double*)g->contrib[r])[(size_t)me * unit + i];
+    for (int r = 0; r < n; r++)
+        for (size_t i = 0; i < unit; i++) o[i] += ((const double*)contrib[r])[(size_t)me * unit + i];
 }
-static void emu_allreduce(const emu_group* g, int me, void* out, size_t unit) {
+static void emu_allreduce(int n, int me, void* const* contrib, void* out, size_t unit) {
     (void)me;
     double* o = (double*)out;
     for (size_t i = 0; i < unit; i++) o[i] = 0.0;
-    for (int r = 0; r < g->n; r++)
-        for (size_t i = 0; i < unit; i++) o[i] += ((const double*)g->contrib[r])[i];
+    for (int r = 0; r < n; r++)
+        for (size_t i = 0; i < unit; i++) o[i] += ((const double*)contrib[r])[i];
 }
 int hnh_comm_allgather(hnh_ctx* c, void* comm, const void* s, void* r, size_t b, int st) {
     emu_comm* ec = (emu_comm*)comm;
     if (!ec) return fail(c, HNH_ERR_INVALID, "hnh_comm_allgather: null communicator");
-    return emu_collective(c, ec, s, b, r, b * (size_t)ec->g->n, st, "ncclAllGather", emu_allgather, b);
+    return emu_collective(c, ec, s, b, r, b * (size_t)ec->n, st, "ncclAllGather", emu_allgather, b);
 }
 int hnh_comm_reduce_scatter_f64(hnh_ctx* c, void* comm, const double* s, double* r, size_t n, int st) {
     emu_comm* ec = (emu_comm*)comm;
     if (!ec) return fail(c, HNH_ERR_INVALID, "hnh_comm_reduce_scatter_f64: null communicator");
-    return emu_collective(c, ec, s, n * (size_t)ec->g->n * sizeof(double), r, n * sizeof(double), st, "ncclReduceScatter", emu_reduce_scatter, n);
+    return emu_collective(c, ec, s, n * (size_t)ec->n * sizeof(double), r, n * sizeof(double), st, "ncclReduceScatter", emu_reduce_scatter, n);
 }
 int hnh_comm_allreduce_f64(hnh_ctx* c, void* comm, const double* s, double* r, size_t n, int st) {
     emu_comm* ec = (emu_comm*)comm;

@@ -20,9 +20,16 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     dist.init_process_group(backend="gloo", rank=rank, world_size=n)
-    device = rank % torch.cuda.device_count()
-    torch.cuda.set_device(device)
-    assert H.load_backend(None) == "hip-gfx950"
+    # HNH_RCCL_WORKER_DOUBLE=1 (tests/test_rccl_emulation_cpu.py): the same worker without GPUs — the kernel test double, whose RCCL section
+    # emulates RCCL's calling contract between the processes of this host
+    double = os.environ.get("HNH_RCCL_WORKER_DOUBLE") == "1"
+    if double:
+        device, backend = 0, "oracle-cpu-test-double"
+        assert H.load_backend(T.ORACLE_BACKEND) == backend
+    else:
+        device, backend = rank % torch.cuda.device_count(), "hip-gfx950"
+        torch.cuda.set_device(device)
+        assert H.load_backend(None) == backend
     ident = [H.rccl_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(ident, src=0)
     world = H.World.rccl(rank, n, device, ident[0])
@@ -53,7 +60,7 @@ def main():
         if rank == 0:
             try:
                 T.check_against_golden(T.assemble(gathered, case), gathered, case, alg)
-                assert gathered[0]["alg_info"]["transport"] == "rccl" and gathered[0]["alg_info"]["backend"] == "hip-gfx950"
+                assert gathered[0]["alg_info"]["transport"] == "rccl" and gathered[0]["alg_info"]["backend"] == backend
             except AssertionError as e:
                 failures.append("%s: %r" % (item, e))
     world.close()

@@ -1,5 +1,6 @@
 """RcclWorld — the product's default multi-GPU transport — across 2 / 4 / 8 ranks WITHOUT GPUs: the RCCL section of the kernel ABI
-emulated by the test double between ranks that are threads of one process (oracle/hnh_oracle_backend.c, "the RCCL section ... EMULATED").
+emulated by the test double between ranks that are threads of one process or processes of one host (oracle/hnh_oracle_backend.c,
+"the RCCL section ... EMULATED": the communicator's state in a shared-memory segment named after the unique id).
 
 What the emulation holds the host layer to is the calling contract RCCL / NCCL document, which is all RcclWorld depends on: the
 communicator is formed collectively from one unique id; the point-to-point operations of one ncclGroupStart/End are issued together;
@@ -245,3 +246,33 @@ def test_random_configurations_over_the_rccl_emulation(checker, monkeypatch):
     assert done >= 6
     n, text = checker()
     assert n == 0, text
+
+
+@pytest.mark.parametrize("nranks,configs", [(2, ALL_2), (4, ALL_4)], ids=["2", "4"])
+def test_the_gpu_tests_worker_as_processes_over_the_rccl_emulation(nranks, configs):
+    """tests/rccl_worker.py — the worker of the GPU test: one PROCESS per rank, the unique id handed round through torch.distributed,
+    RcclWorld, the preflight, every configuration against the golden vectors — with the kernel test double in place of the HIP library:
+    the emulation's segment lives in shared memory and the bytes move with process_vm_readv."""
+    import subprocess
+    import sys
+    from test_gloo_world import ROOT, free_port
+    from test_ipc_world_cpu import can_read_peer_memory
+    if not can_read_peer_memory():
+        pytest.skip("process_vm_readv between own processes is not permitted here")
+    port = free_port()
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo",
+                   OMP_NUM_THREADS="2", HNH_RCCL_WORKER_DOUBLE="1", HNH_ORACLE_COMM_WAIT_S="120")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py"), "er8_r16", configs], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=600)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    assert "RCCL_OK" in outs[0], outs[0][-3000:]

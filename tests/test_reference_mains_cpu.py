@@ -167,3 +167,30 @@ def test_the_references_launch_line_with_mpiexec(mains):
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert [(x["alg_name"], x["alg_info"]["p"], x["alg_info"]["c"], x["alg_info"]["transport"]) for x in records(out)] == [
         ("15d_fusion1", 4, 2, "ipc-pull"), ("15d_fusion2", 4, 2, "ipc-pull")]
+
+
+def test_the_references_launch_line_on_the_default_transport(mains):
+    """The same launch line with NOTHING else in the environment: the default transport of a multi-process launch is RcclWorld — rank 0
+    leaves the unique id in a file named after the launch, removes it once the communicator exists — here over the test double's
+    emulation of RCCL's calling contract between processes (tests/test_rccl_emulation_cpu.py).  Then scratch.cpp the same way."""
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not os.path.exists(mpiexec):
+        pytest.skip("no mpiexec on this box")
+    if not can_read_peer_memory():
+        pytest.skip("process_vm_readv between own processes is not permitted here")
+    from oracle import oracle as O
+    out = mains["dir"] / "er_rccl.json"
+    token = "t%d_%x" % (os.getpid(), time.time_ns())
+    env = dict(mains["env"], HNH_DEVICE="0", HNH_JOB_TOKEN=token, HNH_ORACLE_COMM_WAIT_S="120")
+    env.pop("HNH_TRANSPORT", None)
+    r = subprocess.run([mpiexec, "-n", "4", os.path.join(mains["bin"], "bench_erdos_renyi"), "9", "8", "15d", "16", "2", str(out)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert [(x["alg_name"], x["alg_info"]["p"], x["alg_info"]["c"], x["alg_info"]["transport"]) for x in records(out)] == [
+        ("15d_fusion1", 4, 2, "rccl"), ("15d_fusion2", 4, 2, "rccl")]
+    r = subprocess.run([mpiexec, "-n", "2", os.path.join(mains["bin"], "scratch"), mains["mtx"], "16", "1"], env=dict(env, HNH_JOB_TOKEN=token + "s"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    want = np.array(O.fingerprints(mains["rows"], mains["cols"], 256, 256, 16))
+    assert np.max(np.abs(fingerprints(r.stdout) - want) / want) <= 1e-5
+    assert not [f for f in os.listdir("/dev/shm") if token in f or f.startswith("hnh_emu_")], "the id file or the emulation's segment was left behind"
