@@ -36,6 +36,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+PRODUCT_BACKEND = "hip-gfx950"  # the only kernel library the product path accepts: there is no CPU mode in this file.  (The CPU test of the
+PROBE_SCRIPT = os.path.abspath(__file__)  # multi-GPU control flow, tests/bench_product_worker.py, replaces both — and the device
+#                                           selection — FROM OUTSIDE, with the kernel test double and its emulated transports.)
 GAT_LAYERS = [(256, 256, 4), (1024, 256, 4), (1024, 256, 6)]  # benchmark_dist.cpp:88-94: (input features, features per head, heads)
 
 
@@ -100,7 +103,8 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--logm", type=int, default=20)
     ap.add_argument("--edge-factor", type=int, default=96)
-    ap.add_argument("--r", type=int, default=128)
+    ap.add_argument("--r", "--rvalue", dest="r", type=int, default=128, help="embedding width R (under torch.distributed.run say --rvalue: its own "
+                    "parser takes a bare --r as an ambiguous abbreviation of its --rdzv-* / --role / --run-path options)")
     ap.add_argument("--alg", default="15d_fusion2")
     ap.add_argument("--workload", default="er", help="er = Erdos-Renyi 2^logm, edge factor (the default); rmat = skewed R-MAT of the same size "
                     "(stand-in for a SuiteSparse graph, BASELINE config 4); mtx:<path> = a MatrixMarket file (bench_file.cpp:23-28)")
@@ -428,7 +432,7 @@ def gpu_world(H, dist, rank, n, local_rank):
     """The default transport of the product: RCCL over xGMI (N = 1: no transport at all)."""
     import torch
     device, ndev = visible_device(rank, n, local_rank)
-    assert H.load_backend(None) == "hip-gfx950"
+    assert H.load_backend(None) == PRODUCT_BACKEND
     if n == 1:
         return H.World.single(device), torch.cuda.synchronize
     try:
@@ -462,7 +466,7 @@ def probe_main(args):
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group(backend="gloo", rank=rank, world_size=n)
     device, _ = visible_device(rank, n, local_rank)
-    assert H.load_backend(None) == "hip-gfx950"
+    assert H.load_backend(None) == PRODUCT_BACKEND
     world = make_gpu_transport(H, dist, rank, n, device, args.probe_transport)
     run_preflight(H, world, 1 << 16)
     wl = Workload("er", 12, 8)
@@ -500,7 +504,7 @@ def probe_transports(args, dist, rank, n, names):
         # rendezvous on a port of their own, where rank 0's child has to host the store itself
         for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
             env.pop(k)
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--probe-transport", name]
+        cmd = [sys.executable, PROBE_SCRIPT, "--gpus", str(n), "--probe-transport", name]
         if args.nchannels:
             cmd += ["--nchannels", str(args.nchannels)]
         t0 = time.perf_counter()
@@ -943,7 +947,7 @@ def run(args, make_world=gpu_world):
     if make_world is gpu_world and n > 1:
         dog.phase("transport creation (device selection)")
         device, ndev = visible_device(rank, n, local_rank)
-        assert H.load_backend(None) == "hip-gfx950"
+        assert H.load_backend(None) == PRODUCT_BACKEND
         wanted = {"auto": ["rccl", "ipc", "ipc-kernel"], "rccl": ["rccl"], "ipc": ["ipc", "ipc-kernel"]}[args.transport]
         dog.phase("transport trials in child processes (%s)" % ", ".join(wanted), args.probe_timeout * len(wanted) + 120.0)
         probe = probe_transports(args, dist, rank, n, [w for w in wanted if w != "ipc-kernel"])  # (the two ipc variants share every primitive but the copy)

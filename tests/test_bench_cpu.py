@@ -111,6 +111,88 @@ def test_bench_over_the_rccl_emulation(nranks):
     assert len(out["preflight"]["primitives_ok"]) == 9
 
 
+def product_launch(nranks, extra_env=None, probe_timeout="120"):
+    """`python bench.py --gpus N` as typed, its workers = tests/bench_product_worker.py: bench.run()'s PRODUCT branch for several GPUs
+    with the kernel library, the device selection and the trial script replaced from outside (see the worker)."""
+    env = dict(os.environ, OMP_NUM_THREADS="2", GLOO_SOCKET_IFNAME="lo", HNH_ORACLE_COMM_WAIT_S="120", HNH_IPC_WAIT_S="120",
+               HNH_BENCH_WORKER=os.path.join(ROOT, "tests", "bench_product_worker.py"), **(extra_env or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--steps", "2", "--warmup", "1", "--logm", "10",
+                          "--edge-factor", "8", "--r", "16", "--no-cpu-baseline", "--probe-timeout", probe_timeout], env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, (res.returncode, res.stdout[-1500:], res.stderr[-1500:])
+    return res, json.loads(lines[0])
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_the_multi_gpu_product_path_with_every_transport_usable(nranks):
+    """What the first run on a node with several GPUs will do, for the first time anywhere (on a one-GPU box RCCL never passes its
+    trial): both transports pass their child-process trials, all three variants are created in the benchmark process and run the
+    preflight, the default route is measured on each of them, the search continues on the fastest, the winner is measured in full."""
+    from test_ipc_world_cpu import can_read_peer_memory
+    if not can_read_peer_memory():
+        pytest.skip("process_vm_readv between own processes is not permitted here")
+    res, out = product_launch(nranks)
+    assert res.returncode == 0 and "error" not in out, (out.get("error"), res.stderr[-1500:])
+    assert out["n_gpus"] == nranks and out["check"]["ok"] and out["value"] > 0
+    trials = out["config"]["transport_trials"]
+    assert set(trials) == {"rccl", "ipc"} and all(v.startswith("ok") for v in trials.values()), trials
+    assert out["preflight"]["transports"] == ["ipc", "ipc-kernel", "rccl"] and len(out["preflight"]["primitives_ok"]) == 9
+    tuned = out["config"]["route_tuning_ms_per_step"]
+    default = [k for k in tuned if k.startswith("c=1 mesh/heights 1,2,2,2,1,1 [")]
+    assert {k.rsplit("[", 1)[1] for k in default} == {"rccl]", "ipc]", "ipc-kernel]"}   # stage 1: the default route on every transport
+    assert len(tuned) >= 10 and all(v is not None for v in tuned.values()) and "route_tuning_failures" not in out["config"], tuned
+    assert out["config"]["transport"] in ("rccl", "ipc-pull")
+
+
+def test_the_multi_gpu_product_path_when_rccl_cannot_be_created():
+    """RCCL fails in its child-process trial (here: the transport constructor raises): the verdict says so, the benchmark process never
+    tries it, and the run completes over the ipc-pull transport."""
+    from test_ipc_world_cpu import can_read_peer_memory
+    if not can_read_peer_memory():
+        pytest.skip("process_vm_readv between own processes is not permitted here")
+    res, out = product_launch(2, {"BENCH_PRODUCT_BREAK": "rccl"})
+    assert res.returncode == 0 and out["check"]["ok"], (out.get("error"), res.stderr[-1500:])
+    trials = out["config"]["transport_trials"]
+    assert trials["ipc"].startswith("ok") and not trials["rccl"].startswith("ok") and "exit code" in trials["rccl"], trials
+    assert out["config"]["transport"] == "ipc-pull" and out["preflight"]["transports"] == ["ipc", "ipc-kernel"]
+    assert not [k for k in out["config"]["route_tuning_ms_per_step"] if k.endswith("[rccl]")]
+
+
+def test_the_multi_gpu_product_path_when_a_transport_trial_hangs():
+    """A transport whose child-process trial never answers (an RCCL bootstrap stuck on this node, say) is ended at --probe-timeout, recorded
+    as a hang, and left alone; the hang never reaches the benchmark process."""
+    from test_ipc_world_cpu import can_read_peer_memory
+    if not can_read_peer_memory():
+        pytest.skip("process_vm_readv between own processes is not permitted here")
+    res, out = product_launch(2, {"BENCH_PRODUCT_BREAK": "rccl-hang"}, probe_timeout="8")
+    assert res.returncode == 0 and out["check"]["ok"], (out.get("error"), res.stderr[-1500:])
+    trials = out["config"]["transport_trials"]
+    assert "no answer within 8 s (hang)" in trials["rccl"] and trials["ipc"].startswith("ok"), trials
+    assert out["config"]["transport"] == "ipc-pull"
+
+
+def test_the_multi_gpu_product_path_under_torch_distributed_run():
+    """The driver's launch line — python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    <script> --gpus N ... — around the product branch: the transport trials scrub the elastic agent's environment (their children host
+    their own store), one JSON line comes out."""
+    from test_ipc_world_cpu import can_read_peer_memory
+    if not can_read_peer_memory():
+        pytest.skip("process_vm_readv between own processes is not permitted here")
+    env = dict(os.environ, OMP_NUM_THREADS="2", GLOO_SOCKET_IFNAME="lo", HNH_ORACLE_COMM_WAIT_S="120", HNH_IPC_WAIT_S="120")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                          str(free_port()), os.path.join(ROOT, "tests", "bench_product_worker.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--logm", "9",
+                          "--edge-factor", "8", "--rvalue", "16", "--no-cpu-baseline", "--probe-timeout", "120"], env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert res.returncode == 0 and len(lines) == 1, (res.returncode, res.stdout[-1000:], res.stderr[-1500:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["check"]["ok"] and out["config"]["R"] == 16 if "R" in out["config"] else out["check"]["ok"]
+    assert all(v.startswith("ok") for v in out["config"]["transport_trials"].values())
+
+
 def self_launch(extra_env, nranks=2, extra_args=()):
     env = dict(os.environ, OMP_NUM_THREADS="2", GLOO_SOCKET_IFNAME="lo", **extra_env)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
