@@ -447,7 +447,7 @@ def run_preflight(H, world, count, dog=None):
     res = {}
     for what, name in enumerate(H.World.PREFLIGHT):
         if dog is not None:
-            dog.phase("preflight: " + name, 90.0)
+            dog.phase("preflight: " + name, 150.0)  # (longer than HNH_IPC_WAIT_S: a transport with a time limit of its own reports instead of being cut off)
         res[name] = world.preflight(what, count)
         if dog is not None:
             dog.done()
@@ -957,9 +957,22 @@ def run(args, make_world=gpu_world):
             # here after all, under the watchdog, rather than give up without a number
             sys.stderr.write("[bench.py] rank %d: no transport passed its child-process trial (%r); trying them in this process\n" % (rank, probe))
             probe = {k: "ok (trial failed: %s; created in the benchmark process)" % v[:120] for k, v in probe.items()}
-        for name in wanted:
-            if not probe[name if name != "ipc-kernel" else "ipc"].startswith("ok"):
-                continue
+        later = [name for name in wanted if probe[name if name != "ipc-kernel" else "ipc"].startswith("ok")]
+    else:
+        dog.phase("transport creation")
+        world, device_sync = make_world(H, dist, rank, n, local_rank)
+        b.add_transport("single" if n == 1 else "default", world, device_sync)
+        later = []
+    dog.done()
+
+    # ---- bringing a transport up in this process: creation, then the preflight — every transport primitive the schedules use, on small
+    # buffers with known contents, each under the watchdog — then the order in which the ranks created their communicators is compared.
+    # A transport that fails either step ON ANY RANK is left alone (the ranks agree); the others are not affected.
+    if n > 1 and not args.no_preflight:
+        preflight = {}
+
+    def bring_up(name, create):
+        if create:
             dog.phase("transport creation (%s)" % name)
             err = None
             try:
@@ -968,41 +981,41 @@ def run(args, make_world=gpu_world):
                 err = str(e)[:200]
             if not b.all_ok(err is None):
                 probe[name] = "creation failed in the benchmark process: %s" % (err or "on another rank")
-                continue
+                return False
             b.add_transport(name, world, torch.cuda.synchronize)
-        if not b.transports:
-            raise SystemExit("bench.py --gpus %d: no usable device-to-device transport on this node: %r" % (n, probe))
-    else:
-        dog.phase("transport creation")
-        world, device_sync = make_world(H, dist, rank, n, local_rank)
-        b.add_transport("single" if n == 1 else "default", world, device_sync)
-    dog.done()
+            dog.done()
+        if preflight is None:
+            return True
+        dog.note("preflight [%s]" % name)
+        err = None
+        try:
+            res = run_preflight(H, b.world(name), 1 << 16, dog)
+        except Exception as e:  # noqa: BLE001
+            err = str(e)[:200]
+        if not b.all_ok(err is None):
+            sys.stderr.write("[bench.py preflight] rank %d, transport %s: %s\n" % (rank, name, err or "failed on another rank"))
+            b.transports[name]["dead"] = "preflight failed: %s" % (err or "on another rank")
+            if probe is not None:
+                probe[name] = "preflight failed in the benchmark process: %s" % (err or "on another rank")
+            return False
+        preflight[name] = res
+        sig = [None] * n
+        dist.all_gather_object(sig, b.world(name).split_signature())
+        if len(set(sig)) != 1:
+            sys.stderr.write("[bench.py preflight] ranks created their communicators in different orders: %r\n" % (sig,))
+            sys.stderr.flush()
+            os._exit(4)
+        return True
 
-    # ---- multi-GPU preflight in this process: every transport primitive the schedules use, on small buffers with known contents, each
-    # under the watchdog; then the order in which the ranks created their communicators is compared
-    if n > 1 and not args.no_preflight:
-        preflight = {}
-        for name in list(b.transports):
-            dog.note("preflight [%s]" % name)
-            err = None
-            try:
-                res = run_preflight(H, b.world(name), 1 << 16, dog)
-            except Exception as e:  # noqa: BLE001
-                err = str(e)[:200]
-            if not b.all_ok(err is None):
-                if len(b.usable()) <= 1:
-                    sys.stderr.write("[bench.py preflight] rank %d, transport %s: %s\n" % (rank, name, err or "failed on another rank"))
-                    sys.stderr.flush()
-                    os._exit(4)
-                b.transports[name]["dead"] = "preflight failed: %s" % (err or "on another rank")
-                continue
-            preflight[name] = res
-            sig = [None] * n
-            dist.all_gather_object(sig, b.world(name).split_signature())
-            if len(set(sig)) != 1:
-                sys.stderr.write("[bench.py preflight] ranks created their communicators in different orders: %r\n" % (sig,))
-                sys.stderr.flush()
-                os._exit(4)
+    # Only ONE transport is brought up before the first measurement: whatever the others do when they are created or run their preflight
+    # — fail, or hang until the watchdog ends the run — happens with a complete line in hand.
+    if later:
+        while later and not bring_up(later.pop(0), True):
+            pass
+        if not b.usable():
+            raise SystemExit("bench.py --gpus %d: no usable device-to-device transport on this node: %r" % (n, probe))
+    elif n > 1 and not bring_up(b.usable()[0], False):
+        raise SystemExit("bench.py --gpus %d: the transport failed its preflight" % n)
     fallback.watch_sigterm()
 
     # ---- the default route, measured in full first: from here on there is a number in hand whatever the search runs into
@@ -1034,6 +1047,10 @@ def run(args, make_world=gpu_world):
 
     if rank == 0:
         fallback.keep(finish_line(res, None))
+    for name in later:  # the remaining transports, with that line in hand
+        bring_up(name, True)
+        if rank == 0:
+            fallback.keep(finish_line(res, None))
 
     # ---- several GPUs, 1.5D dense shift: transport, replication factor and route of the moving operand.  The reference takes c on the
     # command line (bench_erdos_renyi.cpp:23-28) and relays the moving operand round a neighbour ring (one xGMI link per direction);

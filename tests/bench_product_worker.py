@@ -37,6 +37,32 @@ if os.environ.get("BENCH_PRODUCT_BREAK") == "rccl":  # one transport that cannot
         return real_make(H_, dist, rank, n, device, name)
     bench.make_gpu_transport = make_gpu_transport
 
+if os.environ.get("BENCH_PRODUCT_BREAK") == "rccl-preflight" and "--probe-transport" not in sys.argv:
+    # a transport that passes its child-process trial and then delivers wrong data in the benchmark process's own preflight
+    real_make2, real_preflight = bench.make_gpu_transport, bench.run_preflight
+
+    def make_tagged(H_, dist, rank, n, device, name):
+        w = real_make2(H_, dist, rank, n, device, name)
+        w._test_transport = name
+        return w
+
+    def preflight(H_, world, count, dog=None):
+        if getattr(world, "_test_transport", None) == "rccl" and int(os.environ["RANK"]) == 1:
+            raise RuntimeError("preflight: ring sendrecv delivered wrong data (test)")
+        return real_preflight(H_, world, count, dog)
+    bench.make_gpu_transport, bench.run_preflight = make_tagged, preflight
+
+if os.environ.get("BENCH_PRODUCT_BREAK") == "ipc-hang-late" and "--probe-transport" not in sys.argv:
+    # the SECOND transport hangs while it is created in the benchmark process, on one rank (its peers wait for it inside the transport)
+    real_make3 = bench.make_gpu_transport
+
+    def make_late(H_, dist, rank, n, device, name):
+        if name == "ipc" and rank == 1:
+            import time
+            time.sleep(3600)
+        return real_make3(H_, dist, rank, n, device, name)
+    bench.make_gpu_transport = make_late
+
 if __name__ == "__main__":
     if os.environ.get("BENCH_PRODUCT_BREAK") == "rccl-hang" and "--probe-transport" in sys.argv and sys.argv[sys.argv.index("--probe-transport") + 1] == "rccl":
         import time

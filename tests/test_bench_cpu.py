@@ -111,15 +111,17 @@ def test_bench_over_the_rccl_emulation(nranks):
     assert len(out["preflight"]["primitives_ok"]) == 9
 
 
-def product_launch(nranks, extra_env=None, probe_timeout="120"):
+def product_launch(nranks, extra_env=None, probe_timeout="120", extra_args=()):
     """`python bench.py --gpus N` as typed, its workers = tests/bench_product_worker.py: bench.run()'s PRODUCT branch for several GPUs
     with the kernel library, the device selection and the trial script replaced from outside (see the worker)."""
     env = dict(os.environ, OMP_NUM_THREADS="2", GLOO_SOCKET_IFNAME="lo", HNH_ORACLE_COMM_WAIT_S="120", HNH_IPC_WAIT_S="120",
-               HNH_BENCH_WORKER=os.path.join(ROOT, "tests", "bench_product_worker.py"), **(extra_env or {}))
+               HNH_BENCH_WORKER=os.path.join(ROOT, "tests", "bench_product_worker.py"))
+    env.update(extra_env or {})
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--steps", "2", "--warmup", "1", "--logm", "10",
-                          "--edge-factor", "8", "--r", "16", "--no-cpu-baseline", "--probe-timeout", probe_timeout], env=env, capture_output=True, text=True, timeout=900)
+                          "--edge-factor", "8", "--r", "16", "--no-cpu-baseline", "--probe-timeout", probe_timeout, *extra_args], env=env, capture_output=True, text=True,
+                         timeout=900)
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, (res.returncode, res.stdout[-1500:], res.stderr[-1500:])
     return res, json.loads(lines[0])
@@ -171,6 +173,31 @@ def test_the_multi_gpu_product_path_when_a_transport_trial_hangs():
     trials = out["config"]["transport_trials"]
     assert "no answer within 8 s (hang)" in trials["rccl"] and trials["ipc"].startswith("ok"), trials
     assert out["config"]["transport"] == "ipc-pull"
+
+
+def test_the_multi_gpu_product_path_when_a_transport_fails_its_preflight_on_one_rank():
+    """RCCL passes its trial, is created in the benchmark process, and then fails the preflight ON ONE RANK ONLY: the ranks agree (a
+    transport that failed anywhere failed), it is marked dead, the other rank does not wait for it, and the run completes over ipc-pull."""
+    from test_ipc_world_cpu import can_read_peer_memory
+    if not can_read_peer_memory():
+        pytest.skip("process_vm_readv between own processes is not permitted here")
+    res, out = product_launch(2, {"BENCH_PRODUCT_BREAK": "rccl-preflight", "HNH_ORACLE_COMM_WAIT_S": "8"})  # (the stuck rank's transport gives up after 8 s)
+    assert res.returncode == 0 and out["check"]["ok"], (out.get("error"), res.stderr[-1500:])
+    trials = out["config"]["transport_trials"]
+    assert trials["ipc"].startswith("ok") and trials["rccl"].startswith("preflight failed in the benchmark process"), trials
+    assert out["preflight"]["transports"] == ["ipc", "ipc-kernel"] and out["config"]["transport"] == "ipc-pull"
+    assert not [k for k in out["config"]["route_tuning_ms_per_step"] if k.endswith("[rccl]")]
+
+
+def test_the_multi_gpu_product_path_when_a_later_transport_hangs():
+    """Only one transport is brought up before the first complete measurement.  The second one hangs while it is created (one rank never
+    arrives): the watchdog ends the run — with the line measured on the first transport, marked incomplete, not with an error."""
+    from test_ipc_world_cpu import can_read_peer_memory
+    if not can_read_peer_memory():
+        pytest.skip("process_vm_readv between own processes is not permitted here")
+    res, out = product_launch(2, {"BENCH_PRODUCT_BREAK": "ipc-hang-late"}, extra_args=("--watchdog", "12"))
+    assert res.returncode == 0 and out["value"] > 0 and out["check"]["ok"], (out.get("error"), res.stderr[-1500:])
+    assert out["config"]["transport"] == "rccl" and "transport creation (ipc)" in out["incomplete"], out.get("incomplete")
 
 
 def test_the_multi_gpu_product_path_under_torch_distributed_run():
