@@ -168,10 +168,10 @@ def test_the_multi_gpu_product_path_when_a_transport_trial_hangs():
     from test_ipc_world_cpu import can_read_peer_memory
     if not can_read_peer_memory():
         pytest.skip("process_vm_readv between own processes is not permitted here")
-    res, out = product_launch(2, {"BENCH_PRODUCT_BREAK": "rccl-hang"}, probe_timeout="8")
+    res, out = product_launch(2, {"BENCH_PRODUCT_BREAK": "rccl-hang"}, probe_timeout="6")
     assert res.returncode == 0 and out["check"]["ok"], (out.get("error"), res.stderr[-1500:])
     trials = out["config"]["transport_trials"]
-    assert "no answer within 8 s (hang)" in trials["rccl"] and trials["ipc"].startswith("ok"), trials
+    assert "no answer within 6 s (hang)" in trials["rccl"] and trials["ipc"].startswith("ok"), trials
     assert out["config"]["transport"] == "ipc-pull"
 
 
@@ -181,7 +181,7 @@ def test_the_multi_gpu_product_path_when_a_transport_fails_its_preflight_on_one_
     from test_ipc_world_cpu import can_read_peer_memory
     if not can_read_peer_memory():
         pytest.skip("process_vm_readv between own processes is not permitted here")
-    res, out = product_launch(2, {"BENCH_PRODUCT_BREAK": "rccl-preflight", "HNH_ORACLE_COMM_WAIT_S": "8"})  # (the stuck rank's transport gives up after 8 s)
+    res, out = product_launch(2, {"BENCH_PRODUCT_BREAK": "rccl-preflight", "HNH_ORACLE_COMM_WAIT_S": "5"})  # (the stuck rank's transport gives up after 5 s)
     assert res.returncode == 0 and out["check"]["ok"], (out.get("error"), res.stderr[-1500:])
     trials = out["config"]["transport_trials"]
     assert trials["ipc"].startswith("ok") and trials["rccl"].startswith("preflight failed in the benchmark process"), trials
@@ -195,7 +195,7 @@ def test_the_multi_gpu_product_path_when_a_later_transport_hangs():
     from test_ipc_world_cpu import can_read_peer_memory
     if not can_read_peer_memory():
         pytest.skip("process_vm_readv between own processes is not permitted here")
-    res, out = product_launch(2, {"BENCH_PRODUCT_BREAK": "ipc-hang-late"}, extra_args=("--watchdog", "12"))
+    res, out = product_launch(2, {"BENCH_PRODUCT_BREAK": "ipc-hang-late"}, extra_args=("--watchdog", "8"))
     assert res.returncode == 0 and out["value"] > 0 and out["check"]["ok"], (out.get("error"), res.stderr[-1500:])
     assert out["config"]["transport"] == "rccl" and "transport creation (ipc)" in out["incomplete"], out.get("incomplete")
 
@@ -256,7 +256,7 @@ def test_bench_self_launch_ends_a_hung_run():
     """A rank that hangs before it gets anywhere: at --launch-timeout the launcher ends exactly the workers it started and prints
     ONE JSON line that says where every rank was; non-zero exit."""
     res = self_launch({"HNH_BENCH_WORKER": os.path.join(ROOT, "tests", "bench_worker.py"), "BENCH_WORKER_HANG_RANK": "1"},
-                      extra_args=("--no-tune", "--launch-timeout", "25", "--watchdog", "15"))
+                      extra_args=("--no-tune", "--launch-timeout", "14", "--watchdog", "9"))
     assert res.returncode != 0
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout[-1500:]
