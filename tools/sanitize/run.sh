@@ -42,3 +42,18 @@ for cfg in "4 2 15d_fusion1" "4 1 15d_fusion2" "4 1 15d_sparse" "4 1 25d_dense_r
     for p in "${pids[@]}"; do wait "$p"; done
     echo "ipc $cfg: $(grep -h Fingerprint "$OUT/ipc_rank0.log" | tr '\n' ' ')"
 done
+
+# Third stage: RcclWorld — the default transport (explicit-peer groups, native collectives on the world, host data staged through device
+# memory) — the same way, over the test double's emulation of RCCL between processes; the unique id travels through the launch-named file.
+cp "$OUT/liboracle_asan.so" "$OUT/libhnh_kernels.so"   # (sanitized double: its emulation and stream-order checker are under the sanitizers too)
+for cfg in "4 2 15d_fusion1" "4 1 15d_fusion2" "4 1 15d_sparse" "4 1 25d_dense_replicate" "8 2 25d_sparse_replicate"; do
+    set -- $cfg
+    pids=()
+    for r in $(seq 0 $(($1 - 1))); do
+        RANK=$r WORLD_SIZE=$1 LOCAL_RANK=$r HNH_DEVICE=0 HNH_JOB_TOKEN="asan_$$_$3" HNH_ORACLE_COMM_WAIT_S=120 HNH_HOST_SETUP=1 HNH_ORDER_CHECK=1 \
+            ASAN_OPTIONS=detect_leaks=0 OMP_NUM_THREADS=1 "$OUT/verify_asan" er:8:6 "$3" 16 "$2" > "$OUT/rccl_rank$r.log" 2>&1 &
+        pids+=($!)
+    done
+    for p in "${pids[@]}"; do wait "$p"; done
+    echo "rccl $cfg: $(grep -h Fingerprint "$OUT/rccl_rank0.log" | tr '\n' ' ')"
+done
