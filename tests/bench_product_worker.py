@@ -63,7 +63,19 @@ if os.environ.get("BENCH_PRODUCT_BREAK") == "ipc-hang-late" and "--probe-transpo
         return real_make3(H_, dist, rank, n, device, name)
     bench.make_gpu_transport = make_late
 
+if os.environ.get("BENCH_PRODUCT_BREAK") == "rccl-dies-in-search" and "--probe-transport" not in sys.argv:
+    # the transports work until the search: there a candidate raises on one rank (the other rank is inside the transport, waiting)
+    real_build = bench.Bench.build
+
+    def build(self, route):
+        if route[3] == "4" and int(os.environ["RANK"]) == 1:  # (whichever transport won the first stage)
+            raise RuntimeError("transport error mid-search (test)")
+        return real_build(self, route)
+    bench.Bench.build = build
+
 if __name__ == "__main__":
+    if os.environ.get("BENCH_PRODUCT_BREAK") == "all-trials" and "--probe-transport" in sys.argv:
+        sys.exit(9)  # the trial machinery itself is broken on this "node": every child fails before it gets anywhere
     if os.environ.get("BENCH_PRODUCT_BREAK") == "rccl-hang" and "--probe-transport" in sys.argv and sys.argv[sys.argv.index("--probe-transport") + 1] == "rccl":
         import time
         time.sleep(3600)  # a transport whose trial never answers: the parent ends it at --probe-timeout

@@ -200,6 +200,34 @@ def test_the_multi_gpu_product_path_when_a_later_transport_hangs():
     assert out["config"]["transport"] == "rccl" and "transport creation (ipc)" in out["incomplete"], out.get("incomplete")
 
 
+def test_the_multi_gpu_product_path_when_every_trial_fails():
+    """No transport passes its child-process trial — the trial machinery itself may be what is broken: the transports are tried in the
+    benchmark process after all rather than giving up without a number."""
+    from test_ipc_world_cpu import can_read_peer_memory
+    if not can_read_peer_memory():
+        pytest.skip("process_vm_readv between own processes is not permitted here")
+    res, out = product_launch(2, {"BENCH_PRODUCT_BREAK": "all-trials"})
+    assert res.returncode == 0 and out["check"]["ok"] and out["value"] > 0, (out.get("error"), res.stderr[-1500:])
+    assert all("trial failed" in v and "created in the benchmark process" in v for v in out["config"]["transport_trials"].values())
+    assert out["preflight"]["transports"] == ["ipc", "ipc-kernel", "rccl"]
+
+
+def test_the_multi_gpu_product_path_when_a_transport_dies_in_the_search():
+    """The fastest transport measures the default route, then one of its candidates raises on ONE rank while the other waits inside the
+    transport (which gives up after its own time limit here): the candidate is recorded with its reason, that transport is not used
+    again, and the line that was measured stays."""
+    from test_ipc_world_cpu import can_read_peer_memory
+    if not can_read_peer_memory():
+        pytest.skip("process_vm_readv between own processes is not permitted here")
+    res, out = product_launch(2, {"BENCH_PRODUCT_BREAK": "rccl-dies-in-search", "HNH_ORACLE_COMM_WAIT_S": "5"})
+    assert res.returncode == 0 and out["check"]["ok"] and out["value"] > 0, (out.get("error"), res.stderr[-1500:])
+    tuned, failed = out["config"]["route_tuning_ms_per_step"], out["config"].get("route_tuning_failures", {})
+    broken = [k for k in tuned if k.startswith("c=1 mesh/4 chunks [")]
+    assert len(broken) == 1 and tuned[broken[0]] is None and broken[0] in failed, (tuned, failed)
+    transport = broken[0].rsplit("[", 1)[1]
+    assert tuned["c=1 mesh/heights 1,2,2,2,1,1 [" + transport] is not None  # its default route had been measured before it died
+
+
 def test_the_multi_gpu_product_path_under_torch_distributed_run():
     """The driver's launch line — python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
     <script> --gpus N ... — around the product branch: the transport trials scrub the elastic agent's environment (their children host
