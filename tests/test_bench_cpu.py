@@ -219,7 +219,7 @@ def test_the_multi_gpu_product_path_when_a_transport_dies_in_the_search():
     from test_ipc_world_cpu import can_read_peer_memory
     if not can_read_peer_memory():
         pytest.skip("process_vm_readv between own processes is not permitted here")
-    res, out = product_launch(2, {"BENCH_PRODUCT_BREAK": "rccl-dies-in-search", "HNH_ORACLE_COMM_WAIT_S": "5"})
+    res, out = product_launch(2, {"BENCH_PRODUCT_BREAK": "rccl-dies-in-search", "HNH_ORACLE_COMM_WAIT_S": "5", "HNH_IPC_WAIT_S": "5"})
     assert res.returncode == 0 and out["check"]["ok"] and out["value"] > 0, (out.get("error"), res.stderr[-1500:])
     tuned, failed = out["config"]["route_tuning_ms_per_step"], out["config"].get("route_tuning_failures", {})
     broken = [k for k in tuned if k.startswith("c=1 mesh/4 chunks [")]
