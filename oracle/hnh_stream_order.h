@@ -26,7 +26,7 @@
 #include <string.h>
 #include <unistd.h>
 
-#define HB_CTX_SLOTS 64
+#define HB_CTX_SLOTS 32
 #define HB_LANES 4                       /* per context: stream 0 (compute), 1 (communication), 2 (auxiliary), 3 = the host thread */
 #define HB_T (HB_CTX_SLOTS * HB_LANES)   /* timelines */
 #define HB_HOST 3
