@@ -16,10 +16,6 @@ def cpu_world(H, dist, rank, n, local_rank):
     assert H.load_backend(T.ORACLE_BACKEND) == "oracle-cpu-test-double"
     if n == 1:
         return H.World.single(0), (lambda: None)
-    if os.environ.get("BENCH_WORKER_TRANSPORT") == "rccl":  # RcclWorld over the test double's emulation of RCCL between processes
-        ident = [H.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ident, src=0)
-        return H.World.rccl(rank, n, 0, ident[0]), (lambda: None)
     from gloo_worker import make_callbacks
     cpu_world.cb = make_callbacks()  # keep the ctypes thunks alive
     return H.World.callback(rank, n, 0, cpu_world.cb), (lambda: None)

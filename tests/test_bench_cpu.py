@@ -88,29 +88,6 @@ def test_bench_contract(nranks, alg, c, ring):
         assert "preflight" not in out
 
 
-@pytest.mark.parametrize("nranks", [2, 4])
-def test_bench_over_the_rccl_emulation(nranks):
-    """bench.run() with its ranks on RcclWorld (the product's default transport) over the test double's emulation of RCCL between
-    processes: set-up, the default route in full, the whole route search (c x chunk shapes x relay ring x 15d_fusion1), the keyed check."""
-    from test_ipc_world_cpu import can_read_peer_memory
-    if not can_read_peer_memory():
-        pytest.skip("process_vm_readv between own processes is not permitted here")
-    port = free_port()
-    procs = []
-    for r in range(nranks):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="2", GLOO_SOCKET_IFNAME="lo", BENCH_RING_MODE="", BENCH_WORKER_TRANSPORT="rccl", HNH_ORACLE_COMM_WAIT_S="120")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "bench_worker.py"), "15d_fusion2", "0"], env=env,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=600)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
-    out = json.loads([ln for ln in outs[0].splitlines() if ln.startswith("BENCH_JSON ")][0][len("BENCH_JSON "):])
-    assert out["n_gpus"] == nranks and out["check"]["ok"] and out["config"]["transport"] == "rccl"
-    tuned = out["config"]["route_tuning_ms_per_step"]
-    assert len(tuned) >= 8 and all(v is not None for v in tuned.values()), tuned
-    assert len(out["preflight"]["primitives_ok"]) == 9
-
-
 def product_launch(nranks, extra_env=None, probe_timeout="120", extra_args=()):
     """`python bench.py --gpus N` as typed, its workers = tests/bench_product_worker.py: bench.run()'s PRODUCT branch for several GPUs
     with the kernel library, the device selection and the trial script replaced from outside (see the worker)."""
