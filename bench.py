@@ -17,1555 +17,32 @@ Other workloads / applications of the reference's harness (benchmark_dist.cpp:88
 N = 1 run also times a bounded instance of each and lists them under "secondary" (outside the timed region).
 Inputs are resident in HBM before the timed region (A = B = 0.001, S = 1 as benchmark_dist.cpp:102-106).
 
+The code lives in benchlib/: timed.py is the timed path (build, step, measure, the line), run.py the order of a run; cli, guards
+(watchdog, time budget, line in hand), transports, search, checks, secondary, baseline and launcher are around them.
+
 One JSON line is printed by rank 0.  Extra objects:
   roofline     — the dominant kernel (fused row pass): algorithmic bytes per launch / average launch
                  duration measured live with HIP events on the compute stream, against 8.0 TB/s HBM.
+  roofline     — ... `frac` = `frac_kernel` on one GPU; on several GPUs `frac` = `frac_step` = total B_fused / ms_per_step / (N x 8 TB/s)
+                 (exposed communication counts), with `frac_kernel`, `kernel_ms_per_step` and `exposed_comm_ms` beside it.
   cpu_baseline — the reference itself (oracle/_ref/ref_driver = unmodified reference sources + MKL/MPICH)
-                 timed on this box's host cores on a bounded sample of the same workload (N = 1 only).
+                 timed on this box's host cores: measured by the N = 1 run (thread sweep on a bounded sample, then the same
+                 workload once), quoted from that run's record by the N > 1 runs that follow on the host (else its sample leg).
+  phases_s     — wall seconds per phase of the run (start-up, transport trials, bring-up, first measurement, tuning, ...);
+                 --budget-s (default 1200) bounds the whole run: optional work is only started while it fits.
   secondary    — N = 1: R-MAT (hub rows), config 4's schedule on 8 logical ranks, one ALS-CG step, the GAT forward pass,
                  narrow and wide operands, the one point the reference's tree prints a time for; each with its
                  own byte model, fraction of 8 TB/s and a closed-form check.
 """
-import argparse
-import json
 import os
 import sys
-import time
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-
-HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
-PRODUCT_BACKEND = "hip-gfx950"  # the only kernel library the product path accepts: there is no CPU mode in this file.  (The CPU test of the
-PROBE_SCRIPT = os.path.abspath(__file__)  # multi-GPU control flow, tests/bench_product_worker.py, replaces both — and the device
-#                                           selection — FROM OUTSIDE, with the kernel test double and its emulated transports.)
-GAT_LAYERS = [(256, 256, 4), (1024, 256, 4), (1024, 256, 6)]  # benchmark_dist.cpp:88-94: (input features, features per head, heads)
-
-
-_JSON_FD = None
-
-
-def claim_stdout():
-    """stdout carries exactly ONE line, the JSON result: everything else this process writes to file descriptor 1 (the host
-    library mirrors the reference's console messages, e.g. "R-mat generator created ... nonzeros") goes to stderr instead."""
-    global _JSON_FD
-    if _JSON_FD is None:
-        sys.stdout.flush()
-        _JSON_FD = os.dup(1)
-        os.dup2(2, 1)
-
-
-def emit(obj):
-    line = (obj if isinstance(obj, str) else json.dumps(obj)) + "\n"
-    if _JSON_FD is None:
-        sys.stdout.write(line)
-        sys.stdout.flush()
-    else:
-        os.write(_JSON_FD, line.encode())
-
-
-DEFAULT_CHUNKS = "1,2,2,2,1,1"  # the library's default shape of the mesh fetch (dense_shift_15d.hpp)
-
-
-def set_chunk_spec(spec):
-    """A chunk spec is a number (Q symmetric chunks, HNH_MESH_CHUNKS) or a comma list of heights (HNH_MESH_TAPER)."""
-    if "," in spec:
-        os.environ["HNH_MESH_TAPER"] = spec
-        os.environ.pop("HNH_MESH_CHUNKS", None)
-    else:
-        os.environ["HNH_MESH_CHUNKS"] = spec
-        os.environ.pop("HNH_MESH_TAPER", None)
-
-
-def current_chunk_spec():
-    return os.environ.get("HNH_MESH_TAPER") or os.environ.get("HNH_MESH_CHUNKS") or DEFAULT_CHUNKS
-
-
-def route_name(route):
-    """route = (transport, c, mode, chunk spec)"""
-    tr, c, mode, q = route
-    mesh = ("mesh/heights %s" % q) if (q and "," in str(q)) else ("mesh/%s chunks" % q)
-    return "c=%d %s [%s]" % (c, {"mesh": mesh, "relay": "relay ring", "none": "replication only",
-                                 "fusion1": "15d_fusion1 (replication reuse: SDDMM + SpMM, accumulator ring in two halves)"}[mode], tr)
-
-
-def keyed(idx, salt):
-    """Deterministic value in [0.5, 1.5) per global index (multiplicative hash): the operands of the result check."""
-    import numpy as np
-    h = (idx.astype(np.uint64) * np.uint64(2654435761) + np.uint64(salt) * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
-    return 0.5 + h.astype(np.float64) / 4294967296.0
-
-
-def parse(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--logm", type=int, default=20)
-    ap.add_argument("--edge-factor", type=int, default=96)
-    ap.add_argument("--r", "--rvalue", dest="r", type=int, default=128, help="embedding width R (under torch.distributed.run say --rvalue: its own "
-                    "parser takes a bare --r as an ambiguous abbreviation of its --rdzv-* / --role / --run-path options)")
-    ap.add_argument("--alg", default="15d_fusion2")
-    ap.add_argument("--workload", default="er", help="er = Erdos-Renyi 2^logm, edge factor (the default); rmat = skewed R-MAT of the same size "
-                    "(stand-in for a SuiteSparse graph, BASELINE config 4); mtx:<path> = a MatrixMarket file (bench_file.cpp:23-28)")
-    ap.add_argument("--app", choices=["vanilla", "als", "gat"], default="vanilla", help="what a step is (benchmark_dist.cpp:117-141): vanilla = one "
-                    "fusedSpMM; als = one alternating ALS step by batched CG (run_cg(1)); gat = one GAT forward pass (layers of benchmark_dist.cpp:88-94)")
-    ap.add_argument("--c", type=int, default=None, help="replication factor of the 1.5D/2.5D schedule (the reference's command-line "
-                    "argument, bench_erdos_renyi.cpp:23-28).  Not given: 1 on one GPU; on several GPUs the candidates 1 / 2 / 4 that "
-                    "divide N are MEASURED together with the route (below) and the fastest is timed")
-    ap.add_argument("--transport", choices=["auto", "rccl", "ipc"], default="auto", help="several GPUs: device-to-device transport.  auto = "
-                    "both are probed in child processes, the usable ones are measured (ipc with copy engines and with a pull kernel) and the "
-                    "fastest is timed")
-    ap.add_argument("--ring-mode", choices=["mesh", "relay"], default=None,
-                    help="route of the 1.5D dense shift's moving operand: mesh = every block straight from its owner (default), "
-                         "relay = the reference's neighbour ring (sets HNH_RING_MODE)")
-    ap.add_argument("--chunks", default=None, help="chunks of the pipelined mesh fetch: a number Q = symmetric chunks of heights "
-                    "(1, 2, .., 2, 1) (HNH_MESH_CHUNKS), or a comma list of heights, e.g. 1,2,2,2,1,1 (HNH_MESH_TAPER)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-logm", type=int, default=18, help="size of the CPU baseline's thread-sweep sample")
-    ap.add_argument("--cpu-trials", type=int, default=2)
-    ap.add_argument("--no-cpu-full", action="store_true", help="skip the CPU baseline's run at the GPU line's full size")
-    ap.add_argument("--no-check", action="store_true", help="skip the closed-form result check (outside the timed region)")
-    ap.add_argument("--no-preflight", action="store_true", help="skip the transport self-tests of a multi-GPU run")
-    ap.add_argument("--no-tune", action="store_true", help="several GPUs: keep the default route (first usable transport, mesh fetch, default "
-                    "chunk heights) instead of measuring transports, replication factors, chunk shapes and the relay ring")
-    ap.add_argument("--no-secondary", action="store_true", help="one GPU: skip the secondary workloads (R-MAT, config 4's schedule, ALS, GAT, other widths)")
-    ap.add_argument("--watchdog", type=float, default=240.0, help="seconds a multi-GPU phase may take before the rank reports "
-                    "where it is stuck and exits (with the best line measured so far, if there is one)")
-    ap.add_argument("--probe-timeout", type=float, default=300.0, help="several GPUs: seconds a transport's child-process trial may take")
-    ap.add_argument("--no-live-traffic", action="store_true", help="one GPU: do not run the two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE) "
-                    "behind roofline.traffic; the tracked profiles/hbm_traffic.json is quoted instead")
-    ap.add_argument("--nchannels", type=int, default=None, help="several GPUs: pin RCCL's channel count (NCCL_MIN/MAX_NCHANNELS); every "
-                    "channel is a workgroup that competes with the row kernel for CUs and HBM")
-    ap.add_argument("--comm-cus", type=int, default=None, help="compute units masked off the compute stream (HNH_COMM_CUS; the library's default is 0 = "
-                    "no mask, see hnh_runtime.hip for why)")
-    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="self-launched run (--gpus N without WORLD_SIZE): seconds "
-                    "before the launcher ends its workers and reports the phase each one was in")
-    ap.add_argument("--probe-transport", default=None, help=argparse.SUPPRESS)  # internal: the child-process trial of one transport
-    return ap.parse_args(argv)
-
-
-class Fallback:
-    """What rank 0 prints if the run cannot finish: the best COMPLETE measurement so far (timed steps + result check of one
-    route), marked, or nothing.  A hang inside a transport call cannot be undone from Python, but it need not cost the number
-    that is already in hand."""
-
-    def __init__(self, rank):
-        self.rank, self.best, self.printed = rank, None, False
-
-    def keep(self, line):
-        self.best = line
-
-    def emit_best(self, why):
-        """True when a line went out."""
-        if self.rank != 0 or self.printed or self.best is None:
-            return False
-        out = dict(self.best)
-        out["incomplete"] = why
-        emit(out)
-        self.printed = True
-        return True
-
-    def watch_sigterm(self):
-        """torch.distributed.run ends the surviving workers with SIGTERM when one of them exits: a thread that sigwait()s for it
-        prints the line in hand even while the main thread sits in a C call."""
-        import signal
-        import threading
-        if self.rank != 0 or not hasattr(signal, "pthread_sigmask"):
-            return
-        try:
-            signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
-        except (ValueError, OSError):
-            return
-
-        def wait():
-            signal.sigwait({signal.SIGTERM})
-            ok = self.emit_best("the launcher ended this rank (another rank failed or hung) before the route search was over")
-            os._exit(0 if ok else 143)
-
-        threading.Thread(target=wait, daemon=True).start()
-
-
-class Watchdog:
-    """Per-phase watchdog of a multi-GPU run: a phase that does not finish in time prints rank + phase and ends the
-    process (transport problems show up as hangs inside C calls; ctypes releases the GIL there).  If rank 0 already holds a
-    complete measurement it prints that line, marked, and exits 0."""
-
-    def __init__(self, rank, seconds, enabled, fallback=None):
-        self.rank, self.seconds, self.enabled, self.fallback = rank, seconds, enabled, fallback
-        self.timer = None
-        self.name = "start-up"
-        # a self-launched run (launch() below) reads these files to say which phase a failed or stuck rank was in
-        d = os.environ.get("HNH_BENCH_STATUS_DIR")
-        self.status = os.path.join(d, "rank%d.phase" % rank) if d else None
-        self.note("start-up")
-
-    def note(self, name):
-        self.name = name
-        if self.status:
-            try:
-                with open(self.status, "w") as f:
-                    f.write(name)
-            except OSError:
-                pass
-
-    def phase(self, name, seconds=None):
-        import threading
-        self.done()
-        self.note(name)
-        if not self.enabled:
-            return
-        limit = seconds or self.seconds
-
-        def fire():
-            sys.stderr.write("[bench.py watchdog] rank %d stuck in phase '%s' for more than %.0f s - giving up\n" % (self.rank, self.name, limit))
-            sys.stderr.flush()
-            if self.fallback is not None and self.fallback.emit_best("rank %d was stuck in phase '%s' for more than %.0f s" % (self.rank, self.name, limit)):
-                os._exit(0)
-            os._exit(3)
-
-        self.timer = threading.Timer(limit, fire)
-        self.timer.daemon = True
-        self.timer.start()
-
-    def done(self):
-        if self.timer is not None:
-            self.timer.cancel()
-            self.timer = None
-
-
-def cpu_baseline(args):
-    """The reference timed on the host cores: a thread sweep on a bounded sample (ER 2^cpu_logm, same edge factor and R), then
-    the best thread count ONCE at the GPU line's own size (1 warm-up + cpu_trials timed calls, benchmark_dist.cpp:117-149);
-    `value` is the full-size figure when that leg ran."""
-    import numpy as np
-    from distributed_sddmm_amd import api as H
-    from oracle import refrun as RR
-    ncpu = os.cpu_count() or 1
-    m = 1 << args.cpu_logm
-    if RR.available():
-        rows, cols = H.generate_er(m, m, m * args.edge_factor, 12345)
-        # The reference does not scale with the thread count on big hosts (measured on 2 x EPYC 9575F: 32 threads
-        # beat 64/128/256, and 1 MPI rank beats 4..32, profiles/r01_cpu_baseline_sweep.log), so a few counts are
-        # tried on the sample and the best one is used; `cores` is the thread count of the reported run.
-        tried, best = [], None
-        # (MPI ranks, OpenMP/MKL threads per rank): the thread counts on one rank, then the same cores split over several ranks
-        # (the reference is an MPI + OpenMP code; on the driver box one rank beat 4 .. 32, but that is the box's call)
-        configs = [(1, t) for t in sorted({min(ncpu, 16), min(ncpu, 32), min(ncpu, 64)})]
-        configs += [(pr, max(1, min(ncpu, 64) // pr)) for pr in (4, 8) if ncpu >= 2 * pr]
-        for ranks, threads in configs:
-            try:
-                res = RR.bench(m, m, rows, cols, args.r, "15d_fusion2", ranks, 1, True, args.cpu_trials, threads=threads, timeout=300.0)
-            except Exception as e:  # one configuration failing (e.g. no MPI launcher for several ranks) does not lose the others
-                tried.append((ranks, threads, None, str(e)[:80]))
-                continue
-            tried.append((ranks, threads, res["nnz_R_per_s"], None))
-            if best is None or res["nnz_R_per_s"] > best[2]["nnz_R_per_s"]:
-                best = (ranks, threads, res)
-        if best is None:
-            raise RuntimeError("the compiled reference ran in none of the configurations: %r" % (tried,))
-        ranks, threads, res = best
-        comp = res["perf_stats"].get("Computation Time", 0.0)
-        sweep = "ER 2^%d, edge factor %d (%d nnz), ranks x threads -> nnz*R/s: %s (host has %d hardware threads)" % (
-            args.cpu_logm, args.edge_factor, len(rows),
-            ", ".join("%dx%d: %s" % (pr, t, ("%.2e" % v) if v is not None else "failed") for pr, t, v, _ in tried), ncpu)
-        out = {"value": res["nnz_R_per_s"], "unit": "nnz*R/s", "cores": ranks * threads, "kind": "reference",
-               "sample": "ER 2^%d, edge factor %d (%d nnz), R=%d, 15d_fusion2 fused, %d timed fusedSpMM calls after 1 warm-up, "
-                         "%d MPI rank(s) x %d OpenMP/MKL threads (best of the sweep)" % (args.cpu_logm, args.edge_factor, len(rows), args.r,
-                                                                                       args.cpu_trials, ranks, threads),
-               "thread_sweep": sweep, "ranks": ranks, "threads_per_rank": threads, "elapsed_s": res["elapsed"],
-               "kernel_only_value": (len(rows) * args.r * args.cpu_trials / comp) if comp > 0 else None}
-        if not args.no_cpu_full and args.logm != args.cpu_logm:
-            try:
-                t0 = time.perf_counter()
-                mf = 1 << args.logm
-                rows, cols = H.generate_er(mf, mf, mf * args.edge_factor, 12345)
-                full = RR.bench(mf, mf, rows, cols, args.r, "15d_fusion2", ranks, 1, True, args.cpu_trials, threads=threads, timeout=900.0)
-                compf = full["perf_stats"].get("Computation Time", 0.0)
-                out.update({"sample_value": out["value"], "sample_workload": out["sample"],
-                            "value": full["nnz_R_per_s"], "elapsed_s": full["elapsed"],
-                            "kernel_only_value": (len(rows) * args.r * args.cpu_trials / compf) if compf > 0 else None,
-                            "sample": "the GPU line's own workload: ER 2^%d, edge factor %d (%d nnz), R=%d, 15d_fusion2 fused, %d timed "
-                                      "fusedSpMM calls after 1 warm-up, %d MPI rank(s) x %d OpenMP/MKL threads (chosen by the sweep); "
-                                      "whole leg incl. the reference's set-up %.0f s" % (args.logm, args.edge_factor, len(rows), args.r,
-                                                                                       args.cpu_trials, ranks, threads, time.perf_counter() - t0)})
-            except Exception as e:  # keep the sample figure
-                out["full_size_error"] = str(e)[:300]
-        return out
-    # no compiled reference on this box: time the numpy port on a smaller sample
-    from oracle import oracle as O
-    m = 1 << 14
-    rows, cols = O.erdos_renyi(14, args.edge_factor)
-    a, b = np.full((m, args.r), 0.001), np.full((m, args.r), 0.001)
-    t0 = time.perf_counter()
-    O.fused_a(rows, cols, np.ones(len(rows)), a, b)
-    dt = time.perf_counter() - t0
-    return {"value": len(rows) * args.r / dt, "unit": "nnz*R/s", "cores": 1, "kind": "port",
-            "sample": "numpy restatement, ER 2^14, edge factor %d (%d nnz), R=%d, one fused call" % (args.edge_factor, len(rows), args.r)}
-
-
-def live_traffic(args):
-    """roofline.traffic collected in THIS run: two short rocprofv3 passes of this very command in a child process — FETCH_SIZE
-    and WRITE_SIZE each in its own pass (they do not fit one; a counter pass is never combined with a trace domain) — read from
-    rocprofv3's rocpd database, per launch of the fused row kernel, with the micro-architecture guide's gfx950 correction
-    (FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane reads at 64 bytes: x 2; WRITE_SIZE as reported).  Runs outside
-    the timed region while this process is idle.  None when rocprofv3 is absent, this run is itself being profiled, or a pass fails."""
-    import glob
-    import shutil
-    import sqlite3
-    import subprocess
-    import tempfile
-    prof = shutil.which("rocprofv3")
-    if prof is None or "rocprofiler" in os.environ.get("LD_PRELOAD", "") or "ROCPROFILER_SDK_TOOL_LIBRARIES" in os.environ or "ROCP_TOOL_LIBRARIES" in os.environ:
-        return None
-    env = dict(os.environ, TMPDIR="/tmp")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
-        env.pop(k, None)
-    means, t0 = {}, time.perf_counter()
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = tempfile.mkdtemp(prefix="hnh_pmc_", dir="/tmp")
-        try:
-            cmd = [prof, "--pmc", counter, "-d", d, "-o", "pass", "--", sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "2",
-                   "--warmup", "1", "--no-cpu-baseline", "--no-check", "--no-live-traffic", "--no-secondary", "--logm", str(args.logm), "--edge-factor",
-                   str(args.edge_factor), "--r", str(args.r), "--alg", args.alg, "--workload", args.workload, "--app", args.app]
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420, check=True)
-            vals = []
-            for db in glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True):
-                cur = sqlite3.connect(db).cursor()
-                vals += [r[0] for r in cur.execute("select value from counters_collection where kernel_name like ? and counter_name = ?",
-                                                   ("%::row_kernel<%", counter))]
-            if not vals:
-                return None
-            means[counter] = (sum(vals) / len(vals), len(vals))
-        except Exception:
-            return None
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
-    fetch_kb, write_kb = means["FETCH_SIZE"][0], means["WRITE_SIZE"][0]
-    return {"bytes_per_launch": 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0, "fetch_size_kb_raw": fetch_kb, "write_size_kb_raw": write_kb,
-            "launches_sampled": means["FETCH_SIZE"][1], "seconds": round(time.perf_counter() - t0, 1)}
-
-
-# ------------------------------------------------------------------------------------------------ workloads
-class Workload:
-    """The sparse matrix of the run (benchmark_dist.cpp / bench_erdos_renyi.cpp / bench_file.cpp): how every rank gets its
-    tuples, and the host copy of the nonzeros the result checks sum over."""
-
-    def __init__(self, spec, logm, edge_factor):
-        self.spec, self.logm, self.ef = spec, logm, edge_factor
-        self.kind = "mtx" if spec.startswith("mtx:") else spec
-        if self.kind not in ("er", "rmat", "mtx"):
-            raise SystemExit("bench.py --workload %r: use er, rmat or mtx:<path>" % spec)
-        self.path = spec[4:] if self.kind == "mtx" else None
-        self._host = None
-
-    def host_nonzeros(self, H):
-        """(rows, cols) of the global matrix on the host — the generators are deterministic and bit-identical to the device
-        ones; a file is parsed with scipy when it is small enough."""
-        if self._host is None:
-            m = 1 << self.logm
-            if self.kind == "er":
-                self._host = H.generate_er(m, m, m * self.ef, 12345)
-            elif self.kind == "rmat":
-                self._host = H.generate_rmat(self.logm, m * self.ef)
-            else:
-                if os.path.getsize(self.path) > 400 << 20:
-                    return None
-                import numpy as np
-                import scipy.io
-                a = scipy.io.mmread(self.path).tocsr()
-                a.sum_duplicates()
-                a = a.tocoo()
-                self._host = (a.row.astype(np.int64), a.col.astype(np.int64))
-        return self._host
-
-    def load(self, H, world):
-        if self.kind == "er":
-            return H.SpmatLocal.load_tuples(world, False, self.logm, self.ef)
-        if self.kind == "mtx":
-            return H.SpmatLocal.load_tuples(world, True, 0, 0, self.path)
-        import numpy as np
-        rows, cols = self.host_nonzeros(H)
-        m = 1 << self.logm
-        return H.SpmatLocal.from_global(world, m, m, rows, cols, np.ones(len(rows)))
-
-    def describe(self, nnz):
-        if self.kind == "er":
-            return "Erdos-Renyi 2^%d x 2^%d, edge factor %d (%d unique nnz)" % (self.logm, self.logm, self.ef, nnz)
-        if self.kind == "rmat":
-            return "R-MAT 2^%d x 2^%d (a,b,c = .57,.19,.19), edge factor %d (%d unique nnz)" % (self.logm, self.logm, self.ef, nnz)
-        return "MatrixMarket file %s (%d nnz)" % (os.path.basename(self.path), nnz)
-
-
-def fused_bytes(nnz, r, rows):
-    return nnz * (8 * r + 24) + 16 * r * rows  # SURVEY 8(d)
-
-
-# ------------------------------------------------------------------------------------------------ transports
-def visible_device(rank, n, local_rank):
-    import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
-    ndev = torch.cuda.device_count()
-    if n > 1 and 1 < ndev < n:
-        raise SystemExit("bench.py --gpus %d: this process sees %d GPUs; one process per GPU needs either all %d visible to every rank "
-                         "(LOCAL_RANK picks one) or exactly one per rank (launcher-side isolation)" % (n, ndev, n))
-    device = local_rank % ndev
-    torch.cuda.set_device(device)
-    return device, ndev
-
-
-def make_gpu_transport(H, dist, rank, n, device, name):
-    """One process per GPU.  rccl: explicit-peer send/recv groups over xGMI (unique id handed round through torch.distributed);
-    ipc / ipc-kernel: receivers pull out of their peers' mapped buffers — copy engines on forked streams / one gather-copy kernel."""
-    if name == "rccl":
-        ident = [H.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ident, src=0)
-        return H.World.rccl(rank, n, device, ident[0])
-    session = [H.ipc_session_id() if rank == 0 else None]
-    dist.broadcast_object_list(session, src=0)
-    os.environ["HNH_IPC_PULL"] = "kernel" if name == "ipc-kernel" else "engine"
-    return H.World.ipc(rank, n, device, session[0])
-
-
-def gpu_world(H, dist, rank, n, local_rank):
-    """The default transport of the product: RCCL over xGMI (N = 1: no transport at all)."""
-    import torch
-    device, ndev = visible_device(rank, n, local_rank)
-    assert H.load_backend(None) == PRODUCT_BACKEND
-    if n == 1:
-        return H.World.single(device), torch.cuda.synchronize
-    try:
-        return make_gpu_transport(H, dist, rank, n, device, "rccl"), torch.cuda.synchronize
-    except Exception as e:
-        raise SystemExit("bench.py --gpus %d, rank %d on device %d of %d visible: the RCCL communicator could not be created: %s\n"
-                         "(\"invalid usage\" here usually means two ranks share one physical GPU, which RCCL refuses)" % (n, rank, device, ndev, e))
-
-
-def run_preflight(H, world, count, dog=None):
-    """Every transport primitive the schedules use, on small buffers with known contents; returns {name: max deviation}."""
-    res = {}
-    for what, name in enumerate(H.World.PREFLIGHT):
-        if dog is not None:
-            dog.phase("preflight: " + name, 150.0)  # (longer than HNH_IPC_WAIT_S: a transport with a time limit of its own reports instead of being cut off)
-        res[name] = world.preflight(what, count)
-        if dog is not None:
-            dog.done()
-        if not res[name] <= 1e-9:
-            raise RuntimeError("preflight: %s delivered wrong data (max deviation %.3e)" % (name, res[name]))
-    return res
-
-
-def probe_main(args):
-    """Child process of probe_transports(): create the transport, run the preflight and one small keyed fusedSpMM over it.
-    Exit code 0 = usable.  Whatever goes wrong here — an exception, a hang the parent ends — stays in this process."""
-    import torch
-    import torch.distributed as dist
-    from distributed_sddmm_amd import api as H
-    rank, n, local_rank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
-    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-    dist.init_process_group(backend="gloo", rank=rank, world_size=n)
-    device, _ = visible_device(rank, n, local_rank)
-    assert H.load_backend(None) == PRODUCT_BACKEND
-    world = make_gpu_transport(H, dist, rank, n, device, args.probe_transport)
-    run_preflight(H, world, 1 << 16)
-    wl = Workload("er", 12, 8)
-    b = Bench(argparse.Namespace(**dict(vars(args), r=32, alg="15d_fusion2", app="vanilla", steps=1, warmup=0, no_check=False)), H, torch, dist, rank, n,
-              Watchdog(rank, 0, False), wl)
-    b.add_transport(args.probe_transport, world, torch.cuda.synchronize)
-    b.build((args.probe_transport, 1, "mesh" if n > 1 else "none", "2"))
-    chk = b.check()
-    b.free_current()
-    b.close_transports()
-    dist.barrier()
-    dist.destroy_process_group()
-    if not chk["ok"]:
-        sys.stderr.write("[bench.py transport probe] rank %d, %s: the keyed result check failed: %r\n" % (rank, args.probe_transport, chk))
-        sys.exit(4)
-    sys.exit(0)
-
-
-def probe_transports(args, dist, rank, n, names):
-    """Tries each transport in a CHILD process per rank (own rendezvous port) under a time limit, so that a transport that
-    cannot initialise, delivers wrong data or hangs on this node never gets into this process.  Returns {name: "ok" | reason}."""
-    import socket
-    import subprocess
-    verdicts = {}
-    for name in names:
-        port = [None]
-        if rank == 0:
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                port[0] = sk.getsockname()[1]
-        dist.broadcast_object_list(port, src=0)
-        env = dict(os.environ, MASTER_PORT=str(port[0]), MASTER_ADDR="127.0.0.1")
-        env.pop("HNH_BENCH_STATUS_DIR", None)
-        # under torch.distributed.run the workers are told to use the AGENT's store (TORCHELASTIC_USE_AGENT_STORE): the children
-        # rendezvous on a port of their own, where rank 0's child has to host the store itself
-        for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
-            env.pop(k)
-        cmd = [sys.executable, PROBE_SCRIPT, "--gpus", str(n), "--probe-transport", name]
-        if args.nchannels:
-            cmd += ["--nchannels", str(args.nchannels)]
-        t0 = time.perf_counter()
-        try:
-            res = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=args.probe_timeout)
-            mine = "ok" if res.returncode == 0 else "rank %d: exit code %d: %s" % (rank, res.returncode, (res.stderr or "").strip().splitlines()[-1][:200] if (res.stderr or "").strip() else "")
-        except subprocess.TimeoutExpired:
-            mine = "rank %d: no answer within %.0f s (hang)" % (rank, args.probe_timeout)
-        everyone = [None] * n
-        dist.all_gather_object(everyone, mine)
-        bad = [v for v in everyone if v != "ok"]
-        verdicts[name] = "ok (%.0f s)" % (time.perf_counter() - t0) if not bad else bad[0]
-    return verdicts
-
-
-# ------------------------------------------------------------------------------------------------ the measured object
-class Bench:
-    """Operator + operands of ONE route at a time, on one of several transports; builds, times and checks it."""
-
-    def __init__(self, args, H, torch, dist, rank, n, dog, workload):
-        self.args, self.H, self.torch, self.dist, self.rank, self.n, self.dog, self.wl = args, H, torch, dist, rank, n, dog, workload
-        self.transports = {}  # name -> {"world", "sync", "sp", "dead"}
-        self.route, self.op, self.A, self.B, self.S, self.buf, self.als, self.gat, self.gat_x = None, None, None, None, None, None, None, None, None
-        self.nnz, self.m = None, None
-        self.setup_s = None
-
-    # -- transports
-    def add_transport(self, name, world, device_sync):
-        self.transports[name] = {"world": world, "sync": device_sync, "sp": None, "dead": None}
-
-    def usable(self):
-        return [k for k, t in self.transports.items() if t["dead"] is None]
-
-    def world(self, name=None):
-        return self.transports[name or self.route[0]]["world"]
-
-    def close_transports(self):
-        for t in self.transports.values():
-            if t["sp"] is not None:
-                t["sp"].free()
-                t["sp"] = None
-            if t["world"] is not None:
-                t["world"].close()
-                t["world"] = None
-
-    def barrier(self, name=None):
-        t = self.transports[name or self.route[0]]
-        if self.dist is not None:
-            self.dist.barrier()
-        t["world"].sync()
-        t["sync"]()
-
-    def max_over_ranks(self, v):
-        if self.dist is None:
-            return v
-        t = self.torch.tensor([v], dtype=self.torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def all_ok(self, ok):
-        """True iff every rank says so (a candidate that failed on one rank failed)."""
-        if self.dist is None:
-            return ok
-        t = self.torch.tensor([1.0 if ok else 0.0], dtype=self.torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
-        return bool(t.item() > 0.5)
-
-    # -- one route
-    def free_current(self):
-        for x in (self.A, self.B, self.S, self.buf, self.gat_x):
-            if x is not None:
-                x.free()
-        for x in (self.als, self.gat):
-            if x is not None:
-                x.free()
-        if self.op is not None:
-            self.op.free()
-        self.route, self.op, self.A, self.B, self.S, self.buf, self.als, self.gat, self.gat_x = None, None, None, None, None, None, None, None, None
-
-    def build(self, route):
-        if route == self.route:
-            return
-        self.free_current()
-        H, args = self.H, self.args
-        tr, c, mode, q = route
-        t = self.transports[tr]
-        if mode in ("mesh", "relay"):
-            os.environ["HNH_RING_MODE"] = mode
-        if q is not None:
-            set_chunk_spec(q)
-        t0 = time.perf_counter()
-        if t["sp"] is None:
-            t["sp"] = self.wl.load(H, t["world"])
-            info = t["sp"].info()
-            self.nnz, self.m = info["dist_nnz"], info["M"]
-        r0 = GAT_LAYERS[0][0] if args.app == "gat" else args.r
-        self.op = H.DistributedSparse(t["world"], "15d_fusion1" if mode == "fusion1" else args.alg, t["sp"], r0, c)
-        self.route = route
-        if args.app == "als":
-            self.als = H.DistributedALS(self.op, True)
-        elif args.app == "gat":
-            self.gat = H.GAT(self.op, GAT_LAYERS, 0.2)
-            self.op.setRValue(GAT_LAYERS[0][0])
-            self.gat_x = H.Dense.create(t["world"], *self.gat.buffer_shape(0))
-            self.gat_x.fill(0.001)
-            self.gat.set_input(self.gat_x)
-        else:
-            self.A, self.B = self.op.like_A_matrix(0.001), self.op.like_B_matrix(0.001)
-            self.S, self.buf = self.op.like_S_values(1.0), self.op.like_S_values(0.0)
-        self.barrier()
-        if self.setup_s is None:
-            self.setup_s = time.perf_counter() - t0
-
-    def step(self):
-        if self.als is not None:
-            self.als.run_cg(1)  # benchmark_dist.cpp:134-137
-        elif self.gat is not None:
-            self.gat.forwardPass()  # benchmark_dist.cpp:131-133
-        else:
-            self.op.fusedSpMM(self.A, self.B, self.S, self.buf, self.H.AMAT)
-
-    def quick_time(self, calls=5):
-        """one warm-up call, then `calls` calls timed one by one (barrier + device synchronise around each, max over ranks): the
-        MEDIAN — candidates a per cent apart are within the noise of a mean of three"""
-        self.step()
-        self.barrier()
-        times = []
-        for _ in range(calls):
-            t0 = time.perf_counter()
-            self.step()
-            self.barrier()
-            times.append(self.max_over_ranks(time.perf_counter() - t0))
-        times.sort()
-        return times[len(times) // 2] * 1e3
-
-    def try_route(self, route, calls=5):
-        """quick_time(route) with failure isolation: (ms, None) or (None, reason); a transport on which a candidate failed is
-        not used again (its streams may hold half a call)."""
-        tr = route[0]
-        if self.transports[tr]["dead"] is not None:
-            return None, "skipped: " + self.transports[tr]["dead"]
-        err = None
-        try:
-            self.build(route)
-            ms = self.quick_time(calls)
-        except Exception as e:  # noqa: BLE001 — every failure of a candidate is a recorded null, not the end of the run
-            err, ms = "%s: %s" % (type(e).__name__, str(e)[:200]), None
-        if not self.all_ok(err is None):
-            err = err or "failed on another rank"
-            self.transports[tr]["dead"] = "transport %s gave up on %s" % (tr, route_name(route))
-            try:
-                self.free_current()
-            except Exception:  # noqa: BLE001
-                self.route = self.op = self.A = self.B = self.S = self.buf = self.als = self.gat = self.gat_x = None
-            return None, err
-        return ms, None
-
-    # -- the closed-form check of a vanilla fused call, with operands a mis-routed block cannot survive:
-    # A[i,k] = a_i u_k, B[j,k] = b_j v_k (hashes of the GLOBAL indices), S = 1  =>  sddmm(i,j) = a_i b_j W with W = sum_k u_k v_k and one
-    # fused call leaves  A[i,k] = W a_i v_k sum_{j in row i} b_j^2.  The sum comes from the HOST generator's draws (bit-identical to the
-    # device generator, independent of every device code path) in O(nnz).
-    def check(self):
-        import numpy as np
-        H, op, r = self.H, self.op, self.op.info()["R"]
-        host = self.wl.host_nonzeros(H)
-        if host is None:
-            return {"what": "skipped: the input file is too large to parse a second time on the host", "ok": True, "skipped": True}
-        grows, gcols = host
-        m, nnz_host = self.m, int(len(grows))
-        a_key, b_key = keyed(np.arange(m), 1), keyed(np.arange(m), 2)
-        u_key, v_key = keyed(np.arange(r), 3), keyed(np.arange(r), 4)
-        rowsum = np.bincount(grows, weights=b_key[gcols] ** 2, minlength=m)
-        want_row = float(np.dot(u_key, v_key)) * a_key * rowsum  # times v_k per column
-
-        def keyed_local(mat_mode, row_key, col_key):
-            parts = []
-            for top, left, rc, cc in op.submatrices(mat_mode):
-                blk = np.zeros((rc, cc))
-                keep = int(max(0, min(rc, m - top)))
-                blk[:keep] = row_key[top:top + keep, None] * col_key[None, left:left + cc]
-                parts.append(blk.reshape(-1))
-            return np.concatenate(parts)
-
-        A, B = op.like_A_matrix(0.0), op.like_B_matrix(0.0)
-        S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
-        A.upload(keyed_local(H.AMAT, a_key, u_key).reshape(A.shape))
-        B.upload(keyed_local(H.BMAT, b_key, v_key).reshape(B.shape))
-        op.initial_shift(A, B, H.K_SDDMM_A)  # (Cannon's skew for the 2.5D schedules; empty for the 1.5D ones)
-        op.fusedSpMM(A, B, S, buf, H.AMAT)
-        op.de_shift(A, B, H.K_SDDMM_A)
-        self.world().sync()
-        got = A.download().reshape(-1)
-        for x in (A, B, S, buf):
-            x.free()
-        worst, elems_checked, off = 0.0, 0, 0
-        for top, left, rc, cc in op.submatrices(H.AMAT):
-            keep = int(max(0, min(rc, m - top)))
-            blk = got[off:off + rc * cc].reshape(rc, cc)[:keep]
-            off += rc * cc
-            if keep:
-                worst = max(worst, float(np.max(np.abs(blk - want_row[top:top + keep, None] * v_key[None, left:left + cc]))))
-                elems_checked += keep * cc
-        ref = float(want_row.max() * v_key.max())
-        local_n = float(op.info()["nS"])
-        if self.dist is not None:
-            t = self.torch.tensor([worst], dtype=self.torch.float64)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-            worst = float(t[0])
-            t = self.torch.tensor([float(elems_checked), local_n], dtype=self.torch.float64)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-            elems_checked, local_n = int(t[0]), float(t[1])
-        rows_checked = elems_checked // r  # every rank checks the rows (and, under an R split, the columns) it owns
-        return {"what": "one fresh fusedSpMM from operands keyed by global row and column (A[i,k] = a_i u_k, B[j,k] = b_j v_k, S = 1) against "
-                        "the closed form A[i,k] = (u.v) a_i v_k sum_{j in row i} b_j^2, the sum taken over the host generator's nonzeros",
-                "rel_err": worst / ref, "tolerance": 1e-11, "rows_checked": int(rows_checked),
-                "nnz_operator": int(self.nnz), "nnz_host_generator": nnz_host, "nnz_in_blocks_all_ranks": int(local_n),
-                "ok": bool(worst / ref <= 1e-11 and nnz_host == self.nnz and rows_checked == m)}
-
-    def check_app(self):
-        """als: one alternating step lowers the residual of the artificial ground truth; gat: the forward pass from a rank-one
-        input X[i,k] = a_i u_k with non-negative weights has a closed form layer by layer —
-        H_h[i,:] = a_i s_i |w_h|^2 w_h,  w_h = u^T W_h,  s_i = sum_{j in row i} a_j^2  (every SDDMM value is positive, so both
-        activations are the identity) — summed over the host generator's nonzeros."""
-        import numpy as np
-        H = self.H
-        if self.als is not None:
-            self.als.initializeEmbeddings()
-            r0 = self.als.computeResidual()
-            self.als.cg_optimizer(H.AMAT, 10)
-            self.als.cg_optimizer(H.BMAT, 10)
-            r1 = self.als.computeResidual()
-            return {"what": "ALS by batched CG on an artificial ground truth: residual before / after one alternating step (10 CG iterations each)",
-                    "residual_before": r0, "residual_after": r1, "ok": bool(np.isfinite(r1) and r1 < r0)}
-        host = self.wl.host_nonzeros(H)
-        if host is None or self.args.alg not in ("15d_fusion1", "15d_fusion2"):
-            return {"what": "skipped: the GAT closed form is stated for schedules that keep whole rows on a rank", "ok": True, "skipped": True}
-        grows, gcols = host
-        m, op = self.m, self.op
-        a = keyed(np.arange(m), 11)
-        u = keyed(np.arange(GAT_LAYERS[0][0]), 12) / GAT_LAYERS[0][0]
-        for li, (fin, fph, heads) in enumerate(GAT_LAYERS):
-            for h in range(heads):
-                k, ncol = self.gat.weight_shape(li, h)
-                self.gat.set_weight(li, h, (keyed(np.arange(k * ncol), 100 + 16 * li + h).reshape(k, ncol)) / float(k))
-        op.setRValue(GAT_LAYERS[0][0])
-        sub_b = op.submatrices(H.BMAT)
-        parts = []
-        for top, left, rc, cc in sub_b:
-            blk = np.zeros((rc, cc))
-            keep = int(max(0, min(rc, m - top)))
-            blk[:keep] = a[top:top + keep, None] * u[None, left:left + cc]
-            parts.append(blk.reshape(-1))
-        self.gat_x.upload(np.concatenate(parts).reshape(self.gat_x.shape))
-        self.gat.set_input(self.gat_x)
-        self.gat.forwardPass()
-        for li, (fin, fph, heads) in enumerate(GAT_LAYERS):  # the closed form, layer by layer
-            s = np.bincount(grows, weights=a[gcols] ** 2, minlength=m)
-            nxt = []
-            for h in range(heads):
-                k, ncol = self.gat.weight_shape(li, h)
-                w = u @ ((keyed(np.arange(k * ncol), 100 + 16 * li + h).reshape(k, ncol)) / float(k))
-                nxt.append(float(np.dot(w, w)) * w)
-            a, u = a * s, np.concatenate(nxt)
-        op.setRValue(GAT_LAYERS[-1][1] * GAT_LAYERS[-1][2])
-        out = H.Dense.create(self.world(), *self.gat.buffer_shape(len(GAT_LAYERS)))
-        self.gat.get_output(out)
-        got = out.download().reshape(-1)
-        out.free()
-        worst, off = 0.0, 0
-        for top, left, rc, cc in op.submatrices(H.AMAT):
-            keep = int(max(0, min(rc, m - top)))
-            blk = got[off:off + rc * cc].reshape(rc, cc)[:keep]
-            off += rc * cc
-            if keep:
-                worst = max(worst, float(np.max(np.abs(blk - a[top:top + keep, None] * u[None, left:left + cc]))))
-        worst = self.max_over_ranks(worst)
-        ref = float(a.max() * u.max())
-        self.gat_x.fill(0.001)
-        self.gat.set_input(self.gat_x)
-        return {"what": "GAT forward pass from a rank-one input and non-negative weights against its closed form "
-                        "H_h[i,:] = a_i s_i |w_h|^2 w_h (w_h = u^T W_h, s_i = sum_{j in row i} a_j^2), layer by layer",
-                "rel_err": worst / ref, "tolerance": 1e-9, "ok": bool(worst / ref <= 1e-9)}
-
-    # -- the full measurement of the current route
-    def measure(self):
-        """warm-up, K timed steps (barrier + device synchronise on both sides, max over ranks), the roofline leg and the check."""
-        args, torch, dist, H = self.args, self.torch, self.dist, self.H
-        self.dog.phase("warm-up steps [%s]" % route_name(self.route))
-        for _ in range(args.warmup):
-            self.step()
-        self.barrier()
-        self.dog.phase("timed steps [%s]" % route_name(self.route))
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            self.step()
-        self.barrier()
-        elapsed = self.max_over_ranks(time.perf_counter() - t0)
-        self.dog.phase("roofline leg and result check [%s]" % route_name(self.route), max(args.watchdog, 600.0))
-        # roofline leg (outside the timed region): HIP events around every local kernel launch
-        prof_calls = max(2, min(5, args.steps))
-        self.op.kernel_profile(1)
-        for _ in range(prof_calls):
-            self.step()
-        self.world().sync()
-        kern_ms, launches = self.op.kernel_profile(0)
-        info = self.op.info()
-        c_now = self.route[1]
-        # SURVEY 8(d), per fused call of this rank: per nonzero 8R + 24 bytes, per output row 16R (row operand read + output row written
-        # ONCE) — however many launches the implementation uses (it re-reads rows per launch; that is its cost)
-        if args.app == "gat":  # one fused head per (layer, head) at R = features per head
-            alg_bytes_per_step = sum(h * (info["nS"] * (8 * f + 24) + 16 * f * info["localArows"] * c_now) for _, f, h in GAT_LAYERS)
-        elif args.app == "als":  # run_cg(1): two half-steps of (1 + 1 + 10) fused calls (als_conjugate_gradients.cpp:38-141)
-            alg_bytes_per_step = 2 * 12 * (info["nS"] * (8 * args.r + 24) + 16 * args.r * info["localArows"] * c_now)
-        else:
-            alg_bytes_per_step = info["nS"] * (8 * args.r + 24) + 16 * args.r * info["localArows"] * c_now
-        if dist is not None:
-            t = torch.tensor([kern_ms, float(launches), float(alg_bytes_per_step)], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            kern_ms, launches, alg_bytes_per_step = float(t[0]) / self.n, int(t[1]) // self.n, float(t[2]) / self.n
-        self.barrier()
-        check = None
-        if not args.no_check:
-            check = self.check() if args.app == "vanilla" else self.check_app()
-            self.barrier()
-        transport_kind = self.op.json_algorithm_info().get("transport", "?")  # (collective: every rank asks)
-        return {"route": self.route, "elapsed": elapsed, "kern_ms": kern_ms, "launches": launches, "prof_calls": prof_calls,
-                "alg_bytes_per_step": alg_bytes_per_step, "check": check, "transport_kind": transport_kind}
-
-
-def compose_line(args, b, res, extra):
-    """The JSON line of one complete measurement (rank 0)."""
-    H, n = b.H, b.n
-    tr, c_now, mode, q = res["route"]
-    ms_per_step = res["elapsed"] / args.steps * 1e3
-    value = b.nnz * args.r * args.steps / res["elapsed"]
-    launches_per_step = max(1, res["launches"] // res["prof_calls"])
-    dur = res["kern_ms"] / max(1, res["launches"]) * 1e-3  # average launch duration, seconds
-    bytes_per_launch = res["alg_bytes_per_step"] / launches_per_step
-    achieved = bytes_per_launch / dur if dur > 0 else 0.0
-    ring_mode_now = None if (n == 1 or mode == "none") else ("accumulator ring (two halves)" if mode == "fusion1" else mode)
-    alg_now = "15d_fusion1" if mode == "fusion1" else args.alg
-    step_is = {"vanilla": "fused SDDMM->SpMM (fusedSpMM, Amat)", "als": "one alternating ALS step by batched CG (run_cg(1): 24 fused calls)",
-               "gat": "one GAT forward pass (3 layers, 14 heads, benchmark_dist.cpp:88-94)"}[args.app]
-    how = "" if n == 1 else ", %s (%s)" % (
-        {"rccl": "RCCL over xGMI", "ipc": "ipc-pull over mapped peer memory, copy engines", "ipc-kernel": "ipc-pull over mapped peer memory, pull kernel"}.get(tr, "transport: " + tr),
-        {"relay": "neighbour relay ring", "mesh": "chunked fetch from the owners", None: "replication only, nothing shifts"}.get(ring_mode_now, ring_mode_now))
-    out = {
-        "backend": H.backend_name(),
-        "metric": "fused SDDMM+SpMM nnz*R/s", "value": value, "unit": "nnz*R/s", "n_gpus": n, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic" if b.wl.kind != "mtx" else "file",
-        "config": {"workload": "%s, R=%d, %s, %s c=%d on %d x MI355X%s" % (b.wl.describe(b.nnz), args.r, step_is, alg_now, c_now, n, how),
-                   "nnz": b.nnz, "M": b.m, "R": args.r, "algorithm": alg_now, "app": args.app, "c": c_now,
-                   "transport": "none" if n == 1 else res["transport_kind"],
-                   "transport_variant": None if n == 1 else tr, "ring_mode": ring_mode_now,
-                   # Q symmetric chunks (a number) or the chunk heights (a comma list)
-                   "mesh_chunks": (q if ring_mode_now == "mesh" else None),
-                   "rccl_channels": (os.environ.get("NCCL_MAX_NCHANNELS", "default") if n > 1 else None),
-                   # compute units masked off the compute stream (the library's own default unless HNH_COMM_CUS / --comm-cus say otherwise)
-                   "comm_cus": int(os.environ.get("HNH_COMM_CUS", "0")),
-                   "setup_s": round(b.setup_s or 0.0, 2)},
-        # `achieved` is an ALGORITHMIC rate (SURVEY 8d byte model / measured launch time), not DRAM utilisation: part of every
-        # launch's gathers is served by the 256 MiB Infinity Cache, which sits behind the counters `traffic` comes from
-        "roofline": {"bound": "hbm", "bound_detail": "hbm gather model (Infinity-Cache assisted); the saturated resource is the memory side "
-                                                      "serving scattered dense rows, see DESIGN.md section 3 and profiles/r02_gather_probe*.log",
-                     "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK, "traffic": None, "traffic_source": None,
-                     "kernel": ("row_kernel<fused> (hnh_fused_sddmm_spmm_csr_p), one launch per Infinity-Cache panel of B" if n == 1 else
-                                "row_kernel<fused> (hnh_fused_sddmm_spmm_csr_p): one launch per visiting block of the relay ring"
-                                if ring_mode_now == "relay" else
-                                "row_kernel<fused> (hnh_fused_sddmm_spmm_csr_p): the rank's one block (replication only)" if ring_mode_now is None else
-                                "row_kernel<sddmm> + row_kernel<spmm> per visiting block (15d_fusion1 runs the pair, not the fused pass; the byte model stays the fused one)"
-                                if mode == "fusion1" else
-                                "row_kernel<fused> (hnh_fused_sddmm_spmm_csr_p): own block, then one windowed pass over the fetched blocks per landed chunk"),
-                     # device time of a kernel CALL (HIP events around it on the compute stream) divided by the row-kernel launches it made
-                     "avg_launch_ms": dur * 1e3,
-                     "avg_launch_ms_is": "event-bracketed call time / row-kernel launches of the call (structure plans are cached: a steady-state call launches row kernels only)",
-                     "traffic_rate": None,
-                     "compulsory_bytes_per_call": 8 * args.r * (2 * b.m + b.m) + 24 * b.nnz,
-                     "launches_per_step": launches_per_step, "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "model": "per fused call nnz*(8R+24) + 16*R*rows (SURVEY 8d), divided evenly over its launches"},
-    }
-    if res["check"] is not None:
-        out["check"] = res["check"]
-    out.update(extra)
-    return out
-
-
-def run(args, make_world=gpu_world):
-    """`make_world` is replaceable so that tests can drive this exact function over gloo on CPU."""
-    if args.gpus > 1 and "HNH_KEEP_OMP" not in os.environ:
-        # torch.distributed.run pins OMP_NUM_THREADS=1 per worker; the host-side setup (generator, sorts, CSR build)
-        # is OpenMP code, so give every rank its share of the host cores instead (must happen before libgomp starts)
-        os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // args.gpus))
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL / mapped peer memory across processes)
-    # HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share one serialise: with the
-    # framework's own streams (compute, its unmasked twin, communication, the pull's forked streams) and RCCL's in the process, make
-    # sure streams that wait for OTHER PROCESSES never share a queue with the streams those processes wait for
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-    os.environ.setdefault("HNH_IPC_WAIT_S", "120")
-    if args.gpus > 1:
-        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: RCCL's bootstrap must not depend on an external interface
-    if args.ring_mode:
-        os.environ["HNH_RING_MODE"] = args.ring_mode
-    if args.chunks:
-        set_chunk_spec(str(args.chunks))
-    if getattr(args, "comm_cus", None) is not None:
-        os.environ["HNH_COMM_CUS"] = str(args.comm_cus)
-    if args.gpus > 1 and getattr(args, "nchannels", None):
-        os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"] = str(args.nchannels)
-    if getattr(args, "probe_transport", None):
-        return probe_main(args)
-    import torch  # first: one HIP runtime per process (see distributed_sddmm_amd/_kernels.py)
-    from distributed_sddmm_amd import api as H
-
-    rank = int(os.environ.get("RANK", "0"))
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n = args.gpus
-    if world_size != n:  # main() self-launches when WORLD_SIZE is absent; this is a launcher that disagrees with --gpus
-        raise SystemExit("bench.py --gpus %d was started as rank %d of WORLD_SIZE=%d: the launcher's process count and --gpus disagree" % (n, rank, world_size))
-    for name, default in (("workload", "er"), ("app", "vanilla"), ("transport", "auto"), ("no_secondary", True), ("probe_timeout", 300.0)):
-        if not hasattr(args, name):  # (tests build their own argument namespaces)
-            setattr(args, name, default)
-    dist = None
-    if n > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: never depend on the container hostname resolving
-        if not dist.is_initialized():
-            dist.init_process_group(backend="gloo", rank=rank, world_size=n)  # bootstrap + barriers only; data moves over the device transports
-    fallback = Fallback(rank)
-    dog = Watchdog(rank, args.watchdog, n > 1, fallback)
-    wl = Workload(args.workload, args.logm, args.edge_factor)
-    b = Bench(args, H, torch, dist, rank, n, dog, wl)
-    extra, preflight, probe = {}, None, None
-
-    # ---- transports.  One GPU: none.  Several GPUs through the product path: every wanted transport is tried in a child process
-    # first, the usable ones are created here and run their preflight.  Tests substitute their own single transport.
-    if make_world is gpu_world and n > 1:
-        dog.phase("transport creation (device selection)")
-        device, ndev = visible_device(rank, n, local_rank)
-        assert H.load_backend(None) == PRODUCT_BACKEND
-        wanted = {"auto": ["rccl", "ipc", "ipc-kernel"], "rccl": ["rccl"], "ipc": ["ipc", "ipc-kernel"]}[args.transport]
-        dog.phase("transport trials in child processes (%s)" % ", ".join(wanted), args.probe_timeout * len(wanted) + 120.0)
-        probe = probe_transports(args, dist, rank, n, [w for w in wanted if w != "ipc-kernel"])  # (the two ipc variants share every primitive but the copy)
-        dog.done()
-        if not any(v.startswith("ok") for v in probe.values()):
-            # nothing passed its trial: the trial machinery itself (child start-up, rendezvous) may be what failed — try the transports
-            # here after all, under the watchdog, rather than give up without a number
-            sys.stderr.write("[bench.py] rank %d: no transport passed its child-process trial (%r); trying them in this process\n" % (rank, probe))
-            probe = {k: "ok (trial failed: %s; created in the benchmark process)" % v[:120] for k, v in probe.items()}
-        later = [name for name in wanted if probe[name if name != "ipc-kernel" else "ipc"].startswith("ok")]
-    else:
-        dog.phase("transport creation")
-        world, device_sync = make_world(H, dist, rank, n, local_rank)
-        b.add_transport("single" if n == 1 else "default", world, device_sync)
-        later = []
-    dog.done()
-
-    # ---- bringing a transport up in this process: creation, then the preflight — every transport primitive the schedules use, on small
-    # buffers with known contents, each under the watchdog — then the order in which the ranks created their communicators is compared.
-    # A transport that fails either step ON ANY RANK is left alone (the ranks agree); the others are not affected.
-    if n > 1 and not args.no_preflight:
-        preflight = {}
-
-    def bring_up(name, create):
-        if create:
-            dog.phase("transport creation (%s)" % name)
-            err = None
-            try:
-                world = make_gpu_transport(H, dist, rank, n, device, name)
-            except Exception as e:  # noqa: BLE001
-                err = str(e)[:200]
-            if not b.all_ok(err is None):
-                probe[name] = "creation failed in the benchmark process: %s" % (err or "on another rank")
-                return False
-            b.add_transport(name, world, torch.cuda.synchronize)
-            dog.done()
-        if preflight is None:
-            return True
-        dog.note("preflight [%s]" % name)
-        err = None
-        try:
-            res = run_preflight(H, b.world(name), 1 << 16, dog)
-        except Exception as e:  # noqa: BLE001
-            err = str(e)[:200]
-        if not b.all_ok(err is None):
-            sys.stderr.write("[bench.py preflight] rank %d, transport %s: %s\n" % (rank, name, err or "failed on another rank"))
-            b.transports[name]["dead"] = "preflight failed: %s" % (err or "on another rank")
-            if probe is not None:
-                probe[name] = "preflight failed in the benchmark process: %s" % (err or "on another rank")
-            return False
-        preflight[name] = res
-        sig = [None] * n
-        dist.all_gather_object(sig, b.world(name).split_signature())
-        if len(set(sig)) != 1:
-            sys.stderr.write("[bench.py preflight] ranks created their communicators in different orders: %r\n" % (sig,))
-            sys.stderr.flush()
-            os._exit(4)
-        return True
-
-    # Only ONE transport is brought up before the first measurement: whatever the others do when they are created or run their preflight
-    # — fail, or hang until the watchdog ends the run — happens with a complete line in hand.
-    if later:
-        while later and not bring_up(later.pop(0), True):
-            pass
-        if not b.usable():
-            raise SystemExit("bench.py --gpus %d: no usable device-to-device transport on this node: %r" % (n, probe))
-    elif n > 1 and not bring_up(b.usable()[0], False):
-        raise SystemExit("bench.py --gpus %d: the transport failed its preflight" % n)
-    fallback.watch_sigterm()
-
-    # ---- the default route, measured in full first: from here on there is a number in hand whatever the search runs into
-    dog.phase("set-up (generator, redistribution, CSR blocks)", max(args.watchdog, 600.0))
-    first = b.usable()[0]
-    # (what the flags / environment fixed, read before build() starts writing HNH_RING_MODE itself)
-    fixed_mode = os.environ.get("HNH_RING_MODE") if (args.ring_mode or "HNH_RING_MODE" in os.environ) else None
-    c0 = args.c or 1
-    mode0 = "none" if n // c0 == 1 else os.environ.get("HNH_RING_MODE", "mesh")
-    default_q = current_chunk_spec()
-    route0 = (first, c0, mode0, default_q if mode0 == "mesh" else None)
-    b.build(route0)
-    res = b.measure()
-    tuning_failures = {}
-
-    def finish_line(res, tuning):
-        ex = dict(extra)
-        if preflight is not None:
-            ex["preflight"] = {"primitives_ok": sorted(next(iter(preflight.values()))) if preflight else [], "transports": sorted(preflight),
-                               "communicator_split_order": "identical on all ranks"}
-        line = compose_line(args, b, res, ex)
-        if probe is not None:
-            line["config"]["transport_trials"] = probe
-        if tuning is not None:
-            line["config"]["route_tuning_ms_per_step"] = {route_name(k): (round(v, 4) if v is not None else None) for k, v in tuning.items()}
-            if tuning_failures:
-                line["config"]["route_tuning_failures"] = {route_name(k): v for k, v in tuning_failures.items()}
-        return line
-
-    if rank == 0:
-        fallback.keep(finish_line(res, None))
-    for name in later:  # the remaining transports, with that line in hand
-        bring_up(name, True)
-        if rank == 0:
-            fallback.keep(finish_line(res, None))
-
-    # ---- several GPUs, 1.5D dense shift: transport, replication factor and route of the moving operand.  The reference takes c on the
-    # command line (bench_erdos_renyi.cpp:23-28) and relays the moving operand round a neighbour ring (one xGMI link per direction);
-    # the default here fetches every block straight from its owner (all links at once) in chunks, with one windowed kernel pass per
-    # landed chunk — how many chunks trades kernel efficiency against fetch/compute overlap, c trades ring traffic against
-    # replication traffic, and the transports differ in who moves the bytes (RCCL channels, copy engines, a pull kernel); all of it
-    # depends on the xGMI bandwidth actually delivered.  Unless flags fix them, the candidates are MEASURED (1 warm-up + 5 calls each, the
-    # median, max over ranks): first the default route on every transport, then replication factors and chunk shapes on the fastest one.
-    # A candidate that fails is recorded as null with its reason and the search goes on without its transport.
-    tuning = None
-    if n > 1 and args.alg == "15d_fusion2" and not args.no_tune:
-        cs = [args.c] if args.c else [c for c in (1, 2, 4) if n % c == 0]
-
-        def shapes_for(tr):
-            cand = []
-            for c in cs:
-                if n // c == 1:  # the whole ring is one rank: nothing shifts, the layers only replicate and reduce
-                    cand.append((tr, c, "none", None))
-                    continue
-                if fixed_mode != "relay":
-                    # chunk shapes: the library's default, symmetric Q = 2 / 4 (/ 3 / 8), and for c = 1 a longer falling shape
-                    qs = [str(args.chunks)] if args.chunks else sorted(
-                        {default_q, DEFAULT_CHUNKS, "2", "4"} | ({"3", "8", "3,4,4,3,2,1,1"} if c == 1 else set()), key=lambda q: (q != default_q, len(q), q))
-                    cand += [(tr, c, "mesh", q) for q in qs]
-                if fixed_mode != "mesh":
-                    cand.append((tr, c, "relay", None))
-                if fixed_mode is None and args.app == "vanilla":
-                    # the other fusion strategy of the same schedule (replication reuse): twice the gathers, but its moving operand is
-                    # replicated once for both kernels and its accumulator travels in two halves under the kernels
-                    cand.append((tr, c, "fusion1", None))
-            return cand
-
-        stage1 = [(tr, c0, mode0, default_q if mode0 == "mesh" else None) for tr in b.usable()]
-        total = len(stage1) + len(shapes_for(first)) - 1
-        if total > 1:
-            dog.phase("route tuning (transports, replication factor, mesh chunk shapes, relay ring)", max(args.watchdog, 900.0))
-            tuning = {}
-
-            def trial(route):
-                dog.phase("route tuning: " + route_name(route))  # (every candidate has the watchdog's whole allowance)
-                ms, why = b.try_route(route)
-                tuning[route] = ms
-                if ms is None:
-                    tuning_failures[route] = why
-
-            for route in stage1:
-                trial(route)
-            alive = {k: v for k, v in tuning.items() if v is not None}
-            if alive:
-                best_tr = min(alive, key=alive.get)[0]
-                for route in shapes_for(best_tr):
-                    if route not in tuning:
-                        trial(route)
-            alive = {k: v for k, v in tuning.items() if v is not None}
-            winner = min(alive, key=alive.get) if alive else None  # the same choice on every rank: the times are the all-reduced maxima
-            if rank == 0:
-                fallback.keep(finish_line(res, tuning))
-            if winner is not None and winner != res["route"]:
-                dog.phase("final measurement of the fastest route", max(args.watchdog, 600.0))
-                err, res2 = None, None
-                try:
-                    b.build(winner)
-                    res2 = b.measure()
-                except Exception as e:  # noqa: BLE001
-                    err = "%s: %s" % (type(e).__name__, str(e)[:200])
-                if b.all_ok(err is None):
-                    if res2["elapsed"] <= res["elapsed"] or (res["check"] and not res["check"].get("ok", True)):
-                        res = res2
-                else:
-                    tuning_failures[winner] = "final measurement: " + (err or "failed on another rank")
-                    b.route = None  # (whatever is left of it is not used again)
-
-    out = None
-    if rank == 0:
-        out = finish_line(res, tuning)
-        dur = out["roofline"]["avg_launch_ms"] * 1e-3
-        traffic, traffic_source, live = None, None, None
-        if n == 1 and not args.no_live_traffic and H.backend_name() == "hip-gfx950":
-            dog.note("live counter passes")
-            live = live_traffic(args)
-        if live is not None:
-            traffic = live["bytes_per_launch"]
-            traffic_source = ("live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this command run by this process (%d launches "
-                              "sampled, %.0f s, outside the timed region); 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of the "
-                              "micro-architecture guide); raw KB: fetch %.0f, write %.0f" % (live["launches_sampled"], live["seconds"],
-                                                                                              live["fetch_size_kb_raw"], live["write_size_kb_raw"]))
-        else:
-            tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-            if os.path.exists(tf):
-                try:
-                    with open(tf) as f:
-                        rec = json.load(f)
-                    if args.workload == "er" and args.app == "vanilla" and rec.get("workload_key") == "er%d_ef%d_r%d_n%d" % (args.logm, args.edge_factor, args.r, n):
-                        traffic = rec.get("bytes_per_launch")
-                        traffic_source = ("profiles/hbm_traffic.json (static: rocprofv3 FETCH_SIZE/WRITE_SIZE passes of an earlier run of "
-                                          "this command, not collected live)")
-                except Exception:
-                    traffic = None
-        out["roofline"].update({"traffic": traffic, "traffic_source": traffic_source,
-                                # SURVEY 8(d): the counter-side rate (L2 <-> fabric bytes per launch / launch time; Infinity-Cache hits included)
-                                "traffic_rate": (traffic / dur / 1e9) if (traffic is not None and dur > 0) else None})
-        fallback.keep(out)
-
-    # ---- one GPU: the other workloads of the reference's harness, bounded, outside the timed region
-    if n == 1 and not args.no_secondary:
-        dog.note("secondary workloads")
-        sec = secondary(args, b)
-        if out is not None:
-            out["secondary"] = sec
-    if rank == 0 and n == 1 and not args.no_cpu_baseline and out["backend"] == "hip-gfx950":
-        try:
-            out["cpu_baseline"] = cpu_baseline(args)
-        except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
-            out["cpu_baseline"] = {"value": None, "unit": "nnz*R/s", "cores": os.cpu_count(), "kind": "reference",
-                                   "sample": "FAILED: %s" % str(e)[:300]}
-    if rank == 0:
-        emit(out)
-        fallback.printed = True
-
-    dog.phase("teardown")
-    try:
-        b.free_current()
-    except Exception:  # noqa: BLE001
-        pass
-    if dist is not None:
-        dist.barrier()
-    for t in b.transports.values():  # (a transport that gave up mid-call is left to the process exit)
-        if t["dead"] is not None:
-            t["world"], t["sp"] = None, None
-    b.close_transports()
-    dog.done()
-    check = res["check"]
-    if check is not None and not check["ok"]:
-        raise SystemExit("bench.py: the result check FAILED: %r" % (check,))
-    return out if rank == 0 else None
-
-
-# ------------------------------------------------------------------------------------------------ secondary workloads (N = 1)
-def secondary(args, b):
-    """The rest of the reference's harness on one GPU, each entry bounded to a few seconds and carrying its own byte model and
-    check: (i) R-MAT (hub rows), (ii) config 4's schedule — 2.5D dense-replicate, p = 8, c = 2, R = 256 — on 8 logical ranks sharing
-    this GPU through the loopback transport, (iii) one ALS-CG step, (iv) the GAT forward pass, (v) fused / SDDMM / SpMM at R = 8, 16, 256.
-    Every failure is recorded in its entry; none of them touches the headline."""
-    import numpy as np
-    H, torch = b.H, b.torch
-    world = b.world()
-    out = []
-    small = os.environ.get("HNH_BENCH_SECONDARY_SMALL") is not None  # (the CPU test of this function: same code, toy sizes)
-
-    def entry(name, fn):
-        t0 = time.perf_counter()
-        try:
-            e = fn()
-        except Exception as ex:  # noqa: BLE001
-            e = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
-        e = dict({"workload": name}, **e)
-        e["seconds"] = round(time.perf_counter() - t0, 1)
-        out.append(e)
-
-    def kernel_time(op, fn, calls):
-        """event-bracketed device time of the local kernels of `calls` invocations (ms per invocation), after one warm-up"""
-        fn()
-        world.sync()
-        op.kernel_profile(1)
-        for _ in range(calls):
-            fn()
-        world.sync()
-        ms, launches = op.kernel_profile(0)
-        return ms / calls, max(1, launches // calls)
-
-    def call_time(fn, calls):
-        """wall time per WHOLE operator call (ms), device drained on both sides: the local kernels plus whatever the operation does around
-        them (value copies, zero fills, the closing Hadamard of an SDDMM)"""
-        fn()
-        world.sync()
-        t0 = time.perf_counter()
-        for _ in range(calls):
-            fn()
-        world.sync()
-        return (time.perf_counter() - t0) * 1e3 / calls
-
-    def frac_of(bytes_alg, ms):
-        return bytes_alg / (ms * 1e-3) / HBM_PEAK
-
-    # (v) other widths on the headline matrix and operator (the structure plans and blocks are the headline's)
-    if args.app == "vanilla" and b.op is not None:
-        op, m, nnz = b.op, b.m, b.nnz
-        host = b.wl.host_nonzeros(H)
-        for r in (8, 16, 128, 256):
-            def widths(r=r):
-                op.setRValue(r)
-                A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
-                S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
-                res = {"R": r}
-                try:
-                    ms, _ = kernel_time(op, lambda: op.fusedSpMM(A, B, S, buf, H.AMAT), 3)
-                    res["fused"] = {"ms": ms, "algorithmic_bytes": fused_bytes(nnz, r, m), "frac": frac_of(fused_bytes(nnz, r, m), ms)}
-                    ms, _ = kernel_time(op, lambda: op.sddmmA(A, B, S, buf), 3)
-                    by = nnz * (8 * r + 20) + 8 * r * m
-                    res["sddmm"] = {"ms": ms, "algorithmic_bytes": by, "frac": frac_of(by, ms), "call_ms": call_time(lambda: op.sddmmA(A, B, S, buf), 3)}
-                    ms, _ = kernel_time(op, lambda: op.spmmA(A, B, S), 3)
-                    by = nnz * (8 * r + 12) + 16 * r * m
-                    res["spmm"] = {"ms": ms, "algorithmic_bytes": by, "frac": frac_of(by, ms), "call_ms": call_time(lambda: op.spmmA(A, B, S), 3)}
-                    res["borrowed_value_arrays"] = dict(zip(("spmm_lent", "spmm_copied", "sddmm_in_place", "sddmm_hadamard"), op.borrow_stats()))
-                    if host is not None:  # closed forms with the keyed operands: sddmm(i,j) = a_i b_j (u.v); spmm[i,k] = v_k sum_j b_j
-                        grows, gcols = host
-                        a_key, b_key = keyed(np.arange(m), 1), keyed(np.arange(m), 2)
-                        u_key, v_key = keyed(np.arange(r), 3), keyed(np.arange(r), 4)
-                        A.upload(a_key[:, None] * u_key[None, :])
-                        B.upload(b_key[:, None] * v_key[None, :])
-                        op.sddmmA(A, B, S, buf)
-                        got = buf.download()
-                        w = float(np.dot(u_key, v_key))
-                        # the block's value order is row-major (one block on one rank), like the generator's
-                        e1 = float(np.max(np.abs(got - w * a_key[grows] * b_key[gcols])) / (w * 2.25))
-                        op.spmmA(A, B, S)
-                        gotA = A.download()
-                        want = np.bincount(grows, weights=b_key[gcols], minlength=m)
-                        e2 = float(np.max(np.abs(gotA - want[:, None] * v_key[None, :])) / float(want.max() * v_key.max()))
-                        res["check"] = {"what": "sddmmA and spmmA from keyed operands against a_i b_j (u.v) and v_k sum_{j in row i} b_j",
-                                        "rel_err_sddmm": e1, "rel_err_spmm": e2, "ok": bool(e1 <= 1e-11 and e2 <= 1e-11)}
-                finally:
-                    for x in (A, B, S, buf):
-                        x.free()
-                return res
-            entry("the headline matrix at R=%d: fused / SDDMM / SpMM kernels through the operator (ms = device time of the local kernels, "
-                  "call_ms = the whole sddmmA / spmmA call)" % r, widths)
-        b.op.setRValue(args.r)
-
-    # (iii) one ALS step, (iv) the GAT forward pass — on the headline's matrix and transport, a fresh operator each
-    def app_entry(app):
-        def run_it():
-            sub = Bench(argparse.Namespace(**dict(vars(args), app=app, steps=1, warmup=0, no_check=False)), H, torch, None, 0, 1, Watchdog(0, 0, False), b.wl)
-            sub.transports = {"single": dict(b.transports["single"])}
-            sub.nnz, sub.m = b.nnz, b.m
-            small = None
-            if app == "gat":  # the forward pass's buffers are 2^logm x 1536: a bounded instance (2^18 vertices, edge factor 32 as in profiles/)
-                small = Workload(b.wl.kind if b.wl.kind != "mtx" else "er", min(args.logm, 18), min(args.edge_factor, 32))
-                sub.wl = small
-                sub.transports["single"]["sp"] = None
-            try:
-                sub.build(("single", 1, "none", None))
-                ms = sub.quick_time(1)
-                chk = sub.check_app()
-                info = sub.op.info()
-                if app == "als":
-                    by = 24 * fused_bytes(sub.nnz, args.r, sub.m)
-                    what = "24 fused calls (2 half-steps x (2 + 10 CG iterations)) with the CG updates in the row epilogue"
-                else:
-                    by = sum(h * fused_bytes(sub.nnz, f, sub.m) for _, f, h in GAT_LAYERS)
-                    what = "14 fused heads (SDDMM -> LeakyReLU -> SpMM -> ReLU delivery) + 14 fp64 MFMA GEMMs, the product of head j + 1 on a second compute stream beside the attention pass of head j"
-                return {"ms": ms, "what": what, "nnz": sub.nnz, "M": sub.m, "R": info["R"], "algorithmic_bytes_fused_calls": by,
-                        "frac_whole_step": frac_of(by, ms), "check": chk}
-            finally:
-                sub.free_current()
-                if small is not None and sub.transports["single"]["sp"] is not None:
-                    sub.transports["single"]["sp"].free()
-        return run_it
-
-    entry("one alternating ALS-CG step (run_cg(1), benchmark_dist.cpp:134-137) on the headline matrix, R=%d" % args.r, app_entry("als"))
-    entry("GAT forward pass (layers of benchmark_dist.cpp:88-94) on a bounded instance of the workload", app_entry("gat"))
-
-    # (i) R-MAT with hub rows, fused at the headline width
-    def rmat():
-        wl = Workload("rmat", 9 if small else 20, 8 if small else 44)
-        sub = Bench(argparse.Namespace(**dict(vars(args), app="vanilla", steps=1, warmup=0, no_check=False)), H, torch, None, 0, 1, Watchdog(0, 0, False), wl)
-        sub.transports = {"single": dict(b.transports["single"], sp=None)}
-        try:
-            sub.build(("single", 1, "none", None))
-            ms, launches = kernel_time(sub.op, sub.step, 5)
-            chk = sub.check()
-            deg = np.bincount(wl.host_nonzeros(H)[0], minlength=sub.m)
-            by = fused_bytes(sub.nnz, args.r, sub.m)
-            return {"ms": ms, "nnz": sub.nnz, "M": sub.m, "R": args.r, "longest_row": int(deg.max()), "algorithmic_bytes": by, "frac": frac_of(by, ms),
-                    "note": "hot columns are cache-resident on a skewed graph: the gather model can exceed 100 %",
-                    "check": {k: chk[k] for k in ("rel_err", "rows_checked", "ok")}}
-        finally:
-            sub.free_current()
-            if sub.transports["single"]["sp"] is not None:
-                sub.transports["single"]["sp"].free()
-    entry("R-MAT 2^%d, edge factor %d (hub rows: long-row pass with ordered reduction), fused R=%d" % ((9, 8, args.r) if small else (20, 44, args.r)), rmat)
-
-    # (ii) config 4's schedule and width on 8 logical ranks that share this GPU (loopback transport: device-to-device copies)
-    def cfg4():
-        logm, ef, r = (8, 8, 32) if small else (18, 32, 256)
-        rows, cols = H.generate_rmat(logm, (1 << logm) * ef)
-        m = 1 << logm
-        a_key, b_key = keyed(np.arange(m), 1), keyed(np.arange(m), 2)
-        u_key, v_key = keyed(np.arange(r), 3), keyed(np.arange(r), 4)
-        want_row = float(np.dot(u_key, v_key)) * a_key * np.bincount(rows, weights=b_key[cols] ** 2, minlength=m)
-
-        def body(w):
-            sp = H.SpmatLocal.from_global(w, m, m, rows, cols, np.ones(len(rows)))
-            op = H.DistributedSparse(w, "25d_dense_replicate", sp, r, 2)
-            sp.free()
-            A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
-            S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
-            op.fusedSpMM(A, B, S, buf, H.AMAT)
-            w.sync()
-            w.barrier()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                op.fusedSpMM(A, B, S, buf, H.AMAT)
-            w.sync()
-            w.barrier()
-            ms = (time.perf_counter() - t0) / 3 * 1e3
-
-            def keyed_local(mat_mode, row_key, col_key):
-                parts = []
-                for top, left, rc, cc in op.submatrices(mat_mode):
-                    blk = np.zeros((rc, cc))
-                    keep = int(max(0, min(rc, m - top)))
-                    blk[:keep] = row_key[top:top + keep, None] * col_key[None, left:left + cc]
-                    parts.append(blk.reshape(-1))
-                return np.concatenate(parts)
-            A.upload(keyed_local(H.AMAT, a_key, u_key).reshape(A.shape))
-            B.upload(keyed_local(H.BMAT, b_key, v_key).reshape(B.shape))
-            S.fill(1.0)
-            op.initial_shift(A, B, H.K_SDDMM_A)  # Cannon's skew (25D_cannon_dense.hpp:222-248)
-            op.fusedSpMM(A, B, S, buf, H.AMAT)
-            op.de_shift(A, B, H.K_SDDMM_A)
-            w.sync()
-            got, worst, off = A.download().reshape(-1), 0.0, 0
-            for top, left, rc, cc in op.submatrices(H.AMAT):
-                keep = int(max(0, min(rc, m - top)))
-                blk = got[off:off + rc * cc].reshape(rc, cc)[:keep]
-                off += rc * cc
-                if keep:
-                    worst = max(worst, float(np.max(np.abs(blk - want_row[top:top + keep, None] * v_key[None, left:left + cc]))))
-            for x in (A, B, S, buf):
-                x.free()
-            op.free()
-            return ms, worst
-        res = H.run_spmd(8, body)
-        ms = max(x[0] for x in res)
-        err = max(x[1] for x in res) / float(want_row.max() * v_key.max())
-        by = len(rows) * (16 * r + 44) + 16 * r * m  # the unfused pair this schedule runs (SURVEY 8d B_unfused)
-        return {"ms": ms, "nnz": int(len(rows)), "M": m, "R": r, "schedule": "25d_dense_replicate p=8 c=2 (2 x 2 x 2), 8 logical ranks on ONE GPU, loopback copies",
-                "algorithmic_bytes": by, "frac": frac_of(by, ms),
-                "note": "all 8 ranks' kernels AND their device-to-device copies share this one GPU: a correctness-at-shape and cost figure, not a scaling claim",
-                "check": {"rel_err": err, "ok": bool(err <= 1e-11)}}
-    entry("config 4's shape, bounded: R-MAT 2^%d, edge factor %d, R=%d, 2.5D dense-replicate on 8 logical ranks" % ((8, 8, 32) if small else (18, 32, 256)), cfg4)
-
-    # (vi) the one throughput the reference's own tree prints for this path (BASELINE.md section 1): the p = 1 point of its weak-scaling
-    # experiment 1 — `15d_sparse`, fused, 5 FusedMM calls in 0.8375 s on one Cori KNL node (ipdps_chart_generator.ipynb:564), at the size
-    # its own throughput line implies (:573,589: 2^16 rows, 32 nonzeros per row, R = 256) — timed the reference's way (benchmark_dist.cpp:
-    # 117-149: wall time of 5 calls) on this GPU.  Other hardware, a printed cell output, not a controlled comparison: context only.
-    def knl_point():
-        logm, ef, r = (8, 8, 32) if small else (16, 32, 256)
-        wl = Workload("er", logm, ef)
-        sub = Bench(argparse.Namespace(**dict(vars(args), app="vanilla", alg="15d_sparse", r=r, steps=5, warmup=0, no_check=False)), H, torch, None, 0, 1,
-                    Watchdog(0, 0, False), wl)
-        sub.transports = {"single": dict(b.transports["single"], sp=None)}
-        try:
-            sub.build(("single", 1, "none", None))
-            sub.step()
-            world.sync()
-            t0 = time.perf_counter()
-            for _ in range(5):
-                sub.step()
-            world.sync()
-            s5 = time.perf_counter() - t0
-            chk = sub.check()
-            by = sub.nnz * (16 * r + 44) + 16 * r * sub.m  # this schedule runs the SDDMM + SpMM pair (SURVEY 8d B_unfused)
-            ref_s, ref_rate = 0.8375, (2 ** 16) * 32 * 256 * 5 / 0.8375
-            res = {"seconds_for_5_fusedmm": s5, "ms": s5 / 5 * 1e3, "nnz": sub.nnz, "M": sub.m, "R": r, "schedule": "15d_sparse, fused, p = 1, c = 1",
-                   "nnzR_per_s": sub.nnz * r * 5 / s5, "algorithmic_bytes": by, "frac": frac_of(by, s5 / 5 * 1e3),
-                   "check": {k: chk[k] for k in ("rel_err", "rows_checked", "ok")}}
-            if not small:
-                res["reference_printed"] = {"seconds_for_5_fusedmm": ref_s, "nnzR_per_s": ref_rate, "hardware": "one Cori KNL node, 1 MPI rank",
-                                            "source": "ipdps_chart_generator.ipynb:564 (time), :573,589 (the size its throughput line implies)",
-                                            "speedup": ref_s / s5}
-            return res
-        finally:
-            sub.free_current()
-            if sub.transports["single"]["sp"] is not None:
-                sub.transports["single"]["sp"].free()
-    entry("the reference's printed weak-scaling point at p = 1: ER 2^%d, %d nonzeros per row, R=%d, 15d_sparse fused, 5 FusedMM timed the reference's way"
-          % ((8, 8, 32) if small else (16, 32, 256)), knl_point)
-    return out
-
-
-def error_line(args, message, **extra):
-    """The one JSON line of a run that failed: the contract's keys with value null, plus what went wrong and where."""
-    out = {"metric": "fused SDDMM+SpMM nnz*R/s", "value": None, "unit": "nnz*R/s", "n_gpus": args.gpus, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-           "dtype": "f64", "data": "synthetic", "config": {"workload": "%s 2^%d, edge factor %d, R=%d, %s, %s on %d x MI355X" % (
-               args.workload, args.logm, args.edge_factor, args.r, args.app, args.alg, args.gpus)}, "error": message}
-    out.update(extra)
-    return out
-
-
-def launch(args, argv):
-    """`python bench.py --gpus N` typed as is (no WORLD_SIZE in the environment): start the N workers ourselves — one process
-    per GPU, rendezvous on 127.0.0.1 at a free port, the same environment torch.distributed.run would give them — forward
-    rank 0's JSON line, and return the worst exit code.  Whatever happens ONE JSON line is printed: a rank that fails or
-    hangs is named together with the phase it was in (the workers keep that in a status file), the others are ended."""
-    import shutil
-    import socket
-    import subprocess
-    import tempfile
-    import threading
-    n = args.gpus
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    status_dir = tempfile.mkdtemp(prefix="hnh_bench_")
-    worker = os.environ.get("HNH_BENCH_WORKER") or os.path.abspath(__file__)  # tests substitute a worker with a CPU transport
-    procs, lines, pumps = [], [], []
-
-    def pump(stream, rank):
-        for ln in stream:
-            if rank == 0 and ln.lstrip().startswith("{") and '"metric"' in ln:
-                lines.append(ln.strip())
-            else:
-                sys.stderr.write(ln if rank == 0 else "[rank %d] %s" % (rank, ln))
-                sys.stderr.flush()
-
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HNH_BENCH_STATUS_DIR=status_dir)
-        p = subprocess.Popen([sys.executable, worker] + list(argv), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        procs.append(p)
-        t = threading.Thread(target=pump, args=(p.stdout, r), daemon=True)
-        t.start()
-        pumps.append(t)
-
-    def phase_of(r):
-        try:
-            with open(os.path.join(status_dir, "rank%d.phase" % r)) as f:
-                return f.read().strip() or "start-up"
-        except OSError:
-            return "start-up (before the benchmark body)"
-
-    deadline = time.monotonic() + args.launch_timeout
-    first_bad, grace, timed_out = None, None, False
-    while any(p.poll() is None for p in procs):
-        now = time.monotonic()
-        for r, p in enumerate(procs):
-            if first_bad is None and p.poll() not in (None, 0):
-                first_bad, grace = (r, p.returncode, phase_of(r)), now + 20.0  # the others get a moment to report, then are ended
-        if (grace is not None and now > grace) or now > deadline:
-            timed_out = now > deadline and first_bad is None
-            for p in procs:  # exactly the processes started above
-                if p.poll() is None:
-                    p.terminate()
-            for p in procs:
-                try:
-                    p.wait(timeout=10)
-                except subprocess.TimeoutExpired:
-                    p.kill()
-            break
-        time.sleep(0.2)
-    for t in pumps:
-        t.join(timeout=5)
-    codes = [p.returncode for p in procs]
-    phases = {str(r): phase_of(r) for r in range(n)}
-    if first_bad is None and not timed_out:  # everybody had ended between two polls
-        bad = [r for r, c in enumerate(codes) if c != 0]
-        if bad:
-            first_bad = (bad[0], codes[bad[0]], phases[str(bad[0])])
-    shutil.rmtree(status_dir, ignore_errors=True)
-    worst = max((abs(c) if c is not None else 1) for c in codes)
-    if timed_out:
-        emit(error_line(args, "no result after %.0f s: the launcher ended its workers" % args.launch_timeout,
-                        failed_rank=None, phases=phases, exit_codes=codes))
-        return worst or 1
-    if first_bad is None and len(lines) == 1 and worst == 0:
-        emit(lines[0])
-        return 0
-    if first_bad is not None:
-        r, code, ph = first_bad
-        # a rank that gave up AFTER rank 0 held a complete measurement: rank 0 has printed that line, marked "incomplete" — it is the result
-        if lines:
-            try:
-                got = json.loads(lines[-1])
-                if got.get("value") is not None and "incomplete" in got:
-                    got["incomplete"] += "; rank %d exited with code %s in phase '%s'" % (r, code, ph)
-                    got["exit_codes"], got["phases"] = codes, phases
-                    emit(got)
-                    return 0
-            except ValueError:
-                pass
-        msg = "rank %d exited with code %s in phase '%s'" % (r, code, ph)
-        # a failed result check still carries a measured line: keep it, marked
-        extra = {"failed_rank": r, "phase": ph, "phases": phases, "exit_codes": codes}
-        if lines:
-            try:
-                extra["line_of_rank0"] = json.loads(lines[-1])
-            except ValueError:
-                pass
-        emit(error_line(args, msg, **extra))
-        return worst or 1
-    emit(error_line(args, "the workers ended without a result line (%d lines seen)" % len(lines), failed_rank=None,
-                    phases=phases, exit_codes=codes))
-    return worst or 1
-
-
-def main():
-    argv = sys.argv[1:]
-    args = parse(argv)
-    claim_stdout()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch(args, argv))
-    try:
-        run(args)
-    except BaseException as e:  # one GPU, or a worker: a failure is still reported as one JSON line by whoever owns stdout
-        if (int(os.environ.get("RANK", "0")) == 0 and "HNH_BENCH_STATUS_DIR" not in os.environ and not args.probe_transport
-                and not (isinstance(e, SystemExit) and e.code in (0, None))):
-            emit(error_line(args, "%s: %s" % (type(e).__name__, str(e)[:500]), failed_rank=0))
-        raise
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        dist.destroy_process_group()
-
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from benchlib import common  # noqa: E402,F401  (first: the run's clock starts here)
+from benchlib.cli import parse  # noqa: E402,F401
+from benchlib.common import route_name  # noqa: E402,F401
+from benchlib.run import main, run  # noqa: E402,F401
+from benchlib.timed import Bench  # noqa: E402,F401
 
 if __name__ == "__main__":
     main()

@@ -1,0 +1,133 @@
+"""Shared pieces of the benchmark driver: the one-line stdout contract, chunk-shape and route names, the keyed operands of the
+result checks, the workloads (benchmark_dist.cpp / bench_erdos_renyi.cpp / bench_file.cpp) and the SURVEY 8(d) byte model."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T_START = time.monotonic()  # the run's clock: --budget-s and phases_s count from here (bench.py imports this module first)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+GAT_LAYERS = [(256, 256, 4), (1024, 256, 4), (1024, 256, 6)]  # benchmark_dist.cpp:88-94: (input features, features per head, heads)
+
+_JSON_FD = None
+
+
+def claim_stdout():
+    """stdout carries exactly ONE line, the JSON result: everything else this process writes to file descriptor 1 (the host
+    library mirrors the reference's console messages, e.g. "R-mat generator created ... nonzeros") goes to stderr instead."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (obj if isinstance(obj, str) else json.dumps(obj)) + "\n"
+    if _JSON_FD is None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line.encode())
+
+
+def unblock_signals():
+    """preexec_fn of every child this driver starts: rank 0 keeps SIGTERM / SIGINT blocked for its sigwait() thread (guards.Fallback),
+    and a signal mask is inherited across exec."""
+    import signal
+    signal.pthread_sigmask(signal.SIG_UNBLOCK, {signal.SIGTERM, signal.SIGINT})
+
+
+DEFAULT_CHUNKS = "1,2,2,2,1,1"  # the library's default shape of the mesh fetch (dense_shift_15d.hpp)
+
+
+def set_chunk_spec(spec):
+    """A chunk spec is a number (Q symmetric chunks, HNH_MESH_CHUNKS) or a comma list of heights (HNH_MESH_TAPER)."""
+    if "," in spec:
+        os.environ["HNH_MESH_TAPER"] = spec
+        os.environ.pop("HNH_MESH_CHUNKS", None)
+    else:
+        os.environ["HNH_MESH_CHUNKS"] = spec
+        os.environ.pop("HNH_MESH_TAPER", None)
+
+
+def current_chunk_spec():
+    return os.environ.get("HNH_MESH_TAPER") or os.environ.get("HNH_MESH_CHUNKS") or DEFAULT_CHUNKS
+
+
+def route_name(route):
+    """route = (transport, c, mode, chunk spec)"""
+    tr, c, mode, q = route
+    mesh = ("mesh/heights %s" % q) if (q and "," in str(q)) else ("mesh/%s chunks" % q)
+    return "c=%d %s [%s]" % (c, {"mesh": mesh, "relay": "relay ring", "none": "replication only",
+                                 "fusion1": "15d_fusion1 (replication reuse: SDDMM + SpMM, accumulator ring in two halves)"}[mode], tr)
+
+
+def keyed(idx, salt):
+    """Deterministic value in [0.5, 1.5) per global index (multiplicative hash): the operands of the result check."""
+    import numpy as np
+    h = (idx.astype(np.uint64) * np.uint64(2654435761) + np.uint64(salt) * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
+    return 0.5 + h.astype(np.float64) / 4294967296.0
+
+class Workload:
+    """The sparse matrix of the run (benchmark_dist.cpp / bench_erdos_renyi.cpp / bench_file.cpp): how every rank gets its
+    tuples, and the host copy of the nonzeros the result checks sum over."""
+
+    def __init__(self, spec, logm, edge_factor):
+        self.spec, self.logm, self.ef = spec, logm, edge_factor
+        self.kind = "mtx" if spec.startswith("mtx:") else spec
+        if self.kind not in ("er", "rmat", "mtx"):
+            raise SystemExit("bench.py --workload %r: use er, rmat or mtx:<path>" % spec)
+        self.path = spec[4:] if self.kind == "mtx" else None
+        self._host = None
+
+    def host_nonzeros(self, H):
+        """(rows, cols) of the global matrix on the host — the generators are deterministic and bit-identical to the device
+        ones; a file is parsed with scipy when it is small enough."""
+        if self._host is None:
+            m = 1 << self.logm
+            if self.kind == "er":
+                self._host = H.generate_er(m, m, m * self.ef, 12345)
+            elif self.kind == "rmat":
+                self._host = H.generate_rmat(self.logm, m * self.ef)
+            else:
+                if os.path.getsize(self.path) > 400 << 20:
+                    return None
+                import numpy as np
+                import scipy.io
+                a = scipy.io.mmread(self.path).tocsr()
+                a.sum_duplicates()
+                a = a.tocoo()
+                self._host = (a.row.astype(np.int64), a.col.astype(np.int64))
+        return self._host
+
+    def load(self, H, world):
+        if self.kind == "er":
+            return H.SpmatLocal.load_tuples(world, False, self.logm, self.ef)
+        if self.kind == "mtx":
+            return H.SpmatLocal.load_tuples(world, True, 0, 0, self.path)
+        import numpy as np
+        rows, cols = self.host_nonzeros(H)
+        m = 1 << self.logm
+        return H.SpmatLocal.from_global(world, m, m, rows, cols, np.ones(len(rows)))
+
+    def describe(self, nnz):
+        if self.kind == "er":
+            return "Erdos-Renyi 2^%d x 2^%d, edge factor %d (%d unique nnz)" % (self.logm, self.logm, self.ef, nnz)
+        if self.kind == "rmat":
+            return "R-MAT 2^%d x 2^%d (a,b,c = .57,.19,.19), edge factor %d (%d unique nnz)" % (self.logm, self.logm, self.ef, nnz)
+        return "MatrixMarket file %s (%d nnz)" % (os.path.basename(self.path), nnz)
+
+
+def fused_bytes(nnz, r, rows):
+    return nnz * (8 * r + 24) + 16 * r * rows
+def error_line(args, message, **extra):
+    """The one JSON line of a run that failed: the contract's keys with value null, plus what went wrong and where."""
+    out = {"metric": "fused SDDMM+SpMM nnz*R/s", "value": None, "unit": "nnz*R/s", "n_gpus": args.gpus, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic", "config": {"workload": "%s 2^%d, edge factor %d, R=%d, %s, %s on %d x MI355X" % (
+               args.workload, args.logm, args.edge_factor, args.r, args.app, args.alg, args.gpus)}, "error": message}
+    out.update(extra)
+    return out

@@ -106,6 +106,7 @@ SIGNATURES = {
     "hnh_dist_fusedSpMM": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32]),
     "hnh_dist_algorithm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32]),
     "hnh_dist_hold_moving_operand": (_i32, [_vp, _vp]),
+    "hnh_dist_walk_windows_when_held": (_i32, [_vp, _i32]),
     "hnh_dist_fusedSpMM_out": (_i32, [_vp, _vp, _vp, _i32, _vp, _i32, C.c_double, C.c_double, _vp, C.POINTER(C.c_int)]),
     "hnh_als_create": (_i32, [_vp, _i32, _u64, _pvp]),
     "hnh_als_destroy": (_i32, [_vp]),
@@ -518,6 +519,11 @@ class DistributedSparse:
     def hold_moving_operand(self, m=None):
         """Distributed_Sparse::hold_moving_operand(m) / release_moving_operand() (m = None)."""
         _check(lib().hnh_dist_hold_moving_operand(self.h, m.h if m else None), "hold_moving_operand")
+
+    def walk_windows_when_held(self, on=True):
+        """Distributed_Sparse::walk_windows_when_held: a held operand's resident blocks are walked chunk window by chunk window, as a
+        fetching call does (measurement entry point: one rank's kernel sequence alone on a GPU)."""
+        _check(lib().hnh_dist_walk_windows_when_held(self.h, int(bool(on))), "walk_windows_when_held")
 
     def fusedSpMM_out(self, a, b, matmode: int, out, leaky_alpha=None, x_scale: float = 0.0, rowdot=None) -> bool:
         """Distributed_Sparse::fusedSpMM_out; False (nothing done) when the schedule has no single fused pass."""

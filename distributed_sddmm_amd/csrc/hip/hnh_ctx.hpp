@@ -26,7 +26,7 @@ struct hnh_ctx {
     int row_waves_cap = -1;  // HNH_ROW_WAVES_CAP=k: 1..7 = at most k waves per SIMD for every row-kernel launch, 0 = never cap; unset = the
                              // library's rule (uniform blocks of certain widths run at 5, see row_occupancy_pad in hnh_kernels.hip)
     int long_grid = 1024;           // workgroups of the hub-row segment pass (HNH_LONG_GRID, measurement aid)
-    int comm_cus = 0;               // compute units masked off streams[HNH_STREAM_COMPUTE] (HNH_COMM_CUS, default 16; 0 = no mask)
+    int comm_cus = 0;               // compute units masked off streams[HNH_STREAM_COMPUTE] (HNH_COMM_CUS; default 0 = no mask, see hnh_runtime.hip)
     // the unmasked twin of the compute stream for launches that want every CU (hnh::WideLaunch); null when nothing is masked
     hipStream_t wide = nullptr;
     hipEvent_t wide_fork = nullptr, wide_join = nullptr;

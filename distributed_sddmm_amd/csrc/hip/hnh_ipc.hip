@@ -63,11 +63,20 @@ __global__ __launch_bounds__(256) void pull_kernel(PullList list, int wgs) {
         const size_t n = bytes / 16, per = ((n + (size_t)wgs - 1) / (size_t)wgs + 255) / 256 * 256;
         const size_t lo = per * (size_t)part, hi = lo + per < n ? lo + per : n;
         if (lo < hi) pull_part(reinterpret_cast<v2d*>(dst), reinterpret_cast<const v2d*>(src), lo, hi);
-    } else {
+    } else if ((((uintptr_t)dst | (uintptr_t)src) & 7) == 0) {
         const size_t n = bytes / 8, per = ((n + (size_t)wgs - 1) / (size_t)wgs + 255) / 256 * 256;
         const size_t lo = per * (size_t)part, hi = lo + per < n ? lo + per : n;
         if (lo < hi) pull_part(reinterpret_cast<double*>(dst), reinterpret_cast<const double*>(src), lo, hi);
         if (part == 0 && threadIdx.x < (bytes & 7)) dst[n * 8 + threadIdx.x] = src[n * 8 + threadIdx.x];
+    } else if ((((uintptr_t)dst | (uintptr_t)src) & 3) == 0) {  // e.g. an int32 slice at an odd element offset (device_alltoallv displacements)
+        const size_t n = bytes / 4, per = ((n + (size_t)wgs - 1) / (size_t)wgs + 255) / 256 * 256;
+        const size_t lo = per * (size_t)part, hi = lo + per < n ? lo + per : n;
+        if (lo < hi) pull_part(reinterpret_cast<int*>(dst), reinterpret_cast<const int*>(src), lo, hi);
+        if (part == 0 && threadIdx.x < (bytes & 3)) dst[n * 4 + threadIdx.x] = src[n * 4 + threadIdx.x];
+    } else {  // byte-displaced: nothing may be assumed
+        const size_t per = ((bytes + (size_t)wgs - 1) / (size_t)wgs + 255) / 256 * 256;
+        const size_t lo = per * (size_t)part, hi = lo + per < bytes ? lo + per : bytes;
+        if (lo < hi) pull_part(dst, src, lo, hi);
     }
 }
 

@@ -587,6 +587,9 @@ int hnh_dist_hold_moving_operand(hnh_dist* d, hnh_dense* m) {
         else d->d->release_moving_operand();
     });
 }
+int hnh_dist_walk_windows_when_held(hnh_dist* d, int on) {
+    return guarded(d->w, [&] { d->d->walk_windows_when_held(on != 0); });
+}
 int hnh_dist_fusedSpMM_out(hnh_dist* d, hnh_dense* A, hnh_dense* B, int matmode, hnh_dense* Out, int leaky, double leaky_alpha,
                            double x_scale, hnh_vec* rowdot, int* supported) {
     return guarded(d->w, [&] {

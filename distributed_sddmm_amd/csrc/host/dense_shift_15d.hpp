@@ -87,6 +87,8 @@ public:
         held_slot = -1;
         held_in_ring = false;
     }
+    bool force_windows = false;
+    void walk_windows_when_held(bool on) override { force_windows = on; }
 
     Sparse15D_Dense_Shift(SpmatLocal* S_input, int R, int c, int fusionApproach, KernelImplementation* k) : Distributed_Sparse(k) {
         this->fusionApproach = fusionApproach;
@@ -366,13 +368,8 @@ private:
         CSRLocal* remote = choice->csr_blocks[1];
         one(0, *Brole, -1, remote == nullptr);
         if (remote != nullptr) {
-#ifdef HNH_MEASUREMENT_AIDS
-            // (libhnh_host_aids.so only) HNH_FORCE_WINDOWS: walk the windows although a held operand's blocks are already there,
-            // which lets one rank's kernel sequence be timed without its peers (tools/rank_share_probe.py)
-            static const bool force_windows = std::getenv("HNH_FORCE_WINDOWS") != nullptr;
-#else
-            constexpr bool force_windows = false;
-#endif
+            // walk_windows_when_held(): walk the windows although a held operand's blocks are already there, which lets one rank's
+            // kernel sequence be timed without its peers (bench.py's rank-share entries, tools/rank_share_probe.py)
             const bool by_window = kernel->handles_windows() && remote->n_windows > 1 && (!resident || force_windows);
             if (!by_window) {
                 world->event_wait(event(8 + windows - 1), HNH_STREAM_COMPUTE);  // every chunk has landed

@@ -33,6 +33,7 @@ public:
     GAT(std::vector<GATLayer>& l_input, Distributed_Sparse* d_ops) {
         if (l_input.empty()) hnh::fatal("Error, a GAT needs at least one layer!");
         this->d_ops = d_ops;
+        world_ = d_ops->world;  // not owned by the operator: benchmark_dist.cpp:166 deletes d_ops while its GAT is still alive
         layers = l_input;
         d_ops->setRValue(layers[0].input_features);
         buffers.push_back(d_ops->like_B_matrix(0.0));
@@ -47,9 +48,9 @@ public:
         }
     }
 
-    ~GAT() {
-        if (d_ops == nullptr || d_ops->world == nullptr) return;
-        hnh::World* w = d_ops->world;
+    ~GAT() {  // never touches d_ops: the reference's harness has deleted it by now (benchmark_dist.cpp:166 vs the unique_ptr's scope)
+        hnh::World* w = world_;
+        if (w == nullptr) return;
         w->sync_all_nothrow();  // the events below may still be waited on
         for (void* e : {ev_input, ev_gemm[0], ev_gemm[1], ev_head[0], ev_head[1]})
             if (e) w->event_destroy(e);
@@ -103,6 +104,7 @@ public:
     }
 
 private:
+    hnh::World* world_ = nullptr;
     DenseMatrix product[2];  // X * W_j of the head in flight and of the next one
     void* ev_input = nullptr;
     void* ev_gemm[2] = {nullptr, nullptr};

@@ -2,6 +2,7 @@
 
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -10,6 +11,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <chrono>
+#include <cerrno>
 #include <cstdio>
 #include <cstring>
 #include <deque>
@@ -493,22 +495,34 @@ World* world_from_environment() {
     const char* idfile_env = std::getenv("HNH_ID_FILE");
     const bool own_file = (idfile_env == nullptr || !*idfile_env);
     const std::string idfile = own_file ? "/dev/shm/hnh_rccl_id_" + l.token : std::string(idfile_env);
+    // The record is the id followed by rank 0's pid: a file left behind by an earlier launch (a run killed before rank 0 removed it, a
+    // user-named file that was never removed; launches from one shell share the automatic name) names a process that is gone, and is
+    // waited out instead of being joined — ncclCommInitRank on a stale id hangs.
     char id[HNH_UNIQUE_ID_BYTES];
     if (rank == 0) {
         if (be->hnh_comm_unique_id(id) != HNH_OK) fatal("Error, cannot create an RCCL unique id (HNH_TRANSPORT=ipc selects the ipc-pull transport)");
+        std::remove(idfile.c_str());
         const std::string tmp = idfile + ".tmp";
-        std::ofstream(tmp, std::ios::binary).write(id, sizeof(id));
+        const int64_t me = (int64_t)getpid();
+        {
+            std::ofstream f(tmp, std::ios::binary);
+            f.write(id, sizeof(id));
+            f.write(reinterpret_cast<const char*>(&me), sizeof(me));
+        }
         if (std::rename(tmp.c_str(), idfile.c_str()) != 0) fatal("Error, cannot write the RCCL unique id file " + idfile);
     } else {
         for (int tries = 0;; tries++) {
             std::ifstream f(idfile, std::ios::binary);
-            if (f && f.read(id, sizeof(id))) break;
-            if (tries > 6000) fatal("Error, timed out waiting for the RCCL unique id file " + idfile);
+            int64_t writer = 0;
+            if (f && f.read(id, sizeof(id)) && f.read(reinterpret_cast<char*>(&writer), sizeof(writer)) && writer > 0 &&
+                (kill((pid_t)writer, 0) == 0 || errno == EPERM))
+                break;
+            if (tries > 6000) fatal("Error, timed out waiting for the RCCL unique id file " + idfile + " (of a live rank 0)");
             std::this_thread::sleep_for(std::chrono::milliseconds(10));
         }
     }
     World* w = new RcclWorld(rank, n, be, device, id);
-    if (rank == 0 && own_file) std::remove(idfile.c_str());
+    if (rank == 0) std::remove(idfile.c_str());  // creating the communicator is collective: every rank has read the record
     return w;
 }
 
@@ -825,6 +839,7 @@ constexpr uint64_t kIpcMagic = 0x686e685f69706331ULL;
 struct IpcShared {
     std::atomic<uint64_t> magic;
     int nranks;
+    int64_t creator_pid;  // rank 0's: a segment whose creator is gone is a leftover of an earlier launch with the same session name
     std::atomic<int> attached, detached, failed;
     std::atomic<uint64_t> bar_arrived, bar_generation;
     struct Msg {
@@ -871,35 +886,58 @@ IpcWorld::IpcWorld(int r, int nranks, Backend* backend, int device_ordinal, cons
         else if (std::string(m) != "engine") fatal("Error, HNH_IPC_PULL must be engine or kernel!");
     }
     if (const char* w = std::getenv("HNH_IPC_PULL_WGS")) pull_wgs_ = std::max(1, std::min(256, std::atoi(w)));
+    if (const char* w = std::getenv("HNH_IPC_MAX_OPENED")) kIpcMaxOpened = (size_t)std::max(1, std::atoi(w));
     init_device(backend, device_ordinal);
     shm_name_ = "/hnh_ipc_" + session;
-    int fd = -1;
-    if (rank == 0) {
-        shm_unlink(shm_name_.c_str());
-        fd = shm_open(shm_name_.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (fd < 0 || ftruncate(fd, (off_t)sizeof(IpcShared)) != 0) fatal("Error, ipc world: cannot create the shared-memory segment " + shm_name_);
-    } else {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (;;) {
-            fd = shm_open(shm_name_.c_str(), O_RDWR, 0600);
-            struct stat st;
-            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(IpcShared)) break;
-            if (fd >= 0) close(fd);
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_limit_s_)
-                fatal("Error, ipc world: rank 0 never created the shared-memory segment " + shm_name_);
-            usleep(1000);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        int fd = -1;
+        if (rank == 0) {
+            shm_unlink(shm_name_.c_str());
+            fd = shm_open(shm_name_.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+            if (fd < 0 || ftruncate(fd, (off_t)sizeof(IpcShared)) != 0) fatal("Error, ipc world: cannot create the shared-memory segment " + shm_name_);
+        } else {
+            for (;;) {
+                fd = shm_open(shm_name_.c_str(), O_RDWR, 0600);
+                struct stat st;
+                if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(IpcShared)) break;
+                if (fd >= 0) close(fd);
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_limit_s_)
+                    fatal("Error, ipc world: rank 0 never created the shared-memory segment " + shm_name_);
+                usleep(1000);
+            }
         }
-    }
-    void* m = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) fatal("Error, ipc world: cannot map the shared-memory segment");
-    sh_ = static_cast<IpcShared*>(m);
-    if (rank == 0) {
-        sh_->nranks = nranks;  // (a fresh segment is zero-filled)
-        sh_->magic.store(kIpcMagic, std::memory_order_release);
-    } else {
-        wait_host([&] { return sh_->magic.load(std::memory_order_acquire) == kIpcMagic; }, "rank 0 to initialise the segment");
-        if (sh_->nranks != nranks) fatal("Error, ipc world: the ranks disagree about the world size");
+        void* m = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) fatal("Error, ipc world: cannot map the shared-memory segment");
+        sh_ = static_cast<IpcShared*>(m);
+        if (rank == 0) {
+            sh_->nranks = nranks;  // (a fresh segment is zero-filled)
+            sh_->creator_pid = (int64_t)getpid();
+            sh_->magic.store(kIpcMagic, std::memory_order_release);
+            break;
+        }
+        // A leftover of an earlier launch under the same session name (killed before rank 0 removed the name) can be opened before
+        // rank 0 replaces it: its creator is gone, or it already counts a full world.  Drop the mapping and look again.
+        bool stale = false;
+        const auto t1 = std::chrono::steady_clock::now();
+        while (sh_->magic.load(std::memory_order_acquire) != kIpcMagic && !stale) {
+            stale = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() > 5.0;  // a creator that never finished
+            usleep(200);
+        }
+        if (!stale) {
+            const pid_t creator = (pid_t)sh_->creator_pid;
+            stale = creator <= 0 || (kill(creator, 0) != 0 && errno != EPERM) || sh_->attached.load() >= sh_->nranks || sh_->failed.load() != 0;
+        }
+        if (!stale) {
+            if (sh_->nranks != nranks) fatal("Error, ipc world: the ranks disagree about the world size");
+            break;
+        }
+        munmap(m, sizeof(IpcShared));
+        sh_ = nullptr;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_limit_s_)
+            fatal("Error, ipc world: only a stale shared-memory segment " + shm_name_ + " was found (rank 0 never replaced it)");
+        usleep(2000);
     }
     sh_->attached.fetch_add(1);
     wait_host([&] { return sh_->attached.load() >= nranks; }, "every rank to attach");
@@ -993,15 +1031,20 @@ void* IpcWorld::open_peer(const unsigned char* handle, uint64_t alloc_bytes) {
     std::string key(reinterpret_cast<const char*>(handle), HNH_IPC_HANDLE_BYTES);
     auto it = opened_.find(key);
     if (it != opened_.end()) return it->second;
-    if (opened_.size() >= 512) {  // handles of blocks the peers have long freed pile up: drop all mappings at a quiet moment
-        sync_all();
-        for (auto& kv : opened_) check(be->hnh_ipc_close(ctx, kv.second), "hnh_ipc_close");
-        opened_.clear();
-    }
+    // never evicts: a flush() in progress holds `base + offset` of this group's earlier receives (make_room() runs before the group)
     void* base = nullptr;
     check(be->hnh_ipc_open(ctx, handle, alloc_bytes, &base), "hnh_ipc_open");
     opened_[key] = base;
     return base;
+}
+
+// Handles of blocks the peers have long freed pile up.  They are dropped — all of them, behind a drained device — only BETWEEN
+// groups: before a flush() that could take the table past its cap even if every one of its receives names a new allocation.
+void IpcWorld::make_room(size_t incoming) {
+    if (opened_.size() + incoming <= kIpcMaxOpened) return;
+    sync_all();  // nothing of the coming group is enqueued yet: this waits for earlier groups only
+    for (auto& kv : opened_) check(be->hnh_ipc_close(ctx, kv.second), "hnh_ipc_close");
+    opened_.clear();
 }
 
 void IpcWorld::group_begin() { group_depth_++; }
@@ -1024,6 +1067,9 @@ void IpcWorld::flush() {
     ops.swap(pending_);
     const int stream = ops[0].stream;
     const int M = kIpcMaxRanks;
+    size_t incoming = 0;
+    for (const Op& o : ops) incoming += (o.src != rank && o.recvbytes) ? 1 : 0;
+    make_room(incoming);
     // 1. sends: raise "ready" behind everything enqueued so far, then post where the bytes are
     std::vector<uint64_t> sent(ops.size(), 0), received(ops.size(), 0);
     for (size_t i = 0; i < ops.size(); i++) {

@@ -171,6 +171,10 @@ int hnh_dist_fusedSpMM(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_
  * the same until released (m = NULL), so a schedule may keep the blocks of it that it fetched from other ranks (the fixed
  * factor of an ALS half-step, als_conjugate_gradients.cpp:38-141).  Ignored by schedules that cannot use it. */
 int hnh_dist_hold_moving_operand(hnh_dist* d, hnh_dense* m_or_null);
+/* Distributed_Sparse::walk_windows_when_held (an addition, a MEASUREMENT entry point): with a held operand's blocks resident a call
+ * runs one pass over them; on = 1 makes it walk the chunk windows as a fetching call does (own block, then one windowed pass per
+ * chunk), so that one rank's kernel sequence of a p-rank job can be timed alone on a GPU.  Same results either way. */
+int hnh_dist_walk_windows_when_held(hnh_dist* d, int on);
 /* Distributed_Sparse::fusedSpMM_out (an addition): out-of-place fusedSpMM with the applications' surrounding work in the
  * same pass — LeakyReLU between the halves (gat.hpp:96-99), Out += x_scale * X and rowdot[i] = <X[i,:], Out[i,:]>
  * (als_conjugate_gradients.cpp:93,282,295).  *supported = 0 and nothing done when the schedule has no single fused pass. */

@@ -25,6 +25,9 @@ MPIEXEC = os.environ.get("HNH_MPIEXEC", "/opt/conda/bin/mpiexec")
 ALGS = ("15d_fusion1", "15d_fusion2", "15d_sparse", "25d_dense_replicate", "25d_sparse_replicate")
 
 
+PREEXEC = None  # (bench.py's cpu_baseline leg: children get SIGTERM / SIGINT unblocked)
+
+
 def available() -> bool:
     return (os.path.exists(os.path.join(REF_DIR, "ref_driver"))
             and os.path.exists(os.path.join(CONDA_LIB, "libmkl_core.so.1"))
@@ -71,7 +74,7 @@ def run(args, p: int, alg: str, threads: int | None = None, timeout: float = 600
     last = None
     for _ in range(retries):
         try:
-            out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+            out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, preexec_fn=PREEXEC)
         except subprocess.TimeoutExpired as e:  # known reference hang; try again
             last = e
             continue

@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 import bench  # noqa: E402
+from benchlib import transports as BT  # noqa: E402  (where bench.py's transport hooks live)
 import hnh_testlib as T  # noqa: E402
 from distributed_sddmm_amd import api as H  # noqa: E402
 
@@ -23,23 +24,23 @@ def load_backend(path=None):
 
 
 H.load_backend = load_backend
-bench.PRODUCT_BACKEND = "oracle-cpu-test-double"
-bench.PROBE_SCRIPT = os.path.abspath(__file__)
-bench.visible_device = lambda rank, n, local_rank: (0, n)
+BT.PRODUCT_BACKEND = "oracle-cpu-test-double"
+BT.PROBE_SCRIPT = os.path.abspath(__file__)
+BT.visible_device = lambda rank, n, local_rank: (0, n)
 torch.cuda.synchronize = lambda *a, **k: None
 
 if os.environ.get("BENCH_PRODUCT_BREAK") == "rccl":  # one transport that cannot be created on this "node": its trial must say so, the run goes on
-    real_make = bench.make_gpu_transport
+    real_make = BT.make_gpu_transport
 
     def make_gpu_transport(H_, dist, rank, n, device, name):
         if name == "rccl":
             raise RuntimeError("RCCL is broken on this node (test)")
         return real_make(H_, dist, rank, n, device, name)
-    bench.make_gpu_transport = make_gpu_transport
+    BT.make_gpu_transport = make_gpu_transport
 
 if os.environ.get("BENCH_PRODUCT_BREAK") == "rccl-preflight" and "--probe-transport" not in sys.argv:
     # a transport that passes its child-process trial and then delivers wrong data in the benchmark process's own preflight
-    real_make2, real_preflight = bench.make_gpu_transport, bench.run_preflight
+    real_make2, real_preflight = BT.make_gpu_transport, BT.run_preflight
 
     def make_tagged(H_, dist, rank, n, device, name):
         w = real_make2(H_, dist, rank, n, device, name)
@@ -50,18 +51,18 @@ if os.environ.get("BENCH_PRODUCT_BREAK") == "rccl-preflight" and "--probe-transp
         if getattr(world, "_test_transport", None) == "rccl" and int(os.environ["RANK"]) == 1:
             raise RuntimeError("preflight: ring sendrecv delivered wrong data (test)")
         return real_preflight(H_, world, count, dog)
-    bench.make_gpu_transport, bench.run_preflight = make_tagged, preflight
+    BT.make_gpu_transport, BT.run_preflight = make_tagged, preflight
 
 if os.environ.get("BENCH_PRODUCT_BREAK") == "ipc-hang-late" and "--probe-transport" not in sys.argv:
     # the SECOND transport hangs while it is created in the benchmark process, on one rank (its peers wait for it inside the transport)
-    real_make3 = bench.make_gpu_transport
+    real_make3 = BT.make_gpu_transport
 
     def make_late(H_, dist, rank, n, device, name):
         if name == "ipc" and rank == 1:
             import time
             time.sleep(3600)
         return real_make3(H_, dist, rank, n, device, name)
-    bench.make_gpu_transport = make_late
+    BT.make_gpu_transport = make_late
 
 if os.environ.get("BENCH_PRODUCT_BREAK") == "rccl-dies-in-search" and "--probe-transport" not in sys.argv:
     # the transports work until the search: there a candidate raises on one rank (the other rank is inside the transport, waiting)

@@ -89,3 +89,44 @@ def test_a_missing_rank_ends_the_others_with_an_error():
         res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ipc_worker.py"), session, outdir, "er8_r16", "15d_fusion2:1:mesh:4"], env=env,
                              capture_output=True, text=True, timeout=120)
     assert res.returncode != 0 and "every rank to attach" in (res.stdout + res.stderr)
+
+
+@needs_peer_reads
+def test_a_full_handle_table_is_emptied_between_groups_never_inside_one():
+    """HNH_IPC_MAX_OPENED=2 on 4 ranks: every group (3 receives) would overflow the table of mapped peer allocations.  The table is
+    emptied BEFORE a group is issued (IpcWorld::make_room), never while the group's earlier receives already hold `base + offset`
+    of a mapping (round 4's advisor finding: the eviction inside open_peer unmapped sources of the group in flight) — the schedules'
+    results stay the golden ones."""
+    procs, outs = launch_ipc(4, "er8_r16", "15d_fusion2:1:mesh:4;15d_fusion2:2:mesh:2;25d_sparse_replicate:1:mesh:4;als@15d_fusion2:1:mesh:4",
+                             extra_env={"HNH_IPC_MAX_OPENED": "2"})
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    assert "IPC_OK" in outs[0], outs[0][-3000:]
+
+
+@needs_peer_reads
+def test_a_stale_segment_of_an_earlier_launch_is_not_joined():
+    """A shared-memory segment left under the session's name by a launch that was killed (valid size and magic, creator gone, a full
+    world attached): the ranks of the next launch must not take it for theirs — rank 0 replaces it, the others drop the stale mapping
+    and look again — instead of waiting out the time limit."""
+    import struct
+    session = "t%d_%x" % (os.getpid(), time.time_ns())
+    pid = os.fork()
+    if pid == 0:
+        os._exit(0)
+    os.waitpid(pid, 0)  # `pid` now names no process
+    path = "/dev/shm/hnh_ipc_" + session
+    with open(path, "wb") as f:
+        f.truncate(64 << 20)  # (sparse; larger than the segment)
+        f.seek(0)
+        f.write(struct.pack("<QiiqI", 0x686e685f69706331, 2, 0, pid, 2))  # magic, nranks, pad, creator_pid, attached = 2
+    with tempfile.TemporaryDirectory(prefix="hnh_ipc_") as outdir:
+        procs = []
+        for r in (1, 0):  # rank 1 first: it finds the leftover before rank 0 replaces it
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", OMP_NUM_THREADS="2", HNH_TEST_BACKEND="oracle", HNH_IPC_WAIT_S="60")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ipc_worker.py"), session, outdir, "er8_r16", "15d_fusion2:1:mesh:4"],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+            time.sleep(1.0)
+        outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert not os.path.exists(path)
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    assert "IPC_OK" in outs[1], outs[1][-3000:]

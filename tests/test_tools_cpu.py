@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def run_tool(name, *args):
     env = dict(os.environ, OMP_NUM_THREADS="2")
-    for k in ("HNH_MESH_CHUNKS", "HNH_MESH_TAPER", "HNH_PACE_LINK_GBPS", "HNH_PACE_COPY", "HNH_FORCE_WINDOWS"):
+    for k in ("HNH_MESH_CHUNKS", "HNH_MESH_TAPER", "HNH_PACE_LINK_GBPS", "HNH_PACE_COPY"):
         env.pop(k, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", name), "--backend", T.ORACLE_BACKEND, "--logm", "10", "--ef", "8", "--r", "16",
                           "--p", "4", "--iters", "2", *args], env=env, capture_output=True, text=True, timeout=300)

@@ -31,7 +31,7 @@ import time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-# the paced stand-ins and HNH_FORCE_WINDOWS live in the measurement build of the host library only
+# the paced stand-ins live in the measurement build of the host library only
 os.environ.setdefault("HNH_HOST_LIB_DEV", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "distributed_sddmm_amd", "lib", "libhnh_host_aids.so"))
 
 ap = argparse.ArgumentParser()
@@ -49,7 +49,6 @@ ap.add_argument("--copy-wgs", default="0", help="comma list; > 0: the paced stan
                 "the rank's kernels also meet the HBM traffic (896 MiB in + 896 MiB out per call) and the workgroups of a real exchange")
 a = ap.parse_args()
 
-os.environ.setdefault("HNH_FORCE_WINDOWS", "1")
 os.environ.pop("HNH_PACE_LINK_GBPS", None)
 from distributed_sddmm_amd import api as H  # noqa: E402
 
@@ -65,6 +64,7 @@ def body(w):
     A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
     S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
     op.hold_moving_operand(B)
+    op.walk_windows_when_held(True)  # windows are walked (and the paced stand-ins waited for) although the blocks are resident
     op.fusedSpMM(A, B, S, buf, H.AMAT)  # collective: fills the landing buffers
     w.sync()
     w.barrier()

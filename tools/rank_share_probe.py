@@ -18,8 +18,6 @@ import time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-# the paced stand-ins and HNH_FORCE_WINDOWS live in the measurement build of the host library only
-os.environ.setdefault("HNH_HOST_LIB_DEV", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "distributed_sddmm_amd", "lib", "libhnh_host_aids.so"))
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--p", type=int, default=8)
@@ -32,7 +30,6 @@ ap.add_argument("--backend", default=None, help="kernel library to load (default
 ap.add_argument("--chunks", default="", help="comma list of HNH_MESH_CHUNKS values to sweep (default: the library default)")
 a = ap.parse_args()
 
-os.environ.setdefault("HNH_FORCE_WINDOWS", "1")  # the held blocks are resident, but walk the chunk windows as a fetching call does
 from distributed_sddmm_amd import api as H  # noqa: E402
 
 name = H.load_backend(a.backend)
@@ -46,6 +43,7 @@ def body(w):
     A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
     S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
     op.hold_moving_operand(B)
+    op.walk_windows_when_held(True)  # the held blocks are resident, but walk the chunk windows as a fetching call does
     op.fusedSpMM(A, B, S, buf, H.AMAT)  # collective: fills the landing buffers
     w.sync()
     w.barrier()
