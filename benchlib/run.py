@@ -266,7 +266,7 @@ def run(args, make_world=None):
             fallback.keep(out)
     # ---- the reference on this box's host cores, beside every line: measured at N = 1 (and left for the runs that follow on this
     # host), quoted at N > 1 — or its bounded sample leg, with the GPU line already in hand
-    if rank == 0 and not args.no_cpu_baseline and out["backend"] == "hip-gfx950":
+    if rank == 0 and not args.no_cpu_baseline and out["backend"] == transports.PRODUCT_BACKEND:
         phases.start("cpu_baseline")
         dog.note("CPU baseline (the compiled reference on the host cores)")
         out["cpu_baseline"] = baseline.cpu_baseline_for_line(args, n, budget)

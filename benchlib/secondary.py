@@ -250,4 +250,161 @@ def secondary(args, b):
                 sub.transports["single"]["sp"].free()
     entry("the reference's printed weak-scaling point at p = 1: ER 2^%d, %d nonzeros per row, R=%d, 15d_sparse fused, 5 FusedMM timed the reference's way"
           % ((8, 8, 32) if small else (16, 32, 256)), knl_point)
+
+    # ---- ONE RANK'S SHARE of the multi-GPU configurations (BASELINE configs 3, 4, 5) and config 1 as typed.  p logical ranks (host threads
+    # over the loopback transport) build the operator at the configuration's size and run one collective call; then rank 0 repeats the
+    # call BY ITSELF while its peers wait at a barrier, in one of two measurement modes of the library:
+    #   held    hold_moving_operand + walk_windows_when_held: the fetched blocks are resident, the call walks own block + one windowed
+    #           pass per chunk — the rank's KERNEL sequence only;
+    #   solo    World::set_solo: every message the rank would receive is replaced by a device copy of what it would send (same bytes,
+    #           streams, events) — the kernel sequence PLUS the HBM side of its exchange, overlapped as the schedule overlaps them.
+    # What neither shows: the links.  Byte model per rank = the rank's own nonzeros and rows in the SURVEY 8(d) model (15d_fusion2: fused),
+    # or the global unfused model / p where the schedule splits R (every nonzero is visited by several ranks with a slice of the columns).
+    def solo_section(w, fn):
+        """rank 0 alone: wall ms per call and event-bracketed kernel ms + launches per call; its peers wait at the closing barrier"""
+        res = None
+        try:
+            if w.rank == 0:
+                res = fn()
+        finally:
+            if w.rank == 0:
+                w.set_solo(False)
+            w.barrier()
+        return res
+
+    def time_alone(w, op, call, iters):
+        call()
+        w.sync()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            call()
+        w.sync()
+        wall = (time.perf_counter() - t0) * 1e3 / iters
+        op.kernel_profile(1)
+        for _ in range(iters):
+            call()
+        w.sync()
+        kms, launches = op.kernel_profile(0)
+        return wall, (kms / iters) or wall, launches // iters  # (the CPU test double has no event timing)
+
+    def share_of_config3(p, chunk_spec):
+        logm, ef, r = (9, 8, 16) if small else (args.logm, args.edge_factor, args.r)
+        saved = {k: os.environ.get(k) for k in ("HNH_MESH_CHUNKS", "HNH_MESH_TAPER", "HNH_RING_MODE")}
+        os.environ["HNH_RING_MODE"] = "mesh"
+        from .common import set_chunk_spec
+        set_chunk_spec(chunk_spec)
+
+        def body(w):
+            sp = H.SpmatLocal.load_tuples(w, False, logm, ef)
+            op = H.DistributedSparse(w, "15d_fusion2", sp, r, 1)
+            sp.free()
+            A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
+            S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
+            call = lambda: op.fusedSpMM(A, B, S, buf, H.AMAT)  # noqa: E731
+            op.hold_moving_operand(B)
+            op.walk_windows_when_held(True)
+            call()  # collective: fills the landing buffers
+            w.sync()
+            w.barrier()
+
+            def alone():
+                info = op.info()
+                held = time_alone(w, op, call, 5)
+                op.hold_moving_operand(None)
+                op.walk_windows_when_held(False)
+                w.set_solo(True)
+                solo = time_alone(w, op, call, 5)
+                return held, solo, info["nS"], info["localArows"]
+            res = solo_section(w, alone)
+            for x in (A, B, S, buf):
+                x.free()
+            op.free()
+            return res
+        try:
+            held, solo, nnz_rank, rows = H.run_spmd(p, body)[0]
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        by = fused_bytes(nnz_rank, r, rows)
+        return {"p": p, "chunks": chunk_spec, "R": r, "nnz_rank": int(nnz_rank), "rows_rank": int(rows), "algorithmic_bytes_rank": by,
+                "held": {"what": "kernel sequence only (fetched blocks resident, windows walked)", "wall_ms": held[0], "kernel_ms": held[1],
+                         "launches": held[2], "frac": frac_of(by, held[1]), "frac_wall": frac_of(by, held[0])},
+                "solo": {"what": "kernel sequence + the HBM side of the exchange (%d blocks of %d x %d copied device to device per call, overlapped "
+                                 "through the schedule's events)" % (p - 1, rows, r), "wall_ms": solo[0], "kernel_ms": solo[1], "launches": solo[2],
+                         "frac_wall": frac_of(by, solo[0])}}
+
+    for p, spec in ((8, "1,2,2,2,1,1"), (8, "1"), (4, "1,2,2,2,1,1"), (2, "1,2,2,2,1,1")):
+        entry("rank share, config 3: one rank of %d (15d_fusion2, c = 1, mesh fetch, chunk heights %s) alone on this GPU, %s"
+              % (p, spec, "toy size" if small else "ER 2^%d, edge factor %d, R=%d" % (args.logm, args.edge_factor, args.r)),
+              lambda p=p, spec=spec: share_of_config3(p, spec))
+
+    def share_of(alg, p, c, logm, ef, r, kind, unfused, als_iters=0):
+        """one rank of `alg` on p logical ranks, solo replay; als_iters > 0: cg_optimizer(Amat, als_iters) instead of fusedSpMM"""
+        def body(w):
+            if kind == "er":
+                sp = H.SpmatLocal.load_tuples(w, False, logm, ef)
+            else:
+                rows, cols = H.generate_rmat(logm, (1 << logm) * ef)
+                sp = H.SpmatLocal.from_global(w, 1 << logm, 1 << logm, rows, cols, np.ones(len(rows)))
+            gnnz = sp.info()["dist_nnz"]
+            op = H.DistributedSparse(w, alg, sp, r, c)
+            sp.free()
+            als = None
+            if als_iters:
+                als = H.DistributedALS(op, True)
+                als.initializeEmbeddings()
+                call = lambda: als.cg_optimizer(H.AMAT, als_iters)  # noqa: E731
+                ncalls = als_iters + 2  # right-hand side + initial residual + the iterations (als_conjugate_gradients.cpp:38-141)
+            else:
+                A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
+                S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
+                call = lambda: op.fusedSpMM(A, B, S, buf, H.AMAT)  # noqa: E731
+                ncalls = 1
+            # everybody together first: wall time of the collective call with all p ranks' kernels and copies on this ONE GPU
+            call()
+            w.sync()
+            w.barrier()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                call()
+            w.sync()
+            w.barrier()
+            together = (time.perf_counter() - t0) * 1e3 / 3
+
+            def alone():
+                w.set_solo(True)
+                return time_alone(w, op, call, 5 if not als_iters else 2)
+            res = solo_section(w, alone)
+            if als is not None:
+                als.free()
+            else:
+                for x in (A, B, S, buf):
+                    x.free()
+            op.free()
+            return res, together, gnnz, ncalls
+        out_ = H.run_spmd(p, body)
+        (wall, kms, launches), together, gnnz, ncalls = out_[0][0], max(o[1] for o in out_), out_[0][2], out_[0][3]
+        m = 1 << logm
+        by = ((gnnz * (16 * r + 44) + 16 * r * m) if unfused else fused_bytes(gnnz, r, m)) * ncalls / p
+        return {"schedule": "%s p=%d c=%d" % (alg, p, c), "R": r, "nnz": int(gnnz), "M": m,
+                "algorithmic_bytes_rank": by, "model": ("global %s model / p" % ("unfused (SDDMM + SpMM pair)" if unfused else "fused")) +
+                (" x %d fused calls (2 + %d CG iterations)" % (ncalls, als_iters) if als_iters else ""),
+                "solo": {"what": "rank 0 alone: its kernel sequence + the HBM side of its exchange", "wall_ms": wall, "kernel_ms": kms,
+                         "launches": launches, "frac_wall": frac_of(by, wall), "frac_kernel": frac_of(by, kms),
+                         "host_and_wait_ms": wall - kms},
+                "all_ranks_on_this_gpu_ms": together}
+
+    c4 = (8, 8, 32) if small else (18, 32, 256)
+    entry("rank share, config 4: one rank of 8 (2.5D dense-replicate 2 x 2 x 2: R/2 columns, transposed blocks, accumulator in two halves), "
+          "R-MAT 2^%d, edge factor %d, R=%d" % c4, lambda: share_of("25d_dense_replicate", 8, 2, c4[0], c4[1], c4[2], "rmat", True))
+    c5 = (9, 8, 16) if small else (args.logm, args.edge_factor, args.r)
+    entry("rank share, config 5: one rank of 8 through a CG half-step (cg_optimizer(Amat, 10): 12 fused calls with the CG updates in the row "
+          "epilogue, fixed factor held), 15d_fusion2, ER 2^%d, edge factor %d, R=%d" % c5,
+          lambda: share_of("15d_fusion2", 8, 1, c5[0], c5[1], c5[2], "er", False, als_iters=10))
+    c1 = (8, 8, 16) if small else (16, 16, 16)
+    entry("config 1 as typed: ER 2^%d, edge factor %d, R=%d, 15d_sparse, 2 logical ranks (bench_erdos_renyi.cpp:19-120): one fusedSpMM, kernel "
+          "time against call time" % c1, lambda: share_of("15d_sparse", 2, 1, c1[0], c1[1], c1[2], "er", True))
     return out

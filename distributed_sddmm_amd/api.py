@@ -56,6 +56,7 @@ SIGNATURES = {
     "hnh_world_barrier": (_i32, [_vp]),
     "hnh_world_sync": (_i32, [_vp]),
     "hnh_world_set_timing_sync": (_i32, [_vp, _i32]),
+    "hnh_world_set_solo": (_i32, [_vp, _i32]),
     "hnh_world_stream": (_vp, [_vp, _i32]),
     "hnh_world_ctx": (_vp, [_vp]),
     "hnh_world_grid_probe": (_i32, [_vp, _i32, _i32, _i32, _i32, _pi32, _pi32]),
@@ -234,6 +235,10 @@ class World:
 
     def sync(self):
         _check(lib().hnh_world_sync(self.h), "sync")
+
+    def set_solo(self, on: bool):
+        """World::set_solo — solo replay (measurement entry point, loopback transport): this rank runs its side of every collective alone."""
+        _check(lib().hnh_world_set_solo(self.h, int(on)), "set_solo")
 
     def set_timing_sync(self, on: bool):
         lib().hnh_world_set_timing_sync(self.h, int(on))

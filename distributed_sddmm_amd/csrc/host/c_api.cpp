@@ -154,6 +154,9 @@ int hnh_world_barrier(hnh_world* w) {
 int hnh_world_sync(hnh_world* w) {
     return guarded(w->w.get(), [&] { w->w->sync_all(); });
 }
+int hnh_world_set_solo(hnh_world* w, int on) {
+    return guarded(w->w.get(), [&] { w->w->set_solo(on != 0); });
+}
 int hnh_world_set_timing_sync(hnh_world* w, int on) {
     w->w->timing_sync = on != 0;
     return HNH_OK;

@@ -270,6 +270,10 @@ void* World::scratch(int slot, size_t bytes) {
     return s.first;
 }
 
+void World::set_solo(bool on) {
+    if (on) fatal(std::string("Error, solo replay is a measurement mode of the loopback transport, not of ") + kind());
+}
+
 Comm World::world_comm() {
     Comm c;
     c.ranks.resize(size);
@@ -618,6 +622,7 @@ ThreadWorld::ThreadWorld(std::shared_ptr<ThreadGroup> group, int rank_in_group, 
 ThreadWorld::~ThreadWorld() { destroy_device(); }
 
 void ThreadWorld::barrier() {
+    if (solo_) return;
     std::unique_lock<std::mutex> lk(g_->mu);
     const uint64_t gen = g_->generation;
     if (++g_->arrived == g_->n) {
@@ -643,6 +648,10 @@ std::vector<const void*> ThreadWorld::publish(const void* mine) {
 void ThreadWorld::release() { barrier(); }
 
 void ThreadWorld::host_allgather(const void* send, void* recv, size_t bytes) {
+    if (solo_) {
+        for (int r = 0; r < size; r++) std::memcpy(static_cast<char*>(recv) + (size_t)r * bytes, send, bytes);
+        return;
+    }
     auto all = publish(send);
     for (int r = 0; r < size; r++) std::memcpy(static_cast<char*>(recv) + (size_t)r * bytes, all[r], bytes);
     release();
@@ -650,6 +659,12 @@ void ThreadWorld::host_allgather(const void* send, void* recv, size_t bytes) {
 
 void ThreadWorld::host_alltoallv(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl,
                                  void* recv, const std::vector<size_t>& recvbytes, const std::vector<size_t>& recvdispl) {
+    if (solo_) {
+        for (int r = 0; r < size; r++)
+            if (const size_t nb = std::min(sendbytes[r], recvbytes[r]))
+                std::memcpy(static_cast<char*>(recv) + recvdispl[r], static_cast<const char*>(send) + senddispl[r], nb);
+        return;
+    }
     struct Desc { const void* base; const size_t* bytes; const size_t* displ; } mine{send, sendbytes.data(), senddispl.data()};
     auto all = publish(&mine);
     for (int r = 0; r < size; r++) {
@@ -663,6 +678,11 @@ void ThreadWorld::host_alltoallv(const void* send, const std::vector<size_t>& se
 
 void ThreadWorld::sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst_idx, void* recvbuf, size_t recvbytes,
                            int src_idx, int stream) {
+    if (solo_) {  // the message this rank would receive = a copy of the one it would send
+        const size_t nb = std::min(sendbytes, recvbytes);
+        if (nb && sendbuf != recvbuf) copy(recvbuf, sendbuf, nb, HNH_COPY_D2D, stream);
+        return;
+    }
     const int n = g_->n;
     ThreadGroup::Msg* out = nullptr;
     if (sendbytes) {

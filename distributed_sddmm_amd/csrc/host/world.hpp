@@ -58,6 +58,14 @@ public:
     // otherwise wait for this rank until their time limit tells them now (IpcWorld: the session's `failed` word).
     virtual void note_failure() noexcept {}
 
+    // Measurement entry point (an addition): SOLO REPLAY.  While on, this rank runs its own side of every collective call ALONE: each
+    // message it would receive is replaced by a device-to-device copy of the message it would send (same bytes written, same stream,
+    // same events), host collectives return its own contribution for every rank, barriers return at once.  The results of such calls
+    // are meaningless; their kernel sequence, launch pattern, event protocol and the HBM side of the exchange are those of the rank
+    // in a real p-rank call — with the GPU to itself (bench.py's "rank share" entries).  Loopback transport only.
+    virtual void set_solo(bool on);
+    bool solo() const { return solo_; }
+
     // ---- communicators
     Comm world_comm();
     virtual Comm split(int color, int key);  // MPI_Comm_split semantics (FlexibleGrid.hpp:80-88)
@@ -115,6 +123,7 @@ public:
     void* scratch(int slot, size_t bytes);
 
 protected:
+    bool solo_ = false;
     // a device block is about to be given back to the driver (transports that exported it forget the handle)
     virtual void on_device_release(void* p) { (void)p; }
     void host_alltoallv_staged(const void* send, const std::vector<size_t>& sendbytes, const std::vector<size_t>& senddispl, void* recv,
@@ -184,6 +193,7 @@ public:
     ThreadWorld(std::shared_ptr<ThreadGroup> group, int rank_in_group, Backend* backend, int device_ordinal);
     ~ThreadWorld() override;
     const char* kind() const override { return "thread-loopback"; }
+    void set_solo(bool on) override { solo_ = on; }
     void sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes,
                   int src, int stream) override;
     void barrier() override;

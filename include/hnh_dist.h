@@ -74,6 +74,10 @@ int hnh_world_rank(hnh_world* w);
 int hnh_world_size(hnh_world* w);
 int hnh_world_barrier(hnh_world* w);
 int hnh_world_sync(hnh_world* w);                      /* drain compute + communication streams */
+/* World::set_solo (an addition, a MEASUREMENT entry point; loopback transport only): solo replay — while on, the rank runs its own
+ * side of every collective call alone (each receive = a device copy of what it would send, host collectives and barriers local), so
+ * one rank's kernel sequence + the HBM side of its exchange can be timed with the GPU to itself.  Results of such calls are void. */
+int hnh_world_set_solo(hnh_world* w, int on);
 int hnh_world_set_timing_sync(hnh_world* w, int on);   /* perf counters synchronise first (reference-like attribution) */
 void* hnh_world_stream(hnh_world* w, int stream);      /* raw hipStream_t */
 hnh_ctx* hnh_world_ctx(hnh_world* w);                  /* the rank's kernel-level context */

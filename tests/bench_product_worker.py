@@ -74,6 +74,17 @@ if os.environ.get("BENCH_PRODUCT_BREAK") == "rccl-dies-in-search" and "--probe-t
         return real_build(self, route)
     bench.Bench.build = build
 
+if os.environ.get("BENCH_PRODUCT_SLOW") and "--probe-transport" not in sys.argv:
+    # every candidate of the route search takes this many seconds longer (a node whose candidates are slow: the time budget's test)
+    from benchlib import search as BS
+    real_try = BS.try_route
+
+    def slow_try(b, route, calls=5):
+        import time
+        time.sleep(float(os.environ["BENCH_PRODUCT_SLOW"]))
+        return real_try(b, route, calls)
+    BS.try_route = slow_try
+
 if __name__ == "__main__":
     if os.environ.get("BENCH_PRODUCT_BREAK") == "all-trials" and "--probe-transport" in sys.argv:
         sys.exit(9)  # the trial machinery itself is broken on this "node": every child fails before it gets anywhere

@@ -5,6 +5,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -123,6 +124,94 @@ def test_the_multi_gpu_product_path_with_every_transport_usable(nranks):
     assert {k.rsplit("[", 1)[1] for k in default} == {"rccl]", "ipc]", "ipc-kernel]"}   # stage 1: the default route on every transport
     assert len(tuned) >= 10 and all(v is not None for v in tuned.values()) and "route_tuning_failures" not in out["config"], tuned
     assert out["config"]["transport"] in ("rccl", "ipc-pull")
+
+
+def test_the_time_budget_ends_the_search_with_a_complete_line():
+    """Candidates that take seconds each (here: 2 s of sleep per candidate) on a run with --budget-s 45: the search stops taking
+    candidates while the budget still has room for the winner's full measurement, says so in config.budget_stops, and the line is a
+    COMPLETE one (no "incomplete" mark, check ok, phases_s) printed well inside the budget — the launcher's limit is budget + 120."""
+    from test_ipc_world_cpu import can_read_peer_memory
+    if not can_read_peer_memory():
+        pytest.skip("process_vm_readv between own processes is not permitted here")
+    t0 = time.time()
+    res, out = product_launch(2, {"BENCH_PRODUCT_SLOW": "2.0"}, extra_args=("--budget-s", "45"))
+    took = time.time() - t0
+    assert res.returncode == 0 and "error" not in out and "incomplete" not in out, (out.get("error"), out.get("incomplete"), res.stderr[-1500:])
+    assert out["check"]["ok"] and out["value"] > 0 and out["config"]["budget_s"] == 45.0
+    stops = out["config"]["budget_stops"]
+    assert any("no room for another candidate" in s for s in stops), stops
+    tuned = out["config"]["route_tuning_ms_per_step"]
+    assert 1 <= len(tuned) < 10, tuned  # (an unbounded search measures 13 or more, see the test above)
+    ph = out["phases_s"]
+    assert ph["tuning"] >= 2.0 and ph["total"] <= 45.0 and took < 60.0, (ph, took)
+    assert {"start_up", "transport_trials", "bring_up", "first_measurement", "tuning", "total"} <= set(ph), ph
+
+
+def test_sigterm_to_the_launcher_prints_the_line_in_hand():
+    """The driver's time limit ends `python bench.py --gpus 2` with SIGTERM in the middle of the route search: the launcher passes it to
+    rank 0 first, which prints the complete measurement it already holds, marked "incomplete"; the launcher forwards that ONE line
+    and exits 0."""
+    import signal
+    from test_ipc_world_cpu import can_read_peer_memory
+    if not can_read_peer_memory():
+        pytest.skip("process_vm_readv between own processes is not permitted here")
+    env = dict(os.environ, OMP_NUM_THREADS="2", GLOO_SOCKET_IFNAME="lo", HNH_ORACLE_COMM_WAIT_S="120", HNH_IPC_WAIT_S="120",
+               HNH_BENCH_WORKER=os.path.join(ROOT, "tests", "bench_product_worker.py"), BENCH_PRODUCT_SLOW="4.0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--logm", "10", "--edge-factor", "8",
+                          "--r", "16", "--no-cpu-baseline", "--probe-timeout", "120"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    time.sleep(25.0)  # trials + bring-up + the first measurement take about 5 s here; the search (4 s per candidate) is under way
+    assert p.poll() is None
+    p.send_signal(signal.SIGTERM)
+    stdout, stderr = p.communicate(timeout=120)
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, stdout[-1500:], stderr[-1500:])
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["check"]["ok"] and "signal 15 sent to the launcher" in out["incomplete"], out.get("incomplete")
+    assert out["phases_s"]["total"] > 20.0 and "phases" in out and "exit_codes" in out
+
+
+def test_a_multi_gpu_line_carries_the_whole_step_roofline_and_the_cpu_baseline(tmp_path):
+    """N = 4: `roofline.frac` is SURVEY 8(d)'s whole-step fraction — total B_fused / ms_per_step / (4 x 8 TB/s) — with the kernel-level
+    figure kept as `frac_kernel` and the difference of the two times as `exposed_comm_ms`; `cpu_baseline` rides on the line too: the
+    record the N = 1 run left on this host is quoted (here: a seeded record), without one the bounded sample leg runs after the line
+    is in hand."""
+    import socket
+    from test_ipc_world_cpu import can_read_peer_memory
+    if not can_read_peer_memory():
+        pytest.skip("process_vm_readv between own processes is not permitted here")
+    key = "er10_ef8_r16_s10_t1"
+    with open(tmp_path / ("hnh_cpu_baseline_%s_%s.json" % (socket.gethostname(), key)), "w") as f:
+        json.dump({"value": 1.25e9, "unit": "nnz*R/s", "cores": 32, "kind": "reference", "sample": "seeded by the test", "_stamp": time.time() - 100.0}, f)
+    env = dict(os.environ, OMP_NUM_THREADS="2", GLOO_SOCKET_IFNAME="lo", HNH_ORACLE_COMM_WAIT_S="120", HNH_IPC_WAIT_S="120", HNH_BENCH_CACHE_DIR=str(tmp_path),
+               HNH_BENCH_WORKER=os.path.join(ROOT, "tests", "bench_product_worker.py"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+
+    def launch(*extra):
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--logm", "10", "--edge-factor", "8",
+                              "--r", "16", "--cpu-logm", "10", "--cpu-trials", "1", "--probe-timeout", "120", "--no-tune", *extra], env=env,
+                             capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+        assert res.returncode == 0 and len(lines) == 1, (res.returncode, res.stdout[-1500:], res.stderr[-1500:])
+        return json.loads(lines[0])
+    out = launch()
+    roof = out["roofline"]
+    total = out["config"]["nnz"] * (8 * 16 + 24) + 16 * 16 * out["config"]["M"]
+    assert roof["algorithmic_bytes_per_step_all_gpus"] == total
+    assert abs(roof["frac_step"] - total / (out["ms_per_step"] * 1e-3) / (4 * 8.0e12)) <= 1e-9 * roof["frac_step"]
+    assert roof["frac"] == roof["frac_step"] and "frac_step" in roof["frac_is"] and roof["frac_kernel"] > 0
+    assert abs(roof["exposed_comm_ms"] - (out["ms_per_step"] - roof["kernel_ms_per_step"])) < 1e-9
+    cb = out["cpu_baseline"]
+    assert cb["value"] == 1.25e9 and cb["kind"] == "reference" and "earlier run of bench.py on this host" in cb["cached"], cb
+    assert out["phases_s"]["cpu_baseline"] >= 0.0
+    # no record on this host: the bounded sample leg of the compiled reference runs, with the line in hand
+    os.remove(tmp_path / ("hnh_cpu_baseline_%s_%s.json" % (socket.gethostname(), key)))
+    from oracle import refrun as RR
+    if RR.available():
+        cb = launch()["cpu_baseline"]
+        assert cb["kind"] == "reference" and cb["value"] > 0 and "cached" not in cb and cb["cores"] >= 1, cb
 
 
 def test_the_multi_gpu_product_path_when_rccl_cannot_be_created():
@@ -369,8 +458,18 @@ def test_secondary_workloads_are_listed_with_their_checks():
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
     sec = out["secondary"]
-    assert len(sec) == 9 and not [e for e in sec if "error" in e], [e.get("error") for e in sec]
+    assert len(sec) == 16 and not [e for e in sec if "error" in e], [e.get("error") for e in sec]
     by_name = {e["workload"]: e for e in sec}
+    # one rank's share of configs 3 / 4 / 5 and config 1 as typed: rank 0 of p logical ranks alone (held blocks / solo replay)
+    shares = [v for k, v in by_name.items() if k.startswith("rank share, config 3")]
+    assert sorted((e["p"], e["chunks"]) for e in shares) == [(2, "1,2,2,2,1,1"), (4, "1,2,2,2,1,1"), (8, "1"), (8, "1,2,2,2,1,1")]
+    for e in shares:
+        assert e["held"]["wall_ms"] > 0 and e["solo"]["wall_ms"] > 0 and e["algorithmic_bytes_rank"] > 0 and e["nnz_rank"] > 0
+        # own block + one pass per chunk window (a single pass over the fetched blocks when there is one chunk)
+        assert e["held"]["launches"] == e["solo"]["launches"] >= (2 if e["chunks"] == "1" else 4), e
+    for key in ("rank share, config 4", "rank share, config 5", "config 1 as typed"):
+        e = next(v for k, v in by_name.items() if k.startswith(key))
+        assert e["solo"]["wall_ms"] > 0 and e["solo"]["launches"] > 0 and e["all_ranks_on_this_gpu_ms"] > 0 and e["algorithmic_bytes_rank"] > 0, e
     for r in (8, 16, 128, 256):
         e = next(v for k, v in by_name.items() if "R=%d:" % r in k)
         assert e["check"]["ok"] and all(e[op]["ms"] > 0 and e[op]["algorithmic_bytes"] > 0 for op in ("fused", "sddmm", "spmm"))
