@@ -34,6 +34,11 @@ struct hnh_ctx {
     bool panels_with_hubs = false;  // HNH_PANELS_WITH_HUBS=1: panel the short rows of blocks that also have hub rows
     int long_row_override = 0;      // HNH_LONG_ROW=<multiple of 64, 64..1984>: fixed hub-row threshold instead of the adaptive one (measurement aid)
     double panel_bytes = 512.0 * 1024.0 * 1024.0;  // bytes of the gathered operand per panel (HNH_PANEL_BYTES; tests shrink it)
+    // Most panels a pass is cut into (HNH_MAX_PANELS, 1 .. 8).  Every panel re-reads the row operand and read-modify-writes the output
+    // (3 dense rows per sparse row and panel), so past four the extra traffic outweighs what the Infinity Cache gives back: measured at
+    // config 2's matrix, R = 512 (8 x 512 MiB): 4 panels 66.7 ms against 8 panels 70.2 ms (counter traffic 1.09 x against 1.21 x the
+    // byte model), R = 384: 50.1 against 52.6 ms — profiles/r05_wide_panels.log
+    int max_panels = 4;
     // peer-to-peer pull (hnh_ipc.hip): auxiliary streams the copy-engine pulls of one group are spread over (created on first use),
     // the fork event recorded on the issuing stream and one join event per auxiliary stream
     static constexpr int kAuxStreams = 8;

@@ -1766,7 +1766,8 @@ constexpr int kMaxPanels = 8;
 int panel_count(const hnh_ctx* ctx, int64_t cols, int R) {
     if (cols <= 0 || ctx->no_panels) return 1;
     const long p = std::lround((double)cols * (double)R * sizeof(double) / ctx->panel_bytes);
-    return (int)(p < 1 ? 1 : (p > kMaxPanels ? kMaxPanels : p));
+    const long most = ctx->max_panels < kMaxPanels ? ctx->max_panels : kMaxPanels;
+    return (int)(p < 1 ? 1 : (p > most ? most : p));
 }
 
 // cols: number of rows of the gathered operand (= columns of the sparse block), or < 0 when unknown (no panels)

@@ -118,6 +118,10 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
         const long v = std::strtol(lr, nullptr, 10);
         if (v >= 64 && v <= 1984) ctx->long_row_override = (int)(v / 64 * 64);
     }
+    if (const char* mp = std::getenv("HNH_MAX_PANELS")) {
+        const int v = std::atoi(mp);
+        if (v >= 1 && v <= 8) ctx->max_panels = v;
+    }
     if (const char* pb = std::getenv("HNH_PANEL_BYTES")) {
         const double v = std::atof(pb);
         if (v >= 1.0) ctx->panel_bytes = v;

@@ -29,9 +29,13 @@ size_t StandardKernel::sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
         return processed;
     }
     if (A.cols() <= kCooSddmmMaxWidth && !fresh && scale == nullptr) {  // (the COO kernel accumulates: first visits take the storing CSR pass)
-        // narrow operands: several sparse rows share a wave in the row kernel, and the wave runs as long as its longest row;
-        // the COO kernel deals nonzeros out evenly instead (measured at config-2 size, R = 16: 2.06 vs 2.64 ms; R = 8: 2.03 vs
-        // 3.37 ms; at R = 128 the row kernel wins 14.4 vs 19.3 ms — profiles/r02_kbench_narrow_and_coo.log)
+        // narrow operands, ACCUMULATING visit (the travelling blocks of 15d_sparse / 2.5D dense after their first step): several sparse
+        // rows share a wave in the row kernel and the wave runs as long as its longest row; the COO kernel deals nonzeros out evenly
+        // instead.  Re-measured in round 5 with the line-granular row loop (config-2 size, profiles/r05_kbench_narrow.log): accumulating
+        // row pass 2.062 / 2.132 ms at R = 8 / 16 against 2.025 / 2.055 ms here — the row loop already reads the value line with the
+        // index line and writes whole lines, what it cannot shed is the longest-row effect — so these two widths stay on this kernel
+        // (1.8 % / 3.7 %); STORING visits (every first visit) are faster through the row pass (1.925 / 2.003 ms) and never come here; from
+        // R = 32 the row pass wins either way (3.825 vs 3.978 ms)
         const int32_t* row_idx = blk->ensure_row_idx(HNH_STREAM_COMPUTE);
         w->check(w->be->hnh_sddmm_coo(w->ctx, blk->num_coords, row_idx, active->col_idx, active->values, Xptr, Yptr, (int)A.cols(),
                                       HNH_STREAM_COMPUTE),

@@ -1,8 +1,9 @@
-// The reference's only correctness check — scratch.cpp:26-76 `verify_operation` — against THIS repository's class headers, call
-// for call: fill A and B with the distribution-independent pattern value(row, col) = row * R + col (dummyInitialize,
-// distributed_sparse.h:322-346), S = 1, run sddmmA / spmmA / spmmB (each after initial_shift) and print the globally summed
-// squared norms.  The three numbers must be the same for every algorithm, every process count and every c — and the same as
-// the reference prints for the same matrix, which is how a user of the reference checks a build of this library against it.
+// The fingerprint check a user of the reference knows from scratch.cpp:26-76, as a TABLE of the three operations: for each of
+// sddmmA / spmmA / spmmB fill A and B with the distribution-independent pattern value(row, col) = row * R + col (dummyInitialize,
+// distributed_sparse.h:322-346), S = 1, apply the schedule's initial_shift, run the operation and sum the squared norm of its result
+// over the ranks.  The three numbers do not depend on the algorithm, the process count or c, and equal what the reference prints
+// for the same matrix.  Beyond the reference: with `all` the program ITSELF compares the algorithms' fingerprints and exits 1 when
+// two of them differ by more than 1e-11 relative.
 //
 //     verify <matrix.mtx> <15d_fusion1|15d_fusion2|15d_sparse|25d_dense_replicate|25d_sparse_replicate|all> <R> <c>
 //     verify er:<logM>:<edgeFactor> <algorithm|all> <R> <c>
@@ -10,39 +11,49 @@
 // (scratch.cpp takes `file R c` and has the algorithm edited into its main(), scratch.cpp:95-122.)
 #include "bench_common.hpp"
 
-static void verify_operation(Distributed_Sparse* d_ops) {  // scratch.cpp:26-76
+#include <array>
+#include <cmath>
+#include <functional>
+
+namespace {
+
+struct Operands {
+    DenseMatrix A, B;
+    VectorXd S, ST, result;
+};
+
+// one row per operation: label, the kernel mode its initial_shift takes, the call, and which object carries the result
+struct Operation {
+    const char* label;
+    KernelMode mode;
+    std::function<void(Distributed_Sparse&, Operands&)> run;
+    std::function<double(const Operands&)> squared_norm;
+};
+
+const std::array<Operation, 3> kOperations = {{
+    {"SDDMM", k_sddmmA, [](Distributed_Sparse& d, Operands& o) { d.sddmmA(o.A, o.B, o.S, o.result); },
+     [](const Operands& o) { return o.result.squaredNorm(); }},
+    {"SpMMA", k_spmmA, [](Distributed_Sparse& d, Operands& o) { d.spmmA(o.A, o.B, o.S); }, [](const Operands& o) { return o.A.squaredNorm(); }},
+    {"SpMMB", k_spmmB, [](Distributed_Sparse& d, Operands& o) { d.spmmB(o.A, o.B, o.ST); }, [](const Operands& o) { return o.B.squaredNorm(); }},
+}};
+
+std::array<double, 3> fingerprints(Distributed_Sparse& d_ops) {
     hnh::World* world = hnh::current_world();
-    DenseMatrix A = d_ops->like_A_matrix(0.0);
-    DenseMatrix B = d_ops->like_B_matrix(0.0);
-    VectorXd S = d_ops->like_S_values(1.0);
-    VectorXd ST = d_ops->like_ST_values(1.0);
-    VectorXd result = d_ops->like_S_values(0.0);
-
-    d_ops->dummyInitialize(A, Amat);
-    d_ops->dummyInitialize(B, Bmat);
-    d_ops->initial_shift(&A, &B, k_sddmmA);
-    d_ops->sddmmA(A, B, S, result);
-    const double sddmm_fingerprint = world->host_allreduce_sum(result.squaredNorm());
-
-    d_ops->dummyInitialize(A, Amat);
-    d_ops->dummyInitialize(B, Bmat);
-    d_ops->initial_shift(&A, &B, k_spmmA);
-    d_ops->spmmA(A, B, S);
-    const double spmmA_fingerprint = world->host_allreduce_sum(A.squaredNorm());
-
-    d_ops->dummyInitialize(A, Amat);
-    d_ops->dummyInitialize(B, Bmat);
-    d_ops->initial_shift(&A, &B, k_spmmB);
-    d_ops->spmmB(A, B, ST);
-    const double spmmB_fingerprint = world->host_allreduce_sum(B.squaredNorm());
-
-    if (world->rank == 0) {
-        cout << setprecision(17);
-        cout << "SDDMM Fingerprint: " << sddmm_fingerprint << endl;
-        cout << "SpMMA Fingerprint: " << spmmA_fingerprint << endl;
-        cout << "SpMMB Fingerprint: " << spmmB_fingerprint << endl;
+    Operands o{d_ops.like_A_matrix(0.0), d_ops.like_B_matrix(0.0), d_ops.like_S_values(1.0), d_ops.like_ST_values(1.0), d_ops.like_S_values(0.0)};
+    std::array<double, 3> out{};
+    for (size_t k = 0; k < kOperations.size(); k++) {
+        const Operation& op = kOperations[k];
+        d_ops.dummyInitialize(o.A, Amat);
+        d_ops.dummyInitialize(o.B, Bmat);
+        d_ops.initial_shift(&o.A, &o.B, op.mode);
+        op.run(d_ops, o);
+        out[k] = world->host_allreduce_sum(op.squared_norm(o));
+        if (world->rank == 0) cout << setprecision(17) << op.label << " Fingerprint: " << out[k] << endl;
     }
+    return out;
 }
+
+}  // namespace
 
 int main(int argc, char** argv) {
     if (argc < 5) {
@@ -53,6 +64,7 @@ int main(int argc, char** argv) {
     hnh::set_current_world(world);
     const string source(argv[1]), which(argv[2]);
     const int R = atoi(argv[3]), c = atoi(argv[4]);
+    bool agree = true;
     {
         SpmatLocal S;
         if (source.rfind("er:", 0) == 0) {
@@ -64,6 +76,7 @@ int main(int argc, char** argv) {
         }
         StandardKernel local_ops;
         const vector<string> all = {"15d_fusion1", "15d_fusion2", "15d_sparse", "25d_dense_replicate", "25d_sparse_replicate"};
+        vector<std::array<double, 3>> seen;
         for (const string& name : (which == "all" ? all : vector<string>{which})) {
             unique_ptr<Distributed_Sparse> d_ops;
             if (name == "15d_fusion1") d_ops.reset(new Sparse15D_Dense_Shift(&S, R, c, 1, &local_ops));
@@ -73,11 +86,16 @@ int main(int argc, char** argv) {
             else if (name == "25d_sparse_replicate") d_ops.reset(new Sparse25D_Cannon_Sparse(&S, R, c, &local_ops));
             else hnh::fatal("Error, unknown algorithm " + name);
             if (world->rank == 0) cout << "== " << name << " (R = " << R << ", c = " << c << ", " << world->size << " rank(s))" << endl;
-            verify_operation(d_ops.get());
+            seen.push_back(fingerprints(*d_ops));
         }
+        for (size_t a = 1; a < seen.size(); a++)
+            for (size_t k = 0; k < 3; k++)
+                if (std::fabs(seen[a][k] - seen[0][k]) > 1e-11 * std::fabs(seen[0][k])) agree = false;
+        if (world->rank == 0 && seen.size() > 1)
+            cout << (agree ? "all algorithms agree to 1e-11" : "MISMATCH: the algorithms' fingerprints differ by more than 1e-11") << endl;
     }
     world->sync_all();
     hnh::set_current_world(nullptr);
     delete world;
-    return 0;
+    return agree ? 0 : 1;
 }

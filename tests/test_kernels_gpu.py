@@ -580,6 +580,7 @@ def test_infinity_cache_panels_do_not_change_results(monkeypatch, R, panel_bytes
     """With the `cols` hint a pass runs as one launch per column panel of the block (a contiguous piece of every CSR row);
     the panel size is shrunk here so that small blocks get 2..8 panels.  sddmm / spmm / fused (+ extras) must match."""
     monkeypatch.setenv("HNH_PANEL_BYTES", str(panel_bytes))
+    monkeypatch.setenv("HNH_MAX_PANELS", "8")  # (the default cap is 4, where the Infinity Cache stops paying for the re-read rows)
     if hubs:
         monkeypatch.setenv("HNH_PANELS_WITH_HUBS", "1")  # off by default: no gain on skewed graphs
     from distributed_sddmm_amd import _kernels as K

@@ -55,6 +55,7 @@ def measure(a):
         model = nnz * (8 * R + 24) + 16 * R * m
         for panels in a.panels:
             os.environ["HNH_PANEL_BYTES"] = str(int(m * R * 8 / panels) + 1)
+            os.environ["HNH_MAX_PANELS"] = "8"
             if panels == 1:
                 os.environ["HNH_NO_PANELS"] = "1"
             else:
