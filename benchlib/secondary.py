@@ -302,26 +302,28 @@ def secondary(args, b):
             S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
             call = lambda: op.fusedSpMM(A, B, S, buf, H.AMAT)  # noqa: E731
             op.hold_moving_operand(B)
-            op.walk_windows_when_held(True)
+            op.walk_windows_when_held(2)
             call()  # collective: fills the landing buffers
             w.sync()
             w.barrier()
 
             def alone():
                 info = op.info()
-                held = time_alone(w, op, call, 5)
+                held = time_alone(w, op, call, 5)      # one windowed pass per chunk: the sequence of a call whose chunks arrive one by one
+                op.walk_windows_when_held(1)
+                landed = time_alone(w, op, call, 5)    # adaptive windows with everything landed: own block + one pass
                 op.hold_moving_operand(None)
-                op.walk_windows_when_held(False)
+                op.walk_windows_when_held(0)
                 w.set_solo(True)
                 solo = time_alone(w, op, call, 5)
-                return held, solo, info["nS"], info["localArows"]
+                return held, landed, solo, info["nS"], info["localArows"]
             res = solo_section(w, alone)
             for x in (A, B, S, buf):
                 x.free()
             op.free()
             return res
         try:
-            held, solo, nnz_rank, rows = H.run_spmd(p, body)[0]
+            held, landed, solo, nnz_rank, rows = H.run_spmd(p, body)[0]
         finally:
             for k, v in saved.items():
                 if v is None:
@@ -330,10 +332,15 @@ def secondary(args, b):
                     os.environ[k] = v
         by = fused_bytes(nnz_rank, r, rows)
         return {"p": p, "chunks": chunk_spec, "R": r, "nnz_rank": int(nnz_rank), "rows_rank": int(rows), "algorithmic_bytes_rank": by,
-                "held": {"what": "kernel sequence only (fetched blocks resident, windows walked)", "wall_ms": held[0], "kernel_ms": held[1],
+                "held": {"what": "kernel sequence only (fetched blocks resident), ONE windowed pass PER CHUNK: what a call runs whose chunks arrive "
+                                 "one by one (links slower than the kernels)", "wall_ms": held[0], "kernel_ms": held[1],
                          "launches": held[2], "frac": frac_of(by, held[1]), "frac_wall": frac_of(by, held[0])},
+                "held_all_landed": {"what": "kernel sequence only, adaptive windows with every chunk landed when the host decides: own block + one "
+                                            "pass over all fetched blocks (links faster than the kernels)", "wall_ms": landed[0],
+                                    "kernel_ms": landed[1], "launches": landed[2], "frac": frac_of(by, landed[1]), "frac_wall": frac_of(by, landed[0])},
                 "solo": {"what": "kernel sequence + the HBM side of the exchange (%d blocks of %d x %d copied device to device per call, overlapped "
-                                 "through the schedule's events)" % (p - 1, rows, r), "wall_ms": solo[0], "kernel_ms": solo[1], "launches": solo[2],
+                                 "through the schedule's events; adaptive windows: a pass takes every chunk whose copy has completed)" % (p - 1, rows, r),
+                         "wall_ms": solo[0], "kernel_ms": solo[1], "launches": solo[2],
                          "frac_wall": frac_of(by, solo[0])}}
 
     for p, spec in ((8, "1,2,2,2,1,1"), (8, "1"), (4, "1,2,2,2,1,1"), (2, "1,2,2,2,1,1")):

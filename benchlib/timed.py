@@ -16,7 +16,7 @@ class Bench:
         self.transports = {}  # name -> {"world", "sync", "sp", "dead"}
         self.route, self.op, self.A, self.B, self.S, self.buf, self.als, self.gat, self.gat_x = None, None, None, None, None, None, None, None, None
         self.nnz, self.m = None, None
-        self.setup_s = None
+        self.setup_s, self.parse_s = None, None
 
     # -- transports
     def add_transport(self, name, world, device_sync):
@@ -85,6 +85,8 @@ class Bench:
         t0 = time.perf_counter()
         if t["sp"] is None:
             t["sp"] = self.wl.load(H, t["world"])
+            t["world"].sync()
+            self.parse_s = time.perf_counter() - t0  # generator / file parser + duplicate merge (the tuples are on the device)
             info = t["sp"].info()
             self.nnz, self.m = info["dist_nnz"], info["M"]
         r0 = GAT_LAYERS[0][0] if args.app == "gat" else args.r
@@ -201,7 +203,9 @@ def compose_line(args, b, res, extra):
                    "rccl_channels": (os.environ.get("NCCL_MAX_NCHANNELS", "default") if n > 1 else None),
                    # compute units masked off the compute stream (the library's own default unless HNH_COMM_CUS / --comm-cus say otherwise)
                    "comm_cus": int(os.environ.get("HNH_COMM_CUS", "0") or 0),
-                   "setup_s": round(b.setup_s or 0.0, 2)},
+                   # set-up of the first route: the tuples (generated on the device, or parsed from the file and merged), then redistribution,
+                   # CSR blocks and operands; parse_s is the first part alone
+                   "setup_s": round(b.setup_s or 0.0, 2), "parse_s": round(b.parse_s or 0.0, 3)},
         # `achieved` is an ALGORITHMIC rate (SURVEY 8d byte model / measured launch time), not DRAM utilisation: part of every
         # launch's gathers is served by the 256 MiB Infinity Cache, which sits behind the counters `traffic` comes from
         "roofline": {"bound": "hbm", "bound_detail": "hbm gather model (Infinity-Cache assisted); the saturated resource is the memory side "

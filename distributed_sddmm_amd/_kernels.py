@@ -35,6 +35,7 @@ SIGNATURES = {
     "hnh_event_record": (_i32, [_vp, _vp, _i32]),
     "hnh_event_wait": (_i32, [_vp, _vp, _i32]),
     "hnh_event_sync": (_i32, [_vp, _vp]),
+    "hnh_event_query": (_i32, [_vp, _vp, _vp]),
     "hnh_event_elapsed_ms": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float)]),
     "hnh_sddmm_coo": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32]),
     "hnh_sddmm_csr": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32]),

@@ -70,6 +70,7 @@ SIGNATURES = {
     "hnh_er_generate": (_i32, [_u64, _u64, _u64, _u64, _pvp, _pi64]),
     "hnh_rmat_generate": (_i32, [_i32, _u64, _dbl, _dbl, _dbl, _u64, _i32, _pvp, _pi64]),
     "hnh_er_fetch": (_i32, [_vp, _vp, _vp]),
+    "hnh_write_matrix_market": (_i32, [C.c_char_p, _i64, _i64, _i64, _vp, _vp, _vp, _i32]),
     "hnh_dist_create": (_i32, [_vp, C.c_char_p, _vp, _i32, _i32, _pvp]),
     "hnh_dist_destroy": (_i32, [_vp]),
     "hnh_dist_info": (_i32, [_vp, _pi64]),
@@ -187,6 +188,14 @@ def generate_rmat(logm: int, edges: int, a: float = 0.57, b: float = 0.19, c: fl
     rows, cols = np.empty(cnt.value, np.int64), np.empty(cnt.value, np.int64)
     _check(lib().hnh_er_fetch(h, rows.ctypes.data, cols.ctypes.data), "hnh_er_fetch")
     return rows, cols
+
+
+def write_matrix_market(path: str, m: int, n: int, rows, cols, values=None, symmetric: bool = False):
+    """hnh_write_matrix_market: the entries as a MatrixMarket coordinate file, formatted by all host cores."""
+    rows, cols = np.ascontiguousarray(rows, np.int64), np.ascontiguousarray(cols, np.int64)
+    vals = None if values is None else np.ascontiguousarray(values, np.float64)
+    _check(lib().hnh_write_matrix_market(path.encode(), m, n, len(rows), rows.ctypes.data, cols.ctypes.data,
+                                         None if vals is None else vals.ctypes.data, int(symmetric)), "hnh_write_matrix_market")
 
 
 # --------------------------------------------------------------------------------------------- worlds
@@ -526,9 +535,10 @@ class DistributedSparse:
         _check(lib().hnh_dist_hold_moving_operand(self.h, m.h if m else None), "hold_moving_operand")
 
     def walk_windows_when_held(self, on=True):
-        """Distributed_Sparse::walk_windows_when_held: a held operand's resident blocks are walked chunk window by chunk window, as a
-        fetching call does (measurement entry point: one rank's kernel sequence alone on a GPU)."""
-        _check(lib().hnh_dist_walk_windows_when_held(self.h, int(bool(on))), "walk_windows_when_held")
+        """Distributed_Sparse::walk_windows_when_held: a held operand's resident blocks are walked by chunk windows, as a fetching call
+        does (measurement entry point: one rank's kernel sequence alone on a GPU).  on = 1 / True: adaptive windows (everything has
+        landed: one pass); on = 2: one pass per chunk."""
+        _check(lib().hnh_dist_walk_windows_when_held(self.h, int(on)), "walk_windows_when_held")
 
     def fusedSpMM_out(self, a, b, matmode: int, out, leaky_alpha=None, x_scale: float = 0.0, rowdot=None) -> bool:
         """Distributed_Sparse::fusedSpMM_out; False (nothing done) when the schedule has no single fused pass."""

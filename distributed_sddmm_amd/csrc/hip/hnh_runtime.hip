@@ -324,6 +324,19 @@ int hnh_event_sync(hnh_ctx* ctx, void* event) {
     return hnh::check_hip(ctx, hipEventSynchronize((hipEvent_t)event), "hipEventSynchronize");
 }
 
+int hnh_event_query(hnh_ctx* ctx, void* event, int* done) {
+    if (!ctx || !event || !done) return HNH_ERR_INVALID;
+    HNH_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    const hipError_t e = hipEventQuery((hipEvent_t)event);
+    if (e == hipErrorNotReady) {
+        (void)hipGetLastError();
+        *done = 0;
+        return HNH_OK;
+    }
+    *done = 1;
+    return hnh::check_hip(ctx, e, "hipEventQuery");
+}
+
 int hnh_event_elapsed_ms(hnh_ctx* ctx, void* start, void* stop, float* ms) {
     if (!ctx || !start || !stop || !ms) return HNH_ERR_INVALID;
     HNH_TRY_HIP(ctx, hipSetDevice(ctx->device));

@@ -22,7 +22,7 @@ struct Backend {
     HNH_FN(hnh_ctx_create) HNH_FN(hnh_ctx_destroy) HNH_FN(hnh_last_error) HNH_FN(hnh_ctx_stream)
     HNH_FN(hnh_malloc) HNH_FN(hnh_free) HNH_FN(hnh_memcpy) HNH_FN(hnh_memset) HNH_FN(hnh_stream_sync)
     HNH_FN(hnh_event_create) HNH_FN(hnh_event_destroy) HNH_FN(hnh_event_record) HNH_FN(hnh_event_wait)
-    HNH_FN(hnh_event_sync) HNH_FN(hnh_event_elapsed_ms)
+    HNH_FN(hnh_event_sync) HNH_FN(hnh_event_query) HNH_FN(hnh_event_elapsed_ms)
     HNH_FN(hnh_sddmm_coo) HNH_FN(hnh_sddmm_csr) HNH_FN(hnh_spmm_csr) HNH_FN(hnh_fused_sddmm_spmm_csr)
     HNH_FN(hnh_sddmm_csr_ex) HNH_FN(hnh_spmm_csr_ex) HNH_FN(hnh_fused_sddmm_spmm_csr_ex) HNH_FN(hnh_csr_max_row_nnz)
     HNH_FN(hnh_fused_sddmm_spmm_csr_x) HNH_FN(hnh_row_epilogue_f64) HNH_FN(hnh_row_epilogue_x) HNH_FN(hnh_cg_step_f64)

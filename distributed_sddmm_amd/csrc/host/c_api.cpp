@@ -1,5 +1,6 @@
 // C ABI of the host layer (include/hnh_dist.h): thin handle wrappers over the C++ classes.
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -408,6 +409,39 @@ int hnh_er_fetch(void* handle, int64_t* rows, int64_t* cols) {
     delete k;
     return HNH_OK;
 }
+// A MatrixMarket coordinate file of the given entries (1-based on disk), written by all host cores: every thread formats its slice
+// of the lines, the slices go out in order.  Tests and benchmarks of the input side (SpmatLocal::loadTuples(readFromFile = true)).
+int hnh_write_matrix_market(const char* path, int64_t M, int64_t N, int64_t n, const int64_t* rows, const int64_t* cols, const double* values,
+                            int symmetric) {
+    return guarded(nullptr, [&] {
+        if (!path || M < 1 || N < 1 || n < 0 || (n && (!rows || !cols))) hnh::fatal("Error, bad arguments for the MatrixMarket writer");
+        FILE* f = std::fopen(path, "wb");
+        if (!f) hnh::fatal(std::string("Error, cannot create ") + path);
+        std::fprintf(f, "%%%%MatrixMarket matrix coordinate real %s\n%% written by hnh_write_matrix_market\n%lld %lld %lld\n", symmetric ? "symmetric" : "general",
+                     (long long)M, (long long)N, (long long)n);
+        const int64_t slice = 1 << 20;
+        const int64_t nslices = (n + slice - 1) / slice;
+        bool ok = true;
+        for (int64_t s0 = 0; s0 < nslices && ok; s0 += 64) {  // 64 slices formatted side by side, then written in order
+            const int64_t s1 = std::min(nslices, s0 + 64);
+            std::vector<std::string> text((size_t)(s1 - s0));
+#pragma omp parallel for schedule(dynamic, 1)
+            for (int64_t s = s0; s < s1; s++) {
+                std::string& t = text[(size_t)(s - s0)];
+                t.reserve((size_t)slice * 24);
+                char line[96];
+                for (int64_t e = s * slice; e < std::min(n, (s + 1) * slice); e++) {
+                    int len;
+                    if (values) len = std::snprintf(line, sizeof(line), "%lld %lld %.17g\n", (long long)rows[e] + 1, (long long)cols[e] + 1, values[e]);
+                    else len = std::snprintf(line, sizeof(line), "%lld %lld 1\n", (long long)rows[e] + 1, (long long)cols[e] + 1);
+                    t.append(line, (size_t)len);
+                }
+            }
+            for (const std::string& t : text) ok = ok && std::fwrite(t.data(), 1, t.size(), f) == t.size();
+        }
+        if (std::fclose(f) != 0 || !ok) hnh::fatal(std::string("Error, writing ") + path + " failed");
+    });
+}
 
 // ------------------------------------------------------------------ operator
 int hnh_dist_create(hnh_world* w, const char* alg_c, hnh_spmat* s, int R, int c, hnh_dist** out) {
@@ -591,7 +625,7 @@ int hnh_dist_hold_moving_operand(hnh_dist* d, hnh_dense* m) {
     });
 }
 int hnh_dist_walk_windows_when_held(hnh_dist* d, int on) {
-    return guarded(d->w, [&] { d->d->walk_windows_when_held(on != 0); });
+    return guarded(d->w, [&] { d->d->walk_windows_when_held(on); });
 }
 int hnh_dist_fusedSpMM_out(hnh_dist* d, hnh_dense* A, hnh_dense* B, int matmode, hnh_dense* Out, int leaky, double leaky_alpha,
                            double x_scale, hnh_vec* rowdot, int* supported) {

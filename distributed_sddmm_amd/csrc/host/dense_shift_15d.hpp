@@ -64,6 +64,18 @@ public:
     // here a row's nonzeros of all fetched blocks are consecutive, so the gather batches of the row kernel stay full however
     // many ranks and chunks there are.  HNH_MESH_CHUNKS = Q symmetric chunks (1 = whole blocks), HNH_MESH_TAPER = any heights;
     // default (1, 2, 2, 2, 1, 1).
+    // ADAPTIVE WINDOWS (round 5).  Every windowed pass re-reads the row operand and read-modify-writes the output rows (3 dense rows per
+    // sparse row and window: counter traffic 1.17 x the byte model at the default six chunks against 1.05 x for one pass over all
+    // fetched blocks, profiles/r05_rank_share_p8_counter_traffic.log) — the price of starting before everything has landed.  It is
+    // only worth paying for chunks that have NOT landed: the host therefore decides each pass's window RANGE as late as it can — when
+    // pass k - 2 has completed, i.e. while pass k - 1 runs and with one pass always queued behind it — and lets the pass cover every
+    // chunk whose arrival event has completed by then, not just the next one.  Links slower than the kernels: the passes follow the
+    // chunks one by one, as before; links faster than the kernels (or blocks that are already resident): the later chunks are taken in
+    // one pass.  The order of the nonzeros within a row, and with it every result bit, is the same for any grouping of consecutive
+    // windows.  The host blocks inside the call for this (the reference's calls are synchronous too); HNH_WINDOW_MERGE=0: one pass per
+    // chunk whatever has landed (round 2-4 behaviour), HNH_WINDOW_MERGE_CAP=n: at most n chunks per pass.
+    bool merge_windows = true;
+    int merge_cap = 1 << 20;
     bool merged = false;
     int windows = 1;
     std::vector<int> taper;  // chunk heights in units of a "fine" chunk; empty = the symmetric default (1, 2, .., 2, 1)
@@ -87,8 +99,11 @@ public:
         held_slot = -1;
         held_in_ring = false;
     }
-    bool force_windows = false;
-    void walk_windows_when_held(bool on) override { force_windows = on; }
+    bool force_windows = false, force_one_chunk_per_pass = false;
+    void walk_windows_when_held(int mode) override {
+        force_windows = mode != 0;
+        force_one_chunk_per_pass = mode == 2;
+    }
 
     Sparse15D_Dense_Shift(SpmatLocal* S_input, int R, int c, int fusionApproach, KernelImplementation* k) : Distributed_Sparse(k) {
         this->fusionApproach = fusionApproach;
@@ -99,6 +114,8 @@ public:
             else if (std::string(m) != "mesh") hnh::fatal("Error, HNH_RING_MODE must be relay or mesh!");
         }
         if (const char* h = std::getenv("HNH_ACC_HALVES")) acc_halves = std::atoi(h) != 0;
+        if (const char* mw = std::getenv("HNH_WINDOW_MERGE")) merge_windows = std::atoi(mw) != 0;
+        if (const char* mc = std::getenv("HNH_WINDOW_MERGE_CAP")) merge_cap = std::max(1, std::atoi(mc));
         if (c < 1 || p % c != 0) hnh::fatal("Error, for 1.5D algorithm, must have c divide num_procs!");
         if (fusionApproach != 1 && fusionApproach != 2) hnh::fatal("Error, fusion approach must be 1 or 2!");
 
@@ -366,18 +383,31 @@ private:
         const bool resident = fetch_into_landing(Brole, slot, br, slot == 0 ? cutB : cutA);
         auto t = phase_begin("Computation Time");
         CSRLocal* remote = choice->csr_blocks[1];
-        one(0, *Brole, -1, remote == nullptr);
+        one(0, *Brole, -1, -1, remote == nullptr);
         if (remote != nullptr) {
             // walk_windows_when_held(): walk the windows although a held operand's blocks are already there, which lets one rank's
             // kernel sequence be timed without its peers (bench.py's rank-share entries, tools/rank_share_probe.py)
             const bool by_window = kernel->handles_windows() && remote->n_windows > 1 && (!resident || force_windows);
             if (!by_window) {
                 world->event_wait(event(8 + windows - 1), HNH_STREAM_COMPUTE);  // every chunk has landed
-                one(1, landing[slot], -1, true);
-            } else {
+                one(1, landing[slot], -1, -1, true);
+            } else if (!merge_windows || (resident && force_one_chunk_per_pass)) {
                 for (int q = 0; q < windows; q++) {
                     world->event_wait(event(8 + q), HNH_STREAM_COMPUTE);  // chunk q of every remote block has landed
-                    one(1, landing[slot], q, q == windows - 1);
+                    one(1, landing[slot], q, q + 1, q == windows - 1);
+                }
+            } else {
+                // adaptive windows (see above): pass k covers the chunks [q, L) that have landed when the host gets to decide it
+                world->event_record(event(24), HNH_STREAM_COMPUTE);  // pass 0 (the own block) is enqueued
+                int k = 1;
+                for (int q = 0; q < windows; k++) {
+                    if (k >= 2) world->event_sync(event(24 + (k - 2) % 3));  // pass k - 2 is done: pass k - 1 runs, this one queues behind it
+                    int L = q + 1;
+                    while (L < windows && L - q < merge_cap && world->event_done(event(8 + L))) L++;
+                    world->event_wait(event(8 + L - 1), HNH_STREAM_COMPUTE);  // chunks q .. L - 1 of every remote block have landed
+                    one(1, landing[slot], q, L, L == windows);
+                    world->event_record(event(24 + k % 3), HNH_STREAM_COMPUTE);
+                    q = L;
                 }
             }
         } else {
@@ -417,23 +447,26 @@ private:
         const unsigned base = HNH_FUSED_VALUES_OVERWRITE | act_flag;
         bool out_fresh = true;
         // the fused kernel on one block (or one window of it); `ex` = what the call applies besides the multiplication
-        auto fused_on = [&](int block_id, DenseMatrix& Y, int window, const hnh_fused_extras* ex) {
+        auto fused_on = [&](int block_id, DenseMatrix& Y, int window, int window_end, const hnh_fused_extras* ex) {
             CSRLocal* blk = choice->csr_blocks[block_id];
             if (blk == nullptr && ex == act) return;  // nothing to multiply and no epilogue to run
-            if (blk != nullptr) blk->window = window;
+            if (blk != nullptr) {
+                blk->window = window;
+                blk->window_end = window_end;
+            }
             kernel->fused_local(*choice, *rowOperand, Y, *accum, block_id, base | (out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u), ex);
-            if (blk != nullptr) blk->window = -1;
+            if (blk != nullptr) blk->window = blk->window_end = -1;
             out_fresh = false;
         };
 
         if (merged) {
-            walk_merged(choice, Brole, [&](int block_id, DenseMatrix& Y, int window, bool is_last) {
-                fused_on(block_id, Y, window, is_last ? last : act);
+            walk_merged(choice, Brole, [&](int block_id, DenseMatrix& Y, int window, int window_end, bool is_last) {
+                fused_on(block_id, Y, window, window_end, is_last ? last : act);
             });
         } else {
             ring_readonly(Brole, n, [&](int i, DenseMatrix& cur) {
                 auto t = phase_begin("Computation Time");
-                fused_on(block_at(i), cur, -1, (i == n - 1) ? last : act);
+                fused_on(block_at(i), cur, -1, -1, (i == n - 1) ? last : act);
                 phase_end(t);
             });
         }
@@ -515,14 +548,15 @@ public:
         if (merged) {
             // same kernels on the same nonzeros as the reference's block-by-block walk; the fetched blocks' share runs
             // window by window as the chunks land
-            walk_merged(choice, Brole, [&](int block_id, DenseMatrix& Y, int window, bool) {
+            walk_merged(choice, Brole, [&](int block_id, DenseMatrix& Y, int window, int window_end, bool) {
                 CSRLocal* blk = choice->csr_blocks[block_id];
                 if (blk == nullptr) return;
                 blk->window = window;
+                blk->window_end = window_end;
                 blk->values_fresh = fresh;
                 kernel->triple_function(mode_temp, *choice, stationary, Y, block_id, 0);
                 blk->values_fresh = false;
-                blk->window = -1;
+                blk->window = blk->window_end = -1;
             });
         } else if (moving_readonly) {
             ring_readonly(Brole, n, step);

@@ -273,10 +273,11 @@ public:
     virtual void hold_moving_operand(const DenseMatrix* m) { (void)m; }
     virtual void release_moving_operand() {}
     // Measurement entry point (an addition): a held operand's fetched blocks are resident, so a call normally runs ONE pass over them.
-    // With this switch on the call walks the chunk windows exactly as a fetching call does — own block, then one windowed pass per
-    // chunk — which is what lets ONE rank's kernel sequence of a p-rank job be timed alone on a GPU (bench.py's "rank share"
-    // entries, tools/rank_share_probe.py).  Results are identical either way.  Default: ignored.
-    virtual void walk_windows_when_held(bool on) { (void)on; }
+    // mode 1: the call walks the chunk windows as a fetching call does — own block, then windowed passes over whatever has "landed"
+    // (everything, here: the adaptive windows take it in one pass); mode 2: one windowed pass per chunk, the sequence of a call whose
+    // chunks arrive one by one — which is what lets ONE rank's kernel sequence of a p-rank job be timed alone on a GPU (bench.py's
+    // "rank share" entries, tools/rank_share_probe.py).  Results are identical either way.  Default: ignored.
+    virtual void walk_windows_when_held(int mode) { (void)mode; }
 
     // Out-of-place fusedSpMM with the applications' surrounding work folded in (an addition; hnh_fused_extras in
     // hnh_kernels.h).  With X = localA for Amat (localB for Bmat) and Y the other operand:

@@ -73,6 +73,7 @@ public:
     int32_t* win_split = nullptr;
     int n_windows = 1;
     int window = -1;
+    int window_end = -1;  // one past the last selected window when several consecutive ones are taken in one pass (-1: just `window`)
     // Set by a schedule around an SDDMM call: the values of the selected window are known to be zero (nobody has written them
     // since the operation began), so a kernel that says overwrites_fresh_values() may store its results instead of adding to them
     // — and the schedule has skipped the zero fill.  Kernels that do not know the hint are never given unfilled values.
@@ -100,9 +101,10 @@ public:
     // the kernel-ABI description of the selected window; false when the whole block is selected
     bool window_args(hnh_csr_window* w) const {
         if (window < 0 || n_windows <= 1) return false;
+        const int last = (window_end > window ? window_end : window + 1) - 1;  // the last window of the range (consecutive windows are one column range)
         w->beg = (window == 0) ? nullptr : win_split + (size_t)(window - 1) * (size_t)rows;
-        w->end = (window == n_windows - 1) ? nullptr : win_split + (size_t)window * (size_t)rows;
-        w->last = (window == n_windows - 1) ? 1 : 0;
+        w->end = (last == n_windows - 1) ? nullptr : win_split + (size_t)last * (size_t)rows;
+        w->last = (last == n_windows - 1) ? 1 : 0;
         return true;
     }
 

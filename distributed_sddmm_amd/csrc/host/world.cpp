@@ -86,7 +86,7 @@ Backend* load_backend(const char* path_c) {
     HNH_BIND(hnh_ctx_create) HNH_BIND(hnh_ctx_destroy) HNH_BIND(hnh_last_error) HNH_BIND(hnh_ctx_stream)
     HNH_BIND(hnh_malloc) HNH_BIND(hnh_free) HNH_BIND(hnh_memcpy) HNH_BIND(hnh_memset) HNH_BIND(hnh_stream_sync)
     HNH_BIND(hnh_event_create) HNH_BIND(hnh_event_destroy) HNH_BIND(hnh_event_record) HNH_BIND(hnh_event_wait)
-    HNH_BIND(hnh_event_sync) HNH_BIND(hnh_event_elapsed_ms)
+    HNH_BIND(hnh_event_sync) HNH_BIND(hnh_event_query) HNH_BIND(hnh_event_elapsed_ms)
     HNH_BIND(hnh_sddmm_coo) HNH_BIND(hnh_sddmm_csr) HNH_BIND(hnh_spmm_csr) HNH_BIND(hnh_fused_sddmm_spmm_csr)
     HNH_BIND(hnh_sddmm_csr_ex) HNH_BIND(hnh_spmm_csr_ex) HNH_BIND(hnh_fused_sddmm_spmm_csr_ex) HNH_BIND(hnh_csr_max_row_nnz)
     HNH_BIND(hnh_fused_sddmm_spmm_csr_x) HNH_BIND(hnh_row_epilogue_f64) HNH_BIND(hnh_row_epilogue_x) HNH_BIND(hnh_cg_step_f64)
@@ -268,6 +268,12 @@ void* World::scratch(int slot, size_t bytes) {
         s.second = bytes;
     }
     return s.first;
+}
+void World::event_sync(void* e) { check(be->hnh_event_sync(ctx, e), "hnh_event_sync"); }
+bool World::event_done(void* e) {
+    int done = 0;
+    check(be->hnh_event_query(ctx, e, &done), "hnh_event_query");
+    return done != 0;
 }
 
 void World::set_solo(bool on) {

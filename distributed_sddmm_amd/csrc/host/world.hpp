@@ -116,6 +116,8 @@ public:
     void event_destroy(void* e);
     void event_record(void* e, int stream);
     void event_wait(void* e, int stream);
+    void event_sync(void* e);   // the host waits
+    bool event_done(void* e);   // the host asks (never blocks)
 #ifdef HNH_MEASUREMENT_AIDS
     void delay_us(double us, int stream);  // holds the stream without memory traffic (paced stand-in of a transfer)
 #endif

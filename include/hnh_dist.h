@@ -120,6 +120,11 @@ int hnh_er_generate(uint64_t m, uint64_t n, uint64_t draws, uint64_t seed, void*
 int hnh_rmat_generate(int logm, uint64_t edges, double a, double b, double c, uint64_t seed, int scramble, void** handle,
                       int64_t* count);
 int hnh_er_fetch(void* handle, int64_t* rows, int64_t* cols); /* also frees the handle */
+/* (an addition) writes the entries as a MatrixMarket coordinate file (1-based; values NULL = all 1; symmetric != 0: the header says so
+ * and the caller passes one triangle), formatted by all host cores — the files the input side (loadTuples(readFromFile = true),
+ * SpmatLocal.hpp:485-498) is tested and benchmarked with. */
+int hnh_write_matrix_market(const char* path, int64_t M, int64_t N, int64_t n, const int64_t* rows, const int64_t* cols, const double* values,
+                            int symmetric);
 
 /* ---- operator construction (benchmark_dist.cpp:45-82): alg in
  *   "15d_fusion1" | "15d_fusion2" | "15d_sparse" | "25d_dense_replicate" | "25d_sparse_replicate" */
@@ -176,8 +181,9 @@ int hnh_dist_fusedSpMM(hnh_dist* d, hnh_dense* A, hnh_dense* B, hnh_vec* S, hnh_
  * factor of an ALS half-step, als_conjugate_gradients.cpp:38-141).  Ignored by schedules that cannot use it. */
 int hnh_dist_hold_moving_operand(hnh_dist* d, hnh_dense* m_or_null);
 /* Distributed_Sparse::walk_windows_when_held (an addition, a MEASUREMENT entry point): with a held operand's blocks resident a call
- * runs one pass over them; on = 1 makes it walk the chunk windows as a fetching call does (own block, then one windowed pass per
- * chunk), so that one rank's kernel sequence of a p-rank job can be timed alone on a GPU.  Same results either way. */
+ * runs one pass over them; on = 1 makes it walk the chunk windows as a fetching call does (own block, then windowed passes over what
+ * has landed — everything, here), on = 2 one windowed pass per chunk (the sequence of a call whose chunks arrive one by one), so that
+ * one rank's kernel sequence of a p-rank job can be timed alone on a GPU.  Same results either way. */
 int hnh_dist_walk_windows_when_held(hnh_dist* d, int on);
 /* Distributed_Sparse::fusedSpMM_out (an addition): out-of-place fusedSpMM with the applications' surrounding work in the
  * same pass — LeakyReLU between the halves (gat.hpp:96-99), Out += x_scale * X and rowdot[i] = <X[i,:], Out[i,:]>

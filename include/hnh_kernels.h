@@ -74,6 +74,7 @@ int hnh_event_destroy(hnh_ctx* ctx, void* event);
 int hnh_event_record(hnh_ctx* ctx, void* event, int stream);
 int hnh_event_wait(hnh_ctx* ctx, void* event, int stream); /* `stream` waits for `event` (device side) */
 int hnh_event_sync(hnh_ctx* ctx, void* event);            /* host waits for `event`                    */
+int hnh_event_query(hnh_ctx* ctx, void* event, int* done); /* host asks: *done = 1 when `event` has completed, never blocks */
 int hnh_event_elapsed_ms(hnh_ctx* ctx, void* start, void* stop, float* ms);
 /* ---- local kernels --------------------------------------------------------------------------------
  * hnh_sddmm_coo — replaces StandardKernel::sddmm_local (sparse_kernels.cpp:13-57), COO view:

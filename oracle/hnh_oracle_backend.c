@@ -303,6 +303,22 @@ int hnh_event_sync(hnh_ctx* c, void* e) {
     return HNH_OK;
 }
 
+/* The double runs every call on the spot, so an event that was recorded has completed; a query that says so tells the host what a
+ * synchronise would (same edge).  HNH_ORACLE_EVENTS_PENDING=k: every k-th query (counted over the process) answers "not yet" — for
+ * tests of callers that act on the answer (the adaptive chunk windows of the 1.5D dense shift take fewer chunks per pass then). */
+int hnh_event_query(hnh_ctx* c, void* e, int* done) {
+    if (!e || !done) return HNH_ERR_INVALID;
+    static long asked = 0;
+    const char* k = getenv("HNH_ORACLE_EVENTS_PENDING");
+    const long every = k ? atol(k) : 0;
+    if (every > 0 && __atomic_add_fetch(&asked, 1, __ATOMIC_RELAXED) % every == 0) {
+        *done = 0;
+        return HNH_OK;
+    }
+    *done = 1;
+    return hnh_event_sync(c, e);
+}
+
 /* ---- the checker's own entry points (tests only) */
 void hnh_oracle_order_enable(int on) {
     pthread_mutex_lock(&g_mu);

@@ -466,7 +466,8 @@ def test_secondary_workloads_are_listed_with_their_checks():
     for e in shares:
         assert e["held"]["wall_ms"] > 0 and e["solo"]["wall_ms"] > 0 and e["algorithmic_bytes_rank"] > 0 and e["nnz_rank"] > 0
         # own block + one pass per chunk window (a single pass over the fetched blocks when there is one chunk)
-        assert e["held"]["launches"] == e["solo"]["launches"] >= (2 if e["chunks"] == "1" else 4), e
+        # one pass per chunk: own block + one launch per chunk window; everything landed: own block + ONE pass over the fetched blocks
+        assert e["held"]["launches"] == (2 if e["chunks"] == "1" else 7) and e["held_all_landed"]["launches"] == 2 and e["solo"]["launches"] >= 2, e
     for key in ("rank share, config 4", "rank share, config 5", "config 1 as typed"):
         e = next(v for k, v in by_name.items() if k.startswith(key))
         assert e["solo"]["wall_ms"] > 0 and e["solo"]["launches"] > 0 and e["all_ranks_on_this_gpu_ms"] > 0 and e["algorithmic_bytes_rank"] > 0, e

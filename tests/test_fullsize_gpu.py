@@ -266,3 +266,107 @@ def test_config5_als_step_at_full_size(config2):
     for x in (A, B, gts[0], gts[1]):
         x.free()
     d.free(); sp.free(); w.close()
+
+
+def test_input_side_at_size_matrix_market_to_25d_dense(tmp_path):
+    """The input side (row f3) at the size of a real graph file: an R-MAT graph on 2^20 vertices, edge factor 8, written by the
+    library's writer as a SYMMETRIC MatrixMarket file (one triangle stored) in which every third entry appears twice and every seventh
+    three times (1.2e7 lines, about 170 MB), then
+      (a) read by 8 logical ranks through SpmatLocal::loadTuples(readFromFile) — the parallel mmap parser, both triangles, duplicates
+          merged by the device `maximum` pass (SpmatLocal.hpp:485-498) — into 2.5D dense-replicate p = 8, c = 2 at R = 256
+          (bench_file.cpp:23-103 with config 4's schedule): the tuple count equals the generator's, one fusedSpMM from keyed operands
+          equals the closed form summed over the generator's nonzeros on every rank's rows;
+      (b) timed by `bench.py --workload mtx:<file>`: its own host-side parse (pandas, no code shared with the library's parser) finds the
+          same nonzeros, the result check passes and the line reports the parse + set-up seconds.
+    /tmp holds the file (tmp_path may be a small tmpfs)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import time
+    logm, ef, r, p, c = 20, 8, 256, 8, 2
+    m = 1 << logm
+    gr, gc = H.generate_rmat(logm, m * ef)
+    lo = np.unique(np.maximum(gr, gc) * m + np.minimum(gr, gc))  # the distinct lower-triangle coordinates of the symmetrised graph
+    dup = np.concatenate([lo, lo[::3], lo[::7]])
+    np.random.default_rng(5).shuffle(dup)
+    vals = ((dup % 13) - 6.0) * 0.25  # duplicates of a coordinate carry the same value here; the count is what the merge is held to
+    path = "/tmp/hnh_rmat20_sym_dup.mtx"
+    t0 = time.perf_counter()
+    H.write_matrix_market(path, m, m, dup // m, dup % m, vals, symmetric=True)
+    write_s = time.perf_counter() - t0
+    try:
+        size_mb = os.path.getsize(path) / 1e6
+        i, j = lo // m, lo % m
+        off = i != j
+        rows, cols = np.concatenate([i, j[off]]), np.concatenate([j, i[off]])  # what a reader must deliver
+        nnz = len(rows)
+        assert len(dup) > 1.1e7 and size_mb > 150.0 and nnz > 1.9e7, (len(dup), size_mb, nnz)
+        from benchlib.common import keyed
+        a_key, b_key, u_key, v_key = keyed(np.arange(m), 1), keyed(np.arange(m), 2), keyed(np.arange(r), 3), keyed(np.arange(r), 4)
+        want_row = float(np.dot(u_key, v_key)) * a_key * np.bincount(rows, weights=b_key[cols] ** 2, minlength=m)
+
+        def body(w):
+            t0 = time.perf_counter()
+            sp = H.SpmatLocal.load_tuples(w, True, 0, 0, path)
+            w.sync()
+            parse_s = time.perf_counter() - t0
+            info = sp.info()
+            t0 = time.perf_counter()
+            op = H.DistributedSparse(w, "25d_dense_replicate", sp, r, c)
+            w.sync()
+            setup_s = time.perf_counter() - t0
+            sp.free()
+
+            def keyed_local(mat_mode, row_key, col_key):
+                parts = []
+                for top, left, rc, cc in op.submatrices(mat_mode):
+                    blk = np.zeros((rc, cc))
+                    keep = int(max(0, min(rc, m - top)))
+                    blk[:keep] = row_key[top:top + keep, None] * col_key[None, left:left + cc]
+                    parts.append(blk.reshape(-1))
+                return np.concatenate(parts)
+            A, B = op.like_A_matrix(0.0), op.like_B_matrix(0.0)
+            S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
+            A.upload(keyed_local(H.AMAT, a_key, u_key).reshape(A.shape))
+            B.upload(keyed_local(H.BMAT, b_key, v_key).reshape(B.shape))
+            op.initial_shift(A, B, H.K_SDDMM_A)
+            op.fusedSpMM(A, B, S, buf, H.AMAT)
+            op.de_shift(A, B, H.K_SDDMM_A)
+            w.sync()
+            got, worst, off_, checked = A.download().reshape(-1), 0.0, 0, 0
+            for top, left, rc, cc in op.submatrices(H.AMAT):
+                keep = int(max(0, min(rc, m - top)))
+                blk = got[off_:off_ + rc * cc].reshape(rc, cc)[:keep]
+                off_ += rc * cc
+                if keep:
+                    worst = max(worst, float(np.max(np.abs(blk - want_row[top:top + keep, None] * v_key[None, left:left + cc]))))
+                    checked += keep * cc
+            for x in (A, B, S, buf):
+                x.free()
+            op.free()
+            return info["dist_nnz"], info["M"], parse_s, setup_s, worst, checked
+        res = H.run_spmd(p, body)
+        assert all(x[0] == nnz and x[1] == m for x in res), (res[0][:2], nnz)
+        assert sum(x[5] for x in res) == m * r  # every element of the output was compared by the rank that owns it
+        assert max(x[4] for x in res) <= T.TOL * float(want_row.max() * v_key.max())
+        parse_s, setup_s = max(x[2] for x in res), max(x[3] for x in res)
+        print("\n[input side at size] %.0f MB, %d lines -> %d tuples on %d logical ranks: written in %.2f s, parsed + merged in %.2f s, "
+              "2.5D dense-replicate operator (R = %d) set up in %.2f s" % (size_mb, len(dup), nnz, p, write_s, parse_s, r, setup_s))
+        assert parse_s < 60.0 and setup_s < 60.0
+        # (b) the benchmark driver on the same file
+        env = dict(os.environ)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        out = subprocess.run([sys.executable, os.path.join(T.ROOT, "bench.py"), "--workload", "mtx:" + path, "--alg", "25d_dense_replicate", "--rvalue", str(r),
+                              "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--no-live-traffic"], env=env, capture_output=True,
+                             text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        assert line["check"]["ok"] and line["check"]["nnz_host_generator"] == nnz == line["config"]["nnz"] and line["data"] == "file"
+        assert line["config"]["setup_s"] > 0 and line["config"]["parse_s"] > 0 and line["config"]["algorithm"] == "25d_dense_replicate"
+        print("[input side at size] bench.py --workload mtx: parse %.2f s, set-up %.2f s, %.2f ms per fused call" % (
+            line["config"]["parse_s"], line["config"]["setup_s"], line["ms_per_step"]))
+    finally:
+        if os.path.exists(path):
+            os.remove(path)

@@ -1,7 +1,7 @@
 """Randomised differential test of the host logic (CPU ranks + the oracle's C test double) against the numpy oracle:
 random schedule, grid (powers of two and grids with remainders, up to 18 ranks), sizes (incl. M < p, non-square, 1-nonzero
-matrices), chunk counts and heights, ring modes, accumulator halves, borrowed value arrays, shift payload and both set-up
-pipelines.  A fixed seed keeps the suite deterministic; `python tests/test_fuzz_cpu.py SEED COUNT` explores further (round 4:
+matrices), chunk counts and heights, adaptive window grouping, ring modes, accumulator halves, borrowed value arrays, shift payload
+and both set-up pipelines.  A fixed seed keeps the suite deterministic; `python tests/test_fuzz_cpu.py SEED COUNT` explores further (round 4:
 4 x 1500 draws, 4 153 valid configurations, no deviation)."""
 import os
 import random
@@ -16,11 +16,15 @@ from oracle import oracle as O  # noqa: E402
 
 GRIDS = [(1, 1), (2, 1), (2, 2), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2), (8, 4), (8, 8),
          (3, 1), (3, 3), (5, 1), (6, 2), (6, 3), (7, 1), (9, 1), (9, 3), (12, 2), (12, 3), (16, 4), (18, 2)]  # (grids with remainders)
-KNOBS = ("HNH_MESH_CHUNKS", "HNH_RING_MODE", "HNH_HOST_SETUP", "HNH_ACC_HALVES", "HNH_BORROW", "HNH_SHIP_INDICES", "HNH_MESH_TAPER")
+KNOBS = ("HNH_MESH_CHUNKS", "HNH_RING_MODE", "HNH_HOST_SETUP", "HNH_ACC_HALVES", "HNH_BORROW", "HNH_SHIP_INDICES", "HNH_MESH_TAPER",
+         "HNH_WINDOW_MERGE", "HNH_WINDOW_MERGE_CAP", "HNH_ORACLE_EVENTS_PENDING")
 # switches that select another host code path: the whole accumulator instead of two halves, borrowed value arrays off / forced,
 # the reference's shift payload, chunk heights of the mesh fetch
 EXTRA = {"HNH_ACC_HALVES": [None, "0"], "HNH_BORROW": [None, "off", "force"], "HNH_SHIP_INDICES": [None, "1"],
-         "HNH_MESH_TAPER": [None, None, "1,2,2,2,1,1", "3,4,4,3,2,1,1", "2,1"]}
+         "HNH_MESH_TAPER": [None, None, "1,2,2,2,1,1", "3,4,4,3,2,1,1", "2,1"],
+         # adaptive chunk windows of the mesh fetch: off, at most n chunks per pass, and arrival events that answer "not yet" to every
+         # k-th query of the host (the test double completes everything at once: without this every pass would take all chunks)
+         "HNH_WINDOW_MERGE": [None, None, "0"], "HNH_WINDOW_MERGE_CAP": [None, "1", "2", "3"], "HNH_ORACLE_EVENTS_PENDING": [None, "2", "3"]}
 
 
 def one(rng, it):

@@ -292,3 +292,52 @@ def test_in_place_sddmm_does_not_borrow(monkeypatch):
     for res, inplace, before, after in H.run_spmd(2, body):
         assert np.array_equal(res, inplace)
         assert before[2] > 0 and after[2] == before[2] and after[3] > before[3]
+
+
+@pytest.mark.parametrize("merge,cap,pending,want_launches", [
+    ("0", None, None, 7),   # one pass per chunk whatever has landed (rounds 2-4): own block + six windows
+    (None, None, None, 2),  # everything has landed when the host decides (the double completes at once): own block + ONE pass
+    (None, "2", None, 4),   # at most two chunks per pass: (1,2) (2,2) (1,1)
+    (None, "4", None, 3),
+    (None, None, "2", None),  # every second arrival query answers "not yet": some grouping in between
+    (None, None, "3", None),
+])
+def test_adaptive_chunk_windows_of_the_mesh_fetch(monkeypatch, merge, cap, pending, want_launches):
+    """1.5D dense shift, mesh fetch, default chunk heights (1,2,2,2,1,1): a windowed pass covers every chunk whose arrival event has
+    completed when the host decides it (Sparse15D_Dense_Shift::walk_merged).  Whatever the grouping — none, everything at once, capped,
+    or cut short by arrival events that are not yet complete — the results are the reference's golden vectors (the nonzeros of a row
+    are taken in the same order), the number of row-kernel launches per fused call says how the chunks were grouped, and the
+    stream-order checker sees no race (the pass waits for the arrival event of its LAST chunk)."""
+    for k, v in (("HNH_WINDOW_MERGE", merge), ("HNH_WINDOW_MERGE_CAP", cap), ("HNH_ORACLE_EVENTS_PENDING", pending)):
+        if v is None:
+            monkeypatch.delenv(k, raising=False)
+        else:
+            monkeypatch.setenv(k, v)
+    monkeypatch.setenv("HNH_RING_MODE", "mesh")
+    monkeypatch.delenv("HNH_MESH_CHUNKS", raising=False)
+    monkeypatch.delenv("HNH_MESH_TAPER", raising=False)
+    case = T.case_inputs("er8_r16")
+    for p, c in ((4, 1), (8, 2)):
+        per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, "15d_fusion2", c, case))
+        T.check_against_golden(T.assemble(per_rank, case), per_rank, case, "15d_fusion2")
+
+    def launches(w):
+        sp = H.SpmatLocal.from_global(w, case["M"], case["N"], case["rows"], case["cols"], None)
+        op = H.DistributedSparse(w, "15d_fusion2", sp, case["R"], 1)
+        sp.free()
+        A, B = op.like_A_matrix(0.5), op.like_B_matrix(0.25)
+        S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
+        op.kernel_profile(1)
+        op.fusedSpMM(A, B, S, buf, H.AMAT)
+        w.sync()
+        n = op.kernel_profile(0)[1]
+        for x in (A, B, S, buf):
+            x.free()
+        op.free()
+        return n
+    got = H.run_spmd(4, launches)
+    if want_launches is not None:
+        assert got == [want_launches] * 4, got
+    else:
+        # (the "not yet" answers are dealt over the four rank threads' queries: each rank gets some grouping between the extremes)
+        assert all(2 <= n <= 7 for n in got) and any(2 < n < 7 for n in got), got

@@ -128,6 +128,9 @@ def test_the_checker_sees_the_protocol(checker, monkeypatch):
     racy — kernels against the transfers that fill and drain their operands, transfers against transfers — so silence above means the
     events are really there."""
     monkeypatch.setenv("HNH_ORDER_CHECK_DROP_WAITS", "1")
+    # (one windowed pass per chunk, ordered by event waits alone: with the adaptive windows the host ASKS whether a chunk's arrival event
+    # has completed before it enqueues the pass — in the double that answer is itself an edge, as a completed hipEventQuery is)
+    monkeypatch.setenv("HNH_WINDOW_MERGE", "0")
     case = T.case_inputs("er8_r16")
     seen = {}
     for alg, p, c in (("15d_fusion2", 4, 1), ("15d_fusion1", 4, 1), ("15d_sparse", 4, 1), ("25d_dense_replicate", 4, 1)):
@@ -165,12 +168,13 @@ print("done")
     assert r.returncode == 0
 
 
-def test_single_missing_waits_are_detected(checker):
+def test_single_missing_waits_are_detected(checker, monkeypatch):
     """Fault injection one wait at a time: the k-th hnh_event_wait of a run is ignored by the checker, everything else as ever.  Measured
     over ALL waits of a run (round 4): 15d_fusion2 p = 2: 178 of 490 detected as a race, 15d_fusion1 p = 2: 171 of 332, 15d_sparse p = 2:
     138 of 324, 2.5D dense-replicate p = 4: 548 of 1318 — the others are implied by another path (e.g. the caching allocator orders a
     recycled block behind BOTH streams' last use; a stream that has nothing in flight waits for nothing).  Here: every 16th wait of one
     schedule; at least a fifth of the single faults must be seen."""
+    monkeypatch.setenv("HNH_WINDOW_MERGE", "0")  # (event waits alone order the windowed passes: see test_the_checker_sees_the_protocol)
     lib = ctypes.CDLL(T.ORACLE_BACKEND)
     lib.hnh_oracle_order_drop_wait.restype = ctypes.c_long
     lib.hnh_oracle_order_drop_wait.argtypes = [ctypes.c_long]

@@ -64,7 +64,7 @@ def body(w):
     A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
     S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
     op.hold_moving_operand(B)
-    op.walk_windows_when_held(True)  # windows are walked (and the paced stand-ins waited for) although the blocks are resident
+    op.walk_windows_when_held(1)  # windows are walked (and the paced stand-ins waited for) although the blocks are resident
     op.fusedSpMM(A, B, S, buf, H.AMAT)  # collective: fills the landing buffers
     w.sync()
     w.barrier()

@@ -43,7 +43,7 @@ def body(w):
     A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
     S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
     op.hold_moving_operand(B)
-    op.walk_windows_when_held(True)  # the held blocks are resident, but walk the chunk windows as a fetching call does
+    op.walk_windows_when_held(2)  # the held blocks are resident, but walk the chunk windows one by one, as a call whose chunks arrive one by one does
     op.fusedSpMM(A, B, S, buf, H.AMAT)  # collective: fills the landing buffers
     w.sync()
     w.barrier()
