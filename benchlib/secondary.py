@@ -122,8 +122,15 @@ def secondary(args, b):
                 else:
                     by = sum(h * fused_bytes(sub.nnz, f, sub.m) for _, f, h in GAT_LAYERS)
                     what = "14 fused heads (SDDMM -> LeakyReLU -> SpMM -> ReLU delivery) + 14 fp64 MFMA GEMMs, the product of head j + 1 on a second compute stream beside the attention pass of head j"
-                return {"ms": ms, "what": what, "nnz": sub.nnz, "M": sub.m, "R": info["R"], "algorithmic_bytes_fused_calls": by,
-                        "frac_whole_step": frac_of(by, ms), "check": chk}
+                res = {"ms": ms, "what": what, "nnz": sub.nnz, "M": sub.m, "R": info["R"], "algorithmic_bytes_fused_calls": by,
+                       "frac_whole_step": frac_of(by, ms), "check": chk}
+                if app == "als":
+                    # what the fused-call model leaves out: the 20 CG iterations' own row streams — x and r read and written, p written
+                    # (als_conjugate_gradients.cpp:112-139) — which ride in the fused call's row epilogue here: 5 x 8 R M bytes each
+                    # (profiles/r05_als_step_kernel_stats.csv: the launch that carries them takes 8.51 ms against 7.39 ms without)
+                    by_cg = by + 20 * 5 * 8 * args.r * sub.m
+                    res.update({"algorithmic_bytes_with_cg_row_streams": by_cg, "frac_with_cg_row_streams": frac_of(by_cg, ms)})
+                return res
             finally:
                 sub.free_current()
                 if small is not None and sub.transports["single"]["sp"] is not None:

@@ -35,10 +35,12 @@ struct hnh_ctx {
     int long_row_override = 0;      // HNH_LONG_ROW=<multiple of 64, 64..1984>: fixed hub-row threshold instead of the adaptive one (measurement aid)
     double panel_bytes = 512.0 * 1024.0 * 1024.0;  // bytes of the gathered operand per panel (HNH_PANEL_BYTES; tests shrink it)
     // Most panels a pass is cut into (HNH_MAX_PANELS, 1 .. 8).  Every panel re-reads the row operand and read-modify-writes the output
-    // (3 dense rows per sparse row and panel), so past four the extra traffic outweighs what the Infinity Cache gives back: measured at
-    // config 2's matrix, R = 512 (8 x 512 MiB): 4 panels 66.7 ms against 8 panels 70.2 ms (counter traffic 1.09 x against 1.21 x the
-    // byte model), R = 384: 50.1 against 52.6 ms — profiles/r05_wide_panels.log
-    int max_panels = 4;
+    // (3 dense rows per sparse row and panel: counter traffic 1.03 / 1.09 / 1.21 x the byte model at 2 / 4 / 8 panels), which the
+    // Infinity Cache has to earn back.  Where the balance tips depends on the BOX: R = 512 (8 x 512 MiB) on three leases — 4 panels
+    // 66.7 ms against 8 panels 70.2 ms; 6 panels 71.8 against 4 panels 73.2; 8 panels 73.5, 6 panels 74.3, 4 panels 76.5 — the same
+    // launch sequence differs by more between boxes than between panel counts (profiles/r05_wide_panels*.log).  Six is never more than
+    // 1-2 % from the best of any of them; R <= 384 is not affected (its natural count is at most six).
+    int max_panels = 6;
     // peer-to-peer pull (hnh_ipc.hip): auxiliary streams the copy-engine pulls of one group are spread over (created on first use),
     // the fork event recorded on the issuing stream and one join event per auxiliary stream
     static constexpr int kAuxStreams = 8;
@@ -46,6 +48,7 @@ struct hnh_ctx {
     hipEvent_t aux_fork = nullptr, aux_join[kAuxStreams] = {nullptr};
     unsigned long long* pace_stamp[HNH_STREAMS] = {nullptr};  // measurement aid (hnh_stream_pace_begin / _end): the clock at the begin mark
     int gemm_waves = 4;     // HNH_GEMM_WAVES=8: hnh_gemm_f64 with 256 x 128 tiles of 8 waves instead of 128 x 128 tiles of 4
+    int gemm_lds_extra = 0; // HNH_GEMM_LDS_EXTRA=<bytes>: unused dynamic LDS added to every GEMM workgroup's request (occupancy experiments)
     int flag_kernels = -1;  // HNH_IPC_FLAGS=kernel: flag words are written / awaited by one-lane kernels instead of stream memory operations
 };
 

@@ -2410,10 +2410,11 @@ int hnh_gemm_f64(hnh_ctx* ctx, int64_t M, int64_t N, int64_t K, const double* A,
     const bool vec_ok = (K % 2 == 0) && (N % 2 == 0) && aligned16(A) && aligned16(B);
     hnh::WideLaunch wide(ctx, stream);  // a dense contraction wants every matrix core
     if (wide.status != HNH_OK) return wide.status;
+    const unsigned extra = (unsigned)ctx->gemm_lds_extra;  // (an LDS request the kernel never touches: caps its workgroups per CU)
     if (tall)
-        hipLaunchKernelGGL(gemm_f64_kernel<4>, dim3((unsigned)grid), dim3(512), 0, wide.stream(), M, N, K, A, B, C, row_blocks, (int)col_blocks, vec_ok);
+        hipLaunchKernelGGL(gemm_f64_kernel<4>, dim3((unsigned)grid), dim3(512), extra, wide.stream(), M, N, K, A, B, C, row_blocks, (int)col_blocks, vec_ok);
     else
-        hipLaunchKernelGGL(gemm_f64_kernel<2>, dim3((unsigned)grid), dim3(256), 0, wide.stream(), M, N, K, A, B, C, row_blocks, (int)col_blocks, vec_ok);
+        hipLaunchKernelGGL(gemm_f64_kernel<2>, dim3((unsigned)grid), dim3(256), extra, wide.stream(), M, N, K, A, B, C, row_blocks, (int)col_blocks, vec_ok);
     return wide.finish(hnh::check_hip(ctx, hipGetLastError(), "gemm_f64_kernel launch"));
 }
 

@@ -108,6 +108,7 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
         if (v >= 0 && v <= 7) ctx->row_waves_cap = (int)v;
     }
     if (const char* gw = std::getenv("HNH_GEMM_WAVES")) ctx->gemm_waves = std::atoi(gw) == 8 ? 8 : 4;
+    if (const char* ge = std::getenv("HNH_GEMM_LDS_EXTRA")) ctx->gemm_lds_extra = std::max(0, std::min(64 * 1024, std::atoi(ge)));
     ctx->panels_with_hubs = std::getenv("HNH_PANELS_WITH_HUBS") != nullptr;
     if (const char* nr = std::getenv("HNH_NARROW_ROWS")) ctx->narrow_rows = std::atoi(nr) != 0;
     if (const char* lg = std::getenv("HNH_LONG_GRID")) {

@@ -271,7 +271,7 @@ def test_config5_als_step_at_full_size(config2):
 def test_input_side_at_size_matrix_market_to_25d_dense(tmp_path):
     """The input side (row f3) at the size of a real graph file: an R-MAT graph on 2^20 vertices, edge factor 8, written by the
     library's writer as a SYMMETRIC MatrixMarket file (one triangle stored) in which every third entry appears twice and every seventh
-    three times (1.2e7 lines, about 170 MB), then
+    three times (1.2e7 lines, 218 MB), then
       (a) read by 8 logical ranks through SpmatLocal::loadTuples(readFromFile) — the parallel mmap parser, both triangles, duplicates
           merged by the device `maximum` pass (SpmatLocal.hpp:485-498) — into 2.5D dense-replicate p = 8, c = 2 at R = 256
           (bench_file.cpp:23-103 with config 4's schedule): the tuple count equals the generator's, one fusedSpMM from keyed operands
@@ -301,7 +301,7 @@ def test_input_side_at_size_matrix_market_to_25d_dense(tmp_path):
         off = i != j
         rows, cols = np.concatenate([i, j[off]]), np.concatenate([j, i[off]])  # what a reader must deliver
         nnz = len(rows)
-        assert len(dup) > 1.1e7 and size_mb > 150.0 and nnz > 1.9e7, (len(dup), size_mb, nnz)
+        assert len(dup) > 1.1e7 and size_mb > 150.0 and nnz > 1.5e7, (len(dup), size_mb, nnz)
         from benchlib.common import keyed
         a_key, b_key, u_key, v_key = keyed(np.arange(m), 1), keyed(np.arange(m), 2), keyed(np.arange(r), 3), keyed(np.arange(r), 4)
         want_row = float(np.dot(u_key, v_key)) * a_key * np.bincount(rows, weights=b_key[cols] ** 2, minlength=m)
