@@ -276,7 +276,7 @@ def run(args, make_world=None):
         emit(out)
         fallback.printed = True
 
-    dog.phase("teardown")
+    dog.phase("teardown", max(args.watchdog, 600.0))  # (the other ranks wait here while rank 0 runs the CPU baseline's sample leg)
     try:
         b.free_current()
     except Exception:  # noqa: BLE001

@@ -411,7 +411,7 @@ def secondary(args, b):
                          "host_and_wait_ms": wall - kms},
                 "all_ranks_on_this_gpu_ms": together}
 
-    c4 = (8, 8, 32) if small else (18, 32, 256)
+    c4 = (8, 8, 32) if small else (20, 44, 256)  # (the R-MAT of entry (i): 4.3e7 nonzeros, longest row 8e4 — a rank's kernels take milliseconds)
     entry("rank share, config 4: one rank of 8 (2.5D dense-replicate 2 x 2 x 2: R/2 columns, transposed blocks, accumulator in two halves), "
           "R-MAT 2^%d, edge factor %d, R=%d" % c4, lambda: share_of("25d_dense_replicate", 8, 2, c4[0], c4[1], c4[2], "rmat", True))
     c5 = (9, 8, 16) if small else (args.logm, args.edge_factor, args.r)

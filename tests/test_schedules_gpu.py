@@ -341,6 +341,30 @@ def test_column_chunks_hip(monkeypatch, chunks):
             T.check_against_golden(T.assemble(per_rank, case), per_rank, case, "15d_fusion2")
 
 
+@pytest.mark.parametrize("merge,cap", [("0", None), (None, None), (None, "2")])
+def test_window_groupings_of_the_mesh_fetch_hip(monkeypatch, merge, cap):
+    """Adaptive chunk windows (Sparse15D_Dense_Shift::walk_merged) on the HIP library, where arrival events really complete late: one
+    pass per chunk (HNH_WINDOW_MERGE=0), the default (a pass takes every chunk that has landed when the host decides it) and at most two
+    chunks per pass — the reference's golden vectors whatever the grouping, every operation, ALS and the fused pass with its extras."""
+    for k, v in (("HNH_WINDOW_MERGE", merge), ("HNH_WINDOW_MERGE_CAP", cap)):
+        if v is None:
+            monkeypatch.delenv(k, raising=False)
+        else:
+            monkeypatch.setenv(k, v)
+    monkeypatch.setenv("HNH_RING_MODE", "mesh")
+    monkeypatch.delenv("HNH_MESH_CHUNKS", raising=False)
+    for name in ("er8_r16", "ragged_r8"):
+        case = T.case_inputs(name)
+        for p, c in [(2, 1), (4, 1), (8, 1), (8, 2)]:
+            per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, "15d_fusion2", c, case))
+            T.check_against_golden(T.assemble(per_rank, case), per_rank, case, "15d_fusion2")
+    case = T.case_inputs("er8_r16")
+    T.check_als_against_golden(H.run_spmd(4, lambda w: T.run_als(w, "15d_fusion2", 1, case, 1, 5)), case)
+    for matmode in (H.AMAT, H.BMAT):
+        per_rank = H.run_spmd(4, lambda w: T.run_fused_out(w, "15d_fusion2", 1, case, matmode, 0.3, 0.7, True))
+        T.check_fused_out(per_rank, case, matmode, 0.3, 0.7, True)
+
+
 @pytest.mark.parametrize("alg", ["15d_fusion2", "15d_fusion1"])
 def test_fingerprints_at_scale_against_the_compiled_reference(alg):
     """The HIP path against the REFERENCE ITSELF (oracle/_ref/ref_driver = its unmodified sources + MKL) at 8.4e6 nonzeros,
