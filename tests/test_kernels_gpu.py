@@ -769,3 +769,35 @@ def test_stream_delay_and_paced_copy(ctx):
         assert np.array_equal(d_dst.get(), np.tile(src, 5))
     assert lib.hnh_stream_paced_copy(ctx.h, 1, d_dst.ptr, d_src.ptr, 24, 5, 0.0, 1) != 0  # slices must be multiples of 16 bytes
     d_src.free(); d_dst.free()
+
+
+@pytest.mark.parametrize("mode", [1, 0])  # HNH_IPC_PULL_KERNEL, HNH_IPC_PULL_ENGINE
+def test_ipc_pull_copies_every_alignment_class(ctx, mode):
+    """hnh_ipc_pull is a public entry point used for every exchange of the ipc-pull transport, byte-displaced slices included
+    (device_alltoallv, staged host exchanges): sources and destinations that are 16-, 8-, 4-byte aligned or not aligned at all, sizes
+    that are not multiples of the element the copy uses, several copies per launch — every byte arrives and no byte beside the
+    destination changes.  (In-process pointers: what crosses a process boundary is only where `src` came from.)"""
+    import ctypes as C
+    lib = ctx.lib
+    rng = np.random.default_rng(7)
+    n_buf = 1 << 16
+    src_host = rng.integers(0, 256, n_buf, dtype=np.uint8)
+    d_src, d_dst = ctx.upload(src_host), ctx.upload(np.full(n_buf, 0xEE, np.uint8))
+    cases = [(0, 0, 4096), (16, 32, 4000), (8, 24, 1000), (8, 8, 1003), (4, 12, 996), (4, 4, 999), (1, 3, 777), (3, 1, 5), (7, 2, 1), (0, 5, 2049)]
+    dst_ptrs, src_ptrs, sizes, placed = [], [], [], []
+    at_s, at_d = 0, 0
+    for so, do, nb in cases:
+        s0 = (at_s + 255) // 256 * 256 + so
+        d0 = (at_d + 255) // 256 * 256 + do
+        src_ptrs.append(d_src.ptr + s0); dst_ptrs.append(d_dst.ptr + d0); sizes.append(nb); placed.append((s0, d0, nb))
+        at_s, at_d = s0 + nb + 64, d0 + nb + 64
+    n = len(cases)
+    a_dst = (C.c_void_p * n)(*dst_ptrs); a_src = (C.c_void_p * n)(*src_ptrs); a_sz = (C.c_size_t * n)(*sizes)
+    ctx.check(lib.hnh_ipc_pull(ctx.h, 0, n, a_dst, a_src, a_sz, mode, 4), "hnh_ipc_pull")
+    ctx.sync()
+    got = d_dst.get()
+    want = np.full(n_buf, 0xEE, np.uint8)
+    for s0, d0, nb in placed:
+        want[d0:d0 + nb] = src_host[s0:s0 + nb]
+    assert np.array_equal(got, want), [(s0, d0, nb) for s0, d0, nb in placed if not np.array_equal(got[d0:d0 + nb], src_host[s0:s0 + nb])]
+    d_src.free(); d_dst.free()
