@@ -128,26 +128,24 @@ public:
 
         // Replicate the dense operand that the sparse block's columns index: p/c slab-wise all-gathers over
         // the layer communicator (15D_sparse_shift.hpp:203-214).
-        if (initial_replicate) {
+        if (initial_replicate && c > 1) {  // (c == 1: nothing is replicated, and no counter events are spent on an empty phase — small calls are host bound)
             auto t = phase_begin("Replication Time");
-            if (c > 1) {
-                if (accumulation_buffer.rows() != Brole->rows() * c || accumulation_buffer.cols() != cols)
-                    accumulation_buffer = DenseMatrix(Brole->rows() * c, cols);
-                const size_t slab = (size_t)brBwidth * cols;
-                for (int i = 0; i < n; i++)
-                    world->allgather(grid->row_world, Brole->data() + slab * i, accumulation_buffer.data() + slab * c * i,
-                                     slab * sizeof(double), HNH_STREAM_COMPUTE);
-            }
+            if (accumulation_buffer.rows() != Brole->rows() * c || accumulation_buffer.cols() != cols)
+                accumulation_buffer = DenseMatrix(Brole->rows() * c, cols);
+            const size_t slab = (size_t)brBwidth * cols;
+            for (int i = 0; i < n; i++)
+                world->allgather(grid->row_world, Brole->data() + slab * i, accumulation_buffer.data() + slab * c * i,
+                                 slab * sizeof(double), HNH_STREAM_COMPUTE);
             phase_end(t);
         }
 
         // SDDMM: the travelling block accumulates partial dot products (R is split over the ring); its FIRST visit — step 0, at home —
         // may store instead of add when the kernel honours CSRLocal::values_fresh, and then nobody has to zero the values first
         const bool fresh = is_sddmm && kernel->overwrites_fresh_values();
-        {
+        if (!(is_sddmm && fresh)) {  // (a storing first visit needs no preparation at all)
             auto t = phase_begin("Computation Time");
-            if (is_sddmm && !fresh) choice->setValuesConstant(0.0);
-            else if (!is_sddmm) {
+            if (is_sddmm) choice->setValuesConstant(0.0);
+            else {
                 choice->setCSRValues(SValues);
                 Arole->setZero();  // every slab is produced exactly once below (`tmp *= 0.0` in the reference)
             }

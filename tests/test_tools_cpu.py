@@ -141,3 +141,43 @@ def test_cpp_verify_across_processes_over_ipc(tmp_path):
             assert all(p.returncode == 0 for p in procs), "\n".join(o[-1000:] for o in outs)
             got = np.array([float(ln.split(":")[1]) for ln in outs[0].splitlines() if "Fingerprint:" in ln])
             assert got.shape == (3,) and np.max(np.abs(got - want) / want) <= 1e-11, (alg, n, c, got, want)
+
+
+def test_matrix_market_writer_parser_and_the_benchmarks_own_reader_agree(tmp_path):
+    """hnh_write_matrix_market (formatted by all host cores) -> the library's parallel parser + duplicate merge (8 logical ranks on the
+    test double) -> the tuple count of the generator; and benchlib's host-side reader (pandas' C parser, no code shared with the
+    library's) finds the same coordinates — general and symmetric files, duplicates, values with 17 digits.  The GPU twin at the size of
+    a real graph file is tests/test_fullsize_gpu.py::test_input_side_at_size_matrix_market_to_25d_dense."""
+    import numpy as np
+    from benchlib.common import read_mtx_coordinates
+    H = T.H
+    H.load_backend(T.ORACLE_BACKEND)
+    m = 1 << 11
+    gr, gc = H.generate_rmat(11, m * 6)
+    # general file: the generator's coordinates, every fifth twice
+    rows, cols = np.concatenate([gr, gr[::5]]), np.concatenate([gc, gc[::5]])
+    vals = np.random.default_rng(1).uniform(-1, 1, len(rows))
+    general = str(tmp_path / "general.mtx")
+    H.write_matrix_market(general, m, m, rows, cols, vals, symmetric=False)
+    text = open(general).read().splitlines()
+    assert text[0] == "%%MatrixMarket matrix coordinate real general" and text[2].split() == [str(m), str(m), str(len(rows))]
+    assert len(text) == 3 + len(rows) and float(text[3].split()[2]) == vals[0]  # (%.17g round-trips a double)
+    hr, hc = read_mtx_coordinates(general)
+    key = np.unique(gr * m + gc)
+    assert np.array_equal(hr * m + hc, key)
+    # symmetric file: one triangle stored, duplicates, pattern values
+    lo = np.unique(np.maximum(gr, gc) * m + np.minimum(gr, gc))
+    dup = np.concatenate([lo, lo[::3]])
+    sym = str(tmp_path / "sym.mtx")
+    H.write_matrix_market(sym, m, m, dup // m, dup % m, None, symmetric=True)
+    i, j = lo // m, lo % m
+    want = np.unique(np.concatenate([i * m + j, j * m + i]))
+    hr, hc = read_mtx_coordinates(sym)
+    assert np.array_equal(hr * m + hc, want)
+    for path, count in ((general, len(key)), (sym, len(want))):
+        def body(w, path=path):
+            sp = H.SpmatLocal.load_tuples(w, True, 0, 0, path)
+            info = sp.info()
+            sp.free()
+            return info["dist_nnz"], info["M"], info["N"]
+        assert set(H.run_spmd(8, body)) == {(count, m, m)}
