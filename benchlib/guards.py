@@ -53,8 +53,9 @@ class Fallback:
     route), marked, or nothing.  A hang inside a transport call cannot be undone from Python, but it need not cost the number
     that is already in hand."""
 
-    def __init__(self, rank, phases=None):
-        self.rank, self.best, self.printed, self.phases = rank, None, False, phases
+    def __init__(self, rank, phases=None, no_line=None):
+        # no_line(why): what to print when the run is ended before ANY complete measurement exists (an error line: stdout still carries one JSON line)
+        self.rank, self.best, self.printed, self.phases, self.no_line = rank, None, False, phases, no_line
 
     def keep(self, line):
         self.best = line
@@ -88,6 +89,11 @@ class Fallback:
             signal.sigwait({signal.SIGTERM, signal.SIGINT})
             ok = self.emit_best("the run was ended from outside (SIGTERM / SIGINT: the launcher's or the driver's time limit, or another "
                                 "rank that failed or hung) before it was over")
+            if not ok and not self.printed and self.no_line is not None and "HNH_BENCH_STATUS_DIR" not in os.environ:
+                try:  # (a worker of bench.py's own launcher leaves the error line to the launcher, which names the phase of every rank)
+                    self.no_line("the run was ended from outside (SIGTERM / SIGINT) before its first complete measurement")
+                except Exception:  # noqa: BLE001
+                    pass
             os._exit(0 if ok else 143)
 
         threading.Thread(target=wait, daemon=True).start()

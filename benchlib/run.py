@@ -44,7 +44,7 @@ def run(args, make_world=None):
     n = args.gpus
     phases = guards.Phases()
     budget = guards.Budget(args.budget_s)
-    fallback = guards.Fallback(rank, phases)
+    fallback = guards.Fallback(rank, phases, (lambda why: emit(error_line(args, why, failed_rank=None, phases_s=phases.snapshot()))) if rank == 0 else None)
     # SIGTERM / SIGINT are blocked HERE, before torch, OpenMP or HIP start a thread: every thread of the process inherits the mask,
     # so the signal stays pending for the sigwait() thread, which prints the line in hand — whenever it arrives after the first
     # complete measurement — instead of landing on some library thread with the default action

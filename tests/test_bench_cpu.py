@@ -483,3 +483,20 @@ def test_secondary_workloads_are_listed_with_their_checks():
     assert next(v for k, v in by_name.items() if "config 4" in k)["check"]["ok"]
     knl = next(v for k, v in by_name.items() if "printed weak-scaling point" in k)  # (the comparison itself is only made at the printed size)
     assert knl["check"]["ok"] and knl["seconds_for_5_fusedmm"] > 0 and knl["schedule"].startswith("15d_sparse") and "reference_printed" not in knl
+
+
+def test_a_signal_before_the_first_measurement_still_leaves_one_json_line():
+    """SIGTERM while rank 0 holds no complete measurement yet (a driver that ends the run during set-up): the sigwait() thread prints
+    the contract's error line instead of dying silently; exit code 143."""
+    import signal
+    code = ("import sys, time\nsys.path.insert(0, %r)\nfrom benchlib import guards, common\ncommon.claim_stdout()\n"
+            "fb = guards.Fallback(0, guards.Phases(), lambda why: common.emit({'metric': 'fused SDDMM+SpMM nnz*R/s', 'value': None, 'error': why}))\n"
+            "fb.watch_sigterm()\nprint('armed', file=sys.stderr, flush=True)\ntime.sleep(120)\n" % ROOT)
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.stderr.readline().strip() == "armed"
+    p.send_signal(signal.SIGTERM)
+    out, _ = p.communicate(timeout=60)
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert p.returncode == 143 and len(lines) == 1, (p.returncode, out)
+    rec = json.loads(lines[0])
+    assert rec["value"] is None and "before its first complete measurement" in rec["error"]
