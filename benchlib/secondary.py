@@ -130,6 +130,15 @@ def secondary(args, b):
                     # (profiles/r05_als_step_kernel_stats.csv: the launch that carries them takes 8.51 ms against 7.39 ms without)
                     by_cg = by + 20 * 5 * 8 * args.r * sub.m
                     res.update({"algorithmic_bytes_with_cg_row_streams": by_cg, "frac_with_cg_row_streams": frac_of(by_cg, ms)})
+                else:
+                    # what the fused-call model leaves out: the 14 dense products X * W_h — their compulsory bytes (X read, the product written;
+                    # W is small) and their fp64 matrix-core work, which shares the chip with the attention passes
+                    gemm_bytes = sum(h * 8 * sub.m * (fin + f) for fin, f, h in GAT_LAYERS)
+                    gemm_flops = sum(h * 2 * sub.m * fin * f for fin, f, h in GAT_LAYERS)
+                    res.update({"algorithmic_bytes_with_gemm_operands": by + gemm_bytes, "frac_with_gemm_operands": frac_of(by + gemm_bytes, ms),
+                                "gemm_tflops_over_the_whole_pass": gemm_flops / (ms * 1e-3) / 1e12, "gemm_flops": gemm_flops,
+                                "note": "two roofline-bound kernels side by side: the attention passes alone take ~37 ms (HBM gathers), the products alone ~23 ms "
+                                        "(84 % of the fp64 matrix peak); what they share is the L2 request stream (DESIGN section 4)"})
                 return res
             finally:
                 sub.free_current()
