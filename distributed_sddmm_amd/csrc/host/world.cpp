@@ -912,7 +912,7 @@ IpcWorld::IpcWorld(int r, int nranks, Backend* backend, int device_ordinal, cons
         else if (std::string(m) != "engine") fatal("Error, HNH_IPC_PULL must be engine or kernel!");
     }
     if (const char* w = std::getenv("HNH_IPC_PULL_WGS")) pull_wgs_ = std::max(1, std::min(256, std::atoi(w)));
-    if (const char* w = std::getenv("HNH_IPC_MAX_OPENED")) kIpcMaxOpened = (size_t)std::max(1, std::atoi(w));
+    if (const char* w = std::getenv("HNH_IPC_MAX_OPENED")) max_opened_ = (size_t)std::max(1, std::atoi(w));
     init_device(backend, device_ordinal);
     shm_name_ = "/hnh_ipc_" + session;
     const auto t0 = std::chrono::steady_clock::now();
@@ -1067,7 +1067,7 @@ void* IpcWorld::open_peer(const unsigned char* handle, uint64_t alloc_bytes) {
 // Handles of blocks the peers have long freed pile up.  They are dropped — all of them, behind a drained device — only BETWEEN
 // groups: before a flush() that could take the table past its cap even if every one of its receives names a new allocation.
 void IpcWorld::make_room(size_t incoming) {
-    if (opened_.size() + incoming <= kIpcMaxOpened) return;
+    if (opened_.size() + incoming <= max_opened_) return;
     sync_all();  // nothing of the coming group is enqueued yet: this waits for earlier groups only
     for (auto& kv : opened_) check(be->hnh_ipc_close(ctx, kv.second), "hnh_ipc_close");
     opened_.clear();

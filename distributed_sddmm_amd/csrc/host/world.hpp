@@ -290,7 +290,7 @@ private:
     const Exported& export_of(const void* ptr, uint64_t* offset, Exported* scratch);
     void* open_peer(const unsigned char* handle, uint64_t alloc_bytes);
     void make_room(size_t incoming);
-    size_t kIpcMaxOpened = 512;  // HNH_IPC_MAX_OPENED (tests force evictions with a small table)
+    size_t max_opened_ = 512;  // HNH_IPC_MAX_OPENED (tests force evictions with a small table)
     template <typename Pred>
     void wait_host(Pred&& done, const char* what);
 };
