@@ -65,6 +65,9 @@ def secondary(args, b):
                 A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
                 S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
                 res = {"R": r}
+                if r == 8:
+                    res["note"] = ("a 64-byte dense row costs a whole 128-byte request between L2 and the fabric, and the row kernels are bound by the "
+                                   "number of such requests (about 55 G/s at every width, DESIGN section 3.2): the byte model cannot exceed ~0.55 here")
                 try:
                     ms, _ = kernel_time(op, lambda: op.fusedSpMM(A, B, S, buf, H.AMAT), 3)
                     res["fused"] = {"ms": ms, "algorithmic_bytes": fused_bytes(nnz, r, m), "frac": frac_of(fused_bytes(nnz, r, m), ms)}
@@ -225,8 +228,9 @@ def secondary(args, b):
         err = max(x[1] for x in res) / float(want_row.max() * v_key.max())
         by = len(rows) * (16 * r + 44) + 16 * r * m  # the unfused pair this schedule runs (SURVEY 8d B_unfused)
         return {"ms": ms, "nnz": int(len(rows)), "M": m, "R": r, "schedule": "25d_dense_replicate p=8 c=2 (2 x 2 x 2), 8 logical ranks on ONE GPU, loopback copies",
-                "algorithmic_bytes": by, "frac": frac_of(by, ms),
-                "note": "all 8 ranks' kernels AND their device-to-device copies share this one GPU: a correctness-at-shape and cost figure, not a scaling claim",
+                "algorithmic_bytes": by, "frac_all_ranks_on_this_one_gpu": frac_of(by, ms),
+                "note": "all 8 ranks' kernels AND their device-to-device copies share this one GPU: a correctness-at-shape and cost figure, not a scaling "
+                        "claim — one rank's efficiency with the GPU to itself is the 'rank share, config 4' entry below",
                 "check": {"rel_err": err, "ok": bool(err <= 1e-11)}}
     entry("config 4's shape, bounded: R-MAT 2^%d, edge factor %d, R=%d, 2.5D dense-replicate on 8 logical ranks" % ((8, 8, 32) if small else (18, 32, 256)), cfg4)
 
