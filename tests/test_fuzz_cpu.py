@@ -2,7 +2,7 @@
 random schedule, grid (powers of two and grids with remainders, up to 18 ranks), sizes (incl. M < p, non-square, 1-nonzero
 matrices), chunk counts and heights, adaptive window grouping, ring modes, accumulator halves, borrowed value arrays, shift payload
 and both set-up pipelines.  A fixed seed keeps the suite deterministic; `python tests/test_fuzz_cpu.py SEED COUNT` explores further (round 4:
-4 x 1500 draws, 4 153 valid configurations, no deviation)."""
+4 x 1500 draws, 4 153 valid configurations, no deviation; round 5, with the window-grouping switches: 3 x 300 draws, 645 valid, no deviation)."""
 import os
 import random
 import sys
