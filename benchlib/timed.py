@@ -201,7 +201,7 @@ def compose_line(args, b, res, extra):
                    # Q symmetric chunks (a number) or the chunk heights (a comma list)
                    "mesh_chunks": (q if ring_mode_now == "mesh" else None),
                    "rccl_channels": (os.environ.get("NCCL_MAX_NCHANNELS", "default") if n > 1 else None),
-                   # compute units masked off the compute stream (the library's own default unless HNH_COMM_CUS / --comm-cus say otherwise)
+                   # compute units masked off the compute stream (the library's default, 0, unless HNH_COMM_CUS says otherwise)
                    "comm_cus": int(os.environ.get("HNH_COMM_CUS", "0") or 0),
                    # set-up of the first route: the tuples (generated on the device, or parsed from the file and merged), then redistribution,
                    # CSR blocks and operands; parse_s is the first part alone

@@ -46,7 +46,7 @@ if __name__ == "__main__":
     args = argparse.Namespace(gpus=n, steps=2, warmup=1, logm=10, edge_factor=8, r=16, alg=sys.argv[1], c=int(sys.argv[2]) or None,
                               no_cpu_baseline=True, cpu_logm=10, cpu_trials=1, ring_mode=os.environ.get("BENCH_RING_MODE") or None,
                               chunks=None, no_cpu_full=True, no_check=False, no_preflight=False, no_tune=False, watchdog=120.0, no_live_traffic=True,
-                              nchannels=None, comm_cus=None, workload="er", app="vanilla", transport="auto", no_secondary=True, probe_timeout=60.0)
+                              nchannels=None, workload="er", app="vanilla", transport="auto", no_secondary=True, probe_timeout=60.0)
     out = bench.run(args, make_world=cpu_world)
     if out is not None:
         print("BENCH_JSON " + json.dumps(out), flush=True)
