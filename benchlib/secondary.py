@@ -438,6 +438,8 @@ def secondary(args, b):
     entry("rank share, 2.5D sparse-replicate (the one schedule the configurations do not name): one rank of 8 (2 x 2 x 2: S stationary and "
           "replicated, both dense operands move, R/4 columns per rank), SDDMM + SpMM pair, ER 2^%d, edge factor %d, R=%d" % c13,
           lambda: share_of("25d_sparse_replicate", 8, 2, c13[0], c13[1], c13[2], "er", True))
+    entry("rank share, 1.5D dense shift by replication reuse (15d_fusion1): one rank of 8, SDDMM + SpMM pair, the SpMM's accumulator travelling in two "
+          "row halves, ER 2^%d, edge factor %d, R=%d" % c13, lambda: share_of("15d_fusion1", 8, 1, c13[0], c13[1], c13[2], "er", True))
     c1 = (8, 8, 16) if small else (16, 16, 16)
     entry("config 1 as typed: ER 2^%d, edge factor %d, R=%d, 15d_sparse, 2 logical ranks (bench_erdos_renyi.cpp:19-120): one fusedSpMM, kernel "
           "time against call time" % c1, lambda: share_of("15d_sparse", 2, 1, c1[0], c1[1], c1[2], "er", True))

@@ -462,7 +462,7 @@ def test_secondary_workloads_are_listed_with_their_checks():
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
     sec = out["secondary"]
-    assert len(sec) == 17 and not [e for e in sec if "error" in e], [e.get("error") for e in sec]
+    assert len(sec) == 18 and not [e for e in sec if "error" in e], [e.get("error") for e in sec]
     by_name = {e["workload"]: e for e in sec}
     # one rank's share of configs 3 / 4 / 5 and config 1 as typed: rank 0 of p logical ranks alone (held blocks / solo replay)
     shares = [v for k, v in by_name.items() if k.startswith("rank share, config 3")]
@@ -472,7 +472,7 @@ def test_secondary_workloads_are_listed_with_their_checks():
         # own block + one pass per chunk window (a single pass over the fetched blocks when there is one chunk)
         # one pass per chunk: own block + one launch per chunk window; everything landed: own block + ONE pass over the fetched blocks
         assert e["held"]["launches"] == (2 if e["chunks"] == "1" else 7) and e["held_all_landed"]["launches"] == 2 and e["solo"]["launches"] >= 2, e
-    for key in ("rank share, config 4", "rank share, config 5", "rank share, 2.5D sparse-replicate", "config 1 as typed"):
+    for key in ("rank share, config 4", "rank share, config 5", "rank share, 2.5D sparse-replicate", "rank share, 1.5D dense shift by replication reuse", "config 1 as typed"):
         e = next(v for k, v in by_name.items() if k.startswith(key))
         assert e["solo"]["wall_ms"] > 0 and e["solo"]["launches"] > 0 and e["all_ranks_on_this_gpu_ms"] > 0 and e["algorithmic_bytes_rank"] > 0, e
     for r in (8, 16, 128, 256):

@@ -1,4 +1,4 @@
-# round 5, GPU job 15: the bench line with the 2.5D sparse-replicate rank share
+# round 5, GPU job 15: the bench line with the 2.5D sparse-replicate and 15d_fusion1 rank shares
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/r05_job15
 mkdir -p "$OUT"
