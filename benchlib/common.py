@@ -43,8 +43,21 @@ def unblock_signals():
 DEFAULT_CHUNKS = "1,2,2,2,1,1"  # the library's default shape of the mesh fetch (dense_shift_15d.hpp)
 
 
+_merge_switched_off_here = False
+STATIC_WINDOWS = "/one-pass-per-chunk"  # suffix of a chunk spec: HNH_WINDOW_MERGE=0 (the route search measures it against the adaptive windows)
+
+
 def set_chunk_spec(spec):
-    """A chunk spec is a number (Q symmetric chunks, HNH_MESH_CHUNKS) or a comma list of heights (HNH_MESH_TAPER)."""
+    """A chunk spec is a number (Q symmetric chunks, HNH_MESH_CHUNKS) or a comma list of heights (HNH_MESH_TAPER); with the suffix
+    STATIC_WINDOWS the windowed passes take exactly one chunk each (HNH_WINDOW_MERGE=0) instead of every chunk that has landed."""
+    global _merge_switched_off_here
+    if spec.endswith(STATIC_WINDOWS):
+        spec = spec[:-len(STATIC_WINDOWS)]
+        os.environ["HNH_WINDOW_MERGE"] = "0"
+        _merge_switched_off_here = True
+    elif _merge_switched_off_here:  # (a HNH_WINDOW_MERGE the USER set is never undone)
+        os.environ.pop("HNH_WINDOW_MERGE", None)
+        _merge_switched_off_here = False
     if "," in spec:
         os.environ["HNH_MESH_TAPER"] = spec
         os.environ.pop("HNH_MESH_CHUNKS", None)

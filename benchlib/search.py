@@ -7,9 +7,10 @@ bandwidth actually delivered.  Unless flags fix them, the candidates are MEASURE
 ranks): first the default route on every transport, then replication factors and chunk shapes on the fastest one.  A candidate that
 fails is recorded as null with its reason and the search goes on without its transport; a candidate is only started while the
 run's time budget (--budget-s) has room for the slowest candidate seen so far."""
+import os
 import time
 
-from .common import DEFAULT_CHUNKS, route_name
+from .common import DEFAULT_CHUNKS, STATIC_WINDOWS, route_name
 
 
 def quick_time(b, calls=5):
@@ -63,6 +64,10 @@ def candidates(args, n, tr, fixed_mode, default_q):
             qs = [str(args.chunks)] if args.chunks else sorted(
                 {default_q, DEFAULT_CHUNKS, "2", "4"} | ({"3", "8", "3,4,4,3,2,1,1"} if c == 1 else set()), key=lambda q: (q != default_q, len(q), q))
             cand += [(tr, c, "mesh", q) for q in qs]
+            if c == 1 and not args.chunks and os.environ.get("HNH_WINDOW_MERGE") != "0":
+                # the default shape with one pass per chunk whatever has landed: adaptive windows (the default) against rounds 2-4's behaviour,
+                # measured on the node's own links
+                cand.append((tr, c, "mesh", default_q + STATIC_WINDOWS))
         if fixed_mode != "mesh":
             cand.append((tr, c, "relay", None))
         if fixed_mode is None and args.app == "vanilla":

@@ -55,6 +55,8 @@ def test_bench_contract(nranks, alg, c, ring):
             if ring != "relay":
                 want |= {"c=%d mesh/%d chunks" % (k, q) for q in ((2, 3, 4, 8) if k == 1 else (2, 4))}
                 want |= {"c=%d mesh/heights %s" % (k, h) for h in (("1,2,2,2,1,1", "3,4,4,3,2,1,1") if k == 1 else ("1,2,2,2,1,1",))}
+                if k == 1:  # the default shape with one windowed pass per chunk (HNH_WINDOW_MERGE=0) against the adaptive windows
+                    want.add("c=1 mesh/heights 1,2,2,2,1,1/one-pass-per-chunk")
             if ring != "mesh":
                 want.add("c=%d relay ring" % k)
             if ring is None:  # the schedule's other fusion strategy joins the search when nothing fixes the route
@@ -76,7 +78,7 @@ def test_bench_contract(nranks, alg, c, ring):
                     return out["config"]["algorithm"] == "15d_fusion1" and out["config"]["ring_mode"].startswith("accumulator ring")
                 return (out["config"]["algorithm"] == "15d_fusion2" and
                         out["config"]["ring_mode"] == {"relay ring": "relay", "replication only": None}.get(broute, "mesh") and
-                        out["config"]["mesh_chunks"] == (broute.split("/")[1].split()[-1 if "heights" in broute else 0] if broute.startswith("mesh") else None))
+                        out["config"]["mesh_chunks"] == (broute.split("/", 1)[1].split(" ", 1)[-1 if "heights" in broute else 0] if broute.startswith("mesh") else None))
 
             c0 = c or 1
             default = ("c=%d replication only" % c0) if nranks // c0 == 1 else (("c=%d relay ring" % c0) if ring == "relay" else "c=%d mesh/heights 1,2,2,2,1,1" % c0)
