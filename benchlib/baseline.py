@@ -55,15 +55,17 @@ def cpu_baseline_for_line(args, n, budget):
             return {"value": None, "unit": "nnz*R/s", "cores": os.cpu_count(), "kind": "reference",
                     "sample": "NOT RUN: no record of an N = 1 run on this host and %.0f s left of --budget-s" % budget.left()}
         import argparse
-        return cpu_baseline(argparse.Namespace(**dict(vars(args), no_cpu_full=True)), quick=True)
+        return cpu_baseline(argparse.Namespace(**dict(vars(args), cpu_full=False)), quick=True)
     except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
         return {"value": None, "unit": "nnz*R/s", "cores": os.cpu_count(), "kind": "reference", "sample": "FAILED: %s" % str(e)[:300]}
 
 
 def cpu_baseline(args, quick=False):
-    """The reference timed on the host cores: a thread sweep on a bounded sample (ER 2^cpu_logm, same edge factor and R), then
-    the best thread count ONCE at the GPU line's own size (1 warm-up + cpu_trials timed calls, benchmark_dist.cpp:117-149);
-    `value` is the full-size figure when that leg ran."""
+    """The reference timed on the host cores, bounded (about 30-40 s): ONE run of the compiled reference on a sample of the GPU line's
+    workload (ER 2^cpu_logm, same edge factor and R; one MPI rank), which behind one set-up times the loop of benchmark_dist.cpp:117-149
+    (1 warm-up + cpu_trials fused calls) at a few OpenMP/MKL thread counts, two batches per count, the better batch counted; `value` is
+    the best point, `cores` the threads it used.  --cpu-full adds the winner once at the GPU line's own size (about a minute more, nearly
+    all of it the reference's set-up) and reports that as `value` instead."""
     import numpy as np
     from distributed_sddmm_amd import api as H
     from oracle import refrun as RR
@@ -71,53 +73,33 @@ def cpu_baseline(args, quick=False):
     ncpu = os.cpu_count() or 1
     m = 1 << args.cpu_logm
     if RR.available():
+        t0 = time.perf_counter()
         rows, cols = H.generate_er(m, m, m * args.edge_factor, 12345)
-        # The reference does not scale with the thread count on big hosts (measured on 2 x EPYC 9575F: 32 threads
-        # beat 64/128/256, and 1 MPI rank beats 4..32, profiles/r01_cpu_baseline_sweep.log), so a few counts are
-        # tried on the sample and the best one is used; `cores` is the thread count of the reported run.
-        tried, best = [], None
-        # (MPI ranks, OpenMP/MKL threads per rank): the thread counts on one rank, then the same cores split over several ranks
-        # (the reference is an MPI + OpenMP code; on the driver box one rank beat 4 .. 32, but that is the box's call)
-        configs = [(1, t) for t in sorted({min(ncpu, 16), min(ncpu, 32), min(ncpu, 64)})]
-        configs += [(pr, max(1, min(ncpu, 64) // pr)) for pr in (4, 8) if ncpu >= 2 * pr]
-        if quick:  # (several GPUs without an N = 1 record: the one configuration that won on every box so far)
-            configs = [(1, min(ncpu, 32))]
-        for ranks, threads in configs:
-            try:
-                res = RR.bench(m, m, rows, cols, args.r, "15d_fusion2", ranks, 1, True, args.cpu_trials, threads=threads, timeout=300.0)
-            except Exception as e:  # one configuration failing (e.g. no MPI launcher for several ranks) does not lose the others
-                tried.append((ranks, threads, None, str(e)[:80]))
-                continue
-            tried.append((ranks, threads, res["nnz_R_per_s"], None))
-            if best is None or res["nnz_R_per_s"] > best[2]["nnz_R_per_s"]:
-                best = (ranks, threads, res)
-        if best is None:
-            raise RuntimeError("the compiled reference ran in none of the configurations: %r" % (tried,))
-        ranks, threads, res = best
-        comp = res["perf_stats"].get("Computation Time", 0.0)
-        sweep = "ER 2^%d, edge factor %d (%d nnz), ranks x threads -> nnz*R/s: %s (host has %d hardware threads)" % (
-            args.cpu_logm, args.edge_factor, len(rows),
-            ", ".join("%dx%d: %s" % (pr, t, ("%.2e" % v) if v is not None else "failed") for pr, t, v, _ in tried), ncpu)
-        out = {"value": res["nnz_R_per_s"], "unit": "nnz*R/s", "cores": ranks * threads, "kind": "reference",
-               "sample": "ER 2^%d, edge factor %d (%d nnz), R=%d, 15d_fusion2 fused, %d timed fusedSpMM calls after 1 warm-up, "
-                         "%d MPI rank(s) x %d OpenMP/MKL threads (best of the sweep)" % (args.cpu_logm, args.edge_factor, len(rows), args.r,
-                                                                                       args.cpu_trials, ranks, threads),
-               "thread_sweep": sweep, "ranks": ranks, "threads_per_rank": threads, "elapsed_s": res["elapsed"],
+        # The reference does not scale with the thread count on big hosts (2 x EPYC 9575F: 32 threads beat 64/128/256 and one MPI rank
+        # beats 4 .. 32 on every box so far, profiles/r01_cpu_baseline_sweep.log, BENCH_r04/r05), so a few counts are tried
+        counts = sorted({min(ncpu, 16), min(ncpu, 32), min(ncpu, 64)}) if not quick else [min(ncpu, 32)]
+        res = RR.sweep(m, m, rows, cols, args.r, "15d_fusion2", 1, 1, True, args.cpu_trials, 2, counts, timeout=300.0)
+        best = max(res["points"], key=lambda pt: pt["nnz_R_per_s"])
+        threads, comp = best["threads"], best.get("computation_time", 0.0)
+        out = {"value": best["nnz_R_per_s"], "unit": "nnz*R/s", "cores": threads, "kind": "reference",
+               "sample": "ER 2^%d ef %d (%.3g nnz) R=%d fused, 1 rank x %d thr, best of 2 x %d calls; leg %.0f s" % (
+                   args.cpu_logm, args.edge_factor, len(rows), args.r, threads, args.cpu_trials, time.perf_counter() - t0),
+               "threads_used": threads, "host_hw_threads": ncpu, "ranks": 1, "elapsed_s": best["elapsed"],
+               "thread_sweep": {str(pt["threads"]): float("%.4g" % pt["nnz_R_per_s"]) for pt in res["points"]},
+               "batches_s": {str(pt["threads"]): [round(x, 3) for x in pt["batches"]] for pt in res["points"]},
                "kernel_only_value": (len(rows) * args.r * args.cpu_trials / comp) if comp > 0 else None}
-        if not args.no_cpu_full and args.logm != args.cpu_logm:
+        if getattr(args, "cpu_full", False) and args.logm != args.cpu_logm:
             try:
-                t0 = time.perf_counter()
+                t1 = time.perf_counter()
                 mf = 1 << args.logm
                 rows, cols = H.generate_er(mf, mf, mf * args.edge_factor, 12345)
-                full = RR.bench(mf, mf, rows, cols, args.r, "15d_fusion2", ranks, 1, True, args.cpu_trials, threads=threads, timeout=900.0)
+                full = RR.bench(mf, mf, rows, cols, args.r, "15d_fusion2", 1, 1, True, args.cpu_trials, threads=threads, timeout=900.0)
                 compf = full["perf_stats"].get("Computation Time", 0.0)
                 out.update({"sample_value": out["value"], "sample_workload": out["sample"],
                             "value": full["nnz_R_per_s"], "elapsed_s": full["elapsed"],
                             "kernel_only_value": (len(rows) * args.r * args.cpu_trials / compf) if compf > 0 else None,
-                            "sample": "the GPU line's own workload: ER 2^%d, edge factor %d (%d nnz), R=%d, 15d_fusion2 fused, %d timed "
-                                      "fusedSpMM calls after 1 warm-up, %d MPI rank(s) x %d OpenMP/MKL threads (chosen by the sweep); "
-                                      "whole leg incl. the reference's set-up %.0f s" % (args.logm, args.edge_factor, len(rows), args.r,
-                                                                                       args.cpu_trials, ranks, threads, time.perf_counter() - t0)})
+                            "sample": "the GPU line's size: ER 2^%d ef %d (%.3g nnz) R=%d fused, 1 rank x %d thr, %d calls; leg %.0f s" % (
+                                args.logm, args.edge_factor, len(rows), args.r, threads, args.cpu_trials, time.perf_counter() - t1)})
             except Exception as e:  # keep the sample figure
                 out["full_size_error"] = str(e)[:300]
         return out

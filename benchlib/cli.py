@@ -28,9 +28,11 @@ def parse(argv=None):
     ap.add_argument("--chunks", default=None, help="chunks of the pipelined mesh fetch: a number Q = symmetric chunks of heights "
                     "(1, 2, .., 2, 1) (HNH_MESH_CHUNKS), or a comma list of heights, e.g. 1,2,2,2,1,1 (HNH_MESH_TAPER)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-logm", type=int, default=18, help="size of the CPU baseline's thread-sweep sample")
+    ap.add_argument("--cpu-logm", type=int, default=18, help="the CPU baseline's sample: ER 2^cpu_logm at the line's edge factor and R")
     ap.add_argument("--cpu-trials", type=int, default=2)
-    ap.add_argument("--no-cpu-full", action="store_true", help="skip the CPU baseline's run at the GPU line's full size")
+    ap.add_argument("--cpu-full", action="store_true", help="CPU baseline: also run the sweep's winner once at the GPU line's full size and report "
+                    "that as cpu_baseline.value (about a minute more, nearly all of it the reference's set-up)")
+    ap.add_argument("--no-cpu-full", action="store_true", help=argparse.SUPPRESS)  # (the default since round 6; kept for old command lines)
     ap.add_argument("--no-check", action="store_true", help="skip the closed-form result check (outside the timed region)")
     ap.add_argument("--no-preflight", action="store_true", help="skip the transport self-tests of a multi-GPU run")
     ap.add_argument("--no-tune", action="store_true", help="several GPUs: keep the default route (first usable transport, mesh fetch, default "

@@ -25,12 +25,21 @@ def claim_stdout():
 
 
 def emit(obj):
-    line = (obj if isinstance(obj, str) else json.dumps(obj)) + "\n"
+    """Print THE line: a dict goes out compacted to at most line.LINE_LIMIT bytes (benchlib/line.py), its full form into the record file
+    beside it; the write is repeated until every byte is out (a pipe may take a long line in pieces)."""
+    from . import line as L
+    data, _ = L.render(obj)
     if _JSON_FD is None:
-        sys.stdout.write(line)
         sys.stdout.flush()
+        fd = sys.stdout.fileno()
     else:
-        os.write(_JSON_FD, line.encode())
+        fd = _JSON_FD
+    view = memoryview(data)
+    while len(view):
+        try:
+            view = view[os.write(fd, view):]
+        except InterruptedError:
+            continue
 
 
 def unblock_signals():

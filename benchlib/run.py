@@ -233,10 +233,11 @@ def run(args, make_world=None):
             live = baseline.live_traffic(args)
         if live is not None:
             traffic = live["bytes_per_launch"]
-            traffic_source = ("live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this command run by this process (%d launches "
-                              "sampled, %.0f s, outside the timed region); 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of the "
-                              "micro-architecture guide); raw KB: fetch %.0f, write %.0f" % (live["launches_sampled"], live["seconds"],
-                                                                                              live["fetch_size_kb_raw"], live["write_size_kb_raw"]))
+            # two rocprofv3 --pmc passes of this command run by this process, outside the timed region; 2 x FETCH_SIZE + WRITE_SIZE
+            # (the micro-architecture guide's gfx950 correction)
+            traffic_source = "live rocprofv3 --pmc passes: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)"
+            out["roofline"]["traffic_detail"] = {"launches_sampled": live["launches_sampled"], "seconds": live["seconds"],
+                                                 "fetch_size_kb_raw": live["fetch_size_kb_raw"], "write_size_kb_raw": live["write_size_kb_raw"]}
         else:
             tf = os.path.join(common.ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(tf):
@@ -245,8 +246,7 @@ def run(args, make_world=None):
                         rec = json.load(f)
                     if args.workload == "er" and args.app == "vanilla" and rec.get("workload_key") == "er%d_ef%d_r%d_n%d" % (args.logm, args.edge_factor, args.r, n):
                         traffic = rec.get("bytes_per_launch")
-                        traffic_source = ("profiles/hbm_traffic.json (static: rocprofv3 FETCH_SIZE/WRITE_SIZE passes of an earlier run of "
-                                          "this command, not collected live)")
+                        traffic_source = "profiles/hbm_traffic.json (static: counter passes of an earlier run, not live)"
                 except Exception:
                     traffic = None
         out["roofline"].update({"traffic": traffic, "traffic_source": traffic_source,

@@ -20,13 +20,14 @@ def secondary(args, b):
     out = []
     small = os.environ.get("HNH_BENCH_SECONDARY_SMALL") is not None  # (the CPU test of this function: same code, toy sizes)
 
-    def entry(name, fn):
+    def entry(ident, name, fn):
+        """`ident` = the entry's row in the printed line's table (benchlib/line.py); the entry itself goes to the record file"""
         t0 = time.perf_counter()
         try:
             e = fn()
         except Exception as ex:  # noqa: BLE001
             e = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
-        e = dict({"workload": name}, **e)
+        e = dict({"id": ident, "workload": name}, **e)
         e["seconds"] = round(time.perf_counter() - t0, 1)
         out.append(e)
 
@@ -99,7 +100,7 @@ def secondary(args, b):
                     for x in (A, B, S, buf):
                         x.free()
                 return res
-            entry("the headline matrix at R=%d: fused / SDDMM / SpMM kernels through the operator (ms = device time of the local kernels, "
+            entry("width_R%d" % r, "the headline matrix at R=%d: fused / SDDMM / SpMM kernels through the operator (ms = device time of the local kernels, "
                   "call_ms = the whole sddmmA / spmmA call)" % r, widths)
         b.op.setRValue(args.r)
 
@@ -149,8 +150,8 @@ def secondary(args, b):
                     sub.transports["single"]["sp"].free()
         return run_it
 
-    entry("one alternating ALS-CG step (run_cg(1), benchmark_dist.cpp:134-137) on the headline matrix, R=%d" % args.r, app_entry("als"))
-    entry("GAT forward pass (layers of benchmark_dist.cpp:88-94) on a bounded instance of the workload", app_entry("gat"))
+    entry("als_step", "one alternating ALS-CG step (run_cg(1), benchmark_dist.cpp:134-137) on the headline matrix, R=%d" % args.r, app_entry("als"))
+    entry("gat_forward", "GAT forward pass (layers of benchmark_dist.cpp:88-94) on a bounded instance of the workload", app_entry("gat"))
 
     # (i) R-MAT with hub rows, fused at the headline width
     def rmat():
@@ -170,7 +171,7 @@ def secondary(args, b):
             sub.free_current()
             if sub.transports["single"]["sp"] is not None:
                 sub.transports["single"]["sp"].free()
-    entry("R-MAT 2^%d, edge factor %d (hub rows: long-row pass with ordered reduction), fused R=%d" % ((9, 8, args.r) if small else (20, 44, args.r)), rmat)
+    entry("rmat_fused", "R-MAT 2^%d, edge factor %d (hub rows: long-row pass with ordered reduction), fused R=%d" % ((9, 8, args.r) if small else (20, 44, args.r)), rmat)
 
     # (ii) config 4's schedule and width on 8 logical ranks that share this GPU (loopback transport: device-to-device copies)
     def cfg4():
@@ -232,7 +233,7 @@ def secondary(args, b):
                 "note": "all 8 ranks' kernels AND their device-to-device copies share this one GPU: a correctness-at-shape and cost figure, not a scaling "
                         "claim — one rank's efficiency with the GPU to itself is the 'rank share, config 4' entry below",
                 "check": {"rel_err": err, "ok": bool(err <= 1e-11)}}
-    entry("config 4's shape, bounded: R-MAT 2^%d, edge factor %d, R=%d, 2.5D dense-replicate on 8 logical ranks" % ((8, 8, 32) if small else (18, 32, 256)), cfg4)
+    entry("cfg4_8ranks_one_gpu", "config 4's shape, bounded: R-MAT 2^%d, edge factor %d, R=%d, 2.5D dense-replicate on 8 logical ranks" % ((8, 8, 32) if small else (18, 32, 256)), cfg4)
 
     # (vi) the one throughput the reference's own tree prints for this path: the p = 1 point of its weak-scaling
     # experiment 1 — `15d_sparse`, fused, 5 FusedMM calls in 0.8375 s on one Cori KNL node (ipdps_chart_generator.ipynb:564), at the size
@@ -268,7 +269,7 @@ def secondary(args, b):
             sub.free_current()
             if sub.transports["single"]["sp"] is not None:
                 sub.transports["single"]["sp"].free()
-    entry("the reference's printed weak-scaling point at p = 1: ER 2^%d, %d nonzeros per row, R=%d, 15d_sparse fused, 5 FusedMM timed the reference's way"
+    entry("knl_point", "the reference's printed weak-scaling point at p = 1: ER 2^%d, %d nonzeros per row, R=%d, 15d_sparse fused, 5 FusedMM timed the reference's way"
           % ((8, 8, 32) if small else (16, 32, 256)), knl_point)
 
     # ---- ONE RANK'S SHARE of the multi-GPU configurations (BASELINE configs 3, 4, 5) and config 1 as typed.  p logical ranks (host threads
@@ -367,7 +368,7 @@ def secondary(args, b):
                          "frac_wall": frac_of(by, solo[0])}}
 
     for p, spec in ((8, "1,2,2,2,1,1"), (8, "1"), (4, "1,2,2,2,1,1"), (2, "1,2,2,2,1,1")):
-        entry("rank share, config 3: one rank of %d (15d_fusion2, c = 1, mesh fetch, chunk heights %s) alone on this GPU, %s"
+        entry("rank_cfg3_p%d%s" % (p, "" if "," in spec else "_q" + spec), "rank share, config 3: one rank of %d (15d_fusion2, c = 1, mesh fetch, chunk heights %s) alone on this GPU, %s"
               % (p, spec, "toy size" if small else "ER 2^%d, edge factor %d, R=%d" % (args.logm, args.edge_factor, args.r)),
               lambda p=p, spec=spec: share_of_config3(p, spec))
 
@@ -428,19 +429,19 @@ def secondary(args, b):
                 "all_ranks_on_this_gpu_ms": together}
 
     c4 = (8, 8, 32) if small else (20, 44, 256)  # (the R-MAT of entry (i): 4.3e7 nonzeros, longest row 8e4 — a rank's kernels take milliseconds)
-    entry("rank share, config 4: one rank of 8 (2.5D dense-replicate 2 x 2 x 2: R/2 columns, transposed blocks, accumulator in two halves), "
+    entry("rank_cfg4", "rank share, config 4: one rank of 8 (2.5D dense-replicate 2 x 2 x 2: R/2 columns, transposed blocks, accumulator in two halves), "
           "R-MAT 2^%d, edge factor %d, R=%d" % c4, lambda: share_of("25d_dense_replicate", 8, 2, c4[0], c4[1], c4[2], "rmat", True))
     c5 = (9, 8, 16) if small else (args.logm, args.edge_factor, args.r)
-    entry("rank share, config 5: one rank of 8 through a CG half-step (cg_optimizer(Amat, 10): 12 fused calls with the CG updates in the row "
+    entry("rank_cfg5", "rank share, config 5: one rank of 8 through a CG half-step (cg_optimizer(Amat, 10): 12 fused calls with the CG updates in the row "
           "epilogue, fixed factor held), 15d_fusion2, ER 2^%d, edge factor %d, R=%d" % c5,
           lambda: share_of("15d_fusion2", 8, 1, c5[0], c5[1], c5[2], "er", False, als_iters=10))
     c13 = (9, 8, 16) if small else (args.logm, args.edge_factor, args.r)
-    entry("rank share, 2.5D sparse-replicate (the one schedule the configurations do not name): one rank of 8 (2 x 2 x 2: S stationary and "
+    entry("rank_25d_sparse", "rank share, 2.5D sparse-replicate (the one schedule the configurations do not name): one rank of 8 (2 x 2 x 2: S stationary and "
           "replicated, both dense operands move, R/4 columns per rank), SDDMM + SpMM pair, ER 2^%d, edge factor %d, R=%d" % c13,
           lambda: share_of("25d_sparse_replicate", 8, 2, c13[0], c13[1], c13[2], "er", True))
-    entry("rank share, 1.5D dense shift by replication reuse (15d_fusion1): one rank of 8, SDDMM + SpMM pair, the SpMM's accumulator travelling in two "
+    entry("rank_15d_fusion1", "rank share, 1.5D dense shift by replication reuse (15d_fusion1): one rank of 8, SDDMM + SpMM pair, the SpMM's accumulator travelling in two "
           "row halves, ER 2^%d, edge factor %d, R=%d" % c13, lambda: share_of("15d_fusion1", 8, 1, c13[0], c13[1], c13[2], "er", True))
     c1 = (8, 8, 16) if small else (16, 16, 16)
-    entry("config 1 as typed: ER 2^%d, edge factor %d, R=%d, 15d_sparse, 2 logical ranks (bench_erdos_renyi.cpp:19-120): one fusedSpMM, kernel "
+    entry("cfg1_as_typed", "config 1 as typed: ER 2^%d, edge factor %d, R=%d, 15d_sparse, 2 logical ranks (bench_erdos_renyi.cpp:19-120): one fusedSpMM, kernel "
           "time against call time" % c1, lambda: share_of("15d_sparse", 2, 1, c1[0], c1[1], c1[2], "er", True))
     return out

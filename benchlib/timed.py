@@ -159,8 +159,9 @@ class Bench:
             check = checks.check(self) if args.app == "vanilla" else checks.check_app(self)
             self.barrier()
         transport_kind = self.op.json_algorithm_info().get("transport", "?")  # (collective: every rank asks)
+        ranks = self.world().identities()  # (collective) where every rank runs: pid, device ordinal, PCI bus id, the RCCL communicator's view
         return {"route": self.route, "elapsed": elapsed, "kern_ms": kern_ms, "kern_ms_slowest": kern_ms_slowest, "launches": launches, "prof_calls": prof_calls,
-                "alg_bytes_per_step": alg_bytes_per_step, "check": check, "transport_kind": transport_kind}
+                "alg_bytes_per_step": alg_bytes_per_step, "check": check, "transport_kind": transport_kind, "ranks": ranks}
 
 
 def compose_line(args, b, res, extra):
@@ -186,6 +187,10 @@ def compose_line(args, b, res, extra):
     alg_now = "15d_fusion1" if mode == "fusion1" else args.alg
     step_is = {"vanilla": "fused SDDMM->SpMM (fusedSpMM, Amat)", "als": "one alternating ALS step by batched CG (run_cg(1): 24 fused calls)",
                "gat": "one GAT forward pass (3 layers, 14 heads, benchmark_dist.cpp:88-94)"}[args.app]
+    # where the ranks ran, from the ranks themselves: a line of N processes that shared fewer than N GPUs says so in its first sentence
+    ranks = res.get("ranks") or []
+    distinct = len({r["pci_bus_id"] for r in ranks}) or n
+    where = ("%d x MI355X" % n) if distinct == n else ("%d processes on %d x MI355X (ranks SHARE a GPU: time-sliced, not a scaling number)" % (n, distinct))
     how = "" if n == 1 else ", %s (%s)" % (
         {"rccl": "RCCL over xGMI", "ipc": "ipc-pull over mapped peer memory, copy engines", "ipc-kernel": "ipc-pull over mapped peer memory, pull kernel"}.get(tr, "transport: " + tr),
         {"relay": "neighbour relay ring", "mesh": "chunked fetch from the owners", None: "replication only, nothing shifts"}.get(ring_mode_now, ring_mode_now))
@@ -194,7 +199,7 @@ def compose_line(args, b, res, extra):
         "metric": "fused SDDMM+SpMM nnz*R/s", "value": value, "unit": "nnz*R/s", "n_gpus": n, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic" if b.wl.kind != "mtx" else "file",
-        "config": {"workload": "%s, R=%d, %s, %s c=%d on %d x MI355X%s" % (b.wl.describe(b.nnz), args.r, step_is, alg_now, c_now, n, how),
+        "config": {"workload": "%s, R=%d, %s, %s c=%d on %s%s" % (b.wl.describe(b.nnz), args.r, step_is, alg_now, c_now, where, how),
                    "nnz": b.nnz, "M": b.m, "R": args.r, "algorithm": alg_now, "app": args.app, "c": c_now,
                    "transport": "none" if n == 1 else res["transport_kind"],
                    "transport_variant": None if n == 1 else tr, "ring_mode": ring_mode_now,
@@ -205,34 +210,35 @@ def compose_line(args, b, res, extra):
                    "comm_cus": int(os.environ.get("HNH_COMM_CUS", "0") or 0),
                    # set-up of the first route: the tuples (generated on the device, or parsed from the file and merged), then redistribution,
                    # CSR blocks and operands; parse_s is the first part alone
-                   "setup_s": round(b.setup_s or 0.0, 2), "parse_s": round(b.parse_s or 0.0, 3)},
+                   "setup_s": round(b.setup_s or 0.0, 2), "parse_s": round(b.parse_s or 0.0, 3),
+                   # one record per rank: [rank, pid, device ordinal, PCI bus id] + RCCL's own [ncclCommCount, ncclCommUserRank, ncclCommCuDevice]
+                   "distinct_devices": distinct,
+                   "ranks": [[r["rank"], r["pid"], r["device_ordinal"], r["pci_bus_id"]] + ([r["comm_count"], r["comm_rank"], r["comm_device"]] if "comm_count" in r else [])
+                             for r in ranks]},
         # `achieved` is an ALGORITHMIC rate (SURVEY 8d byte model / measured launch time), not DRAM utilisation: part of every
         # launch's gathers is served by the 256 MiB Infinity Cache, which sits behind the counters `traffic` comes from
-        "roofline": {"bound": "hbm", "bound_detail": "hbm gather model (Infinity-Cache assisted); the saturated resource is the memory side "
-                                                      "serving scattered dense rows, see DESIGN.md section 3 and profiles/r02_gather_probe*.log",
+        "roofline": {"bound": "hbm", "bound_detail": "HBM gather model, Infinity-Cache assisted (DESIGN.md 3.2)",
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": None, "traffic_source": None,
-                     "frac_is": ("frac_kernel (one GPU: the step IS the dominant kernel's launches)" if n == 1 else
-                                 "frac_step (SURVEY 8d: total B_fused / ms_per_step / (n_gpus x 8.0e12): exposed communication counts)"),
+                     # one GPU: the step IS the dominant kernel's launches; several: SURVEY 8d's whole-step figure, exposed communication counts
+                     "frac_is": "frac_kernel (one GPU)" if n == 1 else "frac_step = total B_fused / ms_per_step / (n_gpus x 8 TB/s)",
                      "frac_kernel": achieved_kernel / HBM_PEAK, "achieved_kernel": achieved_kernel / 1e9,
                      "frac_step": achieved_step / HBM_PEAK, "achieved_step_per_gpu": achieved_step / 1e9,
                      "algorithmic_bytes_per_step_all_gpus": total_bytes,
                      # the slowest rank's event-bracketed kernel time per step, and what the timed step spends beyond it
                      "kernel_ms_per_step": kernel_ms_per_step, "exposed_comm_ms": ms_per_step - kernel_ms_per_step,
-                     "kernel": ("row_kernel<fused> (hnh_fused_sddmm_spmm_csr_p), one launch per Infinity-Cache panel of B" if n == 1 else
-                                "row_kernel<fused> (hnh_fused_sddmm_spmm_csr_p): one launch per visiting block of the relay ring"
-                                if ring_mode_now == "relay" else
-                                "row_kernel<fused> (hnh_fused_sddmm_spmm_csr_p): the rank's one block (replication only)" if ring_mode_now is None else
-                                "row_kernel<sddmm> + row_kernel<spmm> per visiting block (15d_fusion1 runs the pair, not the fused pass; the byte model stays the fused one)"
-                                if mode == "fusion1" else
-                                "row_kernel<fused> (hnh_fused_sddmm_spmm_csr_p): own block, then one windowed pass over the fetched blocks per landed chunk"),
+                     "kernel": ("row_kernel<fused>, 1 launch per Infinity-Cache panel of B" if n == 1 else
+                                "row_kernel<fused>, 1 launch per visiting block (relay ring)" if ring_mode_now == "relay" else
+                                "row_kernel<fused>, the rank's one block (replication only)" if ring_mode_now is None else
+                                "row_kernel<sddmm> + row_kernel<spmm> per visiting block (15d_fusion1)" if mode == "fusion1" else
+                                "row_kernel<fused>: own block + adaptive windowed passes over fetched blocks"),
                      # device time of a kernel CALL (HIP events around it on the compute stream) divided by the row-kernel launches it made
-                     "avg_launch_ms": dur * 1e3,
-                     "avg_launch_ms_is": "event-bracketed call time / row-kernel launches of the call (structure plans are cached: a steady-state call launches row kernels only)",
+                     # (structure plans are cached: a steady-state call launches row kernels only)
+                     "avg_launch_ms": dur * 1e3, "avg_launch_ms_is": "HIP-event time of the call / its row-kernel launches",
                      "traffic_rate": None,
                      "compulsory_bytes_per_call": 8 * args.r * (2 * b.m + b.m) + 24 * b.nnz,
                      "launches_per_step": launches_per_step, "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "model": "per fused call nnz*(8R+24) + 16*R*rows (SURVEY 8d), divided evenly over its launches"},
+                     "model": "nnz*(8R+24) + 16*R*rows per fused call (SURVEY 8d), split evenly over launches"},
     }
     if res["check"] is not None:
         out["check"] = res["check"]

@@ -25,6 +25,7 @@ SIGNATURES = {
     "hnh_ctx_destroy": (_i32, [_vp]),
     "hnh_last_error": (C.c_char_p, [_vp]),
     "hnh_ctx_stream": (_vp, [_vp, _i32]),
+    "hnh_ctx_device_identity": (_i32, [_vp, C.POINTER(_i32), C.c_char_p, _i32]),
     "hnh_malloc": (_i32, [_vp, _sz, C.POINTER(_vp)]),
     "hnh_free": (_i32, [_vp, _vp]),
     "hnh_memcpy": (_i32, [_vp, _vp, _vp, _sz, _i32, _i32]),
@@ -80,6 +81,7 @@ SIGNATURES = {
     "hnh_comm_init": (_i32, [_vp, _i32, _i32, _vp, C.POINTER(_vp)]),
     "hnh_comm_split": (_i32, [_vp, _vp, _i32, _i32, C.POINTER(_vp)]),
     "hnh_comm_destroy": (_i32, [_vp, _vp]),
+    "hnh_comm_identity": (_i32, [_vp, _vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "hnh_comm_sendrecv": (_i32, [_vp, _vp, _vp, _sz, _i32, _vp, _sz, _i32, _i32]),
     "hnh_comm_group_begin": (_i32, [_vp]),
     "hnh_comm_group_end": (_i32, [_vp]),

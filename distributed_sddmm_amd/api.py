@@ -62,6 +62,7 @@ SIGNATURES = {
     "hnh_world_grid_probe": (_i32, [_vp, _i32, _i32, _i32, _i32, _pi32, _pi32]),
     "hnh_world_preflight": (_i32, [_vp, _i32, _i64, C.POINTER(_dbl)]),
     "hnh_world_split_signature": (_i32, [_vp, C.POINTER(_u64), _pi32]),
+    "hnh_world_identities": (_i32, [_vp, _vp]),
     "hnh_spmat_create": (_i32, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _pvp]),
     "hnh_spmat_load_tuples": (_i32, [_vp, _i32, _i32, _i32, C.c_char_p, _pvp]),
     "hnh_spmat_info": (_i32, [_vp, _pi64]),
@@ -265,6 +266,23 @@ class World:
         err = _dbl()
         _check(lib().hnh_world_preflight(self.h, what, count, C.byref(err)), "preflight: " + self.PREFLIGHT[what])
         return err.value
+
+    def identities(self):
+        """Collective: where every rank of the world runs — [{"rank", "pid", "device_ordinal", "pci_bus_id", + "comm_count", "comm_rank",
+        "comm_device" when the transport has a communicator (RCCL)}], the same list on every rank (hnh_world_identities)."""
+        class Rec(C.Structure):
+            _fields_ = [("rank", _i32), ("pid", _i32), ("device_ordinal", _i32), ("comm_count", _i32), ("comm_rank", _i32), ("comm_device", _i32),
+                        ("pci_bus_id", C.c_char * 40)]
+        n = lib().hnh_world_size(self.h)
+        buf = (Rec * n)()
+        _check(lib().hnh_world_identities(self.h, C.cast(buf, _vp)), "identities")
+        out = []
+        for r in buf:
+            rec = {"rank": r.rank, "pid": r.pid, "device_ordinal": r.device_ordinal, "pci_bus_id": r.pci_bus_id.decode("ascii", "replace")}
+            if r.comm_count >= 0:
+                rec.update(comm_count=r.comm_count, comm_rank=r.comm_rank, comm_device=r.comm_device)
+            out.append(rec)
+        return out
 
     def split_signature(self):
         sig, n = _u64(), _i32()

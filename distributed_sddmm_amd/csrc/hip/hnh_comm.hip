@@ -64,6 +64,14 @@ int hnh_comm_destroy(hnh_ctx* ctx, void* comm) {
     return check_nccl(ctx, ncclCommDestroy((ncclComm_t)comm), "ncclCommDestroy");
 }
 
+int hnh_comm_identity(hnh_ctx* ctx, void* comm, int* nranks, int* rank, int* device) {
+    if (!ctx || !comm || !nranks || !rank || !device) return HNH_ERR_INVALID;
+    HNH_TRY_NCCL(ctx, ncclCommCount((ncclComm_t)comm, nranks));
+    HNH_TRY_NCCL(ctx, ncclCommUserRank((ncclComm_t)comm, rank));
+    HNH_TRY_NCCL(ctx, ncclCommCuDevice((ncclComm_t)comm, device));
+    return HNH_OK;
+}
+
 int hnh_comm_sendrecv(hnh_ctx* ctx, void* comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf,
                       size_t recvbytes, int src, int stream) {
     HNH_ENTER(ctx, stream);

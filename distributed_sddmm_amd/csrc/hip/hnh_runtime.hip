@@ -87,6 +87,13 @@ int hnh_stream_delay_us(hnh_ctx* ctx, int stream, double microseconds) {
 
 const char* hnh_backend_name(void) { return "hip-gfx950"; }
 
+int hnh_ctx_device_identity(hnh_ctx* ctx, int* ordinal, char* pci_bus_id, int len) {
+    if (!ctx || !ordinal || !pci_bus_id || len < 16) return HNH_ERR_INVALID;
+    *ordinal = ctx->device;
+    pci_bus_id[0] = 0;
+    return hnh::check_hip(ctx, hipDeviceGetPCIBusId(pci_bus_id, len, ctx->device), "hipDeviceGetPCIBusId");
+}
+
 int hnh_ctx_create(int device, hnh_ctx** out) {
     if (!out) return HNH_ERR_INVALID;
     *out = nullptr;

@@ -19,7 +19,7 @@ struct Backend {
 
 #define HNH_FN(sym) decltype(&::sym) sym = nullptr;
     HNH_FN(hnh_backend_name)
-    HNH_FN(hnh_ctx_create) HNH_FN(hnh_ctx_destroy) HNH_FN(hnh_last_error) HNH_FN(hnh_ctx_stream)
+    HNH_FN(hnh_ctx_create) HNH_FN(hnh_ctx_destroy) HNH_FN(hnh_last_error) HNH_FN(hnh_ctx_stream) HNH_FN(hnh_ctx_device_identity)
     HNH_FN(hnh_malloc) HNH_FN(hnh_free) HNH_FN(hnh_memcpy) HNH_FN(hnh_memset) HNH_FN(hnh_stream_sync)
     HNH_FN(hnh_event_create) HNH_FN(hnh_event_destroy) HNH_FN(hnh_event_record) HNH_FN(hnh_event_wait)
     HNH_FN(hnh_event_sync) HNH_FN(hnh_event_query) HNH_FN(hnh_event_elapsed_ms)
@@ -32,7 +32,7 @@ struct Backend {
     HNH_FN(hnh_fill_f64) HNH_FN(hnh_hadamard_f64) HNH_FN(hnh_axpy_f64) HNH_FN(hnh_expand_rowptr)
     HNH_FN(hnh_rowdot_f64) HNH_FN(hnh_row_scale_add_f64) HNH_FN(hnh_vec_add_scalar_f64) HNH_FN(hnh_vec_div_f64) HNH_FN(hnh_fill_hashed_f64)
     HNH_FN(hnh_gemm_f64) HNH_FN(hnh_leaky_relu_f64) HNH_FN(hnh_relu_store_cols_f64)
-    HNH_FN(hnh_comm_unique_id) HNH_FN(hnh_comm_init) HNH_FN(hnh_comm_split) HNH_FN(hnh_comm_destroy)
+    HNH_FN(hnh_comm_unique_id) HNH_FN(hnh_comm_init) HNH_FN(hnh_comm_split) HNH_FN(hnh_comm_destroy) HNH_FN(hnh_comm_identity)
     HNH_FN(hnh_comm_sendrecv) HNH_FN(hnh_comm_group_begin) HNH_FN(hnh_comm_group_end) HNH_FN(hnh_comm_allgather) HNH_FN(hnh_comm_reduce_scatter_f64)
     HNH_FN(hnh_comm_allreduce_f64)
     HNH_FN(hnh_ipc_export) HNH_FN(hnh_ipc_open) HNH_FN(hnh_ipc_close) HNH_FN(hnh_ipc_pull) HNH_FN(hnh_ipc_flags_register) HNH_FN(hnh_ipc_flags_unregister)

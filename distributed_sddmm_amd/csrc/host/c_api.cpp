@@ -175,6 +175,14 @@ int hnh_world_grid_probe(hnh_world* w, int nr, int nc, int nh, int adjacency, in
     });
 }
 
+int hnh_world_identities(hnh_world* wh, hnh_rank_identity* out) {
+    if (!wh || !out) return HNH_ERR_INVALID;
+    return guarded(wh->w.get(), [&] {
+        const std::vector<hnh_rank_identity> all = wh->w->identities();
+        std::copy(all.begin(), all.end(), out);
+    });
+}
+
 int hnh_world_split_signature(hnh_world* w, uint64_t* signature, int* count) {
     if (!w || !signature || !count) return HNH_ERR_INVALID;
     *signature = w->w->split_signature;

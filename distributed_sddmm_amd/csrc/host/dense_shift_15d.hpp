@@ -391,7 +391,7 @@ private:
             if (!by_window) {
                 world->event_wait(event(8 + windows - 1), HNH_STREAM_COMPUTE);  // every chunk has landed
                 one(1, landing[slot], -1, -1, true);
-            } else if (!merge_windows || (resident && force_one_chunk_per_pass)) {
+            } else if (!merge_windows || !kernel->handles_window_ranges() || (resident && force_one_chunk_per_pass)) {
                 for (int q = 0; q < windows; q++) {
                     world->event_wait(event(8 + q), HNH_STREAM_COMPUTE);  // chunk q of every remote block has landed
                     one(1, landing[slot], q, q + 1, q == windows - 1);

@@ -58,6 +58,11 @@ public:
     // work on data that arrives piece by piece.  An implementation that honours CSRLocal::window says so here; for the
     // others (plugins written against the reference's two pure virtuals) the schedule waits for the whole block instead.
     virtual bool handles_windows() const { return false; }
+    // Window RANGES (CSRLocal::window .. window_end, round 5's adaptive windows): the schedule may select SEVERAL consecutive windows
+    // for one pass — [window, window_end) — when their data has landed together.  Only an implementation that reads the selection
+    // through CSRLocal::window_args() (or honours window_end itself) may say so; a plugin that reads CSRLocal::window alone keeps
+    // the default and gets exactly one window per pass (window_end == window + 1 always), as in rounds 2-4.
+    virtual bool handles_window_ranges() const { return false; }
 
     // Row parts (CSRLocal::row_part): the SpMM of the selected half of a block's rows.  An implementation that honours it says so
     // here; for the others the schedule keeps the whole-block step (kernel, then shift).
@@ -100,6 +105,7 @@ public:
     long kernel_launches = 0;
 
     bool handles_windows() const override { return true; }
+    bool handles_window_ranges() const override { return true; }
     bool overwrites_fresh_values() const override { return true; }
     bool handles_row_parts() const override { return true; }
     bool borrows_value_arrays() const override { return true; }

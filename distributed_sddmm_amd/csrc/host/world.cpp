@@ -83,7 +83,7 @@ Backend* load_backend(const char* path_c) {
     b->sym = (decltype(b->sym))dlsym(dl, #sym);                                        \
     if (!b->sym) fatal(std::string("Error, kernel library ") + path + " lacks symbol " #sym);
     HNH_BIND(hnh_backend_name)
-    HNH_BIND(hnh_ctx_create) HNH_BIND(hnh_ctx_destroy) HNH_BIND(hnh_last_error) HNH_BIND(hnh_ctx_stream)
+    HNH_BIND(hnh_ctx_create) HNH_BIND(hnh_ctx_destroy) HNH_BIND(hnh_last_error) HNH_BIND(hnh_ctx_stream) HNH_BIND(hnh_ctx_device_identity)
     HNH_BIND(hnh_malloc) HNH_BIND(hnh_free) HNH_BIND(hnh_memcpy) HNH_BIND(hnh_memset) HNH_BIND(hnh_stream_sync)
     HNH_BIND(hnh_event_create) HNH_BIND(hnh_event_destroy) HNH_BIND(hnh_event_record) HNH_BIND(hnh_event_wait)
     HNH_BIND(hnh_event_sync) HNH_BIND(hnh_event_query) HNH_BIND(hnh_event_elapsed_ms)
@@ -96,7 +96,7 @@ Backend* load_backend(const char* path_c) {
     HNH_BIND(hnh_fill_f64) HNH_BIND(hnh_hadamard_f64) HNH_BIND(hnh_axpy_f64) HNH_BIND(hnh_expand_rowptr)
     HNH_BIND(hnh_rowdot_f64) HNH_BIND(hnh_row_scale_add_f64) HNH_BIND(hnh_vec_add_scalar_f64) HNH_BIND(hnh_vec_div_f64) HNH_BIND(hnh_fill_hashed_f64)
     HNH_BIND(hnh_gemm_f64) HNH_BIND(hnh_leaky_relu_f64) HNH_BIND(hnh_relu_store_cols_f64)
-    HNH_BIND(hnh_comm_unique_id) HNH_BIND(hnh_comm_init) HNH_BIND(hnh_comm_split) HNH_BIND(hnh_comm_destroy)
+    HNH_BIND(hnh_comm_unique_id) HNH_BIND(hnh_comm_init) HNH_BIND(hnh_comm_split) HNH_BIND(hnh_comm_destroy) HNH_BIND(hnh_comm_identity)
     HNH_BIND(hnh_comm_sendrecv) HNH_BIND(hnh_comm_group_begin) HNH_BIND(hnh_comm_group_end) HNH_BIND(hnh_comm_allgather) HNH_BIND(hnh_comm_reduce_scatter_f64)
     HNH_BIND(hnh_comm_allreduce_f64)
     HNH_BIND(hnh_ipc_export) HNH_BIND(hnh_ipc_open) HNH_BIND(hnh_ipc_close) HNH_BIND(hnh_ipc_pull) HNH_BIND(hnh_ipc_flags_register) HNH_BIND(hnh_ipc_flags_unregister)
@@ -278,6 +278,24 @@ bool World::event_done(void* e) {
 
 void World::set_solo(bool on) {
     if (on) fatal(std::string("Error, solo replay is a measurement mode of the loopback transport, not of ") + kind());
+}
+
+hnh_rank_identity World::identity() {
+    hnh_rank_identity id;
+    std::memset(&id, 0, sizeof id);
+    id.rank = rank;
+    id.pid = (int32_t)getpid();
+    id.comm_count = id.comm_rank = id.comm_device = -1;
+    int ordinal = device;
+    check(be->hnh_ctx_device_identity(ctx, &ordinal, id.pci_bus_id, (int)sizeof id.pci_bus_id), "hnh_ctx_device_identity");
+    id.device_ordinal = ordinal;
+    return id;
+}
+std::vector<hnh_rank_identity> World::identities() {
+    const hnh_rank_identity mine = identity();
+    std::vector<hnh_rank_identity> all((size_t)size);
+    host_allgather(&mine, all.data(), sizeof mine);
+    return all;
 }
 
 Comm World::world_comm() {
@@ -757,6 +775,15 @@ RcclWorld::RcclWorld(int r, int nranks, Backend* backend, int device_ordinal, co
     size = nranks;
     init_device(backend, device_ordinal);
     check(be->hnh_comm_init(ctx, nranks, r, unique_id, &comm_), "hnh_comm_init");
+}
+hnh_rank_identity RcclWorld::identity() {
+    hnh_rank_identity id = World::identity();
+    int n = -1, r = -1, d = -1;
+    check(be->hnh_comm_identity(ctx, comm_, &n, &r, &d), "hnh_comm_identity");
+    id.comm_count = n;
+    id.comm_rank = r;
+    id.comm_device = d;
+    return id;
 }
 RcclWorld::~RcclWorld() {
     if (ctx) {

@@ -66,6 +66,11 @@ public:
     virtual void set_solo(bool on);
     bool solo() const { return solo_; }
 
+    // Where this rank runs: pid, device ordinal, the GPU's PCI bus id and (RCCL) the communicator's own view; identities() gathers
+    // every rank's record (collective).  include/hnh_dist.h: hnh_rank_identity.
+    virtual hnh_rank_identity identity();
+    std::vector<hnh_rank_identity> identities();
+
     // ---- communicators
     Comm world_comm();
     virtual Comm split(int color, int key);  // MPI_Comm_split semantics (FlexibleGrid.hpp:80-88)
@@ -215,6 +220,7 @@ public:
     RcclWorld(int rank, int nranks, Backend* backend, int device_ordinal, const void* unique_id);
     ~RcclWorld() override;
     const char* kind() const override { return "rccl"; }
+    hnh_rank_identity identity() override;
     void group_begin() override;
     void group_end() override;
     void sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes,

@@ -10,6 +10,7 @@
 #include <iostream>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cannon_dense_25d.hpp"
@@ -30,6 +31,37 @@ public:
     size_t spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, MatMode mode, int block) override {
         spmm_calls++;
         return inner.spmm_local(S, A, B, mode, block);
+    }
+};
+
+// A plugin written against round 2-4's window contract: it honours CSRLocal::window — ONE column range of a block per pass — and has
+// never heard of window ranges (round 5's adaptive windows: [window, window_end)), so it does not override handles_window_ranges().
+// The schedule must therefore never hand it more than one window at a time; it checks that on every call and computes the window
+// it is told about by reading `window` alone (by narrowing the selection to it before it delegates).
+class OneWindowKernel : public KernelImplementation {
+public:
+    StandardKernel inner;
+    size_t windowed_calls = 0, range_violations = 0;
+    bool handles_windows() const override { return true; }
+    void look(SpmatLocal& S, int block) {
+        CSRLocal* blk = S.csr_blocks[block];
+        if (blk == nullptr || blk->window < 0) return;
+        windowed_calls++;
+        if (blk->window_end > blk->window + 1) range_violations++;
+        blk->window_end = blk->window + 1;  // "reads window alone": whatever else was selected is not computed by this plugin
+    }
+    size_t sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, int block, int offset) override {
+        look(S, block);
+        return inner.sddmm_local(S, A, B, block, offset);
+    }
+    size_t spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, MatMode mode, int block) override {
+        look(S, block);
+        return inner.spmm_local(S, A, B, mode, block);
+    }
+    size_t fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, DenseMatrix& Out, int block, unsigned flags,
+                       const hnh_fused_extras* extras = nullptr) override {
+        look(S, block);
+        return inner.fused_local(S, A, B, Out, block, flags, extras);
     }
 };
 
@@ -92,6 +124,49 @@ int main(int argc, char** argv) {
     }
     world.sync_all();
     hnh::set_current_world(nullptr);
+    // ---- the window contract on 4 logical ranks (the mesh fetch of the 1.5D dense shift walks the fetched blocks window by window):
+    // StandardKernel takes window ranges, the one-window plugin must get one window per pass and the same results
+    {
+        const int p = 4;
+        auto group = hnh::make_thread_group(p);
+        vector<vector<vector<double>>> want(p), got(p);
+        vector<size_t> calls(p, 0), violations(p, 0);
+        vector<thread> threads;
+        for (int r = 0; r < p; r++)
+            threads.emplace_back([&, r] {
+                hnh::ThreadWorld w(group, r, be, 0);
+                hnh::set_current_world(&w);
+                {
+                    SpmatLocal S;
+                    S.loadTuples(false, logM, ef, "");
+                    StandardKernel standard;
+                    OneWindowKernel plugin;
+                    want[r] = run("15d_fusion2", &S, R, &standard);
+                    got[r] = run("15d_fusion2", &S, R, &plugin);
+                    calls[r] = plugin.windowed_calls;
+                    violations[r] = plugin.range_violations;
+                }
+                w.sync_all();
+                w.barrier();
+                hnh::set_current_world(nullptr);
+            });
+        for (auto& t : threads) t.join();
+        double worst = 0.0;
+        size_t ncalls = 0, nviol = 0;
+        for (int r = 0; r < p; r++) {
+            ncalls += calls[r];
+            nviol += violations[r];
+            for (size_t k = 0; k < want[r].size(); k++)
+                for (size_t e = 0; e < want[r][k].size(); e++) {
+                    const double scale = max(1e-300, fabs(want[r][k][e]));
+                    worst = max(worst, fabs(want[r][k][e] - got[r][k][e]) / max(scale, 1e-6));
+                }
+        }
+        const bool ok = worst <= 1e-11 && ncalls > 0 && nviol == 0;
+        cout << "window contract (4 ranks, 15d_fusion2): one-window plugin vs StandardKernel rel err " << worst << ", windowed calls " << ncalls
+             << ", passes handed more than one window " << nviol << (ok ? " ok" : " MISMATCH") << endl;
+        if (!ok) bad++;
+    }
     cout << (bad ? "custom kernel plugin: FAILED" : "custom kernel plugin: all schedules ok") << endl;
     return bad ? 1 : 0;
 }

@@ -102,6 +102,16 @@ int hnh_world_preflight(hnh_world* w, int what, int64_t count, double* max_err);
 /* running hash / number of the communicator splits so far: identical on every rank iff they split in the same order */
 int hnh_world_split_signature(hnh_world* w, uint64_t* signature, int* count);
 int hnh_world_grid_probe(hnh_world* w, int nr, int nc, int nh, int adjacency, int* out9, int* ok);
+/* Where every rank of the world runs (collective; `out` takes hnh_world_size() records, the same on every rank): process id, device
+ * ordinal and PCI bus id of the rank's GPU and — RCCL transport — what its communicator reports about itself (ncclCommCount,
+ * ncclCommUserRank, ncclCommCuDevice; -1 for the other transports).  A job whose ranks report fewer distinct bus ids than ranks shares
+ * GPUs: bench.py prints these records so that its N > 1 line certifies where it ran (the reference's ranks are host processes). */
+typedef struct hnh_rank_identity {
+    int32_t rank, pid, device_ordinal;
+    int32_t comm_count, comm_rank, comm_device;
+    char pci_bus_id[40];
+} hnh_rank_identity;
+int hnh_world_identities(hnh_world* w, hnh_rank_identity* out);
 
 /* ---- sparse input (SpmatLocal.hpp:267-606) */
 /* Wraps tuples that this rank holds initially (any distribution; coords / M / N / dist_nnz as the reference's

@@ -64,6 +64,10 @@ int hnh_ctx_create(int device, hnh_ctx** out);
 int hnh_ctx_destroy(hnh_ctx* ctx);
 const char* hnh_last_error(hnh_ctx* ctx);
 void* hnh_ctx_stream(hnh_ctx* ctx, int stream); /* the raw hipStream_t, for interop (RCCL, torch) */
+/* Which physical device the context runs on: the ordinal it was created with and the device's PCI bus id ("0000:c1:00.0"; at most
+ * len - 1 characters + NUL, len >= 16).  Two ranks of one job that report the same bus id share ONE GPU — what a benchmark line of
+ * N processes has to be able to prove about itself (the reference's MPI ranks are host processes: no counterpart there). */
+int hnh_ctx_device_identity(hnh_ctx* ctx, int* ordinal, char* pci_bus_id, int len);
 int hnh_malloc(hnh_ctx* ctx, size_t bytes, void** out);
 int hnh_free(hnh_ctx* ctx, void* ptr);
 int hnh_memcpy(hnh_ctx* ctx, void* dst, const void* src, size_t bytes, int kind, int stream);
@@ -359,6 +363,9 @@ int hnh_comm_unique_id(void* id_host /* HNH_UNIQUE_ID_BYTES, host */);
 int hnh_comm_init(hnh_ctx* ctx, int nranks, int rank, const void* id_host, void** comm);
 int hnh_comm_split(hnh_ctx* ctx, void* comm, int color, int key, void** newcomm);
 int hnh_comm_destroy(hnh_ctx* ctx, void* comm);
+/* What the COMMUNICATOR says about itself (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): its size, this rank's index in it and
+ * the device it is bound to. */
+int hnh_comm_identity(hnh_ctx* ctx, void* comm, int* nranks, int* rank, int* device);
 int hnh_comm_sendrecv(hnh_ctx* ctx, void* comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf,
                       size_t recvbytes, int src, int stream);
 /* Everything enqueued between begin and end is issued as ONE RCCL group (ncclGroupStart/End), so that

@@ -75,6 +75,15 @@ int hnh_ctx_destroy(hnh_ctx* c) {
 }
 const char* hnh_last_error(hnh_ctx* c) { return c ? c->err : "null context"; }
 void* hnh_ctx_stream(hnh_ctx* c, int s) { (void)c; (void)s; return NULL; }
+/* the double's "devices" are the host: one bus id per ordinal ($HNH_ORACLE_PCI_BUS_ID replaces it: tests of ranks that share a device) */
+int hnh_ctx_device_identity(hnh_ctx* c, int* ordinal, char* pci_bus_id, int len) {
+    if (!c || !ordinal || !pci_bus_id || len < 16) return HNH_ERR_INVALID;
+    *ordinal = c->device;
+    const char* forced = getenv("HNH_ORACLE_PCI_BUS_ID");
+    if (forced && *forced) snprintf(pci_bus_id, (size_t)len, "%s", forced);
+    else snprintf(pci_bus_id, (size_t)len, "cpu0:%02x:00.0", c->device & 0xff);
+    return HNH_OK;
+}
 /* "device" blocks are remembered (base, size) so that the ipc double below can say which block a pointer lies in */
 typedef struct block { char* base; size_t bytes; struct block* next; hb_rec* recs; int nrec, cap; } block;
 static block* g_blocks = NULL;
@@ -1164,6 +1173,14 @@ int hnh_comm_destroy(hnh_ctx* c, void* comm) {
     if (!ec) return HNH_OK;
     munmap(ec->g, sizeof(emu_shared));
     free(ec);
+    return HNH_OK;
+}
+int hnh_comm_identity(hnh_ctx* c, void* comm, int* nranks, int* rank, int* device) {
+    emu_comm* ec = (emu_comm*)comm;
+    if (!c || !ec || !nranks || !rank || !device) return HNH_ERR_INVALID;
+    *nranks = ec->n;
+    *rank = ec->rank;
+    *device = c->device;
     return HNH_OK;
 }
 static void emu_declare_send(emu_op* o) {

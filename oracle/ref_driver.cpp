@@ -18,6 +18,8 @@
 //   ref_driver dump  <case.bin> <alg> <c> <outprefix>     element-wise results, all ops
 //   ref_driver fp    <case.bin> <alg> <c>                 scratch.cpp:26-76 style fingerprints
 //   ref_driver bench <case.bin> <alg> <c> <fused> <trials> benchmark_dist.cpp:102-162 timing loop
+//   ref_driver sweep <case.bin> <alg> <c> <fused> <trials> <reps> <t1,t2,...>   the same timing loop at several OpenMP/MKL thread
+//        counts behind ONE set-up: per count one warm-up call, then <reps> batches of <trials> timed calls (every batch reported)
 //   ref_driver als   <case.bin> <alg> <c> <outprefix> <steps> <cg_iters>   ALS-CG (als_conjugate_gradients.cpp):
 //        ground truth = the input S values (keyed by coordinate), embeddings initialised from the case's A, B,
 //        `steps` x { cg_optimizer(Amat, cg_iters); cg_optimizer(Bmat, cg_iters) } (= run_cg, :235-263), dumps A, B
@@ -267,6 +269,48 @@ void run_bench(const Case& cs, Distributed_Sparse* d, const std::string& name, b
     }
 }
 
+extern "C" void MKL_Set_Num_Threads(int);  // mkl_service.h: mkl_set_num_threads
+
+// The timing loop of run_bench at each of `counts` threads, one set-up for all of them (bench.py's cpu_baseline leg: the reference's
+// set-up takes several times longer than its timed calls, so a sweep of separate runs is mostly set-up).
+void run_sweep(const Case& cs, Distributed_Sparse* d, const std::string& name, bool fused, int trials, int reps, const std::vector<int>& counts) {
+    DenseMatrix A = d->like_A_matrix(0.001), B = d->like_B_matrix(0.001);
+    VectorXd S = d->like_S_values(1.0), res = d->like_S_values(0.0);
+    auto call = [&]() { if (fused) d->fusedSpMM(A, B, S, res, Amat); else { d->sddmmA(A, B, S, res); d->spmmA(A, B, S); } };
+    json points = json::array();
+    for (int t : counts) {
+        omp_set_num_threads(t);
+        MKL_Set_Num_Threads(t);
+        call();  // untimed warm-up at this thread count
+        json batches = json::array();
+        double best = -1.0, best_comp = 0.0;
+        for (int rep = 0; rep < reps; rep++) {
+            MPI_Barrier(MPI_COMM_WORLD);
+            d->reset_performance_timers();
+            my_timer_t tm = start_clock();
+            for (int it = 0; it < trials; it++) call();
+            MPI_Barrier(MPI_COMM_WORLD);
+            double elapsed = stop_clock_get_elapsed(tm);
+            json stats = d->json_perf_statistics();
+            batches.push_back(elapsed);
+            if (best < 0.0 || elapsed < best) {
+                best = elapsed;
+                best_comp = stats.contains("Computation Time") ? stats["Computation Time"].get<double>() : 0.0;
+            }
+        }
+        json pt;
+        pt["threads"] = t; pt["elapsed"] = best; pt["batches"] = batches; pt["computation_time"] = best_comp;
+        pt["nnz_R_per_s"] = (double)cs.nnz * (double)d->R * trials / best;
+        points.push_back(pt);
+    }
+    if (d->proc_rank == 0) {
+        json j;
+        j["alg_name"] = name; j["fused"] = fused; j["num_trials"] = trials; j["reps"] = reps; j["nnz"] = cs.nnz; j["r"] = d->R;
+        j["p"] = d->p; j["c"] = d->c; j["points"] = points;
+        std::printf("%s\n", j.dump().c_str());
+    }
+}
+
 // ALS-CG on the reference's own Distributed_ALS (als_conjugate_gradients.cpp:148-301).  The random
 // initialisations (:143-146, :225-233) are replaced by the case's keyed fills through public members.
 void run_als(const Case& cs, Distributed_Sparse* d, const std::string& prefix, int steps, int cg_iters) {
@@ -381,6 +425,11 @@ int main(int argc, char** argv) {
             bool fused = argc > 5 ? std::atoi(argv[5]) != 0 : true;
             int trials = argc > 6 ? std::atoi(argv[6]) : 5;
             run_bench(cs, d, alg, fused, trials);
+        } else if (mode == "sweep") {
+            if (argc < 9) die("sweep needs <fused> <trials> <reps> <t1,t2,...>");
+            std::vector<int> counts;
+            for (char* tok = std::strtok(argv[8], ","); tok; tok = std::strtok(nullptr, ",")) counts.push_back(std::max(1, std::atoi(tok)));
+            run_sweep(cs, d, alg, std::atoi(argv[5]) != 0, std::atoi(argv[6]), std::max(1, std::atoi(argv[7])), counts);
         } else {
             die("unknown mode " + mode);
         }

@@ -143,6 +143,17 @@ def bench(m, n, rows, cols, r, alg: str, p: int, c: int, fused: bool, trials: in
         return json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
 
 
+def sweep(m, n, rows, cols, r, alg: str, p: int, c: int, fused: bool, trials: int, reps: int, thread_counts, timeout: float = 600.0) -> dict:
+    """The timing loop of bench() at several OpenMP/MKL thread counts behind one set-up (ref_driver sweep): per count one warm-up
+    call and `reps` batches of `trials` timed calls; "points" = [{"threads", "elapsed" (best batch), "batches", "nnz_R_per_s"}]."""
+    with tempfile.TemporaryDirectory(prefix="hnh_ref_") as td:
+        case = os.path.join(td, "case.bin")
+        write_case(case, m, n, rows, cols, np.ones(len(rows)), r)
+        counts = sorted(set(int(t) for t in thread_counts))
+        out = run(["sweep", case, alg, c, int(fused), trials, reps, ",".join(str(t) for t in counts)], p, alg, threads=max(counts), timeout=timeout, retries=1)
+        return json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+
+
 def als(m, n, rows, cols, vals, r, a, b, alg: str, p: int, c: int, steps: int, cg_iters: int, timeout: float = 300.0,
         threads: int | None = None) -> dict:
     """ALS-CG of the reference (als_conjugate_gradients.cpp) with ground truth = `vals`, embeddings initialised

@@ -14,6 +14,11 @@ os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 # exit with status 86 and the report if they saw one); this process reports at the end of the session (below).  HNH_ORDER_CHECK=0 turns it off.
 os.environ.setdefault("HNH_ORDER_CHECK", "1")
 
+# bench.py writes the full record of a run beside its (bounded) line: tests keep it out of the tree
+if "HNH_BENCH_RECORD" not in os.environ:
+    import tempfile
+    os.environ["HNH_BENCH_RECORD"] = os.path.join(tempfile.mkdtemp(prefix="hnh_bench_record_"), "bench_secondary.json")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

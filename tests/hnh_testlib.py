@@ -234,7 +234,20 @@ def check_against_oracle(glob: dict, case: dict, alg: str, tol: float = TOL):
     assert rel(glob["fingerprints"], np.array(O.fingerprints(rows, cols, m, n, case["R"]))) <= tol
 
 
-ALS_TOL = 1e-9  # CG amplifies summation-order differences: the reference's own schedules differ by up to 1.2e-11 (als_manifest.json)
+# ALS factors and residuals against the reference's: batched CG amplifies summation-order differences — the reference's OWN five
+# schedules disagree by up to 1.14e-11 on the golden cases (tests/golden/als_manifest.json, "deviation_from_canonical") — so the bound is
+# 10 x that spread.  What this repository's path actually differs by is recorded in the same manifest ("observed_vs_reference": HIP on
+# an MI355X and the CPU test double, fixtures and config 2's full size): at most a few 1e-12.
+ALS_TOL = 1.2e-10
+
+
+def record_observed(kind, **fields):
+    """Append one observed-error record to $HNH_OBSERVED_LOG (JSON lines) — how the numbers in als_manifest.json were collected."""
+    path = os.environ.get("HNH_OBSERVED_LOG")
+    if path:
+        import json
+        with open(path, "a") as f:
+            f.write(json.dumps(dict({"kind": kind, "backend": H.backend_name()}, **{k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in fields.items()})) + "\n")
 
 
 def run_als(world: H.World, alg: str, c: int, case: dict, steps: int, iters: int) -> dict:
@@ -289,6 +302,8 @@ def check_als_against_golden(per_rank, case):
     gold = dict(np.load(os.path.join(GOLDEN, "als_%s.npz" % case["name"])))
     a = assemble_dense(per_rank, "alsA", "subA", case["M"], case["R"])
     b = assemble_dense(per_rank, "alsB", "subB", case["N"], case["R"])
+    record_observed("als_fixture", case=case["name"], ranks=len(per_rank), A=rel(a, gold["A"]), B=rel(b, gold["B"]),
+                    residuals=rel(per_rank[0]["residuals"], gold["residuals"]))
     assert rel(a, gold["A"]) <= ALS_TOL, rel(a, gold["A"])
     assert rel(b, gold["B"]) <= ALS_TOL, rel(b, gold["B"])
     assert rel(per_rank[0]["residuals"], gold["residuals"]) <= ALS_TOL

@@ -11,6 +11,45 @@ import pytest
 
 from test_gloo_world import ROOT, free_port
 
+LINE_LIMIT = 8192  # bytes; the driver reads the result out of a bounded tail of the run's output (BENCH_r05: a 19 KB line, parsed: null)
+
+
+def _no_constants(name):
+    raise ValueError("not strict JSON: %s" % name)
+
+
+def read_line(text, want_record=True):
+    """The ONE line a run prints: at most LINE_LIMIT bytes, strict JSON (no NaN / Infinity), every string bounded, the contract's keys —
+    checked for every line any test of this file sees.  Returns the run's FULL record, which the line names in `full_record`
+    (benchlib/line.py: the line is the record's bounded form), so that the tests below keep reading every detail."""
+    assert len(text.encode()) + 1 <= LINE_LIMIT, len(text)
+    line = json.loads(text, parse_constant=_no_constants)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in line, key
+    assert "workload" in line["config"]
+
+    def strings(v):
+        if isinstance(v, str):
+            yield v
+        elif isinstance(v, dict):
+            for k, x in v.items():
+                yield k
+                yield from strings(x)
+        elif isinstance(v, list):
+            for x in v:
+                yield from strings(x)
+    assert max(len(x) for x in strings(line)) <= 300
+    if line.get("value") is not None:
+        assert "roofline" in line and {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+    if not want_record:
+        return line
+    assert "full_record" in line, sorted(line)
+    with open(line["full_record"] if os.path.isabs(line["full_record"]) else os.path.join(ROOT, line["full_record"])) as f:
+        rec = json.load(f)
+    for key in ("value", "n_gpus", "steps", "ms_per_step"):  # the line IS the record, shortened
+        assert rec.get(key) == line.get(key), key
+    return rec
+
 
 @pytest.mark.parametrize("nranks,alg,c,ring", [(1, "15d_fusion2", 1, None), (2, "15d_fusion2", 1, None), (4, "15d_fusion2", 1, None),
                                                 (4, "15d_fusion2", 2, None), (2, "15d_fusion1", 1, None), (4, "15d_fusion2", 1, "relay"), (2, "15d_fusion2", 1, "mesh"),
@@ -104,7 +143,7 @@ def product_launch(nranks, extra_env=None, probe_timeout="120", extra_args=()):
                          timeout=900)
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, (res.returncode, res.stdout[-1500:], res.stderr[-1500:])
-    return res, json.loads(lines[0])
+    return res, read_line(lines[0])
 
 
 @pytest.mark.parametrize("nranks", [2, 4])
@@ -173,7 +212,7 @@ def test_sigterm_to_the_launcher_prints_the_line_in_hand():
     stdout, stderr = p.communicate(timeout=120)
     lines = [ln for ln in stdout.splitlines() if ln.strip()]
     assert p.returncode == 0 and len(lines) == 1, (p.returncode, stdout[-1500:], stderr[-1500:])
-    out = json.loads(lines[0])
+    out = read_line(lines[0])
     assert out["value"] > 0 and out["check"]["ok"] and "signal 15 sent to the launcher" in out["incomplete"], out.get("incomplete")
     assert out["phases_s"]["total"] > 3.0 and "phases" in out and "exit_codes" in out
 
@@ -201,7 +240,7 @@ def test_a_multi_gpu_line_carries_the_whole_step_roofline_and_the_cpu_baseline(t
                              capture_output=True, text=True, timeout=900)
         lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
         assert res.returncode == 0 and len(lines) == 1, (res.returncode, res.stdout[-1500:], res.stderr[-1500:])
-        return json.loads(lines[0])
+        return read_line(lines[0])
     out = launch()
     roof = out["roofline"]
     total = out["config"]["nnz"] * (8 * 16 + 24) + 16 * 16 * out["config"]["M"]
@@ -315,7 +354,7 @@ def test_the_multi_gpu_product_path_under_torch_distributed_run():
                           "--edge-factor", "8", "--rvalue", "16", "--no-cpu-baseline", "--probe-timeout", "120"], env=env, capture_output=True, text=True, timeout=900)
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert res.returncode == 0 and len(lines) == 1, (res.returncode, res.stdout[-1000:], res.stderr[-1500:])
-    out = json.loads(lines[0])
+    out = read_line(lines[0])
     assert out["n_gpus"] == 2 and out["check"]["ok"] and out["config"]["R"] == 16 if "R" in out["config"] else out["check"]["ok"]
     assert all(v.startswith("ok") for v in out["config"]["transport_trials"].values())
 
@@ -335,7 +374,7 @@ def test_bench_launches_its_own_workers():
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout[-2000:]
-    out = json.loads(lines[0])
+    out = read_line(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["check"]["ok"] and "error" not in out
     assert {k.split()[0] for k in out["config"]["route_tuning_ms_per_step"]} == {"c=1", "c=2"}
 
@@ -346,7 +385,7 @@ def test_bench_self_launch_reports_a_failing_rank():
     assert res.returncode == 7, (res.returncode, res.stderr[-1500:])
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
-    out = json.loads(lines[0])
+    out = read_line(lines[0])
     assert out["value"] is None and out["failed_rank"] == 1 and out["exit_codes"] == [0, 7] and "rank 1" in out["error"]
     assert out["phase"] and set(out["phases"]) == {"0", "1"}
     assert out["line_of_rank0"]["n_gpus"] == 2  # what rank 0 had measured before the failure is kept, marked as part of an error
@@ -360,7 +399,7 @@ def test_bench_self_launch_ends_a_hung_run():
     assert res.returncode != 0
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout[-1500:]
-    out = json.loads(lines[0])
+    out = read_line(lines[0])
     assert out["value"] is None and "error" in out and set(out["phases"]) == {"0", "1"}
     assert out["phases"]["1"].startswith("start-up")  # the hung rank never reached the benchmark body
 
@@ -374,7 +413,7 @@ def test_bench_without_a_gpu_fails_loudly_with_one_line():
     assert res.returncode != 0
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
-    out = json.loads(lines[0])
+    out = read_line(lines[0])
     assert out["value"] is None and "error" in out and out["failed_rank"] in (0, 1) and "transport creation" in out["phase"]
     assert "no GPU visible" in res.stderr
 
@@ -386,7 +425,7 @@ def test_a_failing_route_candidate_is_recorded_and_the_line_survives():
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout[-2000:]
-    out = json.loads(lines[0])
+    out = read_line(lines[0])
     assert out["value"] > 0 and out["check"]["ok"] and "error" not in out
     tuned, failed = out["config"]["route_tuning_ms_per_step"], out["config"]["route_tuning_failures"]
     assert tuned["c=1 mesh/4 chunks [default]"] is None and "c=1 mesh/4 chunks [default]" in failed
@@ -404,7 +443,7 @@ def test_a_candidate_that_hangs_still_leaves_the_line_in_hand():
                        "BENCH_WORKER_POISON_RANK": "1"}, extra_args=("--watchdog", "12"))
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout[-2000:] + res.stderr[-2000:]
-    out = json.loads(lines[0])
+    out = read_line(lines[0])
     assert res.returncode == 0 and out["value"] > 0 and out["check"]["ok"]
     assert "stuck in phase 'route tuning: c=1 mesh/4 chunks [default]'" in out["incomplete"]
     assert out["config"]["mesh_chunks"] == "1,2,2,2,1,1"  # the default route's measurement
@@ -422,7 +461,7 @@ def run_worker_directly(n, *cli, timeout=600):
     assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-1500:] for o in outs)
     lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
     assert len(lines) == 1, outs[0][0][-1500:]
-    return json.loads(lines[0])
+    return read_line(lines[0])
 
 
 @pytest.mark.parametrize("n,cli,app", [(1, ("--workload", "rmat", "--logm", "9", "--edge-factor", "8", "--r", "16"), "vanilla"),
@@ -462,7 +501,13 @@ def test_secondary_workloads_are_listed_with_their_checks():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_worker.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
                           "--logm", "9", "--edge-factor", "8", "--r", "16"], env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
-    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    printed = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][0]
+    out = read_line(printed)
+    # the printed line carries one row per entry — id, ms, frac — and the count of entries and failed checks
+    table = json.loads(printed)
+    assert [r["id"] for r in table["secondary"]] == [e["id"] for e in out["secondary"]] and table["secondary_checks"] == {"entries": 18, "failed": []}
+    assert all(set(r) <= {"id", "ms", "frac", "sddmm", "spmm", "frac_wall", "launches"} and r["ms"] > 0 for r in table["secondary"])
+    assert len(json.dumps(table["secondary"])) <= 1700
     sec = out["secondary"]
     assert len(sec) == 18 and not [e for e in sec if "error" in e], [e.get("error") for e in sec]
     by_name = {e["workload"]: e for e in sec}
@@ -505,4 +550,4 @@ def test_a_signal_before_the_first_measurement_still_leaves_one_json_line():
     lines = [ln for ln in out.splitlines() if ln.strip()]
     assert p.returncode == 143 and len(lines) == 1, (p.returncode, out)
     rec = json.loads(lines[0])
-    assert rec["value"] is None and "before its first complete measurement" in rec["error"]
+    assert rec["value"] is None and "before its first complete measurement" in rec["error"] and len(lines[0]) < LINE_LIMIT

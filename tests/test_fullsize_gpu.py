@@ -252,6 +252,11 @@ def test_config5_als_step_at_full_size(config2):
         # the reference's factors on 512 evenly spaced rows element by element, every row through the column sums (an error of
         # tolerance x max|A| in each element of a column is what the sums allow: the element-wise criterion, aggregated)
         idx = gold["rows"]
+        T.record_observed("als_fullsize", case="config 2 size, 15d_fusion2, 2 + 2 CG iterations",
+                          **{name: float(np.max(np.abs(got[idx] - gold[name])) / float(gold["absmax"][k])) for got, name, k in ((ga, "A", 0), (gb, "B", 1))},
+                          **{"colsum_" + name: float(np.max(np.abs(got.sum(axis=0) - gold["colsum_" + name])) / (float(gold["absmax"][k]) * m))
+                             for got, name, k in ((ga, "A", 0), (gb, "B", 1))},
+                          residuals=T.rel(np.array(residuals), gold["residuals"]))
         for got, name, k in ((ga, "A", 0), (gb, "B", 1)):
             top = float(gold["absmax"][k])
             assert np.max(np.abs(got[idx] - gold[name])) <= T.ALS_TOL * top, (name, np.max(np.abs(got[idx] - gold[name])) / top)
