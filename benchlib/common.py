@@ -84,7 +84,7 @@ def route_name(route):
     tr, c, mode, q = route
     mesh = ("mesh/heights %s" % q) if (q and "," in str(q)) else ("mesh/%s chunks" % q)
     return "c=%d %s [%s]" % (c, {"mesh": mesh, "relay": "relay ring", "none": "replication only",
-                                 "fusion1": "15d_fusion1 (replication reuse: SDDMM + SpMM, accumulator ring in two halves)"}[mode], tr)
+                                 "fusion1": "15d_fusion1 (replication reuse: SDDMM + SpMM, mesh fetch + mesh reduce-scatter)"}[mode], tr)
 
 
 def keyed(idx, salt):

@@ -183,7 +183,7 @@ def compose_line(args, b, res, extra):
     kernel_ms_per_step = res["kern_ms_slowest"] / res["prof_calls"]
     # one GPU: the dominant kernel's own rate (its launches are the step); several GPUs: the step's, exposed communication included
     achieved = achieved_kernel if n == 1 else achieved_step
-    ring_mode_now = None if (n == 1 or mode == "none") else ("accumulator ring (two halves)" if mode == "fusion1" else mode)
+    ring_mode_now = None if (n == 1 or mode == "none") else ("mesh fetch + mesh reduce-scatter" if mode == "fusion1" else mode)
     alg_now = "15d_fusion1" if mode == "fusion1" else args.alg
     step_is = {"vanilla": "fused SDDMM->SpMM (fusedSpMM, Amat)", "als": "one alternating ALS step by batched CG (run_cg(1): 24 fused calls)",
                "gat": "one GAT forward pass (3 layers, 14 heads, benchmark_dist.cpp:88-94)"}[args.app]
@@ -230,7 +230,7 @@ def compose_line(args, b, res, extra):
                      "kernel": ("row_kernel<fused>, 1 launch per Infinity-Cache panel of B" if n == 1 else
                                 "row_kernel<fused>, 1 launch per visiting block (relay ring)" if ring_mode_now == "relay" else
                                 "row_kernel<fused>, the rank's one block (replication only)" if ring_mode_now is None else
-                                "row_kernel<sddmm> + row_kernel<spmm> per visiting block (15d_fusion1)" if mode == "fusion1" else
+                                "row_kernel<sddmm> on row ranges + row_kernel<spmm> staging passes (15d_fusion1, mesh)" if mode == "fusion1" else
                                 "row_kernel<fused>: own block + adaptive windowed passes over fetched blocks"),
                      # device time of a kernel CALL (HIP events around it on the compute stream) divided by the row-kernel launches it made
                      # (structure plans are cached: a steady-state call launches row kernels only)

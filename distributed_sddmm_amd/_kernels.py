@@ -101,6 +101,8 @@ SIGNATURES = {
     "hnh_sddmm_csr_p": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _vp, _i32]),
     "hnh_sddmm_csr_ps": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _vp, _i32]),
     "hnh_spmm_csr_p": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32]),
+    "hnh_sum_chunked_blocks_f64": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32]),
+    "hnh_spmm_csr_pf": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _vp, _i32]),
     "hnh_fused_sddmm_spmm_csr_p": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_uint, _vp, _vp, _i32]),
 }
 

@@ -1127,6 +1127,42 @@ __global__ __launch_bounds__(kBlock) void axpy_kernel(double* y, const double* _
     }
 }
 
+// dst[i,:] += sum_k src[chunk-major row of (block k, row i), :] for the rows of chunks [q0, q1) — the closing step of the mesh
+// reduce-scatter (hnh_sum_chunked_blocks_f64): the nb partial blocks a rank has received are added to its own rows in block order
+// k = 0 .. nb - 1, whatever the launch geometry (bit-identical run to run).  Each thread owns one 16-byte piece of an output row and
+// keeps its nb + 1 loads in flight together.
+struct ChunkCuts {
+    long long cut[HNH_MAX_CHUNKS + 1];
+};
+template <bool VEC2>
+__global__ __launch_bounds__(kBlock) void sum_chunks_kernel(double* dst, const double* __restrict__ src, int nb, ChunkCuts cc, int q0, int q1, int R) {
+    const long long row0 = cc.cut[q0], row1 = cc.cut[q1];
+    constexpr int W = VEC2 ? 2 : 1;
+    const long long per_row = R / W, items = (row1 - row0) * per_row, stride = (long long)gridDim.x * kBlock;
+    for (long long t = (long long)blockIdx.x * kBlock + threadIdx.x; t < items; t += stride) {
+        const long long i = row0 + t / per_row;
+        const int col = (int)(t % per_row) * W;
+        int q = q0;
+        while (q + 1 < q1 && cc.cut[q + 1] <= i) q++;
+        const long long w = cc.cut[q + 1] - cc.cut[q];
+        const double* s = src + ((long long)nb * cc.cut[q] + (i - cc.cut[q])) * R + col;
+        double* d = dst + i * R + col;
+        if constexpr (VEC2) {
+            double2 acc = *reinterpret_cast<const double2*>(d);
+            for (int k = 0; k < nb; k++) {
+                const double2 v = *reinterpret_cast<const double2*>(s + (long long)k * w * R);
+                acc.x += v.x;
+                acc.y += v.y;
+            }
+            *reinterpret_cast<double2*>(d) = acc;
+        } else {
+            double acc = *d;
+            for (int k = 0; k < nb; k++) acc += s[(long long)k * w * R];
+            *d = acc;
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void expand_rowptr_kernel(int64_t rows, const int32_t* __restrict__ rowptr,
                                                                int32_t* __restrict__ rowidx) {
     // one wave per row (rows are short on the target matrices)
@@ -2212,17 +2248,24 @@ int hnh_sddmm_csr_ps(hnh_ctx* ctx, const hnh_csr_block* b, double* values, const
                                                 values, scale, X, Y, nullptr, R, flags, Extras(), nullptr, window, b->plan));
 }
 
-int hnh_spmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* b, const double* values, const double* X, double* Out, int R, const hnh_csr_window* window,
-                   int stream) {
+int hnh_spmm_csr_pf(hnh_ctx* ctx, const hnh_csr_block* b, const double* values, const double* X, double* Out, int R, unsigned flags,
+                    const hnh_csr_window* window, int stream) {
     HNH_ENTER(ctx, stream);
     if (!b) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_spmm_csr_p: null block");
     if (int rc = check_common(ctx, b->rows, R, "hnh_spmm_csr_p")) return rc;
+    if (flags & ~HNH_FUSED_OUT_OVERWRITE) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_spmm_csr_pf: unknown flag");
+    if ((flags & HNH_FUSED_OUT_OVERWRITE) && window) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_spmm_csr_pf: a window of a block cannot overwrite its rows");
     if (b->rows == 0) return HNH_OK;
     if (!b->rowptr || !b->col_idx || !values || !X || !Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_spmm_csr_p: null pointer");
     if (X == Out) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_spmm_csr_p: X and Out alias");
     const Shape s = pick_shape(R, aligned16(X) && aligned16(Out));
     return dispatch_row<Op::kSpmm>(ctx, ctx->streams[stream], stream, s, b->rows, b->nnz, b->max_row_nnz, window ? -1 : b->cols, b->rowptr, b->col_idx,
-                                   const_cast<double*>(values), nullptr, X, nullptr, Out, R, 0u, Extras(), nullptr, window, b->plan);
+                                   const_cast<double*>(values), nullptr, X, nullptr, Out, R, flags, Extras(), nullptr, window, b->plan);
+}
+
+int hnh_spmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* b, const double* values, const double* X, double* Out, int R, const hnh_csr_window* window,
+                   int stream) {
+    return hnh_spmm_csr_pf(ctx, b, values, X, Out, R, 0u, window, stream);
 }
 
 int hnh_fused_sddmm_spmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* b, double* values, const double* svalues, const double* X, const double* Y,
@@ -2332,6 +2375,26 @@ int hnh_axpy_f64(hnh_ctx* ctx, double* y, const double* x, double alpha, int64_t
     hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n / 2 / kEwUnroll + 1)), dim3(kBlock), 0, ctx->streams[stream], y, x, alpha, n,
                        aligned16(y) && aligned16(x));
     return hnh::check_hip(ctx, hipGetLastError(), "axpy_kernel launch");
+}
+
+int hnh_sum_chunked_blocks_f64(hnh_ctx* ctx, double* dst, const double* src, int nblocks, int nchunks, const int64_t* cuts_host, int q0, int q1,
+                               int R, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (nblocks < 0 || nchunks < 1 || nchunks > HNH_MAX_CHUNKS || !cuts_host || q0 < 0 || q1 > nchunks || q0 > q1 || R <= 0)
+        return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sum_chunked_blocks_f64: bad argument");
+    ChunkCuts cc;
+    for (int q = 0; q <= nchunks; q++) {
+        cc.cut[q] = cuts_host[q];
+        if (cuts_host[q] < 0 || (q > 0 && cuts_host[q] < cuts_host[q - 1])) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sum_chunked_blocks_f64: cuts must not decrease");
+    }
+    const int64_t rows = cc.cut[q1] - cc.cut[q0];
+    if (rows == 0 || nblocks == 0) return HNH_OK;
+    if (!dst || !src) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_sum_chunked_blocks_f64: null pointer");
+    const bool vec = (R % 2 == 0) && aligned16(dst) && aligned16(src);
+    const int64_t items = rows * (vec ? R / 2 : R);
+    if (vec) hipLaunchKernelGGL(sum_chunks_kernel<true>, dim3(ew_grid(items)), dim3(kBlock), 0, ctx->streams[stream], dst, src, nblocks, cc, q0, q1, R);
+    else hipLaunchKernelGGL(sum_chunks_kernel<false>, dim3(ew_grid(items)), dim3(kBlock), 0, ctx->streams[stream], dst, src, nblocks, cc, q0, q1, R);
+    return hnh::check_hip(ctx, hipGetLastError(), "sum_chunks_kernel launch");
 }
 
 int hnh_rowdot_f64(hnh_ctx* ctx, const double* A, const double* B, double* out, int64_t rows, int R, int stream) {

@@ -29,7 +29,7 @@ struct Backend {
     HNH_FN(hnh_tuples_sort) HNH_FN(hnh_tuples_bucket_starts) HNH_FN(hnh_tuples_transform) HNH_FN(hnh_tuples_to_csr)
     HNH_FN(hnh_csr_window_bounds) HNH_FN(hnh_sddmm_csr_w) HNH_FN(hnh_spmm_csr_w) HNH_FN(hnh_fused_sddmm_spmm_csr_w) HNH_FN(hnh_tuples_remap_cols) HNH_FN(hnh_tuples_dedup_max) HNH_FN(hnh_tuples_take_strided)
     HNH_FN(hnh_panel_count) HNH_FN(hnh_generate_er_keys) HNH_FN(hnh_tuples_from_keys) HNH_FN(hnh_tuples_relabel)
-    HNH_FN(hnh_fill_f64) HNH_FN(hnh_hadamard_f64) HNH_FN(hnh_axpy_f64) HNH_FN(hnh_expand_rowptr)
+    HNH_FN(hnh_fill_f64) HNH_FN(hnh_hadamard_f64) HNH_FN(hnh_axpy_f64) HNH_FN(hnh_expand_rowptr) HNH_FN(hnh_sum_chunked_blocks_f64)
     HNH_FN(hnh_rowdot_f64) HNH_FN(hnh_row_scale_add_f64) HNH_FN(hnh_vec_add_scalar_f64) HNH_FN(hnh_vec_div_f64) HNH_FN(hnh_fill_hashed_f64)
     HNH_FN(hnh_gemm_f64) HNH_FN(hnh_leaky_relu_f64) HNH_FN(hnh_relu_store_cols_f64)
     HNH_FN(hnh_comm_unique_id) HNH_FN(hnh_comm_init) HNH_FN(hnh_comm_split) HNH_FN(hnh_comm_destroy) HNH_FN(hnh_comm_identity)
@@ -37,7 +37,7 @@ struct Backend {
     HNH_FN(hnh_comm_allreduce_f64)
     HNH_FN(hnh_ipc_export) HNH_FN(hnh_ipc_open) HNH_FN(hnh_ipc_close) HNH_FN(hnh_ipc_pull) HNH_FN(hnh_ipc_flags_register) HNH_FN(hnh_ipc_flags_unregister)
     HNH_FN(hnh_stream_write_flag) HNH_FN(hnh_stream_wait_flag)
-    HNH_FN(hnh_csr_plan_create) HNH_FN(hnh_csr_plan_destroy) HNH_FN(hnh_sddmm_csr_p) HNH_FN(hnh_sddmm_csr_ps) HNH_FN(hnh_spmm_csr_p) HNH_FN(hnh_fused_sddmm_spmm_csr_p)
+    HNH_FN(hnh_csr_plan_create) HNH_FN(hnh_csr_plan_destroy) HNH_FN(hnh_sddmm_csr_p) HNH_FN(hnh_sddmm_csr_ps) HNH_FN(hnh_spmm_csr_p) HNH_FN(hnh_spmm_csr_pf) HNH_FN(hnh_fused_sddmm_spmm_csr_p)
 #ifdef HNH_MEASUREMENT_AIDS
     HNH_FN(hnh_stream_delay_us) HNH_FN(hnh_stream_paced_copy) HNH_FN(hnh_stream_pace_begin) HNH_FN(hnh_stream_pace_end)
 #endif

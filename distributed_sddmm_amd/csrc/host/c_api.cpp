@@ -509,6 +509,10 @@ int hnh_dist_reset_timers(hnh_dist* d) {
     return guarded(d->w, [&] { d->d->reset_performance_timers(); });
 }
 int hnh_dist_kernel_profile(hnh_dist* d, int enable, double* total_ms, int64_t* launches) {
+    {
+        const int st = guarded(d->w, [&] { d->kernel->resolve_profile(); });  // the pairs recorded so far are read here, not inside the calls
+        if (st != HNH_OK) return st;
+    }
     if (total_ms) *total_ms = d->kernel->kernel_ms;
     if (launches) *launches = d->kernel->kernel_launches;
     if (enable >= 0) {

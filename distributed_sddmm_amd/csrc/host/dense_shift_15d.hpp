@@ -77,6 +77,23 @@ public:
     bool merge_windows = true;
     int merge_cap = 1 << 20;
     bool merged = false;
+    // ROW-MERGED layout (round 6: approach 1 — replication reuse — under the mesh fetch).  The visiting blocks of approach 1 are
+    // stored transposed (15D_dense_shift.hpp:141: rows of a block = rows of the MOVING operand, columns = rows of the stationary one),
+    // so the same relabelling of the moving operand's rows to "own block | landing-buffer row" makes all fetched blocks ONE transposed
+    // CSR block whose ROWS are the rows of the chunk-major landing buffer: chunk q of every fetched block is the contiguous row range
+    // [(n-1) cut[q], (n-1) cut[q+1]).
+    //   SDDMM (moving operand read-only): mesh fetch as in approach 2, then own block + one pass per ROW RANGE of landed chunks
+    //   (CSRLocal::select_row_range) — rows, not column windows, so nothing is re-streamed and taking several landed chunks in one
+    //   pass costs nothing (the reference: one kernel per visiting block behind each shift, :343-356);
+    //   SpMM (moving operand = the accumulator): MESH REDUCE-SCATTER instead of the ring — the rank computes its partial result for every
+    //   block into a chunk-major STAGING buffer, one pass per chunk, each followed by ONE group of n-1 explicit-peer transfers that
+    //   carries chunk q of every partial block straight to its owner (n-1 links at once; the ring moves the same bytes over one link,
+    //   block after block) while the next chunk's pass runs; the own block's pass accumulates into the caller's matrix while the last
+    //   group flies; the owner adds the n-1 partial blocks it received in ring-step order, chunk by chunk as they land
+    //   (hnh_sum_chunked_blocks_f64) — a fixed order, so results are bit-identical run to run.
+    // HNH_FUSION1_MESH=0 (or HNH_RING_MODE=relay, or a kernel plugin without handles_row_ranges()): the block-by-block ring of rounds 1-5.
+    bool row_merged = false;
+    DenseMatrix staging[2];      // [slot]: partial results for the n-1 other owners, chunk-major like the landing buffer
     int windows = 1;
     std::vector<int> taper;  // chunk heights in units of a "fine" chunk; empty = the symmetric default (1, 2, .., 2, 1)
     std::vector<int64_t> cutA, cutB;  // chunk boundaries (windows + 1 entries, rows of a visiting A / B block)
@@ -140,18 +157,21 @@ public:
         setRValue(R);
 
         merged = (fusionApproach == 2 && ring_mode == kMeshFetch && p / c > 1);
+        const bool f1_mesh = std::getenv("HNH_FUSION1_MESH") == nullptr || std::atoi(std::getenv("HNH_FUSION1_MESH")) != 0;
+        row_merged = (fusionApproach == 1 && ring_mode == kMeshFetch && p / c > 1 && f1_mesh && k->handles_row_ranges());
+        const bool chunked = merged || row_merged;
         // default: six chunks of heights (1, 2, 2, 2, 1, 1) / 9 — against paced transfers of 40 .. 100 GB/s per link it beats the
         // symmetric four (1, 2, 2, 1) / 6 of round 2 by 1 .. 6 % (a smaller last chunk: a fetch-bound call ends one last-chunk kernel
         // after the fetch) and loses 4 % to it only when the links are so fast that the kernels bind
         windows = 1;
-        if (merged) {
+        if (chunked) {
             taper = {1, 2, 2, 2, 1, 1};
             windows = (int)taper.size();
         }
         if (const char* q = std::getenv("HNH_MESH_CHUNKS")) {  // Q chunks of the symmetric shape (1, 2, .., 2, 1)
             const int v = std::atoi(q);
             if (v < 1 || v > 8) hnh::fatal("Error, HNH_MESH_CHUNKS must be between 1 and 8!");
-            if (merged) {
+            if (chunked) {
                 windows = v;
                 taper.clear();
             }
@@ -169,7 +189,7 @@ public:
                 if (*e2 != ',' && *e2 != 0) hnh::fatal("Error, HNH_MESH_TAPER must be a comma list of weights between 1 and 64!");
             }
             if (w.empty() || w.size() > 12) hnh::fatal("Error, HNH_MESH_TAPER takes 1 to 12 weights!");
-            if (merged) {
+            if (chunked) {
                 taper = w;
                 windows = (int)w.size();
             }
@@ -180,7 +200,7 @@ public:
         const uint64_t arows = (uint64_t)localArows * c, brows = (uint64_t)localBrows * c;
         S->localize(arows, 0);
         ST->localize(brows, 0);
-        if (merged) {
+        if (chunked) {
             lay_out_merged(S.get(), localBrows, cutB, fineB);
             lay_out_merged(ST.get(), localArows, cutA, fineA);
         } else {
@@ -192,13 +212,15 @@ public:
         ST->own_all_coordinates();
 
         const bool local_tpose = (fusionApproach == 1);
-        if (merged) {
+        if (chunked) {
             const int n = p / c;
             const std::vector<int64_t> wS = {localBrows, (int64_t)(n - 1) * localBrows}, wST = {localArows, (int64_t)(n - 1) * localArows};
-            S->initializeCSRBlocks(localArows * c, 0, -1, false, &wS);
-            ST->initializeCSRBlocks(localBrows * c, 0, -1, false, &wST);
-            set_chunk_windows(S.get(), cutB);
-            set_chunk_windows(ST.get(), cutA);
+            S->initializeCSRBlocks(localArows * c, 0, -1, local_tpose, &wS);
+            ST->initializeCSRBlocks(localBrows * c, 0, -1, local_tpose, &wST);
+            if (merged) {  // (row-merged: the chunks are row ranges of the transposed block, no window boundaries)
+                set_chunk_windows(S.get(), cutB);
+                set_chunk_windows(ST.get(), cutA);
+            }
         } else {
             S->initializeCSRBlocks(localArows * c, localBrows, -1, local_tpose);
             ST->initializeCSRBlocks(localBrows * c, localArows, -1, local_tpose);
@@ -387,11 +409,11 @@ private:
         if (remote != nullptr) {
             // walk_windows_when_held(): walk the windows although a held operand's blocks are already there, which lets one rank's
             // kernel sequence be timed without its peers (bench.py's rank-share entries, tools/rank_share_probe.py)
-            const bool by_window = kernel->handles_windows() && remote->n_windows > 1 && (!resident || force_windows);
+            const bool by_window = (row_merged ? windows > 1 : (kernel->handles_windows() && remote->n_windows > 1)) && (!resident || force_windows);
             if (!by_window) {
                 world->event_wait(event(8 + windows - 1), HNH_STREAM_COMPUTE);  // every chunk has landed
                 one(1, landing[slot], -1, -1, true);
-            } else if (!merge_windows || !kernel->handles_window_ranges() || (resident && force_one_chunk_per_pass)) {
+            } else if (!merge_windows || !(row_merged || kernel->handles_window_ranges()) || (resident && force_one_chunk_per_pass)) {
                 for (int q = 0; q < windows; q++) {
                     world->event_wait(event(8 + q), HNH_STREAM_COMPUTE);  // chunk q of every remote block has landed
                     one(1, landing[slot], q, q + 1, q == windows - 1);
@@ -558,6 +580,20 @@ public:
                 blk->values_fresh = false;
                 blk->window = blk->window_end = -1;
             });
+        } else if (row_merged && is_sddmm) {
+            // row-merged layout: the chunks [window, window_end) of the fetched blocks are ONE row range of the transposed block
+            const std::vector<int64_t>& cut = (choice == S.get()) ? cutB : cutA;
+            walk_merged(choice, Brole, [&](int block_id, DenseMatrix& Y, int window, int window_end, bool) {
+                CSRLocal* blk = choice->csr_blocks[block_id];
+                if (blk == nullptr) return;
+                if (window >= 0) blk->select_row_range((int64_t)(n - 1) * cut[(size_t)window], (int64_t)(n - 1) * cut[(size_t)window_end]);
+                blk->values_fresh = fresh;
+                kernel->triple_function(mode_temp, *choice, stationary, Y, block_id, 0);
+                blk->values_fresh = false;
+                blk->select_row_range(-1, -1);
+            });
+        } else if (row_merged) {
+            spmm_mesh_reduce_scatter(choice, Brole, stationary, mode_temp);
         } else if (moving_readonly) {
             ring_readonly(Brole, n, step);
         } else if (n > 1 && acc_halves && kernel->handles_row_parts()) {
@@ -586,6 +622,80 @@ private:
         if (m.rows() == rows && m.cols() == cols) return false;
         m = DenseMatrix(rows, cols);
         return true;
+    }
+
+    // SpMM of replication reuse as a MESH REDUCE-SCATTER (row-merged layout, see the class comment).  `home` is the caller's block of the
+    // output (the accumulator's home: the SpMM adds to what is there, sparse_kernels.cpp:95-121 with beta = 1), `stationary` the gathered
+    // operand.  Events: 28 + q  = the staging pass of chunk q is done (compute -> comm), 8 + q = chunk q of every partial block has
+    // landed (comm -> compute; the numbers the fetch uses: a landing buffer is either a fetch's or an exchange's at any one time).
+    void spmm_mesh_reduce_scatter(SpmatLocal* choice, DenseMatrix* home, DenseMatrix& stationary, KernelMode mode_temp) {
+        const int n = p / c;
+        const int slot = (choice == S.get()) ? 0 : 1;
+        const int br = slot == 0 ? localBrows : localArows;
+        const std::vector<int64_t>& cut = slot == 0 ? cutB : cutA;
+        ensure(staging[slot], (int64_t)(n - 1) * br, R);
+        ensure(landing[slot], (int64_t)(n - 1) * br, R);
+        if (held_slot == slot) held_slot = -1;  // the landing buffer is about to hold partial results, not a held operand's blocks
+        CSRLocal* remote = choice->csr_blocks[1];
+        CSRLocal* own = choice->csr_blocks[0];
+        const bool store = kernel->stores_fresh_output();
+        {
+            // the staging buffer's last readers (the previous call's sends) and the landing buffer's (its adds) are behind these
+            auto t = phase_begin("Cyclic Shift Time");
+            order(HNH_STREAM_COMM, HNH_STREAM_COMPUTE, 5);
+            order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);
+            phase_end(t);
+        }
+        if (remote == nullptr || !store) {
+            auto t = phase_begin("Computation Time");
+            staging[slot].setZero();  // no nonzero in any other rank's block (the partial results are zero), or a kernel that adds
+            phase_end(t);
+        }
+        for (int q = 0; q < windows; q++) {
+            const int64_t r0 = (int64_t)(n - 1) * cut[(size_t)q], r1 = (int64_t)(n - 1) * cut[(size_t)q + 1];
+            if (remote != nullptr && r1 > r0) {
+                auto t = phase_begin("Computation Time");
+                remote->select_row_range(r0, r1);
+                remote->out_fresh = store;
+                kernel->triple_function(mode_temp, *choice, stationary, staging[slot], 1, 0);
+                remote->out_fresh = false;
+                remote->select_row_range(-1, -1);
+                phase_end(t);
+            }
+            auto t = phase_begin("Cyclic Shift Time");
+            world->event_record(event(28 + q), HNH_STREAM_COMPUTE);
+            world->event_wait(event(28 + q), HNH_STREAM_COMM);
+            const int64_t w = cut[(size_t)q + 1] - cut[(size_t)q];
+            const size_t bytes = (size_t)w * (size_t)R * sizeof(double);
+            if (bytes > 0) {
+                world->group_begin();
+                for (int k = 1; k < n; k++)  // my partial result for the block I visit at step k goes to its owner, ring rank me - k; mine arrive from me + k
+                    world->sendrecv(grid->col_world, staging[slot].data() + landing_row(k, q, cut) * R, bytes, pMod(grid->rankInCol - k, n),
+                                    landing[slot].data() + landing_row(k, q, cut) * R, bytes, pMod(grid->rankInCol + k, n), HNH_STREAM_COMM);
+                world->group_end();
+            }
+            world->event_record(event(8 + q), HNH_STREAM_COMM);
+            phase_end(t);
+        }
+        {
+            auto t = phase_begin("Computation Time");  // the own block's share goes straight into the caller's rows, under the last transfers
+            if (own != nullptr) kernel->triple_function(mode_temp, *choice, stationary, *home, 0, 0);
+            phase_end(t);
+        }
+        // the n-1 partial blocks are added in ring-step order, chunk by chunk as they land; consecutive chunks that have landed together
+        // go in one launch (the host decides as late as it can, like the windowed passes of the fetch)
+        auto t = phase_begin("Computation Time");
+        for (int q = 0; q < windows;) {
+            int L = q + 1;
+            if (merge_windows)
+                while (L < windows && L - q < merge_cap && world->event_done(event(8 + L))) L++;
+            world->event_wait(event(8 + L - 1), HNH_STREAM_COMPUTE);
+            world->check(world->be->hnh_sum_chunked_blocks_f64(world->ctx, home->data(), landing[slot].data(), n - 1, windows, cut.data(), q, L, R,
+                                                               HNH_STREAM_COMPUTE),
+                         "hnh_sum_chunked_blocks_f64");
+            q = L;
+        }
+        phase_end(t);
     }
 
     // n kernel steps over a READ-ONLY moving operand on the neighbour ring: n-1 overlapped shifts, caller's buffer untouched.

@@ -12,7 +12,7 @@ size_t StandardKernel::sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
     size_t processed = 0;
     CSRLocal* blk = S.csr_blocks[block];
     if (blk == nullptr || blk->num_coords == 0) return processed;
-    double* Xptr = blk->transpose ? B.data() : A.data();
+    double* Xptr = (blk->transpose ? B.data() : A.data()) + blk->part_first_row() * A.cols();  // (a row range reads its own rows of the row operand)
     double* Yptr = blk->transpose ? A.data() : B.data();
     CSRHandle* active = blk->getActive();
     hnh::World* w = S.world;
@@ -28,7 +28,7 @@ size_t StandardKernel::sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
         end(w);
         return processed;
     }
-    if (A.cols() <= kCooSddmmMaxWidth && !fresh && scale == nullptr) {  // (the COO kernel accumulates: first visits take the storing CSR pass)
+    if (A.cols() <= kCooSddmmMaxWidth && !fresh && scale == nullptr && blk->range_sel < 0) {  // (the COO kernel accumulates: first visits take the storing CSR pass)
         // narrow operands, ACCUMULATING visit (the travelling blocks of 15d_sparse / 2.5D dense after their first step): several sparse
         // rows share a wave in the row kernel and the wave runs as long as its longest row; the COO kernel deals nonzeros out evenly
         // instead.  Re-measured in round 5 with the line-granular row loop (config-2 size, profiles/r05_kbench_narrow.log): accumulating
@@ -44,7 +44,7 @@ size_t StandardKernel::sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
         return processed;
     }
     w->check(w->be->hnh_sddmm_csr_ps(w->ctx, &desc, dst, scale, Xptr, Yptr, (int)A.cols(), fresh, nullptr, HNH_STREAM_COMPUTE), "hnh_sddmm_csr_ps");
-    end(w, profile ? w->be->hnh_panel_count(w->ctx, blk->rows, blk->num_coords, blk->cols, (int)A.cols(), blk->row_hint()) : 1);
+    end(w, profile ? w->be->hnh_panel_count(w->ctx, desc.rows, desc.nnz, desc.cols, (int)A.cols(), desc.max_row_nnz) : 1);
     return processed;
 }
 
@@ -69,8 +69,10 @@ size_t StandardKernel::spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B,
         end(w);
         return processed;
     }
-    w->check(w->be->hnh_spmm_csr_p(w->ctx, &desc, vals, X, Out, (int)A.cols(), nullptr, HNH_STREAM_COMPUTE), "hnh_spmm_csr_p");
-    end(w, profile ? w->be->hnh_panel_count(w->ctx, blk->rows, blk->num_coords, blk->cols, (int)A.cols(), blk->row_hint()) : 1);
+    // (a fresh output: the selected rows of Out are STORED, not added to — the staging rows of the mesh reduce-scatter are written once)
+    w->check(w->be->hnh_spmm_csr_pf(w->ctx, &desc, vals, X, Out, (int)A.cols(), blk->out_fresh ? HNH_FUSED_OUT_OVERWRITE : 0u, nullptr, HNH_STREAM_COMPUTE),
+             "hnh_spmm_csr_pf");
+    end(w, profile ? w->be->hnh_panel_count(w->ctx, desc.rows, desc.nnz, desc.cols, (int)A.cols(), desc.max_row_nnz) : 1);
     return processed;
 }
 
@@ -102,33 +104,44 @@ size_t StandardKernel::fused_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B
     w->check(w->be->hnh_fused_sddmm_spmm_csr_p(w->ctx, &desc, active->values, nullptr, A.data(), B.data(), Out.data(), (int)A.cols(), flags, extras,
                                                nullptr, HNH_STREAM_COMPUTE),
              "hnh_fused_sddmm_spmm_csr_p");
-    end(w, profile ? w->be->hnh_panel_count(w->ctx, blk->rows, blk->num_coords, blk->cols, (int)A.cols(), blk->row_hint()) : 1);
+    end(w, profile ? w->be->hnh_panel_count(w->ctx, desc.rows, desc.nnz, desc.cols, (int)A.cols(), desc.max_row_nnz) : 1);
     return 0;
 }
 
 void StandardKernel::begin(hnh::World* w) {
     if (!profile) return;
-    if (!ev0_) {
-        ev0_ = w->event_create();
-        ev1_ = w->event_create();
-        evw_ = w;
+    if (evw_ != nullptr && evw_ != w) hnh::fatal("Error, a profiled StandardKernel belongs to one world!");
+    evw_ = w;
+    if (used_ == pairs_.size()) {
+        if (used_ >= 4096) resolve_profile();  // (bounded: a very long profiled section reads its pairs now and reuses them)
+        else pairs_.emplace_back(w->event_create(), w->event_create());
     }
-    w->event_record(ev0_, HNH_STREAM_COMPUTE);
+    w->event_record(pairs_[used_].first, HNH_STREAM_COMPUTE);
 }
 
 void StandardKernel::end(hnh::World* w, long launches) {
     if (!profile) return;
-    w->event_record(ev1_, HNH_STREAM_COMPUTE);
-    w->check(w->be->hnh_event_sync(w->ctx, ev1_), "hnh_event_sync");
-    float ms = 0.f;
-    w->check(w->be->hnh_event_elapsed_ms(w->ctx, ev0_, ev1_, &ms), "hnh_event_elapsed_ms");
-    kernel_ms += ms;
+    w->event_record(pairs_[used_].second, HNH_STREAM_COMPUTE);
+    used_++;
     kernel_launches += launches;  // a row pass may run as several column-panel launches (hnh_panel_count)
 }
 
-StandardKernel::~StandardKernel() {
-    if (evw_) {
-        evw_->event_destroy(ev0_);
-        evw_->event_destroy(ev1_);
+void StandardKernel::resolve_profile() {
+    if (used_ == 0) return;
+    hnh::World* w = evw_;
+    w->check(w->be->hnh_event_sync(w->ctx, pairs_[used_ - 1].second), "hnh_event_sync");  // (same stream: the last pair completes last)
+    for (size_t k = 0; k < used_; k++) {
+        float ms = 0.f;
+        w->check(w->be->hnh_event_elapsed_ms(w->ctx, pairs_[k].first, pairs_[k].second, &ms), "hnh_event_elapsed_ms");
+        kernel_ms += ms;
     }
+    used_ = 0;
+}
+
+StandardKernel::~StandardKernel() {
+    if (evw_)
+        for (auto& pr : pairs_) {
+            evw_->event_destroy(pr.first);
+            evw_->event_destroy(pr.second);
+        }
 }

@@ -72,6 +72,15 @@ public:
     // an SDDMM (distributed_sparse.h:280's setValuesConstant) and mark every first visit instead.
     virtual bool overwrites_fresh_values() const { return false; }
 
+    // An implementation that honours CSRLocal::out_fresh says so here: the SpMM of rows whose output nobody has written yet STORES its sums,
+    // and the schedules skip zeroing such an output buffer first.
+    virtual bool stores_fresh_output() const { return false; }
+
+    // Row RANGES (CSRLocal::select_row_range): SDDMM / SpMM of rows [r0, r1) of a block — the row operand and the output are addressed
+    // from the range's first row (CSRLocal::part_first_row()).  An implementation that honours it says so here; for the others the 1.5D
+    // replication-reuse schedule keeps the reference's block-by-block ring.
+    virtual bool handles_row_ranges() const { return false; }
+
     // An implementation that honours CSRLocal::spmm_values and CSRLocal::sddmm_dst / sddmm_scale says so here: the schedules then
     // let stationary blocks read SValues in place (no setCSRValues copy) and write `SValues .* dots` straight into the result of an
     // SDDMM (no closing Hadamard pass).  Requires overwrites_fresh_values().
@@ -99,15 +108,20 @@ public:
 class StandardKernel : public KernelImplementation {
 public:
     // Accumulated device time of the kernels launched through this object, measured with HIP events on
-    // the compute stream when profiling is enabled (bench.py's roofline leg).
+    // the compute stream when profiling is enabled (bench.py's roofline leg).  The event pairs are only RECORDED while the calls
+    // run — the host never waits inside a profiled call, so a schedule whose control flow depends on what has completed when
+    // (the adaptive windows of the 1.5D dense shift) makes the same decisions profiled as timed — and are read by resolve_profile().
     bool profile = false;
     double kernel_ms = 0.0;
     long kernel_launches = 0;
+    void resolve_profile();  // waits for the recorded pairs and adds their elapsed times to kernel_ms
 
     bool handles_windows() const override { return true; }
     bool handles_window_ranges() const override { return true; }
     bool overwrites_fresh_values() const override { return true; }
     bool handles_row_parts() const override { return true; }
+    bool handles_row_ranges() const override { return true; }
+    bool stores_fresh_output() const override { return true; }
     bool borrows_value_arrays() const override { return true; }
     size_t sddmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, int block, int offset) override;
     size_t spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B, MatMode mode, int block) override;
@@ -116,8 +130,8 @@ public:
     ~StandardKernel() override;
 
 private:
-    void* ev0_ = nullptr;
-    void* ev1_ = nullptr;
+    std::vector<std::pair<void*, void*>> pairs_;  // (start, stop) events; the first `used_` are recorded and not yet read
+    size_t used_ = 0;
     hnh::World* evw_ = nullptr;
     void begin(hnh::World* w);
     void end(hnh::World* w, long launches = 1);

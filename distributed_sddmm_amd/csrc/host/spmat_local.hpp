@@ -78,6 +78,10 @@ public:
     // since the operation began), so a kernel that says overwrites_fresh_values() may store its results instead of adding to them
     // — and the schedule has skipped the zero fill.  Kernels that do not know the hint are never given unfilled values.
     bool values_fresh = false;
+    // The SpMM twin, set by a schedule around an SpMM whose output rows (of the selected row range) nobody has written yet: a kernel
+    // that says stores_fresh_output() stores the sums instead of adding them to what is there — and the schedule has skipped the zero
+    // fill of that buffer (the staging rows of 1.5D replication reuse's mesh reduce-scatter are each written exactly once).
+    bool out_fresh = false;
     // Borrowed value arrays.  A schedule whose kernel says borrows_value_arrays() may, for ONE operation on a block that never
     // shifts, point the kernels at slices of the CALLER's vectors instead of the block's own value array:
     //   spmm_values               the SpMM reads its nonzero values here — the copy of setCSRValues (SpmatLocal.hpp:571-579) is skipped;
@@ -229,6 +233,8 @@ public:
             world->dfree(buffer[t].row_idx);
         }
         if (static_plan) world->be->hnh_csr_plan_destroy(world->ctx, static_plan);
+        for (RowRange& rr : row_ranges)
+            if (rr.plan) world->be->hnh_csr_plan_destroy(world->ctx, rr.plan);
         for (hnh_csr_plan* pp : part_plan)
             if (pp) world->be->hnh_csr_plan_destroy(world->ctx, pp);
         for (RingIndex& ri : ring_index) {
@@ -294,7 +300,37 @@ public:
     int64_t part_rows0 = 0;
     int part_nnz0 = -1;  // nonzeros of part 0 (read back once, when the parts are first used)
     hnh_csr_plan* part_plan[2] = {nullptr, nullptr};
-    int64_t part_first_row() const { return row_part == 1 ? part_rows0 : 0; }
+    int64_t part_first_row() const { return range_sel >= 0 ? row_ranges[(size_t)range_sel].r0 : (row_part == 1 ? part_rows0 : 0); }
+    // Row RANGES (round 6): the same view for any rows [r0, r1) of a block that never shifts.  The row-merged layout of 1.5D replication
+    // reuse keeps all fetched blocks as ONE transposed CSR block whose rows are the rows of the chunk-major landing buffer: chunk q of
+    // every fetched block is then a contiguous row range, and a pass over the chunks that have landed is a pass over one range — no
+    // window boundaries, nothing re-streamed.  Each distinct range keeps its nonzero count (read back once) and its own plan.
+    struct RowRange {
+        int64_t r0, r1;
+        int nnz_before, nnz;
+        hnh_csr_plan* plan;
+    };
+    std::vector<RowRange> row_ranges;
+    int range_sel = -1;
+    void select_row_range(int64_t r0, int64_t r1) {
+        if (r0 < 0) {
+            range_sel = -1;
+            return;
+        }
+        if (shifting) hnh::fatal("Error, row ranges need a block whose index arrays keep their contents!");
+        if (r1 < r0 || r1 > rows) hnh::fatal("Error, row range outside the block!");
+        for (size_t k = 0; k < row_ranges.size(); k++)
+            if (row_ranges[k].r0 == r0 && row_ranges[k].r1 == r1) {
+                range_sel = (int)k;
+                return;
+            }
+        int32_t v[2] = {0, 0};
+        world->copy(&v[0], getActive()->rowStart + r0, sizeof(int32_t), HNH_COPY_D2H, HNH_STREAM_COMPUTE);
+        world->copy(&v[1], getActive()->rowStart + r1, sizeof(int32_t), HNH_COPY_D2H, HNH_STREAM_COMPUTE);
+        world->sync(HNH_STREAM_COMPUTE);
+        row_ranges.push_back(RowRange{r0, r1, v[0], v[1] - v[0], nullptr});
+        range_sel = (int)row_ranges.size() - 1;
+    }
     // whether this block can be run in row parts: its structure must keep its contents (never shifts, or ring-resident indices)
     bool supports_row_parts() const { return !shifting || !ring_index.empty(); }
     void select_row_part(int part) {
@@ -323,7 +359,13 @@ public:
         b.reserved = 0;
         b.rowptr = h->rowStart;
         b.col_idx = h->col_idx;
-        if (row_part >= 0) {
+        if (range_sel >= 0) {
+            RowRange& rr = row_ranges[(size_t)range_sel];
+            slot = &rr.plan;
+            b.rows = rr.r1 - rr.r0;
+            b.nnz = rr.nnz;
+            b.rowptr = h->rowStart + rr.r0;  // (row pointers are offsets into the block's col_idx / values: still valid)
+        } else if (row_part >= 0) {
             const bool ring = !ring_index.empty();
             slot = ring ? &ring_index[(size_t)active_slot].part_plan[row_part] : &part_plan[row_part];
             const int nnz0 = ring ? ring_index[(size_t)active_slot].part_nnz0 : part_nnz0;

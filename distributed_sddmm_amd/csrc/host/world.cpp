@@ -93,7 +93,7 @@ Backend* load_backend(const char* path_c) {
     HNH_BIND(hnh_tuples_sort) HNH_BIND(hnh_tuples_bucket_starts) HNH_BIND(hnh_tuples_transform) HNH_BIND(hnh_tuples_to_csr)
     HNH_BIND(hnh_csr_window_bounds) HNH_BIND(hnh_sddmm_csr_w) HNH_BIND(hnh_spmm_csr_w) HNH_BIND(hnh_fused_sddmm_spmm_csr_w) HNH_BIND(hnh_tuples_remap_cols) HNH_BIND(hnh_tuples_dedup_max) HNH_BIND(hnh_tuples_take_strided)
     HNH_BIND(hnh_panel_count) HNH_BIND(hnh_generate_er_keys) HNH_BIND(hnh_tuples_from_keys) HNH_BIND(hnh_tuples_relabel)
-    HNH_BIND(hnh_fill_f64) HNH_BIND(hnh_hadamard_f64) HNH_BIND(hnh_axpy_f64) HNH_BIND(hnh_expand_rowptr)
+    HNH_BIND(hnh_fill_f64) HNH_BIND(hnh_hadamard_f64) HNH_BIND(hnh_axpy_f64) HNH_BIND(hnh_expand_rowptr) HNH_BIND(hnh_sum_chunked_blocks_f64)
     HNH_BIND(hnh_rowdot_f64) HNH_BIND(hnh_row_scale_add_f64) HNH_BIND(hnh_vec_add_scalar_f64) HNH_BIND(hnh_vec_div_f64) HNH_BIND(hnh_fill_hashed_f64)
     HNH_BIND(hnh_gemm_f64) HNH_BIND(hnh_leaky_relu_f64) HNH_BIND(hnh_relu_store_cols_f64)
     HNH_BIND(hnh_comm_unique_id) HNH_BIND(hnh_comm_init) HNH_BIND(hnh_comm_split) HNH_BIND(hnh_comm_destroy) HNH_BIND(hnh_comm_identity)
@@ -101,7 +101,7 @@ Backend* load_backend(const char* path_c) {
     HNH_BIND(hnh_comm_allreduce_f64)
     HNH_BIND(hnh_ipc_export) HNH_BIND(hnh_ipc_open) HNH_BIND(hnh_ipc_close) HNH_BIND(hnh_ipc_pull) HNH_BIND(hnh_ipc_flags_register) HNH_BIND(hnh_ipc_flags_unregister)
     HNH_BIND(hnh_stream_write_flag) HNH_BIND(hnh_stream_wait_flag)
-    HNH_BIND(hnh_csr_plan_create) HNH_BIND(hnh_csr_plan_destroy) HNH_BIND(hnh_sddmm_csr_p) HNH_BIND(hnh_sddmm_csr_ps) HNH_BIND(hnh_spmm_csr_p) HNH_BIND(hnh_fused_sddmm_spmm_csr_p)
+    HNH_BIND(hnh_csr_plan_create) HNH_BIND(hnh_csr_plan_destroy) HNH_BIND(hnh_sddmm_csr_p) HNH_BIND(hnh_sddmm_csr_ps) HNH_BIND(hnh_spmm_csr_p) HNH_BIND(hnh_spmm_csr_pf) HNH_BIND(hnh_fused_sddmm_spmm_csr_p)
 #ifdef HNH_MEASUREMENT_AIDS
     HNH_BIND(hnh_stream_delay_us) HNH_BIND(hnh_stream_paced_copy) HNH_BIND(hnh_stream_pace_begin) HNH_BIND(hnh_stream_pace_end)
 #endif
@@ -700,6 +700,18 @@ void ThreadWorld::host_alltoallv(const void* send, const std::vector<size_t>& se
     release();
 }
 
+#ifdef HNH_MEASUREMENT_AIDS
+void ThreadWorld::group_begin() {
+    in_group_ = true;
+    group_us_ = 0.0;
+}
+void ThreadWorld::group_end() {
+    if (group_us_ > 0.0) check(be->hnh_stream_pace_end(ctx, group_stream_, group_us_), "hnh_stream_pace_end");
+    in_group_ = false;
+    group_us_ = 0.0;
+}
+#endif
+
 void ThreadWorld::sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst_idx, void* recvbuf, size_t recvbytes,
                            int src_idx, int stream) {
     if (solo_) {  // the message this rank would receive = a copy of the one it would send
@@ -741,6 +753,14 @@ void ThreadWorld::sendrecv(const Comm& comm, const void* sendbuf, size_t sendbyt
         if (const char* pace = std::getenv("HNH_PACE_LINK_GBPS")) {
             const double gbps = std::atof(pace);
             if (gbps > 0.0) pace_us = (double)recvbytes / (gbps * 1e3);
+        }
+        // The messages of ONE group (group_begin .. group_end) go to different peers over different links and travel together: the group
+        // as a whole takes as long as its longest message, not their sum (clock stamped before the first copy, stream held at group_end).
+        if (pace_us > 0.0 && in_group_) {
+            if (group_us_ == 0.0) check(be->hnh_stream_pace_begin(ctx, stream), "hnh_stream_pace_begin");
+            group_us_ = std::max(group_us_, pace_us);
+            group_stream_ = stream;
+            pace_us = 0.0;
         }
         if (pace_us > 0.0) check(be->hnh_stream_pace_begin(ctx, stream), "hnh_stream_pace_begin");
 #endif

@@ -201,6 +201,14 @@ public:
     ~ThreadWorld() override;
     const char* kind() const override { return "thread-loopback"; }
     void set_solo(bool on) override { solo_ = on; }
+#ifdef HNH_MEASUREMENT_AIDS
+    // (measurement build only) a group's paced messages travel together: see sendrecv
+    void group_begin() override;
+    void group_end() override;
+    bool in_group_ = false;
+    double group_us_ = 0.0;
+    int group_stream_ = 0;
+#endif
     void sendrecv(const Comm& comm, const void* sendbuf, size_t sendbytes, int dst, void* recvbuf, size_t recvbytes,
                   int src, int stream) override;
     void barrier() override;

@@ -209,6 +209,14 @@ int hnh_fill_f64(hnh_ctx* ctx, double* dst, int64_t n, double value, int stream)
 int hnh_hadamard_f64(hnh_ctx* ctx, double* out, const double* a, const double* b, int64_t n, int stream);
 int hnh_axpy_f64(hnh_ctx* ctx, double* y, const double* x, double alpha, int64_t n, int stream);
 int hnh_expand_rowptr(hnh_ctx* ctx, int64_t rows, const int32_t* rowptr, int32_t* row_idx, int stream);
+/* The closing step of a mesh reduce-scatter (replaces the additions the reference's accumulator collects on its way round the ring,
+ * 15D_dense_shift.hpp:331-356): `src` holds `nblocks` partial copies of a block of cuts[nchunks] rows x R in CHUNK-MAJOR order — the
+ * rows [cuts[q], cuts[q+1]) of block k start at row nblocks * cuts[q] + k * (cuts[q+1] - cuts[q]) — and
+ *     dst[i,:] += src(block 0, row i) + src(block 1, row i) + ... (in block order)   for the rows i of chunks [q0, q1).
+ * cuts_host: nchunks + 1 non-decreasing row numbers on the HOST, cuts[0] = 0; nchunks <= HNH_MAX_CHUNKS. */
+#define HNH_MAX_CHUNKS 12
+int hnh_sum_chunked_blocks_f64(hnh_ctx* ctx, double* dst, const double* src, int nblocks, int nchunks, const int64_t* cuts_host, int q0, int q1,
+                               int R, int stream);
 
 /* ---- setup on the device: routing, ordering and CSR conversion of the matrix's (row, col, value) tuples ---------------
  * Replaces host code of the reference's SpmatLocal.hpp: getOwner + the Alltoallv pack (:45-52, :404-420), the
@@ -345,6 +353,12 @@ int hnh_sddmm_csr_ps(hnh_ctx* ctx, const hnh_csr_block* block, double* dst, cons
                      int R, unsigned flags, const hnh_csr_window* window, int stream);
 int hnh_spmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* block, const double* values, const double* X, double* Out, int R,
                    const hnh_csr_window* window, int stream);
+/* hnh_spmm_csr_pf: hnh_spmm_csr_p with flags.  HNH_FUSED_OUT_OVERWRITE = the output rows are known to hold nothing yet — a staging
+ * buffer that every row of the block writes exactly once — so Out[i,:] = sum is STORED instead of read, added to and stored (the
+ * reference's mkl_sparse_d_mm call has beta = 1, sparse_kernels.cpp:95-121, onto a buffer it zeroed; here neither the zero fill nor the
+ * read happen).  Rows without nonzeros store zeros.  flags == 0: hnh_spmm_csr_p. */
+int hnh_spmm_csr_pf(hnh_ctx* ctx, const hnh_csr_block* block, const double* values, const double* X, double* Out, int R, unsigned flags,
+                    const hnh_csr_window* window, int stream);
 int hnh_fused_sddmm_spmm_csr_p(hnh_ctx* ctx, const hnh_csr_block* block, double* values, const double* svalues, const double* X,
                                const double* Y, double* Out, int R, unsigned flags, const hnh_fused_extras* extras,
                                const hnh_csr_window* window, int stream);

@@ -756,6 +756,27 @@ int hnh_expand_rowptr(hnh_ctx* c, int64_t rows, const int32_t* rowptr, int32_t* 
     return HNH_OK;
 }
 
+int hnh_sum_chunked_blocks_f64(hnh_ctx* c, double* dst, const double* src, int nblocks, int nchunks, const int64_t* cuts, int q0, int q1, int R,
+                               int stream) {
+    if (nblocks < 0 || nchunks < 1 || nchunks > HNH_MAX_CHUNKS || !cuts || q0 < 0 || q1 > nchunks || q0 > q1 || R <= 0)
+        return fail(c, HNH_ERR_INVALID, "hnh_sum_chunked_blocks_f64: bad argument");
+    if (cuts[q1] == cuts[q0] || nblocks == 0) return HNH_OK;
+    if (!dst || !src) return fail(c, HNH_ERR_INVALID, "null pointer");
+    HB_OP(c, stream, "hnh_sum_chunked_blocks_f64");
+    HB_W(dst + cuts[q0] * R, (size_t)(cuts[q1] - cuts[q0]) * R * sizeof(double));
+    HB_R(src + (int64_t)nblocks * cuts[q0] * R, (size_t)nblocks * (size_t)(cuts[q1] - cuts[q0]) * R * sizeof(double));
+    for (int q = q0; q < q1; q++) {
+        const int64_t w = cuts[q + 1] - cuts[q];
+        for (int64_t i = 0; i < w; i++)
+            for (int k = 0; k < R; k++) {
+                double acc = dst[(cuts[q] + i) * R + k];
+                for (int b = 0; b < nblocks; b++) acc += src[((int64_t)nblocks * cuts[q] + (int64_t)b * w + i) * R + k];
+                dst[(cuts[q] + i) * R + k] = acc;
+            }
+    }
+    return HNH_OK;
+}
+
 /* als_conjugate_gradients.cpp:9-11 */
 int hnh_rowdot_f64(hnh_ctx* c, const double* A, const double* B, double* out, int64_t rows, int R, int stream) {
     HB_OP(c, stream, "hnh_rowdot_f64");
@@ -1505,6 +1526,19 @@ int hnh_sddmm_csr_ps(hnh_ctx* c, const hnh_csr_block* b, double* dst, const doub
 }
 int hnh_spmm_csr_p(hnh_ctx* c, const hnh_csr_block* b, const double* values, const double* X, double* Out, int R, const hnh_csr_window* w, int stream) {
     if (!b) return fail(c, HNH_ERR_INVALID, "null block");
+    return hnh_spmm_csr_w(c, b->rows, b->rowptr, b->col_idx, values, X, Out, R, b->nnz, b->max_row_nnz, w ? w : &whole_block, stream);
+}
+int hnh_spmm_csr_pf(hnh_ctx* c, const hnh_csr_block* b, const double* values, const double* X, double* Out, int R, unsigned flags,
+                    const hnh_csr_window* w, int stream) {
+    if (!b) return fail(c, HNH_ERR_INVALID, "null block");
+    if (flags & ~HNH_FUSED_OUT_OVERWRITE) return fail(c, HNH_ERR_INVALID, "hnh_spmm_csr_pf: unknown flag");
+    if ((flags & HNH_FUSED_OUT_OVERWRITE) && w) return fail(c, HNH_ERR_INVALID, "hnh_spmm_csr_pf: a window of a block cannot overwrite its rows");
+    if ((flags & HNH_FUSED_OUT_OVERWRITE) && b->rows > 0) {  /* the stored rows start from nothing: what was there is never read */
+        if (!Out) return fail(c, HNH_ERR_INVALID, "null pointer");
+        HB_OP(c, stream, "hnh_spmm_csr_pf (store)");
+        HB_W(Out, (size_t)b->rows * R * sizeof(double));
+        memset(Out, 0, sizeof(double) * (size_t)b->rows * (size_t)R);
+    }
     return hnh_spmm_csr_w(c, b->rows, b->rowptr, b->col_idx, values, X, Out, R, b->nnz, b->max_row_nnz, w ? w : &whole_block, stream);
 }
 int hnh_fused_sddmm_spmm_csr_p(hnh_ctx* c, const hnh_csr_block* b, double* values, const double* svalues, const double* X, const double* Y,

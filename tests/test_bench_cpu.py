@@ -11,44 +11,7 @@ import pytest
 
 from test_gloo_world import ROOT, free_port
 
-LINE_LIMIT = 8192  # bytes; the driver reads the result out of a bounded tail of the run's output (BENCH_r05: a 19 KB line, parsed: null)
-
-
-def _no_constants(name):
-    raise ValueError("not strict JSON: %s" % name)
-
-
-def read_line(text, want_record=True):
-    """The ONE line a run prints: at most LINE_LIMIT bytes, strict JSON (no NaN / Infinity), every string bounded, the contract's keys —
-    checked for every line any test of this file sees.  Returns the run's FULL record, which the line names in `full_record`
-    (benchlib/line.py: the line is the record's bounded form), so that the tests below keep reading every detail."""
-    assert len(text.encode()) + 1 <= LINE_LIMIT, len(text)
-    line = json.loads(text, parse_constant=_no_constants)
-    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
-        assert key in line, key
-    assert "workload" in line["config"]
-
-    def strings(v):
-        if isinstance(v, str):
-            yield v
-        elif isinstance(v, dict):
-            for k, x in v.items():
-                yield k
-                yield from strings(x)
-        elif isinstance(v, list):
-            for x in v:
-                yield from strings(x)
-    assert max(len(x) for x in strings(line)) <= 300
-    if line.get("value") is not None:
-        assert "roofline" in line and {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
-    if not want_record:
-        return line
-    assert "full_record" in line, sorted(line)
-    with open(line["full_record"] if os.path.isabs(line["full_record"]) else os.path.join(ROOT, line["full_record"])) as f:
-        rec = json.load(f)
-    for key in ("value", "n_gpus", "steps", "ms_per_step"):  # the line IS the record, shortened
-        assert rec.get(key) == line.get(key), key
-    return rec
+from bench_line import LINE_LIMIT, read_line  # noqa: E402,F401
 
 
 @pytest.mark.parametrize("nranks,alg,c,ring", [(1, "15d_fusion2", 1, None), (2, "15d_fusion2", 1, None), (4, "15d_fusion2", 1, None),
@@ -99,7 +62,7 @@ def test_bench_contract(nranks, alg, c, ring):
             if ring != "mesh":
                 want.add("c=%d relay ring" % k)
             if ring is None:  # the schedule's other fusion strategy joins the search when nothing fixes the route
-                want.add("c=%d 15d_fusion1 (replication reuse: SDDMM + SpMM, accumulator ring in two halves)" % k)
+                want.add("c=%d 15d_fusion1 (replication reuse: SDDMM + SpMM, mesh fetch + mesh reduce-scatter)" % k)
         tuned = alg == "15d_fusion2" and len(want) > 1
         assert ("route_tuning_ms_per_step" in out["config"]) == tuned
         if tuned:
@@ -114,7 +77,7 @@ def test_bench_contract(nranks, alg, c, ring):
                 if out["config"]["c"] != int(bc[2:]):
                     return False
                 if broute.startswith("15d_fusion1"):
-                    return out["config"]["algorithm"] == "15d_fusion1" and out["config"]["ring_mode"].startswith("accumulator ring")
+                    return out["config"]["algorithm"] == "15d_fusion1" and out["config"]["ring_mode"].startswith("mesh fetch + mesh reduce")
                 return (out["config"]["algorithm"] == "15d_fusion2" and
                         out["config"]["ring_mode"] == {"relay ring": "relay", "replication only": None}.get(broute, "mesh") and
                         out["config"]["mesh_chunks"] == (broute.split("/", 1)[1].split(" ", 1)[-1 if "heights" in broute else 0] if broute.startswith("mesh") else None))

@@ -9,6 +9,7 @@ import sys
 import pytest
 
 from test_gloo_world import ROOT, free_port
+from bench_line import read_line
 
 pytestmark = pytest.mark.gpu
 
@@ -103,7 +104,7 @@ def test_bench_self_launch_on_real_gpus(n):
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
-    out = json.loads(lines[0])
+    out = read_line(lines[0])
     assert out["n_gpus"] == n and out["backend"] == "hip-gfx950" and out["check"]["ok"] and out["check"]["rows_checked"] == 1 << 16
     assert len(out["preflight"]["primitives_ok"]) == 9 and out["config"]["transport"] in ("rccl", "ipc-pull")
     assert all(v.startswith("ok") for v in out["config"]["transport_trials"].values()), out["config"]["transport_trials"]
@@ -128,7 +129,7 @@ def test_bench_processes_share_one_gpu(n):
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout[-2000:]
-    out = json.loads(lines[0])
+    out = read_line(lines[0])
     assert out["n_gpus"] == n and out["backend"] == "hip-gfx950" and out["config"]["transport"] == "ipc-pull" and "incomplete" not in out
     assert out["check"]["ok"] and out["check"]["rows_checked"] == 1 << 14 and out["check"]["rel_err"] <= 1e-11
     trials = out["config"]["transport_trials"]
@@ -156,7 +157,7 @@ def test_bench_under_torch_distributed_run_on_one_gpu():
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
-    out = json.loads(lines[0])
+    out = read_line(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["transport"] == "ipc-pull" and out["check"]["ok"] and "incomplete" not in out
     assert out["config"]["transport_trials"]["ipc"].startswith("ok (") and "trial failed" not in out["config"]["transport_trials"]["ipc"]
 
@@ -170,7 +171,7 @@ def test_bench_rccl_only_on_one_gpu_ends_with_an_error_line():
     assert res.returncode != 0
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout[-2000:]
-    out = json.loads(lines[0])
+    out = read_line(lines[0])
     assert out["value"] is None and "error" in out and out["n_gpus"] == 2
     assert any("transport" in ph for ph in out["phases"].values()), out
     assert "no usable device-to-device transport" in res.stderr
