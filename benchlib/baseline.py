@@ -76,7 +76,7 @@ def cpu_baseline(args, quick=False):
         t0 = time.perf_counter()
         rows, cols = H.generate_er(m, m, m * args.edge_factor, 12345)
         # The reference does not scale with the thread count on big hosts (2 x EPYC 9575F: 32 threads beat 64/128/256 and one MPI rank
-        # beats 4 .. 32 on every box so far, profiles/r01_cpu_baseline_sweep.log, BENCH_r04/r05), so a few counts are tried
+        # beats 4 .. 32 on every box so far, profiles/archive/r01_cpu_baseline_sweep.log, BENCH_r04/r05), so a few counts are tried
         counts = sorted({min(ncpu, 16), min(ncpu, 32), min(ncpu, 64)}) if not quick else [min(ncpu, 32)]
         res = RR.sweep(m, m, rows, cols, args.r, "15d_fusion2", 1, 1, True, args.cpu_trials, 2, counts, timeout=300.0)
         best = max(res["points"], key=lambda pt: pt["nnz_R_per_s"])

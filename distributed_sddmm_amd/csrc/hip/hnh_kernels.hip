@@ -202,7 +202,7 @@ constexpr bool fused_op(Op o) { return o == Op::kFused || o == Op::kFusedCg; }
 // graph (R-MAT 2^20, mean 85) rows of 256..1024 nonzeros walked by one wave each still cost 5 % (tail and imbalance inside
 // the CUs; 1024 -> 256: 12.29 -> 11.65 ms at R = 128, 26.1 -> 24.8 ms at R = 256); on a uniform matrix whose mean is that
 // long the same 256 would push every row through the segment path and lose the cache panels (Erdos-Renyi with 300 per row:
-// 44.0 -> 50.5 ms), hence "relative to the mean" (profiles/r02_kbench_rmat_longrow_threshold.log, r02_kbench_er_ef300_*).
+// 44.0 -> 50.5 ms), hence "relative to the mean" (profiles/archive/r02_kbench_rmat_longrow_threshold.log, r02_kbench_er_ef300_*).
 constexpr int kLongRowMin = 256;
 constexpr int kLongRowMax = 1024;
 constexpr int kLongSeg = 256;
@@ -391,7 +391,7 @@ __device__ __forceinline__ void process_row(int64_t row, int beg, int end, bool 
     if constexpr (NARROW) {
         // ---- narrow rows (R = 8 / 16 / 32: 16 / 8 / 4 sparse rows share a wave), line-granular CSR streams.
         // What bounds these widths is the number of 128-byte line requests that reach the fabric (about 55 G lines/s, counters in
-        // profiles/r03_narrow_R16_pmc_by_kernel.txt): every gathered dense row is one such request, and so is every piece of
+        // profiles/archive/r03_narrow_R16_pmc_by_kernel.txt): every gathered dense row is one such request, and so is every piece of
         // `colidx` / `values` a group touches — with 256 .. 512 groups per CU each walking its own sparse row, a stream line is
         // long gone from L1 AND L2 (4 MiB per XCD turn over in about 5 us) when the group's next trip comes back for its second
         // half, so the loop above fetches every stream line 2 .. 8 times (+26 % requests at R = 16).  Here a group moves through its
@@ -1568,10 +1568,10 @@ struct LongCtl {
 };
 
 // Occupancy of the row kernels.  The memory system serves scattered rows a little FASTER when fewer waves compete for it: the
-// pure-gather probe gains 2 % going from 8 to 2-3 waves per SIMD (profiles/r02_gather_probe_occupancy.log), and the row kernels,
+// pure-gather probe gains 2 % going from 8 to 2-3 waves per SIMD (profiles/archive/r02_gather_probe_occupancy.log), and the row kernels,
 // which register use would let run at 6-8 waves, gain 2-3 % at 4-5 on a uniform matrix (Erdos-Renyi, R = 32 / 128 / 256;
 // R = 64 loses 0.8 %) — but lose 9 % on a skewed one, where waves finish at very different times and more of them are needed
-// to keep the CU busy (profiles/r02_kbench_waves_cap_sweep.log).  So: blocks whose longest row is at most twice the mean, widths
+// to keep the CU busy (profiles/archive/r02_kbench_waves_cap_sweep.log).  So: blocks whose longest row is at most twice the mean, widths
 // that were measured to gain, 5 waves per SIMD.  A workgroup is one wave per SIMD, so the cap is an LDS request the kernel never
 // touches: 160 KiB / 5 per workgroup leaves room for exactly 5 of them on a CU.
 size_t row_occupancy_pad(const hnh_ctx* ctx, const Shape& s, int64_t rows, int64_t nnz, int max_row_nnz) {

@@ -135,14 +135,14 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
         if (v >= 1.0) ctx->panel_bytes = v;
     }
     // HNH_COMM_PRIORITY=1: the communication stream gets the highest priority the device offers.  Opt-in: on one GPU shared by 8
-    // logical ranks it makes no measurable difference (profiles/r02_loopback_p8_comm_priority.log).  A masked stream (below) is
+    // logical ranks it makes no measurable difference (profiles/archive/r02_loopback_p8_comm_priority.log).  A masked stream (below) is
     // created by hipExtStreamCreateWithCUMask, which takes neither a priority nor hipStreamNonBlocking: the mask supersedes both.
     int least = 0, greatest = 0;
     const bool has_priorities = std::getenv("HNH_COMM_PRIORITY") != nullptr &&
                                 hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least;
     // Compute units of the compute stream (HNH_COMM_CUS=<n>, default 0 = no mask).  The row kernels are bound by the memory side,
     // not by CUs: with 16 of the 256 CUs masked off their stream the fused pass and SpMM run 0.3-2 % FASTER depending on the box
-    // (fewer requesters queueing at the fabric; profiles/r03_kbench_cus_off_x_waves_cap.log, r04_job1_bench_masked_default.json),
+    // (fewer requesters queueing at the fabric; profiles/archive/r03_kbench_cus_off_x_waves_cap.log, r04_job1_bench_masked_default.json),
     // while arithmetic-heavier launches lose — the stand-alone SDDMM 5 %, the fp64 GEMM its share of the matrix cores.  With a
     // mask the library therefore decides per operation: streams[HNH_STREAM_COMPUTE] is masked and the entry points that want the
     // whole chip (hnh_sddmm_*, hnh_gemm_f64) fork onto `wide`, an unmasked stream, and join back (hnh::WideLaunch) — callers keep

@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE (oracle tooling): the compiled reference's fused throughput vs (MPI ranks x OpenMP/MKL threads)
-on this box — how the thread counts tried by bench.py's cpu_baseline leg were chosen (profiles/r01_cpu_baseline_sweep.log)."""
+on this box — how the thread counts tried by bench.py's cpu_baseline leg were chosen (profiles/archive/r01_cpu_baseline_sweep.log)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distributed_sddmm_amd import api as H

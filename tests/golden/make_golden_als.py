@@ -36,7 +36,15 @@ def main():
                                               "residuals": T.rel(res["residuals"], canon["residuals"])}
             print(name, alg, p, c, dev["%s p%d c%d" % (alg, p, c)], flush=True)
         manifest[name] = {"steps": STEPS, "cg_iters": ITERS, "residuals": canon["residuals"].tolist(), "deviation_from_canonical": dev}
-    with open(os.path.join(HERE, "als_manifest.json"), "w") as f:
+    path = os.path.join(HERE, "als_manifest.json")
+    try:  # (what the asserting tests observed against these vectors — HNH_OBSERVED_LOG, see tests/hnh_testlib.py — is kept across regeneration)
+        with open(path) as f:
+            old = json.load(f)
+        if "observed_vs_reference" in old:
+            manifest["observed_vs_reference"] = old["observed_vs_reference"]
+    except (OSError, ValueError):
+        pass
+    with open(path, "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
 
 

@@ -8,7 +8,7 @@ Checkers (test infrastructure only):
     fullsize_cfg5_als.npz, written by tests/golden/make_golden_fullsize.py in the build container: minutes of host time that the
     GPU box no longer spends on every run).  HNH_LIVE_REFERENCE=1, or a missing fixture, runs the reference on this box instead.
 Tolerances: 1e-11 relative (fp64, only the summation order differs), 1e-9 for ALS factors (CG amplifies the summation-order
-differences; the reference's own five schedules differ by 1.2e-11 after two steps, tests/golden/als_manifest.json)."""
+differences; the reference's own five schedules differ by 1.14e-11, ALS_TOL = 10 x that; tests/golden/als_manifest.json)."""
 import numpy as np
 import pytest
 
@@ -16,7 +16,7 @@ import hnh_testlib as T
 from distributed_sddmm_amd import api as H
 
 pytestmark = pytest.mark.gpu
-# the reference does not scale beyond ~32 OpenMP/MKL threads on a big host (profiles/r01_cpu_baseline_sweep.log); with all 256
+# the reference does not scale beyond ~32 OpenMP/MKL threads on a big host (profiles/archive/r01_cpu_baseline_sweep.log); with all 256
 # hardware threads its full-size runs take three times as long
 REF_THREADS = min(32, __import__("os").cpu_count() or 1)
 LIVE_REFERENCE = __import__("os").environ.get("HNH_LIVE_REFERENCE") == "1"

@@ -122,6 +122,25 @@ def test_whole_accumulator_shifts_and_travelling_indices_agree_with_the_referenc
     T.check_against_golden(T.assemble(per_rank, case), per_rank, case, alg)
 
 
+@pytest.mark.parametrize("env", [{}, {"HNH_MESH_CHUNKS": "1"}, {"HNH_MESH_TAPER": "3,2,1"}, {"HNH_WINDOW_MERGE": "0"}, {"HNH_ORACLE_EVENTS_PENDING": "2"},
+                                 {"HNH_WINDOW_MERGE_CAP": "2", "HNH_ORACLE_EVENTS_PENDING": "3"},
+                                 {"HNH_FUSION1_MESH": "0"}, {"HNH_FUSION1_MESH": "0", "HNH_ACC_HALVES": "0"}])
+@pytest.mark.parametrize("p,c,case_name", [(4, 1, "er8_r16"), (8, 2, "ragged_r8"), (6, 3, "rect_r16"), (5, 1, "tiny_r8"), (2, 1, "ragged_r8")])
+def test_replication_reuse_on_the_mesh_and_on_the_ring_agree_with_the_reference(monkeypatch, env, p, c, case_name):
+    """15d_fusion1 (15D_dense_shift.hpp:276-384 with invert): round 6's default — row-merged transposed layout, the SDDMM as row-range passes
+    over the landed chunks of the mesh fetch, the SpMM as a mesh reduce-scatter (staging passes, one group of n - 1 transfers per chunk,
+    the received partial blocks added in ring-step order) — for chunk shapes and pass groupings (one pass per chunk; arrival queries that
+    answer "not yet" so that a pass takes fewer chunks), grids with remainders, null blocks; and the block-by-block rings it replaced
+    (HNH_FUSION1_MESH=0: accumulator in two halves / whole).  All against the reference's golden vectors."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    case = T.case_inputs(case_name)
+    if not T.valid_config("15d_fusion1", p, c, case["R"]):
+        pytest.skip("R not divisible for this grid")
+    per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, "15d_fusion1", c, case))
+    T.check_against_golden(T.assemble(per_rank, case), per_rank, case, "15d_fusion1")
+
+
 @pytest.mark.parametrize("mode", ["relay", "mesh"])
 @pytest.mark.parametrize("alg,p,c", [("15d_fusion2", 4, 1), ("15d_fusion2", 8, 1), ("15d_fusion2", 8, 2), ("15d_fusion1", 8, 1), ("15d_fusion1", 4, 1)])
 def test_relay_ring_and_mesh_fetch_agree_with_the_reference(monkeypatch, mode, alg, p, c):

@@ -89,7 +89,8 @@ def test_an_unordered_pair_is_a_race_and_an_event_orders_it(checker):
 
 
 STREAM_HEAVY = [("15d_fusion2", 4, 1, {}), ("15d_fusion2", 8, 2, {"HNH_MESH_TAPER": "3,4,4,3,2,1,1"}), ("15d_fusion2", 4, 1, {"HNH_RING_MODE": "relay"}),
-                ("15d_fusion1", 4, 1, {}), ("15d_fusion1", 6, 2, {"HNH_ACC_HALVES": "0"}), ("15d_sparse", 4, 1, {"HNH_SHIP_INDICES": "1"}),
+                ("15d_fusion1", 4, 1, {}), ("15d_fusion1", 8, 2, {"HNH_MESH_TAPER": "2,1"}),  # row-merged layout: row-range passes, mesh reduce-scatter
+                ("15d_fusion1", 4, 1, {"HNH_FUSION1_MESH": "0"}), ("15d_fusion1", 6, 2, {"HNH_FUSION1_MESH": "0", "HNH_ACC_HALVES": "0"}),  # the rings ("15d_sparse", 4, 1, {"HNH_SHIP_INDICES": "1"}),
                 ("25d_dense_replicate", 8, 2, {}), ("25d_sparse_replicate", 8, 2, {"HNH_BORROW": "force"}), ("25d_dense_replicate", 16, 4, {})]
 
 
@@ -123,14 +124,20 @@ def test_als_and_the_gat_pipeline_are_race_free(checker):
     assert n == 0, text
 
 
-def test_the_checker_sees_the_protocol(checker, monkeypatch):
+@pytest.mark.parametrize("windows", ["one pass per chunk", "adaptive, every query answers not yet"])
+def test_the_checker_sees_the_protocol(checker, monkeypatch, windows):
     """Sensitivity: the same schedules with every hnh_event_wait ignored BY THE CHECKER (the double computes as ever) are reported as
     racy — kernels against the transfers that fill and drain their operands, transfers against transfers — so silence above means the
     events are really there."""
     monkeypatch.setenv("HNH_ORDER_CHECK_DROP_WAITS", "1")
-    # (one windowed pass per chunk, ordered by event waits alone: with the adaptive windows the host ASKS whether a chunk's arrival event
-    # has completed before it enqueues the pass — in the double that answer is itself an edge, as a completed hipEventQuery is)
-    monkeypatch.setenv("HNH_WINDOW_MERGE", "0")
+    # With the adaptive windows the host ASKS whether a chunk's arrival event has completed before it enqueues the pass — in the double a
+    # "yes" is itself an edge, as a completed hipEventQuery is, and could stand in for a missing device-side wait.  Both ways of taking that
+    # edge away: one windowed pass per chunk (no queries), and the ADAPTIVE code path — its event_wait(event(8 + L - 1)), the ring of events
+    # 24..26 — with every query answering "not yet" (HNH_ORACLE_EVENTS_PENDING=1), so that ordering rests on the event waits alone.
+    if windows == "one pass per chunk":
+        monkeypatch.setenv("HNH_WINDOW_MERGE", "0")
+    else:
+        monkeypatch.setenv("HNH_ORACLE_EVENTS_PENDING", "1")
     case = T.case_inputs("er8_r16")
     seen = {}
     for alg, p, c in (("15d_fusion2", 4, 1), ("15d_fusion1", 4, 1), ("15d_sparse", 4, 1), ("25d_dense_replicate", 4, 1)):
@@ -168,13 +175,17 @@ print("done")
     assert r.returncode == 0
 
 
-def test_single_missing_waits_are_detected(checker, monkeypatch):
+@pytest.mark.parametrize("windows", ["one pass per chunk", "adaptive, every query answers not yet"])
+def test_single_missing_waits_are_detected(checker, monkeypatch, windows):
     """Fault injection one wait at a time: the k-th hnh_event_wait of a run is ignored by the checker, everything else as ever.  Measured
     over ALL waits of a run (round 4): 15d_fusion2 p = 2: 178 of 490 detected as a race, 15d_fusion1 p = 2: 171 of 332, 15d_sparse p = 2:
     138 of 324, 2.5D dense-replicate p = 4: 548 of 1318 — the others are implied by another path (e.g. the caching allocator orders a
     recycled block behind BOTH streams' last use; a stream that has nothing in flight waits for nothing).  Here: every 16th wait of one
     schedule; at least a fifth of the single faults must be seen."""
-    monkeypatch.setenv("HNH_WINDOW_MERGE", "0")  # (event waits alone order the windowed passes: see test_the_checker_sees_the_protocol)
+    if windows == "one pass per chunk":  # (event waits alone order the windowed passes: see test_the_checker_sees_the_protocol)
+        monkeypatch.setenv("HNH_WINDOW_MERGE", "0")
+    else:
+        monkeypatch.setenv("HNH_ORACLE_EVENTS_PENDING", "1")
     lib = ctypes.CDLL(T.ORACLE_BACKEND)
     lib.hnh_oracle_order_drop_wait.restype = ctypes.c_long
     lib.hnh_oracle_order_drop_wait.argtypes = [ctypes.c_long]
