@@ -133,6 +133,9 @@ public:
     VectorXd like_S_values(double value) override { return VectorXd::Constant((int64_t)ST->blockStarts[1], value); }
     VectorXd like_ST_values(double value) override { return VectorXd::Constant((int64_t)S->blockStarts[1], value); }
 
+    // the SpMM's accumulator starts at home holding nothing: step 0's kernel on every rank may store its rows (two-half ring only)
+    bool spmm_stores_output() const override { return sqrtpc > 1 && acc_halves && kernel->handles_row_parts() && kernel->stores_fresh_output(); }
+
     void algorithm(DenseMatrix& localA, DenseMatrix& localB, VectorXd& SValues, VectorXd* sddmm_result_ptr, KernelMode mode,
                    bool initial_replicate) override {
         SpmatLocal* choice;
@@ -145,6 +148,9 @@ public:
         }
         if ((uint64_t)SValues.size() != choice->blockStarts[1]) hnh::fatal("Error, sparse value vector has the wrong length!");
         const bool is_sddmm = (mode == k_sddmmA || mode == k_sddmmB);
+        // SpMM through spmmA / spmmB / fusedSpMM: the accumulator (Brole) has not been zeroed when this schedule said it stores (see
+        // spmm_stores_output()); a path below that cannot store zeroes it first
+        bool acc_unset = !is_sddmm && take_output_unset(*Brole);
 
         // (SDDMM: the travelling block's first visit — step 0, at home — may store instead of add, see CSRLocal::values_fresh)
         const bool fresh = is_sddmm && kernel->overwrites_fresh_values();
@@ -209,6 +215,9 @@ public:
             }
             if (s > 1) world->event_wait(event(1 + (s - 1) % 2), HNH_STREAM_COMPUTE);  // the sparse block is home again
         } else if (s > 1 && acc_halves && kernel->handles_row_parts() && blk != nullptr && blk->supports_row_parts()) {
+            const bool store0 = acc_unset && kernel->stores_fresh_output();
+            if (acc_unset && !store0) Brole->setZero();
+            acc_unset = false;
             // SpMM: the moving dense operand is the ACCUMULATOR, so its shift has to follow the kernel that wrote it
             // (25D_cannon_dense.hpp:274-302: kernel -> two shifts -> barrier).  In two row halves (CSRLocal::row_part) one half travels
             // under the other half's kernel:
@@ -226,7 +235,9 @@ public:
                 for (int part = 0; part < 2; part++) {
                     if (i > 0) world->event_wait(event(14 + part), HNH_STREAM_COMPUTE);    // this half of the accumulator has landed
                     blk->select_row_part(part);
+                    blk->out_fresh = store0 && i == 0;  // the accumulator's first kernel: its rows are stored, nobody zeroed them
                     kernel->triple_function(kmode, *choice, stationary, *act, 0, localAcols * grid->j);
+                    blk->out_fresh = false;
                     blk->select_row_part(-1);
                     world->event_record(event(10 + 2 * (i % 2) + part), HNH_STREAM_COMPUTE);
                 }
@@ -253,6 +264,8 @@ public:
             world->event_wait(event(15), HNH_STREAM_COMPUTE);
             bBuf.sync_active();
         } else {
+            if (acc_unset) Brole->setZero();
+            acc_unset = false;
             hnh::BufferPair bBuf(Brole, &ring_spare);
             for (int i = 0; i < s; i++) {
                 auto t = phase_begin("Computation Time");

@@ -165,7 +165,11 @@ public:
         // after the fetch) and loses 4 % to it only when the links are so fast that the kernels bind
         windows = 1;
         if (chunked) {
-            taper = {1, 2, 2, 2, 1, 1};
+            // (row-merged: three chunks (1, 2, 1) / 4 — a staging pass and its group of transfers per chunk; measured against six on 8
+            // logical ranks and paced links: 58 vs 75 ms per pair at 60 GB/s, 60 vs 75 at 100, and 4.95 vs 5.14 ms for one rank alone,
+            // profiles/r06_job3_overlap_accumulator_p8_chunk_shapes.log, r06_job2_fusion1_rank_share.log)
+            if (row_merged) taper = {1, 2, 1};
+            else taper = {1, 2, 2, 2, 1, 1};
             windows = (int)taper.size();
         }
         if (const char* q = std::getenv("HNH_MESH_CHUNKS")) {  // Q chunks of the symmetric shape (1, 2, .., 2, 1)

@@ -95,8 +95,8 @@ public:
             for (void* e : events_) world->be->hnh_event_destroy(world->ctx, e);
             for (void* e : spare_events_) world->be->hnh_event_destroy(world->ctx, e);
             for (auto& sp : spans_) {
-                world->be->hnh_event_destroy(world->ctx, sp.e0);
-                world->be->hnh_event_destroy(world->ctx, sp.e1);
+                if (sp.own0) world->be->hnh_event_destroy(world->ctx, sp.e0);
+                if (sp.own1) world->be->hnh_event_destroy(world->ctx, sp.e1);
             }
         }
     }
@@ -183,6 +183,7 @@ public:
         int stream = HNH_STREAM_COMPUTE;
         int key = -1;
         bool off = false;
+        bool own0 = true;  // the span recycles its start event (false: it belongs to the span that ended there)
         my_timer_t host;
     };
     // HNH_PERF_COUNTERS=0: the phases are counted but not timed (their event pairs are two thirds of the host's work in a call of
@@ -224,9 +225,50 @@ public:
         }
         void* e1 = take_event();
         world->event_record(e1, t.stream);
-        spans_.push_back({t.e0, e1, t.key});
+        spans_.push_back({t.e0, e1, t.key, t.own0, true});
         t.e0 = nullptr;
         if (spans_.size() > 2048) resolve_spans(spans_.size() / 2);  // old spans finished long ago: no stall to speak of
+    }
+    // SHARED BOUNDARY EVENTS (round 6: calls of config 1's size are host bound, and 38 hipEventRecord of 2.5 us were half of a fused
+    // call's host time).  A loop whose phases follow one another on a stream needs ONE event per boundary, not three: the end of a
+    // phase IS the ordering event the other stream waits for, and IS the start of the next phase on that stream.
+    //   phase_end_mark(t, slot)   ends the phase like phase_end() and returns the event recorded at its end, for the caller to use as
+    //                             its ordering event (timed: the span's end event; counters off or reference-like attribution: the
+    //                             pool's event(slot), recorded here) — valid for waits enqueued before the caller's next end_mark with
+    //                             the same slot;
+    //   phase_begin_at(name, e)   begins a phase at `e`, an event the caller has just had recorded on the phase's stream with nothing
+    //                             enqueued on that stream since (nullptr: phase_begin).
+    void* phase_end_mark(PhaseClock& t, size_t slot) {
+        const std::string& key = perf_counter_keys[(size_t)t.key];
+        const int stream = phase_stream(key);
+        if (t.off || t.e0 == nullptr) {
+            phase_end(t);
+            void* e = event(slot);
+            world->event_record(e, stream);
+            return e;
+        }
+        phase_end(t);
+        return spans_.back().e1;
+    }
+    PhaseClock phase_begin_at(const char* counter_name, void* at) {
+        if (at == nullptr || !perf_counters_on() || world->timing_sync) return phase_begin(counter_name);
+        PhaseClock t;
+        auto it = std::find(perf_counter_keys.begin(), perf_counter_keys.end(), counter_name);
+        if (it == perf_counter_keys.end()) hnh::fatal(std::string("Error, performance counter ") + counter_name + " not registered.");
+        t.key = (int)(it - perf_counter_keys.begin());
+        t.host = start_clock();
+        t.stream = phase_stream(*it);
+        t.e0 = at;
+        t.own0 = false;
+        // the span that ended at `at` hands the event's recycling over to this one (it is resolved first)
+        for (size_t k = spans_.size(); k-- > 0 && k + 8 > spans_.size();)
+            if (spans_[k].e1 == at && spans_[k].own1) {
+                spans_[k].own1 = false;
+                t.own0 = true;
+                break;
+            }
+        if (!t.own0) return phase_begin(counter_name);  // (not an event of a live span: nothing to share)
+        return t;
     }
 
     hnh::json json_perf_statistics() {  // mean over ranks, as distributed_sparse.h:245-261
@@ -254,11 +296,11 @@ public:
 
     // ---- the five convenience operations (distributed_sparse.h:274-312)
     void spmmA(DenseMatrix& localA, DenseMatrix& localB, VectorXd& SValues) {
-        localA.setZero();
+        prepare_spmm_output(localA);
         algorithm(localA, localB, SValues, nullptr, k_spmmA, true);
     }
     void spmmB(DenseMatrix& localA, DenseMatrix& localB, VectorXd& SValues) {
-        localB.setZero();
+        prepare_spmm_output(localB);
         algorithm(localA, localB, SValues, nullptr, k_spmmB, true);
     }
     void sddmmA(DenseMatrix& localA, DenseMatrix& localB, VectorXd& SValues, VectorXd& sddmm_result) {
@@ -273,11 +315,11 @@ public:
     virtual void fusedSpMM(DenseMatrix& localA, DenseMatrix& localB, VectorXd& Svalues, VectorXd& sddmm_buffer, MatMode mode) {
         if (mode == Amat) {
             algorithm(localA, localB, Svalues, &sddmm_buffer, k_sddmmA, true);
-            localA.setZero();
+            prepare_spmm_output(localA);
             algorithm(localA, localB, sddmm_buffer, nullptr, k_spmmA, false);
         } else if (mode == Bmat) {
             algorithm(localA, localB, Svalues, &sddmm_buffer, k_sddmmB, true);
-            localB.setZero();
+            prepare_spmm_output(localB);
             algorithm(localA, localB, sddmm_buffer, nullptr, k_spmmB, false);
         }
     }
@@ -375,11 +417,43 @@ protected:
         if (blk) blk->ring_max_row_nnz = *std::max_element(all.begin(), all.end());
     }
 
+    // The output of an SpMM.  spmmA / spmmB / the generic fusedSpMM zero it before they call algorithm() (distributed_sparse.h:284,293,303,
+    // 307), and some schedules zero it again at their start (15D_sparse_shift.hpp:216 `tmp *= 0`).  Here the wrapper ASKS the schedule:
+    //   spmm_stores_output() (a schedule whose SpMM stores every output row on first touch — its kernel says stores_fresh_output()):
+    //       nothing is filled; algorithm() is told that the matrix holds nothing yet (take_output_unset) and either stores, or — on a
+    //       path that cannot — zeroes it itself;
+    //   otherwise: the wrapper zeroes it and says so (take_output_zeroed), so that the schedule does not fill it a second time.
+    // One or two memsets per call, which a call of config 1's size notices (and 0.1 ms of config 4's rank).  algorithm() called directly:
+    // neither is set and everything is as in the reference.
+    virtual bool spmm_stores_output() const { return false; }
+    const double* output_zeroed_ = nullptr;
+    const double* output_unset_ = nullptr;
+    void prepare_spmm_output(DenseMatrix& out) {
+        output_zeroed_ = output_unset_ = nullptr;
+        if (spmm_stores_output()) {
+            output_unset_ = out.data();
+        } else {
+            out.setZero();
+            output_zeroed_ = out.data();
+        }
+    }
+    bool take_output_zeroed(const DenseMatrix& m) {
+        const bool yes = output_zeroed_ != nullptr && output_zeroed_ == m.data();
+        output_zeroed_ = nullptr;
+        return yes;
+    }
+    bool take_output_unset(const DenseMatrix& m) {
+        const bool yes = output_unset_ != nullptr && output_unset_ == m.data();
+        output_unset_ = nullptr;
+        return yes;
+    }
+
     // device-timed phases waiting to be resolved, and recycled events
     struct Span {
         void* e0;
         void* e1;
         int key;
+        bool own0, own1;  // which of the two this span hands back to the pool (a shared boundary event belongs to the later span)
     };
     std::vector<Span> spans_;
     std::vector<void*> spare_events_;
@@ -396,8 +470,8 @@ protected:
             world->check(world->be->hnh_event_sync(world->ctx, spans_[i].e1), "hnh_event_sync");
             world->check(world->be->hnh_event_elapsed_ms(world->ctx, spans_[i].e0, spans_[i].e1, &ms), "hnh_event_elapsed_ms");
             total_time[perf_counter_keys[(size_t)spans_[i].key]] += (double)ms * 1e-3;
-            spare_events_.push_back(spans_[i].e0);
-            spare_events_.push_back(spans_[i].e1);
+            if (spans_[i].own0) spare_events_.push_back(spans_[i].e0);
+            if (spans_[i].own1) spare_events_.push_back(spans_[i].e1);
         }
         spans_.erase(spans_.begin(), spans_.begin() + (long)count);
     }

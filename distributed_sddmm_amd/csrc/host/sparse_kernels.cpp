@@ -55,11 +55,17 @@ size_t StandardKernel::spmm_local(SpmatLocal& S, DenseMatrix& A, DenseMatrix& B,
     if (blk == nullptr) return processed;
     if (mode == Amat && blk->transpose) hnh::fatal("Error, local matrix is transposed, can't perform SpmmA");
     else if (mode == Bmat && !blk->transpose) hnh::fatal("Error, local matrix is not transposed, can't perform SpmmB");
-    if (blk->num_coords == 0) return processed;
     CSRHandle* active = blk->getActive();
     hnh::World* w = S.world;
     const double* X = (mode == Amat) ? B.data() : A.data();
     double* Out = ((mode == Amat) ? A.data() : B.data()) + blk->part_first_row() * A.cols();  // (a row part writes its own rows of the output)
+    if (blk->num_coords == 0) {  // nothing to multiply; fresh output rows still have to hold zeros afterwards
+        if (blk->out_fresh) {
+            const hnh_csr_block d0 = blk->block_args();
+            w->check(w->be->hnh_fill_f64(w->ctx, Out, d0.rows * A.cols(), 0.0, HNH_STREAM_COMPUTE), "hnh_fill_f64");
+        }
+        return processed;
+    }
     const double* vals = blk->spmm_values ? blk->spmm_values : active->values;  // (lent: the caller's SValues slice, read in place)
     begin(w);
     hnh_csr_window win;

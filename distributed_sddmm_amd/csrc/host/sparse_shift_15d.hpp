@@ -109,6 +109,8 @@ public:
     void initial_shift(DenseMatrix*, DenseMatrix*, KernelMode) override {}  // empty on purpose
     void de_shift(DenseMatrix*, DenseMatrix*, KernelMode) override {}       // empty on purpose
 
+    bool spmm_stores_output() const override { return kernel->stores_fresh_output(); }
+
     void algorithm(DenseMatrix& localA, DenseMatrix& localB, VectorXd& SValues, VectorXd* sddmm_result_ptr, KernelMode mode,
                    bool initial_replicate) override {
         DenseMatrix *Arole, *Brole;
@@ -142,12 +144,16 @@ public:
         // SDDMM: the travelling block accumulates partial dot products (R is split over the ring); its FIRST visit — step 0, at home —
         // may store instead of add when the kernel honours CSRLocal::values_fresh, and then nobody has to zero the values first
         const bool fresh = is_sddmm && kernel->overwrites_fresh_values();
+        // SpMM: every slab of the output is produced exactly once below (`tmp *= 0.0` in the reference): a kernel that stores fresh output
+        // rows needs no zero fill at all (the wrapper skipped its own, spmm_stores_output()); otherwise one fill, the wrapper's or this one
+        const bool zeroed = take_output_zeroed(*Arole), unset = take_output_unset(*Arole);
+        const bool store_out = !is_sddmm && unset && kernel->stores_fresh_output();
         if (!(is_sddmm && fresh)) {  // (a storing first visit needs no preparation at all)
             auto t = phase_begin("Computation Time");
             if (is_sddmm) choice->setValuesConstant(0.0);
             else {
                 choice->setCSRValues(SValues);
-                Arole->setZero();  // every slab is produced exactly once below (`tmp *= 0.0` in the reference)
+                if (!zeroed && !store_out) Arole->setZero();
             }
             phase_end(t);
         }
@@ -157,32 +163,39 @@ public:
         const int src = pMod(grid->i - 1, n), dst = pMod(grid->i + 1, n);
         if (n > 1) order(HNH_STREAM_COMPUTE, HNH_STREAM_COMM, 0);
 
+        // One event per phase boundary (phase_end_mark / phase_begin_at): "kernel i done" ends step i's computation phase, orders the
+        // shift behind it and begins step i + 1's computation phase; "shift i landed" ends its shift phase, orders kernel i + 1 and begins
+        // the next shift phase — 2 records per step instead of 6 (the reference's counters: distributed_sparse.h:212-223 around the
+        // same regions, 15D_sparse_shift.hpp:226-262).
+        void* kernel_done[2] = {nullptr, nullptr};  // by step parity
+        void* landed = nullptr;
         for (int i = 0; i < n; i++) {
-            auto t = phase_begin("Computation Time");
+            auto t = phase_begin_at("Computation Time", i > 0 ? kernel_done[(i - 1) % 2] : nullptr);
             const int block_id = pMod(grid->i - i, n);
             DenseMatrix slab = DenseMatrix::view(Arole->data() + (size_t)block_id * arBwidth * Arole->cols(), arBwidth, Arole->cols());
-            if (i > 0) world->event_wait(event(1 + (i - 1) % 2), HNH_STREAM_COMPUTE);  // shift i-1 landed
+            if (i > 0) world->event_wait(landed, HNH_STREAM_COMPUTE);  // shift i-1 landed
             blk->values_fresh = fresh && i == 0;
+            blk->out_fresh = store_out;
             kernel->triple_function(mode == k_spmmB ? k_spmmA : mode, *choice, slab, gathered, 0, 0);
-            blk->values_fresh = false;
-            phase_end(t);
-
-            if (n > 1) {
-                t = phase_begin("Cyclic Shift Time");
-                world->event_record(event(3 + i % 2), HNH_STREAM_COMPUTE);
-                // SDDMM writes the travelling values: ship after this step's kernel.  SpMM only reads the
-                // block: ship concurrently with this step's kernel, but not before the previous kernel has
-                // released the passive buffer.
-                if (is_sddmm) world->event_wait(event(3 + i % 2), HNH_STREAM_COMM);
-                else if (i >= 1) world->event_wait(event(3 + (i - 1) % 2), HNH_STREAM_COMM);
-                blk->shiftCSR(src, dst, grid->col_world, (*nnz_in_axis)[pMod(grid->i - i - 1, n)], 72, is_sddmm ? coo : csr,
-                              HNH_STREAM_COMM, pMod(grid->i - i - 1, n));
-                choice->blockStarts[1] = blk->num_coords;
-                world->event_record(event(1 + i % 2), HNH_STREAM_COMM);
+            blk->values_fresh = blk->out_fresh = false;
+            if (n == 1) {
                 phase_end(t);
+                break;
             }
+            kernel_done[i % 2] = phase_end_mark(t, 3 + i % 2);
+
+            t = phase_begin_at("Cyclic Shift Time", landed);
+            // SDDMM writes the travelling values: ship after this step's kernel.  SpMM only reads the
+            // block: ship concurrently with this step's kernel, but not before the previous kernel has
+            // released the passive buffer.
+            if (is_sddmm) world->event_wait(kernel_done[i % 2], HNH_STREAM_COMM);
+            else if (i >= 1) world->event_wait(kernel_done[(i - 1) % 2], HNH_STREAM_COMM);
+            blk->shiftCSR(src, dst, grid->col_world, (*nnz_in_axis)[pMod(grid->i - i - 1, n)], 72, is_sddmm ? coo : csr,
+                          HNH_STREAM_COMM, pMod(grid->i - i - 1, n));
+            choice->blockStarts[1] = blk->num_coords;
+            landed = phase_end_mark(t, 1 + i % 2);
         }
-        if (n > 1) world->event_wait(event(1 + (n - 1) % 2), HNH_STREAM_COMPUTE);  // block is home again
+        if (n > 1) world->event_wait(landed, HNH_STREAM_COMPUTE);  // block is home again
 
         if (is_sddmm) {
             auto t = phase_begin("Computation Time");
