@@ -164,9 +164,9 @@ class Workload:
 
     def describe(self, nnz):
         if self.kind == "er":
-            return "Erdos-Renyi 2^%d x 2^%d, edge factor %d (%d unique nnz)" % (self.logm, self.logm, self.ef, nnz)
+            return "Erdos-Renyi 2^%d, edge factor %d (%d nnz)" % (self.logm, self.ef, nnz)
         if self.kind == "rmat":
-            return "R-MAT 2^%d x 2^%d (a,b,c = .57,.19,.19), edge factor %d (%d unique nnz)" % (self.logm, self.logm, self.ef, nnz)
+            return "R-MAT 2^%d (a,b,c = .57,.19,.19), edge factor %d (%d nnz)" % (self.logm, self.ef, nnz)
         return "MatrixMarket file %s (%d nnz)" % (os.path.basename(self.path), nnz)
 
 

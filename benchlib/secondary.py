@@ -60,12 +60,15 @@ def secondary(args, b):
     if args.app == "vanilla" and b.op is not None:
         op, m, nnz = b.op, b.m, b.nnz
         host = b.wl.host_nonzeros(H)
-        for r in (8, 16, 128, 256):
+        for r in (8, 16, 128, 256, 512):
             def widths(r=r):
                 op.setRValue(r)
                 A, B = op.like_A_matrix(0.001), op.like_B_matrix(0.001)
                 S, buf = op.like_S_values(1.0), op.like_S_values(0.0)
                 res = {"R": r}
+                if r == 512:
+                    res["note"] = ("wide operands: the un-fused SDDMM / SpMM run as 128-column slabs (each slab = the R = 128 pass with row pitch R and its own "
+                                   "Infinity-Cache panels); the fused pass needs the whole dot product and stays one wide pass at the DRAM copy rate")
                 if r == 8:
                     res["note"] = ("a 64-byte dense row costs a whole 128-byte request between L2 and the fabric, and the row kernels are bound by the "
                                    "number of such requests (about 55 G/s at every width, DESIGN section 3.2): the byte model cannot exceed ~0.55 here")

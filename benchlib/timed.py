@@ -185,21 +185,21 @@ def compose_line(args, b, res, extra):
     achieved = achieved_kernel if n == 1 else achieved_step
     ring_mode_now = None if (n == 1 or mode == "none") else ("mesh fetch + mesh reduce-scatter" if mode == "fusion1" else mode)
     alg_now = "15d_fusion1" if mode == "fusion1" else args.alg
-    step_is = {"vanilla": "fused SDDMM->SpMM (fusedSpMM, Amat)", "als": "one alternating ALS step by batched CG (run_cg(1): 24 fused calls)",
-               "gat": "one GAT forward pass (3 layers, 14 heads, benchmark_dist.cpp:88-94)"}[args.app]
+    step_is = {"vanilla": "fused SDDMM->SpMM (fusedSpMM, Amat)", "als": "one ALS step by batched CG (run_cg(1): 24 fused calls)",
+               "gat": "one GAT forward pass (3 layers, 14 heads)"}[args.app]
     # where the ranks ran, from the ranks themselves: a line of N processes that shared fewer than N GPUs says so in its first sentence
     ranks = res.get("ranks") or []
     distinct = len({r["pci_bus_id"] for r in ranks}) or n
-    where = ("%d x MI355X" % n) if distinct == n else ("%d processes on %d x MI355X (ranks SHARE a GPU: time-sliced, not a scaling number)" % (n, distinct))
+    where = ("%d x MI355X" % n) if distinct == n else ("%d PROCESSES SHARING %d x MI355X (time-sliced: not a scaling number)" % (n, distinct))
     how = "" if n == 1 else ", %s (%s)" % (
-        {"rccl": "RCCL over xGMI", "ipc": "ipc-pull over mapped peer memory, copy engines", "ipc-kernel": "ipc-pull over mapped peer memory, pull kernel"}.get(tr, "transport: " + tr),
-        {"relay": "neighbour relay ring", "mesh": "chunked fetch from the owners", None: "replication only, nothing shifts"}.get(ring_mode_now, ring_mode_now))
+        {"rccl": "RCCL over xGMI", "ipc": "ipc-pull, copy engines", "ipc-kernel": "ipc-pull, pull kernel"}.get(tr, "transport: " + tr),
+        {"relay": "relay ring", "mesh": "chunked mesh fetch", None: "replication only"}.get(ring_mode_now, ring_mode_now))
     out = {
         "backend": H.backend_name(),
         "metric": "fused SDDMM+SpMM nnz*R/s", "value": value, "unit": "nnz*R/s", "n_gpus": n, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic" if b.wl.kind != "mtx" else "file",
-        "config": {"workload": "%s, R=%d, %s, %s c=%d on %s%s" % (b.wl.describe(b.nnz), args.r, step_is, alg_now, c_now, where, how),
+        "config": {"workload": "%s, R=%d, %s, %s c=%d on %s%s" % (b.wl.describe(b.nnz), args.r, step_is, alg_now, c_now, where, how),  # (<= 200 characters in the printed line)
                    "nnz": b.nnz, "M": b.m, "R": args.r, "algorithm": alg_now, "app": args.app, "c": c_now,
                    "transport": "none" if n == 1 else res["transport_kind"],
                    "transport_variant": None if n == 1 else tr, "ring_mode": ring_mode_now,

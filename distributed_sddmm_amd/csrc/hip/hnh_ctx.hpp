@@ -41,6 +41,8 @@ struct hnh_ctx {
     // launch sequence differs by more between boxes than between panel counts (profiles/r05_wide_panels*.log).  Six is never more than
     // 1-2 % from the best of any of them; R <= 384 is not affected (its natural count is at most six).
     int max_panels = 6;
+    bool wide_slabs = true;  // un-fused SDDMM / SpMM of R >= slab_min_r (a multiple of 128) run as 128-column slabs (HNH_WIDE_SLABS=0: one wide pass)
+    int slab_min_r = 320;    // HNH_SLAB_MIN_R (a multiple of 64 from here on is cut into slabs; 256 keeps its four panels: 93.3 vs 92.8 % SDDMM, 89.6 vs 93.3 % SpMM)
     // peer-to-peer pull (hnh_ipc.hip): auxiliary streams the copy-engine pulls of one group are spread over (created on first use),
     // the fork event recorded on the issuing stream and one join event per auxiliary stream
     static constexpr int kAuxStreams = 8;

@@ -1866,12 +1866,25 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
     // Infinity-Cache panels (see panel_split_kernel): single-pass widths only.  The mechanism handles hub rows (they stay
     // whole and go to the long-row pass once, after the last panel; HNH_PANELS_WITH_HUBS=1), but on skewed graphs the hot
     // columns are cache-resident anyway and panels cost 2.5 % (R-MAT 2^20: 6.85 -> 7.03 ms), so such blocks keep one launch.
-    const int panels = (single_pass && (!lc.enabled || ctx->panels_with_hubs)) ? panel_count(ctx, cols, R) : 1;
-    if (panels > 1) {
+    // WIDE OPERANDS IN 128-COLUMN SLABS (round 6; un-fused SDDMM / SpMM, R >= 320 a multiple of 64: slabs of 128 columns and a last one of 64).  At those widths the gathered operand is
+    // 3 - 4 GiB at config 2's size, nothing of it survives in the 256 MiB Infinity Cache and the pass runs at the DRAM copy rate (72 - 79 % of
+    // 8 TB/s whatever the panel count).  A slab of 128 columns IS the R = 128 problem with row pitch R: its panels are again
+    // 512 MiB of the gathered operand and every gather moves 1 KiB — so each slab runs as the R = 128 pass does (panels and all), slab after
+    // slab.  SpMM slabs are independent columns of the output; the SDDMM's slabs after the first ADD their partial dot products (16 B per
+    // nonzero and slab, and the index stream once more per slab: ~1 % of the slab's gathers).  The fused pass needs the whole dot before
+    // its second half and keeps its single pass.  HNH_WIDE_SLABS=0 restores the single wide pass.  Measured at config 2's size
+    // (profiles/r06_job5_kbench_wide_slabs.log): SpMM 84.2 -> 92.5 % of 8 TB/s at R = 384, 77.3 -> 91.9 % at R = 512; SDDMM 89.8 -> 92.1 %, 86.0 -> 92.0 %.
+    const int slab_w = (ctx->wide_slabs && (OP == Op::kSddmm || OP == Op::kSpmm) && s.w == 2 && R >= ctx->slab_min_r && R % 64 == 0) ? 128 : 0;
+    const int nslabs = slab_w ? (R + slab_w - 1) / slab_w : 1;
+    const int panels = slab_w ? ((!lc.enabled || ctx->panels_with_hubs) ? panel_count(ctx, cols, slab_w) : 1)
+                              : ((single_pass && (!lc.enabled || ctx->panels_with_hubs)) ? panel_count(ctx, cols, R) : 1);
+    if (panels > 1 || slab_w) {
         const size_t need = (size_t)(panels - 1) * (size_t)rows * sizeof(int32_t);
         const int width = (int)((cols + panels - 1) / panels);
         int32_t* split = nullptr;
-        if (plan != nullptr) {
+        if (panels == 1) {
+            // (one panel per slab: the rows' own boundaries)
+        } else if (plan != nullptr) {
             // the boundaries depend on the structure and (panels, width) only: computed once per block and width class
             hnh_csr_plan::Split* slot = nullptr;
             for (auto& sp : plan->splits)
@@ -1906,16 +1919,27 @@ int dispatch_row(hnh_ctx* ctx, hipStream_t st, int sidx, const Shape& s, int64_t
                                width, split);
             if (int rc = hnh::check_hip(ctx, hipGetLastError(), "panel_split_kernel launch")) return rc;
         }
-        for (int q = 0; q < panels; q++) {
-            const int32_t* beg_ptr = (q == 0) ? rowptr : split + (size_t)(q - 1) * rows;
-            const int32_t* end_ptr = (q == panels - 1) ? rowptr + 1 : split + (size_t)q * rows;
-            unsigned f = flags;
-            if (q > 0) f &= ~HNH_FUSED_OUT_OVERWRITE;  // later panels add to the rows the first one wrote
-            if (q == panels - 1) f |= epi;             // the last panel completes the rows
-            if (int rc = launch_closing<OP>(ctx, st, lc, s, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, f, ex,
-                                            q == panels - 1))
-                return rc;
-        }
+        for (int sl = 0; sl < nslabs; sl++)
+            for (int q = 0; q < panels; q++) {
+                const int32_t* beg_ptr = (q == 0) ? rowptr : split + (size_t)(q - 1) * rows;
+                const int32_t* end_ptr = (q == panels - 1) ? rowptr + 1 : split + (size_t)q * rows;
+                unsigned f = flags;
+                if (q > 0) f &= ~HNH_FUSED_OUT_OVERWRITE;  // later panels add to the rows the first one wrote
+                if (q == panels - 1) f |= epi;             // the last panel completes the rows
+                int rc;
+                if (slab_w) {
+                    if (sl > 0) f &= ~HNH_FUSED_VALUES_OVERWRITE;  // later slabs add their partial dot products
+                    if (R - sl * slab_w >= slab_w)
+                        rc = launch_row<OP, 64, 1, 2, true>(ctx, st, lc, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, sl * slab_w,
+                                                            slab_w, f, ex, q == panels - 1);
+                    else  // (the last 64 columns of a width that is an odd multiple of 64: the R = 64 instance, two rows per wave)
+                        rc = launch_row<OP, 32, 1, 2, true>(ctx, st, lc, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, sl * slab_w, 64,
+                                                            f, ex, q == panels - 1);
+                } else {
+                    rc = launch_closing<OP>(ctx, st, lc, s, rows, rowptr, beg_ptr, end_ptr, colidx, values, svalues, X, Y, Out, R, f, ex, q == panels - 1);
+                }
+                if (rc) return rc;
+            }
         return HNH_OK;
     }
 

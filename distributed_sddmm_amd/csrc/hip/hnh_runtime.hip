@@ -130,6 +130,11 @@ int hnh_ctx_create(int device, hnh_ctx** out) {
         const int v = std::atoi(mp);
         if (v >= 1 && v <= 8) ctx->max_panels = v;
     }
+    if (const char* ws = std::getenv("HNH_WIDE_SLABS")) ctx->wide_slabs = std::atoi(ws) != 0;
+    if (const char* sm = std::getenv("HNH_SLAB_MIN_R")) {
+        const int v = std::atoi(sm);
+        if (v >= 128 && v <= 4096) ctx->slab_min_r = v;
+    }
     if (const char* pb = std::getenv("HNH_PANEL_BYTES")) {
         const double v = std::atof(pb);
         if (v >= 1.0) ctx->panel_bytes = v;

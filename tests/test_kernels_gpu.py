@@ -746,6 +746,84 @@ def test_sddmm_with_the_hadamard_folded_in(ctx, R, shift):
         d.free()
 
 
+@pytest.mark.parametrize("R", [320, 384, 448, 512, 640])
+@pytest.mark.parametrize("slabs", ["1", "0"])
+@pytest.mark.parametrize("hubs", [False, True])
+def test_wide_operands_in_128_column_slabs(monkeypatch, R, slabs, hubs):
+    """R >= 320 (a multiple of 64): the un-fused SDDMM / SpMM run as 128-column slabs (and a last one of 64 columns), each slab the R = 128 pass with row pitch R and its
+    own Infinity-Cache panels (shrunk here so that the small block gets several); later slabs ADD their partial dot products, storing
+    first visits and the folded Hadamard scale apply per slab, SpMM slabs store or add their own columns, hub rows go through the long-row
+    pass of every slab.  HNH_WIDE_SLABS=0 = the single wide pass; same results."""
+    monkeypatch.setenv("HNH_WIDE_SLABS", slabs)
+    monkeypatch.setenv("HNH_PANEL_BYTES", "400000")
+    monkeypatch.setenv("HNH_MAX_PANELS", "8")
+    if hubs:
+        monkeypatch.setenv("HNH_PANELS_WITH_HUBS", "1")
+    from distributed_sddmm_amd import _kernels as K
+    c = K.Ctx(0)
+    lib = c.lib
+    rng = np.random.default_rng(R + 7)
+    rows, cols = 190, 2000
+    lens = rng.integers(0, 60, rows)
+    if hubs:
+        lens[3], lens[150] = 1900, 900
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cidx = np.concatenate([np.sort(rng.choice(cols, int(n), replace=False)) for n in lens]).astype(np.int32)
+    ridx = np.repeat(np.arange(rows, dtype=np.int32), lens)
+    nnz = len(cidx)
+    X, Y = rng.uniform(-1, 1, (rows, R)), rng.uniform(-1, 1, (cols, R))
+    sv, v0, out0 = rng.uniform(-1, 1, nnz), rng.uniform(-1, 1, nnz), rng.uniform(-1, 1, (rows, R))
+    dots = O.sddmm_local(ridx, cidx, np.zeros(nnz), X, Y)
+    d_rp, d_c, dX, dY, dv, d_sv, dOut = (c.upload(a) for a in (rowptr, cidx, X, Y, v0, sv, out0))
+    plan = C.c_void_p()
+    c.check(lib.hnh_csr_plan_create(c.h, C.byref(plan)), "plan")
+    blk = K.CsrBlock(rows, nnz, cols, int(lens.max()), 0, d_rp.ptr, d_c.ptr, plan)
+    for rep in range(2):  # (second round: the plan's panel boundaries are reused)
+        dv.set(np.full(nnz, 1e300))
+        c.check(lib.hnh_sddmm_csr_ps(c.h, C.byref(blk), dv.ptr, d_sv.ptr, dX.ptr, dY.ptr, R, K.FUSED_VALUES_OVERWRITE, None, 0), "sddmm_ps store")
+        assert rel(dv.get(), sv * dots) <= TOL
+        dv.set(v0)
+        c.check(lib.hnh_sddmm_csr_ps(c.h, C.byref(blk), dv.ptr, d_sv.ptr, dX.ptr, dY.ptr, R, 0, None, 0), "sddmm_ps add")
+        assert rel(dv.get(), v0 + sv * dots) <= TOL
+        dv.set(v0)
+        c.check(lib.hnh_sddmm_csr_p(c.h, C.byref(blk), dv.ptr, dX.ptr, dY.ptr, R, 0, None, 0), "sddmm_p")
+        assert rel(dv.get(), v0 + dots) <= TOL
+        dv.set(v0)
+        dOut.set(out0)
+        c.check(lib.hnh_spmm_csr_p(c.h, C.byref(blk), dv.ptr, dY.ptr, dOut.ptr, R, None, 0), "spmm_p")
+        assert rel(dOut.get(), O.spmm_local(rowptr, cidx, v0, Y, out0)) <= TOL
+        dOut.set(np.full((rows, R), -1e300))
+        c.check(lib.hnh_spmm_csr_pf(c.h, C.byref(blk), dv.ptr, dY.ptr, dOut.ptr, R, K.FUSED_OUT_OVERWRITE, None, 0), "spmm_pf store")
+        assert rel(dOut.get(), O.spmm_local(rowptr, cidx, v0, Y, np.zeros((rows, R)))) <= TOL
+    c.check(lib.hnh_csr_plan_destroy(c.h, plan), "plan destroy")
+    for d in (d_rp, d_c, dX, dY, dv, d_sv, dOut):
+        d.free()
+    c.close()
+
+
+def test_sum_chunked_blocks(ctx):
+    """The closing step of the mesh reduce-scatter: dst rows of chunks [q0, q1) += the nb partial blocks of the chunk-major buffer, block order."""
+    lib = ctx.lib
+    rng = np.random.default_rng(11)
+    for R, cuts in ((128, [0, 5, 5, 40, 77]), (7, [0, 3, 30]), (16, [0, 64])):
+        nb, rows = 5, cuts[-1]
+        dst0 = rng.uniform(-1, 1, (rows, R))
+        src = rng.uniform(-1, 1, (nb * rows, R))
+        d_dst, d_src = ctx.upload(dst0), ctx.upload(src)
+        ch = np.array(cuts, dtype=np.int64)
+        nch = len(cuts) - 1
+        for q0, q1 in ((0, nch), (1, nch), (0, 1)):
+            d_dst.set(dst0)
+            ctx.check(lib.hnh_sum_chunked_blocks_f64(ctx.h, d_dst.ptr, d_src.ptr, nb, nch, ch.ctypes.data_as(C.c_void_p), q0, q1, R, 0), "sum_chunked")
+            want = dst0.copy()
+            for q in range(q0, q1):
+                w = cuts[q + 1] - cuts[q]
+                for k in range(nb):  # (block order: the sum is taken in this order on the device too)
+                    want[cuts[q]:cuts[q + 1]] += src[nb * cuts[q] + k * w: nb * cuts[q] + (k + 1) * w]
+            assert np.array_equal(d_dst.get(), want)
+        d_dst.free(); d_src.free()
+
+
 def test_stream_delay_and_paced_copy(ctx):
     """The measurement stand-ins of the overlap probe: hnh_stream_delay_us holds a stream for at least the requested time (and not for many times as long),
     hnh_stream_paced_copy delivers every slice bit for bit and takes at least the modelled time."""
