@@ -157,10 +157,17 @@ class Workload:
             return H.SpmatLocal.load_tuples(world, False, self.logm, self.ef)
         if self.kind == "mtx":
             return H.SpmatLocal.load_tuples(world, True, 0, 0, self.path)
-        import numpy as np
-        rows, cols = self.host_nonzeros(H)
-        m = 1 << self.logm
-        return H.SpmatLocal.from_global(world, m, m, rows, cols, np.ones(len(rows)))
+        # the skewed initiator of the same generator call (SpmatLocal.hpp:502-505 with {.57, .19, .19, .05}), evaluated on the device like the
+        # Erdos-Renyi one (hnh_generate_rmat_keys); the host twin (H.generate_rmat) is what the result check sums over
+        saved = os.environ.get("HNH_RMAT")
+        os.environ["HNH_RMAT"] = "0.57,0.19,0.19"
+        try:
+            return H.SpmatLocal.load_tuples(world, False, self.logm, self.ef)
+        finally:
+            if saved is None:
+                os.environ.pop("HNH_RMAT", None)
+            else:
+                os.environ["HNH_RMAT"] = saved
 
     def describe(self, nnz):
         if self.kind == "er":

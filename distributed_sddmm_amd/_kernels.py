@@ -62,6 +62,7 @@ SIGNATURES = {
     "hnh_tuples_dedup_max": (_i32, [_vp, _vp, _i64, C.POINTER(C.c_int64), _i32]),
     "hnh_tuples_take_strided": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i32]),
     "hnh_generate_er_keys": (_i32, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp, C.POINTER(C.c_int64), _i32]),
+    "hnh_generate_rmat_keys": (_i32, [_vp, _i32, C.c_uint64, _dbl, _dbl, _dbl, C.c_uint64, _i32, _vp, C.POINTER(C.c_int64), _i32]),
     "hnh_tuples_from_keys": (_i32, [_vp, _vp, C.c_uint64, _i64, _i64, C.c_double, _vp, _i64, _i32]),
     "hnh_tuples_relabel": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32]),
     "hnh_tuples_to_csr": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(C.c_int), _i32]),

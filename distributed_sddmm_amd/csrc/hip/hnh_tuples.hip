@@ -170,6 +170,30 @@ __global__ __launch_bounds__(kBlock) void er_keys_kernel(unsigned long long m, u
     }
 }
 
+// edge k of the counter-based R-MAT generator (er_generator.hpp: rmat_keys — the same doubles, the same comparisons, bit for bit): logm
+// levels, each picking a quadrant with probabilities (a, b, c, 1 - a - b - c) from its own draw; optional multiplicative scramble of
+// both vertex numbers (the hubs are then spread over the rows instead of sitting at the low numbers)
+__global__ __launch_bounds__(kBlock) void rmat_keys_kernel(int logm, unsigned long long edges, double a, double ab, double abc, unsigned long long seed,
+                                                           int scramble, unsigned long long* __restrict__ keys) {
+    const unsigned long long G = 0x9E3779B97F4A7C15ull, n = 1ull << logm, mask = n - 1;
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; k < edges; k += stride) {
+        unsigned long long r = 0, col = 0;
+        for (int l = 0; l < logm; l++) {
+            const double u = (double)(splitmix64_dev(seed + (k * (unsigned long long)logm + (unsigned long long)l) * G) >> 11) * 0x1.0p-53;
+            const unsigned long long rb = (u >= ab) ? 1 : 0;
+            const unsigned long long cb = ((u >= a && u < ab) || (u >= abc)) ? 1 : 0;
+            r = (r << 1) | rb;
+            col = (col << 1) | cb;
+        }
+        if (scramble) {
+            r = (r * 0x9E3779B1ull + 0x7F4A7C15ull) & mask;
+            col = (col * 0x9E3779B1ull + 0x7F4A7C15ull) & mask;
+        }
+        keys[k] = r * n + col;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void tuples_from_keys_kernel(const unsigned long long* __restrict__ keys, unsigned long long ncols,
                                                                   long long first, long long stride_keys, double value,
                                                                   hnh_tuple* __restrict__ out, long long n_out) {
@@ -391,18 +415,13 @@ int hnh_tuples_to_csr(hnh_ctx* ctx, const hnh_tuple* sorted, int64_t n, int64_t 
     return HNH_OK;
 }
 
-int hnh_generate_er_keys(hnh_ctx* ctx, uint64_t m, uint64_t n, uint64_t draws, uint64_t seed, uint64_t* keys, int64_t* n_unique_host,
-                         int stream) {
-    HNH_ENTER(ctx, stream);
-    if (!n_unique_host || m == 0 || n == 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_generate_er_keys: bad argument");
-    *n_unique_host = 0;
-    if (draws == 0) return HNH_OK;
-    if (!keys) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_generate_er_keys: null pointer");
-    if (m > (~0ull) / n) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "hnh_generate_er_keys: m * n overflows 64 bits");
-    hipStream_t st = ctx->streams[stream];
+}  // extern "C"
+
+namespace {
+// draws of a generator -> sorted unique keys in place (radix sort + unique), their number read back
+template <typename Fill>
+int generate_sorted_unique(hnh_ctx* ctx, hipStream_t st, uint64_t draws, unsigned bits, uint64_t* keys, int64_t* n_unique_host, Fill&& fill) {
     const size_t un = (size_t)draws;
-    unsigned bits = 1;
-    while (bits < 64 && (1ull << bits) < m * n) bits++;
     size_t sort_bytes = 0, uniq_bytes = 0;
     HNH_TRY_HIP(ctx, rocprim::radix_sort_keys(nullptr, sort_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, un, 0, bits, st));
     HNH_TRY_HIP(ctx, rocprim::unique(nullptr, uniq_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t*)nullptr, un,
@@ -416,8 +435,7 @@ int hnh_generate_er_keys(hnh_ctx* ctx, uint64_t m, uint64_t n, uint64_t draws, u
     auto* alt = reinterpret_cast<unsigned long long*>(base + o_alt);
     auto* cnt = reinterpret_cast<size_t*>(base + o_cnt);
     auto* k = reinterpret_cast<unsigned long long*>(keys);
-    hipLaunchKernelGGL(er_keys_kernel, dim3(grid_for((long long)draws)), dim3(kBlock), 0, st, (unsigned long long)m, (unsigned long long)n,
-                       (unsigned long long)draws, (unsigned long long)seed, k);
+    fill(k);
     HNH_TRY_HIP(ctx, hipGetLastError());
     HNH_TRY_HIP(ctx, rocprim::radix_sort_keys(base + o_tmp, sort_bytes, k, alt, un, 0, bits, st));
     HNH_TRY_HIP(ctx, rocprim::unique(base + o_tmp, uniq_bytes, alt, k, cnt, un, rocprim::equal_to<unsigned long long>(), st));
@@ -426,6 +444,42 @@ int hnh_generate_er_keys(hnh_ctx* ctx, uint64_t m, uint64_t n, uint64_t draws, u
     HNH_TRY_HIP(ctx, hipStreamSynchronize(st));
     *n_unique_host = (int64_t)h_cnt;
     return HNH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int hnh_generate_er_keys(hnh_ctx* ctx, uint64_t m, uint64_t n, uint64_t draws, uint64_t seed, uint64_t* keys, int64_t* n_unique_host,
+                         int stream) {
+    HNH_ENTER(ctx, stream);
+    if (!n_unique_host || m == 0 || n == 0) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_generate_er_keys: bad argument");
+    *n_unique_host = 0;
+    if (draws == 0) return HNH_OK;
+    if (!keys) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_generate_er_keys: null pointer");
+    if (m > (~0ull) / n) return hnh::fail(ctx, HNH_ERR_UNSUPPORTED, "hnh_generate_er_keys: m * n overflows 64 bits");
+    hipStream_t st = ctx->streams[stream];
+    unsigned bits = 1;
+    while (bits < 64 && (1ull << bits) < m * n) bits++;
+    return generate_sorted_unique(ctx, st, draws, bits, keys, n_unique_host, [&](unsigned long long* k) {
+        hipLaunchKernelGGL(er_keys_kernel, dim3(grid_for((long long)draws)), dim3(kBlock), 0, st, (unsigned long long)m, (unsigned long long)n,
+                           (unsigned long long)draws, (unsigned long long)seed, k);
+    });
+}
+
+int hnh_generate_rmat_keys(hnh_ctx* ctx, int logm, uint64_t edges, double a, double b, double c, uint64_t seed, int scramble, uint64_t* keys,
+                           int64_t* n_unique_host, int stream) {
+    HNH_ENTER(ctx, stream);
+    if (!n_unique_host || logm < 1 || logm > 31 || a < 0.0 || b < 0.0 || c < 0.0 || a + b + c > 1.0)
+        return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_generate_rmat_keys: bad argument");
+    *n_unique_host = 0;
+    if (edges == 0) return HNH_OK;
+    if (!keys) return hnh::fail(ctx, HNH_ERR_INVALID, "hnh_generate_rmat_keys: null pointer");
+    hipStream_t st = ctx->streams[stream];
+    const double ab = a + b, abc = a + b + c;  // (the sums the host generator compares with: formed once, in the same order)
+    return generate_sorted_unique(ctx, st, edges, (unsigned)(2 * logm), keys, n_unique_host, [&](unsigned long long* k) {
+        hipLaunchKernelGGL(rmat_keys_kernel, dim3(grid_for((long long)edges)), dim3(kBlock), 0, st, logm, (unsigned long long)edges, a, ab, abc,
+                           (unsigned long long)seed, scramble, k);
+    });
 }
 
 int hnh_tuples_from_keys(hnh_ctx* ctx, const uint64_t* keys, uint64_t ncols, int64_t first, int64_t stride_keys, double value,

@@ -28,7 +28,7 @@ struct Backend {
     HNH_FN(hnh_fused_sddmm_spmm_csr_x) HNH_FN(hnh_row_epilogue_f64) HNH_FN(hnh_row_epilogue_x) HNH_FN(hnh_cg_step_f64)
     HNH_FN(hnh_tuples_sort) HNH_FN(hnh_tuples_bucket_starts) HNH_FN(hnh_tuples_transform) HNH_FN(hnh_tuples_to_csr)
     HNH_FN(hnh_csr_window_bounds) HNH_FN(hnh_sddmm_csr_w) HNH_FN(hnh_spmm_csr_w) HNH_FN(hnh_fused_sddmm_spmm_csr_w) HNH_FN(hnh_tuples_remap_cols) HNH_FN(hnh_tuples_dedup_max) HNH_FN(hnh_tuples_take_strided)
-    HNH_FN(hnh_panel_count) HNH_FN(hnh_generate_er_keys) HNH_FN(hnh_tuples_from_keys) HNH_FN(hnh_tuples_relabel)
+    HNH_FN(hnh_panel_count) HNH_FN(hnh_generate_er_keys) HNH_FN(hnh_generate_rmat_keys) HNH_FN(hnh_tuples_from_keys) HNH_FN(hnh_tuples_relabel)
     HNH_FN(hnh_fill_f64) HNH_FN(hnh_hadamard_f64) HNH_FN(hnh_axpy_f64) HNH_FN(hnh_expand_rowptr) HNH_FN(hnh_sum_chunked_blocks_f64)
     HNH_FN(hnh_rowdot_f64) HNH_FN(hnh_row_scale_add_f64) HNH_FN(hnh_vec_add_scalar_f64) HNH_FN(hnh_vec_div_f64) HNH_FN(hnh_fill_hashed_f64)
     HNH_FN(hnh_gemm_f64) HNH_FN(hnh_leaky_relu_f64) HNH_FN(hnh_relu_store_cols_f64)

@@ -303,12 +303,27 @@ void SpmatLocal::loadTuples(bool readFromFile, int logM, int nnz_per_row, std::s
         const uint64_t m = 1ull << logM;
         uint64_t seed = 12345;
         if (const char* s = std::getenv("HNH_ER_SEED")) seed = std::strtoull(s, nullptr, 10);
+        // The reference calls GenGraph500Data with the initiator {.25, .25, .25, .25} (SpmatLocal.hpp:502-505): Erdos-Renyi.  HNH_RMAT="a,b,c"
+        // (e.g. .57,.19,.19: Graph500's) selects a SKEWED initiator instead — the same generator call with other constants, hub rows
+        // included; HNH_RMAT_SCRAMBLE=0 leaves the hubs at the low vertex numbers.
+        double ra = 0.25, rb = 0.25, rc = 0.25;
+        bool skewed = false, scramble = true;
+        if (const char* rm = std::getenv("HNH_RMAT")) {
+            if (std::sscanf(rm, "%lf,%lf,%lf", &ra, &rb, &rc) != 3 || ra < 0 || rb < 0 || rc < 0 || ra + rb + rc > 1.0)
+                hnh::fatal("Error, HNH_RMAT must be three probabilities a,b,c with a + b + c <= 1!");
+            skewed = true;
+        }
+        if (const char* sc = std::getenv("HNH_RMAT_SCRAMBLE")) scramble = std::atoi(sc) != 0;
         if (device_setup()) {
             // the same generator evaluated on this rank's GPU: draws, radix sort, de-duplication, strided slice — the
-            // tuples are born device-resident (hnh_generate_er_keys / hnh_tuples_from_keys)
+            // tuples are born device-resident (hnh_generate_er_keys / hnh_generate_rmat_keys / hnh_tuples_from_keys)
             const uint64_t draws = m * (uint64_t)nnz_per_row;
             hnh::DeviceArray keys(world, std::max<uint64_t>(draws, 1) * sizeof(uint64_t));
             int64_t unique = 0;
+            if (skewed)
+                world->check(world->be->hnh_generate_rmat_keys(world->ctx, logM, draws, ra, rb, rc, seed, scramble ? 1 : 0, static_cast<uint64_t*>(keys.ptr()),
+                                                               &unique, HNH_STREAM_COMPUTE), "hnh_generate_rmat_keys");
+            else
             world->check(world->be->hnh_generate_er_keys(world->ctx, m, m, draws, seed, static_cast<uint64_t*>(keys.ptr()), &unique,
                                                          HNH_STREAM_COMPUTE), "hnh_generate_er_keys");
             M = N = m;
@@ -324,7 +339,8 @@ void SpmatLocal::loadTuples(bool readFromFile, int logM, int nnz_per_row, std::s
             if (const char* ps = std::getenv("HNH_PERMUTE_SEED")) permuteVertices(std::strtoull(ps, nullptr, 10));
             return;
         }
-        std::vector<uint64_t> keys = hnh::erdos_renyi_keys(m, m, m * (uint64_t)nnz_per_row, seed);
+        std::vector<uint64_t> keys = skewed ? hnh::rmat_keys(logM, m * (uint64_t)nnz_per_row, ra, rb, rc, seed, scramble)
+                                            : hnh::erdos_renyi_keys(m, m, m * (uint64_t)nnz_per_row, seed);
         M = N = m;
         dist_nnz = keys.size();
         coords.reserve(keys.size() / p + 1);

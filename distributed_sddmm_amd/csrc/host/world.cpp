@@ -92,7 +92,7 @@ Backend* load_backend(const char* path_c) {
     HNH_BIND(hnh_fused_sddmm_spmm_csr_x) HNH_BIND(hnh_row_epilogue_f64) HNH_BIND(hnh_row_epilogue_x) HNH_BIND(hnh_cg_step_f64)
     HNH_BIND(hnh_tuples_sort) HNH_BIND(hnh_tuples_bucket_starts) HNH_BIND(hnh_tuples_transform) HNH_BIND(hnh_tuples_to_csr)
     HNH_BIND(hnh_csr_window_bounds) HNH_BIND(hnh_sddmm_csr_w) HNH_BIND(hnh_spmm_csr_w) HNH_BIND(hnh_fused_sddmm_spmm_csr_w) HNH_BIND(hnh_tuples_remap_cols) HNH_BIND(hnh_tuples_dedup_max) HNH_BIND(hnh_tuples_take_strided)
-    HNH_BIND(hnh_panel_count) HNH_BIND(hnh_generate_er_keys) HNH_BIND(hnh_tuples_from_keys) HNH_BIND(hnh_tuples_relabel)
+    HNH_BIND(hnh_panel_count) HNH_BIND(hnh_generate_er_keys) HNH_BIND(hnh_generate_rmat_keys) HNH_BIND(hnh_tuples_from_keys) HNH_BIND(hnh_tuples_relabel)
     HNH_BIND(hnh_fill_f64) HNH_BIND(hnh_hadamard_f64) HNH_BIND(hnh_axpy_f64) HNH_BIND(hnh_expand_rowptr) HNH_BIND(hnh_sum_chunked_blocks_f64)
     HNH_BIND(hnh_rowdot_f64) HNH_BIND(hnh_row_scale_add_f64) HNH_BIND(hnh_vec_add_scalar_f64) HNH_BIND(hnh_vec_div_f64) HNH_BIND(hnh_fill_hashed_f64)
     HNH_BIND(hnh_gemm_f64) HNH_BIND(hnh_leaky_relu_f64) HNH_BIND(hnh_relu_store_cols_f64)

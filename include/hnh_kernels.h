@@ -280,6 +280,13 @@ int hnh_tuples_take_strided(hnh_ctx* ctx, const hnh_tuple* src, int64_t first, i
  *                        (PermEdges / RenameVertices, SpmatLocal.hpp:506-507; random_permute.cpp) */
 int hnh_generate_er_keys(hnh_ctx* ctx, uint64_t m, uint64_t n, uint64_t draws, uint64_t seed, uint64_t* keys, int64_t* n_unique_host,
                          int stream);
+/* hnh_generate_rmat_keys: the same for a SKEWED initiator (GenGraph500Data's general case, SpmatLocal.hpp:502-505 with initiator
+ * {a, b, c, 1 - a - b - c}): the counter-based R-MAT generator of er_generator.hpp: rmat_keys / oracle.py:rmat, bit for bit — edge k
+ * descends logm levels, level l picking its quadrant from u = (splitmix64(seed + (k logm + l) G) >> 11) 2^-53; `scramble` multiplies both
+ * vertex numbers by an odd constant mod 2^logm (hubs spread over the rows).  `keys` (device, capacity `edges`) receives the sorted,
+ * de-duplicated keys row * 2^logm + col; synchronous. */
+int hnh_generate_rmat_keys(hnh_ctx* ctx, int logm, uint64_t edges, double a, double b, double c, uint64_t seed, int scramble, uint64_t* keys,
+                           int64_t* n_unique_host, int stream);
 int hnh_tuples_from_keys(hnh_ctx* ctx, const uint64_t* keys, uint64_t ncols, int64_t first, int64_t stride, double value,
                          hnh_tuple* out, int64_t n_out, int stream);
 int hnh_tuples_relabel(hnh_ctx* ctx, hnh_tuple* tuples, int64_t n, const uint64_t* row_label, const uint64_t* col_label, int stream);

@@ -1030,6 +1030,34 @@ int hnh_generate_er_keys(hnh_ctx* c, uint64_t m, uint64_t n, uint64_t draws, uin
     *n_unique = (int64_t)out;
     return hb_synchronous(c, stream);
 }
+/* er_generator.cpp: rmat_keys, restated */
+int hnh_generate_rmat_keys(hnh_ctx* c, int logm, uint64_t edges, double a, double b, double cc, uint64_t seed, int scramble, uint64_t* keys,
+                           int64_t* n_unique, int stream) {
+    if (!n_unique || logm < 1 || logm > 31 || a < 0.0 || b < 0.0 || cc < 0.0 || a + b + cc > 1.0) return fail(c, HNH_ERR_INVALID, "bad argument");
+    HB_OP(c, stream, "hnh_generate_rmat_keys");
+    HB_W(keys, (size_t)edges * sizeof(uint64_t));
+    const uint64_t G = 0x9E3779B97F4A7C15ull, n = 1ull << logm, mask = n - 1;
+    const double ab = a + b, abc = a + b + cc;
+    for (uint64_t k = 0; k < edges; k++) {
+        uint64_t r = 0, col = 0;
+        for (int l = 0; l < logm; l++) {
+            const double u = (double)(splitmix64_c(seed + (k * (uint64_t)logm + (uint64_t)l) * G) >> 11) * 0x1.0p-53;
+            r = (r << 1) | ((u >= ab) ? 1u : 0u);
+            col = (col << 1) | (((u >= a && u < ab) || (u >= abc)) ? 1u : 0u);
+        }
+        if (scramble) {
+            r = (r * 0x9E3779B1ull + 0x7F4A7C15ull) & mask;
+            col = (col * 0x9E3779B1ull + 0x7F4A7C15ull) & mask;
+        }
+        keys[k] = r * n + col;
+    }
+    qsort(keys, (size_t)edges, sizeof(uint64_t), u64_cmp);
+    uint64_t out = 0;
+    for (uint64_t k = 0; k < edges; k++)
+        if (out == 0 || keys[out - 1] != keys[k]) keys[out++] = keys[k];
+    *n_unique = (int64_t)out;
+    return hb_synchronous(c, stream);
+}
 int hnh_tuples_from_keys(hnh_ctx* c, const uint64_t* keys, uint64_t ncols, int64_t first, int64_t stride, double value, hnh_tuple* out,
                          int64_t n_out, int stream) {
     if (n_out < 0 || first < 0 || stride <= 0 || ncols == 0) return fail(c, HNH_ERR_INVALID, "bad argument");

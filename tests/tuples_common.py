@@ -137,3 +137,14 @@ def run_generator(api):
         for x in (dt, drl, dcl):
             x.free()
     dk.free()
+    # the skewed initiator (hnh_generate_rmat_keys) against oracle.rmat, scrambled and not
+    for logm, edges, abc, scramble in ((9, 6000, (0.57, 0.19, 0.19), 1), (7, 900, (0.45, 0.15, 0.15), 0), (10, 5000, (0.25, 0.25, 0.25), 1)):
+        rows, cols = O.rmat(logm, edges, *abc, seed=77, scramble=bool(scramble))
+        dk = api.upload(np.zeros(edges, dtype=np.uint64))
+        cnt = C.c_int64(-1)
+        api.check(lib.hnh_generate_rmat_keys(h, logm, edges, abc[0], abc[1], abc[2], 77, scramble, dk.ptr, C.byref(cnt), 0), "generate_rmat_keys")
+        assert cnt.value == len(rows)
+        assert np.array_equal(dk.get().reshape(-1)[:cnt.value], rows.astype(np.uint64) * np.uint64(1 << logm) + cols.astype(np.uint64))
+        dk.free()
+    cnt = C.c_int64(-1)
+    assert lib.hnh_generate_rmat_keys(h, 9, 10, 0.6, 0.3, 0.3, 1, 1, None, C.byref(cnt), 0) != 0  # probabilities above one
