@@ -75,8 +75,11 @@ def set_chunk_spec(spec):
         os.environ.pop("HNH_MESH_TAPER", None)
 
 
-def current_chunk_spec():
-    return os.environ.get("HNH_MESH_TAPER") or os.environ.get("HNH_MESH_CHUNKS") or DEFAULT_CHUNKS
+FUSION1_CHUNKS = "1,2,1"  # ... and of 15d_fusion1's row-merged layout (staging passes + transfer groups)
+
+
+def current_chunk_spec(alg=None):
+    return os.environ.get("HNH_MESH_TAPER") or os.environ.get("HNH_MESH_CHUNKS") or (FUSION1_CHUNKS if alg == "15d_fusion1" else DEFAULT_CHUNKS)
 
 
 def route_name(route):

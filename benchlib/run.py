@@ -154,7 +154,7 @@ def run(args, make_world=None):
     fixed_mode = os.environ.get("HNH_RING_MODE") if (args.ring_mode or "HNH_RING_MODE" in os.environ) else None
     c0 = args.c or 1
     mode0 = "none" if n // c0 == 1 else os.environ.get("HNH_RING_MODE", "mesh")
-    default_q = common.current_chunk_spec()
+    default_q = common.current_chunk_spec(args.alg)
     route0 = (first, c0, mode0, default_q if mode0 == "mesh" else None)
     t_first = time.monotonic()
     b.build(route0)

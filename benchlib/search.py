@@ -71,9 +71,10 @@ def candidates(args, n, tr, fixed_mode, default_q):
         if fixed_mode != "mesh":
             cand.append((tr, c, "relay", None))
         if fixed_mode is None and args.app == "vanilla":
-            # the other fusion strategy of the same schedule (replication reuse): twice the gathers, but its moving operand is
-            # replicated once for both kernels and its accumulator travels in two halves under the kernels
-            cand.append((tr, c, "fusion1", None))
+            # the other fusion strategy of the same schedule (replication reuse): twice the gathers, but its stationary operand is
+            # replicated once for both kernels; SDDMM over the mesh fetch in row-range passes, SpMM as a mesh reduce-scatter (its own
+            # default chunk shape unless --chunks fixes one)
+            cand.append((tr, c, "fusion1", str(args.chunks) if args.chunks else None))
     return cand
 
 

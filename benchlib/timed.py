@@ -82,6 +82,9 @@ class Bench:
             os.environ["HNH_RING_MODE"] = mode
         if q is not None:
             common.set_chunk_spec(q)
+        elif mode == "fusion1":  # (its own default chunk shape, not the previous candidate's: the library reads the same two variables)
+            os.environ.pop("HNH_MESH_TAPER", None)
+            os.environ.pop("HNH_MESH_CHUNKS", None)
         t0 = time.perf_counter()
         if t["sp"] is None:
             t["sp"] = self.wl.load(H, t["world"])

@@ -2,7 +2,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <memory>
+#include <omp.h>
 #include <string>
 
 #include "als_conjugate_gradients.hpp"
@@ -427,27 +429,46 @@ int hnh_write_matrix_market(const char* path, int64_t M, int64_t N, int64_t n, c
         if (!f) hnh::fatal(std::string("Error, cannot create ") + path);
         std::fprintf(f, "%%%%MatrixMarket matrix coordinate real %s\n%% written by hnh_write_matrix_market\n%lld %lld %lld\n", symmetric ? "symmetric" : "general",
                      (long long)M, (long long)N, (long long)n);
-        const int64_t slice = 1 << 20;
+        // slices of 2^18 entries (at most ~45 bytes each: 12 MB of text per slice), as many side by side as there are threads, written in
+        // order.  Nothing may leave the parallel region as an exception (std::terminate): an allocation failure or an entry outside the
+        // matrix sets a flag, the slice stops, and the error is reported after the region.
+        const int64_t slice = 1 << 18;
         const int64_t nslices = (n + slice - 1) / slice;
+        const int64_t batch = std::max(1, omp_get_max_threads());
         bool ok = true;
-        for (int64_t s0 = 0; s0 < nslices && ok; s0 += 64) {  // 64 slices formatted side by side, then written in order
-            const int64_t s1 = std::min(nslices, s0 + 64);
+        int failure = 0;  // 1 = out of memory, 2 = an entry outside the matrix
+        for (int64_t s0 = 0; s0 < nslices && ok && !failure; s0 += batch) {
+            const int64_t s1 = std::min(nslices, s0 + batch);
             std::vector<std::string> text((size_t)(s1 - s0));
 #pragma omp parallel for schedule(dynamic, 1)
             for (int64_t s = s0; s < s1; s++) {
-                std::string& t = text[(size_t)(s - s0)];
-                t.reserve((size_t)slice * 24);
-                char line[96];
-                for (int64_t e = s * slice; e < std::min(n, (s + 1) * slice); e++) {
-                    int len;
-                    if (values) len = std::snprintf(line, sizeof(line), "%lld %lld %.17g\n", (long long)rows[e] + 1, (long long)cols[e] + 1, values[e]);
-                    else len = std::snprintf(line, sizeof(line), "%lld %lld 1\n", (long long)rows[e] + 1, (long long)cols[e] + 1);
-                    t.append(line, (size_t)len);
+                try {
+                    std::string& t = text[(size_t)(s - s0)];
+                    t.reserve((size_t)slice * 24);
+                    char line[96];
+                    for (int64_t e = s * slice; e < std::min(n, (s + 1) * slice); e++) {
+                        if (rows[e] < 0 || rows[e] >= M || cols[e] < 0 || cols[e] >= N) {
+#pragma omp atomic write
+                            failure = 2;
+                            break;
+                        }
+                        int len;
+                        if (values) len = std::snprintf(line, sizeof(line), "%lld %lld %.17g\n", (long long)rows[e] + 1, (long long)cols[e] + 1, values[e]);
+                        else len = std::snprintf(line, sizeof(line), "%lld %lld 1\n", (long long)rows[e] + 1, (long long)cols[e] + 1);
+                        t.append(line, (size_t)len);
+                    }
+                } catch (...) {  // (std::bad_alloc of reserve / append)
+#pragma omp atomic write
+                    failure = 1;
                 }
             }
-            for (const std::string& t : text) ok = ok && std::fwrite(t.data(), 1, t.size(), f) == t.size();
+            if (!failure)
+                for (const std::string& t : text) ok = ok && std::fwrite(t.data(), 1, t.size(), f) == t.size();
         }
-        if (std::fclose(f) != 0 || !ok) hnh::fatal(std::string("Error, writing ") + path + " failed");
+        const bool closed = std::fclose(f) == 0;
+        if (failure == 1) throw std::bad_alloc();  // -> HNH_ERR_NOMEM through guarded()
+        if (failure == 2) hnh::fatal(std::string("Error, an entry of the MatrixMarket file ") + path + " lies outside the matrix");
+        if (!closed || !ok) hnh::fatal(std::string("Error, writing ") + path + " failed");
     });
 }
 

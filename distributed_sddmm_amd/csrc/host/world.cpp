@@ -63,6 +63,19 @@ std::string dir_of_this_library() {
 }
 }  // namespace
 
+// Whether the process that left a rendezvous record (the RCCL unique id file, the ipc session's segment) is still there: a record whose
+// writer is gone is a leftover of an earlier launch.  The test is by process id, so ranks that share /dev/shm or the id file's directory but
+// run in SEPARATE PID namespaces (one container per rank) see each other's ids as dead: HNH_PID_LIVENESS=0 turns the test off there (records
+// are then told apart by the launch's name alone — HNH_JOB_TOKEN / MASTER_PORT — as before round 5).
+bool pid_is_live(int64_t pid) {
+    static const bool check = [] {
+        const char* v = std::getenv("HNH_PID_LIVENESS");
+        return v == nullptr || std::atoi(v) != 0;
+    }();
+    if (!check) return true;
+    return kill((pid_t)pid, 0) == 0 || errno == EPERM;
+}
+
 std::string default_backend_path() { return dir_of_this_library() + "/libhnh_kernels.so"; }
 
 Backend* load_backend(const char* path_c) {
@@ -542,8 +555,7 @@ World* world_from_environment() {
         for (int tries = 0;; tries++) {
             std::ifstream f(idfile, std::ios::binary);
             int64_t writer = 0;
-            if (f && f.read(id, sizeof(id)) && f.read(reinterpret_cast<char*>(&writer), sizeof(writer)) && writer > 0 &&
-                (kill((pid_t)writer, 0) == 0 || errno == EPERM))
+            if (f && f.read(id, sizeof(id)) && f.read(reinterpret_cast<char*>(&writer), sizeof(writer)) && writer > 0 && pid_is_live(writer))
                 break;
             if (tries > 6000) fatal("Error, timed out waiting for the RCCL unique id file " + idfile + " (of a live rank 0)");
             std::this_thread::sleep_for(std::chrono::milliseconds(10));
@@ -1000,7 +1012,7 @@ IpcWorld::IpcWorld(int r, int nranks, Backend* backend, int device_ordinal, cons
         }
         if (!stale) {
             const pid_t creator = (pid_t)sh_->creator_pid;
-            stale = creator <= 0 || (kill(creator, 0) != 0 && errno != EPERM) || sh_->attached.load() >= sh_->nranks || sh_->failed.load() != 0;
+            stale = creator <= 0 || !pid_is_live((int64_t)creator) || sh_->attached.load() >= sh_->nranks || sh_->failed.load() != 0;
         }
         if (!stale) {
             if (sh_->nranks != nranks) fatal("Error, ipc world: the ranks disagree about the world size");

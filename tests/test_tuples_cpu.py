@@ -45,6 +45,20 @@ def test_c_test_double_tuple_primitives():
     tuples_common.run(DoubleApi())
 
 
+def test_c_test_double_round6_primitives():
+    tuples_common.run_round6_primitives(DoubleApi())
+
+
+def test_world_identities_say_where_every_rank_runs():
+    """World::identities() (hnh_world_identities): one record per rank — pid, device ordinal, the GPU's PCI bus id — the same list on every
+    rank; bench.py builds its workload sentence from the number of distinct bus ids."""
+    import os
+    assert H.load_backend(T.ORACLE_BACKEND) == "oracle-cpu-test-double"
+    res = H.run_spmd(3, lambda w: w.identities())
+    assert res[0] == res[1] == res[2] and [r["rank"] for r in res[0]] == [0, 1, 2]
+    assert all(r["pid"] == os.getpid() and r["device_ordinal"] == 0 and r["pci_bus_id"] for r in res[0]) and "comm_count" not in res[0][0]
+
+
 @pytest.mark.parametrize("R,hubs,windows,standalone", [(16, False, 0, False), (7, False, 3, False), (32, True, 0, False), (16, False, 0, True)])
 def test_c_test_double_folded_cg_iteration(R, hubs, windows, standalone):
     """hnh_cg_update as the test double performs it vs the reference's statement sequence in numpy (the GPU runs the same body)."""

@@ -14,6 +14,13 @@ def test_hip_tuple_primitives():
     ctx.close()
 
 
+def test_hip_round6_primitives():
+    from distributed_sddmm_amd import _kernels as K
+    ctx = K.Ctx(0)
+    tuples_common.run_round6_primitives(ctx)
+    ctx.close()
+
+
 def test_sort_at_scale_is_a_permutation_in_order():
     """1e7 tuples (size-independent properties): sorted by key, same multiset of values."""
     import ctypes as C

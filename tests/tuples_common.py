@@ -148,3 +148,57 @@ def run_generator(api):
         dk.free()
     cnt = C.c_int64(-1)
     assert lib.hnh_generate_rmat_keys(h, 9, 10, 0.6, 0.3, 0.3, 1, 1, None, C.byref(cnt), 0) != 0  # probabilities above one
+
+
+def run_round6_primitives(api):
+    """hnh_spmm_csr_pf (SpMM that STORES fresh output rows), hnh_sum_chunked_blocks_f64 (the closing step of the mesh reduce-scatter) and
+    hnh_ctx_device_identity against numpy — the body the CPU test runs on the test double and the GPU test on the HIP library."""
+    from oracle import oracle as O
+    lib, h = api.lib, api.h
+    rng = np.random.default_rng(5)
+    # ---- SpMM with the store flag: rows without nonzeros end as zeros, garbage in Out is never read
+    rows, cols, R = 90, 400, 48
+    lens = rng.integers(0, 30, rows)
+    lens[7] = 0
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cidx = np.concatenate([np.sort(rng.choice(cols, int(n), replace=False)) for n in lens]).astype(np.int32)
+    vals, Y = rng.uniform(-1, 1, len(cidx)), rng.uniform(-1, 1, (cols, R))
+    d_rp, d_c, d_v, dY = api.upload(rowptr), api.upload(cidx), api.upload(vals), api.upload(Y)
+    blk = K.CsrBlock(rows, len(cidx), cols, int(lens.max()), 0, d_rp.ptr, d_c.ptr, None)
+    want = O.spmm_local(rowptr, cidx, vals, Y, np.zeros((rows, R)))
+    dOut = api.upload(np.full((rows, R), 1e300))
+    api.check(lib.hnh_spmm_csr_pf(h, C.byref(blk), d_v.ptr, dY.ptr, dOut.ptr, R, K.FUSED_OUT_OVERWRITE, None, 0), "spmm_pf store")
+    got = dOut.get().reshape(rows, R)
+    assert np.max(np.abs(got - want)) <= 1e-11 * np.max(np.abs(want)) and np.all(got[7] == 0.0)
+    out0 = rng.uniform(-1, 1, (rows, R))
+    dOut2 = api.upload(out0)
+    api.check(lib.hnh_spmm_csr_pf(h, C.byref(blk), d_v.ptr, dY.ptr, dOut2.ptr, R, 0, None, 0), "spmm_pf add")
+    assert np.max(np.abs(dOut2.get().reshape(rows, R) - (out0 + want))) <= 1e-11 * np.max(np.abs(want))
+    assert lib.hnh_spmm_csr_pf(h, C.byref(blk), d_v.ptr, dY.ptr, dOut2.ptr, R, 64, None, 0) != 0  # unknown flag
+    # ---- the chunk-major sum, in block order (bit for bit)
+    for R2, cuts in ((128, [0, 5, 5, 40, 77]), (7, [0, 3, 30]), (16, [0, 64])):
+        nb, nrows = 5, cuts[-1]
+        dst0, src = rng.uniform(-1, 1, (nrows, R2)), rng.uniform(-1, 1, (nb * nrows, R2))
+        ch = np.array(cuts, dtype=np.int64)
+        nch = len(cuts) - 1
+        d_src = api.upload(src)
+        for q0, q1 in ((0, nch), (1, nch), (0, 1)):
+            d_dst = api.upload(dst0)
+            api.check(lib.hnh_sum_chunked_blocks_f64(h, d_dst.ptr, d_src.ptr, nb, nch, ch.ctypes.data_as(C.c_void_p), q0, q1, R2, 0), "sum_chunked")
+            want2 = dst0.copy()
+            for q in range(q0, q1):
+                w = cuts[q + 1] - cuts[q]
+                for k in range(nb):
+                    want2[cuts[q]:cuts[q + 1]] += src[nb * cuts[q] + k * w: nb * cuts[q] + (k + 1) * w]
+            assert np.array_equal(d_dst.get().reshape(nrows, R2), want2)
+            d_dst.free()
+        d_src.free()
+    bad = np.array([0, 5, 3], dtype=np.int64)
+    assert lib.hnh_sum_chunked_blocks_f64(h, None, None, 2, 2, bad.ctypes.data_as(C.c_void_p), 0, 2, 8, 0) != 0  # cuts that decrease
+    # ---- where the context runs
+    ordinal, bus = C.c_int(-1), C.create_string_buffer(40)
+    api.check(lib.hnh_ctx_device_identity(h, C.byref(ordinal), bus, 40), "device_identity")
+    assert ordinal.value == 0 and len(bus.value) >= 7 and b":" in bus.value
+    assert lib.hnh_ctx_device_identity(h, C.byref(ordinal), bus, 4) != 0  # a buffer too short for a bus id
+    for x in (d_rp, d_c, d_v, dY, dOut, dOut2):
+        x.free()
