@@ -279,7 +279,7 @@ class World:
         out = []
         for r in buf:
             rec = {"rank": r.rank, "pid": r.pid, "device_ordinal": r.device_ordinal, "pci_bus_id": r.pci_bus_id.decode("ascii", "replace")}
-            if r.comm_count >= 0:
+            if r.comm_count != -1:  # (-1: the transport has no communicator; -2: RCCL would not say)
                 rec.update(comm_count=r.comm_count, comm_rank=r.comm_rank, comm_device=r.comm_device)
             out.append(rec)
         return out

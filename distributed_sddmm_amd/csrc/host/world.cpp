@@ -300,7 +300,8 @@ hnh_rank_identity World::identity() {
     id.pid = (int32_t)getpid();
     id.comm_count = id.comm_rank = id.comm_device = -1;
     int ordinal = device;
-    check(be->hnh_ctx_device_identity(ctx, &ordinal, id.pci_bus_id, (int)sizeof id.pci_bus_id), "hnh_ctx_device_identity");
+    if (be->hnh_ctx_device_identity(ctx, &ordinal, id.pci_bus_id, (int)sizeof id.pci_bus_id) != HNH_OK)
+        std::snprintf(id.pci_bus_id, sizeof id.pci_bus_id, "unknown:%d", device);  // (a report, never a reason to fail)
     id.device_ordinal = ordinal;
     return id;
 }
@@ -810,8 +811,9 @@ RcclWorld::RcclWorld(int r, int nranks, Backend* backend, int device_ordinal, co
 }
 hnh_rank_identity RcclWorld::identity() {
     hnh_rank_identity id = World::identity();
+    // (a report, never a reason to fail: identities() is collective, and a rank that threw here would leave the others waiting)
     int n = -1, r = -1, d = -1;
-    check(be->hnh_comm_identity(ctx, comm_, &n, &r, &d), "hnh_comm_identity");
+    if (be->hnh_comm_identity(ctx, comm_, &n, &r, &d) != HNH_OK) n = r = d = -2;
     id.comm_count = n;
     id.comm_rank = r;
     id.comm_device = d;

@@ -19,7 +19,8 @@ for cfg in "1 1 15d_fusion2" "4 1 15d_fusion2" "4 2 15d_fusion2" "8 2 15d_fusion
     HNH_ORDER_CHECK=1 ASAN_OPTIONS=detect_leaks=0 OMP_NUM_THREADS=1 "$OUT/spmd_asan" "$OUT/liboracle_asan.so" $cfg | tail -1
 done
 for envs in HNH_RING_MODE=relay HNH_ACC_HALVES=0 HNH_SHIP_INDICES=1 HNH_BORROW=off HNH_BORROW=force HNH_MESH_CHUNKS=4 HNH_MESH_TAPER=3,4,4,3,2,1,1 \
-            HNH_HOST_SETUP=1 HNH_GAT_SERIAL=1 HNH_WINDOW_MERGE=0 HNH_WINDOW_MERGE_CAP=2 HNH_ORACLE_EVENTS_PENDING=2 HNH_PERF_COUNTERS=0; do
+            HNH_HOST_SETUP=1 HNH_GAT_SERIAL=1 HNH_WINDOW_MERGE=0 HNH_WINDOW_MERGE_CAP=2 HNH_ORACLE_EVENTS_PENDING=2 HNH_PERF_COUNTERS=0 \
+            HNH_FUSION1_MESH=0 HNH_MESH_TAPER=1,2,2,2,1,1 HNH_MESH_CHUNKS=1 HNH_RMAT=0.57,0.19,0.19; do
     for cfg in "4 1 15d_fusion2" "4 2 15d_fusion1" "8 2 25d_dense_replicate" "4 1 15d_sparse"; do
         echo -n "$envs: "
         env "$envs" ASAN_OPTIONS=detect_leaks=0 OMP_NUM_THREADS=1 "$OUT/spmd_asan" "$ROOT/oracle/liboracle_backend.so" $cfg | tail -1
