@@ -136,7 +136,7 @@ def test_config2_full_size_fused_elementwise(config2):
 
 
 @pytest.mark.parametrize("alg,c,chunks,ring", [("15d_fusion2", 1, "4", "mesh"), ("15d_fusion2", 2, "2", "mesh"), ("15d_fusion2", 1, "1", "relay"),
-                                               ("15d_fusion1", 2, "4", "mesh"), ("15d_sparse", 2, "4", "mesh"),
+                                               ("15d_fusion1", 2, "4", "mesh"), ("15d_fusion1", 1, "3", "mesh"), ("15d_sparse", 2, "4", "mesh"),
                                                ("25d_dense_replicate", 2, "4", "mesh"), ("25d_sparse_replicate", 2, "4", "mesh")])
 def test_config3_full_size_on_eight_logical_ranks(config2, monkeypatch, alg, c, chunks, ring):
     """BASELINE config 3 — the schedule an 8-GPU bench.py run executes (1.5D dense shift, local kernel fusion, the same 1.0e8-nonzero
