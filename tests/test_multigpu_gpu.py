@@ -130,7 +130,8 @@ def test_bench_processes_share_one_gpu(n):
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout[-2000:]
     out = read_line(lines[0])
-    assert out["n_gpus"] == n and out["backend"] == "hip-gfx950" and out["config"]["transport"] == "ipc-pull" and "incomplete" not in out
+    assert "incomplete" not in out, (out["incomplete"], out["config"].get("route_tuning_failures"), res.stderr[-3000:])
+    assert out["n_gpus"] == n and out["backend"] == "hip-gfx950" and out["config"]["transport"] == "ipc-pull"
     assert out["check"]["ok"] and out["check"]["rows_checked"] == 1 << 14 and out["check"]["rel_err"] <= 1e-11
     trials = out["config"]["transport_trials"]
     assert trials["ipc"].startswith("ok") and not trials["rccl"].startswith("ok")
