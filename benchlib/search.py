@@ -60,9 +60,11 @@ def candidates(args, n, tr, fixed_mode, default_q):
             cand.append((tr, c, "none", None))
             continue
         if fixed_mode != "relay":
-            # chunk shapes: the library's default, symmetric Q = 2 / 4 (/ 3 / 8), and for c = 1 a longer falling shape
+            # chunk shapes: the library's default, symmetric Q = 2 / 4 (/ 3), and for c = 1 a longer falling shape.  (Q = 8 was a candidate
+            # until round 6: it never won a measurement — every window re-streams three dense rows per sparse row — and it was the one
+            # candidate in which four processes sharing a GPU hung)
             qs = [str(args.chunks)] if args.chunks else sorted(
-                {default_q, DEFAULT_CHUNKS, "2", "4"} | ({"3", "8", "3,4,4,3,2,1,1"} if c == 1 else set()), key=lambda q: (q != default_q, len(q), q))
+                {default_q, DEFAULT_CHUNKS, "2", "4"} | ({"3", "3,4,4,3,2,1,1"} if c == 1 else set()), key=lambda q: (q != default_q, len(q), q))
             cand += [(tr, c, "mesh", q) for q in qs]
             if c == 1 and not args.chunks and os.environ.get("HNH_WINDOW_MERGE") != "0":
                 # the default shape with one pass per chunk whatever has landed: adaptive windows (the default) against rounds 2-4's behaviour,

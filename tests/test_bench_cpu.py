@@ -55,7 +55,7 @@ def test_bench_contract(nranks, alg, c, ring):
                 want.add("c=%d replication only" % k)
                 continue
             if ring != "relay":
-                want |= {"c=%d mesh/%d chunks" % (k, q) for q in ((2, 3, 4, 8) if k == 1 else (2, 4))}
+                want |= {"c=%d mesh/%d chunks" % (k, q) for q in ((2, 3, 4) if k == 1 else (2, 4))}
                 want |= {"c=%d mesh/heights %s" % (k, h) for h in (("1,2,2,2,1,1", "3,4,4,3,2,1,1") if k == 1 else ("1,2,2,2,1,1",))}
                 if k == 1:  # the default shape with one windowed pass per chunk (HNH_WINDOW_MERGE=0) against the adaptive windows
                     want.add("c=1 mesh/heights 1,2,2,2,1,1/one-pass-per-chunk")
