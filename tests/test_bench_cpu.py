@@ -514,3 +514,44 @@ def test_a_signal_before_the_first_measurement_still_leaves_one_json_line():
     assert p.returncode == 143 and len(lines) == 1, (p.returncode, out)
     rec = json.loads(lines[0])
     assert rec["value"] is None and "before its first complete measurement" in rec["error"] and len(lines[0]) < LINE_LIMIT
+
+
+def test_the_line_stays_bounded_whatever_goes_into_it(tmp_path, monkeypatch):
+    """benchlib/line.py on its own: a record with hundreds of search candidates, a hundred secondary entries, kilobyte strings, NaN and
+    infinity still renders to ONE strict-JSON line of at most 8192 bytes that keeps the contract's keys, `roofline` and `cpu_baseline`;
+    what was left out is named in `shed`, and the record file holds everything.  A line that was rendered before (the launcher forwarding
+    rank 0's) keeps its secondary table and amends the record instead of replacing it."""
+    from benchlib import line as L
+    monkeypatch.setenv("HNH_BENCH_RECORD", str(tmp_path / "rec.json"))
+    long = "x" * 5000
+    rec = {"backend": "hip-gfx950", "metric": "fused SDDMM+SpMM nnz*R/s", "value": 1.0e12, "unit": "nnz*R/s", "n_gpus": 8, "steps": 20, "warmup": 5,
+           "ms_per_step": 2.5, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": long, "nnz": 1, "route_tuning_ms_per_step": {"candidate %d %s" % (k, long[:100]): float(k) for k in range(300)},
+                      "route_tuning_failures": {"c %d" % k: long for k in range(50)}, "transport_trials": {"rccl": long, "ipc": long},
+                      "ranks": [[r, 1000 + r, r, "0000:%02x:00.0" % r, 8, r, r] for r in range(8)], "budget_stops": [long] * 5},
+           "roofline": {"bound": "hbm", "achieved": float("nan"), "peak": 8000.0, "unit": "GB/s", "frac": float("inf"), "traffic": None, "model": long},
+           "cpu_baseline": {"value": 3.6e9, "unit": "nnz*R/s", "cores": 32, "kind": "reference", "sample": long},
+           "check": {"what": long, "ok": True}, "phases_s": {"p%d" % k: 1.0 for k in range(40)}, "preflight": {"primitives_ok": [long] * 9},
+           "secondary": [{"id": "entry_%d" % k, "workload": long, "ms": 1.0 + k, "frac": 0.5, "check": {"ok": k != 3}} for k in range(100)]}
+    data, path = L.render(rec)
+    assert len(data) <= L.LINE_LIMIT and data.endswith(b"\n") and data.count(b"\n") == 1
+    line = read_line(data.decode().strip(), want_record=False)
+    assert line["value"] == 1.0e12 and line["roofline"]["achieved"] is None and line["roofline"]["frac"] is None  # strict JSON: no NaN / Infinity
+    assert line["cpu_baseline"]["value"] == 3.6e9 and len(line["config"]["workload"]) <= 200 and line["shed"], sorted(line)
+    with open(path) as f:
+        full = json.load(f)
+    assert len(full["secondary"]) == 100 and len(full["config"]["route_tuning_ms_per_step"]) == 300 and full["config"]["workload"] == long
+    # a second pass over the printed line (the launcher): nothing is lost from the record, its remark is added
+    again = dict(line, incomplete="run ended by signal 15 sent to the launcher", exit_codes=[0] * 8)
+    data2, _ = L.render(again)
+    assert len(data2) <= L.LINE_LIMIT
+    with open(path) as f:
+        full2 = json.load(f)
+    assert len(full2["secondary"]) == 100 and "signal 15" in full2["incomplete"] and full2["exit_codes"] == [0] * 8
+    # a moderately sized record sheds nothing and keeps its whole secondary table
+    small = dict(rec, config={"workload": "w"}, check={"ok": True}, phases_s={"total": 1.0}, preflight=None,
+                 roofline=dict(rec["roofline"], model="m"), cpu_baseline=dict(rec["cpu_baseline"], sample="s"),
+                 secondary=[{"id": "e%d" % k, "workload": "w", "ms": 1.0, "frac": 0.5} for k in range(19)])
+    small.pop("preflight")
+    d3 = json.loads(L.render(small)[0])
+    assert "shed" not in d3 and len(d3["secondary"]) == 19 and d3["secondary_checks"] == {"entries": 19, "failed": []}
