@@ -299,8 +299,14 @@ def secondary(args, b):
     def time_alone(w, op, call, iters):
         call()
         w.sync()
+        t0 = time.perf_counter()
+        call()
+        w.sync()
+        one = time.perf_counter() - t0
+        if one * iters < 0.02:  # calls of config 1's size (0.2 ms): a batch of five is one scheduler hiccup away from nonsense — 20 ms per batch
+            iters = min(400, int(0.02 / max(one, 1e-6)) + 1)
         wall = None
-        for _ in range(2):  # the better of two batches: one host hiccup (a few ms on some boxes) would otherwise weigh on five calls
+        for _ in range(2 if one * iters >= 0.02 else 3):  # the better of two (three) batches: one host hiccup (a few ms on some boxes) would otherwise weigh on five calls
             t0 = time.perf_counter()
             for _ in range(iters):
                 call()

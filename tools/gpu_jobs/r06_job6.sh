@@ -1,6 +1,6 @@
 # round 6, GPU job 6: the state of the tree as the driver will see it — smoke, all GPU tests, the driver's bench command, kernel trace of it
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r06_job6
+OUT=$R/gpurun_out/${JOBTAG:-r06_job6}
 mkdir -p "$OUT"
 cd "$R"
 python -c "import torch" 2>/dev/null
