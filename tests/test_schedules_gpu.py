@@ -454,3 +454,26 @@ def test_borrowed_value_arrays_hip(monkeypatch, mode, alg, p, c):
         assert stats[0] > 0 and stats[1] == 0
         if alg != "25d_sparse_replicate":
             assert stats[2] > 0 and stats[3] == 0
+
+
+@pytest.mark.parametrize("env", [{}, {"HNH_MESH_TAPER": "1,2,2,2,1,1"}, {"HNH_FUSION1_MESH": "0"}])
+@pytest.mark.parametrize("p,c", [(4, 1), (8, 2), (8, 1)])
+def test_replication_reuse_on_the_mesh_with_hub_rows_hip(monkeypatch, env, p, c):
+    """15d_fusion1's row-merged layout on the HIP kernels with HUB rows and hub columns (a skewed graph): the row-range SDDMM passes and the
+    staging passes of the mesh reduce-scatter run the long-row path (segments + ordered reduction; stored output rows start from zero)
+    inside a row range of the transposed block; checked against the oracle for every operation, and against the ring it replaced."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(17)
+    m, r = 2048, 32
+    lens = rng.integers(0, 24, m)
+    lens[5], lens[1500] = 1900, 1200  # hub rows: every rank's share of them is above the long-row threshold
+    rows = np.repeat(np.arange(m, dtype=np.int64), lens)
+    cols = np.concatenate([np.sort(rng.choice(m, int(k), replace=False)) for k in lens]).astype(np.int64)
+    # ... and the same hubs as COLUMNS (the B-side operations see the transpose)
+    key = np.unique(np.concatenate([rows * m + cols, cols * m + rows]))
+    rows, cols = key // m, key % m
+    case = T.make_case("hubs_r32", m, m, r, rows, cols, seed=21)
+    per_rank = H.run_spmd(p, lambda w: T.run_all_ops(w, "15d_fusion1", c, case))
+    assert per_rank[0]["alg_info"]["backend"] == "hip-gfx950"
+    T.check_against_oracle(T.assemble(per_rank, case), case, "15d_fusion1")
